@@ -1,0 +1,179 @@
+/*
+ * u2tok.h -- C ABI of libu2tok_hip.so, the MI355X (gfx950) implementation of the u2Tokenizer forward path.
+ *
+ * The reference (Siyou-Li/u2Tokenizer) has no FFI / operator registry: its hot path
+ * `u2MetaForCausalLM.prepare_inputs_for_multimodal` (src/model/u2_arch.py:96-117) is a chain of Python
+ * nn.Module calls into stock torch ops.  The seam a maintainer would bind is therefore the three module
+ * forwards + the embedding splice; each entry point below names the reference code it replaces.
+ * The Python host side (u2tokenizer_amd/) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions for EVERY function:
+ *   - all pointers are DEVICE pointers (HBM) unless the name says `host`; tensors are dense row-major;
+ *   - "bf16" = raw bfloat16 bits (uint16_t); parameters are expected in bf16 (model.to(torch.bfloat16));
+ *   - work is enqueued on `stream` (a hipStream_t, e.g. torch.cuda.current_stream().cuda_stream);
+ *     nothing allocates, nothing synchronises, the caller owns every buffer including the workspace;
+ *   - return value: 0 = success, negative = U2TOK_ERR_* (the Python shim raises RuntimeError).
+ */
+#ifndef U2TOK_H_
+#define U2TOK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define U2TOK_OK 0
+#define U2TOK_ERR_ARG (-1)        /* bad dimension / null pointer / unsupported combination */
+#define U2TOK_ERR_LAUNCH (-2)     /* a kernel launch failed */
+#define U2TOK_ERR_WORKSPACE (-3)  /* workspace too small: call the matching *_workspace_bytes */
+#define U2TOK_ERR_DEVICE (-4)     /* current device is not gfx950 */
+
+typedef void* u2tok_stream_t; /* hipStream_t */
+
+/* ---- library identity / gating -------------------------------------------------------------- */
+int u2tok_version(void);               /* MAJOR*10000 + MINOR*100 + PATCH */
+const char* u2tok_arch(void);          /* "gfx950" */
+int u2tok_device_check(void);          /* 0 if the current HIP device is gfx950, else U2TOK_ERR_DEVICE */
+int u2tok_set_option(const char* name, int value); /* "gemm_glds" {0,1}, "gemm_tile" {0,64,128},
+                                                      "vit_flash" {0,1}; returns U2TOK_ERR_ARG if unknown */
+
+/* ---- configuration records -------------------------------------------------------------------- */
+
+/* ViT3DTower (src/model/multimodal_encoder/vit.py:132-164) built on MONAI 1.3.0 PatchEmbeddingBlock
+ * (perceptron) + TransformerBlock x depth; hyper-parameters hard-coded at vit.py:33-38,139-146. */
+typedef struct {
+  int32_t nchunk;          /* B*C: 32-slice chunks in this call (u2_arch.py:105-106) */
+  int32_t img[3];          /* config.image_size, e.g. {32,256,256} */
+  int32_t patch[3];        /* config.patch_size, e.g. {4,16,16} */
+  int32_t hidden;          /* 768 */
+  int32_t mlp_dim;         /* 3072 */
+  int32_t depth;           /* 12 */
+  int32_t heads;           /* 12 (head dim must be 64) */
+  int32_t vol_dtype;       /* 0 = fp16, 1 = bf16, 2 = fp32 voxels */
+  int32_t keep_cls;        /* 0: select_feature == "patch" (drop cls, vit.py:157-158); 1: "cls_patch" */
+  float ln_eps;            /* 1e-5 */
+} u2tok_vit_config;
+
+/* ViT weight table: array of (4 + 11*depth + 2) device pointers, all bf16, MONAI state-dict names:
+ *   [0] patch_embedding.position_embeddings (1,ntok,hidden)   [1] patch_embedding.patch_embeddings.1.weight
+ *   [2] patch_embedding.patch_embeddings.1.bias               [3] cls_token
+ *   per block i (base 4 + 11*i): norm1.weight, norm1.bias, attn.qkv.weight, attn.out_proj.weight,
+ *       attn.out_proj.bias, norm2.weight, norm2.bias, mlp.linear1.weight, mlp.linear1.bias,
+ *       mlp.linear2.weight, mlp.linear2.bias
+ *   [4+11*depth] norm.weight   [5+11*depth] norm.bias */
+#define U2TOK_VIT_NW(depth) (4 + 11 * (depth) + 2)
+
+/* SpatialPoolingProjector (src/model/multimodal_projector/spatial_pooling_projector.py:7-59). */
+typedef struct {
+  int32_t nchunk;
+  int32_t grid[3];         /* num_patches_pre = image_size / patch_size */
+  int32_t pooling_size;    /* 2 */
+  int32_t pooling_type;    /* 0 = "spatial" (avg_pool3d), 1 = "sequence" (avg_pool1d over pooling_size^3) */
+  int32_t in_dim;          /* 768 */
+  int32_t out_dim;         /* E = LLM hidden size */
+  int32_t layer_type;      /* 0 = "mlp" (GELU between), 1 = "linear" */
+  int32_t layer_num;       /* 2 */
+} u2tok_spp_config;
+/* SPP weight table: 2*layer_num pointers: projector.{0,2,..}.weight, .bias in order. */
+
+/* u2Tokenizer (src/model/u2tokenizer/u2Tokenizer.py:6-47; builder.py:3-14). */
+typedef struct {
+  int32_t B;               /* volumes */
+  int32_t T;               /* chunks per volume ("frames") */
+  int32_t N;               /* projector tokens per chunk */
+  int32_t E;               /* embed_size == hidden_size */
+  int32_t Lt;              /* text tokens (padded question length) */
+  int32_t num_heads;       /* u2t_num_heads */
+  int32_t num_layers;      /* u2t_num_layers */
+  int32_t top_k;           /* u2t_top_k */
+  int32_t num_query;       /* num_3d_query_token */
+  int32_t use_multi_scale; /* bool */
+  int32_t attn_type;       /* 0 = "rma" (RelativeMultiheadAttention), 1 = "rope" */
+  int32_t enable_diffts;   /* bool: DifferentiableTokenSelection vs TokenSelection */
+  int32_t enable_dmtp;     /* bool: DynamicMultiScalePooling */
+  int32_t max_seq_len;     /* 512: rma.py:6 / rope.py:19 */
+  float diffts_tau;        /* 1.0 (svr.py:94) */
+  float ln_eps;            /* 1e-5 */
+} u2tok_tokenizer_config;
+
+/* Tokenizer weight table (all bf16), in this order; an attention record "ATT" is
+ *   wq.weight, wq.bias, wk.weight, wk.bias, wv.weight, wv.bias, dense.weight, dense.bias, relative_bias
+ * (relative_bias = null for MultiHeadCrossAttention and for attn_type rope):
+ *   [0] query_tokens
+ *   per SVR layer l (base 1 + 18*l):  ATT spatial_attention, ATT temporal_attention
+ *   then token_selection.score_net.weight, .bias
+ *   then dynamic_pool.gate_fc.weight, .bias   (null when !enable_dmtp)
+ *   per TTA layer l (33 pointers): ATT self_attention, ATT visual_cross_attention, ATT text_cross_attention,
+ *       norm_self.weight, .bias, norm_cross_v.weight, .bias, norm_cross_t.weight, .bias
+ *   then ATT layer_linagg.linear_aggregator (wv/dense present in the state dict but never read: tta.py:47-48,62-65) */
+#define U2TOK_TOK_NW(layers) (1 + 18 * (layers) + 4 + 33 * (layers) + 9)
+
+/* ---- the hot path ------------------------------------------------------------------------------ */
+
+/* Replaces ViT3DTower.forward (vit.py:148-164): volume (nchunk,1,D,H,W) -> features
+ * (nchunk, ntok[+1], hidden) bf16. */
+size_t u2tok_vit_workspace_bytes(const u2tok_vit_config* cfg);
+int u2tok_vit_forward(const u2tok_vit_config* cfg, const void* const* weights, const void* volume, void* out,
+                      void* workspace, size_t workspace_bytes, u2tok_stream_t stream);
+
+/* Replaces SpatialPoolingProjector.forward (spatial_pooling_projector.py:34-52):
+ * (nchunk, g1*g2*g3, in_dim) bf16 -> (nchunk, proj_out_num, out_dim) bf16. */
+size_t u2tok_spp_workspace_bytes(const u2tok_spp_config* cfg);
+int u2tok_spp_forward(const u2tok_spp_config* cfg, const void* const* weights, const void* x, void* out,
+                      void* workspace, size_t workspace_bytes, u2tok_stream_t stream);
+
+/* Replaces u2Tokenizer.forward (u2Tokenizer.py:40-47): v_token (B,T,N,E), t_token (B,Lt,E) bf16 ->
+ * aligned tokens (B,num_query,E) bf16.  topk_idx_out (optional, may be null): (B,top_k) int64 indices chosen by
+ * TokenSelection (only written when !enable_diffts) -- the path's integer output. */
+size_t u2tok_tokenizer_workspace_bytes(const u2tok_tokenizer_config* cfg);
+int u2tok_tokenizer_forward(const u2tok_tokenizer_config* cfg, const void* const* weights, const void* v_token,
+                            const void* t_token, void* out, int64_t* topk_idx_out, void* workspace,
+                            size_t workspace_bytes, u2tok_stream_t stream);
+
+/* Replaces embed_tokens(ids) + the splice of u2_arch.py:109,113-116:
+ * out[b][s] = (1 <= s <= nfeat) ? feats[b][s-1] : table[ids[b][s]].  nfeat = 0 / feats = null: plain lookup. */
+int u2tok_embed_splice(const void* table, const int64_t* ids, const void* feats, void* out, int32_t B, int32_t S,
+                       int32_t E, int32_t nfeat, int64_t vocab, u2tok_stream_t stream);
+
+/* ---- building blocks (exported for the parity tests; same kernels the pipelines launch) -------- */
+
+/* C[z] = epi(alpha * A[z] B[z]^T): A (M,K) lda, B (N,K) ldb, C (M,N) ldc; z = zb*nbh + zh with element strides.
+ * flags: 1 bias[n], 2 bias[m], 4 GELU(erf), 8 + R[m][n], 16 C is fp32 (else bf16). */
+int u2tok_gemm_bf16(const void* A, const void* B, void* C, const void* bias, const void* R, int32_t M, int32_t N,
+                    int32_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int32_t nz, int32_t nbh,
+                    int64_t sAb, int64_t sAh, int64_t sBb, int64_t sBh, int64_t sCb, int64_t sCh, int64_t sRb,
+                    int64_t sRh, float alpha, int32_t flags, u2tok_stream_t stream);
+int u2tok_layernorm_bf16(const void* x, const void* res, const void* w, const void* b, void* y, int32_t rows,
+                         int32_t C, float eps, u2tok_stream_t stream);
+int u2tok_softmax_rows(const float* S, void* P, int32_t nz, int32_t rows, int32_t n, int64_t lds, int64_t ldp,
+                       float scale, const void* rel_bias, int32_t H, int32_t max_len, u2tok_stream_t stream);
+int u2tok_transpose_bf16(const void* in, void* out, int32_t nz, int32_t R, int32_t C, int64_t ld_in, int64_t ld_out,
+                         int64_t in_zs, int64_t out_zs, u2tok_stream_t stream);
+int u2tok_im2col_patches(const void* vol, int32_t vol_dtype, void* out, int32_t nchunk, int32_t D, int32_t H,
+                         int32_t W, int32_t p1, int32_t p2, int32_t p3, u2tok_stream_t stream);
+int u2tok_avgpool3d_tokens(const void* x, void* y, int32_t nb, int32_t g1, int32_t g2, int32_t g3, int32_t w1,
+                           int32_t w2, int32_t w3, int32_t C, u2tok_stream_t stream);
+int u2tok_score_gemv(const void* x, const void* w, const void* bias, float* scores, int32_t rows, int32_t E,
+                     u2tok_stream_t stream);
+int u2tok_topk_sorted(const float* scores, int64_t* idx, int32_t B, int32_t n, int32_t k, u2tok_stream_t stream);
+int u2tok_gather_rows(const void* x, const int64_t* idx, void* out, int32_t B, int32_t n, int32_t k, int32_t E,
+                      u2tok_stream_t stream);
+/* ws: B*3*ceil(E/256) floats (only read/written when gate_w != null) */
+int u2tok_multiscale_pool(const void* x, void* out, int32_t B, int32_t k, int32_t E, const void* gate_w,
+                          const void* gate_b, float* ws, u2tok_stream_t stream);
+int u2tok_temporal_attention(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t T,
+                             int32_t N, int32_t H, int32_t d, int64_t ld_qkv, int64_t ld_out, float scale,
+                             const void* rel_bias, int32_t max_len, u2tok_stream_t stream);
+int u2tok_flash_attention_d64(const void* q, const void* k, const void* vt, void* out, int32_t nb, int32_t S,
+                              int32_t H, int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs, int32_t S_pad,
+                              float scale, u2tok_stream_t stream);
+/* in-place rotate-half RoPE (rope.py:6-13,77-80): rows indexed (outer, s, inner), position = s */
+int u2tok_rope_apply(void* x, int64_t n_outer, int32_t S, int32_t n_inner, int32_t H, int32_t d, int64_t ld,
+                     int32_t max_len, u2tok_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* U2TOK_H_ */

@@ -1,0 +1,322 @@
+// Attention cores that do not go through the batched-GEMM path:
+//   * temporal_attention : the across-chunk half of SpatioTemporalAttentionLayer (svr.py:31-36), sequence
+//     length T = number of chunks (<= 16), head dim d = E/8 (256/512).  Reads q/k/v in the (b t n) row
+//     order the projections produced them in, so neither of the reference's two permute().contiguous()
+//     round trips (svr.py:32,36) touches HBM.
+//   * flash_attention_d64: MONAI SABlock attention of the ViT blocks (vit.py:100-105): S = 2049 tokens,
+//     12 heads x 64.  Online-softmax, never materialises the (S x S) probabilities the reference writes
+//     (1.6 GB fp32 per layer per volume).
+#include "kernels.h"
+
+namespace u2 {
+
+// ================================================================= temporal attention
+// One wave64 per (b, n, head).  QK^T on the matrix core straight from HBM fragments (K as the MFMA A
+// operand, Q as B: lane holds S[t1 = lane & 15][t2 = 4*(lane >> 4) + r]); softmax across the 4 lane
+// groups with two xor-shuffles; P through a 1 KB LDS patch; PV on the VALU with each lane owning a
+// contiguous d/64 slice of the head (coalesced 16-byte row reads of V, lane-local accumulation).
+template <int VPL>  // bf16 elements of the head owned per lane: d = 64 * VPL
+__global__ __launch_bounds__(256) void temporal_attention_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                                 const bf16_t* __restrict__ v, bf16_t* __restrict__ out, int B,
+                                                                 int T, int N, int H, int64_t ld_qkv, int64_t ld_out,
+                                                                 float scale, const bf16_t* __restrict__ rel_bias, int max_len) {
+  constexpr int d = 64 * VPL;
+  __shared__ float pl[4][16][17];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t inst = (int64_t)blockIdx.x * 4 + wv;  // (b, n, h)
+  const bool active = inst < (int64_t)B * N * H;
+  const int h = active ? (int)(inst % H) : 0;
+  const int64_t bn = active ? inst / H : 0;
+  const int n = (int)(bn % N);
+  const int b = (int)(bn / N);
+  // row (b, t, n) -> ((b*T + t)*N + n)
+  const int64_t row0 = (int64_t)b * T * N + n;
+  const int64_t rstep = N;
+
+  // ---- S^T tile = K Q^T (16x16, rows >= T are zero fragments)
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  {
+    const int t = lane & 15, g = lane >> 4;
+    const bool valid = active && t < T;
+    const bf16_t* qp = q + (row0 + (int64_t)t * rstep) * ld_qkv + h * d + g * 8;
+    const bf16_t* kp = k + (row0 + (int64_t)t * rstep) * ld_qkv + h * d + g * 8;
+#pragma unroll 4
+    for (int ks = 0; ks < d / 32; ++ks) {
+      bf16x8 qa = {0, 0, 0, 0, 0, 0, 0, 0}, ka = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (valid) {
+        qa = *reinterpret_cast<const bf16x8*>(qp + ks * 32);
+        ka = *reinterpret_cast<const bf16x8*>(kp + ks * 32);
+      }
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qa, acc, 0, 0, 0);
+    }
+  }
+  // lane: t1 = lane & 15 (query), t2 = 4*(lane>>4) + r (key)
+  {
+    const int t1 = lane & 15, t2b = (lane >> 4) * 4;
+    float s[4];
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t2 = t2b + r;
+      float x = acc[r] * scale;
+      if (rel_bias && t1 < T && t2 < T) x += bf16_to_f32(rel_bias[(int64_t)(t2 - t1 + max_len - 1) * H + h]);
+      s[r] = (t2 < T) ? x : -INFINITY;
+      m = fmaxf(m, s[r]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s[r] = __expf(s[r] - m); sum += s[r]; }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pl[wv][t1][t2b + r] = s[r] * inv;
+  }
+  __syncthreads();
+  if (!active) return;
+  // ---- O = P V on the VALU; lane owns columns [lane*VPL, lane*VPL + VPL) of the head
+  float o[16][VPL];
+#pragma unroll
+  for (int t1 = 0; t1 < 16; ++t1)
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) o[t1][j] = 0.f;
+  const bf16_t* vp = v + row0 * ld_qkv + h * d + lane * VPL;
+  for (int t2 = 0; t2 < T; ++t2) {
+    float vv[VPL];
+    const bf16_t* p = vp + (int64_t)t2 * rstep * ld_qkv;
+    if constexpr (VPL == 8) {
+      const uint4 u = *reinterpret_cast<const uint4*>(p);
+      vv[0] = bf16lo(u.x); vv[1] = bf16hi(u.x); vv[2] = bf16lo(u.y); vv[3] = bf16hi(u.y);
+      vv[4] = bf16lo(u.z); vv[5] = bf16hi(u.z); vv[6] = bf16lo(u.w); vv[7] = bf16hi(u.w);
+    } else if constexpr (VPL == 4) {
+      const uint2 u = *reinterpret_cast<const uint2*>(p);
+      vv[0] = bf16lo(u.x); vv[1] = bf16hi(u.x); vv[2] = bf16lo(u.y); vv[3] = bf16hi(u.y);
+    } else if constexpr (VPL == 2) {
+      const uint32_t u = *reinterpret_cast<const uint32_t*>(p);
+      vv[0] = bf16lo(u); vv[1] = bf16hi(u);
+    } else {
+      vv[0] = bf16_to_f32(p[0]);
+    }
+#pragma unroll
+    for (int t1 = 0; t1 < 16; ++t1) {
+      const float pw = pl[wv][t1][t2];  // broadcast read
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) o[t1][j] += pw * vv[j];
+    }
+  }
+  bf16_t* op = out + row0 * ld_out + h * d + lane * VPL;
+#pragma unroll
+  for (int t1 = 0; t1 < 16; ++t1) {
+    if (t1 < T) {
+      bf16_t* p = op + (int64_t)t1 * rstep * ld_out;
+      if constexpr (VPL == 8) {
+        *reinterpret_cast<uint4*>(p) = uint4{pack2_bf16(o[t1][0], o[t1][1]), pack2_bf16(o[t1][2], o[t1][3]),
+                                             pack2_bf16(o[t1][4], o[t1][5]), pack2_bf16(o[t1][6], o[t1][7])};
+      } else if constexpr (VPL == 4) {
+        *reinterpret_cast<uint2*>(p) = uint2{pack2_bf16(o[t1][0], o[t1][1]), pack2_bf16(o[t1][2], o[t1][3])};
+      } else if constexpr (VPL == 2) {
+        *reinterpret_cast<uint32_t*>(p) = pack2_bf16(o[t1][0], o[t1][1]);
+      } else {
+        p[0] = f32_to_bf16(o[t1][0]);
+      }
+    }
+  }
+}
+
+int temporal_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int B, int T, int N, int H,
+                       int d, int64_t ld_qkv, int64_t ld_out, float scale, const bf16_t* rel_bias, int max_len,
+                       hipStream_t stream) {
+  if (!q || !k || !v || !out || B <= 0 || T <= 0 || T > 16 || N <= 0 || H <= 0) return U2_ERR_ARG;
+  if (d != 64 && d != 128 && d != 256 && d != 512) return U2_ERR_ARG;
+  if ((ld_qkv & 7) || (ld_out & 7) || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15)) return U2_ERR_ARG;
+  if (rel_bias && T > max_len) return U2_ERR_ARG;
+  const int64_t ninst = (int64_t)B * N * H;
+  dim3 grid((unsigned)cdiv(ninst, 4));
+#define U2_TA(VPL)                                                                                                   \
+  hipLaunchKernelGGL((temporal_attention_kernel<VPL>), grid, dim3(256), 0, stream, q, k, v, out, B, T, N, H, ld_qkv, \
+                     ld_out, scale, rel_bias, max_len)
+  if (d == 512) U2_TA(8);
+  else if (d == 256) U2_TA(4);
+  else if (d == 128) U2_TA(2);
+  else U2_TA(1);
+#undef U2_TA
+  return launch_status();
+}
+
+// ================================================================= flash attention, head dim 64
+// Block = 4 waves, 128 query rows (32 per wave), KV tiles of 64 keys, v_mfma_f32_32x32x16_bf16.
+//   S^T = K Q^T : A = K fragment (LDS), B = Q fragment (registers, loaded once).  Lane (q = lane&31, hi)
+//                 then owns 16 keys of each 32-key block -> row max/sum are lane-local + one xor-32.
+//   O^T = V^T P^T: A = V^T fragment (LDS, V pre-transposed in HBM), B = P^T = the lane's own exp'd
+//                 scores packed to bf16 -- NO cross-lane movement: the k-slot -> key mapping of the MFMA
+//                 is a free permutation as long as A and B agree, so V^T is read in P's native order.
+//   O^T accumulators keep q = lane&31 per lane, so the online-softmax rescale is lane-local too.
+// LDS tiles ([64][64] bf16, 128 B rows) are XOR-swizzled: K at 16-B granularity with (row>>1)&7, V^T at
+// 8-B granularity with ((row>>1)&7)<<1 | (row>>4)&1 -> conflict-free ds_read_b128 / ds_read_b64.
+__device__ __forceinline__ uint32_t kt_off(int row, int chunk) {  // K tile: 16-B chunk index 0..7
+  return (uint32_t)(row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+}
+__device__ __forceinline__ uint32_t vt_off(int row, int unit) {  // V^T tile: 8-B unit index 0..15
+  return (uint32_t)(row * 128 + ((unit ^ ((((row >> 1) & 7) << 1) | ((row >> 4) & 1))) << 3));
+}
+
+__global__ __launch_bounds__(256, 2) void flash_d64_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                           const bf16_t* __restrict__ vt, bf16_t* __restrict__ out, int S, int H,
+                                                           int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs,
+                                                           int S_pad, float scale_log2e, int nqt) {
+  __shared__ __attribute__((aligned(16))) char lds[2][16384];  // [stage][K tile 8 KB | V^T tile 8 KB]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  int bid = blockIdx.x;
+  const int qt = bid % nqt; bid /= nqt;
+  const int h = bid % H;
+  const int b = bid / H;
+  const bf16_t* qb = q + (int64_t)b * q_bs + h * 64;
+  const bf16_t* kb = k + (int64_t)b * q_bs + h * 64;
+  const bf16_t* vb = vt + ((int64_t)b * H + h) * 64 * S_pad;
+
+  // Q fragments (B operand): Q[q][d = ks*16 + hi*8 .. +7]
+  const int qrow = qt * 128 + wv * 32 + l31;
+  bf16x8 qf[4];
+  {
+    const bf16_t* qp = qb + (int64_t)min(qrow, S - 1) * ld_qk + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+  }
+
+  // staging: K tile = 64 rows x 8 chunks, V^T tile = 64 rows x 8 chunks; 2 chunks of each per thread
+  uint4 rk[2], rv[2];
+  auto gload = [&](int t) {
+    const int kv0 = t * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = i * 256 + tid, row = c >> 3, ch = c & 7;
+      rk[i] = *reinterpret_cast<const uint4*>(kb + (int64_t)min(kv0 + row, S - 1) * ld_qk + ch * 8);
+      rv[i] = *reinterpret_cast<const uint4*>(vb + (int64_t)row * S_pad + kv0 + ch * 8);
+    }
+  };
+  auto lstore = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = i * 256 + tid, row = c >> 3, ch = c & 7;
+      *reinterpret_cast<uint4*>(&lds[st][kt_off(row, ch)]) = rk[i];
+      // 8-B swizzle: chunk moves with (row>>1)&7, halves swap when (row>>4)&1
+      uint4 x = rv[i];
+      if ((row >> 4) & 1) x = uint4{x.z, x.w, x.x, x.y};
+      *reinterpret_cast<uint4*>(&lds[st][8192 + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)]) = x;
+    }
+  };
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[nb][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntile = (S + 63) >> 6;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int t = 0; t < ntile; ++t) {
+    const int st = t & 1;
+    if (t + 1 < ntile) gload(t + 1);
+    const char* sK = lds[st];
+    const char* sV = lds[st] + 8192;
+    // ---- S^T = K Q^T for the two 32-key blocks
+    f32x16 sc[2];
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[kbk][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + kt_off(kbk * 32 + l31, ks * 2 + hi));
+        sc[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[kbk], 0, 0, 0);
+      }
+    }
+    // lane owns keys kv = t*64 + kbk*32 + (r&3) + 8*(r>>2) + 4*hi
+    float mt = -INFINITY;
+    const int kvb = t * 64 + 4 * hi;
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kv = kvb + kbk * 32 + (r & 3) + 8 * (r >> 2);
+        const float x = (kv < S) ? sc[kbk][r] * scale_log2e : -INFINITY;
+        sc[kbk][r] = x;
+        mt = fmaxf(mt, x);
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float ps = 0.f;
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(sc[kbk][r] - m_new);
+        sc[kbk][r] = p;
+        ps += p;
+      }
+    l_run = l_run * alpha + ps;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[nb][r] *= alpha;
+    // ---- O^T += V^T P^T ; k-slots jj of step (kbk, ks2) carry keys kbk*32 + 16*ks2 + 8*(jj>>2) + 4*hi + (jj&3)
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ++ks2) {
+        union { bf16x8 v; uint32_t u[4]; } pf;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pf.u[j] = pack2_bf16(sc[kbk][ks2 * 8 + 2 * j], sc[kbk][ks2 * 8 + 2 * j + 1]);
+        const int unit0 = (kbk * 32 + ks2 * 16 + 4 * hi) >> 2;  // 8-B unit holding keys [.., +4)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const int drow = nb * 32 + l31;
+          union { bf16x8 v; uint2 h[2]; } vf;
+          vf.h[0] = *reinterpret_cast<const uint2*>(sV + vt_off(drow, unit0));
+          vf.h[1] = *reinterpret_cast<const uint2*>(sV + vt_off(drow, unit0 + 2));
+          oacc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, oacc[nb], 0, 0, 0);
+        }
+      }
+    if (t + 1 < ntile) lstore((t + 1) & 1);
+    __syncthreads();
+  }
+  // ---- epilogue: O^T[d][q] / l ; lane: q = lane&31, d = nb*32 + (r&3) + 8*(r>>2) + 4*hi
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.f / l_tot;
+  if (qrow < S) {
+    bf16_t* op = out + (int64_t)b * out_bs + (int64_t)qrow * ld_out + h * 64;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = nb * 32 + 8 * g + 4 * hi;
+        *reinterpret_cast<uint2*>(op + d0) = uint2{pack2_bf16(oacc[nb][4 * g] * inv, oacc[nb][4 * g + 1] * inv),
+                                                   pack2_bf16(oacc[nb][4 * g + 2] * inv, oacc[nb][4 * g + 3] * inv)};
+      }
+  }
+}
+
+int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int nb, int S, int H,
+                        int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs, int S_pad, float scale,
+                        hipStream_t stream) {
+  if (!q || !k || !vt || !out || nb <= 0 || S <= 0 || H <= 0) return U2_ERR_ARG;
+  if ((S_pad & 63) || S_pad < ((S + 63) & ~63)) return U2_ERR_ARG;
+  if ((ld_qk & 7) || (q_bs & 7) || (ld_out & 3) || (out_bs & 3)) return U2_ERR_ARG;
+  if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15) || ((uintptr_t)out & 7)) return U2_ERR_ARG;
+  const int nqt = (S + 127) / 128;
+  const int64_t blocks = (int64_t)nb * H * nqt;
+  if (blocks > 0x7fffffff) return U2_ERR_ARG;
+  hipLaunchKernelGGL(flash_d64_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, q, k, vt, out, S, H, ld_qk, q_bs,
+                     ld_out, out_bs, S_pad, scale * 1.44269504088896340736f, nqt);
+  return launch_status();
+}
+
+}  // namespace u2

@@ -1,0 +1,162 @@
+// extern "C" surface of libu2tok_hip.so (declared in include/u2tok.h).  Thin: argument marshalling only.
+#include <string.h>
+#include "pipeline.h"
+
+using namespace u2;
+
+static_assert(U2TOK_OK == U2_OK && U2TOK_ERR_ARG == U2_ERR_ARG && U2TOK_ERR_LAUNCH == U2_ERR_LAUNCH &&
+                  U2TOK_ERR_WORKSPACE == U2_ERR_WORKSPACE && U2TOK_ERR_DEVICE == U2_ERR_DEVICE,
+              "public and internal status codes must agree");
+
+#define BF(p) reinterpret_cast<const bf16_t*>(p)
+#define BFW(p) reinterpret_cast<bf16_t*>(p)
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" {
+
+int u2tok_version(void) { return 100; /* 0.1.0 */ }
+const char* u2tok_arch(void) { return "gfx950"; }
+
+int u2tok_device_check(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return U2_ERR_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return U2_ERR_DEVICE;
+  return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? U2_OK : U2_ERR_DEVICE;
+}
+
+int u2tok_set_option(const char* name, int value) {
+  if (!name) return U2_ERR_ARG;
+  if (!strcmp(name, "gemm_glds")) { gemm_set_options(value ? 1 : 0, -1); return U2_OK; }
+  if (!strcmp(name, "gemm_tile")) {
+    if (value != 0 && value != 64 && value != 128) return U2_ERR_ARG;
+    gemm_set_options(-1, value);
+    return U2_OK;
+  }
+  if (!strcmp(name, "vit_flash")) { pipeline_set_vit_flash(value); return U2_OK; }
+  return U2_ERR_ARG;
+}
+
+size_t u2tok_vit_workspace_bytes(const u2tok_vit_config* cfg) {
+  if (!cfg) return 0;
+  size_t peak = 0;
+  if (vit_forward(*cfg, nullptr, nullptr, nullptr, nullptr, 0, true, &peak, nullptr) != U2_OK) return 0;
+  return peak + 256;
+}
+int u2tok_vit_forward(const u2tok_vit_config* cfg, const void* const* weights, const void* volume, void* out,
+                      void* workspace, size_t workspace_bytes, u2tok_stream_t stream) {
+  if (!cfg || !workspace || ((uintptr_t)workspace & 255)) return U2_ERR_ARG;
+  return vit_forward(*cfg, weights, volume, BFW(out), workspace, workspace_bytes, false, nullptr, ST(stream));
+}
+
+size_t u2tok_spp_workspace_bytes(const u2tok_spp_config* cfg) {
+  if (!cfg) return 0;
+  size_t peak = 0;
+  if (spp_forward(*cfg, nullptr, nullptr, nullptr, nullptr, 0, true, &peak, nullptr) != U2_OK) return 0;
+  return peak + 256;
+}
+int u2tok_spp_forward(const u2tok_spp_config* cfg, const void* const* weights, const void* x, void* out,
+                      void* workspace, size_t workspace_bytes, u2tok_stream_t stream) {
+  if (!cfg || !workspace || ((uintptr_t)workspace & 255)) return U2_ERR_ARG;
+  return spp_forward(*cfg, weights, BF(x), BFW(out), workspace, workspace_bytes, false, nullptr, ST(stream));
+}
+
+size_t u2tok_tokenizer_workspace_bytes(const u2tok_tokenizer_config* cfg) {
+  if (!cfg) return 0;
+  size_t peak = 0;
+  if (tokenizer_forward(*cfg, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, true, &peak, nullptr) != U2_OK)
+    return 0;
+  return peak + 256;
+}
+int u2tok_tokenizer_forward(const u2tok_tokenizer_config* cfg, const void* const* weights, const void* v_token,
+                            const void* t_token, void* out, int64_t* topk_idx_out, void* workspace,
+                            size_t workspace_bytes, u2tok_stream_t stream) {
+  if (!cfg || !workspace || ((uintptr_t)workspace & 255)) return U2_ERR_ARG;
+  return tokenizer_forward(*cfg, weights, BF(v_token), BF(t_token), BFW(out), topk_idx_out, workspace, workspace_bytes,
+                           false, nullptr, ST(stream));
+}
+
+int u2tok_embed_splice(const void* table, const int64_t* ids, const void* feats, void* out, int32_t B, int32_t S,
+                       int32_t E, int32_t nfeat, int64_t vocab, u2tok_stream_t stream) {
+  return embed_splice(BF(table), ids, BF(feats), BFW(out), B, S, E, nfeat, vocab, ST(stream));
+}
+
+int u2tok_gemm_bf16(const void* A, const void* B, void* C, const void* bias, const void* R, int32_t M, int32_t N,
+                    int32_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int32_t nz, int32_t nbh,
+                    int64_t sAb, int64_t sAh, int64_t sBb, int64_t sBh, int64_t sCb, int64_t sCh, int64_t sRb,
+                    int64_t sRh, float alpha, int32_t flags, u2tok_stream_t stream) {
+  GemmDesc g;
+  g.A = BF(A); g.B = BF(B); g.C = C; g.bias = BF(bias); g.R = BF(R);
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
+  g.nz = nz; g.nbh = nbh;
+  g.sAb = sAb; g.sAh = sAh; g.sBb = sBb; g.sBh = sBh; g.sCb = sCb; g.sCh = sCh; g.sRb = sRb; g.sRh = sRh;
+  g.alpha = alpha;
+  g.flags = flags & (GEMM_BIAS_N | GEMM_BIAS_M | GEMM_GELU | GEMM_RESIDUAL | GEMM_OUT_F32);
+  return gemm_bf16(g, ST(stream));
+}
+
+int u2tok_layernorm_bf16(const void* x, const void* res, const void* w, const void* b, void* y, int32_t rows,
+                         int32_t C, float eps, u2tok_stream_t stream) {
+  return layernorm_bf16(BF(x), BF(res), BF(w), BF(b), BFW(y), 1, rows, C, 0, C, 0, C, 0, C, eps, ST(stream));
+}
+
+int u2tok_softmax_rows(const float* S, void* P, int32_t nz, int32_t rows, int32_t n, int64_t lds, int64_t ldp,
+                       float scale, const void* rel_bias, int32_t H, int32_t max_len, u2tok_stream_t stream) {
+  return softmax_rows(S, BFW(P), nz, rows, n, lds, ldp, (int64_t)rows * lds, (int64_t)rows * ldp, scale, BF(rel_bias), H,
+                      max_len, ST(stream));
+}
+
+int u2tok_transpose_bf16(const void* in, void* out, int32_t nz, int32_t R, int32_t C, int64_t ld_in, int64_t ld_out,
+                         int64_t in_zs, int64_t out_zs, u2tok_stream_t stream) {
+  return transpose_bf16(BF(in), BFW(out), nz, R, C, ld_in, ld_out, in_zs, out_zs, ST(stream));
+}
+
+int u2tok_im2col_patches(const void* vol, int32_t vol_dtype, void* out, int32_t nchunk, int32_t D, int32_t H,
+                         int32_t W, int32_t p1, int32_t p2, int32_t p3, u2tok_stream_t stream) {
+  return im2col_patches(vol, vol_dtype, BFW(out), nchunk, D, H, W, p1, p2, p3, ST(stream));
+}
+
+int u2tok_avgpool3d_tokens(const void* x, void* y, int32_t nb, int32_t g1, int32_t g2, int32_t g3, int32_t w1,
+                           int32_t w2, int32_t w3, int32_t C, u2tok_stream_t stream) {
+  return avgpool3d_tokens(BF(x), BFW(y), nb, g1, g2, g3, w1, w2, w3, C, ST(stream));
+}
+
+int u2tok_score_gemv(const void* x, const void* w, const void* bias, float* scores, int32_t rows, int32_t E,
+                     u2tok_stream_t stream) {
+  return score_gemv(BF(x), BF(w), BF(bias), scores, rows, E, ST(stream));
+}
+
+int u2tok_topk_sorted(const float* scores, int64_t* idx, int32_t B, int32_t n, int32_t k, u2tok_stream_t stream) {
+  return topk_sorted(scores, idx, B, n, k, ST(stream));
+}
+
+int u2tok_gather_rows(const void* x, const int64_t* idx, void* out, int32_t B, int32_t n, int32_t k, int32_t E,
+                      u2tok_stream_t stream) {
+  return gather_rows(BF(x), idx, BFW(out), B, n, k, E, ST(stream));
+}
+
+int u2tok_multiscale_pool(const void* x, void* out, int32_t B, int32_t k, int32_t E, const void* gate_w,
+                          const void* gate_b, float* ws, u2tok_stream_t stream) {
+  return multiscale_pool(BF(x), BFW(out), B, k, E, BF(gate_w), BF(gate_b), ws, ST(stream));
+}
+
+int u2tok_temporal_attention(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t T,
+                             int32_t N, int32_t H, int32_t d, int64_t ld_qkv, int64_t ld_out, float scale,
+                             const void* rel_bias, int32_t max_len, u2tok_stream_t stream) {
+  return temporal_attention(BF(q), BF(k), BF(v), BFW(out), B, T, N, H, d, ld_qkv, ld_out, scale, BF(rel_bias), max_len,
+                            ST(stream));
+}
+
+int u2tok_flash_attention_d64(const void* q, const void* k, const void* vt, void* out, int32_t nb, int32_t S,
+                              int32_t H, int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs, int32_t S_pad,
+                              float scale, u2tok_stream_t stream) {
+  return flash_attention_d64(BF(q), BF(k), BF(vt), BFW(out), nb, S, H, ld_qk, q_bs, ld_out, out_bs, S_pad, scale,
+                             ST(stream));
+}
+
+int u2tok_rope_apply(void* x, int64_t n_outer, int32_t S, int32_t n_inner, int32_t H, int32_t d, int64_t ld,
+                     int32_t max_len, u2tok_stream_t stream) {
+  return rope_apply(BFW(x), n_outer, S, n_inner, H, d, ld, max_len, ST(stream));
+}
+
+}  // extern "C"

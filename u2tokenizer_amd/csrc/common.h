@@ -1,0 +1,68 @@
+// Shared device/host helpers for the u2tok HIP library (gfx950 / CDNA4 only).
+// Everything here is internal; the public surface is include/u2tok.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace u2 {
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits in HBM
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4;    // 16x16 MFMA accumulator fragment
+typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumulator fragment
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw;
+
+// Status codes returned through the C-ABI (0 = ok, negative = error).
+enum : int {
+  U2_OK = 0,
+  U2_ERR_ARG = -1,       // bad dimension / null pointer / unsupported combination
+  U2_ERR_LAUNCH = -2,    // hipGetLastError() after a launch was not hipSuccess
+  U2_ERR_WORKSPACE = -3, // caller-provided workspace too small
+  U2_ERR_DEVICE = -4,    // not a gfx950 device
+};
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+  return __uint_as_float(((uint32_t)v) << 16);
+}
+// Round-to-nearest-even, lowered to v_cvt_pk_bf16_f32 on gfx950.
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;
+  return *reinterpret_cast<bf16_t*>(&b);
+}
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+  f32x2 v = {lo, hi};
+  bf16x2_hw b = __builtin_convertvector(v, bf16x2_hw);
+  return *reinterpret_cast<uint32_t*>(&b);
+}
+__device__ __forceinline__ float bf16lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+static inline int launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? U2_OK : U2_ERR_LAUNCH;
+}
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace u2

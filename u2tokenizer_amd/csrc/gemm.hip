@@ -1,0 +1,273 @@
+// bf16 MFMA GEMM for gfx950:  C[z][m][n] = epilogue( alpha * sum_k A[z][m][k] * B[z][n][k] )
+//
+// Both operands are K-contiguous ("NT" form): A is an activation matrix [M][K], B is a weight in
+// nn.Linear layout [N][K] (or K/V^T/... for the attention products).  This is the workhorse of the
+// hot path: every nn.Linear of the ViT blocks (reference vit.py:100-105 via MONAI SABlock/MLPBlock),
+// the SPP MLP (spatial_pooling_projector.py:22-28), every wq/wk/wv/dense of the tokenizer
+// (rma.py:13-16, tta.py:16-19), the DiffTS score/aggregation products (svr.py:105-115) and the
+// QK^T / PV products of the tokenizer attention (rma.py:61,73; tta.py:56,59).
+//
+// Design (CDNA4):
+//  * 256 threads = 4 wave64 in a 2x2 arrangement; block tile BMxBNx64, wave tile (BM/2)x(BN/2) built
+//    from v_mfma_f32_16x16x32_bf16.  The MFMA is issued with the WEIGHT fragment as the A operand and
+//    the ACTIVATION fragment as the B operand, so a lane ends up holding 4 consecutive output columns
+//    n of one output row m -> 8-byte bf16 / 16-byte fp32 stores and vector bias/residual loads.
+//  * LDS tile = [rows][64 bf16] (128 B per row), 16-byte chunks XOR-swizzled with (row & 7) so the
+//    ds_read_b128 fragment reads of a 16-lane group touch 16 distinct 16-B slots (conflict-free).
+//  * Two LDS stages; global->LDS either through registers (global_load_dwordx4 + ds_write_b128, issued
+//    before the MFMA block, written after it) or by LDS-DMA (global_load_lds_dwordx4, swizzle applied
+//    on the per-lane SOURCE address because the DMA destination is lane-linear).
+//  * XCD-aware, M-grouped tile order so that the 8 private L2s each see a compact band of tiles.
+#include "kernels.h"
+
+namespace u2 {
+
+__device__ uint4 g_zero16;  // zero-initialised; K-tail chunks of the LDS-DMA path read from here
+
+template <int BM, int BN, bool GLDS>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
+  constexpr int BK = 64;
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int MI = WM / 16, NI = WN / 16;
+  constexpr int CA = BM * 8 / 256, CB = BN * 8 / 256;  // 16-B chunks per thread per tile
+  constexpr int STAGE = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- tile order: XCD-contiguous bands, then groups of 8 m-tiles ----
+  const int ntiles = d.tiles_m * d.tiles_n;
+  int pid = blockIdx.x;
+  {
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int xcd = pid & 7, idx = pid >> 3;
+    pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * d.tiles_n;
+  const int group = pid / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(d.tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (pid % per_group) % gsz;
+  const int tn = (pid % per_group) / gsz;
+  const int bm0 = tm * BM, bn0 = tn * BN;
+
+  const int z = blockIdx.y;
+  const int zb = z / d.nbh, zh = z - zb * d.nbh;
+  const bf16_t* __restrict__ A = d.A + zb * d.sAb + zh * d.sAh;
+  const bf16_t* __restrict__ B = d.B + zb * d.sBb + zh * d.sBh;
+
+  // ---- per-thread global source pointers (row clamped, swizzled chunk folded in) ----
+  const bf16_t* pa[CA];
+  const bf16_t* pb[CB];
+  int ka[CA], kb[CB];  // k offset of the thread's chunk inside a K tile
+#pragma unroll
+  for (int i = 0; i < CA; ++i) {
+    const int c = i * 256 + tid, row = c >> 3, gc = (c & 7) ^ (row & 7);
+    const int grow = min(bm0 + row, d.M - 1);
+    ka[i] = gc * 8;
+    pa[i] = A + (int64_t)grow * d.lda + gc * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < CB; ++i) {
+    const int c = i * 256 + tid, row = c >> 3, gc = (c & 7) ^ (row & 7);
+    const int grow = min(bn0 + row, d.N - 1);
+    kb[i] = gc * 8;
+    pb[i] = B + (int64_t)grow * d.ldb + gc * 8;
+  }
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets: row = base + (lane & 15); (row & 7) == (lane & 7) because bases are x16
+  const int frow = (lane & 15) * 128;
+  int foff[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) foff[kk] = (((kk * 4 + (lane >> 4)) ^ (lane & 7)) << 4);
+
+  const int nkt = (d.K + BK - 1) / BK;
+  uint4 ra[CA], rb[CB];
+
+  auto gload = [&](int kt) {
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < CA; ++i)
+      ra[i] = (k0 + ka[i] < d.K) ? *reinterpret_cast<const uint4*>(pa[i] + k0) : uint4{0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < CB; ++i)
+      rb[i] = (k0 + kb[i] < d.K) ? *reinterpret_cast<const uint4*>(pb[i] + k0) : uint4{0, 0, 0, 0};
+  };
+  auto lstore = [&](int buf) {
+    char* s = lds + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < CA; ++i) *reinterpret_cast<uint4*>(s + (i * 256 + tid) * 16) = ra[i];
+#pragma unroll
+    for (int i = 0; i < CB; ++i) *reinterpret_cast<uint4*>(s + BM * 128 + (i * 256 + tid) * 16) = rb[i];
+  };
+  auto dma = [&](int kt, int buf) {
+    const int k0 = kt * BK;
+    char* s = lds + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+      const void* src = (k0 + ka[i] < d.K) ? (const void*)(pa[i] + k0) : (const void*)&g_zero16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(s + (i * 256 + wave * 64) * 16),
+                                       16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+      const void* src = (k0 + kb[i] < d.K) ? (const void*)(pb[i] + k0) : (const void*)&g_zero16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(s + BM * 128 + (i * 256 + wave * 64) * 16),
+                                       16, 0, 0);
+    }
+  };
+  auto compute = [&](int buf) {
+    const char* sA = lds + buf * STAGE + (wm * WM) * 128 + frow;
+    const char* sB = lds + buf * STAGE + BM * 128 + (wn * WN) * 128 + frow;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 xf[MI], wf[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) xf[mi] = *reinterpret_cast<const bf16x8*>(sA + mi * 16 * 128 + foff[kk]);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const bf16x8*>(sB + ni * 16 * 128 + foff[kk]);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[mi][ni], 0, 0, 0);
+    }
+  };
+
+  if constexpr (GLDS) {
+    dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      if (kt + 1 < nkt) dma(kt + 1, (kt + 1) & 1);
+      compute(kt & 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      if (kt + 1 < nkt) gload(kt + 1);
+      compute(kt & 1);
+      if (kt + 1 < nkt) lstore((kt + 1) & 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: lane holds C[m][n0..n0+3], m = tile row (lane & 15), n0 = 4 * (lane >> 4) ----
+  const bool out_f32 = d.flags & GEMM_OUT_F32;
+  char* Cz = reinterpret_cast<char*>(d.C) + (zb * d.sCb + zh * d.sCh) * (out_f32 ? 4 : 2);
+  const bf16_t* Rz = (d.flags & GEMM_RESIDUAL) ? d.R + zb * d.sRb + zh * d.sRh : nullptr;
+  const bool vec = d.flags & GEMM_VEC_OK;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = bm0 + wm * WM + mi * 16 + (lane & 15);
+    if (m >= d.M) continue;
+    float bm_v = 0.f;
+    if (d.flags & GEMM_BIAS_M) bm_v = bf16_to_f32(d.bias[m]);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n0 = bn0 + wn * WN + ni * 16 + (lane >> 4) * 4;
+      if (n0 >= d.N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r] * d.alpha + bm_v;
+      if (vec && n0 + 3 < d.N) {
+        if (d.flags & GEMM_BIAS_N) {
+          const uint2 b2 = *reinterpret_cast<const uint2*>(d.bias + n0);
+          v[0] += bf16lo(b2.x); v[1] += bf16hi(b2.x); v[2] += bf16lo(b2.y); v[3] += bf16hi(b2.y);
+        }
+        if (d.flags & GEMM_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        }
+        if (Rz) {
+          const uint2 r2 = *reinterpret_cast<const uint2*>(Rz + (int64_t)m * d.ldr + n0);
+          v[0] += bf16lo(r2.x); v[1] += bf16hi(r2.x); v[2] += bf16lo(r2.y); v[3] += bf16hi(r2.y);
+        }
+        if (out_f32) {
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cz) + (int64_t)m * d.ldc + n0) =
+              float4{v[0], v[1], v[2], v[3]};
+        } else {
+          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cz) + (int64_t)m * d.ldc + n0) =
+              uint2{pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + r;
+          if (n >= d.N) break;
+          float x = v[r];
+          if (d.flags & GEMM_BIAS_N) x += bf16_to_f32(d.bias[n]);
+          if (d.flags & GEMM_GELU) x = gelu_erf(x);
+          if (Rz) x += bf16_to_f32(Rz[(int64_t)m * d.ldr + n]);
+          if (out_f32) reinterpret_cast<float*>(Cz)[(int64_t)m * d.ldc + n] = x;
+          else reinterpret_cast<bf16_t*>(Cz)[(int64_t)m * d.ldc + n] = f32_to_bf16(x);
+        }
+      }
+    }
+  }
+}
+
+static int g_gemm_glds = 1;      // 1: LDS-DMA staging, 0: register staging
+static int g_gemm_force_tile = 0;  // 0: heuristic, 64 / 128: force
+
+void gemm_set_options(int glds, int force_tile) {
+  if (glds >= 0) g_gemm_glds = glds;
+  if (force_tile >= 0) g_gemm_force_tile = force_tile;
+}
+
+template <int BM, int BN>
+static int launch_tile(GemmDesc d, hipStream_t stream) {
+  d.tiles_m = (int)cdiv(d.M, BM);
+  d.tiles_n = (int)cdiv(d.N, BN);
+  dim3 grid(d.tiles_m * d.tiles_n, d.nz, 1);
+  constexpr int smem = 2 * (BM + BN) * 128;
+  if (g_gemm_glds)
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, true>), grid, dim3(256), smem, stream, d);
+  else
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, false>), grid, dim3(256), smem, stream, d);
+  return launch_status();
+}
+
+int gemm_bf16(GemmDesc d, hipStream_t stream) {
+  if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.nz <= 0 || d.nz > 65535) return U2_ERR_ARG;
+  if (!d.A || !d.B || !d.C) return U2_ERR_ARG;
+  if (d.nbh <= 0) d.nbh = 1;
+  // 16-byte chunked K loads: K, leading dims and batch strides must keep every chunk aligned
+  if ((d.K & 7) || (d.lda & 7) || (d.ldb & 7) || (d.sAb & 7) || (d.sAh & 7) || (d.sBb & 7) || (d.sBh & 7))
+    return U2_ERR_ARG;
+  if (((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15)) return U2_ERR_ARG;
+  if ((d.flags & (GEMM_BIAS_N | GEMM_BIAS_M)) && !d.bias) return U2_ERR_ARG;
+  if ((d.flags & GEMM_RESIDUAL) && !d.R) return U2_ERR_ARG;
+  const bool out_f32 = d.flags & GEMM_OUT_F32;
+  bool vec = (d.ldc % 4 == 0) && (d.sCb % 4 == 0) && (d.sCh % 4 == 0) &&
+             (((uintptr_t)d.C & (out_f32 ? 15 : 7)) == 0);
+  if (d.flags & GEMM_BIAS_N) vec = vec && (((uintptr_t)d.bias & 7) == 0);
+  if (d.flags & GEMM_RESIDUAL)
+    vec = vec && (d.ldr % 4 == 0) && (d.sRb % 4 == 0) && (d.sRh % 4 == 0) && (((uintptr_t)d.R & 7) == 0);
+  d.flags = vec ? (d.flags | GEMM_VEC_OK) : (d.flags & ~GEMM_VEC_OK);
+
+  int tile = g_gemm_force_tile;
+  if (tile != 64 && tile != 128) {
+    const int64_t big = cdiv(d.M, 128) * cdiv(d.N, 128) * d.nz;
+    tile = (big >= 192) ? 128 : 64;  // fill 256 CUs; small-M weight-streaming shapes get 64^2 tiles
+  }
+  return tile == 128 ? launch_tile<128, 128>(d, stream) : launch_tile<64, 64>(d, stream);
+}
+
+}  // namespace u2

@@ -1,0 +1,101 @@
+// Internal C++ launcher API of the u2tok HIP library.  Every function enqueues work on `stream`,
+// never allocates, never synchronises, and returns U2_OK or a negative U2_ERR_* code.
+#pragma once
+#include "common.h"
+
+namespace u2 {
+
+// ------------------------------------------------------------------ GEMM (gemm.hip)
+enum : int {
+  GEMM_BIAS_N = 1,     // + bias[n]   (nn.Linear bias)
+  GEMM_BIAS_M = 2,     // + bias[m]   (operand-swapped products, e.g. DiffTS scores^T)
+  GEMM_GELU = 4,       // exact erf GELU after bias
+  GEMM_RESIDUAL = 8,   // + R[m][n]   (residual stream / position embedding), after GELU
+  GEMM_OUT_F32 = 16,   // C is float32 instead of bf16
+  GEMM_VEC_OK = 32,    // internal: vector epilogue legal (set by the launcher)
+};
+
+struct GemmDesc {
+  const bf16_t* A = nullptr;  // [M][K] row-major, leading dim lda
+  const bf16_t* B = nullptr;  // [N][K] row-major, leading dim ldb
+  void* C = nullptr;          // [M][N] bf16 or f32, leading dim ldc
+  const bf16_t* bias = nullptr;
+  const bf16_t* R = nullptr;  // [M][N] bf16, leading dim ldr
+  int M = 0, N = 0, K = 0;
+  int64_t lda = 0, ldb = 0, ldc = 0, ldr = 0;
+  // batch z in [0, nz): zb = z / nbh, zh = z % nbh; element offsets zb*s?b + zh*s?h
+  int nz = 1, nbh = 1;
+  int64_t sAb = 0, sAh = 0, sBb = 0, sBh = 0, sCb = 0, sCh = 0, sRb = 0, sRh = 0;
+  float alpha = 1.f;
+  int flags = 0;
+  int tiles_m = 0, tiles_n = 0;  // filled by the launcher
+};
+
+int gemm_bf16(GemmDesc d, hipStream_t stream);
+void gemm_set_options(int glds, int force_tile);
+
+// ------------------------------------------------------------------ row ops (rowops.hip)
+// y[b][r][:] = LayerNorm(x[b][r][:] (+ res[b][r][:])) * w + bias   (bf16 in/out, fp32 math)
+int layernorm_bf16(const bf16_t* x, const bf16_t* res, const bf16_t* w, const bf16_t* bias, bf16_t* y,
+                   int nb, int rows, int C, int64_t x_bs, int64_t x_ld, int64_t res_bs, int64_t res_ld,
+                   int64_t y_bs, int64_t y_ld, float eps, hipStream_t stream);
+
+// P[z][r][c] = softmax_c( S[z][r][c] * scale + rel_bias[(c - r) + max_len - 1][z % H] ), bf16 out,
+// columns [n, ldp) of P are written as zero.  rel_bias may be null.
+int softmax_rows(const float* S, bf16_t* P, int nz, int rows, int n, int64_t lds, int64_t ldp,
+                 int64_t s_zs, int64_t p_zs, float scale, const bf16_t* rel_bias, int H, int max_len,
+                 hipStream_t stream);
+
+// out[z][c][r] = in[z][r][c]; columns [R, ld_out) of out are zero-filled.
+int transpose_bf16(const bf16_t* in, bf16_t* out, int nz, int R, int C, int64_t ld_in, int64_t ld_out,
+                   int64_t in_zs, int64_t out_zs, hipStream_t stream);
+
+// ------------------------------------------------------------------ vision (vision.hip)
+enum : int { VOL_F16 = 0, VOL_BF16 = 1, VOL_F32 = 2 };
+// im2col of reference PatchEmbeddingBlock(perceptron): "b c (h p1) (w p2) (d p3) -> b (h w d) (p1 p2 p3 c)"
+// with c == 1.  vol: [nchunk][D][H][W] of vol_dtype; out: [nchunk][nh*nw*nd][p1*p2*p3] bf16.
+int im2col_patches(const void* vol, int vol_dtype, bf16_t* out, int nchunk, int D, int H, int W,
+                   int p1, int p2, int p3, hipStream_t stream);
+
+// SpatialPoolingProjector pooling: tokens (g1,g2,g3) grid -> avg over ps^3 neighbourhoods.
+int avgpool3d_tokens(const bf16_t* x, bf16_t* y, int nb, int g1, int g2, int g3, int w1, int w2, int w3, int C,
+                     hipStream_t stream);
+// dst[b*dst_bs + e] = src[e] for e < n  (cls token / query token broadcast)
+int fill_rows(const bf16_t* src, bf16_t* dst, int nb, int64_t n, int64_t dst_bs, hipStream_t stream);
+// in-place rotate-half RoPE on rows indexed (outer, s, inner), position = s, heads = d-wide column slices
+int rope_apply(bf16_t* x, int64_t n_outer, int S, int n_inner, int H, int d, int64_t ld, int max_len,
+               hipStream_t stream);
+
+// out[b][s] = (s == 0 || s > nfeat) ? table[ids[b][s]] : feats[b][s-1]   (embedding lookup + splice)
+// feats may be null with nfeat == 0 (plain lookup).
+int embed_splice(const bf16_t* table, const int64_t* ids, const bf16_t* feats, bf16_t* out, int B, int S,
+                 int E, int nfeat, int64_t vocab, hipStream_t stream);
+
+// ------------------------------------------------------------------ selection / pooling (select.hip)
+// scores[b][i] = fp32( sum_e x[b][i][e] * w[e] + bias ), accumulated in fp64.
+int score_gemv(const bf16_t* x, const bf16_t* w, const bf16_t* bias, float* scores, int rows, int E,
+               hipStream_t stream);
+// idx[b][0..k) = indices of the k largest scores[b][0..n), descending, ties -> lower index first.
+int topk_sorted(const float* scores, int64_t* idx, int B, int n, int k, hipStream_t stream);
+// out[b][i][:] = x[b][idx[b][i]][:]
+int gather_rows(const bf16_t* x, const int64_t* idx, bf16_t* out, int B, int n, int k, int E,
+                hipStream_t stream);
+// Multi-scale pooling {1,2,4} along the token axis (+ optional DMTP gates).  x: [B][k][E];
+// out: [B][k + k/2 + k/4][E].  gate_w/gate_b null -> fixed pooling.  ws: >= B*3*ceil(E/256) floats.
+int multiscale_pool(const bf16_t* x, bf16_t* out, int B, int k, int E, const bf16_t* gate_w,
+                    const bf16_t* gate_b, float* ws, hipStream_t stream);
+
+// ------------------------------------------------------------------ attention (attn.hip)
+// Temporal attention of SpatioTemporalAttentionLayer: sequences of length T <= 16 that run ACROSS
+// chunks.  q/k/v/out rows are laid out [b][t][n] (leading dim ld), heads are column slices of width d.
+int temporal_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int B, int T, int N,
+                       int H, int d, int64_t ld_qkv, int64_t ld_out, float scale, const bf16_t* rel_bias,
+                       int max_len, hipStream_t stream);
+
+// Flash attention for the ViT blocks (head_dim 64).  q,k: [nb][S][*] with leading dim ld_qk, head h at
+// column h*64; vt: [nb][H][64][S_pad] (S_pad % 64 == 0, zero padded); out: [nb][S][H*64] (ld_out).
+int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int nb, int S,
+                        int H, int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs, int S_pad,
+                        float scale, hipStream_t stream);
+
+}  // namespace u2

@@ -1,0 +1,419 @@
+// Launch sequences of the three module forwards of the hot path (reference: u2_arch.py:91-117):
+//   ViT3DTower (vit.py:114-126,148-164) -> SpatialPoolingProjector (spatial_pooling_projector.py:34-52)
+//   -> u2Tokenizer (u2Tokenizer.py:40-47 = svr.py:166-188 + tta.py:126-140).
+// Everything is enqueued from C++ on one HIP stream (no per-op Python/ctypes round trip); intermediate
+// tensors live in a caller-provided workspace carved by a bump arena.  Each forward is written once and
+// can run "dry" (no launches) to size that workspace.
+#include "pipeline.h"
+
+namespace u2 {
+
+namespace {
+
+struct Arena {
+  char* base;
+  size_t cap;
+  size_t off = 0, peak = 0;
+  bool dry;
+  Arena(void* b, size_t c, bool d) : base((char*)b), cap(c), dry(d) {}
+  template <typename T>
+  T* get(size_t count) {
+    const size_t a = (off + 255) & ~(size_t)255;
+    off = a + count * sizeof(T);
+    if (off > peak) peak = off;
+    if (dry) return reinterpret_cast<T*>((uintptr_t)0x1000 + a);  // never dereferenced
+    return (off <= cap) ? reinterpret_cast<T*>(base + a) : nullptr;
+  }
+  bool ok() const { return dry || peak <= cap; }
+};
+
+#define U2_RUN(expr)                  \
+  do {                                \
+    if (!dry) {                       \
+      const int e_ = (expr);          \
+      if (e_ != U2_OK) return e_;     \
+    }                                 \
+  } while (0)
+#define U2_CHECK_WS(ar) \
+  do {                  \
+    if (!(ar).ok()) return U2_ERR_WORKSPACE; \
+  } while (0)
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// y[rows][ldy] = x[rows][ldx] @ W[out][in]^T + b  (+GELU) (+R)
+int linear(const bf16_t* x, int64_t ldx, const bf16_t* w, const bf16_t* b, bf16_t* y, int64_t ldy, int64_t rows,
+           int in, int out, int extra_flags, const bf16_t* R, int64_t ldr, hipStream_t st) {
+  GemmDesc g;
+  g.A = x; g.B = w; g.C = y; g.bias = b; g.R = R;
+  g.M = (int)rows; g.N = out; g.K = in;
+  g.lda = ldx; g.ldb = in; g.ldc = ldy; g.ldr = ldr;
+  g.flags = (b ? GEMM_BIAS_N : 0) | extra_flags | (R ? GEMM_RESIDUAL : 0);
+  return gemm_bf16(g, st);
+}
+
+struct AttnCore {
+  const bf16_t *q, *k, *v;
+  int64_t ldq, ldk, ldv, q_bs, k_bs, v_bs;
+  bf16_t* out;
+  int64_t ldo, o_bs;
+  int nb, Sq, Skv, H, d;
+  float scale;
+  const bf16_t* rel_bias;
+  int max_len;
+};
+
+// softmax(Q K^T * scale + bias) V via two batched MFMA GEMMs, fp32 scores, bf16 probabilities.
+// Reference: rma.py:60-75 / tta.py:55-61 / rope.py:82-86 (which also materialise the probabilities).
+int attention_core(Arena& ar, const AttnCore& a, bool dry, hipStream_t st) {
+  const size_t mark = ar.off;
+  const int64_t ldS = round_up(a.Skv, 8), ldp = ldS;
+  const int64_t nz = (int64_t)a.nb * a.H;
+  if (nz > 65535) return U2_ERR_ARG;
+  float* S = ar.get<float>((size_t)nz * a.Sq * ldS);
+  bf16_t* P = ar.get<bf16_t>((size_t)nz * a.Sq * ldp);
+  bf16_t* Vt = ar.get<bf16_t>((size_t)a.nb * a.H * a.d * ldp);
+  U2_CHECK_WS(ar);
+  {
+    GemmDesc g;
+    g.A = a.q; g.B = a.k; g.C = S;
+    g.M = a.Sq; g.N = a.Skv; g.K = a.d;
+    g.lda = a.ldq; g.ldb = a.ldk; g.ldc = ldS;
+    g.nz = (int)nz; g.nbh = a.H;
+    g.sAb = a.q_bs; g.sAh = a.d; g.sBb = a.k_bs; g.sBh = a.d;
+    g.sCb = (int64_t)a.H * a.Sq * ldS; g.sCh = (int64_t)a.Sq * ldS;
+    g.flags = GEMM_OUT_F32;
+    U2_RUN(gemm_bf16(g, st));
+  }
+  U2_RUN(softmax_rows(S, P, (int)nz, a.Sq, a.Skv, ldS, ldp, (int64_t)a.Sq * ldS, (int64_t)a.Sq * ldp, a.scale,
+                      a.rel_bias, a.H, a.max_len, st));
+  U2_RUN(transpose_bf16(a.v, Vt, a.nb, a.Skv, a.H * a.d, a.ldv, ldp, a.v_bs, (int64_t)a.H * a.d * ldp, st));
+  {
+    GemmDesc g;
+    g.A = P; g.B = Vt; g.C = a.out;
+    g.M = a.Sq; g.N = a.d; g.K = (int)ldp;
+    g.lda = ldp; g.ldb = ldp; g.ldc = a.ldo;
+    g.nz = (int)nz; g.nbh = a.H;
+    g.sAb = (int64_t)a.H * a.Sq * ldp; g.sAh = (int64_t)a.Sq * ldp;
+    g.sBb = (int64_t)a.H * a.d * ldp; g.sBh = (int64_t)a.d * ldp;
+    g.sCb = a.o_bs; g.sCh = a.d;
+    U2_RUN(gemm_bf16(g, st));
+  }
+  ar.off = mark;
+  return U2_OK;
+}
+
+int g_vit_flash = 1;
+
+}  // namespace
+
+void pipeline_set_vit_flash(int v) { g_vit_flash = v ? 1 : 0; }
+
+// =========================================================================== ViT3DTower
+int vit_forward(const VitConfig& c, const void* const* W, const void* volume, bf16_t* out, void* ws, size_t ws_bytes,
+                bool dry, size_t* peak, hipStream_t st) {
+  if (c.nchunk <= 0 || c.depth < 0 || c.heads <= 0 || c.hidden != c.heads * 64) return U2_ERR_ARG;
+  for (int i = 0; i < 3; ++i)
+    if (c.img[i] <= 0 || c.patch[i] <= 0 || c.img[i] % c.patch[i]) return U2_ERR_ARG;
+  if (!dry && (!W || !volume || !out)) return U2_ERR_ARG;
+  const int nh = c.img[0] / c.patch[0], nw = c.img[1] / c.patch[1], nd = c.img[2] / c.patch[2];
+  const int ntok = nh * nw * nd, S = ntok + 1, Hd = c.hidden, Kp = c.patch[0] * c.patch[1] * c.patch[2];
+  const int nc = c.nchunk;
+  const int64_t rows = (int64_t)nc * S;
+  const int S_pad = (int)round_up(S, 64);
+  auto w = [&](int i) { return dry ? nullptr : reinterpret_cast<const bf16_t*>(W[i]); };
+
+  Arena ar(ws, ws_bytes, dry);
+  bf16_t* x = ar.get<bf16_t>((size_t)rows * Hd);
+  bf16_t* xn = ar.get<bf16_t>((size_t)rows * Hd);
+  bf16_t* qkv = ar.get<bf16_t>((size_t)rows * 3 * Hd);
+  bf16_t* att = ar.get<bf16_t>((size_t)rows * Hd);
+  bf16_t* vt = ar.get<bf16_t>((size_t)nc * Hd * S_pad);
+  // patches (only needed for the embedding) and the MLP hidden share one region
+  const size_t big = std::max((size_t)nc * ntok * Kp, (size_t)rows * c.mlp_dim);
+  bf16_t* h1 = ar.get<bf16_t>(big);
+  bf16_t* patches = h1;
+  U2_CHECK_WS(ar);
+
+  // ---- patch embedding: im2col + Linear + position embedding, cls token prepended (vit.py:115-118)
+  U2_RUN(im2col_patches(volume, c.vol_dtype, patches, nc, c.img[0], c.img[1], c.img[2], c.patch[0], c.patch[1],
+                        c.patch[2], st));
+  U2_RUN(fill_rows(w(3), x, nc, Hd, (int64_t)S * Hd, st));
+  {
+    GemmDesc g;
+    g.A = patches; g.B = w(1); g.C = x + Hd; g.bias = w(2); g.R = w(0);
+    g.M = ntok; g.N = Hd; g.K = Kp;
+    g.lda = Kp; g.ldb = Kp; g.ldc = Hd; g.ldr = Hd;
+    g.nz = nc; g.nbh = 1;
+    g.sAb = (int64_t)ntok * Kp; g.sCb = (int64_t)S * Hd;
+    g.flags = GEMM_BIAS_N | GEMM_RESIDUAL;
+    U2_RUN(gemm_bf16(g, st));
+  }
+  const float scale = 1.0f / sqrtf(64.0f);
+  for (int l = 0; l < c.depth; ++l) {
+    const int b0 = 4 + 11 * l;
+    // x = x + out_proj(attn(qkv(norm1(x))))   (MONAI TransformerBlock / SABlock)
+    U2_RUN(layernorm_bf16(x, nullptr, w(b0 + 0), w(b0 + 1), xn, 1, (int)rows, Hd, 0, Hd, 0, 0, 0, Hd, c.ln_eps, st));
+    U2_RUN(linear(xn, Hd, w(b0 + 2), nullptr, qkv, 3 * Hd, rows, Hd, 3 * Hd, 0, nullptr, 0, st));
+    if (g_vit_flash) {
+      U2_RUN(transpose_bf16(qkv + 2 * Hd, vt, nc, S, Hd, 3 * Hd, S_pad, (int64_t)S * 3 * Hd, (int64_t)Hd * S_pad, st));
+      U2_RUN(flash_attention_d64(qkv, qkv + Hd, vt, att, nc, S, c.heads, 3 * Hd, (int64_t)S * 3 * Hd, Hd,
+                                 (int64_t)S * Hd, S_pad, scale, st));
+    } else {
+      AttnCore a{qkv, qkv + Hd, qkv + 2 * Hd, 3 * Hd, 3 * Hd, 3 * Hd, (int64_t)S * 3 * Hd, (int64_t)S * 3 * Hd,
+                 (int64_t)S * 3 * Hd, att, Hd, (int64_t)S * Hd, nc, S, S, c.heads, 64, scale, nullptr, 0};
+      const int e = attention_core(ar, a, dry, st);
+      if (e != U2_OK) return e;
+    }
+    U2_RUN(linear(att, Hd, w(b0 + 3), w(b0 + 4), x, Hd, rows, Hd, Hd, 0, x, Hd, st));
+    // x = x + linear2(gelu(linear1(norm2(x))))
+    U2_RUN(layernorm_bf16(x, nullptr, w(b0 + 5), w(b0 + 6), xn, 1, (int)rows, Hd, 0, Hd, 0, 0, 0, Hd, c.ln_eps, st));
+    U2_RUN(linear(xn, Hd, w(b0 + 7), w(b0 + 8), h1, c.mlp_dim, rows, Hd, c.mlp_dim, GEMM_GELU, nullptr, 0, st));
+    U2_RUN(linear(h1, c.mlp_dim, w(b0 + 9), w(b0 + 10), x, Hd, rows, c.mlp_dim, Hd, 0, x, Hd, st));
+  }
+  // final norm; drop the cls row unless select_feature == "cls_patch" (vit.py:124,157-160)
+  const int nwt = 4 + 11 * c.depth;
+  if (c.keep_cls)
+    U2_RUN(layernorm_bf16(x, nullptr, w(nwt), w(nwt + 1), out, nc, S, Hd, (int64_t)S * Hd, Hd, 0, 0, (int64_t)S * Hd, Hd,
+                          c.ln_eps, st));
+  else
+    U2_RUN(layernorm_bf16(x + Hd, nullptr, w(nwt), w(nwt + 1), out, nc, ntok, Hd, (int64_t)S * Hd, Hd, 0, 0,
+                          (int64_t)ntok * Hd, Hd, c.ln_eps, st));
+  if (peak) *peak = ar.peak;
+  U2_CHECK_WS(ar);
+  return U2_OK;
+}
+
+// =========================================================================== SpatialPoolingProjector
+int spp_forward(const SppConfig& c, const void* const* W, const bf16_t* x, bf16_t* out, void* ws, size_t ws_bytes,
+                bool dry, size_t* peak, hipStream_t st) {
+  if (c.nchunk <= 0 || c.pooling_size <= 0 || c.layer_num <= 0 || c.in_dim <= 0 || c.out_dim <= 0) return U2_ERR_ARG;
+  if (!dry && (!W || !x || !out)) return U2_ERR_ARG;
+  const int ps = c.pooling_size;
+  int g1 = c.grid[0], g2 = c.grid[1], g3 = c.grid[2], w1 = ps, w2 = ps, w3 = ps;
+  if (c.pooling_type == 1) { g3 = g1 * g2 * g3; g1 = g2 = 1; w1 = w2 = 1; w3 = ps * ps * ps; }
+  else if (c.pooling_type != 0) return U2_ERR_ARG;
+  if (g1 < w1 || g2 < w2 || g3 < w3) return U2_ERR_ARG;
+  const int np = (g1 / w1) * (g2 / w2) * (g3 / w3);
+  const int64_t rows = (int64_t)c.nchunk * np;
+  auto w = [&](int i) { return dry ? nullptr : reinterpret_cast<const bf16_t*>(W[i]); };
+  Arena ar(ws, ws_bytes, dry);
+  bf16_t* pooled = ar.get<bf16_t>((size_t)rows * c.in_dim);
+  bf16_t* ha = ar.get<bf16_t>((size_t)rows * c.out_dim);
+  bf16_t* hb = ar.get<bf16_t>((size_t)rows * c.out_dim);
+  U2_CHECK_WS(ar);
+  U2_RUN(avgpool3d_tokens(x, pooled, c.nchunk, g1, g2, g3, w1, w2, w3, c.in_dim, st));
+  const bf16_t* cur = pooled;
+  int cur_dim = c.in_dim;
+  for (int l = 0; l < c.layer_num; ++l) {
+    const bool last = (l == c.layer_num - 1);
+    bf16_t* dst = last ? out : ((l & 1) ? hb : ha);
+    const int fl = (!last && c.layer_type == 0) ? GEMM_GELU : 0;
+    U2_RUN(linear(cur, cur_dim, w(2 * l), w(2 * l + 1), dst, c.out_dim, rows, cur_dim, c.out_dim, fl, nullptr, 0, st));
+    cur = dst;
+    cur_dim = c.out_dim;
+  }
+  if (peak) *peak = ar.peak;
+  return U2_OK;
+}
+
+// =========================================================================== u2Tokenizer
+namespace {
+struct Att {
+  const bf16_t *wq, *bq, *wk, *bk, *wv, *bv, *wd, *bd, *rb;
+};
+}  // namespace
+
+int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_token, const bf16_t* t_token,
+                      bf16_t* out, int64_t* topk_idx_out, void* ws, size_t ws_bytes, bool dry, size_t* peak,
+                      hipStream_t st) {
+  if (c.B <= 0 || c.T <= 0 || c.N <= 0 || c.E <= 0 || c.Lt <= 0 || c.num_heads <= 0 || c.num_layers < 0) return U2_ERR_ARG;
+  if (c.E % c.num_heads || (c.E / c.num_heads) % 8 || c.top_k <= 0 || c.num_query <= 0) return U2_ERR_ARG;
+  if (c.attn_type != 0 && c.attn_type != 1) return U2_ERR_ARG;
+  if (!dry && (!W || !v_token || !t_token || !out)) return U2_ERR_ARG;
+  const int B = c.B, T = c.T, N = c.N, E = c.E, H = c.num_heads, d = E / H, L = c.num_layers, Q = c.num_query;
+  const int TN = T * N, k = c.top_k;
+  if (!c.enable_diffts && k > TN) return U2_ERR_ARG;                       // torch.topk would raise
+  if (N > c.max_seq_len || T > c.max_seq_len || Q > c.max_seq_len) return U2_ERR_ARG;  // rma.py:64-68 index range
+  if (T > 16) return U2_ERR_ARG;  // temporal kernel limit (round 1)
+  const float scale = 1.0f / sqrtf((float)d);
+  auto wp = [&](int i) { return dry ? nullptr : reinterpret_cast<const bf16_t*>(W[i]); };
+  auto att_at = [&](int i) {
+    Att a{wp(i), wp(i + 1), wp(i + 2), wp(i + 3), wp(i + 4), wp(i + 5), wp(i + 6), wp(i + 7), wp(i + 8)};
+    if (c.attn_type != 0) a.rb = nullptr;
+    return a;
+  };
+  const int i_sel = 1 + 18 * L, i_gate = i_sel + 2, i_tta = i_gate + 2, i_lin = i_tta + 33 * L;
+
+  Arena ar(ws, ws_bytes, dry);
+  const int64_t rows = (int64_t)B * TN;
+  bf16_t* xa = ar.get<bf16_t>((size_t)rows * E);
+  bf16_t* xb = ar.get<bf16_t>((size_t)rows * E);
+  bf16_t* qkv = ar.get<bf16_t>((size_t)rows * 3 * E);
+  bf16_t* ctx = ar.get<bf16_t>((size_t)rows * E);
+  U2_CHECK_WS(ar);
+
+  // ---------------- SVR: SpatioTemporalSignificanceScoring (svr.py:50-62) -- x = attn(x), no residual/norm
+  const bf16_t* x = v_token;
+  for (int l = 0; l < L; ++l) {
+    const Att sp = att_at(1 + 18 * l), tp = att_at(1 + 18 * l + 9);
+    bf16_t* y = (x == xa) ? xb : xa;
+    // spatial: sequences of N tokens inside each chunk (svr.py:27-30)
+    U2_RUN(linear(x, E, sp.wq, sp.bq, qkv, 3 * E, rows, E, E, 0, nullptr, 0, st));
+    U2_RUN(linear(x, E, sp.wk, sp.bk, qkv + E, 3 * E, rows, E, E, 0, nullptr, 0, st));
+    U2_RUN(linear(x, E, sp.wv, sp.bv, qkv + 2 * E, 3 * E, rows, E, E, 0, nullptr, 0, st));
+    if (c.attn_type == 1) {
+      U2_RUN(rope_apply(qkv, (int64_t)B * T, N, 1, H, d, 3 * E, c.max_seq_len, st));
+      U2_RUN(rope_apply(qkv + E, (int64_t)B * T, N, 1, H, d, 3 * E, c.max_seq_len, st));
+    }
+    {
+      AttnCore a{qkv, qkv + E, qkv + 2 * E, 3 * E, 3 * E, 3 * E, (int64_t)N * 3 * E, (int64_t)N * 3 * E,
+                 (int64_t)N * 3 * E, ctx, E, (int64_t)N * E, B * T, N, N, H, d, scale, sp.rb, c.max_seq_len};
+      const int e = attention_core(ar, a, dry, st);
+      if (e != U2_OK) return e;
+    }
+    U2_RUN(linear(ctx, E, sp.wd, sp.bd, y, E, rows, E, E, 0, nullptr, 0, st));
+    // temporal: sequences of T chunks at each token position (svr.py:32-36); rows stay in (b t n) order
+    bf16_t* y2 = (y == xa) ? xb : xa;
+    U2_RUN(linear(y, E, tp.wq, tp.bq, qkv, 3 * E, rows, E, E, 0, nullptr, 0, st));
+    U2_RUN(linear(y, E, tp.wk, tp.bk, qkv + E, 3 * E, rows, E, E, 0, nullptr, 0, st));
+    U2_RUN(linear(y, E, tp.wv, tp.bv, qkv + 2 * E, 3 * E, rows, E, E, 0, nullptr, 0, st));
+    if (c.attn_type == 1) {
+      U2_RUN(rope_apply(qkv, B, T, N, H, d, 3 * E, c.max_seq_len, st));
+      U2_RUN(rope_apply(qkv + E, B, T, N, H, d, 3 * E, c.max_seq_len, st));
+    }
+    U2_RUN(temporal_attention(qkv, qkv + E, qkv + 2 * E, ctx, B, T, N, H, d, 3 * E, E, scale, tp.rb, c.max_seq_len, st));
+    U2_RUN(linear(ctx, E, tp.wd, tp.bd, y2, E, rows, E, E, 0, nullptr, 0, st));
+    x = y2;
+  }
+
+  // ---------------- token selection (svr.py:171)
+  bf16_t* sel = ar.get<bf16_t>((size_t)B * k * E);
+  U2_CHECK_WS(ar);
+  if (c.enable_diffts) {
+    // DifferentiableTokenSelection (svr.py:101-117): weights = softmax_tokens(score_net(x)/tau); out = W^T X.
+    // Computed operand-swapped so the scores land transposed: scT[r][tok] = score_w[r] . x[tok] + b[r].
+    const size_t mark = ar.off;
+    const int64_t ldS = round_up(TN, 8);
+    float* scT = ar.get<float>((size_t)B * k * ldS);
+    bf16_t* P = ar.get<bf16_t>((size_t)B * k * ldS);
+    bf16_t* Xt = ar.get<bf16_t>((size_t)B * E * ldS);
+    U2_CHECK_WS(ar);
+    {
+      GemmDesc g;
+      g.A = wp(i_sel); g.B = x; g.C = scT; g.bias = wp(i_sel + 1);
+      g.M = k; g.N = TN; g.K = E; g.lda = E; g.ldb = E; g.ldc = ldS;
+      g.nz = B; g.sBb = (int64_t)TN * E; g.sCb = (int64_t)k * ldS;
+      g.flags = GEMM_BIAS_M | GEMM_OUT_F32;
+      U2_RUN(gemm_bf16(g, st));
+    }
+    U2_RUN(softmax_rows(scT, P, B, k, TN, ldS, ldS, (int64_t)k * ldS, (int64_t)k * ldS, 1.0f / c.diffts_tau, nullptr, 1,
+                        0, st));
+    U2_RUN(transpose_bf16(x, Xt, B, TN, E, E, ldS, (int64_t)TN * E, (int64_t)E * ldS, st));
+    {
+      GemmDesc g;
+      g.A = P; g.B = Xt; g.C = sel;
+      g.M = k; g.N = E; g.K = (int)ldS; g.lda = ldS; g.ldb = ldS; g.ldc = E;
+      g.nz = B; g.sAb = (int64_t)k * ldS; g.sBb = (int64_t)E * ldS; g.sCb = (int64_t)k * E;
+      U2_RUN(gemm_bf16(g, st));
+    }
+    ar.off = mark;
+  } else {
+    // TokenSelection (svr.py:75-91): hard top-k over the flattened (t n) axis, sorted by score
+    const size_t mark = ar.off;
+    float* scores = ar.get<float>((size_t)rows);
+    int64_t* idx = topk_idx_out ? topk_idx_out : ar.get<int64_t>((size_t)B * k);
+    U2_CHECK_WS(ar);
+    U2_RUN(score_gemv(x, wp(i_sel), wp(i_sel + 1), scores, (int)rows, E, st));
+    U2_RUN(topk_sorted(scores, idx, B, TN, k, st));
+    U2_RUN(gather_rows(x, idx, sel, B, TN, k, E, st));
+    ar.off = mark;
+  }
+
+  // ---------------- multi-scale pooling (svr.py:173-184)
+  const bf16_t* V = sel;
+  int Lv = k;
+  if (c.use_multi_scale) {
+    Lv = k + k / 2 + k / 4;
+    bf16_t* pooled = ar.get<bf16_t>((size_t)B * Lv * E);
+    float* gws = ar.get<float>((size_t)B * 3 * cdiv(E, 256));
+    U2_CHECK_WS(ar);
+    U2_RUN(multiscale_pool(sel, pooled, B, k, E, c.enable_dmtp ? wp(i_gate) : nullptr,
+                           c.enable_dmtp ? wp(i_gate + 1) : nullptr, gws, st));
+    V = pooled;
+  }
+
+  // ---------------- TTA: TextConditionTokenAggregatorModel (tta.py:126-140)
+  const int64_t qrows = (int64_t)B * Q;
+  bf16_t* qa = ar.get<bf16_t>((size_t)qrows * E);
+  bf16_t* qb = ar.get<bf16_t>((size_t)qrows * E);
+  bf16_t* qc = ar.get<bf16_t>((size_t)qrows * E);
+  bf16_t* qproj = ar.get<bf16_t>((size_t)qrows * 3 * E);
+  bf16_t* qctx = ar.get<bf16_t>((size_t)qrows * E);
+  bf16_t* qo = ar.get<bf16_t>((size_t)qrows * E);
+  const int Lmax = Lv > c.Lt ? Lv : c.Lt;
+  bf16_t* kv = ar.get<bf16_t>((size_t)B * Lmax * 2 * E);
+  U2_CHECK_WS(ar);
+  U2_RUN(fill_rows(wp(0), qa, B, (int64_t)Q * E, (int64_t)Q * E, st));  // query_tokens.expand(B,-1,-1)
+  bf16_t* qcur = qa;
+  auto cross = [&](const Att& a, const bf16_t* src, int Ls, const bf16_t* qin, bf16_t* dst) -> int {
+    // MultiHeadCrossAttention.forward (tta.py:42-69), is_compress = False
+    U2_RUN(linear(qin, E, a.wq, a.bq, qproj, E, qrows, E, E, 0, nullptr, 0, st));
+    U2_RUN(linear(src, E, a.wk, a.bk, kv, 2 * E, (int64_t)B * Ls, E, E, 0, nullptr, 0, st));
+    U2_RUN(linear(src, E, a.wv, a.bv, kv + E, 2 * E, (int64_t)B * Ls, E, E, 0, nullptr, 0, st));
+    AttnCore ac{qproj, kv, kv + E, E, 2 * E, 2 * E, (int64_t)Q * E, (int64_t)Ls * 2 * E, (int64_t)Ls * 2 * E,
+                qctx, E, (int64_t)Q * E, B, Q, Ls, H, d, scale, nullptr, 0};
+    const int e = attention_core(ar, ac, dry, st);
+    if (e != U2_OK) return e;
+    U2_RUN(linear(qctx, E, a.wd, a.bd, dst, E, qrows, E, E, 0, nullptr, 0, st));
+    return U2_OK;
+  };
+  for (int l = 0; l < L; ++l) {
+    const int base = i_tta + 33 * l;
+    const Att sa = att_at(base);
+    Att va = att_at(base + 9), ta = att_at(base + 18);
+    va.rb = ta.rb = nullptr;
+    const bf16_t *ns_w = wp(base + 27), *ns_b = wp(base + 28), *nv_w = wp(base + 29), *nv_b = wp(base + 30),
+                 *nt_w = wp(base + 31), *nt_b = wp(base + 32);
+    bf16_t* s1 = (qcur == qa) ? qb : qa;
+    bf16_t* s2 = qc;
+    // self attention on the query tokens + post-LN residual (tta.py:94-96)
+    U2_RUN(linear(qcur, E, sa.wq, sa.bq, qproj, 3 * E, qrows, E, E, 0, nullptr, 0, st));
+    U2_RUN(linear(qcur, E, sa.wk, sa.bk, qproj + E, 3 * E, qrows, E, E, 0, nullptr, 0, st));
+    U2_RUN(linear(qcur, E, sa.wv, sa.bv, qproj + 2 * E, 3 * E, qrows, E, E, 0, nullptr, 0, st));
+    if (c.attn_type == 1) {
+      U2_RUN(rope_apply(qproj, B, Q, 1, H, d, 3 * E, c.max_seq_len, st));
+      U2_RUN(rope_apply(qproj + E, B, Q, 1, H, d, 3 * E, c.max_seq_len, st));
+    }
+    {
+      AttnCore ac{qproj, qproj + E, qproj + 2 * E, 3 * E, 3 * E, 3 * E, (int64_t)Q * 3 * E, (int64_t)Q * 3 * E,
+                  (int64_t)Q * 3 * E, qctx, E, (int64_t)Q * E, B, Q, Q, H, d, scale, sa.rb, c.max_seq_len};
+      const int e = attention_core(ar, ac, dry, st);
+      if (e != U2_OK) return e;
+    }
+    U2_RUN(linear(qctx, E, sa.wd, sa.bd, qo, E, qrows, E, E, 0, nullptr, 0, st));
+    U2_RUN(layernorm_bf16(qcur, qo, ns_w, ns_b, s1, 1, (int)qrows, E, 0, E, 0, E, 0, E, c.ln_eps, st));
+    // visual cross attention (tta.py:97-100)
+    { const int e = cross(va, V, Lv, s1, qo); if (e != U2_OK) return e; }
+    U2_RUN(layernorm_bf16(s1, qo, nv_w, nv_b, s2, 1, (int)qrows, E, 0, E, 0, E, 0, E, c.ln_eps, st));
+    // text cross attention (tta.py:101-103) -- no padding mask in the reference
+    { const int e = cross(ta, t_token, c.Lt, s2, qo); if (e != U2_OK) return e; }
+    U2_RUN(layernorm_bf16(s2, qo, nt_w, nt_b, s1, 1, (int)qrows, E, 0, E, 0, E, 0, E, c.ln_eps, st));
+    qcur = s1;
+  }
+  // ---------------- LinearAggregation (tta.py:109-116): is_compress=True -> V un-projected, no out-proj
+  {
+    const Att la = att_at(i_lin);
+    U2_RUN(linear(qcur, E, la.wq, la.bq, qproj, E, qrows, E, E, 0, nullptr, 0, st));
+    U2_RUN(linear(V, E, la.wk, la.bk, kv, E, (int64_t)B * Lv, E, E, 0, nullptr, 0, st));
+    AttnCore ac{qproj, kv, V, E, E, E, (int64_t)Q * E, (int64_t)Lv * E, (int64_t)Lv * E,
+                out, E, (int64_t)Q * E, B, Q, Lv, H, d, scale, nullptr, 0};
+    const int e = attention_core(ar, ac, dry, st);
+    if (e != U2_OK) return e;
+  }
+  if (peak) *peak = ar.peak;
+  U2_CHECK_WS(ar);
+  return U2_OK;
+}
+
+}  // namespace u2

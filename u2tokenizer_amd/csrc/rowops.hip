@@ -1,0 +1,179 @@
+// HBM-bound row kernels: LayerNorm(+residual), row softmax (+scale, +Toeplitz relative bias), bf16
+// transpose.  One wave64 per row, 16-byte vector accesses, fp32 arithmetic.
+#include "kernels.h"
+
+namespace u2 {
+
+// ---------------------------------------------------------------- LayerNorm
+// Reference: nn.LayerNorm(hidden) in MONAI TransformerBlock norm1/norm2, ViT.norm (vit.py:107,124) and
+// TextConditionTokenAttMap.norm_self/norm_cross_v/norm_cross_t (tta.py:78-79,88,96,100,103) where the
+// residual sum is formed first: LN(q + attn(q)).
+template <int NC>  // chunks (8 bf16) per lane held in registers: C <= NC * 512
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res,
+                                                        const bf16_t* __restrict__ w, const bf16_t* __restrict__ bias,
+                                                        bf16_t* __restrict__ y, int nb, int rows, int C,
+                                                        int64_t x_bs, int64_t x_ld, int64_t res_bs, int64_t res_ld,
+                                                        int64_t y_bs, int64_t y_ld, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)nb * rows) return;
+  const int b = (int)(row / rows), r = (int)(row - (int64_t)b * rows);
+  const bf16_t* xp = x + b * x_bs + r * x_ld;
+  const bf16_t* rp = res ? res + b * res_bs + r * res_ld : nullptr;
+  bf16_t* yp = y + b * y_bs + r * y_ld;
+  const int nchunk = C >> 3;
+  float v[NC][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = i * 64 + lane;
+    if (c < nchunk) {
+      const uint4 u = *reinterpret_cast<const uint4*>(xp + c * 8);
+      v[i][0] = bf16lo(u.x); v[i][1] = bf16hi(u.x); v[i][2] = bf16lo(u.y); v[i][3] = bf16hi(u.y);
+      v[i][4] = bf16lo(u.z); v[i][5] = bf16hi(u.z); v[i][6] = bf16lo(u.w); v[i][7] = bf16hi(u.w);
+      if (rp) {
+        const uint4 q = *reinterpret_cast<const uint4*>(rp + c * 8);
+        v[i][0] += bf16lo(q.x); v[i][1] += bf16hi(q.x); v[i][2] += bf16lo(q.y); v[i][3] += bf16hi(q.y);
+        v[i][4] += bf16lo(q.z); v[i][5] += bf16hi(q.z); v[i][6] += bf16lo(q.w); v[i][7] += bf16hi(q.w);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += v[i][j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    if (i * 64 + lane < nchunk) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float dlt = v[i][j] - mean; sq += dlt * dlt; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = i * 64 + lane;
+    if (c < nchunk) {
+      const uint4 uw = *reinterpret_cast<const uint4*>(w + c * 8);
+      const uint4 ub = *reinterpret_cast<const uint4*>(bias + c * 8);
+      float o[8];
+      o[0] = (v[i][0] - mean) * rstd * bf16lo(uw.x) + bf16lo(ub.x);
+      o[1] = (v[i][1] - mean) * rstd * bf16hi(uw.x) + bf16hi(ub.x);
+      o[2] = (v[i][2] - mean) * rstd * bf16lo(uw.y) + bf16lo(ub.y);
+      o[3] = (v[i][3] - mean) * rstd * bf16hi(uw.y) + bf16hi(ub.y);
+      o[4] = (v[i][4] - mean) * rstd * bf16lo(uw.z) + bf16lo(ub.z);
+      o[5] = (v[i][5] - mean) * rstd * bf16hi(uw.z) + bf16hi(ub.z);
+      o[6] = (v[i][6] - mean) * rstd * bf16lo(uw.w) + bf16lo(ub.w);
+      o[7] = (v[i][7] - mean) * rstd * bf16hi(uw.w) + bf16hi(ub.w);
+      *reinterpret_cast<uint4*>(yp + c * 8) =
+          uint4{pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]), pack2_bf16(o[4], o[5]), pack2_bf16(o[6], o[7])};
+    }
+  }
+}
+
+int layernorm_bf16(const bf16_t* x, const bf16_t* res, const bf16_t* w, const bf16_t* bias, bf16_t* y,
+                   int nb, int rows, int C, int64_t x_bs, int64_t x_ld, int64_t res_bs, int64_t res_ld,
+                   int64_t y_bs, int64_t y_ld, float eps, hipStream_t stream) {
+  if (!x || !w || !bias || !y || nb <= 0 || rows <= 0 || C <= 0) return U2_ERR_ARG;
+  if ((C & 7) || (x_ld & 7) || (y_ld & 7) || (x_bs & 7) || (y_bs & 7) || C > 8192) return U2_ERR_ARG;
+  if (res && ((res_ld & 7) || (res_bs & 7))) return U2_ERR_ARG;
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)res) & 15) return U2_ERR_ARG;
+  const int64_t total = (int64_t)nb * rows;
+  dim3 grid((unsigned)cdiv(total, 4));
+#define U2_LN(NC)                                                                                          \
+  hipLaunchKernelGGL((layernorm_kernel<NC>), grid, dim3(256), 0, stream, x, res, w, bias, y, nb, rows, C,  \
+                     x_bs, x_ld, res_bs, res_ld, y_bs, y_ld, eps)
+  if (C <= 1024) U2_LN(2);
+  else if (C <= 2048) U2_LN(4);
+  else if (C <= 4096) U2_LN(8);
+  else U2_LN(16);
+#undef U2_LN
+  return launch_status();
+}
+
+// ---------------------------------------------------------------- row softmax
+// Reference: rma.py:60-72 (scores / sqrt(depth) + relative_bias[j - i + max_len - 1][head], softmax(-1)),
+// tta.py:55-57 (no bias), svr.py:108 (DiffTS softmax over tokens with temperature).
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, bf16_t* __restrict__ P,
+                                                           int nz, int rows, int n, int64_t lds_, int64_t ldp,
+                                                           int64_t s_zs, int64_t p_zs, float scale,
+                                                           const bf16_t* __restrict__ rel_bias, int H, int max_len) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)nz * rows) return;
+  const int z = (int)(row / rows), r = (int)(row - (int64_t)z * rows);
+  const float* sp = S + z * s_zs + r * lds_;
+  bf16_t* pp = P + z * p_zs + r * ldp;
+  const bf16_t* bp = rel_bias ? rel_bias + (int64_t)(max_len - 1 - r) * H + (z % H) : nullptr;
+  float m = -INFINITY;
+  for (int c = lane; c < n; c += 64) {
+    float s = sp[c] * scale;
+    if (bp) s += bf16_to_f32(bp[(int64_t)c * H]);
+    m = fmaxf(m, s);
+  }
+  m = wave_max(m);
+  float sum = 0.f;
+  for (int c = lane; c < n; c += 64) {
+    float s = sp[c] * scale;
+    if (bp) s += bf16_to_f32(bp[(int64_t)c * H]);
+    sum += __expf(s - m);
+  }
+  const float inv = 1.f / wave_sum(sum);
+  for (int c = lane; c < (int)ldp; c += 64) {
+    float p = 0.f;
+    if (c < n) {
+      float s = sp[c] * scale;
+      if (bp) s += bf16_to_f32(bp[(int64_t)c * H]);
+      p = __expf(s - m) * inv;
+    }
+    pp[c] = f32_to_bf16(p);
+  }
+}
+
+int softmax_rows(const float* S, bf16_t* P, int nz, int rows, int n, int64_t lds_, int64_t ldp, int64_t s_zs,
+                 int64_t p_zs, float scale, const bf16_t* rel_bias, int H, int max_len, hipStream_t stream) {
+  if (!S || !P || nz <= 0 || rows <= 0 || n <= 0 || ldp < n || lds_ < n) return U2_ERR_ARG;
+  if (rel_bias && (H <= 0 || n > max_len || rows > max_len)) return U2_ERR_ARG;  // rma.py: seq_len <= max_seq_len
+  const int64_t total = (int64_t)nz * rows;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)cdiv(total, 4)), dim3(256), 0, stream, S, P, nz, rows, n,
+                     lds_, ldp, s_zs, p_zs, scale, rel_bias, H > 0 ? H : 1, max_len);
+  return launch_status();
+}
+
+// ---------------------------------------------------------------- transpose
+// 64x64 bf16 tiles through LDS (padded rows -> conflict-free column reads), coalesced both sides.
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int R,
+                                                        int C, int64_t ld_in, int64_t ld_out, int64_t in_zs,
+                                                        int64_t out_zs) {
+  __shared__ bf16_t tile[64][66];
+  const int z = blockIdx.z;
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const bf16_t* ip = in + z * in_zs;
+  bf16_t* op = out + z * out_zs;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + ty + i * 4, c = c0 + tx;
+    tile[ty + i * 4][tx] = (r < R && c < C) ? ip[(int64_t)r * ld_in + c] : (bf16_t)0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty + i * 4, r = r0 + tx;
+    if (c < C && r < ld_out) op[(int64_t)c * ld_out + r] = tile[tx][ty + i * 4];
+  }
+}
+
+int transpose_bf16(const bf16_t* in, bf16_t* out, int nz, int R, int C, int64_t ld_in, int64_t ld_out,
+                   int64_t in_zs, int64_t out_zs, hipStream_t stream) {
+  if (!in || !out || nz <= 0 || nz > 65535 || R <= 0 || C <= 0 || ld_in < C || ld_out < R) return U2_ERR_ARG;
+  dim3 grid((unsigned)cdiv(ld_out, 64), (unsigned)cdiv(C, 64), nz);
+  if (grid.y > 65535) return U2_ERR_ARG;
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, in, out, R, C, ld_in, ld_out, in_zs, out_zs);
+  return launch_status();
+}
+
+}  // namespace u2

@@ -1,0 +1,221 @@
+// Token selection and multi-scale pooling of SpatioTemporalVisualTokenRefinerModel (svr.py:153-188):
+// hard top-k (TokenSelection, svr.py:64-91) with exactly reproducible scores and a canonical tie rule,
+// row gather, and the {1,2,4} average pooling with optional DynamicMultiScalePooling gates
+// (svr.py:119-151, 173-184).
+#include "kernels.h"
+
+namespace u2 {
+
+// ---------------------------------------------------------------- score GEMV (E -> 1)
+// score_net = nn.Linear(E, 1) (svr.py:67,78).  The top-k ORDER is an integer output of the path, so the
+// scores must not depend on summation order: bf16 x bf16 products are exact in fp64 and the fp64 sum of
+// E of them is (to ~2^-50) exact, hence the single rounding to fp32 is reproducible by any oracle that
+// also sums in fp64.
+__global__ __launch_bounds__(256) void score_gemv_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                         const bf16_t* __restrict__ bias, float* __restrict__ scores,
+                                                         int rows, int E) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xp = x + row * E;
+  double acc = 0.0;
+  for (int c = lane; c < (E >> 3); c += 64) {
+    const uint4 a = *reinterpret_cast<const uint4*>(xp + c * 8);
+    const uint4 b = *reinterpret_cast<const uint4*>(w + c * 8);
+    acc += (double)bf16lo(a.x) * (double)bf16lo(b.x);
+    acc += (double)bf16hi(a.x) * (double)bf16hi(b.x);
+    acc += (double)bf16lo(a.y) * (double)bf16lo(b.y);
+    acc += (double)bf16hi(a.y) * (double)bf16hi(b.y);
+    acc += (double)bf16lo(a.z) * (double)bf16lo(b.z);
+    acc += (double)bf16hi(a.z) * (double)bf16hi(b.z);
+    acc += (double)bf16lo(a.w) * (double)bf16lo(b.w);
+    acc += (double)bf16hi(a.w) * (double)bf16hi(b.w);
+  }
+  acc = wave_sum_f64(acc);
+  if (lane == 0) scores[row] = (float)(acc + (bias ? (double)bf16_to_f32(bias[0]) : 0.0));
+}
+
+int score_gemv(const bf16_t* x, const bf16_t* w, const bf16_t* bias, float* scores, int rows, int E,
+               hipStream_t stream) {
+  if (!x || !w || !scores || rows <= 0 || E <= 0 || (E & 7)) return U2_ERR_ARG;
+  if (((uintptr_t)x | (uintptr_t)w) & 15) return U2_ERR_ARG;
+  hipLaunchKernelGGL(score_gemv_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, stream, x, w, bias, scores, rows,
+                     E);
+  return launch_status();
+}
+
+// ---------------------------------------------------------------- top-k, sorted, canonical ties
+// torch.topk(scores, k, dim=1) (svr.py:82) returns values sorted descending; its order among EQUAL
+// scores is unspecified.  Canonical rule here (and in oracle/): descending score, ties by ascending
+// index (== torch.sort(stable=True, descending=True)); -0.0 == +0.0.  One workgroup bitonic-sorts the
+// 64-bit keys (orderable score bits << 32 | ~index) of one batch row in LDS.
+__device__ __forceinline__ uint64_t topk_key(float f, uint32_t idx) {
+  if (f == 0.f) f = 0.f;  // -0.0 -> +0.0
+  uint32_t u = __float_as_uint(f);
+  u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;
+  return ((uint64_t)u << 32) | (uint64_t)(0xffffffffu - idx);
+}
+
+__global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ scores, int64_t* __restrict__ idx, int n,
+                                                    int k, int np2) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+  const int b = blockIdx.x;
+  const float* sp = scores + (int64_t)b * n;
+  for (int i = threadIdx.x; i < np2; i += blockDim.x) keys[i] = i < n ? topk_key(sp[i], (uint32_t)i) : 0ull;
+  __syncthreads();
+  for (int size = 2; size <= np2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < (np2 >> 1); t += blockDim.x) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool desc = ((lo & size) == 0);  // final pass (size == np2): every pair sorts descending
+        const uint64_t a = keys[lo], c = keys[hi];
+        if ((a < c) == desc) { keys[lo] = c; keys[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < k; i += blockDim.x)
+    idx[(int64_t)b * k + i] = (int64_t)(0xffffffffu - (uint32_t)(keys[i] & 0xffffffffull));
+}
+
+int topk_sorted(const float* scores, int64_t* idx, int B, int n, int k, hipStream_t stream) {
+  if (!scores || !idx || B <= 0 || n <= 0 || k <= 0 || k > n || n > 8192) return U2_ERR_ARG;
+  int np2 = 2;
+  while (np2 < n) np2 <<= 1;
+  const int threads = np2 / 2 < 1024 ? (np2 / 2 < 64 ? 64 : np2 / 2) : 1024;
+  hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(threads), (size_t)np2 * 8, stream, scores, idx, n, k, np2);
+  return launch_status();
+}
+
+// ---------------------------------------------------------------- gather
+// topk_tokens = x[arange(b)[:, None], idx // n, idx % n]  (svr.py:85-89) == rows of the flattened (t n) axis.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ x, const int64_t* __restrict__ idx,
+                                                          bf16_t* __restrict__ out, int B, int n, int k, int E) {
+  const int e8n = E >> 3;
+  const int64_t total = (int64_t)B * k * e8n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int e8 = (int)(i % e8n);
+    const int64_t bk = i / e8n;
+    const int b = (int)(bk / k);
+    int64_t src = idx[bk];
+    src = src < 0 ? 0 : (src >= n ? n - 1 : src);
+    *reinterpret_cast<uint4*>(out + bk * E + e8 * 8) =
+        *reinterpret_cast<const uint4*>(x + ((int64_t)b * n + src) * E + e8 * 8);
+  }
+}
+
+int gather_rows(const bf16_t* x, const int64_t* idx, bf16_t* out, int B, int n, int k, int E, hipStream_t stream) {
+  if (!x || !idx || !out || B <= 0 || n <= 0 || k <= 0 || (E & 7)) return U2_ERR_ARG;
+  if (((uintptr_t)x | (uintptr_t)out) & 15) return U2_ERR_ARG;
+  const int64_t total = (int64_t)B * k * (E >> 3);
+  const unsigned blocks = (unsigned)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, stream, x, idx, out, B, n, k, E);
+  return launch_status();
+}
+
+// ---------------------------------------------------------------- multi-scale pooling (+ DMTP gates)
+// gate_s = gate_fc(mean_tokens(avg_pool1d(x, s)))  (svr.py:133-138).  The token mean of the pooled block
+// equals the mean of the first floor(k/s)*s tokens, accumulated here in fp32 per column.
+// ws[(b*3 + s)*ncg + cg] = sum over the 256 columns of group cg of colmean_s[e] * gate_w[e].
+__global__ __launch_bounds__(256) void dmtp_gate_partial_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gate_w,
+                                                                float* __restrict__ ws, int k, int E, int ncg) {
+  __shared__ float red[3][4];
+  const int b = blockIdx.y, cg = blockIdx.x;
+  const int e = cg * 256 + threadIdx.x;
+  const int lim2 = (k / 2) * 2, lim4 = (k / 4) * 4;
+  float s1 = 0.f, s2 = 0.f, s4 = 0.f;
+  if (e < E) {
+    const bf16_t* xp = x + (int64_t)b * k * E + e;
+    for (int t = 0; t < k; ++t) {
+      const float v = bf16_to_f32(xp[(int64_t)t * E]);
+      s1 += v;
+      if (t < lim2) s2 += v;
+      if (t < lim4) s4 += v;
+    }
+    const float gw = bf16_to_f32(gate_w[e]);
+    s1 = s1 / (float)k * gw;
+    s2 = lim2 ? s2 / (float)lim2 * gw : 0.f;
+    s4 = lim4 ? s4 / (float)lim4 * gw : 0.f;
+  }
+  s1 = wave_sum(s1); s2 = wave_sum(s2); s4 = wave_sum(s4);
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wv] = s1; red[1][wv] = s2; red[2][wv] = s4; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const float* r = red[threadIdx.x];
+    ws[((int64_t)b * 3 + threadIdx.x) * ncg + cg] = (r[0] + r[1]) + (r[2] + r[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void multiscale_pool_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int k,
+                                                              int E, const float* __restrict__ ws, const bf16_t* __restrict__ gate_b,
+                                                              int ncg, int use_gate) {
+  __shared__ float wsm[3];
+  const int b = blockIdx.y;
+  const int L1 = k, L2 = k / 2, L4 = k / 4;
+  const int Lout = L1 + L2 + L4;
+  if (threadIdx.x == 0) {
+    float w[3] = {1.f, 1.f, 1.f};
+    if (use_gate) {
+      float g[3];
+      const int ns = 1 + (k >= 2) + (k >= 4);
+      float m = -INFINITY;
+      for (int s = 0; s < ns; ++s) {
+        float a = 0.f;
+        for (int c = 0; c < ncg; ++c) a += ws[((int64_t)b * 3 + s) * ncg + c];
+        g[s] = a + bf16_to_f32(gate_b[0]);
+        m = fmaxf(m, g[s]);
+      }
+      float den = 0.f;
+      for (int s = 0; s < ns; ++s) { g[s] = __expf(g[s] - m); den += g[s]; }
+      for (int s = 0; s < ns; ++s) w[s] = g[s] / den;
+    }
+    wsm[0] = w[0]; wsm[1] = w[1]; wsm[2] = w[2];
+  }
+  __syncthreads();
+  const int e8n = E >> 3;
+  const int64_t total = (int64_t)Lout * e8n;
+  const bf16_t* xb = x + (int64_t)b * k * E;
+  bf16_t* ob = out + (int64_t)b * Lout * E;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int e8 = (int)(i % e8n);
+    const int j = (int)(i / e8n);
+    int s, t0, si;
+    if (j < L1) { s = 1; t0 = j; si = 0; }
+    else if (j < L1 + L2) { s = 2; t0 = (j - L1) * 2; si = 1; }
+    else { s = 4; t0 = (j - L1 - L2) * 4; si = 2; }
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int a = 0; a < s; ++a) {
+      const uint4 u = *reinterpret_cast<const uint4*>(xb + (int64_t)(t0 + a) * E + e8 * 8);
+      acc[0] += bf16lo(u.x); acc[1] += bf16hi(u.x); acc[2] += bf16lo(u.y); acc[3] += bf16hi(u.y);
+      acc[4] += bf16lo(u.z); acc[5] += bf16hi(u.z); acc[6] += bf16lo(u.w); acc[7] += bf16hi(u.w);
+    }
+    const float f = wsm[si] / (float)s;
+    *reinterpret_cast<uint4*>(ob + (int64_t)j * E + e8 * 8) =
+        uint4{pack2_bf16(acc[0] * f, acc[1] * f), pack2_bf16(acc[2] * f, acc[3] * f),
+              pack2_bf16(acc[4] * f, acc[5] * f), pack2_bf16(acc[6] * f, acc[7] * f)};
+  }
+}
+
+int multiscale_pool(const bf16_t* x, bf16_t* out, int B, int k, int E, const bf16_t* gate_w, const bf16_t* gate_b,
+                    float* ws, hipStream_t stream) {
+  if (!x || !out || B <= 0 || B > 65535 || k <= 0 || (E & 7)) return U2_ERR_ARG;
+  if (((uintptr_t)x | (uintptr_t)out) & 15) return U2_ERR_ARG;
+  const int ncg = (int)cdiv(E, 256);
+  const int use_gate = gate_w != nullptr;
+  if (use_gate) {
+    if (!gate_b || !ws) return U2_ERR_ARG;
+    hipLaunchKernelGGL(dmtp_gate_partial_kernel, dim3(ncg, B), dim3(256), 0, stream, x, gate_w, ws, k, E, ncg);
+    if (launch_status() != U2_OK) return U2_ERR_LAUNCH;
+  }
+  const int Lout = k + k / 2 + k / 4;
+  const int64_t total = (int64_t)Lout * (E >> 3);
+  const unsigned blocks = (unsigned)(cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048);
+  hipLaunchKernelGGL(multiscale_pool_kernel, dim3(blocks, B), dim3(256), 0, stream, x, out, k, E, ws, gate_b, ncg,
+                     use_gate);
+  return launch_status();
+}
+
+}  // namespace u2
