@@ -1,0 +1,34 @@
+"""Helpers shared by the CPU (oracle) and GPU (HIP vs oracle) parity tests."""
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from oracle import u2_oracle as O
+from u2tokenizer_amd import synth
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+def load_golden(name):
+    with np.load(GOLDEN / f"{name}.npz") as z:
+        return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+def tok_cfg(c) -> O.PathConfig:
+    return O.PathConfig(hidden_size=c["E"], u2t_num_heads=c["heads"], u2t_num_layers=c["layers"], u2t_top_k=c["top_k"],
+                        use_multi_scale=c["use_multi_scale"], num_3d_query_token=c["Q"], attn_type=c["attn_type"],
+                        enable_diffts=c["enable_diffts"], enable_dmtp=c["enable_dmtp"], max_seq_len=c["max_seq_len"])
+
+
+def module_sd(module, prefix, seed, dtype=torch.float32):
+    """Name-seeded synthetic state dict for `module` (keys prefixed), in `dtype`."""
+    return {prefix + k: synth.synth_tensor(prefix + k, v.shape, seed).to(dtype)
+            for k, v in module.state_dict().items() if v.is_floating_point()}
+
+
+def err_stats(a: torch.Tensor, b: torch.Tensor):
+    a, b = a.double().flatten(), b.double().flatten()
+    d = (a - b).abs()
+    return dict(max_abs=d.max().item(), mean_abs=d.mean().item(), ref_rms=b.pow(2).mean().sqrt().item(),
+                rel_rms=(d.pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-30)).item())

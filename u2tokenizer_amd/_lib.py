@@ -1,0 +1,114 @@
+"""ctypes binding of libu2tok_hip.so (C ABI: include/u2tok.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+_LIB = _PKG / "lib" / "libu2tok_hip.so"
+_lock = threading.Lock()
+_handle = None
+
+
+class LibraryNotBuilt(RuntimeError):
+    pass
+
+
+def lib_path() -> Path:
+    return _LIB
+
+
+def build(verbose: bool = False) -> Path:
+    """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", str(_PKG / "csrc"), "-j", str(os.cpu_count() or 4)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libu2tok_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    if verbose:
+        print(r.stdout[-2000:])
+    return _LIB
+
+
+class VitConfig(C.Structure):
+    _fields_ = [("nchunk", C.c_int32), ("img", C.c_int32 * 3), ("patch", C.c_int32 * 3), ("hidden", C.c_int32),
+                ("mlp_dim", C.c_int32), ("depth", C.c_int32), ("heads", C.c_int32), ("vol_dtype", C.c_int32),
+                ("keep_cls", C.c_int32), ("ln_eps", C.c_float)]
+
+
+class SppConfig(C.Structure):
+    _fields_ = [("nchunk", C.c_int32), ("grid", C.c_int32 * 3), ("pooling_size", C.c_int32),
+                ("pooling_type", C.c_int32), ("in_dim", C.c_int32), ("out_dim", C.c_int32),
+                ("layer_type", C.c_int32), ("layer_num", C.c_int32)]
+
+
+class TokConfig(C.Structure):
+    _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("N", C.c_int32), ("E", C.c_int32), ("Lt", C.c_int32),
+                ("num_heads", C.c_int32), ("num_layers", C.c_int32), ("top_k", C.c_int32), ("num_query", C.c_int32),
+                ("use_multi_scale", C.c_int32), ("attn_type", C.c_int32), ("enable_diffts", C.c_int32),
+                ("enable_dmtp", C.c_int32), ("max_seq_len", C.c_int32), ("diffts_tau", C.c_float),
+                ("ln_eps", C.c_float)]
+
+
+_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/u2tok.h declares (tests/test_abi.py checks it)
+SIGNATURES = {
+    "u2tok_version": (_i32, []),
+    "u2tok_arch": (C.c_char_p, []),
+    "u2tok_device_check": (_i32, []),
+    "u2tok_set_option": (_i32, [C.c_char_p, _i32]),
+    "u2tok_vit_workspace_bytes": (_sz, [C.POINTER(VitConfig)]),
+    "u2tok_vit_forward": (_i32, [C.POINTER(VitConfig), C.POINTER(_vp), _vp, _vp, _vp, _sz, _vp]),
+    "u2tok_spp_workspace_bytes": (_sz, [C.POINTER(SppConfig)]),
+    "u2tok_spp_forward": (_i32, [C.POINTER(SppConfig), C.POINTER(_vp), _vp, _vp, _vp, _sz, _vp]),
+    "u2tok_tokenizer_workspace_bytes": (_sz, [C.POINTER(TokConfig)]),
+    "u2tok_tokenizer_forward": (_i32, [C.POINTER(TokConfig), C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "u2tok_embed_splice": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _vp]),
+    "u2tok_gemm_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _i32,
+                               _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _i32, _vp]),
+    "u2tok_layernorm_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
+    "u2tok_softmax_rows": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _f32, _vp, _i32, _i32, _vp]),
+    "u2tok_transpose_bf16": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _vp]),
+    "u2tok_im2col_patches": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "u2tok_avgpool3d_tokens": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "u2tok_score_gemv": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "u2tok_topk_sorted": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "u2tok_gather_rows": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "u2tok_multiscale_pool": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "u2tok_temporal_attention": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _f32, _vp,
+                                        _i32, _vp]),
+    "u2tok_flash_attention_d64": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _f32,
+                                         _vp]),
+    "u2tok_rope_apply": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i64, _i32, _vp]),
+}
+
+ERRORS = {-1: "U2TOK_ERR_ARG (bad dimension / null pointer / unsupported combination)",
+          -2: "U2TOK_ERR_LAUNCH (kernel launch failed)",
+          -3: "U2TOK_ERR_WORKSPACE (workspace too small)",
+          -4: "U2TOK_ERR_DEVICE (current device is not gfx950)"}
+
+
+def load_library() -> C.CDLL:
+    """Load libu2tok_hip.so; raises LibraryNotBuilt when it is absent (never falls back to anything)."""
+    global _handle
+    with _lock:
+        if _handle is not None:
+            return _handle
+        if not _LIB.exists():
+            raise LibraryNotBuilt(
+                f"{_LIB} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C {_PKG / 'csrc'}`. There is no CPU fallback for the u2Tokenizer HIP path.")
+        h = C.CDLL(str(_LIB))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)  # AttributeError here == header/library drift
+            fn.restype, fn.argtypes = res, args
+        _handle = h
+        return h
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        raise RuntimeError(f"{what} failed: {ERRORS.get(status, status)}")

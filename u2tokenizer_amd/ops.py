@@ -1,0 +1,253 @@
+"""Tensor-level wrappers over the C ABI (include/u2tok.h).  PyTorch supplies device memory and the HIP
+stream only; every computation below happens in libu2tok_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+GEMM_BIAS_N, GEMM_BIAS_M, GEMM_GELU, GEMM_RESIDUAL, GEMM_OUT_F32 = 1, 2, 4, 8, 16
+_VOL_DTYPE = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _need(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor (the u2tok HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t
+
+
+def set_option(name: str, value: int) -> None:
+    _lib.check(_lib.load_library().u2tok_set_option(name.encode(), int(value)), f"u2tok_set_option({name})")
+
+
+def device_check() -> None:
+    _lib.check(_lib.load_library().u2tok_device_check(), "u2tok_device_check")
+
+
+def vol_dtype_code(dtype) -> int:
+    if dtype not in _VOL_DTYPE:
+        raise RuntimeError(f"unsupported voxel dtype {dtype} (fp16 / bf16 / fp32)")
+    return _VOL_DTYPE[dtype]
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, bias_m=False, gelu=False, out_f32=False,
+         alpha=1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C = epi(alpha * A B^T) for A (..., M, K), B (N, K) or batched (Z, N, K)."""
+    h = _lib.load_library()
+    _need(a, torch.bfloat16, "A"), _need(b, torch.bfloat16, "B")
+    a3 = a.reshape(-1, a.shape[-2], a.shape[-1]) if b.dim() == 3 else a.reshape(1, -1, a.shape[-1])
+    a3 = a3.contiguous()
+    b = b.contiguous()
+    Z, M, K = a3.shape
+    N = b.shape[-2]
+    assert b.shape[-1] == K
+    if out is None:
+        out = torch.empty((Z, M, N), dtype=torch.float32 if out_f32 else torch.bfloat16, device=a.device)
+    flags = (GEMM_OUT_F32 if out_f32 else 0) | (GEMM_GELU if gelu else 0)
+    if bias is not None:
+        flags |= GEMM_BIAS_M if bias_m else GEMM_BIAS_N
+    if residual is not None:
+        flags |= GEMM_RESIDUAL
+        residual = residual.contiguous()
+    sB = N * K if b.dim() == 3 else 0
+    st = h.u2tok_gemm_bf16(_ptr(a3), _ptr(b), _ptr(out), _ptr(bias), _ptr(residual), M, N, K, K, K, N, N, Z, 1,
+                           M * K, 0, sB, 0, M * N, 0, M * N if residual is not None else 0, 0, float(alpha), flags,
+                           _stream())
+    _lib.check(st, "u2tok_gemm_bf16")
+    return out.reshape(*a.shape[:-1], N) if b.dim() == 2 else out
+
+
+def layernorm(x, w, b, residual=None, eps=1e-5):
+    h = _lib.load_library()
+    x = _need(x, torch.bfloat16, "x").contiguous()
+    y = torch.empty_like(x)
+    rows = x.numel() // x.shape[-1]
+    if residual is not None:
+        residual = residual.contiguous()
+    _lib.check(h.u2tok_layernorm_bf16(_ptr(x), _ptr(residual), _ptr(w), _ptr(b), _ptr(y), rows, x.shape[-1],
+                                      float(eps), _stream()), "u2tok_layernorm_bf16")
+    return y
+
+
+def softmax_rows(s: torch.Tensor, scale=1.0, rel_bias=None, heads=1, max_len=0, ldp=None):
+    """s: (Z, R, n) fp32 -> (Z, R, ldp) bf16 (columns >= n are zero)."""
+    h = _lib.load_library()
+    s = _need(s, torch.float32, "S").contiguous()
+    Z, R, n = s.shape
+    ldp = ldp or (n + 7) // 8 * 8
+    p = torch.empty((Z, R, ldp), dtype=torch.bfloat16, device=s.device)
+    _lib.check(h.u2tok_softmax_rows(_ptr(s), _ptr(p), Z, R, n, n, ldp, float(scale), _ptr(rel_bias), heads, max_len,
+                                    _stream()), "u2tok_softmax_rows")
+    return p
+
+
+def transpose(x: torch.Tensor, ld_out=None):
+    """x: (Z, R, C) bf16 -> (Z, C, ld_out) with zero padding."""
+    h = _lib.load_library()
+    x = _need(x, torch.bfloat16, "x").contiguous()
+    Z, R, Cc = x.shape
+    ld_out = ld_out or R
+    y = torch.empty((Z, Cc, ld_out), dtype=torch.bfloat16, device=x.device)
+    _lib.check(h.u2tok_transpose_bf16(_ptr(x), _ptr(y), Z, R, Cc, Cc, ld_out, R * Cc, Cc * ld_out, _stream()),
+               "u2tok_transpose_bf16")
+    return y
+
+
+def im2col(vol: torch.Tensor, patch):
+    h = _lib.load_library()
+    vol = vol.contiguous()
+    nchunk = vol.shape[0]
+    D, H, W = vol.shape[-3:]
+    p1, p2, p3 = patch
+    ntok = (D // p1) * (H // p2) * (W // p3)
+    out = torch.empty((nchunk, ntok, p1 * p2 * p3), dtype=torch.bfloat16, device=vol.device)
+    _lib.check(h.u2tok_im2col_patches(_ptr(vol), vol_dtype_code(vol.dtype), _ptr(out), nchunk, D, H, W, p1, p2, p3,
+                                      _stream()), "u2tok_im2col_patches")
+    return out
+
+
+def avgpool3d_tokens(x: torch.Tensor, grid, window):
+    h = _lib.load_library()
+    x = _need(x, torch.bfloat16, "x").contiguous()
+    nb, _, Cc = x.shape
+    g1, g2, g3 = grid
+    w1, w2, w3 = window
+    y = torch.empty((nb, (g1 // w1) * (g2 // w2) * (g3 // w3), Cc), dtype=torch.bfloat16, device=x.device)
+    _lib.check(h.u2tok_avgpool3d_tokens(_ptr(x), _ptr(y), nb, g1, g2, g3, w1, w2, w3, Cc, _stream()),
+               "u2tok_avgpool3d_tokens")
+    return y
+
+
+def embed_splice(table: torch.Tensor, ids: torch.Tensor, feats: Optional[torch.Tensor] = None):
+    """embed_tokens(ids) with feats (B, nfeat, E) spliced over positions 1..nfeat (u2_arch.py:109,113-116)."""
+    h = _lib.load_library()
+    table = _need(table, torch.bfloat16, "embed_tokens.weight")
+    if not table.is_contiguous():
+        raise RuntimeError("embed_tokens.weight must be contiguous")
+    ids = _need(ids, torch.int64, "ids").contiguous()
+    B, S = ids.shape
+    E = table.shape[1]
+    nfeat = 0
+    if feats is not None:
+        feats = _need(feats, torch.bfloat16, "feats").contiguous()
+        nfeat = feats.shape[1]
+    out = torch.empty((B, S, E), dtype=torch.bfloat16, device=table.device)
+    _lib.check(h.u2tok_embed_splice(_ptr(table), _ptr(ids), _ptr(feats), _ptr(out), B, S, E, nfeat, table.shape[0],
+                                    _stream()), "u2tok_embed_splice")
+    return out
+
+
+def score_gemv(x, w, bias):
+    h = _lib.load_library()
+    x = _need(x, torch.bfloat16, "x").contiguous()
+    rows = x.numel() // x.shape[-1]
+    s = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+    _lib.check(h.u2tok_score_gemv(_ptr(x), _ptr(w), _ptr(bias), _ptr(s), rows, x.shape[-1], _stream()),
+               "u2tok_score_gemv")
+    return s
+
+
+def topk_sorted(scores: torch.Tensor, k: int):
+    h = _lib.load_library()
+    scores = _need(scores, torch.float32, "scores").contiguous()
+    B, n = scores.shape
+    idx = torch.empty((B, k), dtype=torch.int64, device=scores.device)
+    _lib.check(h.u2tok_topk_sorted(_ptr(scores), _ptr(idx), B, n, k, _stream()), "u2tok_topk_sorted")
+    return idx
+
+
+def gather_rows(x, idx):
+    h = _lib.load_library()
+    x = _need(x, torch.bfloat16, "x").contiguous()
+    B, n, E = x.shape
+    k = idx.shape[1]
+    out = torch.empty((B, k, E), dtype=torch.bfloat16, device=x.device)
+    _lib.check(h.u2tok_gather_rows(_ptr(x), _ptr(idx.contiguous()), _ptr(out), B, n, k, E, _stream()),
+               "u2tok_gather_rows")
+    return out
+
+
+def multiscale_pool(x, gate_w=None, gate_b=None):
+    h = _lib.load_library()
+    x = _need(x, torch.bfloat16, "x").contiguous()
+    B, k, E = x.shape
+    out = torch.empty((B, k + k // 2 + k // 4, E), dtype=torch.bfloat16, device=x.device)
+    ws = torch.empty((B * 3 * ((E + 255) // 256),), dtype=torch.float32, device=x.device)
+    _lib.check(h.u2tok_multiscale_pool(_ptr(x), _ptr(out), B, k, E, _ptr(gate_w), _ptr(gate_b), _ptr(ws), _stream()),
+               "u2tok_multiscale_pool")
+    return out
+
+
+def temporal_attention(q, k, v, B, T, N, H, scale, rel_bias=None, max_len=512):
+    """q/k/v: (B*T*N, E) rows in (b t n) order."""
+    h = _lib.load_library()
+    E = q.shape[-1]
+    out = torch.empty((B * T * N, E), dtype=torch.bfloat16, device=q.device)
+    _lib.check(h.u2tok_temporal_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, T, N, H, E // H, q.stride(0),
+                                          E, float(scale), _ptr(rel_bias), max_len, _stream()),
+               "u2tok_temporal_attention")
+    return out
+
+
+def flash_attention_d64(qkv: torch.Tensor, heads: int, scale: float):
+    """qkv: (nb, S, 3*heads*64) bf16 in MONAI SABlock column order (q | k | v)."""
+    h = _lib.load_library()
+    qkv = _need(qkv, torch.bfloat16, "qkv").contiguous()
+    nb, S, three = qkv.shape
+    Hd = three // 3
+    S_pad = (S + 63) // 64 * 64
+    vt = torch.empty((nb, Hd, S_pad), dtype=torch.bfloat16, device=qkv.device)
+    v_view = qkv[:, :, 2 * Hd:]
+    _lib.check(h.u2tok_transpose_bf16(v_view.data_ptr(), _ptr(vt), nb, S, Hd, 3 * Hd, S_pad, S * 3 * Hd, Hd * S_pad,
+                                      _stream()), "u2tok_transpose_bf16")
+    out = torch.empty((nb, S, Hd), dtype=torch.bfloat16, device=qkv.device)
+    _lib.check(h.u2tok_flash_attention_d64(qkv.data_ptr(), qkv.data_ptr() + 2 * Hd, _ptr(vt), _ptr(out), nb, S, heads,
+                                           3 * Hd, S * 3 * Hd, Hd, S * Hd, S_pad, float(scale), _stream()),
+               "u2tok_flash_attention_d64")
+    return out
+
+
+def rope_apply(x: torch.Tensor, n_outer, S, n_inner, H, d, max_len=512):
+    h = _lib.load_library()
+    _lib.check(h.u2tok_rope_apply(_ptr(x), n_outer, S, n_inner, H, d, x.stride(-2), max_len, _stream()),
+               "u2tok_rope_apply")
+    return x
+
+
+# ---------------------------------------------------------------------------------- pipelines
+class _Workspace:
+    """Grow-only uint8 HBM scratch owned by the calling module (one per module instance)."""
+
+    def __init__(self):
+        self.buf: Optional[torch.Tensor] = None
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self.buf
+
+
+def weight_table(tensors) -> "C.Array":
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        if t is None:
+            arr[i] = None
+            continue
+        if not t.is_cuda or t.dtype != torch.bfloat16 or not t.is_contiguous():
+            raise RuntimeError("u2tok HIP path needs contiguous bf16 parameters on the GPU "
+                               f"(got {t.dtype} on {t.device}); call model.to(torch.bfloat16).cuda()")
+        arr[i] = t.data_ptr()
+    return arr

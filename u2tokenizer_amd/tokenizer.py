@@ -1,0 +1,247 @@
+"""u2Tokenizer (drop-in for /root/reference/src/model/u2tokenizer/{u2Tokenizer,svr,tta,rma,rope}.py).
+
+The sub-modules keep the reference's attribute names, parameter shapes and initialisers, so state dicts are
+interchangeable (including the never-read `linear_aggregator.wv/dense`, tta.py:47-48,62-65).  They only own
+parameters: `u2Tokenizer.forward` passes their device pointers to `u2tok_tokenizer_forward`
+(include/u2tok.h), which runs SVR (spatial + temporal relative attention x L, hard or differentiable token
+selection, {1,2,4} multi-scale pooling with optional gates) and TTA (query self-attention, visual and text
+cross-attention with post-LN x L, un-projected linear aggregation) as one launch sequence.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+
+_ATTN_TYPES = {"rma": 0, "rope": 1}
+
+
+def _init_attn(m):
+    for lin in (m.wq, m.wk, m.wv, m.dense):
+        nn.init.xavier_uniform_(lin.weight)
+        if lin.bias is not None:
+            nn.init.zeros_(lin.bias)
+
+
+class RelativeMultiheadAttention(nn.Module):
+    """Parameters of rma.py:5-35 (relative bias table: (2*max_seq_len-1, heads))."""
+
+    def __init__(self, d_model, num_heads, max_seq_len=512):
+        super().__init__()
+        assert d_model % num_heads == 0
+        self.num_heads, self.d_model, self.depth, self.max_seq_len = num_heads, d_model, d_model // num_heads, max_seq_len
+        self.wq = nn.Linear(d_model, d_model)
+        self.wk = nn.Linear(d_model, d_model)
+        self.wv = nn.Linear(d_model, d_model)
+        self.dense = nn.Linear(d_model, d_model)
+        self.relative_bias = nn.Parameter(torch.zeros(2 * max_seq_len - 1, num_heads))
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        _init_attn(self)
+        nn.init.zeros_(self.relative_bias)
+
+    init_weights = _reset_parameters
+
+
+class RotaryMultiheadAttention(nn.Module):
+    """Parameters of rope.py:16-60 (cos/sin caches are non-persistent buffers there; recomputed on device here)."""
+
+    def __init__(self, d_model, num_heads, max_seq_len=512):
+        super().__init__()
+        assert d_model % num_heads == 0, "d_model must be divisible by num_heads"
+        self.num_heads, self.d_model, self.head_dim, self.max_seq_len = num_heads, d_model, d_model // num_heads, max_seq_len
+        self.wq = nn.Linear(d_model, d_model)
+        self.wk = nn.Linear(d_model, d_model)
+        self.wv = nn.Linear(d_model, d_model)
+        self.dense = nn.Linear(d_model, d_model)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        _init_attn(self)
+
+
+class MultiHeadCrossAttention(nn.Module):
+    """Parameters of tta.py:7-40."""
+
+    def __init__(self, d_model, num_heads):
+        super().__init__()
+        assert d_model % num_heads == 0
+        self.num_heads, self.d_model, self.depth = num_heads, d_model, d_model // num_heads
+        self.wq = nn.Linear(d_model, d_model)
+        self.wk = nn.Linear(d_model, d_model)
+        self.wv = nn.Linear(d_model, d_model)
+        self.dense = nn.Linear(d_model, d_model)
+        _init_attn(self)
+
+
+def _self_attention(embed_size, num_heads, attn_type):
+    if attn_type == "rma":
+        return RelativeMultiheadAttention(embed_size, num_heads)
+    if attn_type == "rope":
+        return RotaryMultiheadAttention(embed_size, num_heads)
+    raise NotImplementedError(
+        f"attn_type={attn_type!r}: the nn.MultiheadAttention ('linvt') ablation of svr.py:17-18 / tta.py:84 is "
+        "not implemented on the HIP path (supported: 'rma', 'rope')")
+
+
+class SpatioTemporalAttentionLayer(nn.Module):
+    def __init__(self, embed_size, num_heads, attn_type="rma"):
+        super().__init__()
+        self.spatial_attention = _self_attention(embed_size, num_heads, attn_type)
+        self.temporal_attention = _self_attention(embed_size, num_heads, attn_type)
+
+
+class SpatioTemporalSignificanceScoring(nn.Module):
+    def __init__(self, embed_size, num_heads, num_layers, attn_type="rma"):
+        super().__init__()
+        self.layers = nn.ModuleList(
+            [SpatioTemporalAttentionLayer(embed_size, num_heads, attn_type) for _ in range(num_layers)])
+
+
+class TokenSelection(nn.Module):
+    def __init__(self, embed_size, top_k):
+        super().__init__()
+        self.score_net = nn.Linear(embed_size, 1)
+        self.top_k = top_k
+        self.score_net.bias.data.zero_()
+
+
+class DifferentiableTokenSelection(nn.Module):
+    def __init__(self, embed_size, top_k, tau=1.0):
+        super().__init__()
+        self.score_net = nn.Linear(embed_size, top_k)
+        self.top_k = top_k
+        self.tau = tau
+
+
+class DynamicMultiScalePooling(nn.Module):
+    def __init__(self, embed_size, scales=(1, 2, 4)):
+        super().__init__()
+        if list(scales) != [1, 2, 4]:
+            raise ValueError("the HIP pooling kernel implements the reference's scales [1, 2, 4] (svr.py:120,177)")
+        self.scales = list(scales)
+        self.gate_fc = nn.Linear(embed_size, 1)
+
+
+class SpatioTemporalVisualTokenRefinerModel(nn.Module):
+    def __init__(self, embed_size, num_heads, num_layers, top_k, use_multi_scale, attn_type="rma",
+                 enable_diffts=False, enable_dmtp=False):
+        super().__init__()
+        self.attention_network = SpatioTemporalSignificanceScoring(embed_size, num_heads, num_layers, attn_type)
+        if enable_diffts:
+            self.token_selection = DifferentiableTokenSelection(embed_size, top_k)
+        else:
+            self.token_selection = TokenSelection(embed_size, top_k)
+        if enable_dmtp:
+            self.dynamic_pool = DynamicMultiScalePooling(embed_size)
+        self.enable_dmtp = enable_dmtp
+        self.use_multi_scale = use_multi_scale
+
+
+class TextConditionTokenAttMap(nn.Module):
+    def __init__(self, d_model, num_heads, attn_type="rma"):
+        super().__init__()
+        self.visual_cross_attention = MultiHeadCrossAttention(d_model, num_heads)
+        self.text_cross_attention = MultiHeadCrossAttention(d_model, num_heads)
+        self.dropout_cross = nn.Identity()
+        self.norm_cross_v = nn.LayerNorm(d_model)
+        self.norm_cross_t = nn.LayerNorm(d_model)
+        self.self_attention = _self_attention(d_model, num_heads, attn_type)
+        self.dropout_self = nn.Identity()
+        self.norm_self = nn.LayerNorm(d_model)
+
+
+class LinearAggregation(nn.Module):
+    def __init__(self, d_model, num_heads):
+        super().__init__()
+        self.linear_aggregator = MultiHeadCrossAttention(d_model, num_heads)
+
+
+class TextConditionTokenAggregatorModel(nn.Module):
+    def __init__(self, d_model, num_layers, num_heads, attn_type="rma"):
+        super().__init__()
+        self.layers_vt = nn.ModuleList([TextConditionTokenAttMap(d_model, num_heads, attn_type)
+                                        for _ in range(num_layers)])
+        self.layer_linagg = LinearAggregation(d_model, num_heads)
+
+
+def _att_ptrs(m):
+    return [m.wq.weight, m.wq.bias, m.wk.weight, m.wk.bias, m.wv.weight, m.wv.bias, m.dense.weight, m.dense.bias,
+            getattr(m, "relative_bias", None)]
+
+
+class u2Tokenizer(nn.Module):
+    """Same constructor and forward as the reference (u2Tokenizer.py:6-47)."""
+
+    def __init__(self, embed_size, num_heads, num_layers, top_k, use_multi_scale, num_3d_query_token, hidden_size,
+                 attn_type="rma", enable_diffts=False, enable_dmtp=False):
+        super().__init__()
+        if embed_size != hidden_size:
+            raise ValueError("embed_size must equal hidden_size (builder.py:5,11 pass config.hidden_size for both)")
+        self.svt_module = SpatioTemporalVisualTokenRefinerModel(
+            embed_size=embed_size, num_heads=num_heads, num_layers=num_layers, top_k=top_k,
+            use_multi_scale=use_multi_scale, attn_type=attn_type, enable_diffts=enable_diffts,
+            enable_dmtp=enable_dmtp)
+        self.tta_module = TextConditionTokenAggregatorModel(d_model=embed_size, num_layers=num_layers,
+                                                            num_heads=num_heads, attn_type=attn_type)
+        self.query_tokens = nn.Parameter(torch.zeros(1, num_3d_query_token, hidden_size))
+        self.query_tokens.data.normal_(mean=0.0, std=0.02)
+        self.embed_size, self.num_heads, self.num_layers, self.top_k = embed_size, num_heads, num_layers, top_k
+        self.use_multi_scale, self.num_query, self.attn_type = bool(use_multi_scale), num_3d_query_token, attn_type
+        self.enable_diffts, self.enable_dmtp = bool(enable_diffts), bool(enable_dmtp)
+        self._ws = ops._Workspace()
+        self.last_topk_indices = None  # (B, top_k) int64 -- set by forward() when hard top-k selection is on
+
+    def _weights(self):
+        w = [self.query_tokens]
+        for layer in self.svt_module.attention_network.layers:
+            w += _att_ptrs(layer.spatial_attention) + _att_ptrs(layer.temporal_attention)
+        sn = self.svt_module.token_selection.score_net
+        w += [sn.weight, sn.bias]
+        if self.enable_dmtp:
+            w += [self.svt_module.dynamic_pool.gate_fc.weight, self.svt_module.dynamic_pool.gate_fc.bias]
+        else:
+            w += [None, None]
+        for layer in self.tta_module.layers_vt:
+            w += _att_ptrs(layer.self_attention) + _att_ptrs(layer.visual_cross_attention) \
+                + _att_ptrs(layer.text_cross_attention)
+            w += [layer.norm_self.weight, layer.norm_self.bias, layer.norm_cross_v.weight, layer.norm_cross_v.bias,
+                  layer.norm_cross_t.weight, layer.norm_cross_t.bias]
+        w += _att_ptrs(self.tta_module.layer_linagg.linear_aggregator)
+        return w
+
+    def forward(self, v_token, t_token):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("the HIP u2Tokenizer is forward-only in this round: call under torch.no_grad()")
+        h = _lib.load_library()
+        v_token = ops._need(v_token, torch.bfloat16, "v_token").contiguous()
+        t_token = ops._need(t_token, torch.bfloat16, "t_token").contiguous()
+        (B, T, N, E) = v_token.size()
+        if E != self.embed_size or t_token.shape[0] != B or t_token.shape[2] != E:
+            raise RuntimeError(f"shape mismatch: v_token {tuple(v_token.shape)}, t_token {tuple(t_token.shape)}")
+        cfg = _lib.TokConfig(B=B, T=T, N=N, E=E, Lt=t_token.shape[1], num_heads=self.num_heads,
+                             num_layers=self.num_layers, top_k=self.top_k, num_query=self.num_query,
+                             use_multi_scale=int(self.use_multi_scale), attn_type=_ATTN_TYPES[self.attn_type],
+                             enable_diffts=int(self.enable_diffts), enable_dmtp=int(self.enable_dmtp),
+                             max_seq_len=512, diffts_tau=float(getattr(self.svt_module.token_selection, "tau", 1.0)),
+                             ln_eps=1e-5)
+        table = ops.weight_table(self._weights())
+        nbytes = h.u2tok_tokenizer_workspace_bytes(C.byref(cfg))
+        if nbytes == 0:
+            raise RuntimeError("u2tok_tokenizer_workspace_bytes rejected the configuration "
+                               f"(B={B}, T={T}, N={N}, E={E}, heads={self.num_heads}, top_k={self.top_k})")
+        ws = self._ws.get(nbytes, v_token.device)
+        out = torch.empty((B, self.num_query, E), dtype=torch.bfloat16, device=v_token.device)
+        idx = None
+        if not self.enable_diffts:
+            idx = torch.empty((B, self.top_k), dtype=torch.int64, device=v_token.device)
+        _lib.check(h.u2tok_tokenizer_forward(C.byref(cfg), table, v_token.data_ptr(), t_token.data_ptr(),
+                                             out.data_ptr(), None if idx is None else idx.data_ptr(), ws.data_ptr(),
+                                             ws.numel(), torch.cuda.current_stream().cuda_stream),
+                   "u2tok_tokenizer_forward")
+        self.last_topk_indices = idx
+        return out
