@@ -37,7 +37,13 @@ int u2tok_version(void);               /* MAJOR*10000 + MINOR*100 + PATCH */
 const char* u2tok_arch(void);          /* "gfx950" */
 int u2tok_device_check(void);          /* 0 if the current HIP device is gfx950, else U2TOK_ERR_DEVICE */
 int u2tok_set_option(const char* name, int value); /* "gemm_glds" {0,1}, "gemm_tile" {0,64,128},
-                                                      "vit_flash" {0,1}; returns U2TOK_ERR_ARG if unknown */
+                                                      "vit_flash" {0,1}, "profile" {0,1};
+                                                      returns U2TOK_ERR_ARG if unknown */
+/* With option "profile" = 1 every launch is bracketed by hipEvents on its stream.  Collect (HOST arrays of ncat <= 5
+ * entries; synchronises on the recorded events, then resets): summed milliseconds, algorithmic FLOPs and launch
+ * counts per kernel class 0 = MFMA GEMM, 1 = ViT flash attention, 2 = temporal attention, 3 = row ops
+ * (LayerNorm / softmax / RoPE / scores / top-k / pooling), 4 = data movement (im2col, transposes, gathers, splice). */
+int u2tok_profile_collect(double* ms_host, double* flops_host, int64_t* count_host, int32_t ncat);
 
 /* ---- configuration records -------------------------------------------------------------------- */
 

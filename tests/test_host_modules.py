@@ -1,0 +1,90 @@
+"""CPU: host-side mirror of the reference interface -- state-dict contract, builders, error behaviour, and that
+the product path refuses to run without the HIP library / a GPU (no silent fallback)."""
+import json
+from pathlib import Path
+from types import SimpleNamespace as NS
+
+import pytest
+import torch
+
+import u2tokenizer_amd as U
+from u2tokenizer_amd import language_model as LM
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+def _cfg(**kw):
+    base = dict(vision_tower="vit3d", image_channel=1, image_size=[32, 64, 64], patch_size=[4, 16, 16],
+                vision_select_layer=-1, vision_select_feature="patch", mm_projector_type="spp", proj_layer_type="mlp",
+                proj_layer_num=2, proj_pooling_type="spatial", proj_pooling_size=2, mm_hidden_size=768,
+                hidden_size=512, enable_u2tokenizer=True, u2t_num_heads=8, u2t_num_layers=1, u2t_top_k=16,
+                use_multi_scale=True, num_3d_query_token=16, attn_type="rma", enable_diffts=True, enable_dmtp=True)
+    base.update(kw)
+    return NS(**base)
+
+
+def test_state_dict_keys_match_reference_contract():
+    """Key names and shapes recorded from the REFERENCE modules (tests/golden/state_dict_keys.json)."""
+    ref = json.loads((GOLDEN / "state_dict_keys.json").read_text())
+    c = _cfg()
+    got = {}
+    for prefix, m in (("vision_tower.", U.build_vision_tower(c)), ("mm_projector.", U.build_mm_projector(c)),
+                      ("u2tokenizer.", U.build_u2tokenizer_tower(c))):
+        got.update({prefix + k: list(v.shape) for k, v in m.state_dict().items()})
+    assert got == ref["mu2_small"]
+    c2 = _cfg(attn_type="rope", enable_diffts=False, enable_dmtp=False)
+    got = {"u2tokenizer." + k: list(v.shape) for k, v in U.build_u2tokenizer_tower(c2).state_dict().items()}
+    assert got == ref["rope_hard_small"]
+
+
+def test_builders_raise_like_the_reference():
+    with pytest.raises(ValueError, match="Unknown vision tower"):
+        U.build_vision_tower(_cfg(vision_tower="resnet"))
+    with pytest.raises(ValueError, match="Unknown projector type"):
+        U.build_mm_projector(_cfg(mm_projector_type="qformer"))
+    with pytest.raises(AssertionError):
+        U.build_u2tokenizer_tower(_cfg(hidden_size=100, u2t_num_heads=8))
+    assert U.build_mm_projector(_cfg()).proj_out_num == 16
+    assert U.build_vision_tower(_cfg()).hidden_size == 768
+
+
+def test_no_cpu_fallback():
+    tok = U.build_u2tokenizer_tower(_cfg()).bfloat16()
+    with torch.no_grad(), pytest.raises(RuntimeError, match="GPU tensor"):
+        tok(v_token=torch.zeros(1, 2, 16, 512, dtype=torch.bfloat16), t_token=torch.zeros(1, 8, 512, dtype=torch.bfloat16))
+    with torch.enable_grad(), pytest.raises(RuntimeError, match="forward-only"):
+        tok(v_token=torch.zeros(1, 2, 16, 512, dtype=torch.bfloat16), t_token=torch.zeros(1, 8, 512, dtype=torch.bfloat16))
+
+
+def test_product_never_imports_the_oracle():
+    import re
+    root = Path(U.__file__).resolve().parent
+    for f in list(root.rglob("*.py")) + list(root.rglob("*.hip")) + list(root.rglob("*.h")):
+        assert not re.search(r"^\s*(from|import)\s+oracle|u2_oracle", f.read_text(), flags=re.M), f
+
+
+def test_hf_surface_and_early_outs():
+    from cases import FULL_CASES
+    c = FULL_CASES["cfg1"]
+    cfg = LM.u2Config(**c["llama"])
+    for k, v in c["mm"].items():
+        setattr(cfg, k, v)
+    m = LM.u2LlamaForCausalLM(cfg).eval()
+    assert m.get_model().get_u2tokenizer() is not None and m.get_vision_tower() is not None
+    ids = torch.randint(0, cfg.vocab_size, (1, 12))
+    # no images -> plain LM path on CPU (u2_arch.py:101-102), same return contract
+    r = m.prepare_inputs_for_multimodal(ids, None, None, None, None, None, None)
+    assert r[0] is ids and r[4] is None
+    r = m.prepare_inputs_for_multimodal(ids[:, :1], None, None, None, None, torch.zeros(1), None)
+    assert r[0].shape[1] == 1 and r[4] is None
+    with torch.no_grad():
+        out = m(input_ids=ids)
+    assert out.logits.shape == (1, 12, cfg.vocab_size)
+    with pytest.raises(NotImplementedError):
+        m.generate(None, ids, inputs_embeds=torch.zeros(1, 2, 512))
+    from transformers import AutoConfig
+    assert isinstance(AutoConfig.for_model("u2llama"), LM.u2Config)
+    q = LM.u2Qwen3ForCausalLM(LM.u2Qwen3Config(vocab_size=64, hidden_size=64, intermediate_size=128,
+                                               num_hidden_layers=1, num_attention_heads=4, num_key_value_heads=2,
+                                               head_dim=16))
+    assert q.get_vision_tower() is None

@@ -134,6 +134,7 @@ int temporal_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t
   if (rel_bias && T > max_len) return U2_ERR_ARG;
   const int64_t ninst = (int64_t)B * N * H;
   dim3 grid((unsigned)cdiv(ninst, 4));
+  ProfScope ps(PROF_TEMPORAL, 4.0 * ninst * T * T * d, stream);
 #define U2_TA(VPL)                                                                                                   \
   hipLaunchKernelGGL((temporal_attention_kernel<VPL>), grid, dim3(256), 0, stream, q, k, v, out, B, T, N, H, ld_qkv, \
                      ld_out, scale, rel_bias, max_len)
@@ -314,6 +315,7 @@ int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16
   const int nqt = (S + 127) / 128;
   const int64_t blocks = (int64_t)nb * H * nqt;
   if (blocks > 0x7fffffff) return U2_ERR_ARG;
+  ProfScope ps(PROF_FLASH, 4.0 * nb * H * (double)S * S * 64, stream);
   hipLaunchKernelGGL(flash_d64_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, q, k, vt, out, S, H, ld_qk, q_bs,
                      ld_out, out_bs, S_pad, scale * 1.44269504088896340736f, nqt);
   return launch_status();

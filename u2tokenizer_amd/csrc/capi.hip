@@ -34,7 +34,13 @@ int u2tok_set_option(const char* name, int value) {
     return U2_OK;
   }
   if (!strcmp(name, "vit_flash")) { pipeline_set_vit_flash(value); return U2_OK; }
+  if (!strcmp(name, "profile")) { prof_enable(value != 0); return U2_OK; }
   return U2_ERR_ARG;
+}
+
+int u2tok_profile_collect(double* ms, double* flops, int64_t* count, int32_t ncat) {
+  if (!ms || !flops || !count || ncat <= 0 || ncat > PROF_NCAT) return U2_ERR_ARG;
+  return prof_collect(ms, flops, count, ncat);
 }
 
 size_t u2tok_vit_workspace_bytes(const u2tok_vit_config* cfg) {

@@ -262,6 +262,7 @@ int gemm_bf16(GemmDesc d, hipStream_t stream) {
     vec = vec && (d.ldr % 4 == 0) && (d.sRb % 4 == 0) && (d.sRh % 4 == 0) && (((uintptr_t)d.R & 7) == 0);
   d.flags = vec ? (d.flags | GEMM_VEC_OK) : (d.flags & ~GEMM_VEC_OK);
 
+  ProfScope ps(PROF_GEMM, 2.0 * d.M * d.N * d.K * d.nz, stream);
   int tile = g_gemm_force_tile;
   if (tile != 64 && tile != 128) {
     const int64_t big = cdiv(d.M, 128) * cdiv(d.N, 128) * d.nz;

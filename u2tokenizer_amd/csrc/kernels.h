@@ -5,6 +5,18 @@
 
 namespace u2 {
 
+// ------------------------------------------------------------------ profiling (prof.hip)
+enum : int { PROF_GEMM = 0, PROF_FLASH = 1, PROF_TEMPORAL = 2, PROF_ROWOP = 3, PROF_MOVE = 4, PROF_NCAT = 5 };
+void prof_enable(bool on);
+bool prof_enabled();
+int prof_collect(double* ms, double* flops, int64_t* count, int ncat);
+struct ProfScope {  // brackets one launch with hipEvents on `st` when profiling is on; free otherwise
+  ProfScope(int cat, double flops, hipStream_t st);
+  ~ProfScope();
+  int idx_;
+  hipStream_t st_;
+};
+
 // ------------------------------------------------------------------ GEMM (gemm.hip)
 enum : int {
   GEMM_BIAS_N = 1,     // + bias[n]   (nn.Linear bias)

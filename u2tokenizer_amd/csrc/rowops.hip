@@ -83,6 +83,7 @@ int layernorm_bf16(const bf16_t* x, const bf16_t* res, const bf16_t* w, const bf
   if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)res) & 15) return U2_ERR_ARG;
   const int64_t total = (int64_t)nb * rows;
   dim3 grid((unsigned)cdiv(total, 4));
+  ProfScope ps(PROF_ROWOP, 0, stream);
 #define U2_LN(NC)                                                                                          \
   hipLaunchKernelGGL((layernorm_kernel<NC>), grid, dim3(256), 0, stream, x, res, w, bias, y, nb, rows, C,  \
                      x_bs, x_ld, res_bs, res_ld, y_bs, y_ld, eps)
@@ -138,6 +139,7 @@ int softmax_rows(const float* S, bf16_t* P, int nz, int rows, int n, int64_t lds
   if (!S || !P || nz <= 0 || rows <= 0 || n <= 0 || ldp < n || lds_ < n) return U2_ERR_ARG;
   if (rel_bias && (H <= 0 || n > max_len || rows > max_len)) return U2_ERR_ARG;  // rma.py: seq_len <= max_seq_len
   const int64_t total = (int64_t)nz * rows;
+  ProfScope ps(PROF_ROWOP, 0, stream);
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)cdiv(total, 4)), dim3(256), 0, stream, S, P, nz, rows, n,
                      lds_, ldp, s_zs, p_zs, scale, rel_bias, H > 0 ? H : 1, max_len);
   return launch_status();
@@ -172,6 +174,7 @@ int transpose_bf16(const bf16_t* in, bf16_t* out, int nz, int R, int C, int64_t 
   if (!in || !out || nz <= 0 || nz > 65535 || R <= 0 || C <= 0 || ld_in < C || ld_out < R) return U2_ERR_ARG;
   dim3 grid((unsigned)cdiv(ld_out, 64), (unsigned)cdiv(C, 64), nz);
   if (grid.y > 65535) return U2_ERR_ARG;
+  ProfScope ps(PROF_MOVE, 0, stream);
   hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, in, out, R, C, ld_in, ld_out, in_zs, out_zs);
   return launch_status();
 }

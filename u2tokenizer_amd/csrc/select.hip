@@ -39,6 +39,7 @@ int score_gemv(const bf16_t* x, const bf16_t* w, const bf16_t* bias, float* scor
                hipStream_t stream) {
   if (!x || !w || !scores || rows <= 0 || E <= 0 || (E & 7)) return U2_ERR_ARG;
   if (((uintptr_t)x | (uintptr_t)w) & 15) return U2_ERR_ARG;
+  ProfScope ps(PROF_ROWOP, 0, stream);
   hipLaunchKernelGGL(score_gemv_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, stream, x, w, bias, scores, rows,
                      E);
   return launch_status();
@@ -85,6 +86,7 @@ int topk_sorted(const float* scores, int64_t* idx, int B, int n, int k, hipStrea
   int np2 = 2;
   while (np2 < n) np2 <<= 1;
   const int threads = np2 / 2 < 1024 ? (np2 / 2 < 64 ? 64 : np2 / 2) : 1024;
+  ProfScope ps(PROF_ROWOP, 0, stream);
   hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(threads), (size_t)np2 * 8, stream, scores, idx, n, k, np2);
   return launch_status();
 }
@@ -111,6 +113,7 @@ int gather_rows(const bf16_t* x, const int64_t* idx, bf16_t* out, int B, int n, 
   if (((uintptr_t)x | (uintptr_t)out) & 15) return U2_ERR_ARG;
   const int64_t total = (int64_t)B * k * (E >> 3);
   const unsigned blocks = (unsigned)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
+  ProfScope ps(PROF_MOVE, 0, stream);
   hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, stream, x, idx, out, B, n, k, E);
   return launch_status();
 }
@@ -205,6 +208,7 @@ int multiscale_pool(const bf16_t* x, bf16_t* out, int B, int k, int E, const bf1
   if (((uintptr_t)x | (uintptr_t)out) & 15) return U2_ERR_ARG;
   const int ncg = (int)cdiv(E, 256);
   const int use_gate = gate_w != nullptr;
+  ProfScope ps(PROF_ROWOP, 0, stream);
   if (use_gate) {
     if (!gate_b || !ws) return U2_ERR_ARG;
     hipLaunchKernelGGL(dmtp_gate_partial_kernel, dim3(ncg, B), dim3(256), 0, stream, x, gate_w, ws, k, E, ncg);

@@ -58,6 +58,7 @@ int im2col_patches(const void* vol, int vol_dtype, bf16_t* out, int nchunk, int 
   const size_t smem = (size_t)p1 * p2 * (W * 2 + 16);
   if (smem > 64 * 1024) return U2_ERR_ARG;
   dim3 grid((unsigned)((int64_t)nchunk * nh * nw));
+  ProfScope ps(PROF_MOVE, 0, stream);
 #define U2_IM2COL(DT) \
   hipLaunchKernelGGL((im2col_kernel<DT>), grid, dim3(256), smem, stream, vol, out, D, H, W, p1, p2, p3, nh, nw, nd)
   if (vol_dtype == VOL_F16) U2_IM2COL(VOL_F16);
@@ -106,6 +107,7 @@ int avgpool3d_tokens(const bf16_t* x, bf16_t* y, int nb, int g1, int g2, int g3,
   if (((uintptr_t)x | (uintptr_t)y) & 15) return U2_ERR_ARG;
   const int64_t total = (int64_t)nb * (g1 / w1) * (g2 / w2) * (g3 / w3) * (C >> 3);
   const unsigned blocks = (unsigned)(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096);
+  ProfScope ps(PROF_MOVE, 0, stream);
   hipLaunchKernelGGL(avgpool3d_kernel, dim3(blocks), dim3(256), 0, stream, x, y, nb, g1, g2, g3, w1, w2, w3, C);
   return launch_status();
 }
@@ -125,6 +127,7 @@ int fill_rows(const bf16_t* src, bf16_t* dst, int nb, int64_t n, int64_t dst_bs,
   if (!src || !dst || nb <= 0 || n <= 0) return U2_ERR_ARG;
   const int64_t total = (int64_t)nb * n;
   const unsigned blocks = (unsigned)(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096);
+  ProfScope ps(PROF_MOVE, 0, stream);
   hipLaunchKernelGGL(fill_rows_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, nb, n, dst_bs);
   return launch_status();
 }
@@ -157,6 +160,7 @@ int rope_apply(bf16_t* x, int64_t n_outer, int S, int n_inner, int H, int d, int
   if (!x || n_outer <= 0 || S <= 0 || n_inner <= 0 || H <= 0 || d <= 0 || (d & 1) || S > max_len) return U2_ERR_ARG;
   const int64_t total = n_outer * S * n_inner * H * (d >> 1);
   const unsigned blocks = (unsigned)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
+  ProfScope ps(PROF_ROWOP, 0, stream);
   hipLaunchKernelGGL(rope_kernel, dim3(blocks), dim3(256), 0, stream, x, n_outer, S, n_inner, H, d, ld);
   return launch_status();
 }
@@ -193,6 +197,7 @@ int embed_splice(const bf16_t* table, const int64_t* ids, const bf16_t* feats, b
   if (((uintptr_t)table | (uintptr_t)out | (uintptr_t)feats) & 15) return U2_ERR_ARG;
   const int64_t total = (int64_t)B * S * (E >> 3);
   const unsigned blocks = (unsigned)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
+  ProfScope ps(PROF_MOVE, 0, stream);
   hipLaunchKernelGGL(embed_splice_kernel, dim3(blocks), dim3(256), 0, stream, table, ids, feats, out, B, S, E, nfeat,
                      vocab);
   return launch_status();
