@@ -132,10 +132,12 @@ int u2tok_spp_forward(const u2tok_spp_config* cfg, const void* const* weights, c
 
 /* Replaces u2Tokenizer.forward (u2Tokenizer.py:40-47): v_token (B,T,N,E), t_token (B,Lt,E) bf16 ->
  * aligned tokens (B,num_query,E) bf16.  topk_idx_out (optional, may be null): (B,top_k) int64 indices chosen by
- * TokenSelection (only written when !enable_diffts) -- the path's integer output. */
+ * TokenSelection (only written when !enable_diffts) -- the path's integer output.  svr_out (optional, may be null):
+ * (B,T*N,E) bf16 copy of the refined tokens the selection stage scores (output of svr.py:166-170), so that a checker
+ * can replay the selection on identical inputs. */
 size_t u2tok_tokenizer_workspace_bytes(const u2tok_tokenizer_config* cfg);
 int u2tok_tokenizer_forward(const u2tok_tokenizer_config* cfg, const void* const* weights, const void* v_token,
-                            const void* t_token, void* out, int64_t* topk_idx_out, void* workspace,
+                            const void* t_token, void* out, int64_t* topk_idx_out, void* svr_out, void* workspace,
                             size_t workspace_bytes, u2tok_stream_t stream);
 
 /* Replaces embed_tokens(ids) + the splice of u2_arch.py:109,113-116:

@@ -1,0 +1,224 @@
+"""GPU: every HIP building block against an fp32 CPU computation of the same bf16 inputs (through the C ABI).
+
+Tolerances: a bf16 result is allowed TWO bf16 roundings of the exact value (|err| <= 2 * 2^-8 * |ref|, plus
+2^-8 of the tensor's max for values near zero); fp32 results 1e-5 of the tensor's max; integer / index /
+data-movement results are bit-exact."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import u2_oracle as O
+
+pytestmark = pytest.mark.gpu
+bf = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from u2tokenizer_amd import ops as _ops
+    _ops.device_check()
+    return _ops
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed * 7919 + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(bf)
+
+
+def close_bf16(got, ref, rounds=2):
+    got, ref = got.float().cpu(), ref.float()
+    assert torch.isfinite(got).all()
+    tol = rounds * 2.0 ** -8 * ref.abs() + 2.0 ** -8 * ref.abs().max()
+    bad = (got - ref).abs() > tol
+    assert not bad.any(), f"{bad.sum().item()} elements off; worst {(got - ref).abs().max().item():.3e}"
+
+
+def close_f32(got, ref):
+    got, ref = got.float().cpu(), ref.float()
+    assert (got - ref).abs().max() <= 1e-5 * ref.abs().max() + 1e-7
+
+
+D = "cuda"
+
+
+@pytest.mark.parametrize("glds", [0, 1])
+@pytest.mark.parametrize("tile", [64, 128])
+def test_gemm_shapes_and_epilogues(ops, glds, tile):
+    ops.set_option("gemm_glds", glds)
+    ops.set_option("gemm_tile", tile)
+    try:
+        for (M, N, K) in [(128, 128, 64), (300, 200, 136), (77, 520, 72), (1, 8, 8), (2049, 768, 768)]:
+            a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
+            close_bf16(ops.gemm(a.to(D), b.to(D)), a.float() @ b.float().t())
+        M, N, K = 300, 264, 200
+        a, b, bias, res, bm = rnd(M, K, seed=3), rnd(N, K, seed=4), rnd(N, seed=5), rnd(M, N, seed=6), rnd(M, seed=7)
+        base = a.float() @ b.float().t()
+        close_bf16(ops.gemm(a.to(D), b.to(D), bias=bias.to(D), residual=res.to(D), gelu=True),
+                   F.gelu(base + bias.float()) + res.float(), rounds=3)
+        close_f32(ops.gemm(a.to(D), b.to(D), bias=bias.to(D), out_f32=True, alpha=0.5), 0.5 * base + bias.float())
+        close_f32(ops.gemm(a.to(D), b.to(D), bias=bm.to(D), bias_m=True, out_f32=True), base + bm.float()[:, None])
+        b2, bias2 = rnd(203, K, seed=8), rnd(203, seed=9)  # N % 4 != 0 -> scalar epilogue
+        close_bf16(ops.gemm(a.to(D), b2.to(D), bias=bias2.to(D)), a.float() @ b2.float().t() + bias2.float())
+        a3, b3 = rnd(6, 100, 64, seed=10), rnd(6, 90, 64, seed=11)
+        close_f32(ops.gemm(a3.to(D), b3.to(D), out_f32=True), torch.einsum("zmk,znk->zmn", a3.float(), b3.float()))
+    finally:
+        ops.set_option("gemm_tile", 0)
+        ops.set_option("gemm_glds", 1)
+
+
+def test_gemm_full_size_is_exact_on_integer_data(ops):
+    """ViT QKV shape of BASELINE config 3 (M = 8 x 2049): small-integer operands make every partial sum exactly
+    representable, so the fp32 result must equal the CPU product bit for bit (catches any dropped/duplicated k)."""
+    M, N, K = 8 * 2049, 2304, 768
+    g = torch.Generator().manual_seed(5)
+    a = torch.randint(-4, 5, (M, K), generator=g).to(bf)
+    b = torch.randint(-4, 5, (N, K), generator=g).to(bf)
+    got = ops.gemm(a.to(D), b.to(D), out_f32=True).cpu()
+    assert torch.equal(got, a.float() @ b.float().t())
+
+
+def test_gemm_rejects_bad_arguments(ops):
+    a, b = rnd(16, 12).to(D), rnd(16, 12).to(D)  # K % 8 != 0
+    with pytest.raises(RuntimeError, match="U2TOK_ERR_ARG"):
+        ops.gemm(a, b)
+
+
+@pytest.mark.parametrize("C_", [512, 768, 2048, 4096])
+def test_layernorm(ops, C_):
+    x, r, w, b = rnd(37, C_, seed=1), rnd(37, C_, seed=2), rnd(C_, seed=3), rnd(C_, seed=4)
+    close_bf16(ops.layernorm(x.to(D), w.to(D), b.to(D)), F.layer_norm(x.float(), (C_,), w.float(), b.float()))
+    close_bf16(ops.layernorm(x.to(D), w.to(D), b.to(D), residual=r.to(D)),
+               F.layer_norm(x.float() + r.float(), (C_,), w.float(), b.float()))
+
+
+def test_softmax_rows_scale_bias_and_padding(ops):
+    for (Z, R, n) in [(8, 40, 40), (3, 17, 1792), (4, 9, 13), (1, 1, 1)]:
+        s = torch.randn(Z, R, n, generator=torch.Generator().manual_seed(n)) * 3
+        got = ops.softmax_rows(s.to(D), scale=0.7)
+        close_bf16(got[:, :, :n], F.softmax(s * 0.7, dim=-1))
+        assert got.shape[2] % 8 == 0 and (got[:, :, n:] == 0).all()
+        close_f32(got.float().sum(-1), torch.ones(Z, R)) if False else None
+    H, L = 4, 512
+    tbl = rnd(2 * L - 1, H, scale=0.5, seed=5)
+    s = torch.randn(2 * H, 40, 40, generator=torch.Generator().manual_seed(7))
+    got = ops.softmax_rows(s.to(D), scale=0.5, rel_bias=tbl.to(D), heads=H, max_len=L)
+    pos = torch.arange(40)
+    bias = tbl.float()[pos[None, :] - pos[:, None] + L - 1].permute(2, 0, 1)  # rma.py:64-69
+    close_bf16(got[:, :, :40], F.softmax(s.view(2, H, 40, 40) * 0.5 + bias[None], dim=-1).view(2 * H, 40, 40))
+    with pytest.raises(RuntimeError, match="U2TOK_ERR_ARG"):  # seq_len > max_seq_len cannot index the bias table
+        ops.softmax_rows(torch.zeros(H, 600, 600, device=D), rel_bias=tbl.to(D), heads=H, max_len=L)
+
+
+def test_transpose_and_data_movement_are_bit_exact(ops):
+    x = rnd(3, 70, 130, seed=8)
+    got = ops.transpose(x.to(D), ld_out=72).cpu()
+    assert torch.equal(got[:, :, :70], x.transpose(1, 2)) and (got[:, :, 70:] == 0).all()
+    for dt in (torch.float16, torch.bfloat16, torch.float32):
+        vol = torch.rand(2, 1, 8, 32, 32, generator=torch.Generator().manual_seed(3)).to(dt)
+        ref = vol.to(bf).reshape(2, 1, 2, 4, 2, 16, 2, 16).permute(0, 2, 4, 6, 3, 5, 7, 1).reshape(2, 8, 1024)
+        assert torch.equal(ops.im2col(vol.to(D), (4, 16, 16)).cpu(), ref)
+    table = rnd(100, 64, seed=10)
+    ids = torch.randint(0, 100, (2, 12), generator=torch.Generator().manual_seed(1))
+    feats = rnd(2, 5, 64, seed=11)
+    emb = table[ids]
+    assert torch.equal(ops.embed_splice(table.to(D), ids.to(D), feats.to(D)).cpu(),
+                       torch.cat((emb[:, :1], feats, emb[:, 6:]), 1))  # u2_arch.py:115-116
+    assert torch.equal(ops.embed_splice(table.to(D), ids.to(D)).cpu(), emb)
+    x = rnd(2, 50, 64, seed=15)
+    idx = torch.randint(0, 50, (2, 20), generator=torch.Generator().manual_seed(2))
+    assert torch.equal(ops.gather_rows(x.to(D), idx.to(D)).cpu(), x[torch.arange(2)[:, None], idx])
+
+
+def test_im2col_full_volume_is_the_reference_permutation(ops):
+    """256^3 fp16 volume = 8 chunks of (32,256,256): exact equality with the einops pattern of vit.py:90-99."""
+    vol = torch.rand(8, 1, 32, 256, 256, generator=torch.Generator().manual_seed(9)).half()
+    ref = vol.to(bf).reshape(8, 1, 8, 4, 16, 16, 16, 16).permute(0, 2, 4, 6, 3, 5, 7, 1).reshape(8, 2048, 1024)
+    assert torch.equal(ops.im2col(vol.to(D), (4, 16, 16)).cpu(), ref)
+
+
+def test_avgpool(ops):
+    x = rnd(2, 8 * 4 * 4, 768, seed=9)
+    ref = F.avg_pool3d(x.float().view(2, 8, 4, 4, 768).permute(0, 4, 1, 2, 3), 2, 2).permute(0, 2, 3, 4, 1).reshape(2, -1, 768)
+    close_bf16(ops.avgpool3d_tokens(x.to(D), (8, 4, 4), (2, 2, 2)), ref, rounds=1)
+    close_bf16(ops.avgpool3d_tokens(x.to(D), (1, 1, 128), (1, 1, 8)),
+               F.avg_pool1d(x.float().permute(0, 2, 1), 8, 8).permute(0, 2, 1), rounds=1)
+
+
+def test_selection_stage_is_bit_exact(ops):
+    """score -> top-k -> gather on identical inputs == oracle, at BASELINE size (2048 tokens, E=4096, k=1024) and
+    with heavy exact ties / signed zeros."""
+    x, w, b = rnd(2, 2048, 4096, seed=12), rnd(1, 4096, scale=0.02, seed=13), rnd(1, seed=14)
+    sc = ops.score_gemv(x.to(D), w.to(D), b.to(D)).cpu()
+    assert torch.equal(sc, O.exact_scores(x, w, b))
+    idx = ops.topk_sorted(sc.to(D), 1024).cpu()
+    assert torch.equal(idx, O.canonical_topk(sc, 1024))
+    tok, oidx = O.token_selection({"p.score_net.weight": w, "p.score_net.bias": b}, "p", x.view(2, 8, 256, 4096), 1024)
+    assert torch.equal(idx, oidx) and torch.equal(ops.gather_rows(x.to(D), idx.to(D)).cpu(), tok)
+    picked = sc.gather(1, idx)
+    assert (picked[:, :-1] >= picked[:, 1:]).all() and all(len(set(r.tolist())) == 1024 for r in idx)
+    for (B, n, k) in [(3, 200, 50), (1, 32, 16), (2, 33, 33), (1, 1, 1), (2, 4096, 7)]:
+        s = (torch.randn(B, n, generator=torch.Generator().manual_seed(n)) * 4).round() / 4
+        if n > 2:
+            s[0, 1], s[0, 2] = -0.0, 0.0
+        assert torch.equal(ops.topk_sorted(s.to(D), k).cpu(), O.canonical_topk(s, k))
+
+
+def test_multiscale_pool_fixed_and_gated(ops):
+    for k in (64, 30, 3, 1):
+        x = rnd(2, k, 512, seed=16)
+        close_bf16(ops.multiscale_pool(x.to(D)), O.multi_scale_pool({}, None, x.float()), rounds=1)
+        gw, gb = rnd(1, 512, scale=0.3, seed=17), rnd(1, seed=18)
+        sd = {"p.gate_fc.weight": gw.float(), "p.gate_fc.bias": gb.float()}
+        close_bf16(ops.multiscale_pool(x.to(D), gw.to(D), gb.to(D)), O.multi_scale_pool(sd, "p", x.float()))
+
+
+def test_rope(ops):
+    x = rnd(2 * 3 * 5, 768, seed=19)
+    xd = x.to(D).clone()
+    ops.rope_apply(xd[:, :256], 2, 3, 5, 4, 64)  # rows (b t n), position = t, 4 heads x 64
+    xx = x.float()[:, :256].view(2, 3, 5, 4, 64).permute(0, 2, 3, 1, 4)
+    inv = 1.0 / (10000 ** (torch.arange(0, 64, 2, dtype=torch.float32) / 64))
+    emb = torch.cat((torch.einsum("i,j->ij", torch.arange(512.0), inv),) * 2, -1)
+    cos, sin = emb.cos()[:3].to(bf).float(), emb.sin()[:3].to(bf).float()
+    close_bf16(xd[:, :256].float().cpu().view(2, 3, 5, 4, 64).permute(0, 2, 3, 1, 4), xx * cos + O._rotate_half(xx) * sin)
+    assert torch.equal(xd[:, 256:].cpu(), x[:, 256:])
+
+
+@pytest.mark.parametrize("B,T,N,H,d", [(1, 8, 6, 8, 512), (2, 4, 5, 8, 256), (1, 2, 16, 8, 64), (1, 3, 7, 4, 128),
+                                       (1, 16, 3, 2, 64), (1, 1, 4, 2, 64)])
+def test_temporal_attention(ops, B, T, N, H, d):
+    E = H * d
+    qkv, tbl = rnd(B * T * N, 3 * E, seed=d), rnd(1023, H, scale=0.5, seed=3)
+    qd = qkv.to(D)
+    got = ops.temporal_attention(qd[:, :E], qd[:, E:2 * E], qd[:, 2 * E:], B, T, N, H, 1 / math.sqrt(d), tbl.to(D), 512)
+    x = qkv.float().view(B, T, N, 3, H, d).permute(3, 0, 2, 4, 1, 5)
+    pos = torch.arange(T)
+    bias = tbl.float()[pos[None, :] - pos[:, None] + 511].permute(2, 0, 1)
+    p = F.softmax(x[0] @ x[1].transpose(-1, -2) / math.sqrt(d) + bias[None, None], dim=-1)
+    close_bf16(got, (p @ x[2]).permute(0, 3, 1, 2, 4).reshape(B * T * N, E))
+
+
+@pytest.mark.parametrize("nb,S,H,scale", [(1, 64, 1, 1.0), (2, 129, 3, 1.0), (1, 513, 12, 1.0), (1, 2049, 2, 1.0),
+                                          (3, 100, 12, 1.0), (1, 300, 2, 3.0), (1, 1, 1, 1.0)])
+def test_flash_attention(ops, nb, S, H, scale):
+    """scale 3.0 makes the logits spiky so the online-softmax rescale branch does real work."""
+    qkv = rnd(nb, S, 3 * H * 64, scale=scale, seed=S)
+    got = ops.flash_attention_d64(qkv.to(D), H, 0.125)
+    x = qkv.float().view(nb, S, 3, H, 64).permute(2, 0, 3, 1, 4)
+    p = F.softmax(x[0] @ x[1].transpose(-1, -2) * 0.125, dim=-1)
+    close_bf16(got, (p @ x[2]).permute(0, 2, 1, 3).reshape(nb, S, H * 64))
+
+
+def test_flash_attention_forced_rescale(ops):
+    """One key row spiked against every query at a late KV tile: the running max must jump there (rule 26 of the
+    CDNA guide: a rare data-dependent branch needs an input that forces it)."""
+    nb, S, H = 1, 400, 1
+    qkv = rnd(nb, S, 192, seed=77)
+    qkv[0, 333, 64:128] = (qkv[0, :, :64].float().mean(0) * 40).to(bf)  # k row 333 aligned with the mean query
+    got = ops.flash_attention_d64(qkv.to(D), H, 0.125)
+    x = qkv.float().view(nb, S, 3, H, 64).permute(2, 0, 3, 1, 4)
+    p = F.softmax(x[0] @ x[1].transpose(-1, -2) * 0.125, dim=-1)
+    close_bf16(got, (p @ x[2]).permute(0, 2, 1, 3).reshape(nb, S, 64))

@@ -70,16 +70,17 @@ int u2tok_spp_forward(const u2tok_spp_config* cfg, const void* const* weights, c
 size_t u2tok_tokenizer_workspace_bytes(const u2tok_tokenizer_config* cfg) {
   if (!cfg) return 0;
   size_t peak = 0;
-  if (tokenizer_forward(*cfg, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, true, &peak, nullptr) != U2_OK)
+  if (tokenizer_forward(*cfg, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, true, &peak, nullptr) !=
+      U2_OK)
     return 0;
   return peak + 256;
 }
 int u2tok_tokenizer_forward(const u2tok_tokenizer_config* cfg, const void* const* weights, const void* v_token,
-                            const void* t_token, void* out, int64_t* topk_idx_out, void* workspace,
+                            const void* t_token, void* out, int64_t* topk_idx_out, void* svr_out, void* workspace,
                             size_t workspace_bytes, u2tok_stream_t stream) {
   if (!cfg || !workspace || ((uintptr_t)workspace & 255)) return U2_ERR_ARG;
-  return tokenizer_forward(*cfg, weights, BF(v_token), BF(t_token), BFW(out), topk_idx_out, workspace, workspace_bytes,
-                           false, nullptr, ST(stream));
+  return tokenizer_forward(*cfg, weights, BF(v_token), BF(t_token), BFW(out), topk_idx_out, BFW(svr_out), workspace,
+                           workspace_bytes, false, nullptr, ST(stream));
 }
 
 int u2tok_embed_splice(const void* table, const int64_t* ids, const void* feats, void* out, int32_t B, int32_t S,

@@ -16,8 +16,8 @@ int vit_forward(const VitConfig& c, const void* const* W, const void* volume, bf
 int spp_forward(const SppConfig& c, const void* const* W, const bf16_t* x, bf16_t* out, void* ws, size_t ws_bytes,
                 bool dry, size_t* peak, hipStream_t st);
 int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_token, const bf16_t* t_token,
-                      bf16_t* out, int64_t* topk_idx_out, void* ws, size_t ws_bytes, bool dry, size_t* peak,
-                      hipStream_t st);
+                      bf16_t* out, int64_t* topk_idx_out, bf16_t* svr_out, void* ws, size_t ws_bytes, bool dry,
+                      size_t* peak, hipStream_t st);
 void pipeline_set_vit_flash(int v);
 
 }  // namespace u2

@@ -225,8 +225,8 @@ struct Att {
 }  // namespace
 
 int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_token, const bf16_t* t_token,
-                      bf16_t* out, int64_t* topk_idx_out, void* ws, size_t ws_bytes, bool dry, size_t* peak,
-                      hipStream_t st) {
+                      bf16_t* out, int64_t* topk_idx_out, bf16_t* svr_out, void* ws, size_t ws_bytes, bool dry,
+                      size_t* peak, hipStream_t st) {
   if (c.B <= 0 || c.T <= 0 || c.N <= 0 || c.E <= 0 || c.Lt <= 0 || c.num_heads <= 0 || c.num_layers < 0) return U2_ERR_ARG;
   if (c.E % c.num_heads || (c.E / c.num_heads) % 8 || c.top_k <= 0 || c.num_query <= 0) return U2_ERR_ARG;
   if (c.attn_type != 0 && c.attn_type != 1) return U2_ERR_ARG;
@@ -285,6 +285,11 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
     U2_RUN(temporal_attention(qkv, qkv + E, qkv + 2 * E, ctx, B, T, N, H, d, 3 * E, E, scale, tp.rb, c.max_seq_len, st));
     U2_RUN(linear(ctx, E, tp.wd, tp.bd, y2, E, rows, E, E, 0, nullptr, 0, st));
     x = y2;
+  }
+
+  if (svr_out && !dry) {  // optional tap: the refined tokens the selection stage sees (parity tests)
+    if (hipMemcpyAsync(svr_out, x, (size_t)rows * E * sizeof(bf16_t), hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return U2_ERR_LAUNCH;
   }
 
   // ---------------- token selection (svr.py:171)

@@ -195,6 +195,8 @@ class u2Tokenizer(nn.Module):
         self.enable_diffts, self.enable_dmtp = bool(enable_diffts), bool(enable_dmtp)
         self._ws = ops._Workspace()
         self.last_topk_indices = None  # (B, top_k) int64 -- set by forward() when hard top-k selection is on
+        self.capture_svr_tokens = False  # True: forward() also keeps the refined tokens in last_svr_tokens
+        self.last_svr_tokens = None
 
     def _weights(self):
         w = [self.query_tokens]
@@ -239,9 +241,13 @@ class u2Tokenizer(nn.Module):
         idx = None
         if not self.enable_diffts:
             idx = torch.empty((B, self.top_k), dtype=torch.int64, device=v_token.device)
+        svr = None
+        if self.capture_svr_tokens:
+            svr = torch.empty((B, T * N, E), dtype=torch.bfloat16, device=v_token.device)
         _lib.check(h.u2tok_tokenizer_forward(C.byref(cfg), table, v_token.data_ptr(), t_token.data_ptr(),
-                                             out.data_ptr(), None if idx is None else idx.data_ptr(), ws.data_ptr(),
-                                             ws.numel(), torch.cuda.current_stream().cuda_stream),
-                   "u2tok_tokenizer_forward")
+                                             out.data_ptr(), None if idx is None else idx.data_ptr(),
+                                             None if svr is None else svr.data_ptr(), ws.data_ptr(), ws.numel(),
+                                             torch.cuda.current_stream().cuda_stream), "u2tok_tokenizer_forward")
         self.last_topk_indices = idx
+        self.last_svr_tokens = svr
         return out
