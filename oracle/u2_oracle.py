@@ -147,7 +147,10 @@ def spp_forward(sd: SD, p: str, x: torch.Tensor, cfg: PathConfig) -> torch.Tenso
     if cfg.proj_pooling_type == "spatial":
         g = cfg.grid
         x = x.reshape(B, g[0], g[1], g[2], dim).permute(0, 4, 1, 2, 3)
-        x = F.avg_pool3d(x, kernel_size=ps, stride=ps)
+        if x.dtype == torch.bfloat16:  # CPU torch has no bf16 avg_pool3d kernel: fp32 accumulate, one rounding
+            x = F.avg_pool3d(x.float(), kernel_size=ps, stride=ps).to(torch.bfloat16)
+        else:
+            x = F.avg_pool3d(x, kernel_size=ps, stride=ps)
         x = x.permute(0, 2, 3, 4, 1).reshape(B, -1, dim)
     elif cfg.proj_pooling_type == "sequence":
         x = F.avg_pool1d(x.permute(0, 2, 1), kernel_size=ps ** 3, stride=ps ** 3).permute(0, 2, 1)
