@@ -157,8 +157,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    from u2tokenizer_amd import replicas
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -167,11 +167,8 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # RCCL ("nccl" backend on ROCm); used only for the timing barrier / MAX
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    # RCCL ("nccl" backend on ROCm) is used only for the timing barrier and the MAX over ranks: replicas share nothing
+    dist, rank, world = replicas.init_from_env("nccl", device)
 
     from u2tokenizer_amd import _lib, ops
     ops.device_check()  # fails loudly off gfx950 / without the HIP library
@@ -193,9 +190,7 @@ def main():
         return path.prepare_inputs_for_multimodal(ids, None, None, None, None, vols[i % nvol], qids)[4]
 
     def sync():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        replicas.barrier(dist, device)
 
     for i in range(args.warmup):
         out = step(i)
@@ -206,10 +201,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     assert out.shape == (B, S, E) and bool(torch.isfinite(out.float()).all())
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    elapsed = replicas.max_over_ranks(dist, elapsed, device)
 
     fl = flops_per_volume(E, Lt)
     value = world * B * args.steps / elapsed
