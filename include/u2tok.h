@@ -157,8 +157,10 @@ int u2tok_layernorm_bf16(const void* x, const void* res, const void* w, const vo
                          int32_t C, float eps, u2tok_stream_t stream);
 int u2tok_softmax_rows(const float* S, void* P, int32_t nz, int32_t rows, int32_t n, int64_t lds, int64_t ldp,
                        float scale, const void* rel_bias, int32_t H, int32_t max_len, u2tok_stream_t stream);
+/* out[z][c][r] = in[z][r][c], pad columns zeroed.  perm16 != 0 (needs ld_out % 16 == 0): inside each group of 16
+ * output columns the order is [0-3, 8-11, 4-7, 12-15] -- the V^T layout u2tok_flash_attention_d64 consumes. */
 int u2tok_transpose_bf16(const void* in, void* out, int32_t nz, int32_t R, int32_t C, int64_t ld_in, int64_t ld_out,
-                         int64_t in_zs, int64_t out_zs, u2tok_stream_t stream);
+                         int64_t in_zs, int64_t out_zs, int32_t perm16, u2tok_stream_t stream);
 int u2tok_im2col_patches(const void* vol, int32_t vol_dtype, void* out, int32_t nchunk, int32_t D, int32_t H,
                          int32_t W, int32_t p1, int32_t p2, int32_t p3, u2tok_stream_t stream);
 int u2tok_avgpool3d_tokens(const void* x, void* y, int32_t nb, int32_t g1, int32_t g2, int32_t g3, int32_t w1,

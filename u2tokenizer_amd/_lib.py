@@ -72,7 +72,7 @@ SIGNATURES = {
                                _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _i32, _vp]),
     "u2tok_layernorm_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
     "u2tok_softmax_rows": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _f32, _vp, _i32, _i32, _vp]),
-    "u2tok_transpose_bf16": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _vp]),
+    "u2tok_transpose_bf16": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _vp]),
     "u2tok_im2col_patches": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "u2tok_avgpool3d_tokens": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "u2tok_score_gemv": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),

@@ -152,15 +152,16 @@ int temporal_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t
 //                 then owns 16 keys of each 32-key block -> row max/sum are lane-local + one xor-32.
 //   O^T = V^T P^T: A = V^T fragment (LDS, V pre-transposed in HBM), B = P^T = the lane's own exp'd
 //                 scores packed to bf16 -- NO cross-lane movement: the k-slot -> key mapping of the MFMA
-//                 is a free permutation as long as A and B agree, so V^T is read in P's native order.
-//   O^T accumulators keep q = lane&31 per lane, so the online-softmax rescale is lane-local too.
-// LDS tiles ([64][64] bf16, 128 B rows) are XOR-swizzled: K at 16-B granularity with (row>>1)&7, V^T at
-// 8-B granularity with ((row>>1)&7)<<1 | (row>>4)&1 -> conflict-free ds_read_b128 / ds_read_b64.
-__device__ __forceinline__ uint32_t kt_off(int row, int chunk) {  // K tile: 16-B chunk index 0..7
+//                 is a free permutation as long as A and B agree, so V^T is stored in P's native order:
+//                 inside every group of 16 keys the HBM/LDS column order is [0-3, 8-11, 4-7, 12-15]
+//                 (transpose_bf16(..., perm16 = 1)), which makes each lane's 8 k-slots one 16-byte read.
+//   O^T accumulators keep q = lane&31 per lane, so the online-softmax rescale is lane-local too; it is
+//   deferred until some row's running max grows by more than 2^8 (wave-uniform branch), the softmax scale
+//   is folded into one FMA per score, and key masking runs only in the last (partial) KV tile.
+// LDS tiles ([64][64] bf16, 128 B rows): 16-byte chunks XOR-swizzled with (row>>1)&7 -> conflict-free
+// ds_read_b128 for the 32x32 fragment pattern.
+__device__ __forceinline__ uint32_t kt_off(int row, int chunk) {  // 16-B chunk index 0..7
   return (uint32_t)(row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-}
-__device__ __forceinline__ uint32_t vt_off(int row, int unit) {  // V^T tile: 8-B unit index 0..15
-  return (uint32_t)(row * 128 + ((unit ^ ((((row >> 1) & 7) << 1) | ((row >> 4) & 1))) << 3));
 }
 
 __global__ __launch_bounds__(256, 2) void flash_d64_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
@@ -168,7 +169,8 @@ __global__ __launch_bounds__(256, 2) void flash_d64_kernel(const bf16_t* __restr
                                                            int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs,
                                                            int S_pad, float scale_log2e, int nqt) {
   __shared__ __attribute__((aligned(16))) char lds[2][16384];  // [stage][K tile 8 KB | V^T tile 8 KB]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
   int bid = blockIdx.x;
   const int qt = bid % nqt; bid /= nqt;
@@ -178,117 +180,130 @@ __global__ __launch_bounds__(256, 2) void flash_d64_kernel(const bf16_t* __restr
   const bf16_t* kb = k + (int64_t)b * q_bs + h * 64;
   const bf16_t* vb = vt + ((int64_t)b * H + h) * 64 * S_pad;
 
-  // Q fragments (B operand): Q[q][d = ks*16 + hi*8 .. +7]
+  // a wave whose 32 rows are all past the sequence end only helps with staging (S = 2049: the 17th q tile)
+  const bool wave_active = (qt * 128 + wv * 32) < S;
   const int qrow = qt * 128 + wv * 32 + l31;
-  bf16x8 qf[4];
+  bf16x8 qf[4];  // Q fragments (B operand): Q[q][d = ks*16 + hi*8 .. +7]
   {
     const bf16_t* qp = qb + (int64_t)min(qrow, S - 1) * ld_qk + hi * 8;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
   }
 
-  // staging: K tile = 64 rows x 8 chunks, V^T tile = 64 rows x 8 chunks; 2 chunks of each per thread
-  uint4 rk[2], rv[2];
-  auto gload = [&](int t) {
-    const int kv0 = t * 64;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = i * 256 + tid, row = c >> 3, ch = c & 7;
-      rk[i] = *reinterpret_cast<const uint4*>(kb + (int64_t)min(kv0 + row, S - 1) * ld_qk + ch * 8);
-      rv[i] = *reinterpret_cast<const uint4*>(vb + (int64_t)row * S_pad + kv0 + ch * 8);
-    }
-  };
-  auto lstore = [&](int st) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = i * 256 + tid, row = c >> 3, ch = c & 7;
-      *reinterpret_cast<uint4*>(&lds[st][kt_off(row, ch)]) = rk[i];
-      // 8-B swizzle: chunk moves with (row>>1)&7, halves swap when (row>>4)&1
-      uint4 x = rv[i];
-      if ((row >> 4) & 1) x = uint4{x.z, x.w, x.x, x.y};
-      *reinterpret_cast<uint4*>(&lds[st][8192 + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)]) = x;
-    }
-  };
+  // staging: K tile = 64 rows x 8 chunks, V^T tile = 64 rows x 8 chunks; 2 chunks of each per thread.
+  // Named scalars + macros on purpose: arrays captured by lambdas ended up in scratch memory here.
+  const int srow0 = tid >> 3, srow1 = 32 + (tid >> 3), sch = tid & 7;
+  const bf16_t* vsrc0 = vb + (int64_t)srow0 * S_pad + sch * 8;
+  const bf16_t* vsrc1 = vb + (int64_t)srow1 * S_pad + sch * 8;
+  const uint32_t soff0 = kt_off(srow0, sch), soff1 = kt_off(srow1, sch);
+  uint4 rk0, rk1, rv0, rv1;
+#define U2_FLASH_GLOAD(t_)                                                                                       \
+  do {                                                                                                           \
+    const int kv0_ = (t_) * 64;                                                                                  \
+    rk0 = *reinterpret_cast<const uint4*>(kb + (int64_t)min(kv0_ + srow0, S - 1) * ld_qk + sch * 8);            \
+    rk1 = *reinterpret_cast<const uint4*>(kb + (int64_t)min(kv0_ + srow1, S - 1) * ld_qk + sch * 8);            \
+    rv0 = *reinterpret_cast<const uint4*>(vsrc0 + kv0_);                                                         \
+    rv1 = *reinterpret_cast<const uint4*>(vsrc1 + kv0_);                                                         \
+  } while (0)
+#define U2_FLASH_LSTORE(st_)                                                  \
+  do {                                                                        \
+    *reinterpret_cast<uint4*>(&lds[st_][soff0]) = rk0;                        \
+    *reinterpret_cast<uint4*>(&lds[st_][soff1]) = rk1;                        \
+    *reinterpret_cast<uint4*>(&lds[st_][8192 + soff0]) = rv0;                 \
+    *reinterpret_cast<uint4*>(&lds[st_][8192 + soff1]) = rv1;                 \
+  } while (0)
 
   f32x16 oacc[2];
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[nb][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;  // m_run in scaled (log2) units
+  constexpr float RESCALE_THR = 8.0f;
 
   const int ntile = (S + 63) >> 6;
-  gload(0);
-  lstore(0);
+  U2_FLASH_GLOAD(0);
+  U2_FLASH_LSTORE(0);
   __syncthreads();
+  // Pin the Q fragments as "arrived" here.  Without this hipcc sinks their loads into the loop pre-header and its
+  // waitcnt pass then drains vmcnt to 0 in front of the first QK^T MFMAs of EVERY iteration -- i.e. it waits for
+  // the K/V prefetch issued a few instructions earlier and exposes the full HBM latency per tile.
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks]));
   for (int t = 0; t < ntile; ++t) {
     const int st = t & 1;
-    if (t + 1 < ntile) gload(t + 1);
-    const char* sK = lds[st];
-    const char* sV = lds[st] + 8192;
-    // ---- S^T = K Q^T for the two 32-key blocks
-    f32x16 sc[2];
+    if (t + 1 < ntile) U2_FLASH_GLOAD(t + 1);
+    if (wave_active) {
+      const char* sK = lds[st];
+      const char* sV = lds[st] + 8192;
+      // ---- S^T = K Q^T for the two 32-key blocks
+      f32x16 sc[2];
 #pragma unroll
-    for (int kbk = 0; kbk < 2; ++kbk) {
+      for (int kbk = 0; kbk < 2; ++kbk) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sc[kbk][r] = 0.f;
+        for (int r = 0; r < 16; ++r) sc[kbk][r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + kt_off(kbk * 32 + l31, ks * 2 + hi));
-        sc[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[kbk], 0, 0, 0);
-      }
-    }
-    // lane owns keys kv = t*64 + kbk*32 + (r&3) + 8*(r>>2) + 4*hi
-    float mt = -INFINITY;
-    const int kvb = t * 64 + 4 * hi;
-#pragma unroll
-    for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kv = kvb + kbk * 32 + (r & 3) + 8 * (r >> 2);
-        const float x = (kv < S) ? sc[kbk][r] * scale_log2e : -INFINITY;
-        sc[kbk][r] = x;
-        mt = fmaxf(mt, x);
-      }
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float m_new = fmaxf(m_run, mt);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float ps = 0.f;
-#pragma unroll
-    for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(sc[kbk][r] - m_new);
-        sc[kbk][r] = p;
-        ps += p;
-      }
-    l_run = l_run * alpha + ps;
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[nb][r] *= alpha;
-    // ---- O^T += V^T P^T ; k-slots jj of step (kbk, ks2) carry keys kbk*32 + 16*ks2 + 8*(jj>>2) + 4*hi + (jj&3)
-#pragma unroll
-    for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-      for (int ks2 = 0; ks2 < 2; ++ks2) {
-        union { bf16x8 v; uint32_t u[4]; } pf;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pf.u[j] = pack2_bf16(sc[kbk][ks2 * 8 + 2 * j], sc[kbk][ks2 * 8 + 2 * j + 1]);
-        const int unit0 = (kbk * 32 + ks2 * 16 + 4 * hi) >> 2;  // 8-B unit holding keys [.., +4)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-          const int drow = nb * 32 + l31;
-          union { bf16x8 v; uint2 h[2]; } vf;
-          vf.h[0] = *reinterpret_cast<const uint2*>(sV + vt_off(drow, unit0));
-          vf.h[1] = *reinterpret_cast<const uint2*>(sV + vt_off(drow, unit0 + 2));
-          oacc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, oacc[nb], 0, 0, 0);
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + kt_off(kbk * 32 + l31, ks * 2 + hi));
+          sc[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[kbk], 0, 0, 0);
         }
       }
-    if (t + 1 < ntile) lstore((t + 1) & 1);
+      // lane owns keys kv = t*64 + kbk*32 + (r&3) + 8*(r>>2) + 4*hi ; only the last tile can be partial
+      if (t == ntile - 1 && (S & 63)) {
+        const int kvb = t * 64 + 4 * hi;
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (kvb + kbk * 32 + (r & 3) + 8 * (r >> 2) >= S) sc[kbk][r] = -INFINITY;
+      }
+      float mt = -INFINITY;
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sc[kbk][r]);
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale_log2e;  // scale > 0: max commutes with it
+      if (__any(mt > m_run + RESCALE_THR)) {  // wave-uniform; always taken on the first tile (m_run = -inf)
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[nb][r] *= alpha;
+      }
+      float ps = 0.f;
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kbk][r], scale_log2e, -m_run));
+          sc[kbk][r] = p;
+          ps += p;
+        }
+      l_run += ps;
+      // ---- O^T += V^T P^T ; k-slots jj of step (kbk, ks2) carry keys kbk*32 + 16*ks2 + 8*(jj>>2) + 4*hi + (jj&3),
+      //      which is exactly 16-byte chunk (kbk*2 + ks2)*2 + hi of the permuted V^T row
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+          union { bf16x8 v; uint32_t u[4]; } pf;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pf.u[j] = pack2_bf16(sc[kbk][ks2 * 8 + 2 * j], sc[kbk][ks2 * 8 + 2 * j + 1]);
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + kt_off(nb * 32 + l31, (kbk * 2 + ks2) * 2 + hi));
+            oacc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, oacc[nb], 0, 0, 0);
+          }
+        }
+    }
+    if (t + 1 < ntile) U2_FLASH_LSTORE((t + 1) & 1);
     __syncthreads();
   }
+#undef U2_FLASH_GLOAD
+#undef U2_FLASH_LSTORE
   // ---- epilogue: O^T[d][q] / l ; lane: q = lane&31, d = nb*32 + (r&3) + 8*(r>>2) + 4*hi
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l_tot;

@@ -114,8 +114,8 @@ int u2tok_softmax_rows(const float* S, void* P, int32_t nz, int32_t rows, int32_
 }
 
 int u2tok_transpose_bf16(const void* in, void* out, int32_t nz, int32_t R, int32_t C, int64_t ld_in, int64_t ld_out,
-                         int64_t in_zs, int64_t out_zs, u2tok_stream_t stream) {
-  return transpose_bf16(BF(in), BFW(out), nz, R, C, ld_in, ld_out, in_zs, out_zs, ST(stream));
+                         int64_t in_zs, int64_t out_zs, int32_t perm16, u2tok_stream_t stream) {
+  return transpose_bf16(BF(in), BFW(out), nz, R, C, ld_in, ld_out, in_zs, out_zs, perm16, ST(stream));
 }
 
 int u2tok_im2col_patches(const void* vol, int32_t vol_dtype, void* out, int32_t nchunk, int32_t D, int32_t H,

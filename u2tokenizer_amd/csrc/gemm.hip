@@ -18,6 +18,7 @@
 //    before the MFMA block, written after it) or by LDS-DMA (global_load_lds_dwordx4, swizzle applied
 //    on the per-lane SOURCE address because the DMA destination is lane-linear).
 //  * XCD-aware, M-grouped tile order so that the 8 private L2s each see a compact band of tiles.
+#include <type_traits>
 #include "kernels.h"
 
 namespace u2 {
@@ -172,52 +173,76 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
   const bool out_f32 = d.flags & GEMM_OUT_F32;
   char* Cz = reinterpret_cast<char*>(d.C) + (zb * d.sCb + zh * d.sCh) * (out_f32 ? 4 : 2);
   const bf16_t* Rz = (d.flags & GEMM_RESIDUAL) ? d.R + zb * d.sRb + zh * d.sRh : nullptr;
-  const bool vec = d.flags & GEMM_VEC_OK;
+  const int m_base = bm0 + wm * WM + (lane & 15);
+  const int n_base = bn0 + wn * WN + (lane >> 4) * 4;
+
+  // Fast path: every column group of this block is inside N and all vector accesses are legal.  The flag set is
+  // resolved ONCE into compile-time booleans (the common combinations), so the unrolled body is branch-free.
+  auto epi_vec = [&](auto BN_, auto GELU_, auto RES_, auto F32_) {
+    float4 bn[NI];
+    if constexpr (decltype(BN_)::value) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const uint2 b2 = *reinterpret_cast<const uint2*>(d.bias + n_base + ni * 16);
+        bn[ni] = float4{bf16lo(b2.x), bf16hi(b2.x), bf16lo(b2.y), bf16hi(b2.y)};
+      }
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = m_base + mi * 16;
+      if (m >= d.M) continue;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int n0 = n_base + ni * 16;
+        float v0 = acc[mi][ni][0] * d.alpha, v1 = acc[mi][ni][1] * d.alpha, v2 = acc[mi][ni][2] * d.alpha,
+              v3 = acc[mi][ni][3] * d.alpha;
+        if constexpr (decltype(BN_)::value) { v0 += bn[ni].x; v1 += bn[ni].y; v2 += bn[ni].z; v3 += bn[ni].w; }
+        if constexpr (decltype(GELU_)::value) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+        if constexpr (decltype(RES_)::value) {
+          const uint2 r2 = *reinterpret_cast<const uint2*>(Rz + (int64_t)m * d.ldr + n0);
+          v0 += bf16lo(r2.x); v1 += bf16hi(r2.x); v2 += bf16lo(r2.y); v3 += bf16hi(r2.y);
+        }
+        if constexpr (decltype(F32_)::value)
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cz) + (int64_t)m * d.ldc + n0) = float4{v0, v1, v2, v3};
+        else
+          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cz) + (int64_t)m * d.ldc + n0) =
+              uint2{pack2_bf16(v0, v1), pack2_bf16(v2, v3)};
+      }
+    }
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  const int ef = d.flags & (GEMM_BIAS_N | GEMM_BIAS_M | GEMM_GELU | GEMM_RESIDUAL | GEMM_OUT_F32);
+  if ((d.flags & GEMM_VEC_OK) && bn0 + BN <= d.N && !(ef & GEMM_BIAS_M)) {
+    switch (ef) {
+      case 0: epi_vec(F_{}, F_{}, F_{}, F_{}); return;
+      case GEMM_OUT_F32: epi_vec(F_{}, F_{}, F_{}, T_{}); return;
+      case GEMM_BIAS_N: epi_vec(T_{}, F_{}, F_{}, F_{}); return;
+      case GEMM_BIAS_N | GEMM_GELU: epi_vec(T_{}, T_{}, F_{}, F_{}); return;
+      case GEMM_BIAS_N | GEMM_RESIDUAL: epi_vec(T_{}, F_{}, T_{}, F_{}); return;
+      case GEMM_RESIDUAL: epi_vec(F_{}, F_{}, T_{}, F_{}); return;
+      default: break;
+    }
+  }
+  // Generic path (tails, unaligned, bias along M, rare flag sets): scalar, fully predicated.  The loops must stay
+  // fully unrolled: a runtime index into acc[][] would move the accumulators to scratch memory.
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
-    const int m = bm0 + wm * WM + mi * 16 + (lane & 15);
+    const int m = m_base + mi * 16;
     if (m >= d.M) continue;
-    float bm_v = 0.f;
-    if (d.flags & GEMM_BIAS_M) bm_v = bf16_to_f32(d.bias[m]);
+    const float bm_v = (d.flags & GEMM_BIAS_M) ? bf16_to_f32(d.bias[m]) : 0.f;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-      const int n0 = bn0 + wn * WN + ni * 16 + (lane >> 4) * 4;
-      if (n0 >= d.N) continue;
-      float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r] * d.alpha + bm_v;
-      if (vec && n0 + 3 < d.N) {
-        if (d.flags & GEMM_BIAS_N) {
-          const uint2 b2 = *reinterpret_cast<const uint2*>(d.bias + n0);
-          v[0] += bf16lo(b2.x); v[1] += bf16hi(b2.x); v[2] += bf16lo(b2.y); v[3] += bf16hi(b2.y);
-        }
-        if (d.flags & GEMM_GELU) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-        }
-        if (Rz) {
-          const uint2 r2 = *reinterpret_cast<const uint2*>(Rz + (int64_t)m * d.ldr + n0);
-          v[0] += bf16lo(r2.x); v[1] += bf16hi(r2.x); v[2] += bf16lo(r2.y); v[3] += bf16hi(r2.y);
-        }
-        if (out_f32) {
-          *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cz) + (int64_t)m * d.ldc + n0) =
-              float4{v[0], v[1], v[2], v[3]};
-        } else {
-          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cz) + (int64_t)m * d.ldc + n0) =
-              uint2{pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int n = n0 + r;
-          if (n >= d.N) break;
-          float x = v[r];
-          if (d.flags & GEMM_BIAS_N) x += bf16_to_f32(d.bias[n]);
-          if (d.flags & GEMM_GELU) x = gelu_erf(x);
-          if (Rz) x += bf16_to_f32(Rz[(int64_t)m * d.ldr + n]);
-          if (out_f32) reinterpret_cast<float*>(Cz)[(int64_t)m * d.ldc + n] = x;
-          else reinterpret_cast<bf16_t*>(Cz)[(int64_t)m * d.ldc + n] = f32_to_bf16(x);
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int n = n_base + ni * 16 + r;
+        if (n >= d.N) break;
+        float x = acc[mi][ni][r] * d.alpha + bm_v;
+        if (d.flags & GEMM_BIAS_N) x += bf16_to_f32(d.bias[n]);
+        if (d.flags & GEMM_GELU) x = gelu_erf(x);
+        if (Rz) x += bf16_to_f32(Rz[(int64_t)m * d.ldr + n]);
+        if (out_f32) reinterpret_cast<float*>(Cz)[(int64_t)m * d.ldc + n] = x;
+        else reinterpret_cast<bf16_t*>(Cz)[(int64_t)m * d.ldc + n] = f32_to_bf16(x);
       }
     }
   }

@@ -58,9 +58,10 @@ int softmax_rows(const float* S, bf16_t* P, int nz, int rows, int n, int64_t lds
                  int64_t s_zs, int64_t p_zs, float scale, const bf16_t* rel_bias, int H, int max_len,
                  hipStream_t stream);
 
-// out[z][c][r] = in[z][r][c]; columns [R, ld_out) of out are zero-filled.
+// out[z][c][r] = in[z][r][c]; columns [R, ld_out) of out are zero-filled.  perm16 != 0: inside every group of
+// 16 output columns the order is [0-3, 8-11, 4-7, 12-15] (layout the flash-attention kernel expects for V^T).
 int transpose_bf16(const bf16_t* in, bf16_t* out, int nz, int R, int C, int64_t ld_in, int64_t ld_out,
-                   int64_t in_zs, int64_t out_zs, hipStream_t stream);
+                   int64_t in_zs, int64_t out_zs, int perm16, hipStream_t stream);
 
 // ------------------------------------------------------------------ vision (vision.hip)
 enum : int { VOL_F16 = 0, VOL_BF16 = 1, VOL_F32 = 2 };
@@ -105,7 +106,7 @@ int temporal_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t
                        int max_len, hipStream_t stream);
 
 // Flash attention for the ViT blocks (head_dim 64).  q,k: [nb][S][*] with leading dim ld_qk, head h at
-// column h*64; vt: [nb][H][64][S_pad] (S_pad % 64 == 0, zero padded); out: [nb][S][H*64] (ld_out).
+// column h*64; vt: [nb][H][64][S_pad] (S_pad % 64 == 0, zero padded, perm16 column order); out: [nb][S][H*64].
 int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int nb, int S,
                         int H, int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs, int S_pad,
                         float scale, hipStream_t stream);

@@ -87,7 +87,7 @@ int attention_core(Arena& ar, const AttnCore& a, bool dry, hipStream_t st) {
   }
   U2_RUN(softmax_rows(S, P, (int)nz, a.Sq, a.Skv, ldS, ldp, (int64_t)a.Sq * ldS, (int64_t)a.Sq * ldp, a.scale,
                       a.rel_bias, a.H, a.max_len, st));
-  U2_RUN(transpose_bf16(a.v, Vt, a.nb, a.Skv, a.H * a.d, a.ldv, ldp, a.v_bs, (int64_t)a.H * a.d * ldp, st));
+  U2_RUN(transpose_bf16(a.v, Vt, a.nb, a.Skv, a.H * a.d, a.ldv, ldp, a.v_bs, (int64_t)a.H * a.d * ldp, 0, st));
   {
     GemmDesc g;
     g.A = P; g.B = Vt; g.C = a.out;
@@ -156,7 +156,7 @@ int vit_forward(const VitConfig& c, const void* const* W, const void* volume, bf
     U2_RUN(layernorm_bf16(x, nullptr, w(b0 + 0), w(b0 + 1), xn, 1, (int)rows, Hd, 0, Hd, 0, 0, 0, Hd, c.ln_eps, st));
     U2_RUN(linear(xn, Hd, w(b0 + 2), nullptr, qkv, 3 * Hd, rows, Hd, 3 * Hd, 0, nullptr, 0, st));
     if (g_vit_flash) {
-      U2_RUN(transpose_bf16(qkv + 2 * Hd, vt, nc, S, Hd, 3 * Hd, S_pad, (int64_t)S * 3 * Hd, (int64_t)Hd * S_pad, st));
+      U2_RUN(transpose_bf16(qkv + 2 * Hd, vt, nc, S, Hd, 3 * Hd, S_pad, (int64_t)S * 3 * Hd, (int64_t)Hd * S_pad, 1, st));
       U2_RUN(flash_attention_d64(qkv, qkv + Hd, vt, att, nc, S, c.heads, 3 * Hd, (int64_t)S * 3 * Hd, Hd,
                                  (int64_t)S * Hd, S_pad, scale, st));
     } else {
@@ -314,7 +314,7 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
     }
     U2_RUN(softmax_rows(scT, P, B, k, TN, ldS, ldS, (int64_t)k * ldS, (int64_t)k * ldS, 1.0f / c.diffts_tau, nullptr, 1,
                         0, st));
-    U2_RUN(transpose_bf16(x, Xt, B, TN, E, E, ldS, (int64_t)TN * E, (int64_t)E * ldS, st));
+    U2_RUN(transpose_bf16(x, Xt, B, TN, E, E, ldS, (int64_t)TN * E, (int64_t)E * ldS, 0, st));
     {
       GemmDesc g;
       g.A = P; g.B = Xt; g.C = sel;

@@ -147,9 +147,11 @@ int softmax_rows(const float* S, bf16_t* P, int nz, int rows, int n, int64_t lds
 
 // ---------------------------------------------------------------- transpose
 // 64x64 bf16 tiles through LDS (padded rows -> conflict-free column reads), coalesced both sides.
+// perm16: inside every group of 16 output columns the order becomes [0-3, 8-11, 4-7, 12-15] -- the k-slot order
+// of the flash-attention P fragments (attn.hip), so V^T fragments are single 16-byte LDS reads.
 __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int R,
                                                         int C, int64_t ld_in, int64_t ld_out, int64_t in_zs,
-                                                        int64_t out_zs) {
+                                                        int64_t out_zs, int perm16) {
   __shared__ bf16_t tile[64][66];
   const int z = blockIdx.z;
   const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
@@ -165,17 +167,24 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int c = c0 + ty + i * 4, r = r0 + tx;
-    if (c < C && r < ld_out) op[(int64_t)c * ld_out + r] = tile[tx][ty + i * 4];
+    int rs = tx;  // source row (inside the tile) that lands in output column r
+    if (perm16) {
+      const int qd = (tx >> 2) & 3;
+      rs = (tx & ~12) | ((qd == 1 ? 2 : (qd == 2 ? 1 : qd)) << 2);
+    }
+    if (c < C && r < ld_out) op[(int64_t)c * ld_out + r] = tile[rs][ty + i * 4];
   }
 }
 
 int transpose_bf16(const bf16_t* in, bf16_t* out, int nz, int R, int C, int64_t ld_in, int64_t ld_out,
-                   int64_t in_zs, int64_t out_zs, hipStream_t stream) {
+                   int64_t in_zs, int64_t out_zs, int perm16, hipStream_t stream) {
   if (!in || !out || nz <= 0 || nz > 65535 || R <= 0 || C <= 0 || ld_in < C || ld_out < R) return U2_ERR_ARG;
+  if (perm16 && (ld_out & 15)) return U2_ERR_ARG;
   dim3 grid((unsigned)cdiv(ld_out, 64), (unsigned)cdiv(C, 64), nz);
   if (grid.y > 65535) return U2_ERR_ARG;
   ProfScope ps(PROF_MOVE, 0, stream);
-  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, in, out, R, C, ld_in, ld_out, in_zs, out_zs);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, in, out, R, C, ld_in, ld_out, in_zs, out_zs,
+                     perm16);
   return launch_status();
 }
 

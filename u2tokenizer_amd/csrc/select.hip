@@ -124,30 +124,50 @@ int gather_rows(const bf16_t* x, const int64_t* idx, bf16_t* out, int B, int n, 
 // ws[(b*3 + s)*ncg + cg] = sum over the 256 columns of group cg of colmean_s[e] * gate_w[e].
 __global__ __launch_bounds__(256) void dmtp_gate_partial_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gate_w,
                                                                 float* __restrict__ ws, int k, int E, int ncg) {
-  __shared__ float red[3][4];
+  // block = 256 columns of one batch element; thread (cgp = tid & 31, ty = tid >> 5) sums 8 columns over tokens
+  // ty, ty + 8, ...: every wave reads 2 x 512 contiguous bytes per token row.
+  __shared__ float red[8][32][9];
+  __shared__ float fin[3][4];
   const int b = blockIdx.y, cg = blockIdx.x;
-  const int e = cg * 256 + threadIdx.x;
+  const int cgp = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int e0 = cg * 256 + cgp * 8;
   const int lim2 = (k / 2) * 2, lim4 = (k / 4) * 4;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bf16_t* xb = x + (int64_t)b * k * E;
+  if (e0 < E) {
+    for (int t = ty; t < lim4; t += 8) {
+      const uint4 u = *reinterpret_cast<const uint4*>(xb + (int64_t)t * E + e0);
+      acc[0] += bf16lo(u.x); acc[1] += bf16hi(u.x); acc[2] += bf16lo(u.y); acc[3] += bf16hi(u.y);
+      acc[4] += bf16lo(u.z); acc[5] += bf16hi(u.z); acc[6] += bf16lo(u.w); acc[7] += bf16hi(u.w);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[ty][cgp][j] = acc[j];
+  __syncthreads();
+  // one thread per column: fixed-order reduction over the 8 token lanes, then the (<= 3) tail tokens
+  const int col = threadIdx.x, e = cg * 256 + col;
   float s1 = 0.f, s2 = 0.f, s4 = 0.f;
   if (e < E) {
-    const bf16_t* xp = x + (int64_t)b * k * E + e;
-    for (int t = 0; t < k; ++t) {
-      const float v = bf16_to_f32(xp[(int64_t)t * E]);
-      s1 += v;
-      if (t < lim2) s2 += v;
-      if (t < lim4) s4 += v;
+    float c4 = 0.f;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) c4 += red[y][col >> 3][col & 7];
+    float c2 = c4, c1 = c4;
+    for (int t = lim4; t < k; ++t) {
+      const float v = bf16_to_f32(xb[(int64_t)t * E + e]);
+      c1 += v;
+      if (t < lim2) c2 += v;
     }
     const float gw = bf16_to_f32(gate_w[e]);
-    s1 = s1 / (float)k * gw;
-    s2 = lim2 ? s2 / (float)lim2 * gw : 0.f;
-    s4 = lim4 ? s4 / (float)lim4 * gw : 0.f;
+    s1 = c1 / (float)k * gw;
+    s2 = lim2 ? c2 / (float)lim2 * gw : 0.f;
+    s4 = lim4 ? c4 / (float)lim4 * gw : 0.f;
   }
   s1 = wave_sum(s1); s2 = wave_sum(s2); s4 = wave_sum(s4);
   const int wv = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { red[0][wv] = s1; red[1][wv] = s2; red[2][wv] = s4; }
+  if ((threadIdx.x & 63) == 0) { fin[0][wv] = s1; fin[1][wv] = s2; fin[2][wv] = s4; }
   __syncthreads();
   if (threadIdx.x < 3) {
-    const float* r = red[threadIdx.x];
+    const float* r = fin[threadIdx.x];
     ws[((int64_t)b * 3 + threadIdx.x) * ncg + cg] = (r[0] + r[1]) + (r[2] + r[3]);
   }
 }

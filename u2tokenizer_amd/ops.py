@@ -94,15 +94,15 @@ def softmax_rows(s: torch.Tensor, scale=1.0, rel_bias=None, heads=1, max_len=0, 
     return p
 
 
-def transpose(x: torch.Tensor, ld_out=None):
+def transpose(x: torch.Tensor, ld_out=None, perm16=False):
     """x: (Z, R, C) bf16 -> (Z, C, ld_out) with zero padding."""
     h = _lib.load_library()
     x = _need(x, torch.bfloat16, "x").contiguous()
     Z, R, Cc = x.shape
     ld_out = ld_out or R
     y = torch.empty((Z, Cc, ld_out), dtype=torch.bfloat16, device=x.device)
-    _lib.check(h.u2tok_transpose_bf16(_ptr(x), _ptr(y), Z, R, Cc, Cc, ld_out, R * Cc, Cc * ld_out, _stream()),
-               "u2tok_transpose_bf16")
+    _lib.check(h.u2tok_transpose_bf16(_ptr(x), _ptr(y), Z, R, Cc, Cc, ld_out, R * Cc, Cc * ld_out, int(perm16),
+                                      _stream()), "u2tok_transpose_bf16")
     return y
 
 
@@ -212,7 +212,7 @@ def flash_attention_d64(qkv: torch.Tensor, heads: int, scale: float):
     vt = torch.empty((nb, Hd, S_pad), dtype=torch.bfloat16, device=qkv.device)
     v_view = qkv[:, :, 2 * Hd:]
     _lib.check(h.u2tok_transpose_bf16(v_view.data_ptr(), _ptr(vt), nb, S, Hd, 3 * Hd, S_pad, S * 3 * Hd, Hd * S_pad,
-                                      _stream()), "u2tok_transpose_bf16")
+                                      1, _stream()), "u2tok_transpose_bf16")
     out = torch.empty((nb, S, Hd), dtype=torch.bfloat16, device=qkv.device)
     _lib.check(h.u2tok_flash_attention_d64(qkv.data_ptr(), qkv.data_ptr() + 2 * Hd, _ptr(vt), _ptr(out), nb, S, heads,
                                            3 * Hd, S * 3 * Hd, Hd, S * Hd, S_pad, float(scale), _stream()),
