@@ -36,7 +36,7 @@ typedef void* u2tok_stream_t; /* hipStream_t */
 int u2tok_version(void);               /* MAJOR*10000 + MINOR*100 + PATCH */
 const char* u2tok_arch(void);          /* "gfx950" */
 int u2tok_device_check(void);          /* 0 if the current HIP device is gfx950, else U2TOK_ERR_DEVICE */
-int u2tok_set_option(const char* name, int value); /* "gemm_glds" {0,1}, "gemm_tile" {0,64,128},
+int u2tok_set_option(const char* name, int value); /* "gemm_glds" {0,1}, "gemm_tile" {0,64,128}, "gemm_bk" {32,64},
                                                       "vit_flash" {0,1}, "profile" {0,1};
                                                       returns U2TOK_ERR_ARG if unknown */
 /* With option "profile" = 1 every launch is bracketed by hipEvents on its stream.  Collect (HOST arrays of ncat <= 5

@@ -46,9 +46,11 @@ D = "cuda"
 
 @pytest.mark.parametrize("glds", [0, 1])
 @pytest.mark.parametrize("tile", [64, 128])
-def test_gemm_shapes_and_epilogues(ops, glds, tile):
+@pytest.mark.parametrize("bk", [32, 64])
+def test_gemm_shapes_and_epilogues(ops, glds, tile, bk):
     ops.set_option("gemm_glds", glds)
     ops.set_option("gemm_tile", tile)
+    ops.set_option("gemm_bk", bk)
     try:
         for (M, N, K) in [(128, 128, 64), (300, 200, 136), (77, 520, 72), (1, 8, 8), (2049, 768, 768)]:
             a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
@@ -67,6 +69,7 @@ def test_gemm_shapes_and_epilogues(ops, glds, tile):
     finally:
         ops.set_option("gemm_tile", 0)
         ops.set_option("gemm_glds", 1)
+        ops.set_option("gemm_bk", 64)
 
 
 def test_gemm_full_size_is_exact_on_integer_data(ops):

@@ -281,15 +281,15 @@ def sec_perf():
     shapes = [(16392, 2304, 768), (16392, 768, 768), (16392, 3072, 768), (16392, 768, 3072), (16384, 768, 1024),
               (2048, 4096, 4096), (2048, 2048, 2048), (256, 4096, 4096), (1792, 4096, 4096), (1024, 4096, 4096),
               (4096, 4096, 4096), (8192, 8192, 8192)]
-    for glds in (0, 1):
-        ops.set_option("gemm_glds", glds)
+    for bk in (64, 32):
+        ops.set_option("gemm_bk", bk)
         for (M, N, K) in shapes:
             a, b = rnd(M, K, seed=1).to(dev), rnd(N, K, seed=2).to(dev)
             out = torch.empty((1, M, N), dtype=bf, device=dev)
             for tile in ((64, 128) if M * N < 4096 * 4096 * 2 else (128,)):
                 ops.set_option("gemm_tile", tile)
                 ms = timeit(lambda: ops.gemm(a, b, out=out), iters=10)
-                print(f"  gemm glds={glds} tile={tile:3d} {M}x{N}x{K}: {ms * 1e3:9.1f} us  {2 * M * N * K / ms / 1e9:8.1f} TF/s",
+                print(f"  gemm bk={bk} tile={tile:3d} {M}x{N}x{K}: {ms * 1e3:9.1f} us  {2 * M * N * K / ms / 1e9:8.1f} TF/s",
                       flush=True)
     ops.set_option("gemm_tile", 0)
     ops.set_option("gemm_glds", 1)
@@ -306,10 +306,10 @@ def sec_perf():
     synth.fill_module_(vit, seed=0, prefix="vision_tower.")
     vit = vit.to(bf).to(dev)
     vol = synth.synth_volume(1, 8, [32, 256, 256], dtype=torch.float16).view(8, 1, 32, 256, 256).to(dev)
-    for glds in (0, 1):
-        ops.set_option("gemm_glds", glds)
+    for bk in (64, 32):
+        ops.set_option("gemm_bk", bk)
         ms = timeit(lambda: vit(vol), iters=5, warm=2)
-        print(f"  ViT tower 256^3 (8 chunks) glds={glds}: {ms:8.3f} ms  {4.048e12 / ms / 1e9:8.1f} TF/s", flush=True)
+        print(f"  ViT tower 256^3 (8 chunks) bk={bk}: {ms:8.3f} ms  {4.048e12 / ms / 1e9:8.1f} TF/s", flush=True)
     feats = vit(vol)
     for E in (2048, 4096):
         spp = SpatialPoolingProjector([32, 256, 256], [4, 16, 16], 768, E, "mlp", 2, "spatial", 2)
@@ -326,11 +326,11 @@ def sec_perf():
                 p.data.normal_(0, 0.02)
         v = spp(feats).view(1, 8, 256, E)
         t = (torch.randn(1, 1024, E, device=dev) * 0.05).to(bf)
-        for glds in (0, 1):
-            ops.set_option("gemm_glds", glds)
+        for bk in (64, 32):
+            ops.set_option("gemm_bk", bk)
             ms = timeit(lambda: tok(v_token=v, t_token=t), iters=5, warm=2)
             fl = {2048: 0.888e12, 4096: 3.43e12}[E]
-            print(f"  u2Tokenizer E={E} glds={glds}: {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TF/s  "
+            print(f"  u2Tokenizer E={E} bk={bk}: {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TF/s  "
                   f"finite={torch.isfinite(tok(v_token=v, t_token=t).float()).all().item()}", flush=True)
 
 

@@ -172,7 +172,14 @@ __global__ __launch_bounds__(256, 2) void flash_d64_kernel(const bf16_t* __restr
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
-  int bid = blockIdx.x;
+  // XCD-aware order: workgroup w runs on XCD w % 8 (observed dispatch rule); give every XCD a contiguous range of
+  // logical ids so that the q tiles of one (batch, head) share that XCD's L2 copy of K and V^T.
+  int bid;
+  {
+    const int nwg = gridDim.x, qn = nwg >> 3, rn = nwg & 7;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+  }
   const int qt = bid % nqt; bid /= nqt;
   const int h = bid % H;
   const int b = bid / H;

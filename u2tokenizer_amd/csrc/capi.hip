@@ -27,10 +27,15 @@ int u2tok_device_check(void) {
 
 int u2tok_set_option(const char* name, int value) {
   if (!name) return U2_ERR_ARG;
-  if (!strcmp(name, "gemm_glds")) { gemm_set_options(value ? 1 : 0, -1); return U2_OK; }
+  if (!strcmp(name, "gemm_glds")) { gemm_set_options(value ? 1 : 0, -1, -1); return U2_OK; }
   if (!strcmp(name, "gemm_tile")) {
     if (value != 0 && value != 64 && value != 128) return U2_ERR_ARG;
-    gemm_set_options(-1, value);
+    gemm_set_options(-1, value, -1);
+    return U2_OK;
+  }
+  if (!strcmp(name, "gemm_bk")) {
+    if (value != 32 && value != 64) return U2_ERR_ARG;
+    gemm_set_options(-1, -1, value);
     return U2_OK;
   }
   if (!strcmp(name, "vit_flash")) { pipeline_set_vit_flash(value); return U2_OK; }

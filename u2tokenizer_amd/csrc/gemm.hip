@@ -25,13 +25,24 @@ namespace u2 {
 
 __device__ uint4 g_zero16;  // zero-initialised; K-tail chunks of the LDS-DMA path read from here
 
-template <int BM, int BN, bool GLDS>
+// LDS chunk swizzle: XOR value for the 16-byte chunk index of `row` (see the conflict analysis in DESIGN.md):
+// BK = 64 (128-B rows, 8 chunks): row & 7;  BK = 32 (64-B rows, 4 chunks): (-(row >> 2)) & 3.
+template <int BK>
+__device__ __forceinline__ int lds_swz(int row) {
+  if constexpr (BK == 64) return row & 7;
+  else return (4 - ((row >> 2) & 3)) & 3;
+}
+
+template <int BM, int BN, int BK, bool GLDS>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
-  constexpr int BK = 64;
+  static_assert(BK == 32 || BK == 64, "BK");
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MI = WM / 16, NI = WN / 16;
-  constexpr int CA = BM * 8 / 256, CB = BN * 8 / 256;  // 16-B chunks per thread per tile
-  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int CPR = BK / 8;                              // 16-B chunks per tile row
+  constexpr int ROWB = BK * 2;                             // bytes per tile row
+  constexpr int CA = BM * CPR / 256, CB = BN * CPR / 256;  // 16-B chunks per thread per tile
+  constexpr int KSTEPS = BK / 32;
+  constexpr int STAGE = (BM + BN) * ROWB;
   extern __shared__ __attribute__((aligned(16))) char lds[];
 
   const int tid = threadIdx.x;
@@ -67,14 +78,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
   int ka[CA], kb[CB];  // k offset of the thread's chunk inside a K tile
 #pragma unroll
   for (int i = 0; i < CA; ++i) {
-    const int c = i * 256 + tid, row = c >> 3, gc = (c & 7) ^ (row & 7);
+    const int c = i * 256 + tid, row = c / CPR, gc = (c % CPR) ^ lds_swz<BK>(row);
     const int grow = min(bm0 + row, d.M - 1);
     ka[i] = gc * 8;
     pa[i] = A + (int64_t)grow * d.lda + gc * 8;
   }
 #pragma unroll
   for (int i = 0; i < CB; ++i) {
-    const int c = i * 256 + tid, row = c >> 3, gc = (c & 7) ^ (row & 7);
+    const int c = i * 256 + tid, row = c / CPR, gc = (c % CPR) ^ lds_swz<BK>(row);
     const int grow = min(bn0 + row, d.N - 1);
     kb[i] = gc * 8;
     pb[i] = B + (int64_t)grow * d.ldb + gc * 8;
@@ -86,11 +97,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // fragment read offsets: row = base + (lane & 15); (row & 7) == (lane & 7) because bases are x16
-  const int frow = (lane & 15) * 128;
-  int foff[2];
+  // fragment read offsets: row = base + (lane & 15) with bases multiples of 16, so swz(row) == swz(lane & 15)
+  const int frow = (lane & 15) * ROWB;
+  int foff[KSTEPS];
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk) foff[kk] = (((kk * 4 + (lane >> 4)) ^ (lane & 7)) << 4);
+  for (int kk = 0; kk < KSTEPS; ++kk) foff[kk] = (((kk * 4 + (lane >> 4)) ^ lds_swz<BK>(lane & 15)) << 4);
 
   const int nkt = (d.K + BK - 1) / BK;
   uint4 ra[CA], rb[CB];
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
 #pragma unroll
     for (int i = 0; i < CA; ++i) *reinterpret_cast<uint4*>(s + (i * 256 + tid) * 16) = ra[i];
 #pragma unroll
-    for (int i = 0; i < CB; ++i) *reinterpret_cast<uint4*>(s + BM * 128 + (i * 256 + tid) * 16) = rb[i];
+    for (int i = 0; i < CB; ++i) *reinterpret_cast<uint4*>(s + BM * ROWB + (i * 256 + tid) * 16) = rb[i];
   };
   auto dma = [&](int kt, int buf) {
     const int k0 = kt * BK;
@@ -125,20 +136,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
     for (int i = 0; i < CB; ++i) {
       const void* src = (k0 + kb[i] < d.K) ? (const void*)(pb[i] + k0) : (const void*)&g_zero16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(s + BM * 128 + (i * 256 + wave * 64) * 16),
+                                       (__attribute__((address_space(3))) void*)(s + BM * ROWB + (i * 256 + wave * 64) * 16),
                                        16, 0, 0);
     }
   };
   auto compute = [&](int buf) {
-    const char* sA = lds + buf * STAGE + (wm * WM) * 128 + frow;
-    const char* sB = lds + buf * STAGE + BM * 128 + (wn * WN) * 128 + frow;
+    const char* sA = lds + buf * STAGE + (wm * WM) * ROWB + frow;
+    const char* sB = lds + buf * STAGE + BM * ROWB + (wn * WN) * ROWB + frow;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < KSTEPS; ++kk) {
       bf16x8 xf[MI], wf[NI];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) xf[mi] = *reinterpret_cast<const bf16x8*>(sA + mi * 16 * 128 + foff[kk]);
+      for (int mi = 0; mi < MI; ++mi) xf[mi] = *reinterpret_cast<const bf16x8*>(sA + mi * 16 * ROWB + foff[kk]);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const bf16x8*>(sB + ni * 16 * 128 + foff[kk]);
+      for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const bf16x8*>(sB + ni * 16 * ROWB + foff[kk]);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -250,22 +261,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
 
 static int g_gemm_glds = 1;      // 1: LDS-DMA staging, 0: register staging
 static int g_gemm_force_tile = 0;  // 0: heuristic, 64 / 128: force
+static int g_gemm_bk = 64;       // K depth of one LDS stage: 64 (2 blocks/CU at 128^2) or 32 (4 blocks/CU)
 
-void gemm_set_options(int glds, int force_tile) {
+void gemm_set_options(int glds, int force_tile, int bk) {
   if (glds >= 0) g_gemm_glds = glds;
   if (force_tile >= 0) g_gemm_force_tile = force_tile;
+  if (bk == 32 || bk == 64) g_gemm_bk = bk;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 static int launch_tile(GemmDesc d, hipStream_t stream) {
   d.tiles_m = (int)cdiv(d.M, BM);
   d.tiles_n = (int)cdiv(d.N, BN);
   dim3 grid(d.tiles_m * d.tiles_n, d.nz, 1);
-  constexpr int smem = 2 * (BM + BN) * 128;
+  constexpr int smem = 2 * (BM + BN) * BK * 2;
   if (g_gemm_glds)
-    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, true>), grid, dim3(256), smem, stream, d);
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, BK, true>), grid, dim3(256), smem, stream, d);
   else
-    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, false>), grid, dim3(256), smem, stream, d);
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, BK, false>), grid, dim3(256), smem, stream, d);
   return launch_status();
 }
 
@@ -293,7 +306,8 @@ int gemm_bf16(GemmDesc d, hipStream_t stream) {
     const int64_t big = cdiv(d.M, 128) * cdiv(d.N, 128) * d.nz;
     tile = (big >= 192) ? 128 : 64;  // fill 256 CUs; small-M weight-streaming shapes get 64^2 tiles
   }
-  return tile == 128 ? launch_tile<128, 128>(d, stream) : launch_tile<64, 64>(d, stream);
+  if (g_gemm_bk == 32) return tile == 128 ? launch_tile<128, 128, 32>(d, stream) : launch_tile<64, 64, 32>(d, stream);
+  return tile == 128 ? launch_tile<128, 128, 64>(d, stream) : launch_tile<64, 64, 64>(d, stream);
 }
 
 }  // namespace u2

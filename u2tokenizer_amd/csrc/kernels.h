@@ -44,7 +44,7 @@ struct GemmDesc {
 };
 
 int gemm_bf16(GemmDesc d, hipStream_t stream);
-void gemm_set_options(int glds, int force_tile);
+void gemm_set_options(int glds, int force_tile, int bk);
 
 // ------------------------------------------------------------------ row ops (rowops.hip)
 // y[b][r][:] = LayerNorm(x[b][r][:] (+ res[b][r][:])) * w + bias   (bf16 in/out, fp32 math)
