@@ -176,9 +176,14 @@ int u2tok_multiscale_pool(const void* x, void* out, int32_t B, int32_t k, int32_
 int u2tok_temporal_attention(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t T,
                              int32_t N, int32_t H, int32_t d, int64_t ld_qkv, int64_t ld_out, float scale,
                              const void* rel_bias, int32_t max_len, u2tok_stream_t stream);
+/* softmax(q k^T * scale) v for head_dim 64 (MONAI SABlock core, vit.py:100-105) over S main rows per batch plus
+ * n_extra (0 / 1) extra row per batch that lives elsewhere (the cls token, kept after all patch rows): row r of batch b
+ * at q + b*q_bs + r*ld_qk, head h at column 64 h; vt = V^T of the main rows, [nb][H][64][S_pad] in perm16 order, zero
+ * padded; extra row of batch b at qx / kx / vx + b*x_bs, its output at outx + b*ox_bs. */
 int u2tok_flash_attention_d64(const void* q, const void* k, const void* vt, void* out, int32_t nb, int32_t S,
                               int32_t H, int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs, int32_t S_pad,
-                              float scale, u2tok_stream_t stream);
+                              float scale, const void* qx, const void* kx, const void* vx, void* outx, int64_t x_bs,
+                              int64_t ox_bs, int32_t n_extra, u2tok_stream_t stream);
 /* in-place rotate-half RoPE (rope.py:6-13,77-80): rows indexed (outer, s, inner), position = s */
 int u2tok_rope_apply(void* x, int64_t n_outer, int32_t S, int32_t n_inner, int32_t H, int32_t d, int64_t ld,
                      int32_t max_len, u2tok_stream_t stream);

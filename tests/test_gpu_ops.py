@@ -204,15 +204,51 @@ def test_temporal_attention(ops, B, T, N, H, d):
     close_bf16(got, (p @ x[2]).permute(0, 3, 1, 2, 4).reshape(B * T * N, E))
 
 
-@pytest.mark.parametrize("nb,S,H,scale", [(1, 64, 1, 1.0), (2, 129, 3, 1.0), (1, 513, 12, 1.0), (1, 2049, 2, 1.0),
-                                          (3, 100, 12, 1.0), (1, 300, 2, 3.0), (1, 1, 1, 1.0)])
-def test_flash_attention(ops, nb, S, H, scale):
-    """scale 3.0 makes the logits spiky so the online-softmax rescale branch does real work."""
-    qkv = rnd(nb, S, 3 * H * 64, scale=scale, seed=S)
-    got = ops.flash_attention_d64(qkv.to(D), H, 0.125)
+def _sdpa_ref(qkv, nb, S, H):
     x = qkv.float().view(nb, S, 3, H, 64).permute(2, 0, 3, 1, 4)
     p = F.softmax(x[0] @ x[1].transpose(-1, -2) * 0.125, dim=-1)
-    close_bf16(got, (p @ x[2]).permute(0, 2, 1, 3).reshape(nb, S, H * 64))
+    return (p @ x[2]).permute(0, 2, 1, 3).reshape(nb, S, H * 64)
+
+
+@pytest.mark.parametrize("nb,S,H,scale", [(1, 64, 1, 1.0), (2, 129, 3, 1.0), (1, 513, 12, 1.0), (1, 2049, 2, 1.0),
+                                          (3, 100, 12, 1.0), (1, 300, 2, 3.0), (1, 1, 1, 1.0)])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_flash_attention(ops, nb, S, H, scale, mode):
+    """scale 3.0 makes the logits spiky so the online-softmax rescale branch does real work.  mode = rows per
+    workgroup unit (128: one 32-row block per wave, 256: two)."""
+    qkv = rnd(nb, S, 3 * H * 64, scale=scale, seed=S)
+    ops.set_option("flash_mode", mode)
+    try:
+        got = ops.flash_attention_d64(qkv.to(D), H, 0.125)
+    finally:
+        ops.set_option("flash_mode", 0)
+    close_bf16(got, _sdpa_ref(qkv, nb, S, H))
+
+
+@pytest.mark.parametrize("nb,S,H,scale,mode", [(2, 129, 3, 1.0, 1), (1, 513, 12, 1.0, 2), (3, 257, 2, 1.0, 3),
+                                               (1, 2049, 3, 1.0, 0), (1, 2049, 3, 1.0, 1), (1, 2049, 3, 1.0, 2),
+                                               (3, 101, 12, 3.0, 0), (1, 2, 1, 1.0, 0)])
+def test_flash_attention_extra_row(ops, nb, S, H, scale, mode):
+    """The ViT path: S - 1 tiled main rows + one "extra" row per batch (the cls token) as key AND query.  The result
+    must equal plain attention over all S rows.  mode 3 (one 256-row + one 128-row unit per workgroup) needs
+    (S - 1) % 256 == 0 and nb * H % 3 == 0; the launcher falls back to mode 1 otherwise."""
+    qkv = rnd(nb, S, 3 * H * 64, scale=scale, seed=S + 1)
+    ops.set_option("flash_mode", mode)
+    try:
+        got = ops.flash_attention_d64(qkv.to(D), H, 0.125, extra_last=True)
+    finally:
+        ops.set_option("flash_mode", 0)
+    close_bf16(got, _sdpa_ref(qkv, nb, S, H))
+
+
+def test_flash_attention_extra_key_forces_rescale(ops):
+    """The extra key dominates every query: the rescale branch of the post-loop VALU step must fire."""
+    nb, S, H = 1, 257, 3
+    qkv = rnd(nb, S, 3 * H * 64, seed=91)
+    for h in range(H):
+        qkv[0, S - 1, 64 * H + 64 * h: 64 * H + 64 * (h + 1)] = (qkv[0, :, 64 * h:64 * (h + 1)].float().mean(0) * 60).to(bf)
+    got = ops.flash_attention_d64(qkv.to(D), H, 0.125, extra_last=True)
+    close_bf16(got, _sdpa_ref(qkv, nb, S, H))
 
 
 def test_flash_attention_forced_rescale(ops):
@@ -225,3 +261,42 @@ def test_flash_attention_forced_rescale(ops):
     x = qkv.float().view(nb, S, 3, H, 64).permute(2, 0, 3, 1, 4)
     p = F.softmax(x[0] @ x[1].transpose(-1, -2) * 0.125, dim=-1)
     close_bf16(got, (p @ x[2]).permute(0, 2, 1, 3).reshape(nb, S, 64))
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_gemm_pingpong_variants(ops, variant):
+    """gemm_pp.hip (persistent 256 x BN ping-pong kernel) forced on shapes with row / column / K tails, several
+    tiles per workgroup, every fused epilogue, batches; each product is launched 3 times and must repeat bit for
+    bit (a race between the LDS-DMA ring and the fragment reads would not)."""
+    ops.set_option("gemm_pp", variant)
+    try:
+        for (M, N, K) in [(256, 256, 64), (300, 200, 136), (77, 520, 72), (1000, 768, 1024), (2049, 768, 768),
+                          (5000, 1536, 256)]:
+            a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
+            ad, bd = a.to(D), b.to(D)
+            outs = [ops.gemm(ad, bd).clone() for _ in range(3)]
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+            close_bf16(outs[0], a.float() @ b.float().t())
+        M, N, K = 515, 264, 200
+        a, b, bias, res = rnd(M, K, seed=3), rnd(N, K, seed=4), rnd(N, seed=5), rnd(M, N, seed=6)
+        base = a.float() @ b.float().t()
+        ad, bd, biasd, resd = a.to(D), b.to(D), bias.to(D), res.to(D)
+        close_bf16(ops.gemm(ad, bd, bias=biasd), base + bias.float())
+        close_bf16(ops.gemm(ad, bd, bias=biasd, gelu=True), F.gelu(base + bias.float()))
+        close_bf16(ops.gemm(ad, bd, bias=biasd, residual=resd), base + bias.float() + res.float())
+        close_bf16(ops.gemm(ad, bd, residual=resd), base + res.float())
+        close_f32(ops.gemm(ad, bd, bias=biasd, out_f32=True, alpha=0.5), 0.5 * base + bias.float())
+        close_f32(ops.gemm(ad, bd, out_f32=True), base)
+        a3, b3 = rnd(6, 300, 64, seed=10), rnd(6, 96, 64, seed=11)
+        close_f32(ops.gemm(a3.to(D), b3.to(D), out_f32=True), torch.einsum("zmk,znk->zmn", a3.float(), b3.float()))
+    finally:
+        ops.set_option("gemm_pp", 0)
+
+
+def test_gemm_heuristic_split_rows(ops):
+    """M = 8 * 2049 (the ViT's row count): the launcher sends 16384 rows to the ping-pong kernel and the 8 leftover
+    rows to the small-tile kernel; the seam must be invisible."""
+    M, N, K = 16392, 768, 768
+    a, b, bias, res = rnd(M, K, seed=21), rnd(N, K, seed=22), rnd(N, seed=23), rnd(M, N, seed=24)
+    got = ops.gemm(a.to(D), b.to(D), bias=bias.to(D), residual=res.to(D))
+    close_bf16(got, a.float() @ b.float().t() + bias.float() + res.float())

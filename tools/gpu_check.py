@@ -275,6 +275,101 @@ def sec_modules():
         print(f"   topk idx {m.model.u2tokenizer.last_topk_indices.cpu().tolist()}", flush=True)
 
 
+
+# ------------------------------------------------------------------------------------------- ping-pong GEMM
+def _pp_cases():
+    return [  # (M, N, K, kwargs)
+        (256, 256, 64, {}), (256, 192, 128, {}), (512, 384, 256, {}), (300, 200, 136, {}), (77, 520, 72, {}),
+        (1000, 768, 1024, {}), (2049, 2304, 768, {}), (515, 264, 200, dict(bias=True, gelu=True)),
+        (515, 264, 200, dict(bias=True, residual=True)), (515, 264, 200, dict(residual=True)),
+        (515, 264, 200, dict(bias=True, out_f32=True, alpha=0.5)), (515, 264, 200, dict(out_f32=True)),
+        (8192, 3072, 256, dict(bias=True)), (4096, 1536, 768, dict(bias=True, residual=True)),
+        (16392, 768, 768, dict(bias=True, residual=True)),
+    ]
+
+
+def sec_ppc(v=None):
+    """correctness + repeatability of one forced ping-pong variant (python tools/gpu_check.py ppc:<v>)"""
+    vs = [int(v)] if v else list(range(1, 9))
+    for v in vs:
+        ops.set_option("gemm_pp", v)
+        print(f"[pp correctness] variant {v}", flush=True)
+        for (M, N, K, kw) in _pp_cases():
+            a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
+            bias = rnd(N, seed=3) if kw.get("bias") else None
+            res = rnd(M, N, seed=4) if kw.get("residual") else None
+            ref = kw.get("alpha", 1.0) * (a.float() @ b.float().t())
+            if bias is not None:
+                ref = ref + bias.float()
+            if kw.get("gelu"):
+                ref = F.gelu(ref)
+            if res is not None:
+                ref = ref + res.float()
+            args = dict(bias=None if bias is None else bias.to(dev), residual=None if res is None else res.to(dev),
+                        gelu=bool(kw.get("gelu")), out_f32=bool(kw.get("out_f32")), alpha=kw.get("alpha", 1.0))
+            ad, bd = a.to(dev), b.to(dev)
+            outs = [ops.gemm(ad, bd, **args).clone() for _ in range(4)]
+            same = all(torch.equal(outs[0], o) for o in outs[1:])
+            stats(f"v{v} {M}x{N}x{K} {sorted(kw)}", outs[0], ref, extra=f"repeatable={same}")
+        # batched (z-major tiles)
+        a3, b3 = rnd(6, 300, 64, seed=10), rnd(6, 96, 64, seed=11)
+        got = ops.gemm(a3.to(dev), b3.to(dev), out_f32=True)
+        stats(f"v{v} batched 6x(300x96x64)", got, torch.einsum("zmk,znk->zmn", a3.float(), b3.float()))
+    ops.set_option("gemm_pp", 0)
+
+
+def sec_ppperf():
+    print("[pp perf] (random normal operands; us and TF/s; c = classic 128^2/64^2 kernel, a = heuristic)", flush=True)
+    shapes = [(16384, 2304, 768, {}), (16392, 2304, 768, {}), (16384, 768, 768, dict(bias=True, residual=True)),
+              (16384, 3072, 768, dict(bias=True, gelu=True)), (16384, 3072, 768, dict(bias=True)),
+              (16384, 768, 3072, dict(bias=True, residual=True)), (16384, 768, 1024, dict(bias=True, residual=True)),
+              (2048, 4096, 4096, dict(bias=True)), (2048, 12288, 4096, dict(bias=True)), (1792, 8192, 4096, dict(bias=True)),
+              (1024, 8192, 4096, dict(bias=True)), (1024, 4096, 4096, dict(bias=True)), (256, 4096, 4096, dict(bias=True)),
+              (256, 12288, 4096, dict(bias=True)), (2048, 1024, 4096, {}), (4096, 4096, 4096, {}), (8192, 8192, 8192, {})]
+    for (M, N, K, kw) in shapes:
+        a, b = rnd(M, K, seed=1).to(dev), rnd(N, K, seed=2).to(dev)
+        bias = rnd(N, seed=3).to(dev) if kw.get("bias") else None
+        res = rnd(M, N, seed=4).to(dev) if kw.get("residual") else None
+        out = torch.empty((1, M, N), dtype=bf, device=dev)
+        line = f"  {M:5d}x{N:5d}x{K:4d} {'+'.join(sorted(kw)) or '-':18s}"
+        for v in (-1, 0, 1, 2, 3, 4, 5, 6, 7, 8):
+            ops.set_option("gemm_pp", v)
+            try:
+                ms = timeit(lambda: ops.gemm(a, b, bias=bias, residual=res, gelu=bool(kw.get("gelu")), out=out), iters=8, warm=2)
+                line += f" | {'c' if v < 0 else ('a' if v == 0 else v)} {ms * 1e3:6.1f} {2 * M * N * K / ms / 1e9:5.0f}"
+            except Exception as e:  # noqa: BLE001
+                line += f" | {v} ERR"
+        print(line, flush=True)
+    ops.set_option("gemm_pp", 0)
+
+
+def sec_flashperf():
+    print("[flash perf] nb=8 H=12 (the ViT-B block at 256^3): us per launch incl. the V transpose, TF/s, MFMA util of 2.5 PF", flush=True)
+    for (nb, S, H, extra) in [(8, 2049, 12, True), (8, 2049, 12, False), (8, 2048, 12, False), (16, 513, 12, True)]:
+        qkv = rnd(nb, S, 3 * H * 64, seed=3).to(dev)
+        fl = 4 * nb * H * S * S * 64
+        for mode in (1, 2, 3):
+            ops.set_option("flash_mode", mode)
+            ms = timeit(lambda: ops.flash_attention_d64(qkv, H, 0.125, extra_last=extra), iters=10)
+            # the transpose alone
+            ref = _flash_ref(qkv[:1, :, :], H)
+            got = ops.flash_attention_d64(qkv[:1].contiguous(), H, 0.125, extra_last=extra)
+            err = (got.float() - ref).abs().max().item()
+            print(f"  nb={nb} S={S} extra={int(extra)} mode={mode}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF/s  "
+                  f"util={fl / ms / 1e9 / 2500:.3f}  max_err={err:.2e}", flush=True)
+    ops.set_option("flash_mode", 0)
+    qkv = rnd(8, 2049, 3 * 768, seed=3).to(dev)
+    vt = torch.empty((8, 768, 2048), dtype=bf, device=dev)
+    ms = timeit(lambda: ops.transpose(qkv[:, :2048, 1536:].contiguous(), ld_out=2048, perm16=True), iters=10)
+    print(f"  (V slice copy + transpose alone: {ms * 1e3:8.1f} us)", flush=True)
+
+
+def _flash_ref(qkv, H):
+    nb, S, _ = qkv.shape
+    x = qkv.float().view(nb, S, 3, H, 64).permute(2, 0, 3, 1, 4)
+    p = F.softmax(x[0] @ x[1].transpose(-1, -2) * 0.125, dim=-1)
+    return (p @ x[2]).permute(0, 2, 1, 3).reshape(nb, S, H * 64)
+
 # ------------------------------------------------------------------------------------------- perf
 def sec_perf():
     print("[perf]", flush=True)
@@ -339,5 +434,6 @@ if __name__ == "__main__":
     ops.device_check()
     t0 = time.time()
     for s in sys.argv[1:]:
-        globals()["sec_" + s]()
+        name, _, arg = s.partition(":")
+        globals()["sec_" + name](*([arg] if arg else []))
     print(f"done in {time.time() - t0:.1f}s", flush=True)

@@ -82,7 +82,7 @@ SIGNATURES = {
     "u2tok_temporal_attention": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _f32, _vp,
                                         _i32, _vp]),
     "u2tok_flash_attention_d64": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _f32,
-                                         _vp]),
+                                         _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "u2tok_rope_apply": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i64, _i32, _vp]),
 }
 

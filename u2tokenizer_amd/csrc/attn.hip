@@ -147,68 +147,82 @@ int temporal_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t
 }
 
 // ================================================================= flash attention, head dim 64
-// Block = 4 waves, 128 query rows (32 per wave), KV tiles of 64 keys, v_mfma_f32_32x32x16_bf16.
-//   S^T = K Q^T : A = K fragment (LDS), B = Q fragment (registers, loaded once).  Lane (q = lane&31, hi)
-//                 then owns 16 keys of each 32-key block -> row max/sum are lane-local + one xor-32.
-//   O^T = V^T P^T: A = V^T fragment (LDS, V pre-transposed in HBM), B = P^T = the lane's own exp'd
-//                 scores packed to bf16 -- NO cross-lane movement: the k-slot -> key mapping of the MFMA
-//                 is a free permutation as long as A and B agree, so V^T is stored in P's native order:
-//                 inside every group of 16 keys the HBM/LDS column order is [0-3, 8-11, 4-7, 12-15]
-//                 (transpose_bf16(..., perm16 = 1)), which makes each lane's 8 k-slots one 16-byte read.
-//   O^T accumulators keep q = lane&31 per lane, so the online-softmax rescale is lane-local too; it is
-//   deferred until some row's running max grows by more than 2^8 (wave-uniform branch), the softmax scale
-//   is folded into one FMA per score, and key masking runs only in the last (partial) KV tile.
+// Sequence = S "main" rows per batch (contiguous, leading dim ld) + an optional single EXTRA row per batch stored
+// elsewhere (the ViT keeps its cls token after all patch rows, so that the 2048 patch rows tile exactly and the
+// GEMMs see M = 16384 + 8 instead of 8 x 2049).
+//
+// A pass = 4 waves x QB blocks of 32 query rows against all keys; KV tiles of 64 keys, v_mfma_f32_32x32x16_bf16.
+//   S^T = K Q^T : A = K fragment (LDS), B = Q fragment (registers, loaded once).  Lane (q = lane&31, hi) then
+//                 owns 16 keys of each 32-key block -> row max/sum are lane-local + one xor-32.
+//   O^T = V^T P^T: A = V^T fragment (LDS, V pre-transposed in HBM), B = P^T = the lane's own exp'd scores packed
+//                 to bf16 -- NO cross-lane movement: the k-slot -> key map of the MFMA is a free permutation as
+//                 long as A and B agree, so V^T is stored in P's native order: inside every group of 16 keys the
+//                 column order is [0-3, 8-11, 4-7, 12-15] (transpose_bf16(..., perm16 = 1)), which makes each
+//                 lane's 8 k-slots one 16-byte read.
+//   QB = 2 reads every K / V^T fragment once for TWO MFMAs: the QB = 1 form spends ~80 % of the LDS bandwidth
+//   of a CU on fragment reads (each wave re-reads the whole 16 KB tile for 32 rows), QB = 2 halves that.
+//   The online-softmax rescale is lane-local (O^T keeps q = lane&31 per lane) and deferred until some row's
+//   running max grows by more than 2^8 (wave-uniform branch); the softmax scale is folded into one FMA per score;
+//   key masking only in a partial last tile; the extra key is one VALU step after the tile loop.
+// Work split ("mode"): 1 = uniform QB = 1 (128-row units), 2 = uniform QB = 2 (256-row units), 3 = every
+//   workgroup runs one 256-row unit (QB = 2) and then one 128-row unit (QB = 1).  At the ViT's 96 heads x 2048
+//   rows mode 3 is exactly one full wave of 512 workgroups (2 per CU); modes 1 / 2 need 3 / 1.5 rounds.
+// Extra query rows (one per head) are handled by small VALU workgroups at the end of the grid.
 // LDS tiles ([64][64] bf16, 128 B rows): 16-byte chunks XOR-swizzled with (row>>1)&7 -> conflict-free
 // ds_read_b128 for the 32x32 fragment pattern.
 __device__ __forceinline__ uint32_t kt_off(int row, int chunk) {  // 16-B chunk index 0..7
   return (uint32_t)(row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
 }
 
-__global__ __launch_bounds__(256, 2) void flash_d64_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
-                                                           const bf16_t* __restrict__ vt, bf16_t* __restrict__ out, int S, int H,
-                                                           int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs,
-                                                           int S_pad, float scale_log2e, int nqt) {
-  __shared__ __attribute__((aligned(16))) char lds[2][16384];  // [stage][K tile 8 KB | V^T tile 8 KB]
-  const int tid = threadIdx.x, lane = tid & 63;
+struct FlashArgs {
+  const bf16_t *q, *k, *vt;
+  bf16_t* out;
+  const bf16_t *qx, *kx, *vx;
+  bf16_t* outx;
+  int S, H, nb, S_pad, n_extra, mode, n_main;
+  int64_t ld_qk, q_bs, ld_out, out_bs, x_bs, ox_bs;
+  float scale_log2e;
+};
+
+constexpr float FLASH_RESCALE_THR = 8.0f;
+
+template <int QB>
+__device__ __forceinline__ void flash_pass(const FlashArgs& a, char (*lds)[16384], const int b, const int h, const int row0,
+                                           const int tid) {
+  const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
-  // XCD-aware order: workgroup w runs on XCD w % 8 (observed dispatch rule); give every XCD a contiguous range of
-  // logical ids so that the q tiles of one (batch, head) share that XCD's L2 copy of K and V^T.
-  int bid;
-  {
-    const int nwg = gridDim.x, qn = nwg >> 3, rn = nwg & 7;
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
-  }
-  const int qt = bid % nqt; bid /= nqt;
-  const int h = bid % H;
-  const int b = bid / H;
-  const bf16_t* qb = q + (int64_t)b * q_bs + h * 64;
-  const bf16_t* kb = k + (int64_t)b * q_bs + h * 64;
-  const bf16_t* vb = vt + ((int64_t)b * H + h) * 64 * S_pad;
+  const int S = a.S;
+  const bf16_t* qb_ = a.q + (int64_t)b * a.q_bs + h * 64;
+  const bf16_t* kb_ = a.k + (int64_t)b * a.q_bs + h * 64;
+  const bf16_t* vb_ = a.vt + ((int64_t)b * a.H + h) * 64 * a.S_pad;
+  const int64_t ld_qk = a.ld_qk;
+  const int S_pad = a.S_pad;
+  const float scale_log2e = a.scale_log2e;
 
-  // a wave whose 32 rows are all past the sequence end only helps with staging (S = 2049: the 17th q tile)
-  const bool wave_active = (qt * 128 + wv * 32) < S;
-  const int qrow = qt * 128 + wv * 32 + l31;
-  bf16x8 qf[4];  // Q fragments (B operand): Q[q][d = ks*16 + hi*8 .. +7]
-  {
-    const bf16_t* qp = qb + (int64_t)min(qrow, S - 1) * ld_qk + hi * 8;
+  // a wave whose rows are all past the sequence end only helps with staging
+  const int wrow0 = row0 + wv * 32 * QB;
+  const bool wave_active = wrow0 < S;
+  bf16x8 qf[QB][4];  // Q fragments (B operand): Q[q][d = ks*16 + hi*8 .. +7]
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+  for (int qb = 0; qb < QB; ++qb) {
+    const bf16_t* qp = qb_ + (int64_t)min(wrow0 + qb * 32 + l31, S - 1) * ld_qk + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
   }
 
   // staging: K tile = 64 rows x 8 chunks, V^T tile = 64 rows x 8 chunks; 2 chunks of each per thread.
   // Named scalars + macros on purpose: arrays captured by lambdas ended up in scratch memory here.
   const int srow0 = tid >> 3, srow1 = 32 + (tid >> 3), sch = tid & 7;
-  const bf16_t* vsrc0 = vb + (int64_t)srow0 * S_pad + sch * 8;
-  const bf16_t* vsrc1 = vb + (int64_t)srow1 * S_pad + sch * 8;
+  const bf16_t* vsrc0 = vb_ + (int64_t)srow0 * S_pad + sch * 8;
+  const bf16_t* vsrc1 = vb_ + (int64_t)srow1 * S_pad + sch * 8;
   const uint32_t soff0 = kt_off(srow0, sch), soff1 = kt_off(srow1, sch);
   uint4 rk0, rk1, rv0, rv1;
 #define U2_FLASH_GLOAD(t_)                                                                                       \
   do {                                                                                                           \
     const int kv0_ = (t_) * 64;                                                                                  \
-    rk0 = *reinterpret_cast<const uint4*>(kb + (int64_t)min(kv0_ + srow0, S - 1) * ld_qk + sch * 8);            \
-    rk1 = *reinterpret_cast<const uint4*>(kb + (int64_t)min(kv0_ + srow1, S - 1) * ld_qk + sch * 8);            \
+    rk0 = *reinterpret_cast<const uint4*>(kb_ + (int64_t)min(kv0_ + srow0, S - 1) * ld_qk + sch * 8);           \
+    rk1 = *reinterpret_cast<const uint4*>(kb_ + (int64_t)min(kv0_ + srow1, S - 1) * ld_qk + sch * 8);           \
     rv0 = *reinterpret_cast<const uint4*>(vsrc0 + kv0_);                                                         \
     rv1 = *reinterpret_cast<const uint4*>(vsrc1 + kv0_);                                                         \
   } while (0)
@@ -220,13 +234,17 @@ __global__ __launch_bounds__(256, 2) void flash_d64_kernel(const bf16_t* __restr
     *reinterpret_cast<uint4*>(&lds[st_][8192 + soff1]) = rv1;                 \
   } while (0)
 
-  f32x16 oacc[2];
+  f32x16 oacc[QB][2];
+  float m_run[QB], l_run[QB];  // m_run in scaled (log2) units
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb)
+  for (int qb = 0; qb < QB; ++qb) {
+    m_run[qb] = -INFINITY;
+    l_run[qb] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[nb][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;  // m_run in scaled (log2) units
-  constexpr float RESCALE_THR = 8.0f;
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[qb][nb][r] = 0.f;
+  }
 
   const int ntile = (S + 63) >> 6;
   U2_FLASH_GLOAD(0);
@@ -236,73 +254,89 @@ __global__ __launch_bounds__(256, 2) void flash_d64_kernel(const bf16_t* __restr
   // waitcnt pass then drains vmcnt to 0 in front of the first QK^T MFMAs of EVERY iteration -- i.e. it waits for
   // the K/V prefetch issued a few instructions earlier and exposes the full HBM latency per tile.
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks]));
+  for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[qb][ks]));
   for (int t = 0; t < ntile; ++t) {
     const int st = t & 1;
     if (t + 1 < ntile) U2_FLASH_GLOAD(t + 1);
     if (wave_active) {
       const char* sK = lds[st];
       const char* sV = lds[st] + 8192;
-      // ---- S^T = K Q^T for the two 32-key blocks
-      f32x16 sc[2];
+      // ---- S^T = K Q^T for the two 32-key blocks; every K fragment feeds QB MFMAs
+      f32x16 sc[QB][2];
 #pragma unroll
       for (int kbk = 0; kbk < 2; ++kbk) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sc[kbk][r] = 0.f;
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc[qb][kbk][r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + kt_off(kbk * 32 + l31, ks * 2 + hi));
-          sc[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[kbk], 0, 0, 0);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb)
+            sc[qb][kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], sc[qb][kbk], 0, 0, 0);
         }
       }
       // lane owns keys kv = t*64 + kbk*32 + (r&3) + 8*(r>>2) + 4*hi ; only the last tile can be partial
       if (t == ntile - 1 && (S & 63)) {
         const int kvb = t * 64 + 4 * hi;
 #pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+          for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (kvb + kbk * 32 + (r & 3) + 8 * (r >> 2) >= S) sc[qb][kbk][r] = -INFINITY;
+      }
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        float mt = -INFINITY;
+#pragma unroll
         for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (kvb + kbk * 32 + (r & 3) + 8 * (r >> 2) >= S) sc[kbk][r] = -INFINITY;
-      }
-      float mt = -INFINITY;
+          for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sc[qb][kbk][r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale_log2e;  // scale > 0: max commutes with it
+        if (__any(mt > m_run[qb] + FLASH_RESCALE_THR)) {  // wave-uniform; always taken on the first tile
+          const float m_new = fmaxf(m_run[qb], mt);
+          const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+          m_run[qb] = m_new;
+          l_run[qb] *= alpha;
 #pragma unroll
-      for (int kbk = 0; kbk < 2; ++kbk)
+          for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sc[kbk][r]);
-      mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale_log2e;  // scale > 0: max commutes with it
-      if (__any(mt > m_run + RESCALE_THR)) {  // wave-uniform; always taken on the first tile (m_run = -inf)
-        const float m_new = fmaxf(m_run, mt);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        l_run *= alpha;
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[nb][r] *= alpha;
-      }
-      float ps = 0.f;
-#pragma unroll
-      for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kbk][r], scale_log2e, -m_run));
-          sc[kbk][r] = p;
-          ps += p;
+            for (int r = 0; r < 16; ++r) oacc[qb][nb][r] *= alpha;
         }
-      l_run += ps;
+        float ps = 0.f;
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[qb][kbk][r], scale_log2e, -m_run[qb]));
+            sc[qb][kbk][r] = p;
+            ps += p;
+          }
+        l_run[qb] += ps;
+      }
       // ---- O^T += V^T P^T ; k-slots jj of step (kbk, ks2) carry keys kbk*32 + 16*ks2 + 8*(jj>>2) + 4*hi + (jj&3),
       //      which is exactly 16-byte chunk (kbk*2 + ks2)*2 + hi of the permuted V^T row
 #pragma unroll
       for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
         for (int ks2 = 0; ks2 < 2; ++ks2) {
-          union { bf16x8 v; uint32_t u[4]; } pf;
+          union { bf16x8 v; uint32_t u[4]; } pf[QB];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) pf.u[j] = pack2_bf16(sc[kbk][ks2 * 8 + 2 * j], sc[kbk][ks2 * 8 + 2 * j + 1]);
+          for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              pf[qb].u[j] = pack2_bf16(sc[qb][kbk][ks2 * 8 + 2 * j], sc[qb][kbk][ks2 * 8 + 2 * j + 1]);
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb) {
             const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + kt_off(nb * 32 + l31, (kbk * 2 + ks2) * 2 + hi));
-            oacc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, oacc[nb], 0, 0, 0);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+              oacc[qb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb].v, oacc[qb][nb], 0, 0, 0);
           }
         }
     }
@@ -311,35 +345,221 @@ __global__ __launch_bounds__(256, 2) void flash_d64_kernel(const bf16_t* __restr
   }
 #undef U2_FLASH_GLOAD
 #undef U2_FLASH_LSTORE
-  // ---- epilogue: O^T[d][q] / l ; lane: q = lane&31, d = nb*32 + (r&3) + 8*(r>>2) + 4*hi
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.f / l_tot;
-  if (qrow < S) {
-    bf16_t* op = out + (int64_t)b * out_bs + (int64_t)qrow * ld_out + h * 64;
+  if (!wave_active) return;
+  // ---- the extra key (one per batch): scores on the VALU from the Q fragments the lane already holds
+  if (a.n_extra) {
+    const bf16_t* kxp = a.kx + (int64_t)b * a.x_bs + h * 64 + hi * 8;
+    const bf16_t* vxp = a.vx + (int64_t)b * a.x_bs + h * 64 + 4 * hi;
+    uint4 kc[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kc[ks] = *reinterpret_cast<const uint4*>(kxp + ks * 16);
+    uint2 vc[2][4];  // V[d], d = nb*32 + 8g + 4hi + e : the 32 rows of O^T this lane owns
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d0 = nb * 32 + 8 * g + 4 * hi;
-        *reinterpret_cast<uint2*>(op + d0) = uint2{pack2_bf16(oacc[nb][4 * g] * inv, oacc[nb][4 * g + 1] * inv),
-                                                   pack2_bf16(oacc[nb][4 * g + 2] * inv, oacc[nb][4 * g + 3] * inv)};
+      for (int g = 0; g < 4; ++g) vc[nb][g] = *reinterpret_cast<const uint2*>(vxp + nb * 32 + 8 * g);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      float part = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        union { bf16x8 v; uint32_t u[4]; } qq;
+        qq.v = qf[qb][ks];
+        const uint32_t kw[4] = {kc[ks].x, kc[ks].y, kc[ks].z, kc[ks].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          part = __builtin_fmaf(bf16lo(qq.u[j]), bf16lo(kw[j]), part);
+          part = __builtin_fmaf(bf16hi(qq.u[j]), bf16hi(kw[j]), part);
+        }
       }
+      const float mt = (part + __shfl_xor(part, 32, 64)) * scale_log2e;
+      if (__any(mt > m_run[qb] + FLASH_RESCALE_THR)) {
+        const float m_new = fmaxf(m_run[qb], mt);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+        m_run[qb] = m_new;
+        l_run[qb] *= alpha;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[qb][nb][r] *= alpha;
+      }
+      const float p = __builtin_amdgcn_exp2f(mt - m_run[qb]);
+      l_run[qb] += 0.5f * p;  // both half-waves hold the same key: the xor-32 sum below counts it once
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          oacc[qb][nb][4 * g + 0] = __builtin_fmaf(p, bf16lo(vc[nb][g].x), oacc[qb][nb][4 * g + 0]);
+          oacc[qb][nb][4 * g + 1] = __builtin_fmaf(p, bf16hi(vc[nb][g].x), oacc[qb][nb][4 * g + 1]);
+          oacc[qb][nb][4 * g + 2] = __builtin_fmaf(p, bf16lo(vc[nb][g].y), oacc[qb][nb][4 * g + 2]);
+          oacc[qb][nb][4 * g + 3] = __builtin_fmaf(p, bf16hi(vc[nb][g].y), oacc[qb][nb][4 * g + 3]);
+        }
+    }
+  }
+  // ---- epilogue: O^T[d][q] / l ; lane: q = lane&31, d = nb*32 + (r&3) + 8*(r>>2) + 4*hi
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+    const float inv = 1.f / l_tot;
+    const int qrow = wrow0 + qb * 32 + l31;
+    if (qrow < S) {
+      bf16_t* op = a.out + (int64_t)b * a.out_bs + (int64_t)qrow * a.ld_out + h * 64;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = nb * 32 + 8 * g + 4 * hi;
+          *reinterpret_cast<uint2*>(op + d0) =
+              uint2{pack2_bf16(oacc[qb][nb][4 * g] * inv, oacc[qb][nb][4 * g + 1] * inv),
+                    pack2_bf16(oacc[qb][nb][4 * g + 2] * inv, oacc[qb][nb][4 * g + 3] * inv)};
+        }
+    }
   }
 }
 
+// The extra QUERY row of head (b, h) against all S + 1 keys, on the VALU (256 threads): scores key-parallel,
+// softmax through LDS, P V with 4 lanes per output column walking the permuted V^T rows.
+__device__ __forceinline__ void flash_extra_row(const FlashArgs& a, char* lds_raw, const int b, const int h, const int tid) {
+  float* sbuf = reinterpret_cast<float*>(lds_raw);            // [S_pad] scaled scores -> probabilities
+  float* red = reinterpret_cast<float*>(lds_raw) + a.S_pad;   // [8] block reductions
+  const int S = a.S, S_pad = a.S_pad;
+  const int lane = tid & 63, wv = tid >> 6;
+  const float c = a.scale_log2e;
+  uint4 qv[8];
+  {
+    const bf16_t* qp = a.qx + (int64_t)b * a.x_bs + h * 64;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qv[i] = *reinterpret_cast<const uint4*>(qp + i * 8);
+  }
+  auto dot_row = [&](const bf16_t* kp) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint4 kk = *reinterpret_cast<const uint4*>(kp + i * 8);
+      acc = __builtin_fmaf(bf16lo(qv[i].x), bf16lo(kk.x), acc); acc = __builtin_fmaf(bf16hi(qv[i].x), bf16hi(kk.x), acc);
+      acc = __builtin_fmaf(bf16lo(qv[i].y), bf16lo(kk.y), acc); acc = __builtin_fmaf(bf16hi(qv[i].y), bf16hi(kk.y), acc);
+      acc = __builtin_fmaf(bf16lo(qv[i].z), bf16lo(kk.z), acc); acc = __builtin_fmaf(bf16hi(qv[i].z), bf16hi(kk.z), acc);
+      acc = __builtin_fmaf(bf16lo(qv[i].w), bf16lo(kk.w), acc); acc = __builtin_fmaf(bf16hi(qv[i].w), bf16hi(kk.w), acc);
+    }
+    return acc;
+  };
+  const bf16_t* kb_ = a.k + (int64_t)b * a.q_bs + h * 64;
+  const float sx = dot_row(a.kx + (int64_t)b * a.x_bs + h * 64) * c;  // the extra key (every thread, redundantly)
+  float m = sx;
+  for (int j = tid; j < S_pad; j += 256) {
+    float s = -INFINITY;  // padding columns of V^T are zero: probability 0 there
+    if (j < S) s = dot_row(kb_ + (int64_t)j * a.ld_qk) * c;
+    sbuf[j] = s;
+    m = fmaxf(m, s);
+  }
+  m = wave_max(m);
+  if (lane == 0) red[wv] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int j = tid; j < S_pad; j += 256) {
+    const float p = __builtin_amdgcn_exp2f(sbuf[j] - m);
+    sbuf[j] = p;
+    sum += p;
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wv] = sum;
+  __syncthreads();
+  const float px = __builtin_amdgcn_exp2f(sx - m);
+  const float l_tot = red[4] + red[5] + red[6] + red[7] + px;
+  // O[d] = sum_j p_j V[j][d]: thread (d = tid >> 2, part = tid & 3) walks 16-byte pieces of row d of V^T; inside a
+  // group of 16 keys the stored order is [0-3, 8-11, 4-7, 12-15], i.e. piece (G, hh) holds keys 16G + 4hh + {0..3}
+  // and 16G + 8 + 4hh + {0..3}.
+  const int d = tid >> 2, part = tid & 3;
+  const bf16_t* vrow = a.vt + (((int64_t)b * a.H + h) * 64 + d) * S_pad;
+  float o = 0.f;
+  for (int pc = part; pc < S_pad / 8; pc += 4) {
+    const uint4 vv = *reinterpret_cast<const uint4*>(vrow + pc * 8);
+    const int G = pc >> 1, hh = pc & 1;
+    const float4 p0 = *reinterpret_cast<const float4*>(sbuf + 16 * G + 4 * hh);
+    const float4 p1 = *reinterpret_cast<const float4*>(sbuf + 16 * G + 8 + 4 * hh);
+    o = __builtin_fmaf(p0.x, bf16lo(vv.x), o); o = __builtin_fmaf(p0.y, bf16hi(vv.x), o);
+    o = __builtin_fmaf(p0.z, bf16lo(vv.y), o); o = __builtin_fmaf(p0.w, bf16hi(vv.y), o);
+    o = __builtin_fmaf(p1.x, bf16lo(vv.z), o); o = __builtin_fmaf(p1.y, bf16hi(vv.z), o);
+    o = __builtin_fmaf(p1.z, bf16lo(vv.w), o); o = __builtin_fmaf(p1.w, bf16hi(vv.w), o);
+  }
+  o += __shfl_xor(o, 1, 64);
+  o += __shfl_xor(o, 2, 64);
+  if (part == 0) {
+    o = __builtin_fmaf(px, bf16_to_f32(a.vx[(int64_t)b * a.x_bs + h * 64 + d]), o);
+    a.outx[(int64_t)b * a.ox_bs + h * 64 + d] = f32_to_bf16(o / l_tot);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void flash_d64_kernel(const FlashArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[2][16384];  // [stage][K tile 8 KB | V^T tile 8 KB]
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= a.n_main) {  // extra query rows: one workgroup per (batch, head)
+    const int e = blockIdx.x - a.n_main;
+    flash_extra_row(a, &lds[0][0], e / a.H, e % a.H, tid);
+    return;
+  }
+  // XCD-aware order: workgroup w runs on XCD w % 8 (observed dispatch rule); give every XCD a contiguous range of
+  // logical ids so that the units of one (batch, head) share that XCD's L2 copy of K and V^T.
+  int bid;
+  {
+    const int nwg = a.n_main, qn = nwg >> 3, rn = nwg & 7;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+  }
+  const int nbh = a.nb * a.H;
+  if (a.mode == 3) {
+    // heads [0, 2 nbh / 3) are cut into 256-row units, heads [2 nbh / 3, nbh) into 128-row units: one of each
+    const int upa = a.S >> 8, upb = a.S >> 7;
+    const int ha = bid / upa, hb = 2 * (nbh / 3) + bid / upb;
+    flash_pass<2>(a, lds, ha / a.H, ha % a.H, (bid % upa) * 256, tid);
+    flash_pass<1>(a, lds, hb / a.H, hb % a.H, (bid % upb) * 128, tid);
+  } else if (a.mode == 2) {
+    const int nqt = (a.S + 255) >> 8;
+    const int hh = bid / nqt;
+    flash_pass<2>(a, lds, hh / a.H, hh % a.H, (bid % nqt) * 256, tid);
+  } else {
+    const int nqt = (a.S + 127) >> 7;
+    const int hh = bid / nqt;
+    flash_pass<1>(a, lds, hh / a.H, hh % a.H, (bid % nqt) * 128, tid);
+  }
+}
+
+static int g_flash_mode = 0;  // 0: pick, 1 / 2 / 3: force where legal
+void flash_set_mode(int m) { g_flash_mode = m; }
+
 int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int nb, int S, int H,
                         int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs, int S_pad, float scale,
-                        hipStream_t stream) {
-  if (!q || !k || !vt || !out || nb <= 0 || S <= 0 || H <= 0) return U2_ERR_ARG;
+                        const bf16_t* qx, const bf16_t* kx, const bf16_t* vx, bf16_t* outx, int64_t x_bs, int64_t ox_bs,
+                        int n_extra, hipStream_t stream) {
+  if (!q || !k || !vt || !out || nb <= 0 || S <= 0 || H <= 0 || n_extra < 0 || n_extra > 1) return U2_ERR_ARG;
   if ((S_pad & 63) || S_pad < ((S + 63) & ~63)) return U2_ERR_ARG;
   if ((ld_qk & 7) || (q_bs & 7) || (ld_out & 3) || (out_bs & 3)) return U2_ERR_ARG;
   if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15) || ((uintptr_t)out & 7)) return U2_ERR_ARG;
-  const int nqt = (S + 127) / 128;
-  const int64_t blocks = (int64_t)nb * H * nqt;
-  if (blocks > 0x7fffffff) return U2_ERR_ARG;
-  ProfScope ps(PROF_FLASH, 4.0 * nb * H * (double)S * S * 64, stream);
-  hipLaunchKernelGGL(flash_d64_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, q, k, vt, out, S, H, ld_qk, q_bs,
-                     ld_out, out_bs, S_pad, scale * 1.44269504088896340736f, nqt);
+  if (n_extra) {
+    if (!qx || !kx || !vx || !outx || (x_bs & 7) || (((uintptr_t)qx | (uintptr_t)kx | (uintptr_t)vx) & 15)) return U2_ERR_ARG;
+    if ((size_t)S_pad * 4 + 64 > 32768) return U2_ERR_ARG;  // probabilities of the extra row live in LDS
+  }
+  FlashArgs a;
+  a.q = q; a.k = k; a.vt = vt; a.out = out; a.qx = qx; a.kx = kx; a.vx = vx; a.outx = outx;
+  a.S = S; a.H = H; a.nb = nb; a.S_pad = S_pad; a.n_extra = n_extra;
+  a.ld_qk = ld_qk; a.q_bs = q_bs; a.ld_out = ld_out; a.out_bs = out_bs; a.x_bs = x_bs; a.ox_bs = ox_bs;
+  a.scale_log2e = scale * 1.44269504088896340736f;
+  const int64_t nbh = (int64_t)nb * H;
+  const bool mixed_ok = (S % 256 == 0) && (nbh % 3 == 0);
+  int mode = g_flash_mode;
+  if (mode == 3 && !mixed_ok) mode = 0;
+  if (mode < 1 || mode > 3) mode = mixed_ok ? 3 : 1;
+  int64_t blocks;
+  if (mode == 3) blocks = nbh * (S / 128) / 3;
+  else if (mode == 2) blocks = nbh * ((S + 255) / 256);
+  else blocks = nbh * ((S + 127) / 128);
+  a.mode = mode;
+  a.n_main = (int)blocks;
+  const int64_t grid = blocks + (n_extra ? nbh : 0);
+  if (grid > 0x7fffffff) return U2_ERR_ARG;
+  ProfScope ps(PROF_FLASH, 4.0 * nbh * (double)(S + n_extra) * (S + n_extra) * 64, stream);
+  hipLaunchKernelGGL(flash_d64_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
   return launch_status();
 }
 

@@ -38,6 +38,21 @@ int u2tok_set_option(const char* name, int value) {
     gemm_set_options(-1, -1, value);
     return U2_OK;
   }
+  if (!strcmp(name, "gemm_pp")) {
+    if (value < -1 || value > 8) return U2_ERR_ARG;
+    gemm_pp_set_options(value, -1);
+    return U2_OK;
+  }
+  if (!strcmp(name, "gemm_pp_grid")) {
+    if (value < 1 || value > 4096) return U2_ERR_ARG;
+    gemm_pp_set_options(-2, value);
+    return U2_OK;
+  }
+  if (!strcmp(name, "flash_mode")) {
+    if (value < 0 || value > 3) return U2_ERR_ARG;
+    flash_set_mode(value);
+    return U2_OK;
+  }
   if (!strcmp(name, "vit_flash")) { pipeline_set_vit_flash(value); return U2_OK; }
   if (!strcmp(name, "profile")) { prof_enable(value != 0); return U2_OK; }
   return U2_ERR_ARG;
@@ -161,9 +176,10 @@ int u2tok_temporal_attention(const void* q, const void* k, const void* v, void* 
 
 int u2tok_flash_attention_d64(const void* q, const void* k, const void* vt, void* out, int32_t nb, int32_t S,
                               int32_t H, int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs, int32_t S_pad,
-                              float scale, u2tok_stream_t stream) {
+                              float scale, const void* qx, const void* kx, const void* vx, void* outx, int64_t x_bs,
+                              int64_t ox_bs, int32_t n_extra, u2tok_stream_t stream) {
   return flash_attention_d64(BF(q), BF(k), BF(vt), BFW(out), nb, S, H, ld_qk, q_bs, ld_out, out_bs, S_pad, scale,
-                             ST(stream));
+                             BF(qx), BF(kx), BF(vx), BFW(outx), x_bs, ox_bs, n_extra, ST(stream));
 }
 
 int u2tok_rope_apply(void* x, int64_t n_outer, int32_t S, int32_t n_inner, int32_t H, int32_t d, int64_t ld,

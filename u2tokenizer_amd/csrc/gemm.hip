@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
         float v0 = acc[mi][ni][0] * d.alpha, v1 = acc[mi][ni][1] * d.alpha, v2 = acc[mi][ni][2] * d.alpha,
               v3 = acc[mi][ni][3] * d.alpha;
         if constexpr (decltype(BN_)::value) { v0 += bn[ni].x; v1 += bn[ni].y; v2 += bn[ni].z; v3 += bn[ni].w; }
-        if constexpr (decltype(GELU_)::value) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+        if constexpr (decltype(GELU_)::value) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
         if constexpr (decltype(RES_)::value) {
           const uint2 r2 = *reinterpret_cast<const uint2*>(Rz + (int64_t)m * d.ldr + n0);
           v0 += bf16lo(r2.x); v1 += bf16hi(r2.x); v2 += bf16lo(r2.y); v3 += bf16hi(r2.y);
@@ -301,6 +301,13 @@ int gemm_bf16(GemmDesc d, hipStream_t stream) {
   d.flags = vec ? (d.flags | GEMM_VEC_OK) : (d.flags & ~GEMM_VEC_OK);
 
   ProfScope ps(PROF_GEMM, 2.0 * d.M * d.N * d.K * d.nz, stream);
+  const int pp = gemm_pp_try(d, stream);  // large products: persistent ping-pong kernel (gemm_pp.hip)
+  if (pp != 0) return pp > 0 ? U2_OK : pp;
+  return gemm_classic(d, stream);
+}
+
+// 128^2 / 64^2 tile kernel above; `d` already validated (GEMM_VEC_OK resolved).
+int gemm_classic(GemmDesc d, hipStream_t stream) {
   int tile = g_gemm_force_tile;
   if (tile != 64 && tile != 128) {
     const int64_t big = cdiv(d.M, 128) * cdiv(d.N, 128) * d.nz;

@@ -1,0 +1,437 @@
+// "Ping-pong" bf16 MFMA GEMM for the large products of the hot path (same contract as gemm.hip:
+//   C[z][m][n] = epilogue(alpha * sum_k A[z][m][k] * B[z][n][k]),  A = activations [M][K], B = nn.Linear weight [N][K]).
+//
+// Why a second kernel: gemm.hip's 128x128 tile with one barrier pair per K step tops out where every
+// "load -> barrier -> MFMA" structure does on CDNA4 (the matrix pipe drains at each barrier while all waves
+// fetch their fragments at once).  Here one persistent workgroup per CU owns a 256 x BN output tile and its
+// 8 waves form two groups of 4 that alternate roles on every barrier:
+//
+//      barrier #  0      1      2      3      4      5   ...
+//      group 0    | L(0) | M(0) | L(1) | M(1) | L(2) | ...      L(t): issue LDS-DMA for K tile t+NS-1, read the
+//      group 1    |  --  | L(0) | M(0) | L(1) | M(1) | ...            MFMA fragments of K tile t from LDS
+//                                                                M(t): MI*NI*KSTEPS back-to-back MFMAs
+//
+// Waves w and w+4 share a SIMD (CDNA4 places a workgroup's waves on SIMDs cyclically), so each SIMD always
+// has one wave in an M segment: the matrix pipe stays busy while the partner wave does the LDS / global
+// traffic.  Global->LDS goes by LDS-DMA (global_load_lds_dwordx4) into a ring of NS stages with COUNTED
+// vmcnt waits, so NS-1 K tiles stay in flight across the barriers; barriers are raw s_barrier.
+//
+//  * group g owns rows [128 g, 128 g + 128) of the tile, its 4 waves a 2 x 2 grid of 64 x BN/2 wave tiles made
+//    of v_mfma_f32_32x32x16_bf16 (weight fragment as the A operand: a lane ends up with 4 consecutive n).
+//  * LDS stage = [256 + BN rows][BK bf16]; 16-byte chunks XOR-swizzled (applied to the per-lane SOURCE
+//    address, the DMA destination is lane-linear) so the 32x32 fragment reads are conflict-free ds_read_b128.
+//  * persistent: grid = min(#tiles, #CUs); a workgroup walks tiles b, b + grid, ... as ONE flattened K loop, so
+//    the next tile's first K tiles are already in flight while the previous tile's epilogue stores drain; the
+//    epilogue of a group runs at the head of its next L segment, under the other group's MFMAs.
+//  * XCD-aware tile order (workgroup b runs on XCD b % 8): every XCD gets a compact band of tiles per round.
+#include <algorithm>
+#include <type_traits>
+#include "kernels.h"
+
+namespace u2 {
+
+__device__ uint4 g_pp_zero16;  // zero source for K-tail chunks
+
+template <int BN_, int BK_, int NS_>
+struct PPCfg {
+  static constexpr int BM = 256, BN = BN_, BK = BK_, NS = NS_;
+  static constexpr int ROWB = BK * 2;            // bytes per LDS row
+  static constexpr int CPR = BK / 8;             // 16-byte chunks per row
+  static constexpr int RPP = 64 / CPR;           // rows covered by one 1-KiB DMA piece (one wave instruction)
+  static constexpr int ROWS = BM + BN;
+  static constexpr int STAGE = ROWS * ROWB;
+  static constexpr int NP = STAGE / 1024;        // pieces per K tile
+  static constexpr int PG0 = (NP / 4 + 1) / 2;   // pieces per wave of group 0 / group 1
+  static constexpr int PG1 = NP / 4 - PG0;
+  static constexpr int KSTEPS = BK / 16;
+  static constexpr int NI = BN / 64;             // 32-wide n fragments per wave (wave tile 64 x BN/2)
+  static constexpr int LDS_BYTES = NS * STAGE;
+  static_assert(BK == 32 || BK == 64, "BK");
+  static_assert(BN % 64 == 0 && NP % 4 == 0 && PG1 >= 1, "piece split");
+  static_assert(NS >= 2 && LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <int BK>
+__device__ __forceinline__ int pp_swz(int row) {
+  if constexpr (BK == 64) return (row >> 1) & 7;
+  else return (row >> 2) & 3;
+}
+
+// round r of workgroup `bid` -> (z, bm0, bn0).  Tiles of one round are remapped so that XCD x (= bid & 7) works
+// on a contiguous range of logical ids; logical ids walk groups of 8 m-tiles column by column.
+template <int BN>
+__device__ __forceinline__ void pp_tile(const GemmDesc& d, int round, int gd, int bid, int total, int tiles_mn, int& z,
+                                        int& bm0, int& bn0) {
+  const int base = round * gd;
+  const int n_r = min(gd, total - base);
+  const int q = n_r >> 3, r = n_r & 7, xcd = bid & 7, idx = bid >> 3;
+  const int pid = base + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  z = pid / tiles_mn;
+  const int rem = pid - z * tiles_mn;
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * d.tiles_n;
+  const int group = rem / per_group, in_g = rem - group * per_group;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(d.tiles_m - first_m, GROUP_M);
+  bm0 = (first_m + in_g % gsz) * 256;
+  bn0 = (in_g / gsz) * BN;
+}
+
+// Epilogue of one 256 x BN tile for the calling wave.  The accumulator fragment of v_mfma_f32_32x32x16 leaves a lane
+// with 4 consecutive n (register quad q) and its partner lane (+32) with the next 4; v_permlane32_swap exchanges
+// quads between the half-waves so that every lane owns 8 CONSECUTIVE n of one row m: 16-byte bias / residual loads
+// and bf16 stores, two float4 stores for fp32 output.
+//   lane (l31, hi), pair t of fragment (mi, ni):  m = m_base + 32 mi,  n = n_tile + 32 ni + 16 t + 8 hi + [0, 8)
+template <class CFG, int G>
+__device__ __forceinline__ void pp_epilogue(const GemmDesc& d, f32x16 (&acc)[2][CFG::NI], int z, int bm0, int bn0, int wm2,
+                                            int wn2, int lane) {
+  constexpr int NI = CFG::NI, BN = CFG::BN;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const bool out_f32 = d.flags & GEMM_OUT_F32;
+  const int zb = z / d.nbh, zh = z - zb * d.nbh;
+  char* Cz = reinterpret_cast<char*>(d.C) + (zb * d.sCb + zh * d.sCh) * (out_f32 ? 4 : 2);
+  const bf16_t* Rz = (d.flags & GEMM_RESIDUAL) ? d.R + zb * d.sRb + zh * d.sRh : nullptr;
+  const int m_base = bm0 + G * 128 + wm2 * 64 + l31;
+  const int n_base = bn0 + wn2 * (BN / 2) + 8 * hi;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mi][ni][8 * t + e]),
+                                                          __float_as_uint(acc[mi][ni][8 * t + 4 + e]), false, false);
+          acc[mi][ni][8 * t + e] = __uint_as_float(r[0]);
+          acc[mi][ni][8 * t + 4 + e] = __uint_as_float(r[1]);
+        }
+  // FULL: the tile lies inside C (no row / column predicates); flags resolved at compile time.
+  auto body = [&](auto FULL_, auto BIAS_, auto GELU_, auto RES_, auto F32_) {
+    constexpr bool FULL = decltype(FULL_)::value;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int n0 = n_base + ni * 32 + t * 16;
+        if (!FULL && n0 >= d.N) continue;
+        float bv[8];
+        if constexpr (decltype(BIAS_)::value) {
+          const uint4 b4 = *reinterpret_cast<const uint4*>(d.bias + n0);
+          bv[0] = bf16lo(b4.x); bv[1] = bf16hi(b4.x); bv[2] = bf16lo(b4.y); bv[3] = bf16hi(b4.y);
+          bv[4] = bf16lo(b4.z); bv[5] = bf16hi(b4.z); bv[6] = bf16lo(b4.w); bv[7] = bf16hi(b4.w);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int m = m_base + mi * 32;
+          if (!FULL && m >= d.M) continue;
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = acc[mi][ni][8 * t + e] * d.alpha;
+          if constexpr (decltype(BIAS_)::value) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bv[e];
+          }
+          if constexpr (decltype(GELU_)::value) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+          }
+          if constexpr (decltype(RES_)::value) {
+            const uint4 r4 = *reinterpret_cast<const uint4*>(Rz + (int64_t)m * d.ldr + n0);
+            v[0] += bf16lo(r4.x); v[1] += bf16hi(r4.x); v[2] += bf16lo(r4.y); v[3] += bf16hi(r4.y);
+            v[4] += bf16lo(r4.z); v[5] += bf16hi(r4.z); v[6] += bf16lo(r4.w); v[7] += bf16hi(r4.w);
+          }
+          if constexpr (decltype(F32_)::value) {
+            float* cp = reinterpret_cast<float*>(Cz) + (int64_t)m * d.ldc + n0;
+            *reinterpret_cast<float4*>(cp) = float4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<float4*>(cp + 4) = float4{v[4], v[5], v[6], v[7]};
+          } else {
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(Cz) + (int64_t)m * d.ldc + n0) =
+                uint4{pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])};
+          }
+        }
+      }
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  const int ef = d.flags & (GEMM_BIAS_N | GEMM_GELU | GEMM_RESIDUAL | GEMM_OUT_F32);
+  if (bm0 + 256 <= d.M && bn0 + BN <= d.N) {
+    switch (ef) {
+      case 0: body(T_{}, F_{}, F_{}, F_{}, F_{}); break;
+      case GEMM_OUT_F32: body(T_{}, F_{}, F_{}, F_{}, T_{}); break;
+      case GEMM_BIAS_N: body(T_{}, T_{}, F_{}, F_{}, F_{}); break;
+      case GEMM_BIAS_N | GEMM_OUT_F32: body(T_{}, T_{}, F_{}, F_{}, T_{}); break;
+      case GEMM_BIAS_N | GEMM_GELU: body(T_{}, T_{}, T_{}, F_{}, F_{}); break;
+      case GEMM_BIAS_N | GEMM_RESIDUAL: body(T_{}, T_{}, F_{}, T_{}, F_{}); break;
+      case GEMM_RESIDUAL: body(T_{}, F_{}, F_{}, T_{}, F_{}); break;
+      default: break;  // the launcher never sends other combinations here
+    }
+  } else {
+    switch (ef) {  // border tiles: same bodies with row / column predicates
+      case 0: body(F_{}, F_{}, F_{}, F_{}, F_{}); break;
+      case GEMM_OUT_F32: body(F_{}, F_{}, F_{}, F_{}, T_{}); break;
+      case GEMM_BIAS_N: body(F_{}, T_{}, F_{}, F_{}, F_{}); break;
+      case GEMM_BIAS_N | GEMM_OUT_F32: body(F_{}, T_{}, F_{}, F_{}, T_{}); break;
+      case GEMM_BIAS_N | GEMM_GELU: body(F_{}, T_{}, T_{}, F_{}, F_{}); break;
+      case GEMM_BIAS_N | GEMM_RESIDUAL: body(F_{}, T_{}, F_{}, T_{}, F_{}); break;
+      case GEMM_RESIDUAL: body(F_{}, F_{}, F_{}, T_{}, F_{}); break;
+      default: break;
+    }
+  }
+}
+
+#define PP_WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
+#define PP_BARRIER()                        \
+  do {                                      \
+    __builtin_amdgcn_sched_barrier(0);      \
+    __builtin_amdgcn_s_barrier();           \
+    __builtin_amdgcn_sched_barrier(0);      \
+  } while (0)
+
+template <class CFG, int G>
+__device__ __forceinline__ void pp_group(const GemmDesc& d, char* lds, const int j, const int lane) {
+  constexpr int BN = CFG::BN, BK = CFG::BK, NS = CFG::NS, ROWB = CFG::ROWB, CPR = CFG::CPR, RPP = CFG::RPP;
+  constexpr int STAGE = CFG::STAGE, KSTEPS = CFG::KSTEPS, NI = CFG::NI;
+  constexpr int PG = (G == 0) ? CFG::PG0 : CFG::PG1;  // DMA pieces this wave issues per K tile
+  constexpr int P0 = (G == 0) ? 0 : 4 * CFG::PG0;
+  constexpr int WAITN = (NS - 2) * PG;                // pieces younger than the K tile that must have landed
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int wm2 = j >> 1, wn2 = j & 1;
+
+  const int tiles_mn = d.tiles_m * d.tiles_n;
+  const int total = tiles_mn * d.nz;
+  const int gd = gridDim.x, bid = blockIdx.x;
+  const int nkt = (d.K + BK - 1) / BK;
+  const int my_tiles = (total - bid + gd - 1) / gd;  // >= 1: grid <= total
+  const int nit = my_tiles * nkt;                     // flattened (tile, K tile) iterations
+
+  // ---------------- issue cursor: DMA source pointers of the tile being staged
+  const bf16_t* src[PG];
+  int kc[PG];
+  int is_kt = 0, is_round = 0, is_stage = 0;
+#define PP_SETUP_ISSUE(round_)                                                                   \
+  {                                                                                              \
+    int z_, bm0_, bn0_;                                                                          \
+    pp_tile<BN>(d, (round_), gd, bid, total, tiles_mn, z_, bm0_, bn0_);                          \
+    const int zb_ = z_ / d.nbh, zh_ = z_ - zb_ * d.nbh;                                          \
+    const bf16_t* A_ = d.A + zb_ * d.sAb + zh_ * d.sAh;                                          \
+    const bf16_t* B_ = d.B + zb_ * d.sBb + zh_ * d.sBh;                                          \
+    _Pragma("unroll") for (int i = 0; i < PG; ++i) {                                             \
+      const int r_ = (P0 + i * 4 + j) * RPP + lane / CPR;                                        \
+      const int gc_ = (lane % CPR) ^ pp_swz<BK>(r_);                                             \
+      kc[i] = gc_ * 8;                                                                           \
+      if (r_ < 256) src[i] = A_ + (int64_t)min(bm0_ + r_, d.M - 1) * d.lda + gc_ * 8;            \
+      else src[i] = B_ + (int64_t)min(bn0_ + r_ - 256, d.N - 1) * d.ldb + gc_ * 8;               \
+    }                                                                                            \
+  }
+#define PP_ISSUE()                                                                                              \
+  {                                                                                                             \
+    char* s_ = lds + is_stage * STAGE + (P0 + j) * 1024;                                                        \
+    const int k0_ = is_kt * BK;                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < PG; ++i) {                                                            \
+      const void* g_ = (k0_ + kc[i] < d.K) ? (const void*)(src[i] + k0_) : (const void*)&g_pp_zero16;           \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_,                       \
+                                       (__attribute__((address_space(3))) void*)(s_ + i * 4096), 16, 0, 0);     \
+    }                                                                                                           \
+    is_stage = (is_stage + 1 == NS) ? 0 : is_stage + 1;                                                         \
+    if (++is_kt == nkt) {                                                                                       \
+      is_kt = 0;                                                                                                \
+      if (++is_round < my_tiles) PP_SETUP_ISSUE(is_round)                                                       \
+    }                                                                                                           \
+  }
+
+  // ---------------- compute cursor
+  f32x16 acc[2][NI];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+  int koff[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) koff[ks] = ((ks * 2 + hi) ^ pp_swz<BK>(l31)) << 4;
+  const int a_base = (G * 128 + wm2 * 64 + l31) * ROWB;
+  const int b_base = (256 + wn2 * (BN / 2) + l31) * ROWB;
+  int c_stage = 0, c_kt = 0, c_round = 0, pend_round = -1;
+
+#define PP_EPILOGUE()                                                                 \
+  {                                                                                   \
+    int z_, bm0_, bn0_;                                                               \
+    pp_tile<BN>(d, pend_round, gd, bid, total, tiles_mn, z_, bm0_, bn0_);             \
+    pp_epilogue<CFG, G>(d, acc, z_, bm0_, bn0_, wm2, wn2, lane);                      \
+    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                  \
+      _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                               \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;          \
+    pend_round = -1;                                                                  \
+  }
+
+  // ---------------- prologue: NS-1 K tiles in flight, the first one landed before barrier #0
+  PP_SETUP_ISSUE(0)
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nit) PP_ISSUE()
+  if (nit >= NS - 1) PP_WAIT_VM(WAITN);
+  else PP_WAIT_VM(0);
+  PP_BARRIER();
+  if constexpr (G == 1) PP_BARRIER();  // group 1 runs one barrier behind group 0
+
+  for (int it = 0;; ++it) {
+    // ======== L segment (the other group is in its M segment)
+    if (pend_round >= 0) PP_EPILOGUE()
+    if (it == nit) break;
+    const bool more = it + NS - 1 < nit;
+    if (more) PP_ISSUE()
+    bf16x8 xf[KSTEPS][2], wf[KSTEPS][NI];
+    {
+      const char* sb = lds + c_stage * STAGE;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          xf[ks][mi] = *reinterpret_cast<const bf16x8*>(sb + a_base + mi * 32 * ROWB + koff[ks]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          wf[ks][ni] = *reinterpret_cast<const bf16x8*>(sb + b_base + ni * 32 * ROWB + koff[ks]);
+      }
+    }
+    // fragment reads retired before the barrier: the stage may be overwritten by DMA issued after it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (G == 1) {  // K tile it+1 (this wave's share) landed before group 0 reads it
+      if (more) PP_WAIT_VM(WAITN);
+      else PP_WAIT_VM(0);
+    }
+    PP_BARRIER();
+    // ======== M segment
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][ni], xf[ks][mi], acc[mi][ni], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    if constexpr (G == 0) {
+      if (more) PP_WAIT_VM(WAITN);
+      else PP_WAIT_VM(0);
+    }
+    PP_BARRIER();
+    c_stage = (c_stage + 1 == NS) ? 0 : c_stage + 1;
+    if (++c_kt == nkt) {
+      c_kt = 0;
+      pend_round = c_round++;
+    }
+  }
+  if constexpr (G == 0) PP_BARRIER();
+#undef PP_SETUP_ISSUE
+#undef PP_ISSUE
+#undef PP_EPILOGUE
+}
+
+template <int BN, int BK, int NS>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmDesc d) {
+  using CFG = PPCfg<BN, BK, NS>;
+  __shared__ __attribute__((aligned(16))) char lds[CFG::LDS_BYTES];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave < 4) pp_group<CFG, 0>(d, lds, wave, lane);
+  else pp_group<CFG, 1>(d, lds, wave - 4, lane);
+}
+
+// ------------------------------------------------------------------------------------------------ launcher
+static int g_pp_mode = 0;      // 0: heuristic, -1: never, v > 0: force variant v where the shape allows it
+static int g_pp_max_grid = 256;
+
+void gemm_pp_set_options(int mode, int max_grid) {
+  if (mode >= -1) g_pp_mode = mode;
+  if (max_grid > 0) g_pp_max_grid = max_grid;
+}
+
+template <int BN, int BK, int NS>
+static int pp_launch(GemmDesc d, hipStream_t stream) {
+  d.tiles_m = (int)cdiv(d.M, 256);
+  d.tiles_n = (int)cdiv(d.N, BN);
+  const int64_t total = (int64_t)d.tiles_m * d.tiles_n * d.nz;
+  if (total > 0x3fffffff) return U2_ERR_ARG;
+  const int grid = (int)std::min<int64_t>(total, g_pp_max_grid);
+  hipLaunchKernelGGL((gemm_pp_kernel<BN, BK, NS>), dim3(grid), dim3(512), 0, stream, d);
+  return launch_status();
+}
+
+static int pp_launch_variant(int v, const GemmDesc& d, hipStream_t stream) {
+  switch (v) {
+    case 1: return pp_launch<128, 64, 3>(d, stream);
+    case 2: return pp_launch<128, 32, 4>(d, stream);
+    case 3: return pp_launch<128, 32, 6>(d, stream);
+    case 4: return pp_launch<192, 32, 4>(d, stream);
+    case 5: return pp_launch<192, 32, 5>(d, stream);
+    case 6: return pp_launch<192, 64, 2>(d, stream);
+    case 7: return pp_launch<256, 32, 4>(d, stream);
+    case 8: return pp_launch<256, 32, 5>(d, stream);
+    default: return U2_ERR_ARG;
+  }
+}
+static int pp_variant_bn(int v) { return v <= 3 ? 128 : (v <= 6 ? 192 : 256); }
+
+// Tile-shape choice: BN in {128, 192, 256} by useful-area efficiency of the last (partial) round of 256 workgroups;
+// wider BN wins ties (fewer LDS bytes per flop).  Variant ids as in pp_launch_variant.
+static int pp_pick(const GemmDesc& d) {
+  static const int cand_bn[3] = {256, 192, 128};
+  static const int cand_v[3] = {8, 5, 3};
+  const int64_t tm = cdiv(d.M, 256);
+  double best = 0.0;
+  int v = 0;
+  for (int i = 0; i < 3; ++i) {
+    const int64_t tiles = tm * cdiv(d.N, cand_bn[i]) * d.nz;
+    const int64_t rounds = cdiv(tiles, g_pp_max_grid);
+    const double eff = (double)d.M * d.N * d.nz / ((double)rounds * g_pp_max_grid * 256.0 * cand_bn[i]);
+    if (eff > best * 1.03) { best = eff; v = cand_v[i]; }
+  }
+  return best >= 0.45 ? v : 0;  // a badly filled machine: gemm.hip's small tiles do better
+}
+
+// Returns 1 when the product was launched here, 0 when the caller should use gemm.hip's kernel, < 0 on error.
+// `d` has been validated by gemm_bf16 (alignment of A / B, GEMM_VEC_OK resolved).
+int gemm_pp_try(const GemmDesc& d, hipStream_t stream) {
+  if (g_pp_mode < 0) return 0;
+  if (!(d.flags & GEMM_VEC_OK) || (d.flags & GEMM_BIAS_M) || (d.N & 7)) return 0;
+  switch (d.flags & (GEMM_BIAS_N | GEMM_GELU | GEMM_RESIDUAL | GEMM_OUT_F32)) {
+    case 0: case GEMM_OUT_F32: case GEMM_BIAS_N: case GEMM_BIAS_N | GEMM_OUT_F32: case GEMM_BIAS_N | GEMM_GELU:
+    case GEMM_BIAS_N | GEMM_RESIDUAL: case GEMM_RESIDUAL: break;
+    default: return 0;
+  }
+  // 16-byte epilogue accesses (8 consecutive n per lane)
+  const bool f32 = d.flags & GEMM_OUT_F32;
+  if (((uintptr_t)d.C & 15) || (d.ldc & (f32 ? 3 : 7)) || (d.sCb & (f32 ? 3 : 7)) || (d.sCh & (f32 ? 3 : 7))) return 0;
+  if ((d.flags & GEMM_BIAS_N) && ((uintptr_t)d.bias & 15)) return 0;
+  if ((d.flags & GEMM_RESIDUAL) && (((uintptr_t)d.R & 15) || (d.ldr & 7) || (d.sRb & 7) || (d.sRh & 7))) return 0;
+  if (g_pp_mode > 0) {
+    const int e = pp_launch_variant(g_pp_mode, d, stream);
+    return e == U2_OK ? 1 : e;
+  }
+  if (d.M < 512 || d.N < 256 || d.K < 128) return 0;
+  // A few rows past a multiple of 256 (the ViT's 8 cls rows: M = 8 * 2049) would cost a whole extra round of
+  // 256-row tiles: run them through the small-tile kernel instead.
+  const int rem = d.M & 255;
+  if (d.nz == 1 && rem != 0 && rem <= 64) {
+    GemmDesc main = d, tail = d;
+    main.M = d.M - rem;
+    const int v = pp_pick(main);
+    if (v == 0) return 0;
+    tail.M = rem;
+    tail.A = d.A + (int64_t)main.M * d.lda;
+    tail.C = reinterpret_cast<char*>(d.C) + (int64_t)main.M * d.ldc * (f32 ? 4 : 2);
+    if (d.flags & GEMM_RESIDUAL) tail.R = d.R + (int64_t)main.M * d.ldr;
+    int e = pp_launch_variant(v, main, stream);
+    if (e != U2_OK) return e;
+    e = gemm_classic(tail, stream);
+    return e == U2_OK ? 1 : e;
+  }
+  const int v = pp_pick(d);
+  if (v == 0) return 0;
+  const int e = pp_launch_variant(v, d, stream);
+  return e == U2_OK ? 1 : e;
+}
+
+}  // namespace u2

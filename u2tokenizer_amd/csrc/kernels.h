@@ -45,6 +45,10 @@ struct GemmDesc {
 
 int gemm_bf16(GemmDesc d, hipStream_t stream);
 void gemm_set_options(int glds, int force_tile, int bk);
+// internal: the two kernels behind gemm_bf16 (descriptor already validated there)
+int gemm_classic(GemmDesc d, hipStream_t stream);       // gemm.hip: 128^2 / 64^2 tiles, 2 workgroups per CU
+int gemm_pp_try(const GemmDesc& d, hipStream_t stream);  // gemm_pp.hip: 1 launched, 0 not applicable, < 0 error
+void gemm_pp_set_options(int mode, int max_grid);        // mode: -1 never, 0 heuristic, v > 0 force variant v
 
 // ------------------------------------------------------------------ row ops (rowops.hip)
 // y[b][r][:] = LayerNorm(x[b][r][:] (+ res[b][r][:])) * w + bias   (bf16 in/out, fp32 math)
@@ -105,10 +109,14 @@ int temporal_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t
                        int H, int d, int64_t ld_qkv, int64_t ld_out, float scale, const bf16_t* rel_bias,
                        int max_len, hipStream_t stream);
 
-// Flash attention for the ViT blocks (head_dim 64).  q,k: [nb][S][*] with leading dim ld_qk, head h at
-// column h*64; vt: [nb][H][64][S_pad] (S_pad % 64 == 0, zero padded, perm16 column order); out: [nb][S][H*64].
-int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int nb, int S,
-                        int H, int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs, int S_pad,
-                        float scale, hipStream_t stream);
+// Flash attention for the ViT blocks (head_dim 64) over S main rows per batch plus n_extra (0 / 1) extra row per
+// batch stored elsewhere (the cls token).  q,k: row r of batch b at q + b*q_bs + r*ld_qk, head h at column h*64;
+// vt: V^T of the main rows, [nb][H][64][S_pad] (S_pad % 64 == 0, zero padded, perm16 column order); out like q with
+// ld_out / out_bs.  Extra row of batch b: qx / kx / vx + b*x_bs, output outx + b*ox_bs (head h at column h*64).
+int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int nb, int S, int H,
+                        int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs, int S_pad, float scale,
+                        const bf16_t* qx, const bf16_t* kx, const bf16_t* vx, bf16_t* outx, int64_t x_bs, int64_t ox_bs,
+                        int n_extra, hipStream_t stream);
+void flash_set_mode(int mode);  // 0 pick, 1: 128-row units, 2: 256-row units, 3: one of each per workgroup
 
 }  // namespace u2

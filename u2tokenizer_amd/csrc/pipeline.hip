@@ -110,6 +110,10 @@ int g_vit_flash = 1;
 void pipeline_set_vit_flash(int v) { g_vit_flash = v ? 1 : 0; }
 
 // =========================================================================== ViT3DTower
+// Row layout of the residual stream: the nc * ntok PATCH rows first (chunk-major), then the nc cls rows.  The
+// reference keeps [cls | patches] per chunk (vit.py:116-118); a transformer is indifferent to the order rows are
+// stored in, and this one makes every GEMM see M = nc*ntok (+ nc), the patch rows of a chunk tile exactly into
+// 128 / 256-row attention units, and the final "drop the cls token" (vit.py:157-160) a no-op.
 int vit_forward(const VitConfig& c, const void* const* W, const void* volume, bf16_t* out, void* ws, size_t ws_bytes,
                 bool dry, size_t* peak, hipStream_t st) {
   if (c.nchunk <= 0 || c.depth < 0 || c.heads <= 0 || c.hidden != c.heads * 64) return U2_ERR_ARG;
@@ -119,8 +123,9 @@ int vit_forward(const VitConfig& c, const void* const* W, const void* volume, bf
   const int nh = c.img[0] / c.patch[0], nw = c.img[1] / c.patch[1], nd = c.img[2] / c.patch[2];
   const int ntok = nh * nw * nd, S = ntok + 1, Hd = c.hidden, Kp = c.patch[0] * c.patch[1] * c.patch[2];
   const int nc = c.nchunk;
-  const int64_t rows = (int64_t)nc * S;
-  const int S_pad = (int)round_up(S, 64);
+  const int64_t prow = (int64_t)nc * ntok;  // patch rows; cls row of chunk b is row prow + b
+  const int64_t rows = prow + nc;
+  const int S_pad = (int)round_up(ntok, 64);
   auto w = [&](int i) { return dry ? nullptr : reinterpret_cast<const bf16_t*>(W[i]); };
 
   Arena ar(ws, ws_bytes, dry);
@@ -135,17 +140,17 @@ int vit_forward(const VitConfig& c, const void* const* W, const void* volume, bf
   bf16_t* patches = h1;
   U2_CHECK_WS(ar);
 
-  // ---- patch embedding: im2col + Linear + position embedding, cls token prepended (vit.py:115-118)
+  // ---- patch embedding: im2col + Linear + position embedding; cls token rows appended (vit.py:115-118)
   U2_RUN(im2col_patches(volume, c.vol_dtype, patches, nc, c.img[0], c.img[1], c.img[2], c.patch[0], c.patch[1],
                         c.patch[2], st));
-  U2_RUN(fill_rows(w(3), x, nc, Hd, (int64_t)S * Hd, st));
+  U2_RUN(fill_rows(w(3), x + prow * Hd, nc, Hd, Hd, st));
   {
     GemmDesc g;
-    g.A = patches; g.B = w(1); g.C = x + Hd; g.bias = w(2); g.R = w(0);
+    g.A = patches; g.B = w(1); g.C = x; g.bias = w(2); g.R = w(0);
     g.M = ntok; g.N = Hd; g.K = Kp;
     g.lda = Kp; g.ldb = Kp; g.ldc = Hd; g.ldr = Hd;
     g.nz = nc; g.nbh = 1;
-    g.sAb = (int64_t)ntok * Kp; g.sCb = (int64_t)S * Hd;
+    g.sAb = (int64_t)ntok * Kp; g.sCb = (int64_t)ntok * Hd;
     g.flags = GEMM_BIAS_N | GEMM_RESIDUAL;
     U2_RUN(gemm_bf16(g, st));
   }
@@ -156,14 +161,38 @@ int vit_forward(const VitConfig& c, const void* const* W, const void* volume, bf
     U2_RUN(layernorm_bf16(x, nullptr, w(b0 + 0), w(b0 + 1), xn, 1, (int)rows, Hd, 0, Hd, 0, 0, 0, Hd, c.ln_eps, st));
     U2_RUN(linear(xn, Hd, w(b0 + 2), nullptr, qkv, 3 * Hd, rows, Hd, 3 * Hd, 0, nullptr, 0, st));
     if (g_vit_flash) {
-      U2_RUN(transpose_bf16(qkv + 2 * Hd, vt, nc, S, Hd, 3 * Hd, S_pad, (int64_t)S * 3 * Hd, (int64_t)Hd * S_pad, 1, st));
-      U2_RUN(flash_attention_d64(qkv, qkv + Hd, vt, att, nc, S, c.heads, 3 * Hd, (int64_t)S * 3 * Hd, Hd,
-                                 (int64_t)S * Hd, S_pad, scale, st));
+      U2_RUN(transpose_bf16(qkv + 2 * Hd, vt, nc, ntok, Hd, 3 * Hd, S_pad, (int64_t)ntok * 3 * Hd, (int64_t)Hd * S_pad, 1, st));
+      const bf16_t* xq = qkv + prow * 3 * Hd;  // q | k | v of the cls rows
+      U2_RUN(flash_attention_d64(qkv, qkv + Hd, vt, att, nc, ntok, c.heads, 3 * Hd, (int64_t)ntok * 3 * Hd, Hd,
+                                 (int64_t)ntok * Hd, S_pad, scale, xq, xq + Hd, xq + 2 * Hd, att + prow * Hd, 3 * Hd, Hd,
+                                 1, st));
     } else {
-      AttnCore a{qkv, qkv + Hd, qkv + 2 * Hd, 3 * Hd, 3 * Hd, 3 * Hd, (int64_t)S * 3 * Hd, (int64_t)S * 3 * Hd,
-                 (int64_t)S * 3 * Hd, att, Hd, (int64_t)S * Hd, nc, S, S, c.heads, 64, scale, nullptr, 0};
-      const int e = attention_core(ar, a, dry, st);
-      if (e != U2_OK) return e;
+      // unfused reference path (debug option "vit_flash" = 0): gather [cls | patches] per chunk, two GEMMs + softmax
+      const size_t mark = ar.off;
+      bf16_t* qc = ar.get<bf16_t>((size_t)rows * 3 * Hd);
+      bf16_t* ac = ar.get<bf16_t>((size_t)rows * Hd);
+      U2_CHECK_WS(ar);
+      const size_t rb = (size_t)3 * Hd * sizeof(bf16_t), ob = (size_t)Hd * sizeof(bf16_t);
+      if (!dry) {
+        const hipError_t e1 = hipMemcpy2DAsync(qc + 3 * Hd, (size_t)S * rb, qkv, (size_t)ntok * rb, (size_t)ntok * rb, nc,
+                                               hipMemcpyDeviceToDevice, st);
+        const hipError_t e2 = hipMemcpy2DAsync(qc, (size_t)S * rb, qkv + prow * 3 * Hd, rb, rb, nc,
+                                               hipMemcpyDeviceToDevice, st);
+        if (e1 != hipSuccess || e2 != hipSuccess) return U2_ERR_LAUNCH;
+      }
+      {
+        AttnCore a{qc, qc + Hd, qc + 2 * Hd, 3 * Hd, 3 * Hd, 3 * Hd, (int64_t)S * 3 * Hd, (int64_t)S * 3 * Hd,
+                   (int64_t)S * 3 * Hd, ac, Hd, (int64_t)S * Hd, nc, S, S, c.heads, 64, scale, nullptr, 0};
+        const int e = attention_core(ar, a, dry, st);
+        if (e != U2_OK) return e;
+      }
+      if (!dry) {
+        const hipError_t e1 = hipMemcpy2DAsync(att, (size_t)ntok * ob, ac + Hd, (size_t)S * ob, (size_t)ntok * ob, nc,
+                                               hipMemcpyDeviceToDevice, st);
+        const hipError_t e2 = hipMemcpy2DAsync(att + prow * Hd, ob, ac, (size_t)S * ob, ob, nc, hipMemcpyDeviceToDevice, st);
+        if (e1 != hipSuccess || e2 != hipSuccess) return U2_ERR_LAUNCH;
+      }
+      ar.off = mark;
     }
     U2_RUN(linear(att, Hd, w(b0 + 3), w(b0 + 4), x, Hd, rows, Hd, Hd, 0, x, Hd, st));
     // x = x + linear2(gelu(linear1(norm2(x))))
@@ -171,14 +200,17 @@ int vit_forward(const VitConfig& c, const void* const* W, const void* volume, bf
     U2_RUN(linear(xn, Hd, w(b0 + 7), w(b0 + 8), h1, c.mlp_dim, rows, Hd, c.mlp_dim, GEMM_GELU, nullptr, 0, st));
     U2_RUN(linear(h1, c.mlp_dim, w(b0 + 9), w(b0 + 10), x, Hd, rows, c.mlp_dim, Hd, 0, x, Hd, st));
   }
-  // final norm; drop the cls row unless select_feature == "cls_patch" (vit.py:124,157-160)
+  // final norm; the cls rows are dropped unless select_feature == "cls_patch" (vit.py:124,157-160), in which case
+  // the output goes back to the reference's [cls | patches] order per chunk
   const int nwt = 4 + 11 * c.depth;
-  if (c.keep_cls)
-    U2_RUN(layernorm_bf16(x, nullptr, w(nwt), w(nwt + 1), out, nc, S, Hd, (int64_t)S * Hd, Hd, 0, 0, (int64_t)S * Hd, Hd,
+  if (c.keep_cls) {
+    U2_RUN(layernorm_bf16(x, nullptr, w(nwt), w(nwt + 1), out + Hd, nc, ntok, Hd, (int64_t)ntok * Hd, Hd, 0, 0,
+                          (int64_t)S * Hd, Hd, c.ln_eps, st));
+    U2_RUN(layernorm_bf16(x + prow * Hd, nullptr, w(nwt), w(nwt + 1), out, nc, 1, Hd, Hd, Hd, 0, 0, (int64_t)S * Hd, Hd,
                           c.ln_eps, st));
-  else
-    U2_RUN(layernorm_bf16(x + Hd, nullptr, w(nwt), w(nwt + 1), out, nc, ntok, Hd, (int64_t)S * Hd, Hd, 0, 0,
-                          (int64_t)ntok * Hd, Hd, c.ln_eps, st));
+  } else {
+    U2_RUN(layernorm_bf16(x, nullptr, w(nwt), w(nwt + 1), out, 1, (int)prow, Hd, 0, Hd, 0, 0, 0, Hd, c.ln_eps, st));
+  }
   if (peak) *peak = ar.peak;
   U2_CHECK_WS(ar);
   return U2_OK;

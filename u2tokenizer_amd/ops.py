@@ -202,20 +202,30 @@ def temporal_attention(q, k, v, B, T, N, H, scale, rel_bias=None, max_len=512):
     return out
 
 
-def flash_attention_d64(qkv: torch.Tensor, heads: int, scale: float):
-    """qkv: (nb, S, 3*heads*64) bf16 in MONAI SABlock column order (q | k | v)."""
+def flash_attention_d64(qkv: torch.Tensor, heads: int, scale: float, extra_last: bool = False):
+    """qkv: (nb, S, 3*heads*64) bf16 in MONAI SABlock column order (q | k | v).  extra_last=True runs the last row of
+    every batch through the kernel's "extra row" path (how the ViT tower feeds its cls token); same result."""
     h = _lib.load_library()
     qkv = _need(qkv, torch.bfloat16, "qkv").contiguous()
     nb, S, three = qkv.shape
     Hd = three // 3
-    S_pad = (S + 63) // 64 * 64
+    Sm = S - 1 if extra_last else S
+    if Sm < 1:
+        raise RuntimeError("flash_attention_d64: at least one main row is required")
+    S_pad = (Sm + 63) // 64 * 64
     vt = torch.empty((nb, Hd, S_pad), dtype=torch.bfloat16, device=qkv.device)
     v_view = qkv[:, :, 2 * Hd:]
-    _lib.check(h.u2tok_transpose_bf16(v_view.data_ptr(), _ptr(vt), nb, S, Hd, 3 * Hd, S_pad, S * 3 * Hd, Hd * S_pad,
+    _lib.check(h.u2tok_transpose_bf16(v_view.data_ptr(), _ptr(vt), nb, Sm, Hd, 3 * Hd, S_pad, S * 3 * Hd, Hd * S_pad,
                                       1, _stream()), "u2tok_transpose_bf16")
     out = torch.empty((nb, S, Hd), dtype=torch.bfloat16, device=qkv.device)
-    _lib.check(h.u2tok_flash_attention_d64(qkv.data_ptr(), qkv.data_ptr() + 2 * Hd, _ptr(vt), _ptr(out), nb, S, heads,
-                                           3 * Hd, S * 3 * Hd, Hd, S * Hd, S_pad, float(scale), _stream()),
+    es = qkv.element_size()
+    x0 = qkv.data_ptr() + (S - 1) * 3 * Hd * es
+    _lib.check(h.u2tok_flash_attention_d64(qkv.data_ptr(), qkv.data_ptr() + Hd * es, _ptr(vt), _ptr(out), nb, Sm, heads,
+                                           3 * Hd, S * 3 * Hd, Hd, S * Hd, S_pad, float(scale),
+                                           x0 if extra_last else None, x0 + Hd * es if extra_last else None,
+                                           x0 + 2 * Hd * es if extra_last else None,
+                                           out.data_ptr() + (S - 1) * Hd * es if extra_last else None,
+                                           S * 3 * Hd, S * Hd, 1 if extra_last else 0, _stream()),
                "u2tok_flash_attention_d64")
     return out
 
