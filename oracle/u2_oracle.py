@@ -214,12 +214,23 @@ def rope_attention(sd: SD, p: str, query, key, value, heads: int, max_seq_len: i
     return _lin(ctx, sd, p + ".dense"), w
 
 
+def mha_attention(sd: SD, p: str, x: torch.Tensor, heads: int) -> torch.Tensor:
+    """torch.nn.MultiheadAttention(embed, heads) called as m(x, x, x) with its default batch_first=False
+    (svr.py:17-18,29,35; tta.py:84,94): dim 0 of x is the SEQUENCE, dim 1 the batch -- so the "spatial" call attends
+    across chunks and the "temporal" call across tokens.  torch's own functional is the reference's
+    dependency, not reference code: call it directly."""
+    out, _ = F.multi_head_attention_forward(
+        x, x, x, x.shape[-1], heads, sd[p + ".in_proj_weight"], sd[p + ".in_proj_bias"], None, None, False, 0.0,
+        sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"], training=False, need_weights=False)
+    return out
+
+
 def self_attention(sd, p, x, heads, attn_type, max_seq_len):
     if attn_type == "rma":
         return rma_attention(sd, p, x, x, x, heads, max_seq_len)[0]
     if attn_type == "rope":
         return rope_attention(sd, p, x, x, x, heads, max_seq_len)[0]
-    raise NotImplementedError("attn_type other than rma/rope (nn.MultiheadAttention 'linvt' ablation) is out of scope")
+    return mha_attention(sd, p, x, heads)  # every other value builds nn.MultiheadAttention (svr.py:16-18, tta.py:83-84)
 
 
 def cross_attention(sd: SD, p: str, query, value, heads: int, is_compress=False):

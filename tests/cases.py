@@ -18,6 +18,9 @@ TOKENIZER_CASES = {
     # diffts with fixed pooling (the "diffts" ablation)
     "diffts_fix": dict(_B, E=512, layers=1, B=1, T=2, N=32, Lt=16, Q=16, top_k=24, use_multi_scale=True,
                        attn_type="rma", enable_diffts=True, enable_dmtp=False, seed=14),
+    # attn_type outside {rma, rope} -> stock nn.MultiheadAttention read sequence-first (the "linvt" ablation)
+    "linvt_2l": dict(_B, E=512, layers=2, B=1, T=4, N=24, Lt=20, Q=16, top_k=32, use_multi_scale=True,
+                     attn_type="linvt", enable_diffts=True, enable_dmtp=True, seed=15),
 }
 
 SPP_CASES = {

@@ -254,6 +254,26 @@ namespace {
 struct Att {
   const bf16_t *wq, *bq, *wk, *bk, *wv, *bv, *wd, *bd, *rb;
 };
+// The host module packs wq | wk | wv (and their biases) back to back in HBM (tokenizer.py: pack_weights); when it
+// did, the three projections of one input are ONE GEMM with N = 3E (2E for the k | v pair of a cross attention):
+// the activation panel is read once and the launch fills the machine 3x better at small M.
+inline bool kv_packed(const Att& a, int E) {
+  return a.wk && a.bk && a.wv == a.wk + (size_t)E * E && a.bv == a.bk + E;
+}
+inline bool qkv_packed(const Att& a, int E) {
+  return a.wq && a.bq && a.wk == a.wq + (size_t)E * E && a.bk == a.bq + E && kv_packed(a, E);
+}
+// q | k | v = x W^T + b into out[rows][3E]
+int qkv_proj(const bf16_t* x, const Att& a, bf16_t* out, int64_t rows, int E, bool dry, hipStream_t st) {
+  if (!dry && qkv_packed(a, E)) {
+    U2_RUN(linear(x, E, a.wq, a.bq, out, 3 * E, rows, E, 3 * E, 0, nullptr, 0, st));
+    return U2_OK;
+  }
+  U2_RUN(linear(x, E, a.wq, a.bq, out, 3 * E, rows, E, E, 0, nullptr, 0, st));
+  U2_RUN(linear(x, E, a.wk, a.bk, out + E, 3 * E, rows, E, E, 0, nullptr, 0, st));
+  U2_RUN(linear(x, E, a.wv, a.bv, out + 2 * E, 3 * E, rows, E, E, 0, nullptr, 0, st));
+  return U2_OK;
+}
 }  // namespace
 
 int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_token, const bf16_t* t_token,
@@ -261,7 +281,11 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
                       size_t* peak, hipStream_t st) {
   if (c.B <= 0 || c.T <= 0 || c.N <= 0 || c.E <= 0 || c.Lt <= 0 || c.num_heads <= 0 || c.num_layers < 0) return U2_ERR_ARG;
   if (c.E % c.num_heads || (c.E / c.num_heads) % 8 || c.top_k <= 0 || c.num_query <= 0) return U2_ERR_ARG;
-  if (c.attn_type != 0 && c.attn_type != 1) return U2_ERR_ARG;
+  if (c.attn_type < 0 || c.attn_type > 2) return U2_ERR_ARG;
+  // attn_type 2 = nn.MultiheadAttention read sequence-first (svr.py:16-18,28-35): attention runs across whatever sits
+  // in dim 0, including the batch entries -- implemented for B = 1, where "spatial" = across the T chunks and
+  // "temporal" = across the N tokens of a chunk, and the TTA self-attention sees a sequence of length 1.
+  if (c.attn_type == 2 && c.B != 1) return U2_ERR_ARG;
   if (!dry && (!W || !v_token || !t_token || !out)) return U2_ERR_ARG;
   const int B = c.B, T = c.T, N = c.N, E = c.E, H = c.num_heads, d = E / H, L = c.num_layers, Q = c.num_query;
   const int TN = T * N, k = c.top_k;
@@ -291,14 +315,14 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
     const Att sp = att_at(1 + 18 * l), tp = att_at(1 + 18 * l + 9);
     bf16_t* y = (x == xa) ? xb : xa;
     // spatial: sequences of N tokens inside each chunk (svr.py:27-30)
-    U2_RUN(linear(x, E, sp.wq, sp.bq, qkv, 3 * E, rows, E, E, 0, nullptr, 0, st));
-    U2_RUN(linear(x, E, sp.wk, sp.bk, qkv + E, 3 * E, rows, E, E, 0, nullptr, 0, st));
-    U2_RUN(linear(x, E, sp.wv, sp.bv, qkv + 2 * E, 3 * E, rows, E, E, 0, nullptr, 0, st));
+    { const int e = qkv_proj(x, sp, qkv, rows, E, dry, st); if (e != U2_OK) return e; }
     if (c.attn_type == 1) {
       U2_RUN(rope_apply(qkv, (int64_t)B * T, N, 1, H, d, 3 * E, c.max_seq_len, st));
       U2_RUN(rope_apply(qkv + E, (int64_t)B * T, N, 1, H, d, 3 * E, c.max_seq_len, st));
     }
-    {
+    if (c.attn_type == 2) {  // sequence = the T chunks, batch = token position
+      U2_RUN(temporal_attention(qkv, qkv + E, qkv + 2 * E, ctx, B, T, N, H, d, 3 * E, E, scale, nullptr, c.max_seq_len, st));
+    } else {
       AttnCore a{qkv, qkv + E, qkv + 2 * E, 3 * E, 3 * E, 3 * E, (int64_t)N * 3 * E, (int64_t)N * 3 * E,
                  (int64_t)N * 3 * E, ctx, E, (int64_t)N * E, B * T, N, N, H, d, scale, sp.rb, c.max_seq_len};
       const int e = attention_core(ar, a, dry, st);
@@ -307,14 +331,19 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
     U2_RUN(linear(ctx, E, sp.wd, sp.bd, y, E, rows, E, E, 0, nullptr, 0, st));
     // temporal: sequences of T chunks at each token position (svr.py:32-36); rows stay in (b t n) order
     bf16_t* y2 = (y == xa) ? xb : xa;
-    U2_RUN(linear(y, E, tp.wq, tp.bq, qkv, 3 * E, rows, E, E, 0, nullptr, 0, st));
-    U2_RUN(linear(y, E, tp.wk, tp.bk, qkv + E, 3 * E, rows, E, E, 0, nullptr, 0, st));
-    U2_RUN(linear(y, E, tp.wv, tp.bv, qkv + 2 * E, 3 * E, rows, E, E, 0, nullptr, 0, st));
+    { const int e = qkv_proj(y, tp, qkv, rows, E, dry, st); if (e != U2_OK) return e; }
     if (c.attn_type == 1) {
       U2_RUN(rope_apply(qkv, B, T, N, H, d, 3 * E, c.max_seq_len, st));
       U2_RUN(rope_apply(qkv + E, B, T, N, H, d, 3 * E, c.max_seq_len, st));
     }
-    U2_RUN(temporal_attention(qkv, qkv + E, qkv + 2 * E, ctx, B, T, N, H, d, 3 * E, E, scale, tp.rb, c.max_seq_len, st));
+    if (c.attn_type == 2) {  // sequence = the N tokens of a chunk, batch = chunk
+      AttnCore a{qkv, qkv + E, qkv + 2 * E, 3 * E, 3 * E, 3 * E, (int64_t)N * 3 * E, (int64_t)N * 3 * E,
+                 (int64_t)N * 3 * E, ctx, E, (int64_t)N * E, B * T, N, N, H, d, scale, nullptr, 0};
+      const int e = attention_core(ar, a, dry, st);
+      if (e != U2_OK) return e;
+    } else {
+      U2_RUN(temporal_attention(qkv, qkv + E, qkv + 2 * E, ctx, B, T, N, H, d, 3 * E, E, scale, tp.rb, c.max_seq_len, st));
+    }
     U2_RUN(linear(ctx, E, tp.wd, tp.bd, y2, E, rows, E, E, 0, nullptr, 0, st));
     x = y2;
   }
@@ -396,8 +425,12 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
   auto cross = [&](const Att& a, const bf16_t* src, int Ls, const bf16_t* qin, bf16_t* dst) -> int {
     // MultiHeadCrossAttention.forward (tta.py:42-69), is_compress = False
     U2_RUN(linear(qin, E, a.wq, a.bq, qproj, E, qrows, E, E, 0, nullptr, 0, st));
-    U2_RUN(linear(src, E, a.wk, a.bk, kv, 2 * E, (int64_t)B * Ls, E, E, 0, nullptr, 0, st));
-    U2_RUN(linear(src, E, a.wv, a.bv, kv + E, 2 * E, (int64_t)B * Ls, E, E, 0, nullptr, 0, st));
+    if (!dry && kv_packed(a, E)) {
+      U2_RUN(linear(src, E, a.wk, a.bk, kv, 2 * E, (int64_t)B * Ls, E, 2 * E, 0, nullptr, 0, st));
+    } else {
+      U2_RUN(linear(src, E, a.wk, a.bk, kv, 2 * E, (int64_t)B * Ls, E, E, 0, nullptr, 0, st));
+      U2_RUN(linear(src, E, a.wv, a.bv, kv + E, 2 * E, (int64_t)B * Ls, E, E, 0, nullptr, 0, st));
+    }
     AttnCore ac{qproj, kv, kv + E, E, 2 * E, 2 * E, (int64_t)Q * E, (int64_t)Ls * 2 * E, (int64_t)Ls * 2 * E,
                 qctx, E, (int64_t)Q * E, B, Q, Ls, H, d, scale, nullptr, 0};
     const int e = attention_core(ar, ac, dry, st);
@@ -415,14 +448,16 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
     bf16_t* s1 = (qcur == qa) ? qb : qa;
     bf16_t* s2 = qc;
     // self attention on the query tokens + post-LN residual (tta.py:94-96)
-    U2_RUN(linear(qcur, E, sa.wq, sa.bq, qproj, 3 * E, qrows, E, E, 0, nullptr, 0, st));
-    U2_RUN(linear(qcur, E, sa.wk, sa.bk, qproj + E, 3 * E, qrows, E, E, 0, nullptr, 0, st));
-    U2_RUN(linear(qcur, E, sa.wv, sa.bv, qproj + 2 * E, 3 * E, qrows, E, E, 0, nullptr, 0, st));
-    if (c.attn_type == 1) {
-      U2_RUN(rope_apply(qproj, B, Q, 1, H, d, 3 * E, c.max_seq_len, st));
-      U2_RUN(rope_apply(qproj + E, B, Q, 1, H, d, 3 * E, c.max_seq_len, st));
-    }
-    {
+    if (c.attn_type == 2) {
+      // (B = 1, Q, E) read sequence-first: every query token is a batch entry with a sequence of ONE key, whose
+      // softmax weight is exactly 1 -> the context is the value projection itself (tta.py:84,94)
+      U2_RUN(linear(qcur, E, sa.wv, sa.bv, qctx, E, qrows, E, E, 0, nullptr, 0, st));
+    } else {
+      { const int e = qkv_proj(qcur, sa, qproj, qrows, E, dry, st); if (e != U2_OK) return e; }
+      if (c.attn_type == 1) {
+        U2_RUN(rope_apply(qproj, B, Q, 1, H, d, 3 * E, c.max_seq_len, st));
+        U2_RUN(rope_apply(qproj + E, B, Q, 1, H, d, 3 * E, c.max_seq_len, st));
+      }
       AttnCore ac{qproj, qproj + E, qproj + 2 * E, 3 * E, 3 * E, 3 * E, (int64_t)Q * 3 * E, (int64_t)Q * 3 * E,
                   (int64_t)Q * 3 * E, qctx, E, (int64_t)Q * E, B, Q, Q, H, d, scale, sa.rb, c.max_seq_len};
       const int e = attention_core(ar, ac, dry, st);

@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from . import _lib, ops
 
-_ATTN_TYPES = {"rma": 0, "rope": 1}
+_ATTN_TYPES = {"rma": 0, "rope": 1}  # every other value: 2 = nn.MultiheadAttention, as in the reference
 
 
 def _init_attn(m):
@@ -83,9 +83,9 @@ def _self_attention(embed_size, num_heads, attn_type):
         return RelativeMultiheadAttention(embed_size, num_heads)
     if attn_type == "rope":
         return RotaryMultiheadAttention(embed_size, num_heads)
-    raise NotImplementedError(
-        f"attn_type={attn_type!r}: the nn.MultiheadAttention ('linvt') ablation of svr.py:17-18 / tta.py:84 is "
-        "not implemented on the HIP path (supported: 'rma', 'rope')")
+    # svr.py:16-18 / tta.py:83-84: any other value builds the stock module (the "linvt" ablation checkpoints);
+    # it only holds the parameters here (in_proj_weight (3E, E), in_proj_bias, out_proj.{weight,bias})
+    return nn.MultiheadAttention(embed_size, num_heads)
 
 
 class SpatioTemporalAttentionLayer(nn.Module):
@@ -169,7 +169,35 @@ class TextConditionTokenAggregatorModel(nn.Module):
         self.layer_linagg = LinearAggregation(d_model, num_heads)
 
 
+def _pack_qkv(m) -> None:
+    if isinstance(m, nn.MultiheadAttention):
+        return  # in_proj_weight is already q | k | v
+    _pack_qkv_linear(m)
+
+
+def _pack_qkv_linear(m) -> None:
+    """Weight packing: lay wq | wk | wv (and biases) of one attention module back to back in HBM so
+    the library can run the three projections as ONE GEMM (pipeline.hip: qkv_packed / kv_packed).  The
+    nn.Parameters keep their names and shapes -- only their storage becomes a view of the packed buffer, so
+    state_dict() / load_state_dict() are unaffected."""
+    ws, bs = [m.wq.weight, m.wk.weight, m.wv.weight], [m.wq.bias, m.wk.bias, m.wv.bias]
+    E = ws[0].shape[0]
+    step_w, step_b = ws[0].numel() * ws[0].element_size(), bs[0].numel() * bs[0].element_size()
+    if all(w.is_contiguous() for w in ws) and all(ws[i + 1].data_ptr() == ws[i].data_ptr() + step_w for i in (0, 1)) \
+            and all(bs[i + 1].data_ptr() == bs[i].data_ptr() + step_b for i in (0, 1)):
+        return
+    W = torch.cat([w.data for w in ws], 0).contiguous()  # noqa: N806
+    Bv = torch.cat([b.data for b in bs], 0).contiguous()
+    for i in range(3):
+        ws[i].data = W[i * E:(i + 1) * E]
+        bs[i].data = Bv[i * E:(i + 1) * E]
+
+
 def _att_ptrs(m):
+    if isinstance(m, nn.MultiheadAttention):  # packed q | k | v rows of in_proj_weight; no relative bias
+        E = m.embed_dim
+        W, b = m.in_proj_weight, m.in_proj_bias
+        return [W[:E], b[:E], W[E:2 * E], b[E:2 * E], W[2 * E:], b[2 * E:], m.out_proj.weight, m.out_proj.bias, None]
     return [m.wq.weight, m.wq.bias, m.wk.weight, m.wk.bias, m.wv.weight, m.wv.bias, m.dense.weight, m.dense.bias,
             getattr(m, "relative_bias", None)]
 
@@ -194,6 +222,7 @@ class u2Tokenizer(nn.Module):
         self.use_multi_scale, self.num_query, self.attn_type = bool(use_multi_scale), num_3d_query_token, attn_type
         self.enable_diffts, self.enable_dmtp = bool(enable_diffts), bool(enable_dmtp)
         self._ws = ops._Workspace()
+        self._packed_key = None
         self.last_topk_indices = None  # (B, top_k) int64 -- set by forward() when hard top-k selection is on
         self.capture_svr_tokens = False  # True: forward() also keeps the refined tokens in last_svr_tokens
         self.last_svr_tokens = None
@@ -216,18 +245,38 @@ class u2Tokenizer(nn.Module):
         w += _att_ptrs(self.tta_module.layer_linagg.linear_aggregator)
         return w
 
+    def pack_weights(self) -> None:
+        """Idempotent; re-run automatically after .to() moved the parameters to fresh (unpacked) storage."""
+        key = (self.query_tokens.data_ptr(), self.query_tokens.dtype)
+        if self._packed_key == key:
+            return
+        for layer in self.svt_module.attention_network.layers:
+            _pack_qkv(layer.spatial_attention)
+            _pack_qkv(layer.temporal_attention)
+        for layer in self.tta_module.layers_vt:
+            for m in (layer.self_attention, layer.visual_cross_attention, layer.text_cross_attention):
+                _pack_qkv(m)
+        self._packed_key = key
+
     def forward(self, v_token, t_token):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise RuntimeError("the HIP u2Tokenizer is forward-only in this round: call under torch.no_grad()")
         h = _lib.load_library()
+        if self.query_tokens.is_cuda:
+            self.pack_weights()
         v_token = ops._need(v_token, torch.bfloat16, "v_token").contiguous()
         t_token = ops._need(t_token, torch.bfloat16, "t_token").contiguous()
         (B, T, N, E) = v_token.size()
+        if self.attn_type not in _ATTN_TYPES and B != 1:
+            raise NotImplementedError(
+                "attn_type outside {'rma', 'rope'}: nn.MultiheadAttention reads (b*t, n, e) sequence-first, i.e. it "
+                "attends ACROSS the batch entries (svr.py:28-35, tta.py:94); the HIP path implements that variant for "
+                "B = 1 only")
         if E != self.embed_size or t_token.shape[0] != B or t_token.shape[2] != E:
             raise RuntimeError(f"shape mismatch: v_token {tuple(v_token.shape)}, t_token {tuple(t_token.shape)}")
         cfg = _lib.TokConfig(B=B, T=T, N=N, E=E, Lt=t_token.shape[1], num_heads=self.num_heads,
                              num_layers=self.num_layers, top_k=self.top_k, num_query=self.num_query,
-                             use_multi_scale=int(self.use_multi_scale), attn_type=_ATTN_TYPES[self.attn_type],
+                             use_multi_scale=int(self.use_multi_scale), attn_type=_ATTN_TYPES.get(self.attn_type, 2),
                              enable_diffts=int(self.enable_diffts), enable_dmtp=int(self.enable_dmtp),
                              max_seq_len=512, diffts_tau=float(getattr(self.svt_module.token_selection, "tau", 1.0)),
                              ln_eps=1e-5)
