@@ -39,6 +39,10 @@ int u2tok_device_check(void);          /* 0 if the current HIP device is gfx950,
 int u2tok_set_option(const char* name, int value); /* "gemm_glds" {0,1}, "gemm_tile" {0,64,128}, "gemm_bk" {32,64},
                                                       "vit_flash" {0,1}, "profile" {0,1};
                                                       returns U2TOK_ERR_ARG if unknown */
+/* Diagnostics only: device buffer (>= 256*8*5 uint64) that the s_memtime-instrumented builds of the ping-pong GEMM
+ * (u2tok_set_option("gemm_pp", 14..17)) fill with per-wave segment timings; NULL detaches it. */
+int u2tok_debug_buffer(void* device_ptr);
+
 /* With option "profile" = 1 every launch is bracketed by hipEvents on its stream.  Collect (HOST arrays of ncat <= 5
  * entries; synchronises on the recorded events, then resets): summed milliseconds, algorithmic FLOPs and launch
  * counts per kernel class 0 = MFMA GEMM, 1 = ViT flash attention, 2 = temporal attention, 3 = row ops

@@ -290,7 +290,7 @@ def _pp_cases():
 
 def sec_ppc(v=None):
     """correctness + repeatability of one forced ping-pong variant (python tools/gpu_check.py ppc:<v>)"""
-    vs = [int(v)] if v else list(range(1, 9))
+    vs = [int(x) for x in str(v).split(",")] if v else list(range(1, 8))
     for v in vs:
         ops.set_option("gemm_pp", v)
         print(f"[pp correctness] variant {v}", flush=True)
@@ -318,7 +318,10 @@ def sec_ppc(v=None):
     ops.set_option("gemm_pp", 0)
 
 
-def sec_ppperf():
+PP_PERF_VARIANTS = (-1, 0, 1, 2, 3, 4, 5, 6, 7, 10, 11, 12, 13)
+
+
+def sec_ppperf(shapes_sel=None):
     print("[pp perf] (random normal operands; us and TF/s; c = classic 128^2/64^2 kernel, a = heuristic)", flush=True)
     shapes = [(16384, 2304, 768, {}), (16392, 2304, 768, {}), (16384, 768, 768, dict(bias=True, residual=True)),
               (16384, 3072, 768, dict(bias=True, gelu=True)), (16384, 3072, 768, dict(bias=True)),
@@ -326,13 +329,15 @@ def sec_ppperf():
               (2048, 4096, 4096, dict(bias=True)), (2048, 12288, 4096, dict(bias=True)), (1792, 8192, 4096, dict(bias=True)),
               (1024, 8192, 4096, dict(bias=True)), (1024, 4096, 4096, dict(bias=True)), (256, 4096, 4096, dict(bias=True)),
               (256, 12288, 4096, dict(bias=True)), (2048, 1024, 4096, {}), (4096, 4096, 4096, {}), (8192, 8192, 8192, {})]
+    if shapes_sel == "few":
+        shapes = [shapes[0], shapes[3], shapes[5], shapes[7], shapes[8], shapes[15], shapes[16]]
     for (M, N, K, kw) in shapes:
         a, b = rnd(M, K, seed=1).to(dev), rnd(N, K, seed=2).to(dev)
         bias = rnd(N, seed=3).to(dev) if kw.get("bias") else None
         res = rnd(M, N, seed=4).to(dev) if kw.get("residual") else None
         out = torch.empty((1, M, N), dtype=bf, device=dev)
         line = f"  {M:5d}x{N:5d}x{K:4d} {'+'.join(sorted(kw)) or '-':18s}"
-        for v in (-1, 0, 1, 2, 3, 4, 5, 6, 7, 8):
+        for v in PP_PERF_VARIANTS:
             ops.set_option("gemm_pp", v)
             try:
                 ms = timeit(lambda: ops.gemm(a, b, bias=bias, residual=res, gelu=bool(kw.get("gelu")), out=out), iters=8, warm=2)
@@ -369,6 +374,29 @@ def _flash_ref(qkv, H):
     x = qkv.float().view(nb, S, 3, H, 64).permute(2, 0, 3, 1, 4)
     p = F.softmax(x[0] @ x[1].transpose(-1, -2) * 0.125, dim=-1)
     return (p @ x[2]).permute(0, 2, 1, 3).reshape(nb, S, H * 64)
+
+
+def sec_pptime():
+    """s_memtime breakdown of the SB-scheduled ping-pong GEMM (variants 14..17), per group, cycles per segment"""
+    from u2tokenizer_amd import _lib
+    h = _lib.load_library()
+    buf = torch.zeros(256 * 8 * 8, dtype=torch.int64, device=dev)
+    _lib.check(h.u2tok_debug_buffer(buf.data_ptr()), "debug_buffer")
+    for (M, N, K) in [(4096, 4096, 4096), (8192, 8192, 8192), (16384, 3072, 768)]:
+        a, b = rnd(M, K, seed=1).to(dev), rnd(N, K, seed=2).to(dev)
+        out = torch.empty((1, M, N), dtype=bf, device=dev)
+        for v, name in [(14, "SB glds"), (15, "SB reg-staged"), (16, "reg-staged no MFMA"), (17, "no DMA")]:
+            ops.set_option("gemm_pp", v)
+            buf.zero_()
+            ms = timeit(lambda: ops.gemm(a, b, out=out), iters=3, warm=1)
+            r = buf.view(256, 2, 4, 8).double()  # [block][group][wave][Lvm, waitL, M, waitM, nseg, Lissue, Lreads, -]
+            n = r[..., 4].clamp_min(1)
+            per = r / n[..., None]
+            g0, g1 = per[:, 0].mean((0, 1)), per[:, 1].mean((0, 1))
+            fmt = lambda g: f"Lissue {g[5]:5.0f} Lreads {g[6]:5.0f} Lvm {g[0]:5.0f} wL {g[1]:5.0f} M {g[2]:5.0f} wM {g[3]:5.0f}"  # noqa: E731
+            print(f"  {M}x{N}x{K} v{v} {name:18s} {ms * 1e3:8.1f} us | G0 {fmt(g0)} | G1 {fmt(g1)}", flush=True)
+    ops.set_option("gemm_pp", 0)
+    h.u2tok_debug_buffer(None)
 
 # ------------------------------------------------------------------------------------------- perf
 def sec_perf():

@@ -98,5 +98,5 @@ def run(BN, BK, NS, M=256, K=128, seed=0):
 
 
 if __name__ == "__main__":
-    for cfg in [(128, 64, 3), (128, 32, 4), (128, 32, 6), (192, 32, 4), (192, 32, 5), (192, 64, 2), (256, 32, 4), (256, 32, 5)]:
+    for cfg in [(128, 64, 3), (192, 64, 2), (256, 64, 2), (256, 32, 4), (192, 32, 4)]:
         print(cfg, run(*cfg))

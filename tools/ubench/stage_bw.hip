@@ -1,0 +1,103 @@
+// Microbenchmark: how fast can one workgroup per CU move GEMM-shaped operand tiles from L2/HBM into LDS?
+//   mode 0: global_load_lds_dwordx4 (LDS-DMA)         mode 1: global_load_dwordx4 -> VGPR -> ds_write_b128
+//   mode 2: global_load_dwordx4 -> VGPR only (no LDS)
+// Access pattern = gemm_pp.hip's: workgroup b streams K tiles of a [ROWS][BK] bf16 panel pair out of two
+// [8192][8192] matrices, 16 bytes per lane, DEPTH K tiles in flight.  build: hipcc --offload-arch=gfx950 -O3
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+template <int MODE, int BK, int DEPTH, int NWAVES_ISSUE, int SWZ = 0>
+__global__ __launch_bounds__(512) void stage_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B,
+                                                    int K, int lda, int ntile, unsigned* sink) {
+  constexpr int ROWS = 512, CPR = BK / 8, RPP = 64 / CPR, STAGE = ROWS * BK * 2, NP = STAGE / 1024;
+  constexpr int PW = NP / NWAVES_ISSUE;  // pieces per issuing wave
+  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned acc = 0;
+  if (wave < NWAVES_ISSUE) {
+    for (int t = 0; t < ntile; ++t) {
+      const int tile = blockIdx.x + t * gridDim.x;
+      const int bm0 = (tile % 32) * 256, bn0 = (tile / 32 % 32) * 256;
+      const unsigned short* src[PW];
+#pragma unroll
+      for (int i = 0; i < PW; ++i) {
+        const int r = (i * NWAVES_ISSUE + wave) * RPP + lane / CPR;
+        int gc = lane % CPR;
+        if (SWZ == 1) gc ^= (r >> 1) & 7;            // full 16-B chunk swizzle (gemm_pp.hip)
+        if (SWZ == 2) gc ^= ((r >> 1) & 3) << 1;     // 32-B pairs stay together
+        if (SWZ == 3) gc ^= ((r >> 1) & 1) << 2;     // swap 64-B halves only
+        if (SWZ == 4) gc = (gc + (r & 7)) & 7;       // rotation
+        src[i] = (r < 256 ? A + (size_t)(bm0 + r) * lda : B + (size_t)(bn0 + r - 256) * lda) + gc * 8;
+      }
+      const int nkt = K / BK;
+      for (int kt = 0; kt < nkt; ++kt) {
+        char* s = lds + (kt & 1) * STAGE + wave * 1024;
+        if constexpr (MODE == 0) {
+#pragma unroll
+          for (int i = 0; i < PW; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)(s + i * NWAVES_ISSUE * 1024), 16, 0, 0);
+          if (kt >= DEPTH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * DEPTH > 63 ? 63 : PW * DEPTH) : "memory");
+        } else {
+          uint4 r[PW];
+#pragma unroll
+          for (int i = 0; i < PW; ++i) r[i] = *reinterpret_cast<const uint4*>(src[i] + kt * BK);
+          if constexpr (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < PW; ++i) *reinterpret_cast<uint4*>(s + i * NWAVES_ISSUE * 1024 + lane * 16) = r[i];
+          } else {
+#pragma unroll
+            for (int i = 0; i < PW; ++i) acc += r[i].x ^ r[i].w;
+          }
+        }
+      }
+    }
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+
+template <int MODE, int BK, int DEPTH, int NW, int SWZ = 0>
+static void run(const char* name, const unsigned short* A, const unsigned short* B, unsigned* sink) {
+  const int K = 8192, ntile = 4;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((stage_kernel<MODE, BK, DEPTH, NW, SWZ>), dim3(256), dim3(512), 0, 0, A, B, K, 8192, ntile, sink);
+  hipEventRecord(e0);
+  const int it = 5;
+  for (int w = 0; w < it; ++w) hipLaunchKernelGGL((stage_kernel<MODE, BK, DEPTH, NW, SWZ>), dim3(256), dim3(512), 0, 0, A, B, K, 8192, ntile, sink);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1); ms /= it;
+  const double bytes = 256.0 * ntile * (K / BK) * 512 * BK * 2;
+  printf("%-44s %8.1f us  %6.2f TB/s  %5.1f B/clk/CU@2.1GHz\n", name, ms * 1e3, bytes / ms / 1e9, bytes / 256 / (ms * 1e-3 * 2.1e9));
+}
+
+int main() {
+  const size_t n = (size_t)8192 * 8192;
+  unsigned short *A, *B; unsigned* sink;
+  hipMalloc(&A, n * 2); hipMalloc(&B, n * 2); hipMalloc(&sink, 64);
+  std::vector<unsigned short> h(n);
+  for (size_t i = 0; i < n; ++i) h[i] = (unsigned short)(rand() & 0x3fff) | 0x3c00;
+  hipMemcpy(A, h.data(), n * 2, hipMemcpyHostToDevice); hipMemcpy(B, h.data(), n * 2, hipMemcpyHostToDevice);
+  run<0, 32, 2, 8>("glds  BK32 depth2 8 waves", A, B, sink);
+  run<0, 32, 4, 8>("glds  BK32 depth4 8 waves", A, B, sink);
+  run<0, 64, 2, 8>("glds  BK64 depth2 8 waves", A, B, sink);
+  run<0, 64, 1, 8>("glds  BK64 depth1 8 waves", A, B, sink);
+  run<0, 64, 2, 4>("glds  BK64 depth2 4 waves", A, B, sink);
+  run<0, 64, 2, 8, 1>("glds  BK64 8 waves swz full-xor", A, B, sink);
+  run<0, 64, 2, 8, 2>("glds  BK64 8 waves swz 32B-pairs", A, B, sink);
+  run<0, 64, 2, 8, 3>("glds  BK64 8 waves swz 64B-halves", A, B, sink);
+  run<0, 64, 2, 8, 4>("glds  BK64 8 waves swz rotate", A, B, sink);
+  run<0, 64, 2, 4, 1>("glds  BK64 4 waves swz full-xor", A, B, sink);
+  run<1, 64, 0, 4, 1>("load+ds_write BK64 4 waves swz full-xor", A, B, sink);
+  run<0, 32, 4, 4>("glds  BK32 depth4 4 waves", A, B, sink);
+  run<1, 32, 0, 8>("load+ds_write BK32 8 waves", A, B, sink);
+  run<1, 64, 0, 8>("load+ds_write BK64 8 waves", A, B, sink);
+  run<1, 64, 0, 4>("load+ds_write BK64 4 waves", A, B, sink);
+  run<2, 32, 0, 8>("load only BK32 8 waves", A, B, sink);
+  run<2, 64, 0, 8>("load only BK64 8 waves", A, B, sink);
+  run<2, 64, 0, 4>("load only BK64 4 waves", A, B, sink);
+  return 0;
+}

@@ -39,7 +39,7 @@ int u2tok_set_option(const char* name, int value) {
     return U2_OK;
   }
   if (!strcmp(name, "gemm_pp")) {
-    if (value < -1 || value > 8) return U2_ERR_ARG;
+    if (value < -1 || value > 17) return U2_ERR_ARG;
     gemm_pp_set_options(value, -1);
     return U2_OK;
   }
@@ -57,6 +57,8 @@ int u2tok_set_option(const char* name, int value) {
   if (!strcmp(name, "profile")) { prof_enable(value != 0); return U2_OK; }
   return U2_ERR_ARG;
 }
+
+int u2tok_debug_buffer(void* device_ptr) { return gemm_pp_set_debug_buffer(device_ptr); }
 
 int u2tok_profile_collect(double* ms, double* flops, int64_t* count, int32_t ncat) {
   if (!ms || !flops || !count || ncat <= 0 || ncat > PROF_NCAT) return U2_ERR_ARG;

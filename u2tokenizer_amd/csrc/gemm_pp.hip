@@ -31,10 +31,18 @@
 namespace u2 {
 
 __device__ uint4 g_pp_zero16;  // zero source for K-tail chunks
+// diagnostics (ABL bit 3 builds only): per (workgroup, wave) 8 uint64: sums of s_memtime deltas [L tail (vmcnt wait),
+// wait at the barrier closing L, M work, wait at the barrier closing M], segment count, [L issue part, L fragment reads]
+__device__ unsigned long long* g_pp_dbg;
 
-template <int BN_, int BK_, int NS_>
+// INM: issue the LDS-DMA of a K tile from the M segment (between the MFMAs) instead of the head of the L segment.
+// ABL: measurement-only ablations (bit 0: no MFMAs, bit 1: no DMA after the prologue, bit 2: no fragment reads).
+// SPLIT: segments per K tile and group (2: a K tile is consumed as two half-depth L/M pairs, which is what lets a
+//        2-stage ring of full 128-byte rows (BK = 64) keep a tile in flight for >= 2 segments).
+template <int BN_, int BK_, int NS_, bool INM_ = false, int ABL_ = 0, int SPLIT_ = 1>
 struct PPCfg {
-  static constexpr int BM = 256, BN = BN_, BK = BK_, NS = NS_;
+  static constexpr int BM = 256, BN = BN_, BK = BK_, NS = NS_, ABL = ABL_, SPLIT = SPLIT_;
+  static constexpr bool INM = INM_;
   static constexpr int ROWB = BK * 2;            // bytes per LDS row
   static constexpr int CPR = BK / 8;             // 16-byte chunks per row
   static constexpr int RPP = 64 / CPR;           // rows covered by one 1-KiB DMA piece (one wave instruction)
@@ -48,7 +56,8 @@ struct PPCfg {
   static constexpr int LDS_BYTES = NS * STAGE;
   static_assert(BK == 32 || BK == 64, "BK");
   static_assert(BN % 64 == 0 && NP % 4 == 0 && PG1 >= 1, "piece split");
-  static_assert(NS >= 2 && LDS_BYTES <= 160 * 1024, "LDS budget");
+  static_assert(NS >= ((INM && SPLIT == 1) ? 3 : 2) && LDS_BYTES <= 160 * 1024, "LDS budget");
+  static_assert((SPLIT == 1 || SPLIT == 2) && KSTEPS % SPLIT == 0 && (SPLIT == 2 || NS >= 3 || !INM), "split");
 };
 
 template <int BK>
@@ -194,7 +203,13 @@ __device__ __forceinline__ void pp_group(const GemmDesc& d, char* lds, const int
   constexpr int STAGE = CFG::STAGE, KSTEPS = CFG::KSTEPS, NI = CFG::NI;
   constexpr int PG = (G == 0) ? CFG::PG0 : CFG::PG1;  // DMA pieces this wave issues per K tile
   constexpr int P0 = (G == 0) ? 0 : 4 * CFG::PG0;
-  constexpr int WAITN = (NS - 2) * PG;                // pieces younger than the K tile that must have landed
+  constexpr bool INM = CFG::INM;
+  constexpr int ABL = CFG::ABL;
+  // pieces this wave issued AFTER the K tile that must have landed at its wait point
+  constexpr int WAITN = (NS - 2) * PG;
+  constexpr int SPLIT = CFG::SPLIT, KH = KSTEPS / SPLIT;
+  constexpr bool LATE = INM && SPLIT == 1;  // group 1's wait precedes its issue of the same iteration
+  constexpr int WAITN_L = LATE ? (NS - 3) * PG : WAITN;
   const int hi = lane >> 5, l31 = lane & 31;
   const int wm2 = j >> 1, wn2 = j & 1;
 
@@ -224,20 +239,27 @@ __device__ __forceinline__ void pp_group(const GemmDesc& d, char* lds, const int
       else src[i] = B_ + (int64_t)min(bn0_ + r_ - 256, d.N - 1) * d.ldb + gc_ * 8;               \
     }                                                                                            \
   }
-#define PP_ISSUE()                                                                                              \
+#define PP_ISSUE_PIECE(i_)                                                                                      \
   {                                                                                                             \
-    char* s_ = lds + is_stage * STAGE + (P0 + j) * 1024;                                                        \
     const int k0_ = is_kt * BK;                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < PG; ++i) {                                                            \
-      const void* g_ = (k0_ + kc[i] < d.K) ? (const void*)(src[i] + k0_) : (const void*)&g_pp_zero16;           \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_,                       \
-                                       (__attribute__((address_space(3))) void*)(s_ + i * 4096), 16, 0, 0);     \
-    }                                                                                                           \
+    const void* g_ = (k0_ + kc[i_] < d.K) ? (const void*)(src[i_] + k0_) : (const void*)&g_pp_zero16;           \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_,                         \
+                                     (__attribute__((address_space(3))) void*)(lds + is_stage * STAGE +         \
+                                                                               (P0 + j) * 1024 + (i_) * 4096),  \
+                                     16, 0, 0);                                                                 \
+  }
+#define PP_ISSUE_ADVANCE()                                                                                      \
+  {                                                                                                             \
     is_stage = (is_stage + 1 == NS) ? 0 : is_stage + 1;                                                         \
     if (++is_kt == nkt) {                                                                                       \
       is_kt = 0;                                                                                                \
       if (++is_round < my_tiles) PP_SETUP_ISSUE(is_round)                                                       \
     }                                                                                                           \
+  }
+#define PP_ISSUE()                                                          \
+  {                                                                         \
+    _Pragma("unroll") for (int i = 0; i < PG; ++i) PP_ISSUE_PIECE(i)        \
+    PP_ISSUE_ADVANCE()                                                      \
   }
 
   // ---------------- compute cursor
@@ -276,47 +298,94 @@ __device__ __forceinline__ void pp_group(const GemmDesc& d, char* lds, const int
   PP_BARRIER();
   if constexpr (G == 1) PP_BARRIER();  // group 1 runs one barrier behind group 0
 
+  bf16x8 xf[KH][2], wf[KH][NI];
+  if constexpr (ABL & 4) {  // "no fragment reads": operands are whatever the registers hold
+#pragma unroll
+    for (int ks = 0; ks < KH; ++ks) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) asm volatile("" : "=v"(xf[ks][mi]));
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) asm volatile("" : "=v"(wf[ks][ni]));
+    }
+  }
   for (int it = 0;; ++it) {
-    // ======== L segment (the other group is in its M segment)
-    if (pend_round >= 0) PP_EPILOGUE()
+    if (pend_round >= 0) PP_EPILOGUE()  // head of an L segment: runs under the other group's MFMAs
     if (it == nit) break;
     const bool more = it + NS - 1 < nit;
-    if (more) PP_ISSUE()
-    bf16x8 xf[KSTEPS][2], wf[KSTEPS][NI];
-    {
-      const char* sb = lds + c_stage * STAGE;
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-          xf[ks][mi] = *reinterpret_cast<const bf16x8*>(sb + a_base + mi * 32 * ROWB + koff[ks]);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          wf[ks][ni] = *reinterpret_cast<const bf16x8*>(sb + b_base + ni * 32 * ROWB + koff[ks]);
+    for (int h = 0; h < SPLIT; ++h) {
+      // ======== L segment (the other group is in its M segment)
+      if constexpr (!INM && !(ABL & 2)) {
+        if (h == 0 && more) PP_ISSUE()
       }
-    }
-    // fragment reads retired before the barrier: the stage may be overwritten by DMA issued after it
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if constexpr (G == 1) {  // K tile it+1 (this wave's share) landed before group 0 reads it
-      if (more) PP_WAIT_VM(WAITN);
-      else PP_WAIT_VM(0);
-    }
-    PP_BARRIER();
-    // ======== M segment
-    __builtin_amdgcn_s_setprio(1);
+      if constexpr (!(ABL & 4)) {
+        const char* sb = lds + c_stage * STAGE;
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks)
+        for (int ks = 0; ks < KH; ++ks) {
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+          for (int mi = 0; mi < 2; ++mi)
+            xf[ks][mi] = *reinterpret_cast<const bf16x8*>(sb + a_base + mi * 32 * ROWB + koff[h * KH + ks]);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][ni], xf[ks][mi], acc[mi][ni], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    if constexpr (G == 0) {
-      if (more) PP_WAIT_VM(WAITN);
-      else PP_WAIT_VM(0);
+          for (int ni = 0; ni < NI; ++ni)
+            wf[ks][ni] = *reinterpret_cast<const bf16x8*>(sb + b_base + ni * 32 * ROWB + koff[h * KH + ks]);
+        }
+      }
+      // fragment reads retired before the barrier: the stage may be overwritten by DMA issued after it
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr (G == 1) {  // K tile it+1 (this wave's share) landed before group 0 reads it
+        if (h == SPLIT - 1) {
+          if (LATE ? (it + NS - 2 < nit) : more) PP_WAIT_VM(WAITN_L);
+          else PP_WAIT_VM(0);
+        }
+      }
+      PP_BARRIER();
+      // ======== M segment
+      __builtin_amdgcn_s_setprio(1);
+      if constexpr (ABL & 1) {  // "no MFMAs": keep the fragments live so their reads stay
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks) {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) asm volatile("" ::"v"(xf[ks][mi]));
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(wf[ks][ni]));
+        }
+        if constexpr (INM && !(ABL & 2)) {
+          if (h == 0 && more) PP_ISSUE()
+        }
+      } else {
+        constexpr int NM = KH * 2 * NI;                      // MFMAs of the segment
+        constexpr int EVERY = NM / PG > 0 ? NM / PG : 1;     // INM: one DMA piece after every EVERY MFMAs
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][ni], xf[ks][mi], acc[mi][ni], 0, 0, 0);
+              if constexpr (INM && !(ABL & 2)) {
+                const int m_idx = (ks * 2 + mi) * NI + ni;
+                if (h == 0 && m_idx % EVERY == EVERY - 1 && m_idx / EVERY < PG) {
+                  if (more) PP_ISSUE_PIECE(m_idx / EVERY)
+                }
+              }
+            }
+        if constexpr (INM && !(ABL & 2)) {
+          if (h == 0 && more) {
+#pragma unroll
+            for (int i = NM / EVERY; i < PG; ++i) PP_ISSUE_PIECE(i)
+            PP_ISSUE_ADVANCE()
+          }
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if constexpr (G == 0) {
+        if (h == SPLIT - 1) {
+          if (more) PP_WAIT_VM(WAITN);
+          else PP_WAIT_VM(0);
+        }
+      }
+      PP_BARRIER();
     }
-    PP_BARRIER();
     c_stage = (c_stage + 1 == NS) ? 0 : c_stage + 1;
     if (++c_kt == nkt) {
       c_kt = 0;
@@ -326,12 +395,291 @@ __device__ __forceinline__ void pp_group(const GemmDesc& d, char* lds, const int
   if constexpr (G == 0) PP_BARRIER();
 #undef PP_SETUP_ISSUE
 #undef PP_ISSUE
+#undef PP_ISSUE_PIECE
+#undef PP_ISSUE_ADVANCE
 #undef PP_EPILOGUE
 }
 
-template <int BN, int BK, int NS>
+// ------------------------------------------------------------------------------------------------ "SB" schedule
+// Two LDS stages of full 128-byte rows (BK = 64), every K tile consumed as two half-depth L/M pairs, and the refill
+// of a stage cut into its four row blocks, each issued in the first L segment after the block's last reader:
+//
+//   seg (mod 4 of K tile t)      0 = G0 L(t,0)        1 = G1 L(t,0)        2 = G0 L(t,1)        3 = G1 L(t,1)
+//   DMA batch issued there       B rows lo of t+1     B rows hi of t+1     A rows 128.. of t+1  A rows 0..127 of t+2
+//
+// (G0 = group 0 reads A rows 0..127 and all B rows, G1 reads A rows 128..255 and all B rows.)  One batch (16 KB at
+// BN = 256) goes out per segment, i.e. the DMA runs continuously at 64 KB per K tile instead of in one burst per tile,
+// every batch has >= 2 segments of flight before the barrier that precedes its first reader, and a wave only ever
+// waits with vmcnt(size of the batch it has just issued).
+//
+// RS = true ("register staged"): measured on MI355X, one global_load_lds_dwordx4 costs the issuing wave 120-180
+// cycles (s_memtime, tools/gpu_check.py pptime) -- four of them make an L segment twice as long as the 16 MFMAs it
+// is supposed to hide under.  With RS the same row blocks travel global_load_dwordx4 -> VGPR -> ds_write_b128: the
+// loads of a batch are issued one L segment early (their latency passes under two segments), the 16-byte writes
+// go to exactly the lane-linear image the DMA would have produced, in the slot where SB issues the DMA.
+template <class CFG, int G, bool RS>
+__device__ __forceinline__ void pp_group_sb(const GemmDesc& d, char* lds, const int j, const int lane) {
+  constexpr int BN = CFG::BN, BK = CFG::BK, ROWB = CFG::ROWB, STAGE = CFG::STAGE, NI = CFG::NI, ABL = CFG::ABL;
+  static_assert(BK == 64 && CFG::NS == 2 && CFG::SPLIT == 2, "SB schedule: BK 64, 2 stages, split K tile");
+  constexpr int KH = 2;                     // k steps of 16 per segment
+  constexpr int PA = 128 / 8 / 4;           // pieces per wave of an A row block (128 rows, 8 rows per piece, 4 waves)
+  constexpr int PB = (BN / 2) / 8 / 4;      // ... of a B row block (BN/2 rows)
+  static_assert((BN / 2) % 32 == 0, "B row block");
+  // batch X is issued in L(.,0), batch Y in L(.,1)
+  constexpr int PX = PB, PY = PA;
+  constexpr int ROWX = 256 + (G == 0 ? 0 : BN / 2);   // first stage row of batch X (B lo for G0, B hi for G1)
+  constexpr int ROWY = (G == 0 ? 128 : 0);            // first stage row of batch Y (A hi for G0, A lo for G1)
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int wm2 = j >> 1, wn2 = j & 1;
+
+  const int tiles_mn = d.tiles_m * d.tiles_n;
+  const int total = tiles_mn * d.nz;
+  const int gd = gridDim.x, bid = blockIdx.x;
+  const int nkt = (d.K + BK - 1) / BK;
+  const int my_tiles = (total - bid + gd - 1) / gd;
+  const int nit = my_tiles * nkt;
+
+  // ---------------- two issue cursors (batch X and batch Y run on different K tiles for group 1)
+  const bf16_t* sx[PX];
+  const bf16_t* sy[PY];
+  int kx[PX], ky[PY];
+  int x_kt = 0, x_round = 0, x_it = 0, y_kt = 0, y_round = 0, y_it = 0;
+#define SB_SETUP(src_, kc_, np_, row0_, round_)                                                   \
+  {                                                                                               \
+    int z_, bm0_, bn0_;                                                                           \
+    pp_tile<BN>(d, (round_), gd, bid, total, tiles_mn, z_, bm0_, bn0_);                           \
+    const int zb_ = z_ / d.nbh, zh_ = z_ - zb_ * d.nbh;                                           \
+    const bf16_t* A_ = d.A + zb_ * d.sAb + zh_ * d.sAh;                                           \
+    const bf16_t* B_ = d.B + zb_ * d.sBb + zh_ * d.sBh;                                           \
+    _Pragma("unroll") for (int i = 0; i < (np_); ++i) {                                           \
+      const int r_ = (row0_) + (i * 4 + j) * 8 + (lane >> 3);                                     \
+      const int gc_ = (lane & 7) ^ pp_swz<BK>(r_);                                                \
+      kc_[i] = gc_ * 8;                                                                           \
+      if ((row0_) < 256) src_[i] = A_ + (int64_t)min(bm0_ + r_, d.M - 1) * d.lda + gc_ * 8;       \
+      else src_[i] = B_ + (int64_t)min(bn0_ + r_ - 256, d.N - 1) * d.ldb + gc_ * 8;               \
+    }                                                                                             \
+  }
+#define SB_ISSUE(src_, kc_, np_, row0_, c_kt_, c_round_, c_it_)                                                       \
+  {                                                                                                                   \
+    const int k0_ = c_kt_ * BK;                                                                                       \
+    char* s_ = lds + (c_it_ & 1) * STAGE + ((row0_) + j * 8) * ROWB;                                                  \
+    _Pragma("unroll") for (int i = 0; i < (np_); ++i) {                                                               \
+      const void* g_ = (k0_ + kc_[i] < d.K) ? (const void*)(src_[i] + k0_) : (const void*)&g_pp_zero16;               \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_,                             \
+                                       (__attribute__((address_space(3))) void*)(s_ + i * 32 * ROWB), 16, 0, 0);      \
+    }                                                                                                                 \
+    ++c_it_;                                                                                                          \
+    if (++c_kt_ == nkt) {                                                                                             \
+      c_kt_ = 0;                                                                                                      \
+      if (++c_round_ < my_tiles) SB_SETUP(src_, kc_, np_, row0_, c_round_)                                            \
+    }                                                                                                                 \
+  }
+#define SB_ISSUE_X() SB_ISSUE(sx, kx, PX, ROWX, x_kt, x_round, x_it)
+#define SB_ISSUE_Y() SB_ISSUE(sy, ky, PY, ROWY, y_kt, y_round, y_it)
+
+  f32x16 acc[2][NI];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+  int koff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = ((ks * 2 + hi) ^ pp_swz<BK>(l31)) << 4;
+  const int a_base = (G * 128 + wm2 * 64 + l31) * ROWB;
+  const int b_base = (256 + wn2 * (BN / 2) + l31) * ROWB;
+  int c_kt = 0, c_round = 0, pend_round = -1;
+
+#define SB_EPILOGUE()                                                                 \
+  {                                                                                   \
+    int z_, bm0_, bn0_;                                                               \
+    pp_tile<BN>(d, pend_round, gd, bid, total, tiles_mn, z_, bm0_, bn0_);             \
+    pp_epilogue<CFG, G>(d, acc, z_, bm0_, bn0_, wm2, wn2, lane);                      \
+    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                  \
+      _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                               \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;          \
+    pend_round = -1;                                                                  \
+  }
+
+  // ---------------- prologue: K tile 0 complete (each group its own two batches), plus A rows 0..127 of K tile 1
+  SB_SETUP(sx, kx, PX, ROWX, 0)
+  SB_SETUP(sy, ky, PY, ROWY, 0)
+  SB_ISSUE_X()
+  SB_ISSUE_Y()
+  if constexpr (G == 1) {
+    if (1 < nit) {
+      SB_ISSUE_Y()
+      PP_WAIT_VM(PY);
+    } else {
+      PP_WAIT_VM(0);
+    }
+  } else {
+    PP_WAIT_VM(0);
+  }
+  PP_BARRIER();
+  if constexpr (G == 1) PP_BARRIER();
+
+  // RS: the batch in flight lives in rb[] (X and Y are never in flight together); x_st / y_st = its LDS stage
+  constexpr int PMAX = PX > PY ? PX : PY;
+  uint4 rb[PMAX];
+  int x_st = 0, y_st = 0;
+  bool x_pend = false, y_pend = false;
+#define RS_LOAD(src_, kc_, np_, c_kt_, c_round_, c_it_, st_, pend_, row0_)                              \
+  {                                                                                                     \
+    const int k0_ = c_kt_ * BK;                                                                         \
+    _Pragma("unroll") for (int i = 0; i < (np_); ++i)                                                   \
+      rb[i] = (k0_ + kc_[i] < d.K) ? *reinterpret_cast<const uint4*>(src_[i] + k0_) : uint4{0, 0, 0, 0}; \
+    st_ = c_it_ & 1;                                                                                    \
+    pend_ = true;                                                                                       \
+    ++c_it_;                                                                                            \
+    if (++c_kt_ == nkt) {                                                                               \
+      c_kt_ = 0;                                                                                        \
+      if (++c_round_ < my_tiles) SB_SETUP(src_, kc_, np_, row0_, c_round_)                              \
+    }                                                                                                   \
+  }
+#define RS_WRITE(np_, row0_, st_, pend_)                                                                \
+  {                                                                                                     \
+    char* s_ = lds + st_ * STAGE + ((row0_) + j * 8) * ROWB + lane * 16;                                \
+    _Pragma("unroll") for (int i = 0; i < (np_); ++i) *reinterpret_cast<uint4*>(s_ + i * 32 * ROWB) = rb[i]; \
+    pend_ = false;                                                                                      \
+  }
+  if constexpr (RS) {  // first X batch (row block of K tile 1) into registers; written in L(0,0)
+    if (x_it < nit) RS_LOAD(sx, kx, PX, x_kt, x_round, x_it, x_st, x_pend, ROWX)
+  }
+  bf16x8 xf[KH][2], wf[KH][NI];
+  unsigned long long tsum[4] = {0, 0, 0, 0}, tsum4 = 0, tsum5 = 0, tprev = 0, nseg = 0;
+  if constexpr (ABL & 8) tprev = __builtin_amdgcn_s_memtime();
+  for (int it = 0;; ++it) {
+    if (pend_round >= 0) SB_EPILOGUE()
+    if (it == nit) break;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      // ======== L segment: one DMA batch, then this half's fragments
+      if constexpr (ABL & 8) {  // time since the previous stamp = wait at the barrier that closed the last M segment
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        tsum[3] += t - tprev; tprev = t;
+      }
+      bool issued = false;
+      if constexpr (RS) {
+        if constexpr (!(ABL & 2)) {
+          // the batch loaded one L segment ago has arrived (>= 2 segments of flight): write it, load the next one
+          PP_WAIT_VM(0);
+          if (h == 0) {
+            if (x_pend) RS_WRITE(PX, ROWX, x_st, x_pend)
+            if (y_it < nit) RS_LOAD(sy, ky, PY, y_kt, y_round, y_it, y_st, y_pend, ROWY)
+          } else {
+            if (y_pend) RS_WRITE(PY, ROWY, y_st, y_pend)
+            if (x_it < nit) RS_LOAD(sx, kx, PX, x_kt, x_round, x_it, x_st, x_pend, ROWX)
+          }
+        }
+      } else if constexpr (!(ABL & 2)) {
+        if (h == 0) {
+          if (x_it < nit) { SB_ISSUE_X() issued = true; }
+        } else {
+          if (y_it < nit) { SB_ISSUE_Y() issued = true; }
+        }
+      }
+      if constexpr (ABL & 8) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        tsum4 += t - tprev; tprev = t;
+      }
+      {
+        const char* sb = lds + (it & 1) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks) {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+            xf[ks][mi] = *reinterpret_cast<const bf16x8*>(sb + a_base + mi * 32 * ROWB + koff[h * KH + ks]);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            wf[ks][ni] = *reinterpret_cast<const bf16x8*>(sb + b_base + ni * 32 * ROWB + koff[h * KH + ks]);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr (ABL & 8) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        tsum5 += t - tprev; tprev = t;
+      }
+      // everything this wave issued before the batch of this segment has landed
+      if constexpr (!RS) {
+        if (issued) {
+          if (h == 0) PP_WAIT_VM(PX);
+          else PP_WAIT_VM(PY);
+        } else {
+          PP_WAIT_VM(0);
+        }
+      }
+      if constexpr (ABL & 8) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        tsum[0] += t - tprev; tprev = t;
+      }
+      PP_BARRIER();
+      // ======== M segment
+      if constexpr (ABL & 8) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        tsum[1] += t - tprev; tprev = t;
+      }
+      if constexpr (!(ABL & 16)) __builtin_amdgcn_s_setprio(1);
+      if constexpr (ABL & 1) {
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks) {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) asm volatile("" ::"v"(xf[ks][mi]));
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(wf[ks][ni]));
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][ni], xf[ks][mi], acc[mi][ni], 0, 0, 0);
+      }
+      if constexpr (!(ABL & 16)) __builtin_amdgcn_s_setprio(0);
+      if constexpr (ABL & 8) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        tsum[2] += t - tprev; tprev = t;
+        ++nseg;
+      }
+      PP_BARRIER();
+    }
+    if (++c_kt == nkt) {
+      c_kt = 0;
+      pend_round = c_round++;
+    }
+  }
+  if constexpr (G == 0) PP_BARRIER();
+  if constexpr (ABL & 8) {
+    if (lane == 0 && g_pp_dbg) {
+      unsigned long long* o = g_pp_dbg + ((size_t)blockIdx.x * 8 + G * 4 + j) * 8;
+      o[0] = tsum[0]; o[1] = tsum[1]; o[2] = tsum[2]; o[3] = tsum[3]; o[4] = nseg; o[5] = tsum4; o[6] = tsum5;
+    }
+  }
+#undef RS_LOAD
+#undef RS_WRITE
+#undef SB_SETUP
+#undef SB_ISSUE
+#undef SB_ISSUE_X
+#undef SB_ISSUE_Y
+#undef SB_EPILOGUE
+}
+
+template <int BN, int ABL, bool RS>
+__global__ __launch_bounds__(512) void gemm_pp_sb_kernel(GemmDesc d) {
+  using CFG = PPCfg<BN, 64, 2, false, ABL, 2>;
+  __shared__ __attribute__((aligned(16))) char lds[CFG::LDS_BYTES];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave < 4) pp_group_sb<CFG, 0, RS>(d, lds, wave, lane);
+  else pp_group_sb<CFG, 1, RS>(d, lds, wave - 4, lane);
+}
+
+template <int BN, int BK, int NS, bool INM, int ABL, int SPLIT>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmDesc d) {
-  using CFG = PPCfg<BN, BK, NS>;
+  using CFG = PPCfg<BN, BK, NS, INM, ABL, SPLIT>;
   __shared__ __attribute__((aligned(16))) char lds[CFG::LDS_BYTES];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -343,52 +691,72 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmDesc d) {
 static int g_pp_mode = 0;      // 0: heuristic, -1: never, v > 0: force variant v where the shape allows it
 static int g_pp_max_grid = 256;
 
+int gemm_pp_set_debug_buffer(void* p) {
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_pp_dbg), &q, sizeof(q)) == hipSuccess ? U2_OK : U2_ERR_LAUNCH;
+}
+
 void gemm_pp_set_options(int mode, int max_grid) {
   if (mode >= -1) g_pp_mode = mode;
   if (max_grid > 0) g_pp_max_grid = max_grid;
 }
 
-template <int BN, int BK, int NS>
+template <int BN, int BK, int NS, bool INM = false, int ABL = 0, int SPLIT = 1>
 static int pp_launch(GemmDesc d, hipStream_t stream) {
   d.tiles_m = (int)cdiv(d.M, 256);
   d.tiles_n = (int)cdiv(d.N, BN);
   const int64_t total = (int64_t)d.tiles_m * d.tiles_n * d.nz;
   if (total > 0x3fffffff) return U2_ERR_ARG;
   const int grid = (int)std::min<int64_t>(total, g_pp_max_grid);
-  hipLaunchKernelGGL((gemm_pp_kernel<BN, BK, NS>), dim3(grid), dim3(512), 0, stream, d);
+  hipLaunchKernelGGL((gemm_pp_kernel<BN, BK, NS, INM, ABL, SPLIT>), dim3(grid), dim3(512), 0, stream, d);
   return launch_status();
 }
 
+template <int BN, int ABL = 0, bool RS = false>
+static int pp_launch_sb(GemmDesc d, hipStream_t stream) {
+  d.tiles_m = (int)cdiv(d.M, 256);
+  d.tiles_n = (int)cdiv(d.N, BN);
+  const int64_t total = (int64_t)d.tiles_m * d.tiles_n * d.nz;
+  if (total > 0x3fffffff) return U2_ERR_ARG;
+  const int grid = (int)std::min<int64_t>(total, g_pp_max_grid);
+  hipLaunchKernelGGL((gemm_pp_sb_kernel<BN, ABL, RS>), dim3(grid), dim3(512), 0, stream, d);
+  return launch_status();
+}
+
+// Variant ids (u2tok_set_option("gemm_pp", id) forces one; every id computes the same C unless marked otherwise).
+// The many other (BN, BK, NS, schedule) points that were measured on MI355X are recorded in DESIGN.md section 3.
 static int pp_launch_variant(int v, const GemmDesc& d, hipStream_t stream) {
   switch (v) {
-    case 1: return pp_launch<128, 64, 3>(d, stream);
-    case 2: return pp_launch<128, 32, 4>(d, stream);
-    case 3: return pp_launch<128, 32, 6>(d, stream);
-    case 4: return pp_launch<192, 32, 4>(d, stream);
-    case 5: return pp_launch<192, 32, 5>(d, stream);
-    case 6: return pp_launch<192, 64, 2>(d, stream);
-    case 7: return pp_launch<256, 32, 4>(d, stream);
-    case 8: return pp_launch<256, 32, 5>(d, stream);
+    case 1: return pp_launch<256, 64, 2, true, 0, 2>(d, stream);   // 256x256, DMA issued between the MFMAs
+    case 2: return pp_launch<192, 64, 2, false, 0, 2>(d, stream);  // 256x192, DMA issued at the head of L
+    case 3: return pp_launch<128, 64, 3, true, 0, 2>(d, stream);   // 256x128, 3 stages
+    case 4: return pp_launch<256, 32, 4>(d, stream);               // 256x256, 64-byte rows, 4 stages
+    case 5: return pp_launch_sb<256>(d, stream);                   // row-block ("SB") DMA schedule
+    case 6: return pp_launch_sb<256, 0, true>(d, stream);          // SB, register staged
+    case 7: return pp_launch_sb<192, 0, true>(d, stream);
+    // measurement-only builds (results of 10..13 are wrong by construction; 14..17 are correct but slower)
+    case 10: return pp_launch<256, 64, 2, true, 1, 2>(d, stream);  // variant 1 without MFMAs
+    case 11: return pp_launch<256, 64, 2, true, 2, 2>(d, stream);  // ... without DMA after the prologue
+    case 12: return pp_launch<256, 64, 2, true, 6, 2>(d, stream);  // ... MFMAs + barriers only
+    case 13: return pp_launch<256, 64, 2, true, 5, 2>(d, stream);  // ... DMA + barriers only
+    case 14: return pp_launch_sb<256, 8>(d, stream);               // variant 5, s_memtime instrumented
+    case 15: return pp_launch_sb<256, 8, true>(d, stream);         // variant 6, s_memtime instrumented
+    case 16: return pp_launch_sb<256, 9, true>(d, stream);         // variant 6 instrumented, no MFMAs (wrong C)
+    case 17: return pp_launch_sb<256, 10>(d, stream);              // variant 5 instrumented, no DMA (wrong C)
     default: return U2_ERR_ARG;
   }
 }
-static int pp_variant_bn(int v) { return v <= 3 ? 128 : (v <= 6 ? 192 : 256); }
 
-// Tile-shape choice: BN in {128, 192, 256} by useful-area efficiency of the last (partial) round of 256 workgroups;
-// wider BN wins ties (fewer LDS bytes per flop).  Variant ids as in pp_launch_variant.
+// Where the ping-pong kernel wins on MI355X (tools/gpu_check.py ppperf, random operands): products that keep all 256
+// workgroups busy for several rounds with a long K loop -- 8192^3: 1.07-1.15 PF/s against 0.89 for gemm.hip's
+// 128x128 tiles.  On the hot path's own shapes (M = 16392 / 2048 / 256 rows at batch 1, K = 768 or 4096) the 128x128
+// kernel with two workgroups per CU is as fast or faster (DESIGN.md section 3 has the table), so the heuristic
+// only takes products of at least 4 full rounds of 256x256 tiles with K >= 2048.
 static int pp_pick(const GemmDesc& d) {
-  static const int cand_bn[3] = {256, 192, 128};
-  static const int cand_v[3] = {8, 5, 3};
-  const int64_t tm = cdiv(d.M, 256);
-  double best = 0.0;
-  int v = 0;
-  for (int i = 0; i < 3; ++i) {
-    const int64_t tiles = tm * cdiv(d.N, cand_bn[i]) * d.nz;
-    const int64_t rounds = cdiv(tiles, g_pp_max_grid);
-    const double eff = (double)d.M * d.N * d.nz / ((double)rounds * g_pp_max_grid * 256.0 * cand_bn[i]);
-    if (eff > best * 1.03) { best = eff; v = cand_v[i]; }
-  }
-  return best >= 0.45 ? v : 0;  // a badly filled machine: gemm.hip's small tiles do better
+  const int64_t tiles = cdiv(d.M, 256) * cdiv(d.N, 256) * d.nz;
+  if (d.K < 2048 || tiles < 4 * (int64_t)g_pp_max_grid) return 0;
+  const double eff = (double)d.M * d.N * d.nz / ((double)cdiv(tiles, g_pp_max_grid) * g_pp_max_grid * 65536.0);
+  return eff >= 0.8 ? 1 : 0;
 }
 
 // Returns 1 when the product was launched here, 0 when the caller should use gemm.hip's kernel, < 0 on error.

@@ -48,7 +48,8 @@ void gemm_set_options(int glds, int force_tile, int bk);
 // internal: the two kernels behind gemm_bf16 (descriptor already validated there)
 int gemm_classic(GemmDesc d, hipStream_t stream);       // gemm.hip: 128^2 / 64^2 tiles, 2 workgroups per CU
 int gemm_pp_try(const GemmDesc& d, hipStream_t stream);  // gemm_pp.hip: 1 launched, 0 not applicable, < 0 error
-void gemm_pp_set_options(int mode, int max_grid);        // mode: -1 never, 0 heuristic, v > 0 force variant v
+void gemm_pp_set_options(int mode, int max_grid);
+int gemm_pp_set_debug_buffer(void* p);                   // diagnostics: >= 256*8*5 uint64 (see gemm_pp.hip), or null        // mode: -1 never, 0 heuristic, v > 0 force variant v
 
 // ------------------------------------------------------------------ row ops (rowops.hip)
 // y[b][r][:] = LayerNorm(x[b][r][:] (+ res[b][r][:])) * w + bias   (bf16 in/out, fp32 math)
