@@ -42,6 +42,9 @@ int u2tok_set_option(const char* name, int value); /* "gemm_glds" {0,1}, "gemm_t
 /* Diagnostics only: device buffer (>= 256*8*5 uint64) that the s_memtime-instrumented builds of the ping-pong GEMM
  * (u2tok_set_option("gemm_pp", 14..17)) fill with per-wave segment timings; NULL detaches it. */
 int u2tok_debug_buffer(void* device_ptr);
+/* Same for the flash attention kernel: >= grid*4*8 uint64, zeroed by the caller; while attached the kernel runs its
+ * s_memtime-instrumented build and ADDS per-phase cycle sums per (workgroup, wave). */
+int u2tok_flash_debug_buffer(void* device_ptr);
 
 /* With option "profile" = 1 every launch is bracketed by hipEvents on its stream.  Collect (HOST arrays of ncat <= 5
  * entries; synchronises on the recorded events, then resets): summed milliseconds, algorithmic FLOPs and launch

@@ -353,7 +353,7 @@ def sec_flashperf():
     for (nb, S, H, extra) in [(8, 2049, 12, True), (8, 2049, 12, False), (8, 2048, 12, False), (16, 513, 12, True)]:
         qkv = rnd(nb, S, 3 * H * 64, seed=3).to(dev)
         fl = 4 * nb * H * S * S * 64
-        for mode in (1, 2, 3):
+        for mode in (1, 2, 3, 4):
             ops.set_option("flash_mode", mode)
             ms = timeit(lambda: ops.flash_attention_d64(qkv, H, 0.125, extra_last=extra), iters=10)
             # the transpose alone
@@ -397,6 +397,33 @@ def sec_pptime():
             print(f"  {M}x{N}x{K} v{v} {name:18s} {ms * 1e3:8.1f} us | G0 {fmt(g0)} | G1 {fmt(g1)}", flush=True)
     ops.set_option("gemm_pp", 0)
     h.u2tok_debug_buffer(None)
+
+
+def sec_flashtime():
+    """s_memtime phase breakdown of the flash attention kernel (cycles per KV tile per wave)"""
+    from u2tokenizer_amd import _lib
+    h = _lib.load_library()
+    nb, S, H = 8, 2049, 12
+    qkv = rnd(nb, S, 3 * H * 64, seed=3).to(dev)
+    names = ["gload", "QK^T", "softmax", "PV", "wait+lstore", "-", "barrier"]
+    for mode in (3, 4, 14, 24):
+        ops.set_option("flash_mode", mode)
+        ms0 = timeit(lambda: ops.flash_attention_d64(qkv, H, 0.125, extra_last=True), iters=5)
+        buf = torch.zeros(4096 * 4 * 8, dtype=torch.int64, device=dev)
+        _lib.check(h.u2tok_flash_debug_buffer(buf.data_ptr()), "flash_debug_buffer")
+        ops.flash_attention_d64(qkv, H, 0.125, extra_last=True)
+        torch.cuda.synchronize()
+        h.u2tok_flash_debug_buffer(None)
+        r = buf.view(-1, 8).double()
+        r = r[r[:, 7] > 0]
+        per = r[:, :7].sum(0) / r[:, 7].sum()
+        if mode % 10 == 4:
+            print(f"  mode {mode}: {ms0 * 1e3:7.1f} us untimed | per KV tile per wave: V {per[0]:6.0f}  wait {per[1]:6.0f}  M {per[2]:6.0f}  "
+                  f"wait {per[3]:6.0f}  total {per[:4].sum():6.0f}", flush=True)
+            continue
+        print(f"  mode {mode}: {ms0 * 1e3:7.1f} us untimed | per KV tile per wave: " +
+              "  ".join(f"{n} {v:6.0f}" for n, v in zip(names, per.tolist()) if n != "-") + f"  total {per.sum():6.0f}", flush=True)
+    ops.set_option("flash_mode", 0)
 
 # ------------------------------------------------------------------------------------------- perf
 def sec_perf():

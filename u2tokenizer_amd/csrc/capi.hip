@@ -49,7 +49,7 @@ int u2tok_set_option(const char* name, int value) {
     return U2_OK;
   }
   if (!strcmp(name, "flash_mode")) {
-    if (value < 0 || value > 3) return U2_ERR_ARG;
+    if (value < 0 || value > 44 || value % 10 > 4) return U2_ERR_ARG;
     flash_set_mode(value);
     return U2_OK;
   }
@@ -59,6 +59,7 @@ int u2tok_set_option(const char* name, int value) {
 }
 
 int u2tok_debug_buffer(void* device_ptr) { return gemm_pp_set_debug_buffer(device_ptr); }
+int u2tok_flash_debug_buffer(void* device_ptr) { return flash_set_debug_buffer(device_ptr); }
 
 int u2tok_profile_collect(double* ms, double* flops, int64_t* count, int32_t ncat) {
   if (!ms || !flops || !count || ncat <= 0 || ncat > PROF_NCAT) return U2_ERR_ARG;

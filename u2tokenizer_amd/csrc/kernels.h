@@ -118,6 +118,7 @@ int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16
                         int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs, int S_pad, float scale,
                         const bf16_t* qx, const bf16_t* kx, const bf16_t* vx, bf16_t* outx, int64_t x_bs, int64_t ox_bs,
                         int n_extra, hipStream_t stream);
+int flash_set_debug_buffer(void* p);  // diagnostics: s_memtime phase sums per (workgroup, wave); see attn.hip
 void flash_set_mode(int mode);  // 0 pick, 1: 128-row units, 2: 256-row units, 3: one of each per workgroup
 
 }  // namespace u2
