@@ -230,14 +230,27 @@ def main():
         ms, flops, cnt = (C.c_double * 5)(), (C.c_double * 5)(), (C.c_int64 * 5)()
         _lib.check(h.u2tok_profile_collect(ms, flops, cnt, 5), "u2tok_profile_collect")
         ops.set_option("profile", 0)
-        names = ["gemm_bf16_nt_kernel", "flash_d64_kernel", "temporal_attention_kernel", "row_ops", "data_movement"]
+        names = ["gemm_bf16 (gemm_bf16_nt_kernel + gemm_pp_kernel)", "flash_d64_kernel", "temporal_attention_kernel", "row_ops",
+                 "data_movement"]
         classes = {n: {"ms_per_step": round(ms[i] / nprof, 4), "launches_per_step": cnt[i] // nprof,
                        "tflops": round(flops[i] / ms[i] / 1e9, 1) if ms[i] > 0 and flops[i] > 0 else None}
                    for i, n in enumerate(names)}
         achieved = flops[0] / ms[0] / 1e9
-        line["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel (all launches of one step)",
+        # HBM-side bytes of the same kernel class come from rocprofv3 PMC passes of THIS command (a process cannot
+        # read its own counters): tools/gpu_round.sh -> tools/pmc_traffic.py -> profiles/r01_traffic.json
+        traffic, traffic_src = None, None
+        tfile = ROOT / "profiles" / "r01_traffic.json"
+        if tfile.exists() and E == 4096 and B == 1:
+            tj = json.loads(tfile.read_text())["kernels"].get("gemm_bf16_nt_kernel")
+            if tj:
+                traffic = round(tj["hbm_bytes_per_launch"])
+                traffic_src = ("profiles/r01_traffic.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / launches, rocprofv3 "
+                               "--pmc, separate passes; fabric-side requests (Infinity Cache hits included)")
+        line["roofline"] = {"bound": "mfma", "kernel": "bf16 MFMA GEMM, all launches of one step (gemm_bf16_nt_kernel)",
                             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                            "traffic_unit": "bytes per launch (average)", "traffic_source": traffic_src,
+                            "algorithmic_bytes_per_launch": round((3.0e9 + 2.3e9) / max(cnt[0] // nprof, 1)),
                             "avg_launch_us": round(1e3 * ms[0] / cnt[0], 2),
                             "flop_per_step": flops[0] / nprof, "classes": classes}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -162,6 +162,18 @@ def gen_full():
         save(f"full_{name}", inputs_embeds=embeds, logits_last=logits[:, -1], greedy_ids=gen)
 
 
+def gen_keys():
+    """state_dict key / shape contract of the reference's u2Tokenizer variants (merged into state_dict_keys.json)."""
+    import json
+    from src.model.u2tokenizer.u2Tokenizer import u2Tokenizer
+    p = OUT / "state_dict_keys.json"
+    ref = json.loads(p.read_text())
+    m = u2Tokenizer(embed_size=512, num_heads=8, num_layers=1, top_k=16, use_multi_scale=True, num_3d_query_token=16,
+                    hidden_size=512, attn_type="linvt", enable_diffts=True, enable_dmtp=True)
+    ref["linvt_small"] = {"u2tokenizer." + k: list(v.shape) for k, v in m.state_dict().items()}
+    p.write_text(json.dumps(ref, indent=0, sort_keys=True))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["tokenizer", "spp", "vit", "full"]
     for w in which:

@@ -35,6 +35,10 @@ def test_state_dict_keys_match_reference_contract():
     c2 = _cfg(attn_type="rope", enable_diffts=False, enable_dmtp=False)
     got = {"u2tokenizer." + k: list(v.shape) for k, v in U.build_u2tokenizer_tower(c2).state_dict().items()}
     assert got == ref["rope_hard_small"]
+    # attn_type outside {rma, rope}: stock nn.MultiheadAttention parameters (in_proj_weight / out_proj), svr.py:16-18
+    c3 = _cfg(attn_type="linvt")
+    got = {"u2tokenizer." + k: list(v.shape) for k, v in U.build_u2tokenizer_tower(c3).state_dict().items()}
+    assert got == ref["linvt_small"]
 
 
 def test_builders_raise_like_the_reference():

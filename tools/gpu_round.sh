@@ -1,11 +1,21 @@
 #!/bin/bash
-# One GPU-box visit: run each diagnostic section in its own process (a fault in one must not hide the others).
-# Usage (through gpurun): bash tools/gpu_round.sh gemm ops attn modules perf
-mkdir -p gpurun_out
-: > gpurun_out/summary.log
-for s in "$@"; do
-  timeout 900 python tools/gpu_check.py "$s" > "gpurun_out/check_$s.log" 2>&1
-  echo "section $s exit $?" >> gpurun_out/summary.log
+# Round-end style visit: GPU pytest suite, smoke, bench line, rocprofv3 kernel stats + HBM counters of the same bench.
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out
+mkdir -p $O; cd $R
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -30 > $O/pytest_gpu.log
+echo "pytest exit ${PIPESTATUS[0]}" >> $O/pytest_gpu.log
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke exit $?" >> $O/smoke.log
+timeout 900 python bench.py --steps 20 --warmup 3 > $O/bench.log 2>&1; echo "bench exit $?" >> $O/bench.log
+cd /tmp && export TMPDIR=/tmp
+rm -rf $O/prof $O/pmc_bench
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline > $O/rocprof.log 2>&1
+echo "rocprof exit $?" >> $O/rocprof.log
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_bench/$c -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_$c.log 2>&1
+  echo "pmc $c exit $?" >> $O/rocprof.log
 done
-cat gpurun_out/summary.log
-for s in "$@"; do echo "=== $s"; tail -n 60 "gpurun_out/check_$s.log"; done
+cd $R
+python tools/pmc_traffic.py $O/pmc_bench 4 > $O/traffic.json 2> $O/traffic.err
+find $O/prof $O/pmc_bench -name "*kernel_trace*" -size +8M -delete 2>/dev/null
+find $O/pmc_bench -name "*counter_collection*" -size +8M -delete 2>/dev/null
+tail -4 $O/pytest_gpu.log; tail -2 $O/smoke.log; tail -2 $O/bench.log; tail -4 $O/rocprof.log; head -c 1500 $O/traffic.json
