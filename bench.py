@@ -227,13 +227,15 @@ def main():
         for i in range(nprof):
             step(i)
         torch.cuda.synchronize()
-        ms, flops, cnt = (C.c_double * 5)(), (C.c_double * 5)(), (C.c_int64 * 5)()
-        _lib.check(h.u2tok_profile_collect(ms, flops, cnt, 5), "u2tok_profile_collect")
+        ms, flops, byts, cnt = (C.c_double * 5)(), (C.c_double * 5)(), (C.c_double * 5)(), (C.c_int64 * 5)()
+        _lib.check(h.u2tok_profile_collect2(ms, flops, byts, cnt, 5), "u2tok_profile_collect2")
         ops.set_option("profile", 0)
         names = ["gemm_bf16 (gemm_bf16_nt_kernel + gemm_pp_kernel)", "flash_d64_kernel", "temporal_attention_kernel", "row_ops",
                  "data_movement"]
+        # per class: time, launches, algorithmic TFLOP/s and algorithmic GB/s (operands + results once) of its launches
         classes = {n: {"ms_per_step": round(ms[i] / nprof, 4), "launches_per_step": cnt[i] // nprof,
-                       "tflops": round(flops[i] / ms[i] / 1e9, 1) if ms[i] > 0 and flops[i] > 0 else None}
+                       "tflops": round(flops[i] / ms[i] / 1e9, 1) if ms[i] > 0 and flops[i] > 0 else None,
+                       "algorithmic_gbytes_per_s": round(byts[i] / ms[i] / 1e6, 1) if ms[i] > 0 and byts[i] > 0 else None}
                    for i, n in enumerate(names)}
         achieved = flops[0] / ms[0] / 1e9
         # HBM-side bytes of the same kernel class come from rocprofv3 PMC passes of THIS command (a process cannot
@@ -250,7 +252,7 @@ def main():
                             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                             "traffic_unit": "bytes per launch (average)", "traffic_source": traffic_src,
-                            "algorithmic_bytes_per_launch": round((3.0e9 + 2.3e9) / max(cnt[0] // nprof, 1)),
+                            "algorithmic_bytes_per_launch": round(byts[0] / max(cnt[0], 1)),
                             "avg_launch_us": round(1e3 * ms[0] / cnt[0], 2),
                             "flop_per_step": flops[0] / nprof, "classes": classes}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -51,6 +51,8 @@ int u2tok_flash_debug_buffer(void* device_ptr);
  * counts per kernel class 0 = MFMA GEMM, 1 = ViT flash attention, 2 = temporal attention, 3 = row ops
  * (LayerNorm / softmax / RoPE / scores / top-k / pooling), 4 = data movement (im2col, transposes, gathers, splice). */
 int u2tok_profile_collect(double* ms_host, double* flops_host, int64_t* count_host, int32_t ncat);
+/* Same, plus the summed ALGORITHMIC bytes (every operand read once + every result written once) per class. */
+int u2tok_profile_collect2(double* ms_host, double* flops_host, double* bytes_host, int64_t* count_host, int32_t ncat);
 
 /* ---- configuration records -------------------------------------------------------------------- */
 

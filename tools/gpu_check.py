@@ -318,7 +318,7 @@ def sec_ppc(v=None):
     ops.set_option("gemm_pp", 0)
 
 
-PP_PERF_VARIANTS = (-1, 0, 1, 2, 3, 4, 5, 6, 7, 10, 11, 12, 13)
+PP_PERF_VARIANTS = (-1, 1, 2, 5, 6, 7)
 
 
 def sec_ppperf(shapes_sel=None):
@@ -424,6 +424,33 @@ def sec_flashtime():
         print(f"  mode {mode}: {ms0 * 1e3:7.1f} us untimed | per KV tile per wave: " +
               "  ".join(f"{n} {v:6.0f}" for n, v in zip(names, per.tolist()) if n != "-") + f"  total {per.sum():6.0f}", flush=True)
     ops.set_option("flash_mode", 0)
+
+
+def sec_cperf():
+    """classic GEMM kernel: DMA burst (glds 1) vs DMA pieces between the MFMAs (glds 2), BK 64 vs 32"""
+    ops.set_option("gemm_pp", -1)
+    shapes = [(16384, 2304, 768, {}), (16384, 768, 768, dict(bias=True, residual=True)),
+              (16384, 3072, 768, dict(bias=True, gelu=True)), (16384, 768, 3072, dict(bias=True, residual=True)),
+              (2048, 4096, 4096, dict(bias=True)), (2048, 12288, 4096, dict(bias=True)), (1792, 8192, 4096, dict(bias=True)),
+              (1024, 8192, 4096, dict(bias=True)), (256, 4096, 4096, dict(bias=True)), (256, 12288, 4096, dict(bias=True)),
+              (1024, 2048, 4096, {}), (8192, 8192, 8192, {})]
+    print("[classic perf] us (TF/s) per configuration glds/bk", flush=True)
+    for (M, N, K, kw) in shapes:
+        a, b = rnd(M, K, seed=1).to(dev), rnd(N, K, seed=2).to(dev)
+        bias = rnd(N, seed=3).to(dev) if kw.get("bias") else None
+        res = rnd(M, N, seed=4).to(dev) if kw.get("residual") else None
+        out = torch.empty((1, M, N), dtype=bf, device=dev)
+        line = f"  {M:5d}x{N:5d}x{K:4d} {'+'.join(sorted(kw)) or '-':14s}"
+        for glds in (1, 2):
+            for bk in (64, 32):
+                ops.set_option("gemm_glds", glds)
+                ops.set_option("gemm_bk", bk)
+                ms = timeit(lambda: ops.gemm(a, b, bias=bias, residual=res, gelu=bool(kw.get("gelu")), out=out), iters=8, warm=2)
+                line += f" | g{glds} bk{bk} {ms * 1e3:7.1f} ({2 * M * N * K / ms / 1e9:4.0f})"
+        print(line, flush=True)
+    ops.set_option("gemm_glds", 1)
+    ops.set_option("gemm_bk", 64)
+    ops.set_option("gemm_pp", 0)
 
 # ------------------------------------------------------------------------------------------- perf
 def sec_perf():

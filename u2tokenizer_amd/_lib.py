@@ -61,6 +61,7 @@ SIGNATURES = {
     "u2tok_device_check": (_i32, []),
     "u2tok_set_option": (_i32, [C.c_char_p, _i32]),
     "u2tok_profile_collect": (_i32, [_vp, _vp, _vp, _i32]),
+    "u2tok_profile_collect2": (_i32, [_vp, _vp, _vp, _vp, _i32]),
     "u2tok_debug_buffer": (_i32, [_vp]),
     "u2tok_flash_debug_buffer": (_i32, [_vp]),
     "u2tok_vit_workspace_bytes": (_sz, [C.POINTER(VitConfig)]),

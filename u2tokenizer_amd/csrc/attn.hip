@@ -898,7 +898,8 @@ int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16
   a.n_main = (int)blocks;
   const int64_t grid = blocks + (n_extra ? nbh : 0);
   if (grid > 0x7fffffff) return U2_ERR_ARG;
-  ProfScope ps(PROF_FLASH, 4.0 * nbh * (double)(S + n_extra) * (S + n_extra) * 64, stream);
+  ProfScope ps(PROF_FLASH, 4.0 * nbh * (double)(S + n_extra) * (S + n_extra) * 64, stream,
+               4.0 * nbh * (double)(S + n_extra) * 64 * 2.0);  // q, k, v^T read + o written, once
 #define U2_FLASH_LAUNCH(M_, W_)                                                                                    \
   do {                                                                                                             \
     if (g_flash_timed) hipLaunchKernelGGL((flash_d64_kernel<M_, W_, true>), dim3((unsigned)grid), dim3(256), 0, stream, a); \

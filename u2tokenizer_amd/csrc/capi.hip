@@ -27,7 +27,11 @@ int u2tok_device_check(void) {
 
 int u2tok_set_option(const char* name, int value) {
   if (!name) return U2_ERR_ARG;
-  if (!strcmp(name, "gemm_glds")) { gemm_set_options(value ? 1 : 0, -1, -1); return U2_OK; }
+  if (!strcmp(name, "gemm_glds")) {
+    if (value < 0 || value > 2) return U2_ERR_ARG;
+    gemm_set_options(value, -1, -1);
+    return U2_OK;
+  }
   if (!strcmp(name, "gemm_tile")) {
     if (value != 0 && value != 64 && value != 128) return U2_ERR_ARG;
     gemm_set_options(-1, value, -1);
@@ -63,7 +67,11 @@ int u2tok_flash_debug_buffer(void* device_ptr) { return flash_set_debug_buffer(d
 
 int u2tok_profile_collect(double* ms, double* flops, int64_t* count, int32_t ncat) {
   if (!ms || !flops || !count || ncat <= 0 || ncat > PROF_NCAT) return U2_ERR_ARG;
-  return prof_collect(ms, flops, count, ncat);
+  return prof_collect(ms, flops, nullptr, count, ncat);
+}
+int u2tok_profile_collect2(double* ms, double* flops, double* bytes, int64_t* count, int32_t ncat) {
+  if (!ms || !flops || !bytes || !count || ncat <= 0 || ncat > PROF_NCAT) return U2_ERR_ARG;
+  return prof_collect(ms, flops, bytes, count, ncat);
 }
 
 size_t u2tok_vit_workspace_bytes(const u2tok_vit_config* cfg) {

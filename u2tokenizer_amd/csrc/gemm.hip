@@ -33,7 +33,10 @@ __device__ __forceinline__ int lds_swz(int row) {
   else return (4 - ((row >> 2) & 3)) & 3;
 }
 
-template <int BM, int BN, int BK, bool GLDS>
+// GLDS: 0 = register staging, 1 = LDS-DMA issued as one burst ahead of the MFMAs, 2 = LDS-DMA pieces spread between
+// the MFMAs of the K tile (a global_load_lds blocks its wave for 100-180 cycles: spread out, the co-resident wave of
+// the other workgroup finds the matrix pipe free far more often than behind an 8-piece burst).
+template <int BM, int BN, int BK, int GLDS>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
   static_assert(BK == 32 || BK == 64, "BK");
   constexpr int WM = BM / 2, WN = BN / 2;
@@ -158,7 +161,65 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
     }
   };
 
-  if constexpr (GLDS) {
+  // one DMA piece of K tile kt into stage buf (i < CA: activation rows, else weight rows)
+  auto dma_piece = [&](int kt, int buf, int i) {
+    const int k0 = kt * BK;
+    char* s = lds + buf * STAGE;
+    if (i < CA) {
+      const void* src = (k0 + ka[i] < d.K) ? (const void*)(pa[i] + k0) : (const void*)&g_zero16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(s + (i * 256 + wave * 64) * 16),
+                                       16, 0, 0);
+    } else {
+      const int jj = i - CA;
+      const void* src = (k0 + kb[jj] < d.K) ? (const void*)(pb[jj] + k0) : (const void*)&g_zero16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(s + BM * ROWB + (jj * 256 + wave * 64) * 16),
+                                       16, 0, 0);
+    }
+  };
+  // MFMAs of stage `buf` with the DMA pieces of K tile kt_next spread between them
+  auto compute_dma = [&](int buf, int kt_next, bool more) {
+    const char* sA = lds + buf * STAGE + (wm * WM) * ROWB + frow;
+    const char* sB = lds + buf * STAGE + BM * ROWB + (wn * WN) * ROWB + frow;
+    constexpr int NM = KSTEPS * MI * NI, NPC = CA + CB;
+    constexpr int EVERY = NM / NPC > 0 ? NM / NPC : 1;
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+      bf16x8 xf[MI], wf[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) xf[mi] = *reinterpret_cast<const bf16x8*>(sA + mi * 16 * ROWB + foff[kk]);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const bf16x8*>(sB + ni * 16 * ROWB + foff[kk]);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[mi][ni], 0, 0, 0);
+          const int m_idx = (kk * MI + mi) * NI + ni;
+          if (m_idx % EVERY == EVERY - 1 && m_idx / EVERY < NPC) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) dma_piece(kt_next, buf ^ 1, m_idx / EVERY);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+    }
+    if (more) {
+#pragma unroll
+      for (int i = NM / EVERY; i < NPC; ++i) dma_piece(kt_next, buf ^ 1, i);
+    }
+  };
+
+  if constexpr (GLDS == 2) {
+    dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      compute_dma(kt & 1, kt + 1, kt + 1 < nkt);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else if constexpr (GLDS == 1) {
     dma(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -259,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
   }
 }
 
-static int g_gemm_glds = 1;      // 1: LDS-DMA staging, 0: register staging
+static int g_gemm_glds = 1;      // 0: register staging, 1: LDS-DMA burst, 2: LDS-DMA pieces between the MFMAs
 static int g_gemm_force_tile = 0;  // 0: heuristic, 64 / 128: force
 static int g_gemm_bk = 64;       // K depth of one LDS stage: 64 (2 blocks/CU at 128^2) or 32 (4 blocks/CU)
 
@@ -275,10 +336,12 @@ static int launch_tile(GemmDesc d, hipStream_t stream) {
   d.tiles_n = (int)cdiv(d.N, BN);
   dim3 grid(d.tiles_m * d.tiles_n, d.nz, 1);
   constexpr int smem = 2 * (BM + BN) * BK * 2;
-  if (g_gemm_glds)
-    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, BK, true>), grid, dim3(256), smem, stream, d);
+  if (g_gemm_glds == 2)
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, BK, 2>), grid, dim3(256), smem, stream, d);
+  else if (g_gemm_glds)
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, BK, 1>), grid, dim3(256), smem, stream, d);
   else
-    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, BK, false>), grid, dim3(256), smem, stream, d);
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, BK, 0>), grid, dim3(256), smem, stream, d);
   return launch_status();
 }
 
@@ -300,7 +363,10 @@ int gemm_bf16(GemmDesc d, hipStream_t stream) {
     vec = vec && (d.ldr % 4 == 0) && (d.sRb % 4 == 0) && (d.sRh % 4 == 0) && (((uintptr_t)d.R & 7) == 0);
   d.flags = vec ? (d.flags | GEMM_VEC_OK) : (d.flags & ~GEMM_VEC_OK);
 
-  ProfScope ps(PROF_GEMM, 2.0 * d.M * d.N * d.K * d.nz, stream);
+  const double zA = (d.sAb || d.sAh) ? d.nz : 1, zB = (d.sBb || d.sBh) ? d.nz : 1;  // a batch-shared operand is read once
+  ProfScope ps(PROF_GEMM, 2.0 * d.M * d.N * d.K * d.nz, stream,
+               2.0 * d.M * d.K * zA + 2.0 * d.N * d.K * zB +
+                   d.nz * ((out_f32 ? 4.0 : 2.0) * d.M * d.N + ((d.flags & GEMM_RESIDUAL) ? 2.0 * d.M * d.N : 0.0)));
   const int pp = gemm_pp_try(d, stream);  // large products: persistent ping-pong kernel (gemm_pp.hip)
   if (pp != 0) return pp > 0 ? U2_OK : pp;
   return gemm_classic(d, stream);

@@ -459,19 +459,21 @@ __device__ __forceinline__ void pp_group_sb(const GemmDesc& d, char* lds, const 
       else src_[i] = B_ + (int64_t)min(bn0_ + r_ - 256, d.N - 1) * d.ldb + gc_ * 8;               \
     }                                                                                             \
   }
+// The source pointers RUN (advanced by BK after the batch): every piece reads its own, already valid address
+// registers, so the pieces issue back to back.  (Computing "base + k0" into one temporary per piece makes each
+// address computation wait until the previous global_load_lds has read that register pair.)  K % 64 == 0 here.
 #define SB_ISSUE(src_, kc_, np_, row0_, c_kt_, c_round_, c_it_)                                                       \
   {                                                                                                                   \
-    const int k0_ = c_kt_ * BK;                                                                                       \
     char* s_ = lds + (c_it_ & 1) * STAGE + ((row0_) + j * 8) * ROWB;                                                  \
-    _Pragma("unroll") for (int i = 0; i < (np_); ++i) {                                                               \
-      const void* g_ = (k0_ + kc_[i] < d.K) ? (const void*)(src_[i] + k0_) : (const void*)&g_pp_zero16;               \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_,                             \
+    _Pragma("unroll") for (int i = 0; i < (np_); ++i)                                                                 \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_[i],                        \
                                        (__attribute__((address_space(3))) void*)(s_ + i * 32 * ROWB), 16, 0, 0);      \
-    }                                                                                                                 \
     ++c_it_;                                                                                                          \
     if (++c_kt_ == nkt) {                                                                                             \
       c_kt_ = 0;                                                                                                      \
       if (++c_round_ < my_tiles) SB_SETUP(src_, kc_, np_, row0_, c_round_)                                            \
+    } else {                                                                                                          \
+      _Pragma("unroll") for (int i = 0; i < (np_); ++i) src_[i] += BK;                                                \
     }                                                                                                                 \
   }
 #define SB_ISSUE_X() SB_ISSUE(sx, kx, PX, ROWX, x_kt, x_round, x_it)
@@ -528,8 +530,7 @@ __device__ __forceinline__ void pp_group_sb(const GemmDesc& d, char* lds, const 
 #define RS_LOAD(src_, kc_, np_, c_kt_, c_round_, c_it_, st_, pend_, row0_)                              \
   {                                                                                                     \
     const int k0_ = c_kt_ * BK;                                                                         \
-    _Pragma("unroll") for (int i = 0; i < (np_); ++i)                                                   \
-      rb[i] = (k0_ + kc_[i] < d.K) ? *reinterpret_cast<const uint4*>(src_[i] + k0_) : uint4{0, 0, 0, 0}; \
+    _Pragma("unroll") for (int i = 0; i < (np_); ++i) rb[i] = *reinterpret_cast<const uint4*>(src_[i] + k0_); \
     st_ = c_it_ & 1;                                                                                    \
     pend_ = true;                                                                                       \
     ++c_it_;                                                                                            \
@@ -714,6 +715,7 @@ static int pp_launch(GemmDesc d, hipStream_t stream) {
 
 template <int BN, int ABL = 0, bool RS = false>
 static int pp_launch_sb(GemmDesc d, hipStream_t stream) {
+  if (d.K % 64) return pp_launch<256, 64, 2, true, 0, 2>(d, stream);  // SB streams whole 64-wide K tiles only
   d.tiles_m = (int)cdiv(d.M, 256);
   d.tiles_n = (int)cdiv(d.N, BN);
   const int64_t total = (int64_t)d.tiles_m * d.tiles_n * d.nz;

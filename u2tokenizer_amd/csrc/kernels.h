@@ -9,9 +9,10 @@ namespace u2 {
 enum : int { PROF_GEMM = 0, PROF_FLASH = 1, PROF_TEMPORAL = 2, PROF_ROWOP = 3, PROF_MOVE = 4, PROF_NCAT = 5 };
 void prof_enable(bool on);
 bool prof_enabled();
-int prof_collect(double* ms, double* flops, int64_t* count, int ncat);
+int prof_collect(double* ms, double* flops, double* bytes, int64_t* count, int ncat);  // bytes may be null
 struct ProfScope {  // brackets one launch with hipEvents on `st` when profiling is on; free otherwise
-  ProfScope(int cat, double flops, hipStream_t st);
+  // flops / bytes: ALGORITHMIC work of the launch (2MNK; operands + results once), for the roofline lines of bench.py
+  ProfScope(int cat, double flops, hipStream_t st, double bytes = 0.0);
   ~ProfScope();
   int idx_;
   hipStream_t st_;

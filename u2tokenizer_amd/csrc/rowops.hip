@@ -83,7 +83,7 @@ int layernorm_bf16(const bf16_t* x, const bf16_t* res, const bf16_t* w, const bf
   if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)res) & 15) return U2_ERR_ARG;
   const int64_t total = (int64_t)nb * rows;
   dim3 grid((unsigned)cdiv(total, 4));
-  ProfScope ps(PROF_ROWOP, 0, stream);
+  ProfScope ps(PROF_ROWOP, 0, stream, (double)total * C * 2.0 * (res ? 3.0 : 2.0));
 #define U2_LN(NC)                                                                                          \
   hipLaunchKernelGGL((layernorm_kernel<NC>), grid, dim3(256), 0, stream, x, res, w, bias, y, nb, rows, C,  \
                      x_bs, x_ld, res_bs, res_ld, y_bs, y_ld, eps)
@@ -139,7 +139,7 @@ int softmax_rows(const float* S, bf16_t* P, int nz, int rows, int n, int64_t lds
   if (!S || !P || nz <= 0 || rows <= 0 || n <= 0 || ldp < n || lds_ < n) return U2_ERR_ARG;
   if (rel_bias && (H <= 0 || n > max_len || rows > max_len)) return U2_ERR_ARG;  // rma.py: seq_len <= max_seq_len
   const int64_t total = (int64_t)nz * rows;
-  ProfScope ps(PROF_ROWOP, 0, stream);
+  ProfScope ps(PROF_ROWOP, 0, stream, (double)total * (4.0 * n + 2.0 * ldp));
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)cdiv(total, 4)), dim3(256), 0, stream, S, P, nz, rows, n,
                      lds_, ldp, s_zs, p_zs, scale, rel_bias, H > 0 ? H : 1, max_len);
   return launch_status();
@@ -182,7 +182,7 @@ int transpose_bf16(const bf16_t* in, bf16_t* out, int nz, int R, int C, int64_t 
   if (perm16 && (ld_out & 15)) return U2_ERR_ARG;
   dim3 grid((unsigned)cdiv(ld_out, 64), (unsigned)cdiv(C, 64), nz);
   if (grid.y > 65535) return U2_ERR_ARG;
-  ProfScope ps(PROF_MOVE, 0, stream);
+  ProfScope ps(PROF_MOVE, 0, stream, (double)nz * C * (2.0 * R + 2.0 * ld_out));
   hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, in, out, R, C, ld_in, ld_out, in_zs, out_zs,
                      perm16);
   return launch_status();

@@ -58,7 +58,7 @@ int im2col_patches(const void* vol, int vol_dtype, bf16_t* out, int nchunk, int 
   const size_t smem = (size_t)p1 * p2 * (W * 2 + 16);
   if (smem > 64 * 1024) return U2_ERR_ARG;
   dim3 grid((unsigned)((int64_t)nchunk * nh * nw));
-  ProfScope ps(PROF_MOVE, 0, stream);
+  ProfScope ps(PROF_MOVE, 0, stream, (double)nchunk * D * H * W * ((vol_dtype == VOL_F32 ? 4.0 : 2.0) + 2.0));
 #define U2_IM2COL(DT) \
   hipLaunchKernelGGL((im2col_kernel<DT>), grid, dim3(256), smem, stream, vol, out, D, H, W, p1, p2, p3, nh, nw, nd)
   if (vol_dtype == VOL_F16) U2_IM2COL(VOL_F16);
