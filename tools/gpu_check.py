@@ -385,7 +385,7 @@ def sec_pptime():
     for (M, N, K) in [(4096, 4096, 4096), (8192, 8192, 8192), (16384, 3072, 768)]:
         a, b = rnd(M, K, seed=1).to(dev), rnd(N, K, seed=2).to(dev)
         out = torch.empty((1, M, N), dtype=bf, device=dev)
-        for v, name in [(14, "SB glds"), (15, "SB reg-staged"), (16, "reg-staged no MFMA"), (17, "no DMA")]:
+        for v, name in [(14, "SB"), (16, "SB, no setprio"), (15, "SB, no MFMA"), (17, "SB, no DMA")]:
             ops.set_option("gemm_pp", v)
             buf.zero_()
             ms = timeit(lambda: ops.gemm(a, b, out=out), iters=3, warm=1)

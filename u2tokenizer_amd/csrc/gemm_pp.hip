@@ -412,12 +412,9 @@ __device__ __forceinline__ void pp_group(const GemmDesc& d, char* lds, const int
 // every batch has >= 2 segments of flight before the barrier that precedes its first reader, and a wave only ever
 // waits with vmcnt(size of the batch it has just issued).
 //
-// RS = true ("register staged"): measured on MI355X, one global_load_lds_dwordx4 costs the issuing wave 120-180
-// cycles (s_memtime, tools/gpu_check.py pptime) -- four of them make an L segment twice as long as the 16 MFMAs it
-// is supposed to hide under.  With RS the same row blocks travel global_load_dwordx4 -> VGPR -> ds_write_b128: the
-// loads of a batch are issued one L segment early (their latency passes under two segments), the 16-byte writes
-// go to exactly the lane-linear image the DMA would have produced, in the slot where SB issues the DMA.
-template <class CFG, int G, bool RS>
+// (A register-staged form of the same schedule -- global_load_dwordx4 -> VGPR -> ds_write_b128 one L segment later --
+// was measured too: no faster, see profiles/r01_gemm_pp_study.log; it is not kept.)
+template <class CFG, int G>
 __device__ __forceinline__ void pp_group_sb(const GemmDesc& d, char* lds, const int j, const int lane) {
   constexpr int BN = CFG::BN, BK = CFG::BK, ROWB = CFG::ROWB, STAGE = CFG::STAGE, NI = CFG::NI, ABL = CFG::ABL;
   static_assert(BK == 64 && CFG::NS == 2 && CFG::SPLIT == 2, "SB schedule: BK 64, 2 stages, split K tile");
@@ -522,32 +519,6 @@ __device__ __forceinline__ void pp_group_sb(const GemmDesc& d, char* lds, const 
   PP_BARRIER();
   if constexpr (G == 1) PP_BARRIER();
 
-  // RS: the batch in flight lives in rb[] (X and Y are never in flight together); x_st / y_st = its LDS stage
-  constexpr int PMAX = PX > PY ? PX : PY;
-  uint4 rb[PMAX];
-  int x_st = 0, y_st = 0;
-  bool x_pend = false, y_pend = false;
-#define RS_LOAD(src_, kc_, np_, c_kt_, c_round_, c_it_, st_, pend_, row0_)                              \
-  {                                                                                                     \
-    const int k0_ = c_kt_ * BK;                                                                         \
-    _Pragma("unroll") for (int i = 0; i < (np_); ++i) rb[i] = *reinterpret_cast<const uint4*>(src_[i] + k0_); \
-    st_ = c_it_ & 1;                                                                                    \
-    pend_ = true;                                                                                       \
-    ++c_it_;                                                                                            \
-    if (++c_kt_ == nkt) {                                                                               \
-      c_kt_ = 0;                                                                                        \
-      if (++c_round_ < my_tiles) SB_SETUP(src_, kc_, np_, row0_, c_round_)                              \
-    }                                                                                                   \
-  }
-#define RS_WRITE(np_, row0_, st_, pend_)                                                                \
-  {                                                                                                     \
-    char* s_ = lds + st_ * STAGE + ((row0_) + j * 8) * ROWB + lane * 16;                                \
-    _Pragma("unroll") for (int i = 0; i < (np_); ++i) *reinterpret_cast<uint4*>(s_ + i * 32 * ROWB) = rb[i]; \
-    pend_ = false;                                                                                      \
-  }
-  if constexpr (RS) {  // first X batch (row block of K tile 1) into registers; written in L(0,0)
-    if (x_it < nit) RS_LOAD(sx, kx, PX, x_kt, x_round, x_it, x_st, x_pend, ROWX)
-  }
   bf16x8 xf[KH][2], wf[KH][NI];
   unsigned long long tsum[4] = {0, 0, 0, 0}, tsum4 = 0, tsum5 = 0, tprev = 0, nseg = 0;
   if constexpr (ABL & 8) tprev = __builtin_amdgcn_s_memtime();
@@ -562,19 +533,7 @@ __device__ __forceinline__ void pp_group_sb(const GemmDesc& d, char* lds, const 
         tsum[3] += t - tprev; tprev = t;
       }
       bool issued = false;
-      if constexpr (RS) {
-        if constexpr (!(ABL & 2)) {
-          // the batch loaded one L segment ago has arrived (>= 2 segments of flight): write it, load the next one
-          PP_WAIT_VM(0);
-          if (h == 0) {
-            if (x_pend) RS_WRITE(PX, ROWX, x_st, x_pend)
-            if (y_it < nit) RS_LOAD(sy, ky, PY, y_kt, y_round, y_it, y_st, y_pend, ROWY)
-          } else {
-            if (y_pend) RS_WRITE(PY, ROWY, y_st, y_pend)
-            if (x_it < nit) RS_LOAD(sx, kx, PX, x_kt, x_round, x_it, x_st, x_pend, ROWX)
-          }
-        }
-      } else if constexpr (!(ABL & 2)) {
+      if constexpr (!(ABL & 2)) {
         if (h == 0) {
           if (x_it < nit) { SB_ISSUE_X() issued = true; }
         } else {
@@ -603,13 +562,11 @@ __device__ __forceinline__ void pp_group_sb(const GemmDesc& d, char* lds, const 
         tsum5 += t - tprev; tprev = t;
       }
       // everything this wave issued before the batch of this segment has landed
-      if constexpr (!RS) {
-        if (issued) {
-          if (h == 0) PP_WAIT_VM(PX);
-          else PP_WAIT_VM(PY);
-        } else {
-          PP_WAIT_VM(0);
-        }
+      if (issued) {
+        if (h == 0) PP_WAIT_VM(PX);
+        else PP_WAIT_VM(PY);
+      } else {
+        PP_WAIT_VM(0);
       }
       if constexpr (ABL & 8) {
         const unsigned long long t = __builtin_amdgcn_s_memtime();
@@ -659,8 +616,6 @@ __device__ __forceinline__ void pp_group_sb(const GemmDesc& d, char* lds, const 
       o[0] = tsum[0]; o[1] = tsum[1]; o[2] = tsum[2]; o[3] = tsum[3]; o[4] = nseg; o[5] = tsum4; o[6] = tsum5;
     }
   }
-#undef RS_LOAD
-#undef RS_WRITE
 #undef SB_SETUP
 #undef SB_ISSUE
 #undef SB_ISSUE_X
@@ -668,14 +623,14 @@ __device__ __forceinline__ void pp_group_sb(const GemmDesc& d, char* lds, const 
 #undef SB_EPILOGUE
 }
 
-template <int BN, int ABL, bool RS>
+template <int BN, int ABL>
 __global__ __launch_bounds__(512) void gemm_pp_sb_kernel(GemmDesc d) {
   using CFG = PPCfg<BN, 64, 2, false, ABL, 2>;
   __shared__ __attribute__((aligned(16))) char lds[CFG::LDS_BYTES];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (wave < 4) pp_group_sb<CFG, 0, RS>(d, lds, wave, lane);
-  else pp_group_sb<CFG, 1, RS>(d, lds, wave - 4, lane);
+  if (wave < 4) pp_group_sb<CFG, 0>(d, lds, wave, lane);
+  else pp_group_sb<CFG, 1>(d, lds, wave - 4, lane);
 }
 
 template <int BN, int BK, int NS, bool INM, int ABL, int SPLIT>
@@ -713,7 +668,7 @@ static int pp_launch(GemmDesc d, hipStream_t stream) {
   return launch_status();
 }
 
-template <int BN, int ABL = 0, bool RS = false>
+template <int BN, int ABL = 0>
 static int pp_launch_sb(GemmDesc d, hipStream_t stream) {
   if (d.K % 64) return pp_launch<256, 64, 2, true, 0, 2>(d, stream);  // SB streams whole 64-wide K tiles only
   d.tiles_m = (int)cdiv(d.M, 256);
@@ -721,7 +676,7 @@ static int pp_launch_sb(GemmDesc d, hipStream_t stream) {
   const int64_t total = (int64_t)d.tiles_m * d.tiles_n * d.nz;
   if (total > 0x3fffffff) return U2_ERR_ARG;
   const int grid = (int)std::min<int64_t>(total, g_pp_max_grid);
-  hipLaunchKernelGGL((gemm_pp_sb_kernel<BN, ABL, RS>), dim3(grid), dim3(512), 0, stream, d);
+  hipLaunchKernelGGL((gemm_pp_sb_kernel<BN, ABL>), dim3(grid), dim3(512), 0, stream, d);
   return launch_status();
 }
 
@@ -734,16 +689,16 @@ static int pp_launch_variant(int v, const GemmDesc& d, hipStream_t stream) {
     case 3: return pp_launch<128, 64, 3, true, 0, 2>(d, stream);   // 256x128, 3 stages
     case 4: return pp_launch<256, 32, 4>(d, stream);               // 256x256, 64-byte rows, 4 stages
     case 5: return pp_launch_sb<256>(d, stream);                   // row-block ("SB") DMA schedule
-    case 6: return pp_launch_sb<256, 0, true>(d, stream);          // SB, register staged
-    case 7: return pp_launch_sb<192, 0, true>(d, stream);
+    case 6: return pp_launch_sb<192>(d, stream);
+    case 7: return pp_launch_sb<128>(d, stream);
     // measurement-only builds (results of 10..13 are wrong by construction; 14..17 are correct but slower)
     case 10: return pp_launch<256, 64, 2, true, 1, 2>(d, stream);  // variant 1 without MFMAs
     case 11: return pp_launch<256, 64, 2, true, 2, 2>(d, stream);  // ... without DMA after the prologue
     case 12: return pp_launch<256, 64, 2, true, 6, 2>(d, stream);  // ... MFMAs + barriers only
     case 13: return pp_launch<256, 64, 2, true, 5, 2>(d, stream);  // ... DMA + barriers only
     case 14: return pp_launch_sb<256, 8>(d, stream);               // variant 5, s_memtime instrumented
-    case 15: return pp_launch_sb<256, 8, true>(d, stream);         // variant 6, s_memtime instrumented
-    case 16: return pp_launch_sb<256, 9, true>(d, stream);         // variant 6 instrumented, no MFMAs (wrong C)
+    case 15: return pp_launch_sb<256, 9>(d, stream);               // variant 5 instrumented, no MFMAs (wrong C)
+    case 16: return pp_launch_sb<256, 24>(d, stream);              // variant 5 instrumented, no s_setprio
     case 17: return pp_launch_sb<256, 10>(d, stream);              // variant 5 instrumented, no DMA (wrong C)
     default: return U2_ERR_ARG;
   }
