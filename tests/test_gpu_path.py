@@ -171,6 +171,24 @@ def test_tokenizer_full_size_properties():
     assert e["rel_rms"] < 5e-3, e  # only the fp32 summation order inside softmax / PV changes
 
 
+def test_tta_side_stream_is_invisible():
+    """The k | v projections of the TTA cross attentions run on a second HIP stream (event-ordered).  Result must be
+    bit-identical to the in-line order, call after call (workspace reuse across calls included)."""
+    from u2tokenizer_amd import ops
+    E = 2048
+    tok = _big_tokenizer(E)
+    g = torch.Generator(device=D).manual_seed(5)
+    v = torch.randn(1, 8, 256, E, device=D, generator=g).to(bf)
+    t = (torch.randn(1, 1024, E, device=D, generator=g) * 0.25).to(bf)
+    ops.set_option("tta_overlap", 0)
+    try:
+        ref = tok(v_token=v, t_token=t).clone()
+    finally:
+        ops.set_option("tta_overlap", 1)
+    for _ in range(4):
+        assert torch.equal(tok(v_token=v, t_token=t), ref)
+
+
 def test_hard_topk_full_size_replay():
     """Hard top-k at BASELINE size inside the pipeline: indices == oracle selection on the same refined tokens."""
     E = 2048

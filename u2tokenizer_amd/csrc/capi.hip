@@ -58,6 +58,7 @@ int u2tok_set_option(const char* name, int value) {
     return U2_OK;
   }
   if (!strcmp(name, "vit_flash")) { pipeline_set_vit_flash(value); return U2_OK; }
+  if (!strcmp(name, "tta_overlap")) { pipeline_set_tta_overlap(value); return U2_OK; }
   if (!strcmp(name, "profile")) { prof_enable(value != 0); return U2_OK; }
   return U2_ERR_ARG;
 }

@@ -19,5 +19,6 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
                       bf16_t* out, int64_t* topk_idx_out, bf16_t* svr_out, void* ws, size_t ws_bytes, bool dry,
                       size_t* peak, hipStream_t st);
 void pipeline_set_vit_flash(int v);
+void pipeline_set_tta_overlap(int v);
 
 }  // namespace u2

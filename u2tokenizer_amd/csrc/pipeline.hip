@@ -104,10 +104,34 @@ int attention_core(Arena& ar, const AttnCore& a, bool dry, hipStream_t st) {
 }
 
 int g_vit_flash = 1;
+int g_tta_overlap = 1;
+
+// Side stream of the tokenizer: the k | v projections of the TTA cross attentions depend only on the selected visual
+// tokens and the text tokens, not on the query chain.  They are large, throughput-bound GEMMs; the query chain is
+// a string of M = 256 GEMMs and small attention launches that cannot fill the machine.  Forked onto a second HIP
+// stream (event-ordered, no host synchronisation) the two overlap on the CUs.  One stream + event set per process:
+// the library is driven from one host thread per GPU (SURVEY 8b "Threading").
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr;
+  hipEvent_t done[16] = {};
+  bool ok = false;
+  bool init() {
+    if (ok) return true;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return false;
+    if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
+    for (auto& e : done)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+    ok = true;
+    return true;
+  }
+};
+SideStream g_side;
 
 }  // namespace
 
 void pipeline_set_vit_flash(int v) { g_vit_flash = v ? 1 : 0; }
+void pipeline_set_tta_overlap(int v) { g_tta_overlap = v ? 1 : 0; }
 
 // =========================================================================== ViT3DTower
 // Row layout of the residual stream: the nc * ntok PATCH rows first (chunk-major), then the nc cls rows.  The
@@ -417,19 +441,56 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
   bf16_t* qproj = ar.get<bf16_t>((size_t)qrows * 3 * E);
   bf16_t* qctx = ar.get<bf16_t>((size_t)qrows * E);
   bf16_t* qo = ar.get<bf16_t>((size_t)qrows * E);
+  // k | v of the two cross attentions of every layer: one buffer each, filled on the side stream (or in line)
+  const bool overlap = g_tta_overlap && L > 0 && L <= 7 && (dry || g_side.init());
   const int Lmax = Lv > c.Lt ? Lv : c.Lt;
-  bf16_t* kv = ar.get<bf16_t>((size_t)B * Lmax * 2 * E);
+  bf16_t* kv_inline = overlap ? nullptr : ar.get<bf16_t>((size_t)B * Lmax * 2 * E);
+  bf16_t* kv_v[8] = {};
+  bf16_t* kv_t[8] = {};
+  if (overlap)
+    for (int l = 0; l < L; ++l) {
+      kv_v[l] = ar.get<bf16_t>((size_t)B * Lv * 2 * E);
+      kv_t[l] = ar.get<bf16_t>((size_t)B * c.Lt * 2 * E);
+    }
+  bf16_t* k_lin = ar.get<bf16_t>((size_t)B * Lv * E);  // key projection of the final linear aggregation
   U2_CHECK_WS(ar);
+  auto kv_proj = [&](const Att& a, const bf16_t* src, int Ls, bf16_t* kv, hipStream_t s_) -> int {
+    if (!dry && kv_packed(a, E)) {
+      U2_RUN(linear(src, E, a.wk, a.bk, kv, 2 * E, (int64_t)B * Ls, E, 2 * E, 0, nullptr, 0, s_));
+    } else {
+      U2_RUN(linear(src, E, a.wk, a.bk, kv, 2 * E, (int64_t)B * Ls, E, E, 0, nullptr, 0, s_));
+      U2_RUN(linear(src, E, a.wv, a.bv, kv + E, 2 * E, (int64_t)B * Ls, E, E, 0, nullptr, 0, s_));
+    }
+    return U2_OK;
+  };
+  if (overlap && !dry) {
+    // fork: everything `st` has enqueued so far (V and t_token are final) precedes the side stream's work
+    if (hipEventRecord(g_side.fork, st) != hipSuccess || hipStreamWaitEvent(g_side.s, g_side.fork, 0) != hipSuccess)
+      return U2_ERR_LAUNCH;
+    for (int l = 0; l < L; ++l) {
+      const int base = i_tta + 33 * l;
+      Att va = att_at(base + 9), ta = att_at(base + 18);
+      { const int e = kv_proj(va, V, Lv, kv_v[l], g_side.s); if (e != U2_OK) return e; }
+      if (hipEventRecord(g_side.done[2 * l], g_side.s) != hipSuccess) return U2_ERR_LAUNCH;
+      { const int e = kv_proj(ta, t_token, c.Lt, kv_t[l], g_side.s); if (e != U2_OK) return e; }
+      if (hipEventRecord(g_side.done[2 * l + 1], g_side.s) != hipSuccess) return U2_ERR_LAUNCH;
+    }
+    const Att la = att_at(i_lin);
+    U2_RUN(linear(V, E, la.wk, la.bk, k_lin, E, (int64_t)B * Lv, E, E, 0, nullptr, 0, g_side.s));
+    if (hipEventRecord(g_side.done[2 * L], g_side.s) != hipSuccess) return U2_ERR_LAUNCH;
+  }
   U2_RUN(fill_rows(wp(0), qa, B, (int64_t)Q * E, (int64_t)Q * E, st));  // query_tokens.expand(B,-1,-1)
   bf16_t* qcur = qa;
-  auto cross = [&](const Att& a, const bf16_t* src, int Ls, const bf16_t* qin, bf16_t* dst) -> int {
+  // kv_ready: index of the side-stream event that publishes `kv` (-1: compute it here)
+  auto cross = [&](const Att& a, const bf16_t* src, int Ls, const bf16_t* qin, bf16_t* dst, bf16_t* kv,
+                   int kv_ready) -> int {
     // MultiHeadCrossAttention.forward (tta.py:42-69), is_compress = False
     U2_RUN(linear(qin, E, a.wq, a.bq, qproj, E, qrows, E, E, 0, nullptr, 0, st));
-    if (!dry && kv_packed(a, E)) {
-      U2_RUN(linear(src, E, a.wk, a.bk, kv, 2 * E, (int64_t)B * Ls, E, 2 * E, 0, nullptr, 0, st));
-    } else {
-      U2_RUN(linear(src, E, a.wk, a.bk, kv, 2 * E, (int64_t)B * Ls, E, E, 0, nullptr, 0, st));
-      U2_RUN(linear(src, E, a.wv, a.bv, kv + E, 2 * E, (int64_t)B * Ls, E, E, 0, nullptr, 0, st));
+    if (kv_ready < 0) {
+      const int e = kv_proj(a, src, Ls, kv, st);
+      if (e != U2_OK) return e;
+    } else if (!dry) {
+      if (hipStreamWaitEvent(st, g_side.done[kv_ready], 0) != hipSuccess) return U2_ERR_LAUNCH;
     }
     AttnCore ac{qproj, kv, kv + E, E, 2 * E, 2 * E, (int64_t)Q * E, (int64_t)Ls * 2 * E, (int64_t)Ls * 2 * E,
                 qctx, E, (int64_t)Q * E, B, Q, Ls, H, d, scale, nullptr, 0};
@@ -466,10 +527,10 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
     U2_RUN(linear(qctx, E, sa.wd, sa.bd, qo, E, qrows, E, E, 0, nullptr, 0, st));
     U2_RUN(layernorm_bf16(qcur, qo, ns_w, ns_b, s1, 1, (int)qrows, E, 0, E, 0, E, 0, E, c.ln_eps, st));
     // visual cross attention (tta.py:97-100)
-    { const int e = cross(va, V, Lv, s1, qo); if (e != U2_OK) return e; }
+    { const int e = cross(va, V, Lv, s1, qo, overlap ? kv_v[l] : kv_inline, overlap ? 2 * l : -1); if (e != U2_OK) return e; }
     U2_RUN(layernorm_bf16(s1, qo, nv_w, nv_b, s2, 1, (int)qrows, E, 0, E, 0, E, 0, E, c.ln_eps, st));
     // text cross attention (tta.py:101-103) -- no padding mask in the reference
-    { const int e = cross(ta, t_token, c.Lt, s2, qo); if (e != U2_OK) return e; }
+    { const int e = cross(ta, t_token, c.Lt, s2, qo, overlap ? kv_t[l] : kv_inline, overlap ? 2 * l + 1 : -1); if (e != U2_OK) return e; }
     U2_RUN(layernorm_bf16(s2, qo, nt_w, nt_b, s1, 1, (int)qrows, E, 0, E, 0, E, 0, E, c.ln_eps, st));
     qcur = s1;
   }
@@ -477,8 +538,12 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
   {
     const Att la = att_at(i_lin);
     U2_RUN(linear(qcur, E, la.wq, la.bq, qproj, E, qrows, E, E, 0, nullptr, 0, st));
-    U2_RUN(linear(V, E, la.wk, la.bk, kv, E, (int64_t)B * Lv, E, E, 0, nullptr, 0, st));
-    AttnCore ac{qproj, kv, V, E, E, E, (int64_t)Q * E, (int64_t)Lv * E, (int64_t)Lv * E,
+    if (!overlap) {
+      U2_RUN(linear(V, E, la.wk, la.bk, k_lin, E, (int64_t)B * Lv, E, E, 0, nullptr, 0, st));
+    } else if (!dry) {
+      if (hipStreamWaitEvent(st, g_side.done[2 * L], 0) != hipSuccess) return U2_ERR_LAUNCH;
+    }
+    AttnCore ac{qproj, k_lin, V, E, E, E, (int64_t)Q * E, (int64_t)Lv * E, (int64_t)Lv * E,
                 out, E, (int64_t)Q * E, B, Q, Lv, H, d, scale, nullptr, 0};
     const int e = attention_core(ar, ac, dry, st);
     if (e != U2_OK) return e;
