@@ -8,6 +8,9 @@ Workload = BASELINE.json configs[2] (u2Qwen3-8B shape: E=4096, full multi-scale 
 weights of that architecture, synthetic data.  N > 1: independent replicas, one process per GPU (weak scaling, no
 data-path collective); launched by torch.distributed.run, timed with barrier + synchronize, MAX over ranks.
 
+Steps are issued round-robin on --streams HIP streams (default 2: two batch-1 volumes in flight per GPU; every step is
+still one complete pass over one volume, and `value_one_stream` reports the same K steps on a single stream).
+
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     -- the dominant kernel class (bf16 MFMA GEMM): algorithmic FLOPs of all its launches in one step /
                   their summed HIP-event durations (instrumented pass after the timed region), vs 2.5 PFLOP/s.
@@ -153,6 +156,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--hidden", type=int, default=4096, help="LLM hidden size E (4096 = Qwen3-8B, 2048 = Qwen3-1.7B)")
     ap.add_argument("--batch", type=int, default=1, help="volumes per step per GPU")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the steps are issued on round-robin (2 = two volumes in flight per GPU: the small "
+                         "launches of one volume's tokenizer fill the machine under the other volume's large GEMMs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -186,8 +192,13 @@ def main():
     qids = torch.zeros((B, Lt), dtype=torch.int64, device=device)
     qids[:, :40] = torch.randint(1, vocab, (B, 40), device=device, generator=g)
 
-    def step(i):
-        return path.prepare_inputs_for_multimodal(ids, None, None, None, None, vols[i % nvol], qids)[4]
+    streams = [torch.cuda.Stream(device=device) for _ in range(args.streams)] if args.streams > 1 else None
+
+    def step(i, multi=True):
+        if streams is None or not multi:
+            return path.prepare_inputs_for_multimodal(ids, None, None, None, None, vols[i % nvol], qids)[4]
+        with torch.cuda.stream(streams[i % len(streams)]):
+            return path.prepare_inputs_for_multimodal(ids, None, None, None, None, vols[i % nvol], qids)[4]
 
     def sync():
         replicas.barrier(dist, device)
@@ -203,6 +214,18 @@ def main():
     assert out.shape == (B, S, E) and bool(torch.isfinite(out.float()).all())
     elapsed = replicas.max_over_ranks(dist, elapsed, device)
 
+    # the same K steps issued on ONE stream (one volume in flight), for reference next to the headline
+    single = None
+    if streams is not None:
+        for i in range(args.warmup):
+            step(i, multi=False)
+        sync()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(i, multi=False)
+        sync()
+        single = replicas.max_over_ranks(dist, time.perf_counter() - t1, device)
+
     fl = flops_per_volume(E, Lt)
     value = world * B * args.steps / elapsed
     line = {
@@ -211,12 +234,14 @@ def main():
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "tokens_per_s": round(value * Q, 1),
+        "value_one_stream": round(world * B * args.steps / single, 3) if single else None,
         "path_tflops": round(value * fl["total"] / 1e12, 1),
         "path_frac_of_bf16_mfma_peak": round(value * fl["total"] / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
         "config": {"workload": "BASELINE configs[2]: u2Qwen3-8B-shaped path, 256^3 volume = 8x(32,256,256) fp16, "
                                "ViT-B 3D x12, SPP, 4-layer rma+diffts+dmtp tokenizer (8 heads, top_k 1024, scales "
                                "{1,2,4}, 256 queries), text 1024, prompt 1024",
-                   "hidden_size": E, "batch_per_gpu": B, "flop_per_volume": fl["total"], "parallelism": f"replicas x{world}"},
+                   "hidden_size": E, "batch_per_gpu": B, "streams_per_gpu": args.streams, "flop_per_volume": fl["total"],
+                   "parallelism": f"replicas x{world}"},
     }
 
     if rank == 0 and not args.no_roofline:
@@ -225,7 +250,7 @@ def main():
         ops.set_option("profile", 1)
         nprof = 3
         for i in range(nprof):
-            step(i)
+            step(i, multi=False)  # one stream: a kernel's own duration, not stretched by a co-running volume
         torch.cuda.synchronize()
         ms, flops, byts, cnt = (C.c_double * 5)(), (C.c_double * 5)(), (C.c_double * 5)(), (C.c_int64 * 5)()
         _lib.check(h.u2tok_profile_collect2(ms, flops, byts, cnt, 5), "u2tok_profile_collect2")

@@ -119,6 +119,15 @@ def test_transpose_and_data_movement_are_bit_exact(ops):
     x = rnd(3, 70, 130, seed=8)
     got = ops.transpose(x.to(D), ld_out=72).cpu()
     assert torch.equal(got[:, :, :70], x.transpose(1, 2)) and (got[:, :, 70:] == 0).all()
+    x = rnd(2, 203, 192, seed=81)  # strides % 4 == 0: the 8-byte vector kernel; ragged rows, several tiles
+    got = ops.transpose(x.to(D), ld_out=208).cpu()
+    assert torch.equal(got[:, :, :203], x.transpose(1, 2)) and (got[:, :, 203:] == 0).all()
+    got = ops.transpose(x.to(D), ld_out=208, perm16=True).cpu()
+    want = torch.zeros(2, 192, 208, dtype=bf)
+    want[:, :, :203] = x.transpose(1, 2)
+    order = [j for g in range(13) for j in (list(range(16 * g, 16 * g + 4)) + list(range(16 * g + 8, 16 * g + 12)) +
+                                             list(range(16 * g + 4, 16 * g + 8)) + list(range(16 * g + 12, 16 * g + 16)))]
+    assert torch.equal(got, want[:, :, order])
     for dt in (torch.float16, torch.bfloat16, torch.float32):
         vol = torch.rand(2, 1, 8, 32, 32, generator=torch.Generator().manual_seed(3)).to(dt)
         ref = vol.to(bf).reshape(2, 1, 2, 4, 2, 16, 2, 16).permute(0, 2, 4, 6, 3, 5, 7, 1).reshape(2, 8, 1024)

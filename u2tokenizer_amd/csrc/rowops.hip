@@ -243,6 +243,50 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
   }
 }
 
+// Vector form (all strides multiples of 4 elements, 8-byte aligned bases): 8-byte global loads and stores, 64x64 tile.
+__global__ __launch_bounds__(256) void transpose_vec_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int R,
+                                                            int C, int64_t ld_in, int64_t ld_out, int64_t in_zs,
+                                                            int64_t out_zs, int perm16) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64][68];  // 136-byte rows: 8-byte aligned, odd multiple of 8 B
+  const int z = blockIdx.z;
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const bf16_t* ip = in + z * in_zs;
+  bf16_t* op = out + z * out_zs;
+  const int q = threadIdx.x & 15, w = threadIdx.x >> 4;  // q: group of 4 columns, w: row 0..15 (+16 i)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + w + i * 16, c = c0 + q * 4;
+    uint2 v = {0u, 0u};
+    if (r < R) {
+      if (c + 3 < C) {
+        v = *reinterpret_cast<const uint2*>(ip + (int64_t)r * ld_in + c);
+      } else if (c < C) {  // ragged right edge (C % 4 != 0 never gets here: launcher)
+        const bf16_t* p = ip + (int64_t)r * ld_in + c;
+        const uint32_t e0 = p[0], e1 = c + 1 < C ? p[1] : 0u, e2 = c + 2 < C ? p[2] : 0u;
+        v = uint2{e0 | (e1 << 16), e2};
+      }
+    }
+    *reinterpret_cast<uint2*>(&tile[w + i * 16][q * 4]) = v;
+  }
+  __syncthreads();
+  // output row = input column cc, output columns = 4 consecutive input rows (the source quad is permuted for perm16)
+  int sq = q;
+  if (perm16) {
+    const int qd = q & 3;
+    sq = (q & ~3) | (qd == 1 ? 2 : (qd == 2 ? 1 : qd));
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cc = w + i * 16;
+    const int c = c0 + cc, r = r0 + q * 4;
+    if (c < C && r < ld_out) {
+      const uint32_t e0 = tile[sq * 4 + 0][cc], e1 = tile[sq * 4 + 1][cc], e2 = tile[sq * 4 + 2][cc],
+                     e3 = tile[sq * 4 + 3][cc];
+      *reinterpret_cast<uint2*>(op + (int64_t)c * ld_out + r) = uint2{e0 | (e1 << 16), e2 | (e3 << 16)};
+    }
+  }
+}
+
 int transpose_bf16(const bf16_t* in, bf16_t* out, int nz, int R, int C, int64_t ld_in, int64_t ld_out,
                    int64_t in_zs, int64_t out_zs, int perm16, hipStream_t stream) {
   if (!in || !out || nz <= 0 || nz > 65535 || R <= 0 || C <= 0 || ld_in < C || ld_out < R) return U2_ERR_ARG;
@@ -250,8 +294,14 @@ int transpose_bf16(const bf16_t* in, bf16_t* out, int nz, int R, int C, int64_t 
   dim3 grid((unsigned)cdiv(ld_out, 64), (unsigned)cdiv(C, 64), nz);
   if (grid.y > 65535) return U2_ERR_ARG;
   ProfScope ps(PROF_MOVE, 0, stream, (double)nz * C * (2.0 * R + 2.0 * ld_out));
-  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, in, out, R, C, ld_in, ld_out, in_zs, out_zs,
-                     perm16);
+  const bool vec = !(C & 3) && !(ld_in & 3) && !(ld_out & 3) && !(in_zs & 3) && !(out_zs & 3) &&
+                   !(((uintptr_t)in | (uintptr_t)out) & 7);
+  if (vec)
+    hipLaunchKernelGGL(transpose_vec_kernel, grid, dim3(256), 0, stream, in, out, R, C, ld_in, ld_out, in_zs, out_zs,
+                       perm16);
+  else
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, in, out, R, C, ld_in, ld_out, in_zs, out_zs,
+                       perm16);
   return launch_status();
 }
 

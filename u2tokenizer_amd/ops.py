@@ -239,15 +239,19 @@ def rope_apply(x: torch.Tensor, n_outer, S, n_inner, H, d, max_len=512):
 
 # ---------------------------------------------------------------------------------- pipelines
 class _Workspace:
-    """Grow-only uint8 HBM scratch owned by the calling module (one per module instance)."""
+    """Grow-only uint8 HBM scratch owned by the calling module: one buffer per (module instance, HIP stream), so
+    calls issued on different streams (two volumes in flight on one GPU) never share scratch."""
 
     def __init__(self):
-        self.buf: Optional[torch.Tensor] = None
+        self.bufs = {}
 
     def get(self, nbytes: int, device) -> torch.Tensor:
-        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
-            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        return self.buf
+        key = (str(device), _stream())
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self.bufs[key] = buf
+        return buf
 
 
 def weight_table(tensors) -> "C.Array":
