@@ -171,6 +171,26 @@ def test_tokenizer_full_size_properties():
     assert e["rel_rms"] < 5e-3, e  # only the fp32 summation order inside softmax / PV changes
 
 
+def test_two_volumes_in_flight_match_sequential():
+    """StreamRoundRobin: the same calls issued on two HIP streams (per-stream workspaces, shared weights, shared side
+    stream of the tokenizer) must give bit-identical results to issuing them one after the other."""
+    from u2tokenizer_amd.replicas import StreamRoundRobin
+    E = 2048
+    tok = _big_tokenizer(E)
+    g = torch.Generator(device=D).manual_seed(9)
+    vs = [torch.randn(1, 8, 256, E, device=D, generator=g).to(bf) for _ in range(4)]
+    t = (torch.randn(1, 1024, E, device=D, generator=g) * 0.25).to(bf)
+    seq = [tok(v_token=v, t_token=t).clone() for v in vs]
+    torch.cuda.synchronize()
+    rr = StreamRoundRobin(2)
+    for _ in range(3):
+        outs = [rr.submit(tok, v_token=v, t_token=t) for v in vs]
+        rr.wait()
+        torch.cuda.synchronize()
+        for a, b in zip(outs, seq):
+            assert torch.equal(a, b)
+
+
 def test_tta_side_stream_is_invisible():
     """The k | v projections of the TTA cross attentions run on a second HIP stream (event-ordered).  Result must be
     bit-identical to the in-line order, call after call (workspace reuse across calls included)."""

