@@ -247,3 +247,38 @@ def test_vit_full_size_properties():
         ops.set_option("vit_flash", 1)
     e = err_stats(b.float().cpu(), a[:2].float().cpu())
     assert e["rel_rms"] < 2e-2, e
+
+
+def test_config2_geometry_vs_oracle():
+    """BASELINE configs[1]: 3-scale tokenizer at E = 2048 (Qwen3-1.7B width), 128^3 volumes = 4 chunks of (32,128,128)
+    -> 512 patches (+cls) per chunk, 64 pooled tokens per chunk, batch 4, rma + DiffTS(1024) + DMTP, 256 queries,
+    text 1024.  Whole path ViT -> SPP -> u2Tokenizer against the oracle run in fp32 and in bf16 on the same
+    synthetic parameters (name-seeded), same bar as the golden cases."""
+    from u2tokenizer_amd.projector import SpatialPoolingProjector
+    from u2tokenizer_amd.tokenizer import u2Tokenizer
+    from u2tokenizer_amd.vit import ViT3DTower
+    E, B, C, img = 2048, 4, 4, [32, 128, 128]
+    vit = ViT3DTower(NS(vision_select_layer=-1, vision_select_feature="patch", image_channel=1, image_size=img,
+                        patch_size=[4, 16, 16]))
+    spp = SpatialPoolingProjector(img, [4, 16, 16], 768, E, "mlp", 2, "spatial", 2)
+    tok = u2Tokenizer(E, 8, 4, 1024, True, 256, E, "rma", True, True)
+    sd32, sd16 = {}, {}
+    for prefix, m in (("model.vision_tower.", vit), ("model.mm_projector.", spp), ("model.u2tokenizer.", tok)):
+        synth.fill_module_(m, seed=61, prefix=prefix)
+        for k, v in m.state_dict().items():
+            sd32[prefix + k], sd16[prefix + k] = v.clone(), v.to(bf)
+    vol = synth.synth_volume(B, C, img, seed=61, dtype=torch.float16)
+    t = 0.25 * synth.synth_tensor("t_token", (B, 1024, E), 61)
+    cfg = O.PathConfig(image_size=img, hidden_size=E)
+
+    def oracle(sd, dt):
+        f = O.vit_tower_forward(sd, "model.vision_tower.vision_tower", vol.to(dt).view(B * C, 1, *img), cfg)
+        f = O.spp_forward(sd, "model.mm_projector", f, cfg)
+        return O.tokenizer_forward(sd, "model.u2tokenizer", f.view(B, C, f.shape[-2], E), t.to(dt), cfg)[0]
+
+    ref32, ref16 = oracle(sd32, torch.float32), oracle(sd16, bf)
+    vit, spp, tok = vit.to(bf).to(D), spp.to(bf).to(D), tok.to(bf).to(D)
+    f = spp(vit(vol.to(D).view(B * C, 1, *img)))
+    got = tok(v_token=f.view(B, C, f.shape[-2], E), t_token=t.to(bf).to(D))
+    assert got.shape == (B, 256, E)
+    check_vs_reference(got, ref32, ref16, "config 2 geometry")
