@@ -154,6 +154,19 @@ int u2tok_tokenizer_forward(const u2tok_tokenizer_config* cfg, const void* const
 int u2tok_embed_splice(const void* table, const int64_t* ids, const void* feats, void* out, int32_t B, int32_t S,
                        int32_t E, int32_t nfeat, int64_t vocab, u2tok_stream_t stream);
 
+/* ---- producer of the path's input ("next" row of the scope table) ------------------------------------------- */
+/* u2Transform.adaptive_resize (src/utils/u2Transform.py:62-122 with the validation transforms of :46-54) on the GPU:
+ * ScaleIntensityRangePercentiles(lower_pct, upper_pct, 0, 1, clip) -> CropForeground -> anti-aliased trilinear
+ * resize to (int(H r), int(W r), min(D, depth_pad)), r = min(target/H, target/W) -> zero pad to
+ * depth_pad x target x target.  vol: fp32 [D][H][W] (the tensor of u2Transform.py:68-69 without the channel axis);
+ * out: [depth_pad][target][target] == (depth_pad/32, 32, target, target) of out_dtype (0 fp16, 1 bf16, 2 fp32);
+ * info (optional, 12 x int32, device): status (0 ok, 1 no foreground, 2 filter too wide), crop lo[3], hi[3] (d,h,w),
+ * resized size[3], then the two percentiles as float. */
+size_t u2tok_preprocess_workspace_bytes(int32_t D, int32_t H, int32_t W);
+int u2tok_preprocess_volume(const float* vol, void* out, int32_t* info, int32_t D, int32_t H, int32_t W, int32_t target,
+                            int32_t depth_pad, float lower_pct, float upper_pct, int32_t out_dtype, void* workspace,
+                            size_t workspace_bytes, u2tok_stream_t stream);
+
 /* ---- building blocks (exported for the parity tests; same kernels the pipelines launch) -------- */
 
 /* C[z] = epi(alpha * A[z] B[z]^T): A (M,K) lda, B (N,K) ldb, C (M,N) ldc; z = zb*nbh + zh with element strides.

@@ -1,0 +1,112 @@
+"""CPU oracle for the volume preprocessing (reference src/utils/u2Transform.py:62-122, validation transforms :46-54)
+-- TEST INFRASTRUCTURE ONLY (imported by tests/ and nothing else).
+
+PARITY UNPINNED.  u2Transform is built from MONAI 1.3.0 transforms (requirements.txt:52: ScaleIntensityRangePercentiles,
+CropForeground, monai.transforms.spatial.functional.resize with anti_aliasing), and MONAI is neither installed nor
+vendored under /root/reference, and the reference holds no vectors for this step.  The functions below restate
+MONAI 1.3.0's published semantics with numpy / torch ops (each cites the MONAI module it follows); everything that is
+torch's own (F.interpolate, F.pad, F.conv1d, erf) is called directly.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def scale_intensity_range_percentiles(img: torch.Tensor, lower=0.5, upper=99.5, b_min=0.0, b_max=1.0, clip=True):
+    """monai.transforms.intensity.array.ScaleIntensityRangePercentiles._normalize + ScaleIntensityRange.__call__:
+    percentiles by np.percentile (monai.transforms.utils_pytorch_numpy_unification.percentile: numpy above 1e6
+    elements, torch.quantile below -- both linear interpolation), arithmetic in the input dtype, result float32."""
+    x = img.double().numpy()
+    a_min, a_max = np.percentile(x, lower), np.percentile(x, upper)
+    if a_max - a_min == 0.0:
+        y = x - a_min + b_min
+    else:
+        y = (x - a_min) / (a_max - a_min)
+        y = y * (b_max - b_min) + b_min
+        if clip:
+            y = np.clip(y, b_min, b_max)
+    return torch.from_numpy(y.astype(np.float32)), float(a_min), float(a_max)
+
+
+def crop_foreground(img: torch.Tensor):
+    """monai.transforms.croppad.array.CropForeground (select_fn = img > 0, margin 0) on a (C, ...) tensor:
+    monai.transforms.utils.generate_spatial_bounding_box."""
+    fg = (img > 0).any(0)
+    lo, hi = [], []
+    for ax in range(fg.dim()):
+        other = tuple(a for a in range(fg.dim()) if a != ax)
+        line = fg.any(other) if other else fg
+        nz = torch.nonzero(line).flatten()
+        if nz.numel() == 0:
+            raise ValueError("no foreground")
+        lo.append(int(nz[0]))
+        hi.append(int(nz[-1]) + 1)
+    sl = (slice(None),) + tuple(slice(a, b) for a, b in zip(lo, hi))
+    return img[sl], lo, hi
+
+
+def gaussian_1d(sigma: float, truncated: float = 4.0) -> torch.Tensor:
+    """monai.networks.layers.convutils.gaussian_1d(approx="erf", normalize=False) as GaussianFilter uses it; the taps
+    are then divided by their sum (GaussianFilter.forward -> separable_filtering of the normalised kernel)."""
+    s = torch.as_tensor(sigma, dtype=torch.float)
+    tail = int(max(float(s) * truncated, 0.5) + 0.5)
+    x = torch.arange(-tail, tail + 1, dtype=torch.float)
+    t = 0.70710678 / torch.abs(s)
+    out = 0.5 * ((t * (x + 0.5)).erf() - (t * (x - 0.5)).erf())
+    out = out.clamp(min=0)
+    return out / out.sum()
+
+
+def separable_gaussian(img: torch.Tensor, sigmas) -> torch.Tensor:
+    """monai.networks.layers.simplelayers.GaussianFilter / separable_filtering, zero padding; img (1, d0, d1, d2)."""
+    x = img.unsqueeze(0)  # (1, 1, d0, d1, d2)
+    for ax, s in enumerate(sigmas):
+        k = gaussian_1d(s)
+        shape = [1, 1, 1, 1, 1]
+        shape[2 + ax] = k.numel()
+        pad = [0, 0, 0]
+        pad[ax] = (k.numel() - 1) // 2
+        x = F.conv3d(x, k.view(shape), padding=pad)
+    return x[0]
+
+
+def resize_aa(img: torch.Tensor, out_size) -> torch.Tensor:
+    """monai.transforms.spatial.functional.resize(mode bilinear -> trilinear for volumes, align_corners=True,
+    anti_aliasing=True, anti_aliasing_sigma=None); img (1, d0, d1, d2) float32."""
+    img_ = img.float()
+    in_size = list(img_.shape[1:])
+    if any(o < i for o, i in zip(out_size, in_size)):
+        factors = torch.div(torch.Tensor(in_size), torch.Tensor(list(out_size)))
+        sig = torch.maximum(torch.zeros(factors.shape), (factors - 1) / 2).tolist()
+        img_ = separable_gaussian(img_, sig)
+    return F.interpolate(img_.unsqueeze(0), size=list(out_size), mode="trilinear", align_corners=True)[0]
+
+
+def adaptive_resize(data_hwd: np.ndarray, target_image_size: int = 256, padding_size: int = 256):
+    """u2Transform.adaptive_resize (u2Transform.py:62-122) from the array nib.load(path).get_fdata() returns.
+    Returns (tensor (padding_size/32, 32, T, T) float32, info dict)."""
+    data = torch.tensor(np.asarray(data_hwd).transpose(2, 0, 1)[np.newaxis, ...])           # :68-69  (1, D, H, W)
+    data, a_min, a_max = scale_intensity_range_percentiles(data)                             # :51
+    data, lo, hi = crop_foreground(data)                                                     # :52
+    data = data[0]                                                                           # :70
+    data = torch.permute(data, (1, 2, 0))                                                    # :71  (H, W, D)
+    input_shape = data.shape
+    ratio = min([target_image_size / input_shape[i] for i in range(2)])                      # :75
+    scaling_shape = [int(input_shape[i] * ratio) for i in range(2)]                          # :76
+    if padding_size >= input_shape[2]:                                                       # :80
+        scaling_shape.append(input_shape[2])
+        data = resize_aa(data.unsqueeze(0), scaling_shape)
+        pad_tuple = (0, padding_size - scaling_shape[2], 0, target_image_size - scaling_shape[1], 0,
+                     target_image_size - scaling_shape[0])
+        data = F.pad(data, pad_tuple, mode="constant", value=0)
+    else:                                                                                    # :96
+        scaling_shape.append(padding_size)
+        data = resize_aa(data.unsqueeze(0), scaling_shape)
+        pad_tuple = (0, 0, 0, target_image_size - scaling_shape[1], 0, target_image_size - scaling_shape[0])
+        data = F.pad(data, pad_tuple, mode="constant", value=0)
+    data = torch.permute(data, (0, 3, 1, 2))                                                 # :117
+    data = data.reshape(-1, 32, target_image_size, target_image_size)                        # :120 (.view on a permuted tensor)
+    info = dict(a_min=a_min, a_max=a_max, lo=lo, hi=hi, out_size=[scaling_shape[2], scaling_shape[0], scaling_shape[1]])
+    return data, info

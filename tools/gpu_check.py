@@ -452,6 +452,29 @@ def sec_cperf():
     ops.set_option("gemm_bk", 64)
     ops.set_option("gemm_pp", 0)
 
+
+def sec_preperf():
+    """u2tok_preprocess_volume (u2Transform.adaptive_resize on the GPU) vs the CPU oracle, 512 x 512 x 200 CT-like volume"""
+    import numpy as np
+    from oracle import u2_preprocess_oracle as P
+    from u2tokenizer_amd.preprocess import u2Transform
+    rng = np.random.default_rng(0)
+    H, W, Dz = 512, 512, 200
+    vol = np.full((H, W, Dz), -1024.0)
+    vol[40:470, 60:450, 10:190] = rng.normal(40, 250, size=(430, 390, 180)).round()
+    tr = u2Transform(device=dev, out_dtype=torch.float16)
+    v = torch.as_tensor(vol).permute(2, 0, 1).to(device=dev, dtype=torch.float32).contiguous()
+    ms = timeit(lambda: tr.from_dhw(v), iters=10, warm=2)
+    nbytes = v.numel() * 4
+    print(f"[preprocess] GPU {H}x{W}x{Dz} -> (8,32,256,256) fp16: {ms:7.3f} ms  ({nbytes / 1e6:.0f} MB in; "
+          f"{9 * nbytes / ms / 1e9:.2f} TB/s over ~9 passes)", flush=True)
+    t0 = time.time()
+    ref, _ = P.adaptive_resize(vol)
+    t1 = time.time() - t0
+    got = tr.from_dhw(v).float().cpu()
+    print(f"[preprocess] CPU oracle (numpy/torch, {torch.get_num_threads()} threads): {t1:6.2f} s;  max |gpu - oracle| = "
+          f"{(got - ref).abs().max().item():.2e} (fp16 output)", flush=True)
+
 # ------------------------------------------------------------------------------------------- perf
 def sec_perf():
     print("[perf]", flush=True)

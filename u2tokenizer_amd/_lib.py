@@ -70,6 +70,8 @@ SIGNATURES = {
     "u2tok_spp_forward": (_i32, [C.POINTER(SppConfig), C.POINTER(_vp), _vp, _vp, _vp, _sz, _vp]),
     "u2tok_tokenizer_workspace_bytes": (_sz, [C.POINTER(TokConfig)]),
     "u2tok_tokenizer_forward": (_i32, [C.POINTER(TokConfig), C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "u2tok_preprocess_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "u2tok_preprocess_volume": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp, _sz, _vp]),
     "u2tok_embed_splice": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _vp]),
     "u2tok_gemm_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _i32,
                                _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _i32, _vp]),

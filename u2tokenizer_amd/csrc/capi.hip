@@ -115,6 +115,14 @@ int u2tok_tokenizer_forward(const u2tok_tokenizer_config* cfg, const void* const
                            workspace_bytes, false, nullptr, ST(stream));
 }
 
+size_t u2tok_preprocess_workspace_bytes(int32_t D, int32_t H, int32_t W) { return preprocess_workspace_bytes(D, H, W); }
+int u2tok_preprocess_volume(const float* vol, void* out, int32_t* info, int32_t D, int32_t H, int32_t W, int32_t target,
+                            int32_t depth_pad, float lower_pct, float upper_pct, int32_t out_dtype, void* workspace,
+                            size_t workspace_bytes, u2tok_stream_t stream) {
+  return preprocess_volume(vol, out, info, D, H, W, target, depth_pad, lower_pct, upper_pct, out_dtype, workspace,
+                           workspace_bytes, ST(stream));
+}
+
 int u2tok_embed_splice(const void* table, const int64_t* ids, const void* feats, void* out, int32_t B, int32_t S,
                        int32_t E, int32_t nfeat, int64_t vocab, u2tok_stream_t stream) {
   return embed_splice(BF(table), ids, BF(feats), BFW(out), B, S, E, nfeat, vocab, ST(stream));

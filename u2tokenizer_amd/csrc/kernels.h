@@ -1,6 +1,7 @@
 // Internal C++ launcher API of the u2tok HIP library.  Every function enqueues work on `stream`,
 // never allocates, never synchronises, and returns U2_OK or a negative U2_ERR_* code.
 #pragma once
+#include <algorithm>
 #include "common.h"
 
 namespace u2 {
@@ -89,6 +90,14 @@ int rope_apply(bf16_t* x, int64_t n_outer, int S, int n_inner, int H, int d, int
 // feats may be null with nfeat == 0 (plain lookup).
 int embed_splice(const bf16_t* table, const int64_t* ids, const bf16_t* feats, bf16_t* out, int B, int S,
                  int E, int nfeat, int64_t vocab, hipStream_t stream);
+
+// ------------------------------------------------------------------ volume preprocessing (preprocess.hip)
+// u2Transform.adaptive_resize on the GPU: vol [D][H][W] fp32 (the tensor of u2Transform.py:68-69 without its channel
+// axis) -> out [depth_pad][target][target] (== (depth_pad/32, 32, target, target)) in out_dtype (VOL_*).
+// info (optional, device, 12 x int32): status, crop box lo[3], hi[3], resized size[3], then a_min, a_max as float.
+size_t preprocess_workspace_bytes(int D, int H, int W);
+int preprocess_volume(const float* vol, void* out, int32_t* info, int D, int H, int W, int target, int depth_pad,
+                      float lower_pct, float upper_pct, int out_dtype, void* ws, size_t ws_bytes, hipStream_t stream);
 
 // ------------------------------------------------------------------ selection / pooling (select.hip)
 // scores[b][i] = fp32( sum_e x[b][i][e] * w[e] + bias ), accumulated in fp64.
