@@ -36,9 +36,12 @@ typedef void* u2tok_stream_t; /* hipStream_t */
 int u2tok_version(void);               /* MAJOR*10000 + MINOR*100 + PATCH */
 const char* u2tok_arch(void);          /* "gfx950" */
 int u2tok_device_check(void);          /* 0 if the current HIP device is gfx950, else U2TOK_ERR_DEVICE */
-int u2tok_set_option(const char* name, int value); /* "gemm_glds" {0,1}, "gemm_tile" {0,64,128}, "gemm_bk" {32,64},
-                                                      "vit_flash" {0,1}, "profile" {0,1};
-                                                      returns U2TOK_ERR_ARG if unknown */
+int u2tok_set_option(const char* name, int value); /* tuning / diagnostics switches, U2TOK_ERR_ARG if unknown:
+    "gemm_glds" {0 register staging, 1 LDS-DMA burst (default), 2 LDS-DMA between the MFMAs}, "gemm_tile" {0,64,128},
+    "gemm_bk" {32,64}, "gemm_pp" {-1 never, 0 heuristic, 1..7 force a ping-pong variant, 10..17 measurement builds},
+    "gemm_pp_grid" {persistent workgroups}, "flash_mode" {0 pick, 1 128-row units, 2 256-row units, 3 one of each,
+    4 8-wave ping-pong}, "vit_flash" {0 unfused attention, 1}, "tta_overlap" {0,1 side stream for the TTA k|v
+    projections}, "profile" {0,1} */
 /* Diagnostics only: device buffer (>= 256*8*5 uint64) that the s_memtime-instrumented builds of the ping-pong GEMM
  * (u2tok_set_option("gemm_pp", 14..17)) fill with per-wave segment timings; NULL detaches it. */
 int u2tok_debug_buffer(void* device_ptr);
@@ -105,7 +108,8 @@ typedef struct {
   int32_t top_k;           /* u2t_top_k */
   int32_t num_query;       /* num_3d_query_token */
   int32_t use_multi_scale; /* bool */
-  int32_t attn_type;       /* 0 = "rma" (RelativeMultiheadAttention), 1 = "rope" */
+  int32_t attn_type;       /* 0 = "rma" (RelativeMultiheadAttention), 1 = "rope", 2 = nn.MultiheadAttention read
+                              sequence-first (every other attn_type string, svr.py:16-18); 2 needs B == 1 */
   int32_t enable_diffts;   /* bool: DifferentiableTokenSelection vs TokenSelection */
   int32_t enable_dmtp;     /* bool: DynamicMultiScalePooling */
   int32_t max_seq_len;     /* 512: rma.py:6 / rope.py:19 */
