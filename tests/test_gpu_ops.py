@@ -221,7 +221,7 @@ def _sdpa_ref(qkv, nb, S, H):
 
 @pytest.mark.parametrize("nb,S,H,scale", [(1, 64, 1, 1.0), (2, 129, 3, 1.0), (1, 513, 12, 1.0), (1, 2049, 2, 1.0),
                                           (3, 100, 12, 1.0), (1, 300, 2, 3.0), (1, 1, 1, 1.0)])
-@pytest.mark.parametrize("mode", [1, 2, 4])
+@pytest.mark.parametrize("mode", [1, 2, 4, 5])
 def test_flash_attention(ops, nb, S, H, scale, mode):
     """scale 3.0 makes the logits spiky so the online-softmax rescale branch does real work.  mode = rows per
     workgroup unit (128: one 32-row block per wave, 256: two)."""
@@ -237,7 +237,9 @@ def test_flash_attention(ops, nb, S, H, scale, mode):
 @pytest.mark.parametrize("nb,S,H,scale,mode", [(2, 129, 3, 1.0, 1), (1, 513, 12, 1.0, 2), (3, 257, 2, 1.0, 3),
                                                (1, 2049, 3, 1.0, 0), (1, 2049, 3, 1.0, 1), (1, 2049, 3, 1.0, 2),
                                                (1, 2049, 3, 1.0, 4), (2, 321, 3, 3.0, 4), (1, 66, 2, 1.0, 4),
-                                               (3, 101, 12, 3.0, 0), (1, 2, 1, 1.0, 0), (1, 2, 1, 1.0, 4)])
+                                               (3, 101, 12, 3.0, 0), (1, 2, 1, 1.0, 0), (1, 2, 1, 1.0, 4),
+                                               (1, 2049, 3, 1.0, 5), (2, 321, 3, 3.0, 5), (1, 66, 2, 1.0, 5), (1, 2, 1, 1.0, 5),
+                                               (2, 577, 3, 1.0, 5), (1, 34, 1, 3.0, 5), (1, 97, 2, 3.0, 5)])
 def test_flash_attention_extra_row(ops, nb, S, H, scale, mode):
     """The ViT path: S - 1 tiled main rows + one "extra" row per batch (the cls token) as key AND query.  The result
     must equal plain attention over all S rows.  mode 3 (one 256-row + one 128-row unit per workgroup) needs

@@ -20,6 +20,14 @@ __global__ __launch_bounds__(512) void stage_kernel(const unsigned short* __rest
     for (int t = 0; t < ntile; ++t) {
       const int tile = blockIdx.x + t * gridDim.x;
       const int bm0 = (tile % 32) * 256, bn0 = (tile / 32 % 32) * 256;
+      const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7fffffff, 0x00020000);
+      int voff[PW];
+#pragma unroll
+      for (int i = 0; i < PW; ++i) {
+        const int r = (i * NWAVES_ISSUE + wave) * RPP + lane / CPR;
+        voff[i] = ((r < 256 ? (bm0 + r) : (bn0 + r - 256)) * lda + (lane % CPR) * 8) * 2;
+      }
       const unsigned short* src[PW];
 #pragma unroll
       for (int i = 0; i < PW; ++i) {
@@ -34,7 +42,21 @@ __global__ __launch_bounds__(512) void stage_kernel(const unsigned short* __rest
       const int nkt = K / BK;
       for (int kt = 0; kt < nkt; ++kt) {
         char* s = lds + (kt & 1) * STAGE + wave * 1024;
-        if constexpr (MODE == 0) {
+        if constexpr (MODE == 3) {
+          // MUBUF form: one descriptor per matrix, 32-bit per-lane offsets, the K advance in the scalar offset
+#pragma unroll
+          for (int i = 0; i < PW; ++i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            if ((i * NWAVES_ISSUE + wave) * RPP < 256)
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(s + i * NWAVES_ISSUE * 1024), 16,
+                                                       voff[i], kt * BK * 2, 0, 0);
+            else
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(s + i * NWAVES_ISSUE * 1024), 16,
+                                                       voff[i], kt * BK * 2, 0, 0);
+#endif
+          }
+          if (kt >= DEPTH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * DEPTH > 63 ? 63 : PW * DEPTH) : "memory");
+        } else if constexpr (MODE == 0) {
 #pragma unroll
           for (int i = 0; i < PW; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + kt * BK),
@@ -86,6 +108,9 @@ int main() {
   run<0, 64, 2, 8>("glds  BK64 depth2 8 waves", A, B, sink);
   run<0, 64, 1, 8>("glds  BK64 depth1 8 waves", A, B, sink);
   run<0, 64, 2, 4>("glds  BK64 depth2 4 waves", A, B, sink);
+  run<3, 64, 2, 8>("buffer_load..lds BK64 depth2 8 waves", A, B, sink);
+  run<3, 64, 2, 4>("buffer_load..lds BK64 depth2 4 waves", A, B, sink);
+  run<3, 32, 4, 8>("buffer_load..lds BK32 depth4 8 waves", A, B, sink);
   run<0, 64, 2, 8, 1>("glds  BK64 8 waves swz full-xor", A, B, sink);
   run<0, 64, 2, 8, 2>("glds  BK64 8 waves swz 32B-pairs", A, B, sink);
   run<0, 64, 2, 8, 3>("glds  BK64 8 waves swz 64B-halves", A, B, sink);

@@ -857,6 +857,185 @@ __global__ __launch_bounds__(512) void flash_pp_kernel(const FlashArgs a) {
 #undef FPP_BARRIER
 #undef FPP_WAIT_VM
 
+// ----------------------------------------------------------------------------------------------------------------
+// Double-pipeline form (mode 5).  The measurements behind it (profiles/r01_flash_study.log, tools/ubench/
+// valu_rate.hip): at head dim 64 a 32 x 64 score block costs a SIMD 16 MFMAs (512 matrix-pipe cycles) and ~550 cycles
+// of softmax VALU issue (v_exp_f32 7.5, 3-operand VALU ~4, 2-operand ~2 cycles per wave64 instruction); the forms
+// above run them one after the other and rely on a second, unrelated wave of the SIMD to fill the gaps, which it
+// does only by chance (matrix pipe busy 28 %).  Here ONE wave owns two 32-row query blocks and alternates phases
+// over 32-key half tiles in which the MFMAs of one block are interleaved, slot by slot, with the softmax VALU of the
+// other:
+//     B(u):   S0(u+1) = K(u+1) Q0^T ; O0 += V(u) P0(u)      ||   P1(u)   = softmax step on S1(u)
+//     A(u+1): S1(u+1) = K(u+1) Q1^T ; O1 += V(u) P1(u)      ||   P0(u+1) = softmax step on S0(u+1)
+// (an in-order wave keeps issuing independent VALU while its own MFMA occupies the matrix pipe; the second wave of
+// the SIMD runs the same mix).  The row max of the block that just got its scores, and the rare rescale branch,
+// close each phase.  K / V^T tiles (64 keys) arrive by LDS-DMA (buffer_load ... lds) into a ring of 4 slots, 3 tiles
+// ahead, one s_barrier per tile.  4 waves x 64 rows = 256-row units, two workgroups per CU.
+// The whole KV loop is ONE generated asm block (flash_dp_asm.inc, written by tools/gen_flash_dp_asm.py; register map
+// and schedule are documented there): hipcc could not be made to keep the slot order AND the six 16-register
+// accumulators in place at 256 VGPRs -- through asm operands it reordered the slots, rotated the accumulators
+// through extra tuples, copied them around pinned registers, or spilled (~290 VGPRs, one wave per SIMD, slower than
+// mode 2).  With every loop register fixed by hand the kernel runs two waves per SIMD.
+constexpr int FDP_SLOTS = 4;
+
+struct FdpBlock {       // final state of one 32-row query block of a wave
+  f32x16 oacc[2];       // O^T accumulators
+  float m_run, l_run;
+};
+
+// the extra key (one per batch) and the output of one block
+__device__ __forceinline__ void fdp_finish(const FlashArgs& a, FdpBlock& x, const bf16x8 (&qfx)[4], const int b, const int h,
+                                           const int qrow, const int hi) {
+  const float scale_log2e = a.scale_log2e;
+  if (a.n_extra) {
+    const bf16_t* kxp = a.kx + (int64_t)b * a.x_bs + h * 64 + hi * 8;
+    const bf16_t* vxp = a.vx + (int64_t)b * a.x_bs + h * 64 + 4 * hi;
+    float part = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const uint4 kc = *reinterpret_cast<const uint4*>(kxp + ks * 16);
+      union { bf16x8 v; uint32_t u[4]; } qq;
+      qq.v = qfx[ks];
+      const uint32_t kw[4] = {kc.x, kc.y, kc.z, kc.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        part = __builtin_fmaf(bf16lo(qq.u[j]), bf16lo(kw[j]), part);
+        part = __builtin_fmaf(bf16hi(qq.u[j]), bf16hi(kw[j]), part);
+      }
+    }
+    const float mt = (part + __shfl_xor(part, 32, 64)) * scale_log2e;
+    if (__any(mt > x.m_run + FLASH_RESCALE_THR)) {
+      const float m_new = fmaxf(x.m_run, mt);
+      const float alpha = __builtin_amdgcn_exp2f(x.m_run - m_new);
+      x.m_run = m_new;
+      x.l_run *= alpha;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x.oacc[nb][r] *= alpha;
+    }
+    const float p = __builtin_amdgcn_exp2f(mt - x.m_run);
+    x.l_run += 0.5f * p;  // both half-waves hold the same key: the xor-32 sum below counts it once
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const uint2 vc = *reinterpret_cast<const uint2*>(vxp + nb * 32 + 8 * g);
+        x.oacc[nb][4 * g + 0] = __builtin_fmaf(p, bf16lo(vc.x), x.oacc[nb][4 * g + 0]);
+        x.oacc[nb][4 * g + 1] = __builtin_fmaf(p, bf16hi(vc.x), x.oacc[nb][4 * g + 1]);
+        x.oacc[nb][4 * g + 2] = __builtin_fmaf(p, bf16lo(vc.y), x.oacc[nb][4 * g + 2]);
+        x.oacc[nb][4 * g + 3] = __builtin_fmaf(p, bf16hi(vc.y), x.oacc[nb][4 * g + 3]);
+      }
+  }
+  const float l_tot = x.l_run + __shfl_xor(x.l_run, 32, 64);
+  const float inv = 1.f / l_tot;
+  if (qrow < a.S) {
+    bf16_t* op = a.out + (int64_t)b * a.out_bs + (int64_t)qrow * a.ld_out + h * 64;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = nb * 32 + 8 * g + 4 * hi;
+        *reinterpret_cast<uint2*>(op + d0) =
+            uint2{pack2_bf16(x.oacc[nb][4 * g] * inv, x.oacc[nb][4 * g + 1] * inv),
+                  pack2_bf16(x.oacc[nb][4 * g + 2] * inv, x.oacc[nb][4 * g + 3] * inv)};
+      }
+  }
+}
+
+#include "flash_dp_asm.inc"
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+template <bool TIMED>
+__global__ __launch_bounds__(256, 2) void flash_dp_kernel(const FlashArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[FDP_SLOTS][16384];  // [slot][K tile 8 KB | V^T tile 8 KB]
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= a.n_main) {
+    const int e = blockIdx.x - a.n_main;
+    flash_extra_row(a, &lds[0][0], e / a.H, e % a.H, tid);
+    return;
+  }
+  int bid;
+  {
+    const int nwg = a.n_main, qn = nwg >> 3, rn = nwg & 7;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+  }
+  const int nqt = (a.S + 255) >> 8;
+  const int hh = bid / nqt, b = hh / a.H, h = hh % a.H, row0 = (bid % nqt) * 256;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int S = a.S, S_pad = a.S_pad;
+  const int64_t ld_qk = a.ld_qk;
+  const bf16_t* qb_ = a.q + (int64_t)b * a.q_bs + h * 64;
+  const bf16_t* kb_ = a.k + (int64_t)b * a.q_bs + h * 64;
+  const bf16_t* vb_ = a.vt + ((int64_t)b * a.H + h) * 64 * S_pad;
+  const int wrow0 = row0 + wv * 64;
+  const int ntile = (S + 63) >> 6;
+
+  bf16x8 qf[2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const bf16_t* qp = qb_ + (int64_t)min(wrow0 + qb * 32 + l31, S - 1) * ld_qk + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+  }
+  // DMA pieces of this wave (as in flash_dp_kernel): MUBUF descriptors built by hand -- K rows past S read as zero
+  const int prow = wv * 16 + (lane >> 3);
+  const int pch0 = (lane & 7) ^ ((prow >> 1) & 7), pch1 = pch0 ^ 4;
+  const int ko0 = (prow * (int)ld_qk + pch0 * 8) * 2, ko1 = ((prow + 8) * (int)ld_qk + pch1 * 8) * 2;
+  const int vo0 = (prow * S_pad + pch0 * 8) * 2, vo1 = ((prow + 8) * S_pad + pch1 * 8) * 2;
+  const int k_tile_bytes = 64 * (int)ld_qk * 2;
+  const uint64_t kaddr = (uint64_t)(uintptr_t)kb_, vaddr = (uint64_t)(uintptr_t)vb_;
+  i32x4_t rsk, rsv;
+  rsk[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)kaddr);
+  rsk[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(kaddr >> 32));
+  rsk[2] = (int)((((int64_t)S - 1) * ld_qk + 64) * 2);
+  rsk[3] = 0x00020000;
+  rsv[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)vaddr);
+  rsv[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(vaddr >> 32));
+  rsv[2] = 64 * S_pad * 2;
+  rsv[3] = 0x00020000;
+  const uint32_t lds_u32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&lds[0][0];
+  const uint32_t dma_base = lds_u32 + wv * 2048;
+  const uint32_t ab0 = kt_off(l31, hi);
+  const uint32_t dump = lds_u32 + wv * 16384 + lane * 16;
+  const int hi4 = 4 * hi;
+  const float scale_log2e = a.scale_log2e;
+  float mr0, lr0, mr1, lr1;
+  unsigned long long* dbg = g_flash_dbg + ((size_t)blockIdx.x * 4 + wv) * 8;  // TIMED: 5 section times, [7] = tiles
+#define FDP_OPERANDS                                                                                                   \
+               : [mr0] "=&v"(mr0), [lr0] "=&v"(lr0), [mr1] "=&v"(mr1), [lr1] "=&v"(lr1)                                 \
+               : [qf00] "v"(qf[0][0]), [qf01] "v"(qf[0][1]), [qf02] "v"(qf[0][2]), [qf03] "v"(qf[0][3]),                \
+                 [qf10] "v"(qf[1][0]), [qf11] "v"(qf[1][1]), [qf12] "v"(qf[1][2]), [qf13] "v"(qf[1][3]),                \
+                 [ab0] "v"(ab0), [ko0] "v"(ko0), [ko1] "v"(ko1), [vo0] "v"(vo0), [vo1] "v"(vo1), [hi4] "v"(hi4),        \
+                 [dump] "v"(dump), [rsk] "s"(rsk), [rsv] "s"(rsv), [lds] "s"(lds_u32), [dma_base] "s"(dma_base),        \
+                 [ktile] "s"(k_tile_bytes), [seq] "s"(S), [ntile] "s"(ntile), [scale] "s"(scale_log2e), [dbg] "v"(dbg)
+  if constexpr (TIMED) {
+    asm volatile(FLASH_DP_ASM_TEXT_TIMED FDP_OPERANDS : FLASH_DP_ASM_CLOBBERS_TIMED);
+    if (lane == 0) dbg[7] = (unsigned long long)ntile;
+  } else {
+    asm volatile(FLASH_DP_ASM_TEXT FDP_OPERANDS : FLASH_DP_ASM_CLOBBERS);
+  }
+#undef FDP_OPERANDS
+  // the block left O^T in LDS: tuple T = 2 * block + nb, 16-byte quarter j at [wave][T * 4 + j][lane]
+  FdpBlock x0, x1;
+  const char* dp = &lds[0][0] + wv * 16384 + lane * 16;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 u0 = *reinterpret_cast<const float4*>(dp + ((0 + nb) * 4 + j) * 1024);
+      const float4 u1 = *reinterpret_cast<const float4*>(dp + ((2 + nb) * 4 + j) * 1024);
+      x0.oacc[nb][4 * j] = u0.x; x0.oacc[nb][4 * j + 1] = u0.y; x0.oacc[nb][4 * j + 2] = u0.z; x0.oacc[nb][4 * j + 3] = u0.w;
+      x1.oacc[nb][4 * j] = u1.x; x1.oacc[nb][4 * j + 1] = u1.y; x1.oacc[nb][4 * j + 2] = u1.z; x1.oacc[nb][4 * j + 3] = u1.w;
+    }
+  x0.m_run = mr0; x0.l_run = lr0; x1.m_run = mr1; x1.l_run = lr1;
+  fdp_finish(a, x0, qf[0], b, h, wrow0 + l31, hi);
+  fdp_finish(a, x1, qf[1], b, h, wrow0 + 32 + l31, hi);
+}
+
 static int g_flash_mode = 0;  // 0: pick, 1 / 2 / 3: force where legal; + 10 * (workgroups per CU) for mode 1
 static bool g_flash_timed = false;
 void flash_set_mode(int m) { g_flash_mode = m; }
@@ -888,9 +1067,9 @@ int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16
   int mode = g_flash_mode % 10;
   const int wps = g_flash_mode / 10;
   if (mode == 3 && !mixed_ok) mode = 0;
-  if (mode < 1 || mode > 4) mode = mixed_ok ? 3 : 1;
+  if (mode < 1 || mode > 5) mode = S >= 512 ? 5 : (mixed_ok ? 3 : 1);  // measured: mode 5 wins from S = 513 up
   int64_t blocks;
-  if (mode == 4) blocks = nbh * ((S + 255) / 256);
+  if (mode == 4 || mode == 5) blocks = nbh * ((S + 255) / 256);
   else if (mode == 3) blocks = nbh * (S / 128) / 3;
   else if (mode == 2) blocks = nbh * ((S + 255) / 256);
   else blocks = nbh * ((S + 127) / 128);
@@ -905,7 +1084,10 @@ int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16
     if (g_flash_timed) hipLaunchKernelGGL((flash_d64_kernel<M_, W_, true>), dim3((unsigned)grid), dim3(256), 0, stream, a); \
     else hipLaunchKernelGGL((flash_d64_kernel<M_, W_, false>), dim3((unsigned)grid), dim3(256), 0, stream, a);     \
   } while (0)
-  if (mode == 4) {
+  if (mode == 5) {
+    if (g_flash_timed) hipLaunchKernelGGL((flash_dp_kernel<true>), dim3((unsigned)grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((flash_dp_kernel<false>), dim3((unsigned)grid), dim3(256), 0, stream, a);
+  } else if (mode == 4) {
 #define U2_FPP_LAUNCH(P_)                                                                                          \
   do {                                                                                                             \
     if (g_flash_timed) hipLaunchKernelGGL((flash_pp_kernel<true, P_>), dim3((unsigned)grid), dim3(512), 0, stream, a); \

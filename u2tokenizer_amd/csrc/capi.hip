@@ -53,7 +53,7 @@ int u2tok_set_option(const char* name, int value) {
     return U2_OK;
   }
   if (!strcmp(name, "flash_mode")) {
-    if (value < 0 || value > 44 || value % 10 > 4) return U2_ERR_ARG;
+    if (value < 0 || value > 45 || value % 10 > 5) return U2_ERR_ARG;
     flash_set_mode(value);
     return U2_OK;
   }
