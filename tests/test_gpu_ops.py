@@ -275,7 +275,7 @@ def test_flash_attention_forced_rescale(ops):
     close_bf16(got, (p @ x[2]).permute(0, 2, 1, 3).reshape(nb, S, 64))
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 20, 21])
 def test_gemm_pingpong_variants(ops, variant):
     """gemm_pp.hip (persistent 256 x BN ping-pong kernel) forced on shapes with row / column / K tails, several
     tiles per workgroup, every fused epilogue, batches; each product is launched 3 times and must repeat bit for

@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Generates u2tokenizer_amd/csrc/gemm_bt_asm.inc: the K loop of the 256 x 256 x 64 "big tile" bf16 GEMM
+(gemm_pp.hip, gemm_bt_kernel) as ONE inline-asm block for gfx950.
+
+One workgroup = 4 waves (2 x 2), one wave per SIMD, each wave a 128 x 128 output tile = 4 x 4 accumulators of
+v_mfma_f32_32x32x16_bf16 in AccVGPRs (asm operands "+a": the compiler zeroes them before and runs the epilogue after).
+LDS: 2 stages x (A tile 256 rows x 128 B | B tile 256 rows x 128 B) = 128 KB, rows XOR-swizzled as in gemm_pp.hip.
+Per K tile a wave issues 64 MFMAs; every MFMA "slot" carries at most one other instruction:
+
+    kk = 0 : slots 0-7  LDS reads of the kk = 1 fragments      slots 8-15  LDS-DMA of the B half of K tile t+1
+    kk = 1 : slots 0-7  LDS reads of the kk = 2 fragments
+    kk = 2 : slots 0-7  LDS reads of the kk = 3 fragments
+    s_waitcnt vmcnt(0) ; s_barrier          (K tile t+1 landed; everybody has read all of K tile t)
+    kk = 3 : slots 0-7  LDS reads of kk = 0 of K tile t+1       slots 8-15  LDS-DMA of the A half of K tile t+2
+
+so the matrix pipe only drains at the one barrier per K tile, the DMA of a tile has >= 32 slots (~1000 cycles) to
+land, and fragments are read one 16-MFMA block ahead into the other half of a double register buffer.
+DMA: MUBUF buffer_load_dwordx4 ... lds, descriptor per matrix (rows past M / N read as zero), 32-bit lane offsets
+(two per matrix: even / odd 8-row pieces differ in the swizzle), K advance and row-block advance in the scalar offset.
+
+    python tools/gen_gemm_bt_asm.py > u2tokenizer_amd/csrc/gemm_bt_asm.inc
+"""
+import sys
+
+# ---- fixed VGPRs (clobbered) ---------------------------------------------------------------------------------------
+AA = [56, 57, 58, 59]      # LDS read addresses of the A fragments, k16 step kk, current stage
+AB = [60, 61, 62, 63]      # ... of the B fragments
+BUF = 64                   # fragment double buffer: buf b at BUF + 32 b: A_i at + 4 i, B_j at + 16 + 4 j
+VLO, VHI = 56, 127
+# ---- fixed SGPRs (clobbered) ---------------------------------------------------------------------------------------
+S_KT, S_K1, S_K2, S_SA, S_SB, S_TMP, S_ST = 36, 37, 38, 39, 40, 41, 42
+S_ROWA = [43, 44, 45, 46]
+S_ROWB = [47, 48, 49, 50]
+S_DA, S_DB = 51, 52          # LDS byte offsets of this wave's DMA rows in the A / B tile of stage 0
+SLO, SHI = 36, 52
+
+out = []
+
+
+def e(s):
+    out.append(s)
+
+
+def v(n):
+    return f"v{n}"
+
+
+def vr(n, w):
+    return f"v[{n}:{n + w - 1}]"
+
+
+def s(n):
+    return f"s{n}"
+
+
+def afrag(b, i):
+    return vr(BUF + 32 * b + 4 * i, 4)
+
+
+def bfrag(b, j):
+    return vr(BUF + 32 * b + 16 + 4 * j, 4)
+
+
+def acc(i, j):
+    return f"%[c{i >> 1}{i & 1}{j}]"
+
+
+NJ = 4                     # 32-column blocks per wave: tile = 256 x (64 NJ); set per variant by gen()
+
+
+def read(b, kk, n):
+    """n-th fragment read (order A0 B0 .. B(NJ-1) A1 A2 A3) of k16 step kk into buffer b"""
+    order = [("a", 0)] + [("b", j) for j in range(NJ)] + [("a", 1), ("a", 2), ("a", 3)]
+    m, idx = order[n]
+    if m == "a":
+        e(f"ds_read_b128 {afrag(b, idx)}, {v(AA[kk])} offset:{4096 * idx}")
+    else:
+        e(f"ds_read_b128 {bfrag(b, idx)}, {v(AB[kk])} offset:{4096 * idx}")
+
+
+def dma(mat, p, s_stage, s_k):
+    """piece p (8 rows x 128 B) of this wave's 64 rows of the A or B tile; s_stage = LDS base of (matrix, stage)"""
+    if p:
+        e(f"s_add_u32 m0, {s(s_stage)}, {1024 * p}")
+    else:
+        e(f"s_mov_b32 m0, {s(s_stage)}")
+    row = (S_ROWA if mat == "a" else S_ROWB)[p >> 1]
+    e(f"s_add_u32 {s(S_TMP)}, {s(s_k)}, {s(row)}")
+    vo = f"%[v{mat}{p & 1}]"
+    e(f"buffer_load_dwordx4 {vo}, %[rs{mat}], {s(S_TMP)} offen lds")
+
+
+def mfma_block(b, extra):
+    """the 4 NJ MFMAs of one k16 step out of buffer b; extra(slot) emits the slot's companion instruction(s)"""
+    e("s_waitcnt lgkmcnt(0)")
+    for slot in range(4 * NJ):
+        i, j = slot // NJ, slot % NJ
+        e(f"v_mfma_f32_32x32x16_bf16 {acc(i, j)}, {bfrag(b, j)}, {afrag(b, i)}, {acc(i, j)}")
+        extra(slot)
+
+
+def gen(nj):
+    """All four waves run the same MFMA / read / barrier skeleton, but each has its own copy of the loop with its
+    LDS-DMA pieces in different slots: issued in the same slot by all four (lock-step) waves, the pieces queue behind
+    one another in the CU's single address path and every one of them blocks its wave for ~130 cycles with the
+    matrix pipe idle (measured: 8192^3 at 48 % of peak, K-step time proportional to the DMA bytes).  The 4 x 16
+    pieces of K tile t+1 are spread over the 3 x 4 NJ slots between the barrier of iteration t-1 and the end of the
+    kk = 1 block of iteration t (they must land by the barrier of iteration t, 4 NJ slots later)."""
+    global NJ
+    NJ = nj
+    del out[:]
+    nslot, nread, npb = 4 * NJ, 4 + NJ, 2 * NJ  # MFMA slots per k16 step, fragment reads, B pieces per wave
+    npw = 8 + npb                               # DMA pieces per wave and K tile
+    window = 3 * nslot
+    # piece n of wave w -> window slot (blocks: 0 = kk 3 of the previous iteration, 1 = kk 0, 2 = kk 1)
+    sched = {w: {} for w in range(4)}
+    for n in range(npw):
+        for w in range(4):
+            g = (n * 4 + w) * window // (4 * npw)
+            sched[w].setdefault(g, []).append(n)
+
+    def piece(n, s_a, s_b, s_k):
+        if n < 8:
+            dma("a", n, s_a, s_k)
+        else:
+            dma("b", n - 8, s_b, s_k)
+
+    # ---- setup (common)
+    for k in (1, 2, 3):
+        e(f"v_xor_b32 {v(AA[k])}, {32 * k}, %[aa0]")
+        e(f"v_xor_b32 {v(AB[k])}, {32 * k}, %[ab0]")
+    e(f"v_mov_b32 {v(AA[0])}, %[aa0]")
+    e(f"v_mov_b32 {v(AB[0])}, %[ab0]")
+    e(f"s_mov_b32 {s(S_ROWA[0])}, 0")
+    e(f"s_mov_b32 {s(S_ROWB[0])}, 0")
+    for q in (1, 2, 3):
+        e(f"s_add_u32 {s(S_ROWA[q])}, {s(S_ROWA[q - 1])}, %[lda16]")
+        e(f"s_add_u32 {s(S_ROWB[q])}, {s(S_ROWB[q - 1])}, %[ldb16]")
+    e(f"s_mov_b32 {s(S_KT)}, 0")
+    e(f"s_mov_b32 {s(S_K1)}, 0")       # byte offset of a K tile: 128 * tile
+    # K tile 0 -> stage 0, all pieces at once
+    e(f"s_lshl_b32 {s(S_DA)}, %[wave], 13")                       # 64 rows x 128 B per wave
+    e(f"s_mul_i32 {s(S_DB)}, %[wave], {2048 * NJ}")               # 16 NJ rows per wave
+    e(f"s_add_u32 {s(S_DB)}, {s(S_DB)}, 0x8000")
+    e(f"s_mov_b32 {s(S_SA)}, {s(S_DA)}")
+    e(f"s_mov_b32 {s(S_SB)}, {s(S_DB)}")
+    for n in range(npw):
+        piece(n, S_SA, S_SB, S_K1)
+    e(f"s_movk_i32 {s(S_K1)}, 128")    # S_K1: the tile whose pieces the kk 0 / kk 1 blocks issue (kt + 1)
+    e(f"s_movk_i32 {s(S_K2)}, 256")    # S_K2: the tile whose first pieces the kk 3 block issues (kt + 2)
+    e(f"s_mov_b32 {s(S_ST)}, 0")       # LDS offset of the stage being computed on
+    for w in (1, 2, 3):
+        e(f"s_cmp_eq_u32 %[wave], {w}")
+        e(f"s_cbranch_scc1 .Lbt_w{w}_%=")
+    for w in range(4):
+        if w:
+            e(f".Lbt_w{w}_%=:")
+        # the part of K tile 1 that the steady state issues in the kk 3 block of "iteration -1"
+        e(f"s_add_u32 {s(S_SA)}, {s(S_DA)}, 0x10000")
+        e(f"s_add_u32 {s(S_SB)}, {s(S_DB)}, 0x10000")
+        early = [n for g in range(nslot) for n in sched[w].get(g, [])]
+        for n in early:
+            piece(n, S_SA, S_SB, S_K1)
+        e(f"s_waitcnt vmcnt({len(early)})")
+        e("s_barrier")
+        for n in range(nread):
+            read(0, 0, n)
+        # ---- K loop of wave w
+        e(f".Lbt_loop{w}_%=:")
+        # targets: rest of tile kt+1 -> other stage (S_SA / S_SB); first pieces of tile kt+2 -> this stage (S_TMP2s)
+        e(f"s_xor_b32 {s(S_TMP)}, {s(S_ST)}, 0x10000")
+        e(f"s_add_u32 {s(S_SA)}, {s(S_TMP)}, {s(S_DA)}")
+        e(f"s_add_u32 {s(S_SB)}, {s(S_TMP)}, {s(S_DB)}")
+
+        def xk(blk, rb, rkk):
+            def f(slot):
+                if slot < nread:
+                    read(rb, rkk, slot)
+                for n in sched[w].get(blk * nslot + slot, []):
+                    piece(n, S_SA, S_SB, S_K1)
+            return f
+
+        mfma_block(0, xk(1, 1, 1))
+        mfma_block(1, xk(2, 0, 2))
+        mfma_block(0, lambda slot: read(1, 3, slot) if slot < nread else None)
+        e("s_waitcnt vmcnt(0)")
+        e("s_barrier")
+        for k in range(4):                                   # fragment addresses -> the other stage
+            e(f"v_xor_b32 {v(AA[k])}, 0x10000, {v(AA[k])}")
+            e(f"v_xor_b32 {v(AB[k])}, 0x10000, {v(AB[k])}")
+        e(f"s_add_u32 {s(S_SA)}, {s(S_ST)}, {s(S_DA)}")       # the stage everybody just left takes tile kt+2
+        e(f"s_add_u32 {s(S_SB)}, {s(S_ST)}, {s(S_DB)}")
+
+        def x3(slot):
+            if slot < nread:
+                read(0, 0, slot)
+            for n in sched[w].get(slot, []):
+                piece(n, S_SA, S_SB, S_K2)
+
+        mfma_block(1, x3)
+        e(f"s_xor_b32 {s(S_ST)}, {s(S_ST)}, 0x10000")
+        e(f"s_add_u32 {s(S_K1)}, {s(S_K1)}, 128")
+        e(f"s_add_u32 {s(S_K2)}, {s(S_K2)}, 128")
+        e(f"s_add_u32 {s(S_KT)}, {s(S_KT)}, 1")
+        e(f"s_cmp_lt_u32 {s(S_KT)}, %[nkt]")
+        e(f"s_cbranch_scc1 .Lbt_loop{w}_%=")
+        if w < 3:
+            e("s_branch .Lbt_done_%=")
+    e(".Lbt_done_%=:")
+    # the loop runs its staging one / two K tiles past the end (reads of in-bounds garbage or zeros into dead stages)
+    e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    e("s_nop 15")                                        # MFMA results -> compiler's VALU reads: 18 wait states
+    e("s_nop 7")
+
+
+print("// GENERATED by tools/gen_gemm_bt_asm.py -- do not edit")
+print("// clang-format off")
+for nj in (4, 3):
+    gen(nj)
+    print(f"#define GEMM_BT_ASM_TEXT_NJ{nj} \\")
+    for i, line in enumerate(out):
+        print(f'  "{line}\\n"' + (" \\" if i + 1 < len(out) else ""))
+clob = [f'"v{i}"' for i in range(VLO, VHI + 1)] + [f'"s{i}"' for i in range(SLO, SHI + 1)] + ['"scc"', '"memory"']
+print("#define GEMM_BT_ASM_CLOBBERS \\")
+for i in range(0, len(clob), 12):
+    tail = ", \\" if i + 12 < len(clob) else ""
+    print("  " + ", ".join(clob[i:i + 12]) + tail)
+print("// clang-format on")

@@ -318,7 +318,7 @@ def sec_ppc(v=None):
     ops.set_option("gemm_pp", 0)
 
 
-PP_PERF_VARIANTS = (-1, 1, 2, 5, 6, 7)
+PP_PERF_VARIANTS = (-1, 20, 21)
 
 
 def sec_ppperf(shapes_sel=None):

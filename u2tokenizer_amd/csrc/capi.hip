@@ -43,7 +43,7 @@ int u2tok_set_option(const char* name, int value) {
     return U2_OK;
   }
   if (!strcmp(name, "gemm_pp")) {
-    if (value < -1 || value > 17) return U2_ERR_ARG;
+    if (value < -1 || value > 21) return U2_ERR_ARG;
     gemm_pp_set_options(value, -1);
     return U2_OK;
   }

@@ -19,6 +19,8 @@
 //    on the per-lane SOURCE address because the DMA destination is lane-linear).
 //  * XCD-aware, M-grouped tile order so that the 8 private L2s each see a compact band of tiles.
 #include <type_traits>
+#include <cstdio>
+#include <cstdlib>
 #include "kernels.h"
 
 namespace u2 {
@@ -349,6 +351,8 @@ int gemm_bf16(GemmDesc d, hipStream_t stream) {
   if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.nz <= 0 || d.nz > 65535) return U2_ERR_ARG;
   if (!d.A || !d.B || !d.C) return U2_ERR_ARG;
   if (d.nbh <= 0) d.nbh = 1;
+  static const bool trace = getenv("U2TOK_GEMM_TRACE") != nullptr;  // diagnostics: one line per product on stderr
+  if (trace) fprintf(stderr, "gemm M=%d N=%d K=%d nz=%d flags=0x%x lda=%d ldb=%d ldc=%d\n", d.M, d.N, d.K, d.nz, d.flags, (int)d.lda, (int)d.ldb, (int)d.ldc);
   // 16-byte chunked K loads: K, leading dims and batch strides must keep every chunk aligned
   if ((d.K & 7) || (d.lda & 7) || (d.ldb & 7) || (d.sAb & 7) || (d.sAh & 7) || (d.sBb & 7) || (d.sBh & 7))
     return U2_ERR_ARG;

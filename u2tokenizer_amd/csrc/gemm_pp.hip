@@ -680,6 +680,99 @@ static int pp_launch_sb(GemmDesc d, hipStream_t stream) {
   return launch_status();
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// "Big tile" kernel (variant 20): 256 x 256 x 64 tiles, ONE workgroup of 4 waves per CU, each wave a 128 x 128 output
+// tile (4 x 4 MFMA accumulators = 256 AccVGPRs), its K loop one generated asm block (gemm_bt_asm.inc, written by
+// tools/gen_gemm_bt_asm.py, which documents the slot schedule).  What it is after: with one wave per SIMD and a
+// hand-placed instruction stream the matrix pipe only drains at the single barrier per K tile, every LDS-DMA piece
+// and fragment read sits in the shadow of an MFMA, and a 256^2 tile needs half the LDS fill bandwidth per flop of
+// the 128^2 kernel (the measured limit of the CU's L2 -> LDS path, ~50 B/clk, profiles/r01_stage_bw.log).
+// Requirements checked by the launcher: K % 64 == 0, operands addressable with 32-bit byte offsets.
+#include "gemm_bt_asm.inc"
+typedef int bt_i32x4 __attribute__((ext_vector_type(4)));
+
+template <int NJ>  // 32-column blocks per wave: tile = 256 x (64 NJ)
+__global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
+  constexpr int BN = 64 * NJ;
+  using CFG = PPCfg<BN, 64, 2>;
+  __shared__ __attribute__((aligned(1024))) char lds[131072];  // [stage][A tile 32 KB | B tile <= 32 KB]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int tiles_mn = d.tiles_m * d.tiles_n;
+  const int total = tiles_mn * d.nz;
+  int z, bm0, bn0;
+  pp_tile<BN>(d, 0, gridDim.x, blockIdx.x, total, tiles_mn, z, bm0, bn0);
+  const int zb = z / d.nbh, zh = z - zb * d.nbh;
+  const bf16_t* A = d.A + zb * d.sAb + zh * d.sAh;
+  const bf16_t* B = d.B + zb * d.sBb + zh * d.sBh;
+  // MUBUF descriptors: rows past M / N read as zero
+  const uint64_t aaddr = (uint64_t)(uintptr_t)A, baddr = (uint64_t)(uintptr_t)B;
+  bt_i32x4 rsa, rsb;
+  rsa[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)aaddr);
+  rsa[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(aaddr >> 32));
+  rsa[2] = (int)((((int64_t)d.M - 1) * d.lda + d.K) * 2);
+  rsa[3] = 0x00020000;
+  rsb[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)baddr);
+  rsb[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(baddr >> 32));
+  rsb[2] = (int)((((int64_t)d.N - 1) * d.ldb + d.K) * 2);
+  rsb[3] = 0x00020000;
+  // DMA pieces of this wave: rows [64 w, 64 w + 64) of the A tile and [16 NJ w, ..) of the B tile, 8 rows x 128 B per
+  // piece; LDS position p of row r holds global chunk p ^ ((r >> 1) & 7): even / odd pieces differ by 4 in that term
+  const int pr = lane >> 3, sw0 = (lane >> 4) & 3, pc = lane & 7;
+  const int ra = bm0 + wave * 64 + pr, rb = bn0 + wave * (16 * NJ) + pr;
+  const int va0 = (ra * (int)d.lda + ((pc ^ sw0) << 3)) * 2;
+  const int va1 = ((ra + 8) * (int)d.lda + ((pc ^ sw0 ^ 4) << 3)) * 2;
+  const int vb0 = (rb * (int)d.ldb + ((pc ^ sw0) << 3)) * 2;
+  const int vb1 = ((rb + 8) * (int)d.ldb + ((pc ^ sw0 ^ 4) << 3)) * 2;
+  const uint32_t lds_u32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&lds[0];  // 0: the only LDS object
+  const uint32_t abk0 = (uint32_t)(l31 * 128 + ((hi ^ ((l31 >> 1) & 7)) << 4));
+  const uint32_t aa0 = lds_u32 + wm * 16384 + abk0, ab0 = lds_u32 + 32768 + wn * (NJ * 4096) + abk0;
+  const int lda16 = 16 * (int)d.lda * 2, ldb16 = 16 * (int)d.ldb * 2;
+  const int nkt = d.K >> 6;
+  f32x16 acc[2][2][NJ];  // [64-row half of the wave tile][32-row block][32-column block]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NJ; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][mi][ni][r] = 0.f;
+#define BT_ACC3(h_, m_) [c##h_##m_##0] "+a"(acc[h_][m_][0]), [c##h_##m_##1] "+a"(acc[h_][m_][1]), [c##h_##m_##2] "+a"(acc[h_][m_][2])
+#define BT_IN                                                                                                         \
+  [va0] "v"(va0), [va1] "v"(va1), [vb0] "v"(vb0), [vb1] "v"(vb1), [aa0] "v"(aa0), [ab0] "v"(ab0), [rsa] "s"(rsa),     \
+      [rsb] "s"(rsb), [lda16] "s"(lda16), [ldb16] "s"(ldb16), [nkt] "s"(nkt), [wave] "s"(wave)
+  if constexpr (NJ == 4) {
+    asm volatile(GEMM_BT_ASM_TEXT_NJ4
+                 : BT_ACC3(0, 0), [c003] "+a"(acc[0][0][3]), BT_ACC3(0, 1), [c013] "+a"(acc[0][1][3]), BT_ACC3(1, 0),
+                   [c103] "+a"(acc[1][0][3]), BT_ACC3(1, 1), [c113] "+a"(acc[1][1][3])
+                 : BT_IN
+                 : GEMM_BT_ASM_CLOBBERS);
+  } else {
+    asm volatile(GEMM_BT_ASM_TEXT_NJ3 : BT_ACC3(0, 0), BT_ACC3(0, 1), BT_ACC3(1, 0), BT_ACC3(1, 1) : BT_IN : GEMM_BT_ASM_CLOBBERS);
+  }
+#undef BT_ACC3
+#undef BT_IN
+  // pp_epilogue's row base is bm0 + 128 G + 64 wm2: G = 0 with the wave's 128-row offset folded into bm0 (its "tile
+  // inside C" fast-path test then only errs towards the predicated path)
+  pp_epilogue<CFG, 0>(d, acc[0], z, bm0 + wm * 128, bn0, 0, wn, lane);
+  pp_epilogue<CFG, 0>(d, acc[1], z, bm0 + wm * 128, bn0, 1, wn, lane);
+}
+
+template <int NJ>
+static int bt_launch(GemmDesc d, hipStream_t stream) {
+  // 64-wide K tiles only; 32-bit byte offsets into A and B (per z)
+  if ((d.K & 63) || (int64_t)d.M * d.lda >= (1ll << 30) || (int64_t)d.N * d.ldb >= (1ll << 30)) return pp_launch<256, 64, 2, true, 0, 2>(d, stream);
+  d.tiles_m = (int)cdiv(d.M, 256);
+  d.tiles_n = (int)cdiv(d.N, 64 * NJ);
+  const int64_t total = (int64_t)d.tiles_m * d.tiles_n * d.nz;
+  if (total > 0x3fffffff) return U2_ERR_ARG;
+  hipLaunchKernelGGL(gemm_bt_kernel<NJ>, dim3((unsigned)total), dim3(256), 0, stream, d);
+  return launch_status();
+}
+
 // Variant ids (u2tok_set_option("gemm_pp", id) forces one; every id computes the same C unless marked otherwise).
 // The many other (BN, BK, NS, schedule) points that were measured on MI355X are recorded in DESIGN.md section 3.
 static int pp_launch_variant(int v, const GemmDesc& d, hipStream_t stream) {
@@ -691,6 +784,8 @@ static int pp_launch_variant(int v, const GemmDesc& d, hipStream_t stream) {
     case 5: return pp_launch_sb<256>(d, stream);                   // row-block ("SB") DMA schedule
     case 6: return pp_launch_sb<192>(d, stream);
     case 7: return pp_launch_sb<128>(d, stream);
+    case 20: return bt_launch<4>(d, stream);                       // 256x256 big tile, asm K loop, 1 workgroup of 4 waves per CU
+    case 21: return bt_launch<3>(d, stream);                       // 256x192 big tile
     // measurement-only builds (results of 10..13 are wrong by construction; 14..17 are correct but slower)
     case 10: return pp_launch<256, 64, 2, true, 1, 2>(d, stream);  // variant 1 without MFMAs
     case 11: return pp_launch<256, 64, 2, true, 2, 2>(d, stream);  // ... without DMA after the prologue
@@ -704,16 +799,26 @@ static int pp_launch_variant(int v, const GemmDesc& d, hipStream_t stream) {
   }
 }
 
-// Where the ping-pong kernel wins on MI355X (tools/gpu_check.py ppperf, random operands): products that keep all 256
-// workgroups busy for several rounds with a long K loop -- 8192^3: 1.07-1.15 PF/s against 0.89 for gemm.hip's
-// 128x128 tiles.  On the hot path's own shapes (M = 16392 / 2048 / 256 rows at batch 1, K = 768 or 4096) the 128x128
-// kernel with two workgroups per CU is as fast or faster (DESIGN.md section 3 has the table), so the heuristic
-// only takes products of at least 4 full rounds of 256x256 tiles with K >= 2048.
+// Which kernel (tools/gpu_check.py ppperf on MI355X, random operands; DESIGN.md section 3 has the tables):
+//  * the big-tile kernel (variants 20 / 21: 256 x 256 / 256 x 192 tiles, one 4-wave workgroup per CU, asm K loop) runs
+//    its K loop at ~50 % of the MFMA peak (8192^3: 1.23-1.29 PF/s; gemm.hip's 128 x 128 tiles: 0.9) but nothing
+//    overlaps its prologue and epilogue, and a product is as slow as its last round of tiles: it is taken when the
+//    tiles fill their rounds of 256 workgroups to >= 70 %, with the tile width that needs the fewest (work-weighted)
+//    rounds -- the ViT's N = 2304 / 768 projections are exactly 3 / 1 rounds of 192-wide tiles, N = 3072 exactly 3
+//    rounds of 256-wide ones.  Not with the GELU epilogue (256 values per lane of VALU work that the 128 x 128
+//    kernel hides under its second workgroup per CU: 112 us either way for the fc1 product).
+//  * the 8-wave ping-pong kernel (variant 1) is behind both on every shape measured since; it stays selectable.
 static int pp_pick(const GemmDesc& d) {
-  const int64_t tiles = cdiv(d.M, 256) * cdiv(d.N, 256) * d.nz;
-  if (d.K < 2048 || tiles < 4 * (int64_t)g_pp_max_grid) return 0;
-  const double eff = (double)d.M * d.N * d.nz / ((double)cdiv(tiles, g_pp_max_grid) * g_pp_max_grid * 65536.0);
-  return eff >= 0.8 ? 1 : 0;
+  if ((d.K & 63) || d.K < 256 || (d.flags & GEMM_GELU)) return 0;
+  if ((int64_t)d.M * d.lda >= (1ll << 30) || (int64_t)d.N * d.ldb >= (1ll << 30)) return 0;
+  const int64_t tm = cdiv(d.M, 256) * d.nz;
+  const int64_t t4 = tm * cdiv(d.N, 256), t3 = tm * cdiv(d.N, 192);
+  const int64_t r4 = cdiv(t4, g_pp_max_grid), r3 = cdiv(t3, g_pp_max_grid);
+  const double fill4 = (double)d.M * d.N * d.nz / ((double)r4 * g_pp_max_grid * 65536.0);
+  const double fill3 = (double)d.M * d.N * d.nz / ((double)r3 * g_pp_max_grid * 49152.0);
+  const double c4 = (double)r4, c3 = 0.9 * (double)r3;  // a 192-wide tile takes ~0.9 of the time of a 256-wide one
+  if (c3 < c4) return fill3 >= 0.7 ? 21 : (fill4 >= 0.7 ? 20 : 0);
+  return fill4 >= 0.7 ? 20 : (fill3 >= 0.7 ? 21 : 0);
 }
 
 // Returns 1 when the product was launched here, 0 when the caller should use gemm.hip's kernel, < 0 on error.
