@@ -38,10 +38,15 @@ const char* u2tok_arch(void);          /* "gfx950" */
 int u2tok_device_check(void);          /* 0 if the current HIP device is gfx950, else U2TOK_ERR_DEVICE */
 int u2tok_set_option(const char* name, int value); /* tuning / diagnostics switches, U2TOK_ERR_ARG if unknown:
     "gemm_glds" {0 register staging, 1 LDS-DMA burst (default), 2 LDS-DMA between the MFMAs}, "gemm_tile" {0,64,128},
-    "gemm_bk" {32,64}, "gemm_pp" {-1 never, 0 heuristic, 1..7 force a ping-pong variant, 10..17 measurement builds},
-    "gemm_pp_grid" {persistent workgroups}, "flash_mode" {0 pick, 1 128-row units, 2 256-row units, 3 one of each,
-    4 8-wave ping-pong}, "vit_flash" {0 unfused attention, 1}, "tta_overlap" {0,1 side stream for the TTA k|v
-    projections}, "profile" {0,1} */
+    "gemm_bk" {32,64}, "gemm_pp" {-1 never, 0 heuristic, 1..7 force a ping-pong variant, 10..17 measurement builds,
+    20 / 21 force the 256x256 / 256x192 big-tile kernel}, "gemm_splitk" {-1 never, 0 heuristic, 2..16 force that many
+    K slices where scratch allows}, "gemm_pp_grid" {persistent workgroups}, "flash_mode" {0 pick, 1 128-row units,
+    2 256-row units, 3 one of each, 4 8-wave ping-pong, 5 double pipeline (asm KV loop)}, "vit_flash" {0 unfused
+    attention, 1}, "tta_overlap" {0,1 side stream for the TTA k|v projections}, "profile" {0,1} */
+/* Scratch for split-K partial sums of u2tok_gemm_bf16 calls on `stream` (fp32, slices x M x N): skinny products
+ * (few output tiles, long K) are cut along K when a scratch is registered; NULL / 0 removes it.  The module
+ * forwards below carve their own from their workspace and do not need this. */
+int u2tok_set_gemm_scratch(void* device_ptr, size_t bytes, void* stream);
 /* Diagnostics only: device buffer (>= 256*8*5 uint64) that the s_memtime-instrumented builds of the ping-pong GEMM
  * (u2tok_set_option("gemm_pp", 14..17)) fill with per-wave segment timings; NULL detaches it. */
 int u2tok_debug_buffer(void* device_ptr);

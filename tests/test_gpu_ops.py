@@ -275,6 +275,37 @@ def test_flash_attention_forced_rescale(ops):
     close_bf16(got, (p @ x[2]).permute(0, 2, 1, 3).reshape(nb, S, 64))
 
 
+@pytest.mark.parametrize("split", [0, 2, 3, 8])
+def test_gemm_split_k(ops, split):
+    """Skinny products (few output tiles, long K) cut along K into fp32 partial sums + a reduce kernel that applies the
+    epilogue: every epilogue, row / column tails, K slices that do not divide, bit-repeatable (fixed summation order).
+    split = 0 is the heuristic (takes M = 256, N = K = 2048 and leaves the 1000 x 1000 product alone)."""
+    scratch = torch.empty(48 << 20, dtype=torch.uint8, device=D)
+    ops.set_gemm_scratch(scratch)
+    ops.set_option("gemm_splitk", split)
+    try:
+        for (M, N, K) in [(256, 2048, 2048), (77, 520, 1160), (256, 1000, 4096), (1000, 1000, 1024)]:
+            a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
+            ad, bd = a.to(D), b.to(D)
+            outs = [ops.gemm(ad, bd).clone() for _ in range(3)]
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+            close_bf16(outs[0], a.float() @ b.float().t())
+        M, N, K = 200, 264, 2048
+        a, b, bias, res = rnd(M, K, seed=3), rnd(N, K, seed=4), rnd(N, seed=5), rnd(M, N, seed=6)
+        base = a.float() @ b.float().t()
+        ad, bd, biasd, resd = a.to(D), b.to(D), bias.to(D), res.to(D)
+        close_bf16(ops.gemm(ad, bd, bias=biasd), base + bias.float())
+        close_bf16(ops.gemm(ad, bd, bias=biasd, gelu=True), F.gelu(base + bias.float()))
+        close_bf16(ops.gemm(ad, bd, bias=biasd, residual=resd), base + bias.float() + res.float())
+        close_f32(ops.gemm(ad, bd, bias=biasd, out_f32=True, alpha=0.5), 0.5 * base + bias.float())
+        bm = rnd(M, seed=7)
+        close_bf16(ops.gemm(ad, bd, bias=bm.to(D), bias_m=True), base + bm.float()[:, None])
+    finally:
+        ops.set_option("gemm_splitk", 0)
+        ops.set_gemm_scratch(None)
+        torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 20, 21])
 def test_gemm_pingpong_variants(ops, variant):
     """gemm_pp.hip (persistent 256 x BN ping-pong kernel) forced on shapes with row / column / K tails, several

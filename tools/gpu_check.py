@@ -321,6 +321,23 @@ def sec_ppc(v=None):
 PP_PERF_VARIANTS = (-1, 20, 21)
 
 
+def sec_skperf():
+    """split-K on the skinny linear layers of the tokenizer (M = 256 queries)"""
+    scratch = torch.empty(48 << 20, dtype=torch.uint8, device=dev)
+    ops.set_gemm_scratch(scratch)
+    for (M, N, K) in [(256, 4096, 4096), (256, 12288, 4096), (1024, 4096, 4096), (2048, 4096, 4096), (256, 2048, 4096)]:
+        a, b, bias = rnd(M, K, seed=1).to(dev), rnd(N, K, seed=2).to(dev), rnd(N, seed=3).to(dev)
+        out = torch.empty((1, M, N), dtype=bf, device=dev)
+        line = f"  {M:5d}x{N:5d}x{K:4d} bias"
+        for sk in (-1, 0, 2, 4, 8):
+            ops.set_option("gemm_splitk", sk)
+            ms = timeit(lambda: ops.gemm(a, b, bias=bias, out=out), iters=10, warm=2)
+            line += f" | split {sk:2d}: {ms * 1e3:6.1f} us {2 * M * N * K / ms / 1e9:5.0f} TF"
+        print(line, flush=True)
+    ops.set_option("gemm_splitk", 0)
+    ops.set_gemm_scratch(None)
+
+
 def sec_ppperf(shapes_sel=None):
     print("[pp perf] (random normal operands; us and TF/s; c = classic 128^2/64^2 kernel, a = heuristic)", flush=True)
     shapes = [(16384, 2304, 768, {}), (16392, 2304, 768, {}), (16384, 768, 768, dict(bias=True, residual=True)),

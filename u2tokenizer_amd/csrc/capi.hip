@@ -42,6 +42,11 @@ int u2tok_set_option(const char* name, int value) {
     gemm_set_options(-1, -1, value);
     return U2_OK;
   }
+  if (!strcmp(name, "gemm_splitk")) {
+    if (value < -1 || value > 16) return U2_ERR_ARG;
+    gemm_set_splitk(value);
+    return U2_OK;
+  }
   if (!strcmp(name, "gemm_pp")) {
     if (value < -1 || value > 21) return U2_ERR_ARG;
     gemm_pp_set_options(value, -1);
@@ -64,6 +69,10 @@ int u2tok_set_option(const char* name, int value) {
 }
 
 int u2tok_debug_buffer(void* device_ptr) { return gemm_pp_set_debug_buffer(device_ptr); }
+int u2tok_set_gemm_scratch(void* device_ptr, size_t bytes, void* stream) {
+  gemm_set_scratch(reinterpret_cast<hipStream_t>(stream), device_ptr, device_ptr ? bytes : 0);
+  return U2_OK;
+}
 int u2tok_flash_debug_buffer(void* device_ptr) { return flash_set_debug_buffer(device_ptr); }
 
 int u2tok_profile_collect(double* ms, double* flops, int64_t* count, int32_t ncat) {

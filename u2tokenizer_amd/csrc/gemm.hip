@@ -20,6 +20,9 @@
 //  * XCD-aware, M-grouped tile order so that the 8 private L2s each see a compact band of tiles.
 #include <type_traits>
 #include <cstdio>
+#include <mutex>
+#include <vector>
+#include <algorithm>
 #include <cstdlib>
 #include "kernels.h"
 
@@ -108,7 +111,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
 #pragma unroll
   for (int kk = 0; kk < KSTEPS; ++kk) foff[kk] = (((kk * 4 + (lane >> 4)) ^ lds_swz<BK>(lane & 15)) << 4);
 
-  const int nkt = (d.K + BK - 1) / BK;
+  const int nkt_all = (d.K + BK - 1) / BK;
+  const int kt0 = (d.ksplit > 1) ? (int)blockIdx.z * d.kt_per : 0;   // split-K: this slice's K tiles
+  const int nkt = (d.ksplit > 1) ? min(nkt_all, kt0 + d.kt_per) : nkt_all;
   uint4 ra[CA], rb[CB];
 
   auto gload = [&](int kt) {
@@ -213,29 +218,29 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
   };
 
   if constexpr (GLDS == 2) {
-    dma(0, 0);
+    dma(kt0, kt0 & 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = kt0; kt < nkt; ++kt) {
       compute_dma(kt & 1, kt + 1, kt + 1 < nkt);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
   } else if constexpr (GLDS == 1) {
-    dma(0, 0);
+    dma(kt0, kt0 & 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = kt0; kt < nkt; ++kt) {
       if (kt + 1 < nkt) dma(kt + 1, (kt + 1) & 1);
       compute(kt & 1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
   } else {
-    gload(0);
-    lstore(0);
+    gload(kt0);
+    lstore(kt0 & 1);
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = kt0; kt < nkt; ++kt) {
       if (kt + 1 < nkt) gload(kt + 1);
       compute(kt & 1);
       if (kt + 1 < nkt) lstore((kt + 1) & 1);
@@ -244,6 +249,28 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
   }
 
   // ---- epilogue: lane holds C[m][n0..n0+3], m = tile row (lane & 15), n0 = 4 * (lane >> 4) ----
+  if (d.ksplit > 1) {  // split-K slice: raw fp32 sums, the reduce kernel does the rest
+    float* P = d.partial + ((int64_t)blockIdx.z * d.nz + z) * (int64_t)d.M * d.N;
+    const int m_b = bm0 + wm * WM + (lane & 15), n_b = bn0 + wn * WN + (lane >> 4) * 4;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = m_b + mi * 16;
+      if (m >= d.M) continue;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int n0 = n_b + ni * 16;
+        float* pp = P + (int64_t)m * d.N + n0;
+        if (n0 + 3 < d.N && (d.N & 3) == 0) {
+          *reinterpret_cast<float4*>(pp) = float4{acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n0 + r < d.N) pp[r] = acc[mi][ni][r];
+        }
+      }
+    }
+    return;
+  }
   const bool out_f32 = d.flags & GEMM_OUT_F32;
   char* Cz = reinterpret_cast<char*>(d.C) + (zb * d.sCb + zh * d.sCh) * (out_f32 ? 4 : 2);
   const bf16_t* Rz = (d.flags & GEMM_RESIDUAL) ? d.R + zb * d.sRb + zh * d.sRh : nullptr;
@@ -322,6 +349,67 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
   }
 }
 
+// out[z][m][n] = epilogue(alpha * sum_s partial[s][z][m][n]); one thread per 4 consecutive n
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmDesc d) {
+  const int64_t n4 = (d.N + 3) >> 2;
+  const int64_t total = (int64_t)d.nz * d.M * n4;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int n0 = (int)(idx % n4) * 4;
+  const int64_t zm = idx / n4;
+  const int m = (int)(zm % d.M), z = (int)(zm / d.M);
+  const int64_t slice = (int64_t)d.nz * d.M * d.N;
+  const float* P = d.partial + ((int64_t)z * d.M + m) * d.N + n0;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool full = (n0 + 3 < d.N) && (d.N & 3) == 0;
+  for (int s = 0; s < d.ksplit; ++s) {
+    if (full) {
+      const float4 t = *reinterpret_cast<const float4*>(P + s * slice);
+      v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+    } else {
+      for (int r = 0; r < 4; ++r)
+        if (n0 + r < d.N) v[r] += P[s * slice + r];
+    }
+  }
+  const int zb = z / d.nbh, zh = z - zb * d.nbh;
+  const bool out_f32 = d.flags & GEMM_OUT_F32;
+  const float bm_v = (d.flags & GEMM_BIAS_M) ? bf16_to_f32(d.bias[m]) : 0.f;
+  const bf16_t* Rz = (d.flags & GEMM_RESIDUAL) ? d.R + zb * d.sRb + zh * d.sRh + (int64_t)m * d.ldr : nullptr;
+  char* Cz = reinterpret_cast<char*>(d.C) + (zb * d.sCb + zh * d.sCh + (int64_t)m * d.ldc) * (out_f32 ? 4 : 2);
+  for (int r = 0; r < 4; ++r) {
+    const int n = n0 + r;
+    if (n >= d.N) break;
+    float x = v[r] * d.alpha + bm_v;
+    if (d.flags & GEMM_BIAS_N) x += bf16_to_f32(d.bias[n]);
+    if (d.flags & GEMM_GELU) x = gelu_erf(x);
+    if (Rz) x += bf16_to_f32(Rz[n]);
+    if (out_f32) reinterpret_cast<float*>(Cz)[n] = x;
+    else reinterpret_cast<bf16_t*>(Cz)[n] = f32_to_bf16(x);
+  }
+}
+
+static int g_gemm_splitk = 0;    // -1 never, 0 heuristic, s > 1 force
+void gemm_set_splitk(int mode) { g_gemm_splitk = mode; }
+
+// split-K scratch per stream (a handful of streams at most: linear search under a mutex)
+namespace {
+struct Scratch { hipStream_t st; void* p; size_t bytes; };
+std::mutex g_scratch_mu;
+std::vector<Scratch> g_scratch;
+}  // namespace
+void gemm_set_scratch(hipStream_t stream, void* p, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  for (auto& s : g_scratch)
+    if (s.st == stream) { s.p = p; s.bytes = bytes; return; }
+  g_scratch.push_back({stream, p, bytes});
+}
+static Scratch scratch_of(hipStream_t stream) {
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  for (auto& s : g_scratch)
+    if (s.st == stream) return s;
+  return {stream, nullptr, 0};
+}
+
 static int g_gemm_glds = 1;      // 0: register staging, 1: LDS-DMA burst, 2: LDS-DMA pieces between the MFMAs
 static int g_gemm_force_tile = 0;  // 0: heuristic, 64 / 128: force
 static int g_gemm_bk = 64;       // K depth of one LDS stage: 64 (2 blocks/CU at 128^2) or 32 (4 blocks/CU)
@@ -336,7 +424,7 @@ template <int BM, int BN, int BK>
 static int launch_tile(GemmDesc d, hipStream_t stream) {
   d.tiles_m = (int)cdiv(d.M, BM);
   d.tiles_n = (int)cdiv(d.N, BN);
-  dim3 grid(d.tiles_m * d.tiles_n, d.nz, 1);
+  dim3 grid(d.tiles_m * d.tiles_n, d.nz, d.ksplit > 1 ? d.ksplit : 1);
   constexpr int smem = 2 * (BM + BN) * BK * 2;
   if (g_gemm_glds == 2)
     hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, BK, 2>), grid, dim3(256), smem, stream, d);
@@ -383,8 +471,36 @@ int gemm_classic(GemmDesc d, hipStream_t stream) {
     const int64_t big = cdiv(d.M, 128) * cdiv(d.N, 128) * d.nz;
     tile = (big >= 192) ? 128 : 64;  // fill 256 CUs; small-M weight-streaming shapes get 64^2 tiles
   }
-  if (g_gemm_bk == 32) return tile == 128 ? launch_tile<128, 128, 32>(d, stream) : launch_tile<64, 64, 32>(d, stream);
-  return tile == 128 ? launch_tile<128, 128, 64>(d, stream) : launch_tile<64, 64, 64>(d, stream);
+  // split-K: a product with fewer workgroups than ~2 per CU runs one single-stage-prefetch K loop per CU and is
+  // latency-bound (M = 256, N = K = 4096: 36 us, 0.24 PF/s).  Slicing K puts several workgroups on every CU.
+  d.ksplit = 1;
+  if (g_gemm_splitk >= 0 && g_gemm_bk != 32) {
+    const int64_t wgs = cdiv(d.M, tile) * cdiv(d.N, tile) * d.nz;
+    const int nkt = (int)cdiv(d.K, 64);
+    int s = g_gemm_splitk > 1 ? g_gemm_splitk : 0;
+    if (s == 0 && d.nz == 1 && wgs <= 320 && nkt >= 16)
+      s = (int)std::min<int64_t>(8, std::min<int64_t>(nkt / 4, cdiv(1024, wgs)));
+    if (s > 1) {
+      const Scratch sc = scratch_of(stream);
+      const size_t slice = (size_t)d.nz * d.M * d.N * sizeof(float);
+      if (g_gemm_splitk <= 1) s = (int)std::min<size_t>(s, std::min<size_t>(sc.bytes, 24u << 20) / slice);  // partial sums cost HBM traffic
+      const size_t need = (size_t)s * slice;
+      if (s > 1 && sc.p && need <= sc.bytes && d.nz <= 65535) {
+        d.ksplit = s;
+        d.kt_per = (int)cdiv(nkt, s);
+        d.ksplit = (int)cdiv(nkt, d.kt_per);  // no empty slices
+        d.partial = reinterpret_cast<float*>(sc.p);
+      }
+    }
+    if (d.ksplit <= 1) d.ksplit = 1;
+  }
+  int e;
+  if (g_gemm_bk == 32) e = tile == 128 ? launch_tile<128, 128, 32>(d, stream) : launch_tile<64, 64, 32>(d, stream);
+  else e = tile == 128 ? launch_tile<128, 128, 64>(d, stream) : launch_tile<64, 64, 64>(d, stream);
+  if (e != U2_OK || d.ksplit == 1) return e;
+  const int64_t total = (int64_t)d.nz * d.M * ((d.N + 3) >> 2);
+  hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, d);
+  return launch_status();
 }
 
 }  // namespace u2

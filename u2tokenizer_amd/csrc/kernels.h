@@ -43,10 +43,18 @@ struct GemmDesc {
   float alpha = 1.f;
   int flags = 0;
   int tiles_m = 0, tiles_n = 0;  // filled by the launcher
+  // split-K (filled by the launcher): K tiles [s * kt_per, (s + 1) * kt_per) go to grid.z slice s, which leaves raw
+  // fp32 sums in partial[s][z][m][n] (dense, ld = N); gemm_splitk_reduce_kernel applies the epilogue
+  int ksplit = 1, kt_per = 0;
+  float* partial = nullptr;
 };
 
 int gemm_bf16(GemmDesc d, hipStream_t stream);
 void gemm_set_options(int glds, int force_tile, int bk);
+// Scratch for split-K partial sums, one registration per stream (the forwards in pipeline.hip carve it from their
+// workspace; u2tok_set_gemm_scratch for direct callers).  Without one, products run unsplit.
+void gemm_set_scratch(hipStream_t stream, void* p, size_t bytes);
+void gemm_set_splitk(int mode);  // -1 never, 0 heuristic, s > 1 force s slices where legal
 // internal: the two kernels behind gemm_bf16 (descriptor already validated there)
 int gemm_classic(GemmDesc d, hipStream_t stream);       // gemm.hip: 128^2 / 64^2 tiles, 2 workgroups per CU
 int gemm_pp_try(const GemmDesc& d, hipStream_t stream);  // gemm_pp.hip: 1 launched, 0 not applicable, < 0 error

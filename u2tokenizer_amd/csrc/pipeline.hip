@@ -326,6 +326,17 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
   const int i_sel = 1 + 18 * L, i_gate = i_sel + 2, i_tta = i_gate + 2, i_lin = i_tta + 33 * L;
 
   Arena ar(ws, ws_bytes, dry);
+  // split-K scratch for the skinny linear layers of this forward (M = 256 queries against E x E weights); registered
+  // for this stream only while the launches below are being enqueued
+  constexpr size_t kSplitK = 24u << 20;
+  char* skw = ar.get<char>(kSplitK);
+  U2_CHECK_WS(ar);
+  struct ScratchGuard {
+    hipStream_t st;
+    bool on;
+    ~ScratchGuard() { if (on) gemm_set_scratch(st, nullptr, 0); }
+  } scratch_guard{st, !dry};
+  if (!dry) gemm_set_scratch(st, skw, kSplitK);
   const int64_t rows = (int64_t)B * TN;
   bf16_t* xa = ar.get<bf16_t>((size_t)rows * E);
   bf16_t* xb = ar.get<bf16_t>((size_t)rows * E);

@@ -70,6 +70,14 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, bias_m=F
     return out.reshape(*a.shape[:-1], N) if b.dim() == 2 else out
 
 
+def set_gemm_scratch(buf: Optional[torch.Tensor]) -> None:
+    """Registers `buf` (any dtype, on the GPU) as split-K scratch for gemm() calls on the current stream; None removes
+    it.  The caller keeps the tensor alive while products may be in flight."""
+    h = _lib.load_library()
+    st = h.u2tok_set_gemm_scratch(_ptr(buf), 0 if buf is None else buf.numel() * buf.element_size(), _stream())
+    _lib.check(st, "u2tok_set_gemm_scratch")
+
+
 def layernorm(x, w, b, residual=None, eps=1e-5):
     h = _lib.load_library()
     x = _need(x, torch.bfloat16, "x").contiguous()
