@@ -28,16 +28,28 @@ AB = [60, 61, 62, 63]      # ... of the B fragments
 BUF = 64                   # fragment double buffer: buf b at BUF + 32 b: A_i at + 4 i, B_j at + 16 + 4 j
 VLO, VHI = 56, 127
 # ---- fixed SGPRs (clobbered) ---------------------------------------------------------------------------------------
-S_KT, S_K1, S_K2, S_SA, S_SB, S_TMP, S_ST = 36, 37, 38, 39, 40, 41, 42
+S_KT, S_K1A, S_K2A, S_SA, S_SB, S_TMP, S_ST = 36, 37, 38, 39, 40, 41, 42
 S_ROWA = [43, 44, 45, 46]
 S_ROWB = [47, 48, 49, 50]
 S_DA, S_DB = 51, 52          # LDS byte offsets of this wave's DMA rows in the A / B tile of stage 0
-SLO, SHI = 36, 52
+S_K1B, S_K2B, S_K0A, S_K0B = 53, 54, 55, 56   # scalar byte offsets of K tiles kt+1 / kt+2 (and 0) per matrix
+SLO, SHI = 36, 56
 
 out = []
+ABL = set()   # measurement-only builds (wrong results): "nodma" / "noread" / "nobar" / "nomfma" inside the K loop
+IN_LOOP = [False]
 
 
 def e(s):
+    if IN_LOOP[0]:
+        if "nodma" in ABL and s.startswith("buffer_load"):
+            return
+        if "noread" in ABL and s.startswith("ds_read"):
+            return
+        if "nobar" in ABL and s.startswith("s_barrier"):
+            return
+        if "nomfma" in ABL and s.startswith("v_mfma"):
+            return
     out.append(s)
 
 
@@ -79,7 +91,9 @@ def read(b, kk, n):
 
 
 def dma(mat, p, s_stage, s_k):
-    """piece p (8 rows x 128 B) of this wave's 64 rows of the A or B tile; s_stage = LDS base of (matrix, stage)"""
+    """piece p (8 rows x 128 B) of this wave's 64 rows of the A or B tile; s_stage = LDS base of (matrix, stage);
+    s_k = (A offset register, B offset register) of the K tile"""
+    s_k = s_k[0] if mat == "a" else s_k[1]
     if p:
         e(f"s_add_u32 m0, {s(s_stage)}, {1024 * p}")
     else:
@@ -125,6 +139,7 @@ def gen(nj):
         else:
             dma("b", n - 8, s_b, s_k)
 
+    K0, K1, K2 = (S_K0A, S_K0B), (S_K1A, S_K1B), (S_K2A, S_K2B)
     # ---- setup (common)
     for k in (1, 2, 3):
         e(f"v_xor_b32 {v(AA[k])}, {32 * k}, %[aa0]")
@@ -137,37 +152,51 @@ def gen(nj):
         e(f"s_add_u32 {s(S_ROWA[q])}, {s(S_ROWA[q - 1])}, %[lda16]")
         e(f"s_add_u32 {s(S_ROWB[q])}, {s(S_ROWB[q - 1])}, %[ldb16]")
     e(f"s_mov_b32 {s(S_KT)}, 0")
-    e(f"s_mov_b32 {s(S_K1)}, 0")       # byte offset of a K tile: 128 * tile
-    # K tile 0 -> stage 0, all pieces at once
     e(f"s_lshl_b32 {s(S_DA)}, %[wave], 13")                       # 64 rows x 128 B per wave
     e(f"s_mul_i32 {s(S_DB)}, %[wave], {2048 * NJ}")               # 16 NJ rows per wave
     e(f"s_add_u32 {s(S_DB)}, {s(S_DB)}, 0x8000")
-    e(f"s_mov_b32 {s(S_SA)}, {s(S_DA)}")
-    e(f"s_mov_b32 {s(S_SB)}, {s(S_DB)}")
-    for n in range(npw):
-        piece(n, S_SA, S_SB, S_K1)
-    e(f"s_movk_i32 {s(S_K1)}, 128")    # S_K1: the tile whose pieces the kk 0 / kk 1 blocks issue (kt + 1)
-    e(f"s_movk_i32 {s(S_K2)}, 256")    # S_K2: the tile whose first pieces the kk 3 block issues (kt + 2)
-    e(f"s_mov_b32 {s(S_ST)}, 0")       # LDS offset of the stage being computed on
+    e(f"s_mov_b32 {s(S_ST)}, %[st0]")                             # LDS offset of the stage being computed on
+    # scalar offsets of K tiles 0 / 1 / 2: the K loop runs on into the NEXT output tile of this workgroup
+    # (K tile nkt of this tile = K tile 0 of the next one, whose origin is nbase), nkt >= 2
+    e(f"s_mov_b32 {s(S_K0A)}, %[base_a]")
+    e(f"s_mov_b32 {s(S_K0B)}, %[base_b]")
+    e(f"s_add_u32 {s(S_K1A)}, %[base_a], 128")
+    e(f"s_add_u32 {s(S_K1B)}, %[base_b], 128")
+    e(f"s_add_u32 {s(S_K2A)}, %[base_a], 256")
+    e(f"s_add_u32 {s(S_K2B)}, %[base_b], 256")
+    e("s_cmp_eq_u32 %[nkt], 2")
+    e(f"s_cselect_b32 {s(S_K2A)}, %[nbase_a], {s(S_K2A)}")
+    e(f"s_cselect_b32 {s(S_K2B)}, %[nbase_b], {s(S_K2B)}")
     for w in (1, 2, 3):
         e(f"s_cmp_eq_u32 %[wave], {w}")
         e(f"s_cbranch_scc1 .Lbt_w{w}_%=")
     for w in range(4):
         if w:
             e(f".Lbt_w{w}_%=:")
-        # the part of K tile 1 that the steady state issues in the kk 3 block of "iteration -1"
-        e(f"s_add_u32 {s(S_SA)}, {s(S_DA)}, 0x10000")
-        e(f"s_add_u32 {s(S_SB)}, {s(S_DB)}, 0x10000")
         early = [n for g in range(nslot) for n in sched[w].get(g, [])]
+        # first tile of the workgroup: K tile 0 -> this stage at once, and the part of K tile 1 that the steady state
+        # issues in the kk 3 block of "iteration -1".  Later tiles: the previous tile's K loop already did both, and
+        # its last barrier made K tile 0 visible.
+        e("s_cmp_eq_u32 %[first], 0")
+        e(f"s_cbranch_scc1 .Lbt_cont{w}_%=")
+        e(f"s_add_u32 {s(S_SA)}, {s(S_DA)}, {s(S_ST)}")
+        e(f"s_add_u32 {s(S_SB)}, {s(S_DB)}, {s(S_ST)}")
+        for n in range(npw):
+            piece(n, S_SA, S_SB, K0)
+        e(f"s_xor_b32 {s(S_TMP)}, {s(S_ST)}, 0x10000")
+        e(f"s_add_u32 {s(S_SA)}, {s(S_DA)}, {s(S_TMP)}")
+        e(f"s_add_u32 {s(S_SB)}, {s(S_DB)}, {s(S_TMP)}")
         for n in early:
-            piece(n, S_SA, S_SB, S_K1)
+            piece(n, S_SA, S_SB, K1)
         e(f"s_waitcnt vmcnt({len(early)})")
         e("s_barrier")
+        e(f".Lbt_cont{w}_%=:")
         for n in range(nread):
             read(0, 0, n)
         # ---- K loop of wave w
         e(f".Lbt_loop{w}_%=:")
-        # targets: rest of tile kt+1 -> other stage (S_SA / S_SB); first pieces of tile kt+2 -> this stage (S_TMP2s)
+        IN_LOOP[0] = True
+        # targets: rest of tile kt+1 -> other stage (S_SA / S_SB); first pieces of tile kt+2 -> this stage
         e(f"s_xor_b32 {s(S_TMP)}, {s(S_ST)}, 0x10000")
         e(f"s_add_u32 {s(S_SA)}, {s(S_TMP)}, {s(S_DA)}")
         e(f"s_add_u32 {s(S_SB)}, {s(S_TMP)}, {s(S_DB)}")
@@ -177,7 +206,7 @@ def gen(nj):
                 if slot < nread:
                     read(rb, rkk, slot)
                 for n in sched[w].get(blk * nslot + slot, []):
-                    piece(n, S_SA, S_SB, S_K1)
+                    piece(n, S_SA, S_SB, K1)
             return f
 
         mfma_block(0, xk(1, 1, 1))
@@ -195,29 +224,42 @@ def gen(nj):
             if slot < nread:
                 read(0, 0, slot)
             for n in sched[w].get(slot, []):
-                piece(n, S_SA, S_SB, S_K2)
+                piece(n, S_SA, S_SB, K2)
 
         mfma_block(1, x3)
         e(f"s_xor_b32 {s(S_ST)}, {s(S_ST)}, 0x10000")
-        e(f"s_add_u32 {s(S_K1)}, {s(S_K1)}, 128")
-        e(f"s_add_u32 {s(S_K2)}, {s(S_K2)}, 128")
         e(f"s_add_u32 {s(S_KT)}, {s(S_KT)}, 1")
+        # K tile offsets of the next iteration: kt+1 <- kt+2;  kt+2 <- next one, which is K tile 0 of the next output
+        # tile when it reaches nkt
+        e(f"s_mov_b32 {s(S_K1A)}, {s(S_K2A)}")
+        e(f"s_mov_b32 {s(S_K1B)}, {s(S_K2B)}")
+        e(f"s_add_u32 {s(S_K2A)}, {s(S_K2A)}, 128")
+        e(f"s_add_u32 {s(S_K2B)}, {s(S_K2B)}, 128")
+        e(f"s_add_u32 {s(S_TMP)}, {s(S_KT)}, 2")
+        e(f"s_cmp_eq_u32 {s(S_TMP)}, %[nkt]")
+        e(f"s_cselect_b32 {s(S_K2A)}, %[nbase_a], {s(S_K2A)}")
+        e(f"s_cselect_b32 {s(S_K2B)}, %[nbase_b], {s(S_K2B)}")
         e(f"s_cmp_lt_u32 {s(S_KT)}, %[nkt]")
         e(f"s_cbranch_scc1 .Lbt_loop{w}_%=")
+        IN_LOOP[0] = False
         if w < 3:
             e("s_branch .Lbt_done_%=")
     e(".Lbt_done_%=:")
-    # the loop runs its staging one / two K tiles past the end (reads of in-bounds garbage or zeros into dead stages)
-    e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    # the loop has staged K tile 0 of the NEXT output tile (landed, visible) and issued the first pieces of its K tile
+    # 1, which stay in flight across the epilogue; its last reads fetched fragments nobody uses
+    e("s_waitcnt lgkmcnt(0)")
     e("s_nop 15")                                        # MFMA results -> compiler's VALU reads: 18 wait states
     e("s_nop 7")
 
 
 print("// GENERATED by tools/gen_gemm_bt_asm.py -- do not edit")
 print("// clang-format off")
-for nj in (4, 3):
+for nj, abl in ((4, ""), (3, "")):
+    ABL.clear()
+    if abl:
+        ABL.add(abl)
     gen(nj)
-    print(f"#define GEMM_BT_ASM_TEXT_NJ{nj} \\")
+    print(f"#define GEMM_BT_ASM_TEXT_NJ{nj}{('_' + abl.upper()) if abl else ''} \\")
     for i, line in enumerate(out):
         print(f'  "{line}\\n"' + (" \\" if i + 1 < len(out) else ""))
 clob = [f'"v{i}"' for i in range(VLO, VHI + 1)] + [f'"s{i}"' for i in range(SLO, SHI + 1)] + ['"scc"', '"memory"']

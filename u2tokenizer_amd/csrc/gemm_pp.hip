@@ -702,74 +702,97 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
   const int hi = lane >> 5, l31 = lane & 31;
   const int tiles_mn = d.tiles_m * d.tiles_n;
   const int total = tiles_mn * d.nz;
-  int z, bm0, bn0;
-  pp_tile<BN>(d, 0, gridDim.x, blockIdx.x, total, tiles_mn, z, bm0, bn0);
-  const int zb = z / d.nbh, zh = z - zb * d.nbh;
-  const bf16_t* A = d.A + zb * d.sAb + zh * d.sAh;
-  const bf16_t* B = d.B + zb * d.sBb + zh * d.sBh;
-  // MUBUF descriptors: rows past M / N read as zero
-  const uint64_t aaddr = (uint64_t)(uintptr_t)A, baddr = (uint64_t)(uintptr_t)B;
-  bt_i32x4 rsa, rsb;
-  rsa[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)aaddr);
-  rsa[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(aaddr >> 32));
-  rsa[2] = (int)((((int64_t)d.M - 1) * d.lda + d.K) * 2);
-  rsa[3] = 0x00020000;
-  rsb[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)baddr);
-  rsb[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(baddr >> 32));
-  rsb[2] = (int)((((int64_t)d.N - 1) * d.ldb + d.K) * 2);
-  rsb[3] = 0x00020000;
+  const int gd = gridDim.x, bid = blockIdx.x;
+  const int my_tiles = (total - bid + gd - 1) / gd;  // >= 1: grid <= total
   // DMA pieces of this wave: rows [64 w, 64 w + 64) of the A tile and [16 NJ w, ..) of the B tile, 8 rows x 128 B per
-  // piece; LDS position p of row r holds global chunk p ^ ((r >> 1) & 7): even / odd pieces differ by 4 in that term
+  // piece; LDS position p of row r holds global chunk p ^ ((r >> 1) & 7): even / odd pieces differ by 4 in that term.
+  // Lane offsets are relative to the tile origin; the origin (and the K tile) travel in the scalar offset.
   const int pr = lane >> 3, sw0 = (lane >> 4) & 3, pc = lane & 7;
-  const int ra = bm0 + wave * 64 + pr, rb = bn0 + wave * (16 * NJ) + pr;
+  const int ra = wave * 64 + pr, rb = wave * (16 * NJ) + pr;
   const int va0 = (ra * (int)d.lda + ((pc ^ sw0) << 3)) * 2;
   const int va1 = ((ra + 8) * (int)d.lda + ((pc ^ sw0 ^ 4) << 3)) * 2;
   const int vb0 = (rb * (int)d.ldb + ((pc ^ sw0) << 3)) * 2;
   const int vb1 = ((rb + 8) * (int)d.ldb + ((pc ^ sw0 ^ 4) << 3)) * 2;
   const uint32_t lds_u32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&lds[0];  // 0: the only LDS object
   const uint32_t abk0 = (uint32_t)(l31 * 128 + ((hi ^ ((l31 >> 1) & 7)) << 4));
-  const uint32_t aa0 = lds_u32 + wm * 16384 + abk0, ab0 = lds_u32 + 32768 + wn * (NJ * 4096) + abk0;
   const int lda16 = 16 * (int)d.lda * 2, ldb16 = 16 * (int)d.ldb * 2;
   const int nkt = d.K >> 6;
-  f32x16 acc[2][2][NJ];  // [64-row half of the wave tile][32-row block][32-column block]
+  const bool chain = d.nz == 1;  // one K loop runs on from tile to tile (same descriptors)
+  uint32_t st0 = 0;              // LDS stage that holds K tile 0 of the current output tile
+  int z, bm0, bn0;
+  pp_tile<BN>(d, 0, gd, bid, total, tiles_mn, z, bm0, bn0);
+  for (int r = 0; r < my_tiles; ++r) {
+    int zn = z, bm0n = bm0, bn0n = bn0;  // next output tile of this workgroup (itself after the last one: its K
+    if (r + 1 < my_tiles) pp_tile<BN>(d, r + 1, gd, bid, total, tiles_mn, zn, bm0n, bn0n);  // loop prefetches in-bounds garbage)
+    const int zb = z / d.nbh, zh = z - zb * d.nbh;
+    const bf16_t* A = d.A + zb * d.sAb + zh * d.sAh;
+    const bf16_t* B = d.B + zb * d.sBb + zh * d.sBh;
+    // MUBUF descriptors: rows past M / N read as zero
+    const uint64_t aaddr = (uint64_t)(uintptr_t)A, baddr = (uint64_t)(uintptr_t)B;
+    bt_i32x4 rsa, rsb;
+    rsa[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)aaddr);
+    rsa[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(aaddr >> 32));
+    rsa[2] = (int)((((int64_t)d.M - 1) * d.lda + d.K) * 2);
+    rsa[3] = 0x00020000;
+    rsb[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)baddr);
+    rsb[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(baddr >> 32));
+    rsb[2] = (int)((((int64_t)d.N - 1) * d.ldb + d.K) * 2);
+    rsb[3] = 0x00020000;
+    const int first = (r == 0 || !chain) ? 1 : 0;
+    if (first) st0 = 0;
+    const uint32_t aa0 = (lds_u32 + wm * 16384 + abk0) ^ st0, ab0 = (lds_u32 + 32768 + wn * (NJ * 4096) + abk0) ^ st0;
+    // (readfirstlane: the values are uniform, but hipcc keeps loop-carried tile coordinates in VGPRs)
+    const int base_a = __builtin_amdgcn_readfirstlane(bm0 * (int)d.lda * 2);
+    const int base_b = __builtin_amdgcn_readfirstlane(bn0 * (int)d.ldb * 2);
+    const int nbase_a = __builtin_amdgcn_readfirstlane((chain ? bm0n : bm0) * (int)d.lda * 2);
+    const int nbase_b = __builtin_amdgcn_readfirstlane((chain ? bn0n : bn0) * (int)d.ldb * 2);
+    const int st0_s = __builtin_amdgcn_readfirstlane((int)st0), first_s = __builtin_amdgcn_readfirstlane(first);
+    f32x16 acc[2][2][NJ];  // [64-row half of the wave tile][32-row block][32-column block]
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < NJ; ++ni)
+        for (int ni = 0; ni < NJ; ++ni)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[h][mi][ni][r] = 0.f;
+          for (int q = 0; q < 16; ++q) acc[h][mi][ni][q] = 0.f;
 #define BT_ACC3(h_, m_) [c##h_##m_##0] "+a"(acc[h_][m_][0]), [c##h_##m_##1] "+a"(acc[h_][m_][1]), [c##h_##m_##2] "+a"(acc[h_][m_][2])
 #define BT_IN                                                                                                         \
   [va0] "v"(va0), [va1] "v"(va1), [vb0] "v"(vb0), [vb1] "v"(vb1), [aa0] "v"(aa0), [ab0] "v"(ab0), [rsa] "s"(rsa),     \
-      [rsb] "s"(rsb), [lda16] "s"(lda16), [ldb16] "s"(ldb16), [nkt] "s"(nkt), [wave] "s"(wave)
-  if constexpr (NJ == 4) {
-    asm volatile(GEMM_BT_ASM_TEXT_NJ4
-                 : BT_ACC3(0, 0), [c003] "+a"(acc[0][0][3]), BT_ACC3(0, 1), [c013] "+a"(acc[0][1][3]), BT_ACC3(1, 0),
-                   [c103] "+a"(acc[1][0][3]), BT_ACC3(1, 1), [c113] "+a"(acc[1][1][3])
-                 : BT_IN
-                 : GEMM_BT_ASM_CLOBBERS);
-  } else {
-    asm volatile(GEMM_BT_ASM_TEXT_NJ3 : BT_ACC3(0, 0), BT_ACC3(0, 1), BT_ACC3(1, 0), BT_ACC3(1, 1) : BT_IN : GEMM_BT_ASM_CLOBBERS);
-  }
+      [rsb] "s"(rsb), [lda16] "s"(lda16), [ldb16] "s"(ldb16), [nkt] "s"(nkt), [wave] "s"(wave), [st0] "s"(st0_s),     \
+      [first] "s"(first_s), [base_a] "s"(base_a), [base_b] "s"(base_b), [nbase_a] "s"(nbase_a), [nbase_b] "s"(nbase_b)
+    if constexpr (NJ == 4) {
+      asm volatile(GEMM_BT_ASM_TEXT_NJ4
+                   : BT_ACC3(0, 0), [c003] "+a"(acc[0][0][3]), BT_ACC3(0, 1), [c013] "+a"(acc[0][1][3]), BT_ACC3(1, 0),
+                     [c103] "+a"(acc[1][0][3]), BT_ACC3(1, 1), [c113] "+a"(acc[1][1][3])
+                   : BT_IN
+                   : GEMM_BT_ASM_CLOBBERS);
+    } else {
+      asm volatile(GEMM_BT_ASM_TEXT_NJ3 : BT_ACC3(0, 0), BT_ACC3(0, 1), BT_ACC3(1, 0), BT_ACC3(1, 1) : BT_IN : GEMM_BT_ASM_CLOBBERS);
+    }
 #undef BT_ACC3
 #undef BT_IN
-  // pp_epilogue's row base is bm0 + 128 G + 64 wm2: G = 0 with the wave's 128-row offset folded into bm0 (its "tile
-  // inside C" fast-path test then only errs towards the predicated path)
-  pp_epilogue<CFG, 0>(d, acc[0], z, bm0 + wm * 128, bn0, 0, wn, lane);
-  pp_epilogue<CFG, 0>(d, acc[1], z, bm0 + wm * 128, bn0, 1, wn, lane);
+    // pp_epilogue's row base is bm0 + 128 G + 64 wm2: G = 0 with the wave's 128-row offset folded into bm0 (its "tile
+    // inside C" fast-path test then only errs towards the predicated path)
+    pp_epilogue<CFG, 0>(d, acc[0], z, bm0 + wm * 128, bn0, 0, wn, lane);
+    pp_epilogue<CFG, 0>(d, acc[1], z, bm0 + wm * 128, bn0, 1, wn, lane);
+    st0 ^= (uint32_t)(nkt & 1) << 16;
+    z = zn; bm0 = bm0n; bn0 = bn0n;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last K loop's prefetch into LDS
 }
 
 template <int NJ>
 static int bt_launch(GemmDesc d, hipStream_t stream) {
-  // 64-wide K tiles only; 32-bit byte offsets into A and B (per z)
-  if ((d.K & 63) || (int64_t)d.M * d.lda >= (1ll << 30) || (int64_t)d.N * d.ldb >= (1ll << 30)) return pp_launch<256, 64, 2, true, 0, 2>(d, stream);
+  // 64-wide K tiles only (at least two); 32-bit byte offsets into A and B (per z)
+  if ((d.K & 63) || d.K < 128 || (int64_t)d.M * d.lda >= (1ll << 30) || (int64_t)d.N * d.ldb >= (1ll << 30))
+    return pp_launch<256, 64, 2, true, 0, 2>(d, stream);
   d.tiles_m = (int)cdiv(d.M, 256);
   d.tiles_n = (int)cdiv(d.N, 64 * NJ);
   const int64_t total = (int64_t)d.tiles_m * d.tiles_n * d.nz;
   if (total > 0x3fffffff) return U2_ERR_ARG;
-  hipLaunchKernelGGL(gemm_bt_kernel<NJ>, dim3((unsigned)total), dim3(256), 0, stream, d);
+  const int grid = (int)std::min<int64_t>(total, g_pp_max_grid);
+  hipLaunchKernelGGL(gemm_bt_kernel<NJ>, dim3(grid), dim3(256), 0, stream, d);
   return launch_status();
 }
 
