@@ -255,7 +255,7 @@ def main():
         ms, flops, byts, cnt = (C.c_double * 5)(), (C.c_double * 5)(), (C.c_double * 5)(), (C.c_int64 * 5)()
         _lib.check(h.u2tok_profile_collect2(ms, flops, byts, cnt, 5), "u2tok_profile_collect2")
         ops.set_option("profile", 0)
-        names = ["gemm_bf16 (gemm_bf16_nt_kernel + gemm_pp_kernel)", "flash_d64_kernel", "temporal_attention_kernel", "row_ops",
+        names = ["gemm_bf16 (gemm_bt_kernel + gemm_bf16_nt_kernel + gemm_splitk_reduce_kernel)", "flash_d64 (flash_dp_kernel)", "temporal_attention_kernel", "row_ops",
                  "data_movement"]
         # per class: time, launches, algorithmic TFLOP/s and algorithmic GB/s (operands + results once) of its launches
         classes = {n: {"ms_per_step": round(ms[i] / nprof, 4), "launches_per_step": cnt[i] // nprof,
@@ -268,12 +268,15 @@ def main():
         traffic, traffic_src = None, None
         tfile = ROOT / "profiles" / "r01_traffic.json"
         if tfile.exists() and E == 4096 and B == 1:
-            tj = json.loads(tfile.read_text())["kernels"].get("gemm_bf16_nt_kernel")
+            tj = json.loads(tfile.read_text())["kernels"].get("gemm_bf16")
             if tj:
-                traffic = round(tj["hbm_bytes_per_launch"])
-                traffic_src = ("profiles/r01_traffic.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / launches, rocprofv3 "
-                               "--pmc, separate passes; fabric-side requests (Infinity Cache hits included)")
-        line["roofline"] = {"bound": "mfma", "kernel": "bf16 MFMA GEMM, all launches of one step (gemm_bf16_nt_kernel)",
+                # per GEMM call as counted here (a call = its main kernel + the 128^2 launch of its row tail / the
+                # split-K reduce where used: 198 dispatches for 137 calls), so that it compares with the algorithmic bytes
+                traffic = round(tj["hbm_bytes_per_step"] / max(cnt[0] // nprof, 1))
+                traffic_src = ("profiles/r01_traffic.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per volume / GEMM calls "
+                               "per volume, rocprofv3 --pmc, separate passes; fabric-side requests (Infinity Cache hits "
+                               "included)")
+        line["roofline"] = {"bound": "mfma", "kernel": "bf16 MFMA GEMM, all launches of one step (gemm_bt_kernel 256x256/256x192 tiles, gemm_bf16_nt_kernel 128^2/64^2 tiles, gemm_splitk_reduce_kernel)",
                             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                             "traffic_unit": "bytes per launch (average)", "traffic_source": traffic_src,

@@ -1,22 +1,29 @@
 #!/usr/bin/env python3
-"""Generates u2tokenizer_amd/csrc/gemm_bt_asm.inc: the K loop of the 256 x 256 x 64 "big tile" bf16 GEMM
-(gemm_pp.hip, gemm_bt_kernel) as ONE inline-asm block for gfx950.
+"""Generates u2tokenizer_amd/csrc/gemm_bt_asm.inc: the K loop of the 256 x (64 NJ) x 64 "big tile" bf16 GEMM
+(gemm_pp.hip, gemm_bt_kernel<NJ>, NJ = 4 or 3) as ONE inline-asm block for gfx950.
 
-One workgroup = 4 waves (2 x 2), one wave per SIMD, each wave a 128 x 128 output tile = 4 x 4 accumulators of
+One workgroup = 4 waves (2 x 2), one wave per SIMD, each wave a 128 x (32 NJ) output tile = 4 x NJ accumulators of
 v_mfma_f32_32x32x16_bf16 in AccVGPRs (asm operands "+a": the compiler zeroes them before and runs the epilogue after).
-LDS: 2 stages x (A tile 256 rows x 128 B | B tile 256 rows x 128 B) = 128 KB, rows XOR-swizzled as in gemm_pp.hip.
-Per K tile a wave issues 64 MFMAs; every MFMA "slot" carries at most one other instruction:
+LDS: 2 stages x (A tile 256 rows x 128 B | B tile 64 NJ rows x 128 B) <= 128 KB, rows XOR-swizzled as in gemm_pp.hip.
+Per K tile a wave issues 16 NJ MFMAs in four k16 blocks; an MFMA "slot" carries at most one LDS read and, in some
+slots, one LDS-DMA piece:
 
-    kk = 0 : slots 0-7  LDS reads of the kk = 1 fragments      slots 8-15  LDS-DMA of the B half of K tile t+1
-    kk = 1 : slots 0-7  LDS reads of the kk = 2 fragments
-    kk = 2 : slots 0-7  LDS reads of the kk = 3 fragments
+    kk = 0 : first 4 + NJ slots: LDS reads of the kk = 1 fragments       + this wave's share of the DMA of K tile t+1
+    kk = 1 : first 4 + NJ slots: LDS reads of the kk = 2 fragments       + ... (rest of K tile t+1)
+    kk = 2 : first 4 + NJ slots: LDS reads of the kk = 3 fragments
     s_waitcnt vmcnt(0) ; s_barrier          (K tile t+1 landed; everybody has read all of K tile t)
-    kk = 3 : slots 0-7  LDS reads of kk = 0 of K tile t+1       slots 8-15  LDS-DMA of the A half of K tile t+2
+    kk = 3 : first 4 + NJ slots: LDS reads of kk = 0 of K tile t+1       + first pieces of K tile t+2
 
-so the matrix pipe only drains at the one barrier per K tile, the DMA of a tile has >= 32 slots (~1000 cycles) to
-land, and fragments are read one 16-MFMA block ahead into the other half of a double register buffer.
+so the matrix pipe only drains at the one barrier per K tile, every DMA piece has >= 4 NJ slots to land, and fragments
+are read one k16 block ahead into the other half of a double register buffer.  The 4 x (8 + 2 NJ) DMA pieces of a K
+tile are spread evenly over the 12 NJ slots of that window, each wave in different slots: the four waves run in lock
+step, and pieces issued in the same slot queue behind one another in the CU's single address path (gen() docstring).
+Each wave therefore has its own copy of the loop.
 DMA: MUBUF buffer_load_dwordx4 ... lds, descriptor per matrix (rows past M / N read as zero), 32-bit lane offsets
-(two per matrix: even / odd 8-row pieces differ in the swizzle), K advance and row-block advance in the scalar offset.
+relative to the tile origin (two per matrix: even / odd 8-row pieces differ in the swizzle); tile origin, K advance and
+row-block advance in the scalar offset.  The K loop of one output tile runs on into the next output tile of the same
+(persistent) workgroup: K tile nkt of this tile IS K tile 0 of the next one (origin nbase), so a tile switch costs no
+DMA burst and no exposed latency (operand `first` = 1 only for a workgroup's first tile).
 
     python tools/gen_gemm_bt_asm.py > u2tokenizer_amd/csrc/gemm_bt_asm.inc
 """

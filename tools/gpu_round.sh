@@ -15,7 +15,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   echo "pmc $c exit $?" >> $O/rocprof.log
 done
 cd $R
-python tools/pmc_traffic.py $O/pmc_bench 4 > $O/traffic.json 2> $O/traffic.err
+python tools/pmc_traffic.py $O/pmc_bench 8 > $O/traffic.json 2> $O/traffic.err
 find $O/prof $O/pmc_bench -name "*kernel_trace*" -size +8M -delete 2>/dev/null
 find $O/pmc_bench -name "*counter_collection*" -size +8M -delete 2>/dev/null
 tail -4 $O/pytest_gpu.log; tail -2 $O/smoke.log; tail -2 $O/bench.log; tail -4 $O/rocprof.log; head -c 1500 $O/traffic.json
