@@ -306,6 +306,27 @@ def test_gemm_split_k(ops, split):
         torch.cuda.synchronize()
 
 
+def test_gemm_ktile_major_weights(ops):
+    """B handed over K-tile-major ([K/64][N][64], ops.pack_ktile_major): same products as the row-major weight, with and
+    without split-K, tails in M and N."""
+    scratch = torch.empty(16 << 20, dtype=torch.uint8, device=D)
+    ops.set_gemm_scratch(scratch)
+    try:
+        for (M, N, K) in [(256, 1024, 2048), (77, 200, 128), (300, 520, 1024)]:
+            a, w, bias = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+            wt = ops.pack_ktile_major(w.to(D))
+            ref = a.float() @ w.float().t() + bias.float()
+            for sk in (-1, 0, 4):
+                ops.set_option("gemm_splitk", sk)
+                got = ops.gemm(a.to(D), wt, bias=bias.to(D), b_ktile=True)
+                close_bf16(got, ref)
+                assert torch.equal(got, ops.gemm(a.to(D), wt, bias=bias.to(D), b_ktile=True))
+    finally:
+        ops.set_option("gemm_splitk", 0)
+        ops.set_gemm_scratch(None)
+        torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 20, 21])
 def test_gemm_pingpong_variants(ops, variant):
     """gemm_pp.hip (persistent 256 x BN ping-pong kernel) forced on shapes with row / column / K tails, several

@@ -321,6 +321,40 @@ def sec_ppc(v=None):
 PP_PERF_VARIANTS = (-1, 20, 21)
 
 
+def sec_coldperf():
+    """GEMMs with COLD weights (16 different weight matrices in rotation: 0.5-1.6 GB, beyond the 256 MB Infinity Cache),
+    the way the pipeline sees them at batch 1: us per call, by kernel choice"""
+    scratch = torch.empty(48 << 20, dtype=torch.uint8, device=dev)
+    ops.set_gemm_scratch(scratch)
+    for (M, N, K) in [(256, 4096, 4096), (256, 12288, 4096), (2048, 4096, 4096), (2048, 12288, 4096), (1792, 8192, 4096)]:
+        nw = 16
+        a, bias = rnd(M, K, seed=1).to(dev), rnd(N, seed=3).to(dev)
+        ws = [rnd(N, K, seed=10 + i).to(dev) for i in range(nw)]
+        out = torch.empty((1, M, N), dtype=bf, device=dev)
+        line = f"  {M:5d}x{N:5d}x{K:4d} bias, cold weights"
+        wt = [ops.pack_ktile_major(w) for w in ws]
+        cfgs = [("classic", -1, -1, 0), ("classic split 4", -1, 4, 0), ("heuristic", 0, 0, 0), ("K-tile-major classic", -1, -1, 1),
+                ("K-tile-major split 4", -1, 4, 1), ("K-tile-major split 8", -1, 8, 1)]
+        for name, pp, sk, kt in cfgs:
+            ops.set_option("gemm_pp", pp)
+            ops.set_option("gemm_splitk", sk)
+            it = [0]
+
+            def f():
+                if kt:
+                    ops.gemm(a, wt[it[0] % nw], bias=bias, out=out[0], b_ktile=True)
+                else:
+                    ops.gemm(a, ws[it[0] % nw], bias=bias, out=out)
+                it[0] += 1
+            ms = timeit(f, iters=32, warm=4)
+            line += f" | {name}: {ms * 1e3:6.1f}"
+        print(line, flush=True)
+        del ws, wt
+    ops.set_option("gemm_pp", 0)
+    ops.set_option("gemm_splitk", 0)
+    ops.set_gemm_scratch(None)
+
+
 def sec_skperf():
     """split-K on the skinny linear layers of the tokenizer (M = 256 queries)"""
     scratch = torch.empty(48 << 20, dtype=torch.uint8, device=dev)

@@ -111,6 +111,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
 #pragma unroll
   for (int kk = 0; kk < KSTEPS; ++kk) foff[kk] = (((kk * 4 + (lane >> 4)) ^ lds_swz<BK>(lane & 15)) << 4);
 
+  // elements between consecutive K tiles of a B row: BK for row-major weights, N * BK for "K-tile-major" packed ones
+  // ([K / 64][N][64]: the 64 x 64 tile a workgroup stages per K step is one contiguous 8 KB block)
+  const int64_t kadv_b = d.ldbk ? d.ldbk : BK;
   const int nkt_all = (d.K + BK - 1) / BK;
   const int kt0 = (d.ksplit > 1) ? (int)blockIdx.z * d.kt_per : 0;   // split-K: this slice's K tiles
   const int nkt = (d.ksplit > 1) ? min(nkt_all, kt0 + d.kt_per) : nkt_all;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
       ra[i] = (k0 + ka[i] < d.K) ? *reinterpret_cast<const uint4*>(pa[i] + k0) : uint4{0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < CB; ++i)
-      rb[i] = (k0 + kb[i] < d.K) ? *reinterpret_cast<const uint4*>(pb[i] + k0) : uint4{0, 0, 0, 0};
+      rb[i] = (k0 + kb[i] < d.K) ? *reinterpret_cast<const uint4*>(pb[i] + (int64_t)kt * kadv_b) : uint4{0, 0, 0, 0};
   };
   auto lstore = [&](int buf) {
     char* s = lds + buf * STAGE;
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
     }
 #pragma unroll
     for (int i = 0; i < CB; ++i) {
-      const void* src = (k0 + kb[i] < d.K) ? (const void*)(pb[i] + k0) : (const void*)&g_zero16;
+      const void* src = (k0 + kb[i] < d.K) ? (const void*)(pb[i] + (int64_t)kt * kadv_b) : (const void*)&g_zero16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(s + BM * ROWB + (i * 256 + wave * 64) * 16),
                                        16, 0, 0);
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
                                        16, 0, 0);
     } else {
       const int jj = i - CA;
-      const void* src = (k0 + kb[jj] < d.K) ? (const void*)(pb[jj] + k0) : (const void*)&g_zero16;
+      const void* src = (k0 + kb[jj] < d.K) ? (const void*)(pb[jj] + (int64_t)kt * kadv_b) : (const void*)&g_zero16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(s + BM * ROWB + (jj * 256 + wave * 64) * 16),
                                        16, 0, 0);
@@ -459,8 +462,10 @@ int gemm_bf16(GemmDesc d, hipStream_t stream) {
   ProfScope ps(PROF_GEMM, 2.0 * d.M * d.N * d.K * d.nz, stream,
                2.0 * d.M * d.K * zA + 2.0 * d.N * d.K * zB +
                    d.nz * ((out_f32 ? 4.0 : 2.0) * d.M * d.N + ((d.flags & GEMM_RESIDUAL) ? 2.0 * d.M * d.N : 0.0)));
-  const int pp = gemm_pp_try(d, stream);  // large products: persistent ping-pong kernel (gemm_pp.hip)
-  if (pp != 0) return pp > 0 ? U2_OK : pp;
+  if (d.ldbk == 0) {  // (the 256-wide-tile kernels read row-major B only)
+    const int pp = gemm_pp_try(d, stream);  // large products: big-tile / ping-pong kernels (gemm_pp.hip)
+    if (pp != 0) return pp > 0 ? U2_OK : pp;
+  }
   return gemm_classic(d, stream);
 }
 

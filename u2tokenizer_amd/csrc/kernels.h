@@ -27,6 +27,7 @@ enum : int {
   GEMM_RESIDUAL = 8,   // + R[m][n]   (residual stream / position embedding), after GELU
   GEMM_OUT_F32 = 16,   // C is float32 instead of bf16
   GEMM_VEC_OK = 32,    // internal: vector epilogue legal (set by the launcher)
+  GEMM_B_KTILE = 64,   // C-ABI only: B is K-tile-major [K/64][N][64] (pack_ktile_major); K % 64 == 0, nz == 1
 };
 
 struct GemmDesc {
@@ -37,6 +38,7 @@ struct GemmDesc {
   const bf16_t* R = nullptr;  // [M][N] bf16, leading dim ldr
   int M = 0, N = 0, K = 0;
   int64_t lda = 0, ldb = 0, ldc = 0, ldr = 0;
+  int64_t ldbk = 0;  // 0: B rows are K-contiguous; else B is K-tile-major [K/64][N][64] (ldb = 64, ldbk = N * 64)
   // batch z in [0, nz): zb = z / nbh, zh = z % nbh; element offsets zb*s?b + zh*s?h
   int nz = 1, nbh = 1;
   int64_t sAb = 0, sAh = 0, sBb = 0, sBh = 0, sCb = 0, sCh = 0, sRb = 0, sRh = 0;

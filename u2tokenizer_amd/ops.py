@@ -43,9 +43,38 @@ def vol_dtype_code(dtype) -> int:
     return _VOL_DTYPE[dtype]
 
 
+GEMM_B_KTILE = 64
+
+
+def pack_ktile_major(w: torch.Tensor) -> torch.Tensor:
+    """nn.Linear weight (N, K) -> K-tile-major (K/64, N, 64): the 64 x 64 tile a workgroup stages per K step becomes one
+    contiguous 8 KB block (cold weights stream from HBM in long bursts instead of 128-byte pieces 2 K bytes apart)."""
+    N, K = w.shape
+    assert K % 64 == 0
+    return w.view(N, K // 64, 64).permute(1, 0, 2).contiguous()
+
+
 def gemm(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, bias_m=False, gelu=False, out_f32=False,
-         alpha=1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """C = epi(alpha * A B^T) for A (..., M, K), B (N, K) or batched (Z, N, K)."""
+         alpha=1.0, out: Optional[torch.Tensor] = None, b_ktile: bool = False) -> torch.Tensor:
+    """C = epi(alpha * A B^T) for A (..., M, K), B (N, K) or batched (Z, N, K); b_ktile: B = pack_ktile_major(weight)."""
+    if b_ktile:
+        kt, n_, _ = b.shape
+        h = _lib.load_library()
+        a2 = _need(a, torch.bfloat16, "A").reshape(-1, a.shape[-1]).contiguous()
+        M, K = a2.shape
+        assert kt * 64 == K
+        if out is None:
+            out = torch.empty((M, n_), dtype=torch.float32 if out_f32 else torch.bfloat16, device=a.device)
+        flags = GEMM_B_KTILE | (GEMM_OUT_F32 if out_f32 else 0) | (GEMM_GELU if gelu else 0)
+        if bias is not None:
+            flags |= GEMM_BIAS_M if bias_m else GEMM_BIAS_N
+        if residual is not None:
+            flags |= GEMM_RESIDUAL
+            residual = residual.contiguous()
+        st = h.u2tok_gemm_bf16(_ptr(a2), _ptr(b), _ptr(out), _ptr(bias), _ptr(residual), M, n_, K, K, 64, n_, n_, 1, 1,
+                               0, 0, 0, 0, 0, 0, 0, 0, float(alpha), flags, _stream())
+        _lib.check(st, "u2tok_gemm_bf16")
+        return out
     h = _lib.load_library()
     _need(a, torch.bfloat16, "A"), _need(b, torch.bfloat16, "B")
     a3 = a.reshape(-1, a.shape[-2], a.shape[-1]) if b.dim() == 3 else a.reshape(1, -1, a.shape[-1])
