@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 counter passes (counters + kernel trace only) for the hot kernels of this round:
+# rocprofv3 counter passes (counters + kernel trace only) for the hot kernels of this round (-> profiles/r01_kernel_pmc.json):
 #   flash attention (mode 5), big-tile GEMM on the ViT qkv shape (256x192 tiles) and on 8192^3 (256x256), 128^2 GEMM.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/pmc2; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 run() {  # name, driver args..., then counter sets come from PASSES
@@ -7,13 +7,15 @@ run() {  # name, driver args..., then counter sets come from PASSES
   i=0
   for ctrs in "${PASSES[@]}"; do
     i=$((i+1))
-    timeout 300 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $O/${name}_p$i -o p -- python $R/tools/prof_kernels.py "$@" > $O/${name}_p$i.log 2>&1
+    timeout 60 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $O/${name}_p$i -o p -- python $R/tools/prof_kernels.py "$@" > $O/${name}_p$i.log 2>&1
     echo "$name pass $i exit $?"
   done
 }
 PASSES=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"
-        "GRBM_GUI_ACTIVE FETCH_SIZE WRITE_SIZE"
-        "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU")
+        "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS")
+# Lessons of round 1 (25 GPU-minutes): "GRBM_GUI_ACTIVE FETCH_SIZE WRITE_SIZE" in ONE pass aborts rocprofv3 (signal 6) --
+# collect them one per pass as tools/gpu_round.sh does; with SQ_INSTS_VALU added to the LDS set the profiled process
+# never exited and every pass ran into its timeout (the counters were still written).  Keep the per-pass timeout short.
 run flash5 flash 3 0 5
 run flash3 flash 3 0 3
 run qkv_bt192 gemm 3 21

@@ -139,6 +139,7 @@ int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16
                         const bf16_t* qx, const bf16_t* kx, const bf16_t* vx, bf16_t* outx, int64_t x_bs, int64_t ox_bs,
                         int n_extra, hipStream_t stream);
 int flash_set_debug_buffer(void* p);  // diagnostics: s_memtime phase sums per (workgroup, wave); see attn.hip
-void flash_set_mode(int mode);  // 0 pick, 1: 128-row units, 2: 256-row units, 3: one of each per workgroup
+void flash_set_mode(int mode);  // 0 pick (5 for S >= 512), 1: 128-row units, 2: 256-row units, 3: one of each per workgroup,
+                                // 4: 8-wave ping-pong, 5: double pipeline with the generated asm KV loop
 
 }  // namespace u2
