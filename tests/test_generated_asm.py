@@ -36,3 +36,121 @@ def test_gemm_bt_schedule_issues_every_piece_once():
             assert sum(l.startswith("v_mfma") for l in loop) == 16 * nj
             assert sum(l.startswith("ds_read_b128") for l in loop) == 4 * (4 + nj)
             assert sum(l.startswith("s_barrier") for l in loop) == 1
+
+
+def _bt_layout(nj):
+    """LDS contents of one K tile as the DMA pieces of gemm_bt_kernel<NJ> write them (formulas of gemm_pp.hip):
+    byte address -> (matrix, tile row, 16-byte K chunk)."""
+    lds = {}
+    for wave in range(4):
+        for lane in range(64):
+            pr, sw0, pc = lane >> 3, (lane >> 4) & 3, lane & 7
+            for mat, rows_per_wave, base in (("a", 64, 0), ("b", 16 * nj, 32768)):
+                for p in range(rows_per_wave // 8):
+                    row = wave * rows_per_wave + p * 8 + pr            # va0 / va1 + (p >> 1) * 16 rows in the scalar offset
+                    chunk = pc ^ sw0 ^ (4 if p & 1 else 0)              # the odd piece's lane offset carries sw0 ^ 4
+                    addr = base + wave * rows_per_wave * 128 + p * 1024 + lane * 16   # M0 = wave base + 1024 p, lane-linear
+                    assert addr not in lds
+                    lds[addr] = (mat, row, chunk)
+    return lds
+
+
+def test_gemm_bt_fragment_reads_hit_the_rows_the_dma_wrote():
+    """Executable spec of the big-tile GEMM's LDS layout: every ds_read_b128 of an MFMA fragment (address registers and
+    immediate offsets taken from the generated asm) must land on the (row, K chunk) the MFMA operand layout wants, in
+    data some DMA piece wrote, and the 16 lanes of each quarter wave must touch 16 different 16-byte bank groups."""
+    import re
+    text = (CSRC / "gemm_bt_asm.inc").read_text()
+    for nj in (4, 3):
+        body = re.search(rf"#define GEMM_BT_ASM_TEXT_NJ{nj} \\\n(.*?)\n#define", text, re.S).group(1)
+        lines = re.findall(r'"(.*)\\n"', body)
+        # address registers: v_xor_b32 vR, 32*k, %[aa0|ab0]; v_mov_b32 vR, %[aa0|ab0]
+        areg = {}
+        for l in lines:
+            m = re.match(r"v_xor_b32 v(\d+), (\d+), %\[(aa0|ab0)\]", l)
+            if m:
+                areg[int(m.group(1))] = (m.group(3)[1], int(m.group(2)))
+            m = re.match(r"v_mov_b32 v(\d+), %\[(aa0|ab0)\]", l)
+            if m:
+                areg[int(m.group(1))] = (m.group(2)[1], 0)
+        assert sorted(x for _, x in areg.values()) == [0, 0, 32, 32, 64, 64, 96, 96]
+        reads = set()
+        for l in lines:
+            m = re.match(r"ds_read_b128 v\[(\d+):\d+\], v(\d+) offset:(\d+)", l)
+            if m:
+                mat, kx = areg[int(m.group(2))]
+                reads.add((mat, kx >> 5, int(m.group(3))))          # (matrix, k16 step kk, immediate offset)
+        assert reads == {("a", kk, 4096 * i) for kk in range(4) for i in range(4)} | \
+                        {("b", kk, 4096 * j) for kk in range(4) for j in range(nj)}
+        lds = _bt_layout(nj)
+        for wave in range(4):
+            wm, wn = wave >> 1, wave & 1
+            for (mat, kk, off) in reads:
+                slots = []
+                for lane in range(64):
+                    hi, l31 = lane >> 5, lane & 31
+                    abk0 = l31 * 128 + ((hi ^ ((l31 >> 1) & 7)) << 4)
+                    base = wm * 16384 if mat == "a" else 32768 + wn * (nj * 4096)
+                    addr = (base + abk0) ^ (kk << 5)                  # aa0 / ab0 of the kernel, xor 32 kk in the asm
+                    addr += off
+                    want_row = (wm * 128 if mat == "a" else wn * 32 * nj) + (off // 4096) * 32 + l31
+                    assert lds[addr] == (mat, want_row, kk * 2 + hi), (nj, wave, mat, kk, off, lane)
+                    slots.append((addr // 16) % 16)
+                for q in range(4):
+                    assert len(set(slots[16 * q:16 * q + 16])) == 16  # conflict-free ds_read_b128
+
+
+def test_flash_dp_fragment_reads_hit_the_rows_the_dma_wrote():
+    """Same executable spec for the flash KV loop: a 64-key ring slot = K tile [64 keys][64 d] at +0 and V^T tile
+    [64 d][64 keys] at +8192, both 128-byte rows with the kt_off swizzle; DMA pieces per attn.hip (flash_dp_kernel), reads
+    from the generated asm (v_add_u32 ADR, S_AK | S_AV, ab[k] ; ds_read_b128 .., ADR offset:..)."""
+    import re
+    text = (CSRC / "flash_dp_asm.inc").read_text()
+    body = re.search(r"#define FLASH_DP_ASM_TEXT \\\n(.*?)\n#define", text, re.S).group(1)
+    lines = re.findall(r'"(.*)\\n"', body)
+    abreg = {"%[ab0]": 0}
+    for l in lines:
+        m = re.match(r"v_xor_b32 v(\d+), (\d+), %\[ab0\]", l)
+        if m:
+            abreg["v" + m.group(1)] = int(m.group(2)) >> 5
+    assert sorted(abreg.values()) == [0, 1, 2, 3]
+    reads = set()
+    for a, b in zip(lines, lines[1:]):
+        m = re.match(r"v_add_u32 v(\d+), s(\d+), (%\[ab0\]|v\d+)", a)
+        n = re.match(r"ds_read_b128 v\[\d+:\d+\], v(\d+) offset:(\d+)", b)
+        if m and n and m.group(1) == n.group(1):
+            reads.add((int(m.group(2)), abreg[m.group(3)], int(n.group(2))))
+    sregs = sorted({r[0] for r in reads})
+    assert len(sregs) == 2
+    s_ak, s_av = sregs                                   # S_AK < S_AV in the generator's register plan
+    assert {(k, off) for (sr, k, off) in reads if sr == s_ak} == {(k, 0) for k in range(4)}
+    assert {(k, off) for (sr, k, off) in reads if sr == s_av} == {(k, off) for k in range(4) for off in (0, 4096)}
+    # what the DMA pieces of the four waves put where (tile-relative byte address -> (row, 16-byte chunk))
+    tile = {}
+    for wv in range(4):
+        for lane in range(64):
+            for piece in range(2):
+                prow = wv * 16 + (lane >> 3) + 8 * piece
+                chunk = (lane & 7) ^ ((prow >> 1) & 7)
+                addr = wv * 2048 + piece * 1024 + lane * 16
+                assert addr not in tile
+                tile[addr] = (prow, chunk)
+    assert len(tile) == 512
+    for half in range(2):                                # K rows 32 half .. : S_AK = slot + 4096 half
+        for k in range(4):
+            slots = []
+            for lane in range(64):
+                hi, l31 = lane >> 5, lane & 31
+                ab = l31 * 128 + (((k * 2 + hi) ^ ((l31 >> 1) & 7)) << 4)
+                assert tile[half * 4096 + ab] == (half * 32 + l31, k * 2 + hi)
+                slots.append(((half * 4096 + ab) // 16) % 16)
+            for q in range(4):
+                assert len(set(slots[16 * q:16 * q + 16])) == 16
+    for vh in range(2):                                  # V^T: d rows nb * 32 + l31, key chunk (vh * 2 + ks2) * 2 + hi
+        for ks2 in range(2):
+            for nb in range(2):
+                for lane in range(64):
+                    hi, l31 = lane >> 5, lane & 31
+                    k = vh * 2 + ks2
+                    ab = l31 * 128 + (((k * 2 + hi) ^ ((l31 >> 1) & 7)) << 4)
+                    assert tile[nb * 4096 + ab] == (nb * 32 + l31, k * 2 + hi)
