@@ -154,3 +154,29 @@ def test_flash_dp_fragment_reads_hit_the_rows_the_dma_wrote():
                     k = vh * 2 + ks2
                     ab = l31 * 128 + (((k * 2 + hi) ^ ((l31 >> 1) & 7)) << 4)
                     assert tile[nb * 4096 + ab] == (nb * 32 + l31, k * 2 + hi)
+
+
+def test_generated_asm_passes_the_hazard_lint():
+    """tools/asm_lint.py: the software wait states hipcc would insert for its own code (transcendental -> VALU, M0 write
+    -> LDS-DMA, MFMA result -> VALU / store, permlane swap) are present in the hand-scheduled loops, and the counted
+    lgkmcnt waits are consistent with the reads issued."""
+    sys.path.insert(0, str(ROOT / "tools"))
+    import asm_lint
+    seen = 0
+    for inc in ("flash_dp_asm.inc", "gemm_bt_asm.inc"):
+        for name, lines in asm_lint.blocks(str(CSRC / inc)):
+            seen += 1
+            assert len(lines) > 200
+            assert asm_lint.lint(name, lines) == []
+    assert seen == 4
+    # the linter itself: each rule fires on a minimal violation
+    bad = {
+        "R1": ["v_exp_f32 v1, v1", "v_add_f32 v2, v1, v1"],
+        "R2": ["s_mov_b32 m0, s4", "buffer_load_dwordx4 v1, s[4:7], s8 offen lds"],
+        "R3": ["v_mfma_f32_32x32x16_bf16 v[16:31], v[0:3], v[4:7], 0", "v_max3_f32 v50, v16, v17, v18"],
+        "R4": ["v_mov_b32 v2, v3", "v_permlane32_swap_b32 v2, v3"],
+        "R5": ["ds_read_b128 v[0:3], v9 offset:0", "s_waitcnt lgkmcnt(2)"],
+    }
+    for rule, text in bad.items():
+        errs = asm_lint.lint(rule, text)
+        assert len(errs) == 1 and rule in errs[0]
