@@ -5,21 +5,33 @@ One step = one pass of the hot path (reference u2_arch.py:96-117) over one batch
 in HBM: fp16 volume (B,8,32,256,256) -> im2col/patch-embed -> ViT-B 3D x12 -> SPP -> u2Tokenizer (SVR x4, DiffTS,
 DMTP multi-scale, TTA x4, linear aggregation) -> 256 tokens spliced into the (B,1024,E) prompt embeddings.
 Workload = BASELINE.json configs[2] (u2Qwen3-8B shape: E=4096, full multi-scale tokenizer, batch 1), random-init
-weights of that architecture, synthetic data.  N > 1: independent replicas, one process per GPU (weak scaling, no
-data-path collective); launched by torch.distributed.run, timed with barrier + synchronize, MAX over ranks.
+weights of that architecture, synthetic data.
 
-Steps are issued round-robin on --streams HIP streams (default 2: two batch-1 volumes in flight per GPU; every step is
-still one complete pass over one volume, and `value_one_stream` reports the same K steps on a single stream).
+N > 1: independent replicas, one process per GPU (weak scaling, no data-path collective: SURVEY.md 8e), timed with
+barrier + synchronize on both sides, MAX over ranks.  `python bench.py --gpus N` launches its N ranks itself
+(re-executes under torch.distributed.run on 127.0.0.1); started under torch.distributed.run it uses the ranks it is
+given.
+
+The timed region (EXACTLY --steps steps between barrier + synchronize) is repeated --repeats times; `value` is the
+MEDIAN repeat, all repeats are listed under "repeats".  Steps are issued round-robin on --streams HIP streams (default 2:
+two batch-1 volumes in flight per GPU; every step is still one complete pass over one volume; `ms_per_step` is
+elapsed / steps, i.e. the reciprocal of the throughput, and `ms_per_step_one_stream` the latency of one volume alone).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- the dominant kernel class (bf16 MFMA GEMM): algorithmic FLOPs of all its launches in one step /
-                  their summed HIP-event durations (instrumented pass after the timed region), vs 2.5 PFLOP/s.
-  cpu_baseline -- the CPU oracle (oracle/u2_oracle.py, fp32, all host cores) timed on a bounded sample of the
-                  same workload (rank 0, N = 1 only).
+  roofline            -- the dominant kernel class (bf16 MFMA GEMM): algorithmic FLOPs of its launches in one step /
+                         their summed HIP-event durations on the launch stream (instrumented one-stream pass after the
+                         timed region; the timed region itself carries no events), vs 2.5 PFLOP/s.
+  roofline_attention  -- the same for the ViT flash-attention kernel (north_star's ">= 40 % MFMA" target).
+  cpu_baseline        -- the CPU oracle (oracle/u2_oracle.py) on the host cores: fp32 and bf16, 1 warm-up + 3 timed
+                         iterations per stage on a bounded sample (1 of 8 chunks through ViT + SPP, 1 of 4 layers of
+                         SVR and TTA, selection / pooling / aggregation in full), rank 0, N = 1 only.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -31,6 +43,8 @@ sys.path.insert(0, str(ROOT))
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 BF = torch.bfloat16
+WORKLOAD = ("BASELINE configs[2]: u2Qwen3-8B-shaped path, 256^3 volume = 8x(32,256,256) fp16, ViT-B 3D x12, SPP, "
+            "4-layer rma+diffts+dmtp tokenizer (8 heads, top_k 1024, scales {1,2,4}, 256 queries), text 1024, prompt 1024")
 
 
 def flops_per_volume(E, Lt=1024, C=8, n=2048, Hd=768, mlp=3072, depth=12, L=4, Q=256, k=1024, N=256):
@@ -52,17 +66,21 @@ def flops_per_volume(E, Lt=1024, C=8, n=2048, Hd=768, mlp=3072, depth=12, L=4, Q
     return dict(vit=vit, spp=spp, svr=svr, select=diffts, tta=tta, total=vit + spp + svr + diffts + tta)
 
 
+def path_config(E):
+    from types import SimpleNamespace as NS
+    return NS(vision_tower="vit3d", image_channel=1, image_size=[32, 256, 256], patch_size=[4, 16, 16],
+              vision_select_layer=-1, vision_select_feature="patch", mm_projector_type="spp", proj_layer_type="mlp",
+              proj_layer_num=2, proj_pooling_type="spatial", proj_pooling_size=2, mm_hidden_size=768, hidden_size=E,
+              enable_u2tokenizer=True, u2t_num_heads=8, u2t_num_layers=4, u2t_top_k=1024, use_multi_scale=True,
+              num_3d_query_token=256, attn_type="rma", enable_diffts=True, enable_dmtp=True)
+
+
 def build_path(E, vocab, device):
     """ViT3DTower + SPP + u2Tokenizer + embedding table, random-init on the GPU (no decoder: outside the path)."""
-    from types import SimpleNamespace as NS
     from u2tokenizer_amd.arch import u2MetaForCausalLM
     from u2tokenizer_amd.builder import build_mm_projector, build_u2tokenizer_tower, build_vision_tower
 
-    cfg = NS(vision_tower="vit3d", image_channel=1, image_size=[32, 256, 256], patch_size=[4, 16, 16],
-             vision_select_layer=-1, vision_select_feature="patch", mm_projector_type="spp", proj_layer_type="mlp",
-             proj_layer_num=2, proj_pooling_type="spatial", proj_pooling_size=2, mm_hidden_size=768, hidden_size=E,
-             enable_u2tokenizer=True, u2t_num_heads=8, u2t_num_layers=4, u2t_top_k=1024, use_multi_scale=True,
-             num_3d_query_token=256, attn_type="rma", enable_diffts=True, enable_dmtp=True)
+    cfg = path_config(E)
 
     class Holder(torch.nn.Module):
         def __init__(self):
@@ -101,25 +119,35 @@ def build_path(E, vocab, device):
             t.normal_(0, 0.02, generator=g)
         p.data = t
         p.requires_grad_(False)
+    holder.u2tokenizer.pack_weights()  # q|k|v packing happens here, not inside the first timed / warm-up step
     return PathOnly(holder), cfg
 
 
-def cpu_baseline(E, Lt, sample_chunks=1):
-    """Oracle (fp32 CPU restatement of the reference) on a bounded sample of the workload: `sample_chunks` of the 8
-    chunks through ViT+SPP (extrapolated x8/sample_chunks) + the full tokenizer + splice.  Weight VALUES do not
-    affect CPU time, so same-shape tensors share storage (keeps host RAM/initialisation bounded)."""
+# ---------------------------------------------------------------------------------------------------- CPU baseline
+def _median_time(fn, iters):
+    fn()  # warm-up
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return statistics.median(ts), ts
+
+
+def cpu_baseline(E, Lt, iters=3, sample_chunks=1):
+    """Oracle (CPU restatement of the reference, oracle/u2_oracle.py) per BASELINE.md section 3: torch.no_grad(), all
+    host threads, fp32 AND bf16, 1 warm-up + `iters` timed iterations per stage (median), per-stage split.  Bounded by
+    SAMPLING the workload, not by dropping repeats: `sample_chunks` of the 8 chunks go through ViT + SPP (chunks are
+    independent: x 8 / sample_chunks), ONE of the 4 identical SVR layers and ONE of the 4 identical TTA layers are
+    timed (x 4); selection, pooling and the final aggregation run in full.  Weight VALUES do not affect CPU time, so
+    same-shape tensors share storage (keeps host RAM / initialisation bounded)."""
     from oracle import u2_oracle as O
     from u2tokenizer_amd.builder import build_mm_projector, build_u2tokenizer_tower, build_vision_tower
-    from types import SimpleNamespace as NS
-    cfgm = NS(vision_tower="vit3d", image_channel=1, image_size=[32, 256, 256], patch_size=[4, 16, 16],
-              vision_select_layer=-1, vision_select_feature="patch", mm_projector_type="spp", proj_layer_type="mlp",
-              proj_layer_num=2, proj_pooling_type="spatial", proj_pooling_size=2, mm_hidden_size=768, hidden_size=E,
-              u2t_num_heads=8, u2t_num_layers=4, u2t_top_k=1024, use_multi_scale=True, num_3d_query_token=256,
-              attn_type="rma", enable_diffts=True, enable_dmtp=True)
+    cfgm = path_config(E)
     with torch.device("meta"):
         mods = {"model.vision_tower.": build_vision_tower(cfgm), "model.mm_projector.": build_mm_projector(cfgm),
                 "model.u2tokenizer.": build_u2tokenizer_tower(cfgm)}
-    pool, sd = {}, {}
+    pool, sd32 = {}, {}
     gen = torch.Generator().manual_seed(0)
     for prefix, m in mods.items():
         for k, v in m.state_dict().items():
@@ -129,24 +157,81 @@ def cpu_baseline(E, Lt, sample_chunks=1):
                 pool[shp] = torch.randn(shp, generator=gen) * std
                 if "norm" in k and k.endswith("weight"):
                     pool[shp] = torch.ones(shp)
-            sd[prefix + k] = pool[shp]
+            sd32[prefix + k] = pool[shp]
+    pool16 = {id(v): v.to(BF) for v in pool.values()}
+    sd16 = {k: pool16[id(v)] for k, v in sd32.items()}
     cfg = O.PathConfig(hidden_size=E)
+    cfg1 = O.PathConfig(hidden_size=E, u2t_num_layers=1)
     threads = torch.get_num_threads()
+    tp = "model.u2tokenizer"
+    res = {}
     with torch.no_grad():
         vol = torch.rand(sample_chunks, 1, 32, 256, 256, generator=gen)
-        t0 = time.perf_counter()
-        feats = O.vit_tower_forward(sd, "model.vision_tower.vision_tower", vol, cfg)
-        feats = O.spp_forward(sd, "model.mm_projector", feats, cfg)
-        t_vis = (time.perf_counter() - t0) * (8.0 / sample_chunks)
         v = torch.randn(1, 8, 256, E, generator=gen)
         t = torch.randn(1, Lt, E, generator=gen) * 0.05
+        for label, sd, dt in (("fp32", sd32, torch.float32), ("bf16", sd16, BF)):
+            vol_d, v_d, t_d = vol.to(dt), v.to(dt), t.to(dt)
+            st = {}
+            feats = O.vit_tower_forward(sd, "model.vision_tower.vision_tower", vol_d, cfg)
+            st["vit"], _ = _median_time(lambda: O.vit_tower_forward(sd, "model.vision_tower.vision_tower", vol_d, cfg), iters)
+            st["vit"] *= 8.0 / sample_chunks
+            st["spp"], _ = _median_time(lambda: O.spp_forward(sd, "model.mm_projector", feats, cfg), iters)
+            st["spp"] *= 8.0 / sample_chunks
+            lp = f"{tp}.svt_module.attention_network.layers.0"
+            x1 = O.st_attention_layer(sd, lp, v_d, cfg)
+            t_layer, _ = _median_time(lambda: O.st_attention_layer(sd, lp, v_d, cfg), iters)
+            st["svr"] = 4.0 * t_layer
+            sel = O.diff_token_selection(sd, f"{tp}.svt_module.token_selection", x1)
+            pooled = O.multi_scale_pool(sd, f"{tp}.svt_module.dynamic_pool", sel)
+            st["select_pool"], _ = _median_time(
+                lambda: O.multi_scale_pool(sd, f"{tp}.svt_module.dynamic_pool",
+                                           O.diff_token_selection(sd, f"{tp}.svt_module.token_selection", x1)), iters)
+            q = sd[f"{tp}.query_tokens"]
+            t_agg, _ = _median_time(lambda: O.cross_attention(sd, f"{tp}.tta_module.layer_linagg.linear_aggregator", q,
+                                                               pooled, 8, is_compress=True), iters)
+            t_l1, _ = _median_time(lambda: O.tta_forward(sd, f"{tp}.tta_module", q, pooled, t_d, cfg1), iters)
+            st["tta"] = 4.0 * max(t_l1 - t_agg, 0.0) + t_agg
+            st["total"] = sum(st.values())
+            res[label] = {k: round(x, 3) for k, x in st.items()}
+    return dict(value=round(1.0 / res["fp32"]["total"], 5), unit="volumes/s", cores=threads, kind="port",
+                value_bf16=round(1.0 / res["bf16"]["total"], 5),
+                seconds_per_volume_fp32=res["fp32"], seconds_per_volume_bf16=res["bf16"],
+                sample=f"oracle/u2_oracle.py on {threads} host threads, torch.no_grad, 1 warm-up + {iters} timed iterations "
+                       f"(median) per stage; {sample_chunks}/8 chunks through ViT + SPP (x{8 // sample_chunks}), 1/4 SVR layers "
+                       f"and 1/4 TTA layers (x4), DiffTS + DMTP pooling + linear aggregation in full; E={E}, text {Lt}")
+
+
+# ---------------------------------------------------------------------------------------------------- launcher
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a torch.distributed.run parent: start the N ranks ourselves."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    return subprocess.call(cmd, env=env)
+
+
+def timed_repeats(step, steps, warmup, repeats, sync, reduce_max):
+    """`repeats` x {barrier + synchronize, EXACTLY `steps` steps, barrier + synchronize}; elapsed = MAX over ranks."""
+    out = None
+    for i in range(warmup):
+        out = step(i)
+    times = []
+    for _ in range(repeats):
+        sync()
         t0 = time.perf_counter()
-        out, _ = O.tokenizer_forward(sd, "model.u2tokenizer", v, t, cfg)
-        t_tok = time.perf_counter() - t0
-    return dict(value=1.0 / (t_vis + t_tok), unit="volumes/s", cores=threads, kind="port",
-                sample=f"oracle fp32: {sample_chunks}/8 chunks through ViT+SPP ({t_vis:.1f} s extrapolated to 8) + "
-                       f"full tokenizer E={E} Lt={Lt} ({t_tok:.1f} s); one run, no warm-up",
-                seconds_per_volume=t_vis + t_tok)
+        for i in range(steps):
+            out = step(i)
+        sync()
+        times.append(reduce_max(time.perf_counter() - t0))
+    return times, out
 
 
 def main():
@@ -154,6 +239,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; value = median")
     ap.add_argument("--hidden", type=int, default=4096, help="LLM hidden size E (4096 = Qwen3-8B, 2048 = Qwen3-1.7B)")
     ap.add_argument("--batch", type=int, default=1, help="volumes per step per GPU")
     ap.add_argument("--streams", type=int, default=2,
@@ -161,130 +247,152 @@ def main():
                          "launches of one volume's tokenizer fill the machine under the other volume's large GEMMs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-baseline-iters", type=int, default=3)
+    ap.add_argument("--stub-cpu", action="store_true",
+                    help="TEST PLUMBING ONLY (tests/test_bench_launcher.py): replace the step by a host no-op and use the "
+                         "gloo backend, so that the launcher / barrier / MAX-over-ranks / JSON path can run on a box "
+                         "without GPUs.  The line it prints is marked invalid.")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     from u2tokenizer_amd import replicas
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
-        args.gpus = world
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    # RCCL ("nccl" backend on ROCm) is used only for the timing barrier and the MAX over ranks: replicas share nothing
-    dist, rank, world = replicas.init_from_env("nccl", device)
-
-    from u2tokenizer_amd import _lib, ops
-    ops.device_check()  # fails loudly off gfx950 / without the HIP library
-    torch.set_grad_enabled(False)
-
+    args.gpus = world
     E, B, S, Lt, Q = args.hidden, args.batch, 1024, 1024, 256
-    vocab = 151936 if E == 4096 else 151936  # Qwen3 vocabulary
-    path, cfg = build_path(E, vocab, device)
-    g = torch.Generator(device=device).manual_seed(1 + rank)
-    nvol = 4  # rotate volumes so no step re-reads its input from the 256 MiB Infinity Cache
-    vols = [torch.rand((B, 8, 32, 256, 256), device=device, generator=g).half() for _ in range(nvol)]
-    for v in vols:
-        v.view(B, 256, 256, 256)[:, 205:] = 0  # trailing depth padding (u2Transform.py:93-94)
-    ids = torch.randint(1, vocab, (B, S), device=device, generator=g)
-    qids = torch.zeros((B, Lt), dtype=torch.int64, device=device)
-    qids[:, :40] = torch.randint(1, vocab, (B, 40), device=device, generator=g)
+    fl = flops_per_volume(E, Lt)
 
-    streams = [torch.cuda.Stream(device=device) for _ in range(args.streams)] if args.streams > 1 else None
+    if args.stub_cpu:
+        device = torch.device("cpu")
+        dist, rank, world = replicas.init_from_env("gloo", device)
+        x = torch.zeros(8)
 
-    def step(i, multi=True):
-        if streams is None or not multi:
-            return path.prepare_inputs_for_multimodal(ids, None, None, None, None, vols[i % nvol], qids)[4]
-        with torch.cuda.stream(streams[i % len(streams)]):
-            return path.prepare_inputs_for_multimodal(ids, None, None, None, None, vols[i % nvol], qids)[4]
+        def step(i, multi=True):
+            time.sleep(0.002)
+            return x
+
+        streams = None
+    else:
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+        # RCCL ("nccl" backend on ROCm) is used only for the timing barrier and the MAX over ranks: replicas share nothing
+        dist, rank, world = replicas.init_from_env("nccl", device)
+        from u2tokenizer_amd import _lib, ops
+        ops.device_check()  # fails loudly off gfx950 / without the HIP library
+        torch.set_grad_enabled(False)
+        vocab = 151936  # Qwen3 vocabulary
+        path, cfg = build_path(E, vocab, device)
+        g = torch.Generator(device=device).manual_seed(1 + rank)
+        nvol = 4  # rotate volumes so no step re-reads its input from the 256 MiB Infinity Cache
+        vols = [torch.rand((B, 8, 32, 256, 256), device=device, generator=g).half() for _ in range(nvol)]
+        for v in vols:
+            v.view(B, 256, 256, 256)[:, 205:] = 0  # trailing depth padding (u2Transform.py:93-94)
+        ids = torch.randint(1, vocab, (B, S), device=device, generator=g)
+        qids = torch.zeros((B, Lt), dtype=torch.int64, device=device)
+        qids[:, :40] = torch.randint(1, vocab, (B, 40), device=device, generator=g)
+        streams = [torch.cuda.Stream(device=device) for _ in range(args.streams)] if args.streams > 1 else None
+        torch.cuda.synchronize(device)  # weights / inputs were produced on the default stream: the side streams are non-blocking
+
+        def step(i, multi=True):
+            if streams is None or not multi:
+                return path.prepare_inputs_for_multimodal(ids, None, None, None, None, vols[i % nvol], qids)[4]
+            with torch.cuda.stream(streams[i % len(streams)]):
+                return path.prepare_inputs_for_multimodal(ids, None, None, None, None, vols[i % nvol], qids)[4]
 
     def sync():
         replicas.barrier(dist, device)
 
-    for i in range(args.warmup):
-        out = step(i)
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(i)
-    sync()
-    elapsed = time.perf_counter() - t0
-    assert out.shape == (B, S, E) and bool(torch.isfinite(out.float()).all())
-    elapsed = replicas.max_over_ranks(dist, elapsed, device)
+    def rmax(x):
+        return replicas.max_over_ranks(dist, x, device)
 
-    # the same K steps issued on ONE stream (one volume in flight), for reference next to the headline
+    times, out = timed_repeats(step, args.steps, args.warmup, args.repeats, sync, rmax)
+    if not args.stub_cpu:
+        assert out.shape == (B, S, E) and bool(torch.isfinite(out.float()).all())
+    elapsed = statistics.median(times)
+
+    # the same K steps issued on ONE stream (one volume in flight): the latency of a volume
     single = None
     if streams is not None:
-        for i in range(args.warmup):
-            step(i, multi=False)
-        sync()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            step(i, multi=False)
-        sync()
-        single = replicas.max_over_ranks(dist, time.perf_counter() - t1, device)
+        t1, _ = timed_repeats(lambda i: step(i, multi=False), args.steps, args.warmup, max(1, args.repeats // 2), sync, rmax)
+        single = statistics.median(t1)
 
-    fl = flops_per_volume(E, Lt)
     value = world * B * args.steps / elapsed
+    per_step = [round(1e3 * t / args.steps, 4) for t in times]
     line = {
         "metric": "CT volumes/sec (256^3 fp16) through u2Tokenizer fwd", "value": round(value, 3),
         "unit": "volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "repeats": {"n": args.repeats, "ms_per_step_each": per_step, "ms_per_step_min": min(per_step),
+                    "ms_per_step_max": max(per_step), "value_is": "median repeat"},
         "tokens_per_s": round(value * Q, 1),
+        "in_flight": (f"{args.streams} volumes per GPU on {args.streams} HIP streams: ms_per_step = elapsed / steps is the "
+                      "reciprocal of the throughput, NOT the latency of a volume (that is ms_per_step_one_stream)"
+                      if streams is not None else "1 volume per GPU"),
         "value_one_stream": round(world * B * args.steps / single, 3) if single else None,
+        "ms_per_step_one_stream": round(1e3 * single / args.steps, 4) if single else None,
         "path_tflops": round(value * fl["total"] / 1e12, 1),
         "path_frac_of_bf16_mfma_peak": round(value * fl["total"] / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
-        "config": {"workload": "BASELINE configs[2]: u2Qwen3-8B-shaped path, 256^3 volume = 8x(32,256,256) fp16, "
-                               "ViT-B 3D x12, SPP, 4-layer rma+diffts+dmtp tokenizer (8 heads, top_k 1024, scales "
-                               "{1,2,4}, 256 queries), text 1024, prompt 1024",
-                   "hidden_size": E, "batch_per_gpu": B, "streams_per_gpu": args.streams, "flop_per_volume": fl["total"],
-                   "parallelism": f"replicas x{world}"},
+        "config": {"workload": WORKLOAD, "hidden_size": E, "batch_per_gpu": B, "streams_per_gpu": args.streams,
+                   "flop_per_volume": fl["total"], "parallelism": f"replicas x{world}"},
     }
+    if args.stub_cpu:
+        line.update({"data": "stub (launcher self-test, no GPU work)", "valid": False})
 
-    if rank == 0 and not args.no_roofline:
-        h = _lib.load_library()
+    if rank == 0 and not args.no_roofline and not args.stub_cpu:
         import ctypes as C
         ops.set_option("profile", 1)
         nprof = 3
         for i in range(nprof):
             step(i, multi=False)  # one stream: a kernel's own duration, not stretched by a co-running volume
         torch.cuda.synchronize()
+        h = _lib.load_library()
+        h.u2tok_ctx_set_current(ops.active_context(device).handle)
         ms, flops, byts, cnt = (C.c_double * 5)(), (C.c_double * 5)(), (C.c_double * 5)(), (C.c_int64 * 5)()
         _lib.check(h.u2tok_profile_collect2(ms, flops, byts, cnt, 5), "u2tok_profile_collect2")
         ops.set_option("profile", 0)
-        names = ["gemm_bf16 (gemm_bt_kernel + gemm_bf16_nt_kernel + gemm_splitk_reduce_kernel)", "flash_d64 (flash_dp_kernel)", "temporal_attention_kernel", "row_ops",
-                 "data_movement"]
+        names = ["gemm_bf16 (gemm_bt_kernel + gemm_bf16_nt_kernel + gemm_skinny_kernel + split-K reduce)",
+                 "flash_d64 (flash_dp_kernel)", "temporal_attention_kernel", "row_ops", "data_movement"]
         # per class: time, launches, algorithmic TFLOP/s and algorithmic GB/s (operands + results once) of its launches
         classes = {n: {"ms_per_step": round(ms[i] / nprof, 4), "launches_per_step": cnt[i] // nprof,
                        "tflops": round(flops[i] / ms[i] / 1e9, 1) if ms[i] > 0 and flops[i] > 0 else None,
                        "algorithmic_gbytes_per_s": round(byts[i] / ms[i] / 1e6, 1) if ms[i] > 0 and byts[i] > 0 else None}
                    for i, n in enumerate(names)}
-        achieved = flops[0] / ms[0] / 1e9
-        # HBM-side bytes of the same kernel class come from rocprofv3 PMC passes of THIS command (a process cannot
-        # read its own counters): tools/gpu_round.sh -> tools/pmc_traffic.py -> profiles/r01_traffic.json
-        traffic, traffic_src = None, None
-        tfile = ROOT / "profiles" / "r01_traffic.json"
-        if tfile.exists() and E == 4096 and B == 1:
-            tj = json.loads(tfile.read_text())["kernels"].get("gemm_bf16")
-            if tj:
-                # per GEMM call as counted here (a call = its main kernel + the 128^2 launch of its row tail / the
-                # split-K reduce where used: 198 dispatches for 137 calls), so that it compares with the algorithmic bytes
-                traffic = round(tj["hbm_bytes_per_step"] / max(cnt[0] // nprof, 1))
-                traffic_src = ("profiles/r01_traffic.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per volume / GEMM calls "
-                               "per volume, rocprofv3 --pmc, separate passes; fabric-side requests (Infinity Cache hits "
-                               "included)")
-        line["roofline"] = {"bound": "mfma", "kernel": "bf16 MFMA GEMM, all launches of one step (gemm_bt_kernel 256x256/256x192 tiles, gemm_bf16_nt_kernel 128^2/64^2 tiles, gemm_splitk_reduce_kernel)",
-                            "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                            "traffic_unit": "bytes per launch (average)", "traffic_source": traffic_src,
-                            "algorithmic_bytes_per_launch": round(byts[0] / max(cnt[0], 1)),
-                            "avg_launch_us": round(1e3 * ms[0] / cnt[0], 2),
-                            "flop_per_step": flops[0] / nprof, "classes": classes}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(E, Lt)
+        # HBM-side bytes of the kernel classes come from rocprofv3 PMC passes of THIS command (a process cannot read
+        # its own counters): tools/gpu_round.sh -> tools/pmc_traffic.py -> profiles/rNN_traffic.json (newest round)
+        traffic = {}
+        tfiles = sorted((ROOT / "profiles").glob("r*_traffic.json"))
+        if tfiles and E == 4096 and B == 1:
+            tj = json.loads(tfiles[-1].read_text())["kernels"]
+            for key, idx in (("gemm_bf16", 0), ("flash_d64", 1)):
+                if key in tj and cnt[idx]:
+                    # per call as counted here (a GEMM call = its main kernel + row-tail / split-K reduce launches)
+                    traffic[key] = (round(tj[key]["hbm_bytes_per_step"] / max(cnt[idx] // nprof, 1)),
+                                    f"{tfiles[-1].relative_to(ROOT)}: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per volume / "
+                                    "calls per volume; rocprofv3 --pmc, separate passes of this command; fabric-side "
+                                    "requests (Infinity Cache hits included)")
+
+        def roof(idx, key, kernel):
+            ach = flops[idx] / ms[idx] / 1e9
+            tr = traffic.get(key, (None, None))
+            return {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": tr[0],
+                    "traffic_unit": "bytes per launch (average)", "traffic_source": tr[1],
+                    "algorithmic_bytes_per_launch": round(byts[idx] / max(cnt[idx], 1)),
+                    "avg_launch_us": round(1e3 * ms[idx] / max(cnt[idx], 1), 2), "flop_per_step": flops[idx] / nprof,
+                    "measured": "HIP events on the launch stream around every launch of the class, one-stream "
+                                "instrumented pass of 3 steps after the timed region"}
+
+        line["roofline"] = roof(0, "gemm_bf16", "bf16 MFMA GEMM, all launches of one step (gemm_bt_kernel 256x256 / 256x192 "
+                                                "tiles, gemm_bf16_nt_kernel 128^2 / 64^2 tiles, skinny / split-K kernels)")
+        line["roofline"]["classes"] = classes
+        if ms[1] > 0:
+            line["roofline_attention"] = roof(1, "flash_d64", "flash_dp_kernel: ViT attention, 8 chunks x 12 heads x 2049 "
+                                                               "tokens x head dim 64 (MONAI SABlock, vit.py:100-105)")
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stub_cpu:
+        line["cpu_baseline"] = cpu_baseline(E, Lt, iters=args.cpu_baseline_iters)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

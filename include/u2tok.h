@@ -11,7 +11,8 @@
  *   - all pointers are DEVICE pointers (HBM) unless the name says `host`; tensors are dense row-major;
  *   - "bf16" = raw bfloat16 bits (uint16_t); parameters are expected in bf16 (model.to(torch.bfloat16));
  *   - work is enqueued on `stream` (a hipStream_t, e.g. torch.cuda.current_stream().cuda_stream);
- *     nothing allocates, nothing synchronises, the caller owns every buffer including the workspace;
+ *     nothing allocates device memory, nothing synchronises, the caller owns every buffer including the workspace;
+ *   - work is launched on the CURRENT HIP device: make the device of the buffers current first (hipSetDevice);
  *   - return value: 0 = success, negative = U2TOK_ERR_* (the Python shim raises RuntimeError).
  */
 #ifndef U2TOK_H_
@@ -36,22 +37,35 @@ typedef void* u2tok_stream_t; /* hipStream_t */
 int u2tok_version(void);               /* MAJOR*10000 + MINOR*100 + PATCH */
 const char* u2tok_arch(void);          /* "gfx950" */
 int u2tok_device_check(void);          /* 0 if the current HIP device is gfx950, else U2TOK_ERR_DEVICE */
-int u2tok_set_option(const char* name, int value); /* tuning / diagnostics switches, U2TOK_ERR_ARG if unknown:
-    "gemm_glds" {0 register staging, 1 LDS-DMA burst (default), 2 LDS-DMA between the MFMAs}, "gemm_tile" {0,64,128},
-    "gemm_bk" {32,64}, "gemm_pp" {-1 never, 0 heuristic, 1..7 force a ping-pong variant, 10..17 measurement builds,
-    20 / 21 force the 256x256 / 256x192 big-tile kernel}, "gemm_splitk" {-1 never, 0 heuristic, 2..16 force that many
-    K slices where scratch allows}, "gemm_pp_grid" {persistent workgroups}, "flash_mode" {0 pick, 1 128-row units,
-    2 256-row units, 3 one of each, 4 8-wave ping-pong, 5 double pipeline (asm KV loop)}, "vit_flash" {0 unfused
-    attention, 1}, "tta_overlap" {0,1 side stream for the TTA k|v projections}, "profile" {0,1} */
-/* Scratch for split-K partial sums of u2tok_gemm_bf16 calls on `stream` (fp32, slices x M x N): skinny products
- * (few output tiles, long K) are cut along K when a scratch is registered; NULL / 0 removes it.  The module
- * forwards below carve their own from their workspace and do not need this. */
+/* ---- execution contexts --------------------------------------------------------------------------------------------
+ * Options, the tokenizer's side streams / events (one set per caller stream), split-K scratch registrations and
+ * profiling records belong to a CONTEXT.  A host thread works on its current context: the one bound with
+ * u2tok_ctx_set_current (thread-local, like hipSetDevice), or the process default context when none is bound.  Give
+ * every model -- or every host thread -- its own context and they share no mutable state; a context used from several
+ * threads at once is safe for launches as long as its options are not changed concurrently.  A context's side streams
+ * are created on the HIP device that is current at their first use: keep one context per device. */
+typedef struct u2tok_ctx* u2tok_ctx_t;
+int u2tok_ctx_create(u2tok_ctx_t* out);
+int u2tok_ctx_destroy(u2tok_ctx_t ctx);      /* no work of this context may still be being enqueued */
+int u2tok_ctx_set_current(u2tok_ctx_t ctx);  /* NULL: back to the process default context */
+u2tok_ctx_t u2tok_ctx_get_current(void);     /* NULL when the thread uses the default context */
+
+/* Tuning / diagnostics switches of the calling thread's current context; U2TOK_ERR_ARG if unknown / out of range:
+    "gemm_tile" {0 heuristic, 64, 128: tile of the small-tile kernel}, "gemm_splitk" {-1 never, 0 heuristic, 2..16 force
+    that many K slices where scratch allows}, "gemm_big" {-1 never, 0 heuristic, 20 / 21 force the 256x256 / 256x192
+    big-tile kernel}, "gemm_big_grid" {persistent workgroups}, "gemm_big_gelu" {0, 1: GELU products may take the
+    big-tile kernel}, "gemm_skinny" {-1 never, 0 heuristic, 1 force the weight-streaming kernel for M <= 256},
+    "flash_mode" {0 pick, 1 plain 128-row units, 5 double pipeline (asm KV loop), 6 double pipeline + split-KV second
+    pass}, "vit_flash" {0 unfused attention, 1}, "tta_overlap" {0, 1: side stream for the TTA k|v projections},
+    "profile" {0, 1} */
+int u2tok_set_option(const char* name, int value);
+/* Scratch for split-K partial sums of u2tok_gemm_bf16 calls on `stream` (fp32, slices x M x N), registered on the
+ * current context: skinny products (few output tiles, long K) are cut along K when a scratch is registered; NULL / 0
+ * removes it.  The module forwards below carve their own from their workspace and do not need this. */
 int u2tok_set_gemm_scratch(void* device_ptr, size_t bytes, void* stream);
-/* Diagnostics only: device buffer (>= 256*8*5 uint64) that the s_memtime-instrumented builds of the ping-pong GEMM
- * (u2tok_set_option("gemm_pp", 14..17)) fill with per-wave segment timings; NULL detaches it. */
-int u2tok_debug_buffer(void* device_ptr);
-/* Same for the flash attention kernel: >= grid*4*8 uint64, zeroed by the caller; while attached the kernel runs its
- * s_memtime-instrumented build and ADDS per-phase cycle sums per (workgroup, wave). */
+/* Diagnostics only, process-wide (not for concurrent use): device buffer (>= grid*4*8 uint64, zeroed by the caller)
+ * for the flash attention kernel; while attached the kernel runs its s_memtime-instrumented build and ADDS per-phase
+ * cycle sums per (workgroup, wave). */
 int u2tok_flash_debug_buffer(void* device_ptr);
 
 /* With option "profile" = 1 every launch is bracketed by hipEvents on its stream.  Collect (HOST arrays of ncat <= 5
@@ -114,7 +128,7 @@ typedef struct {
   int32_t num_query;       /* num_3d_query_token */
   int32_t use_multi_scale; /* bool */
   int32_t attn_type;       /* 0 = "rma" (RelativeMultiheadAttention), 1 = "rope", 2 = nn.MultiheadAttention read
-                              sequence-first (every other attn_type string, svr.py:16-18); 2 needs B == 1 */
+                              sequence-first (every other attn_type string, svr.py:16-18): attends across batch entries */
   int32_t enable_diffts;   /* bool: DifferentiableTokenSelection vs TokenSelection */
   int32_t enable_dmtp;     /* bool: DynamicMultiScalePooling */
   int32_t max_seq_len;     /* 512: rma.py:6 / rope.py:19 */

@@ -21,6 +21,23 @@ TOKENIZER_CASES = {
     # attn_type outside {rma, rope} -> stock nn.MultiheadAttention read sequence-first (the "linvt" ablation)
     "linvt_2l": dict(_B, E=512, layers=2, B=1, T=4, N=24, Lt=20, Q=16, top_k=32, use_multi_scale=True,
                      attn_type="linvt", enable_diffts=True, enable_dmtp=True, seed=15),
+    # ---- "lively" parameter sets (synth.lively_scale): attention stays selective through the residual-free SVR stack,
+    # so token-dependent data reaches the selection, pooling and aggregation stages (the plain sets above collapse to
+    # the token mean after two SVR layers -- they pin the bias / table / layout paths, these pin the data path).
+    # shipped flavour, full depth (4 layers), T = 8 chunks like a 256^3 volume
+    "mu2_4l_live": dict(_B, E=512, layers=4, B=2, T=8, N=32, Lt=40, Q=32, top_k=96, use_multi_scale=True,
+                        attn_type="rma", enable_diffts=True, enable_dmtp=True, seed=16, lively=True),
+    # hard top-k on selective attention output: the reference's torch.topk order must equal the canonical order
+    "hard_2l_live": dict(_B, E=512, layers=2, B=2, T=4, N=32, Lt=24, Q=16, top_k=48, use_multi_scale=True,
+                         attn_type="rma", enable_diffts=False, enable_dmtp=True, seed=17, lively=True),
+    "rope_2l_live": dict(_B, E=512, layers=2, B=1, T=5, N=24, Lt=18, Q=12, top_k=40, use_multi_scale=True,
+                         attn_type="rope", enable_diffts=True, enable_dmtp=False, seed=18, lively=True),
+    # T > 16 chunks (the reference's own smoke uses 64 frames, svr.py:190-205)
+    "mu2_t24_live": dict(_B, E=512, layers=1, B=1, T=24, N=16, Lt=16, Q=16, top_k=64, use_multi_scale=True,
+                         attn_type="rma", enable_diffts=True, enable_dmtp=True, seed=19, lively=True),
+    # nn.MultiheadAttention read sequence-first with B = 2: attention runs ACROSS the batch entries (svr.py:28-35)
+    "linvt_b2_live": dict(_B, E=512, layers=2, B=2, T=4, N=24, Lt=20, Q=16, top_k=32, use_multi_scale=True,
+                          attn_type="linvt", enable_diffts=True, enable_dmtp=True, seed=20, lively=True),
 }
 
 SPP_CASES = {

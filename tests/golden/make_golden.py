@@ -78,8 +78,8 @@ def install_monai_stub():
     sys.modules["monai.networks.blocks.transformerblock"].TransformerBlock = TransformerBlock
 
 
-def fill(module, prefix, seed):
-    synth.fill_module_(module, seed=seed, prefix=prefix)
+def fill(module, prefix, seed, lively=False):
+    synth.fill_module_(module, seed=seed, prefix=prefix, lively=lively)
 
 
 def save(name, **arrs):
@@ -93,13 +93,15 @@ sys.path.insert(0, str(ROOT / "tests"))
 from cases import TOKENIZER_CASES, SPP_CASES, VIT_CASES, FULL_CASES, tokenizer_inputs, spp_inputs  # noqa: E402
 
 
-def gen_tokenizer():
+def gen_tokenizer(only=None):
     from src.model.u2tokenizer.u2Tokenizer import u2Tokenizer
     for name, c in TOKENIZER_CASES.items():
+        if only and name not in only:
+            continue
         m = u2Tokenizer(embed_size=c["E"], num_heads=c["heads"], num_layers=c["layers"], top_k=c["top_k"],
                         use_multi_scale=c["use_multi_scale"], num_3d_query_token=c["Q"], hidden_size=c["E"],
                         attn_type=c["attn_type"], enable_diffts=c["enable_diffts"], enable_dmtp=c["enable_dmtp"]).eval()
-        fill(m, "u2tokenizer.", c["seed"])
+        fill(m, "u2tokenizer.", c["seed"], c.get("lively", False))
         v, t = tokenizer_inputs(c)
         out = m(v_token=v, t_token=t)
         extra = {}
@@ -109,6 +111,14 @@ def gen_tokenizer():
             sc = m.svt_module.token_selection.score_net(x).squeeze(-1).view(v.shape[0], -1)
             extra["ref_topk_idx"] = torch.topk(sc, c["top_k"], dim=1).indices
             extra["ref_scores"] = sc
+        if c.get("lively"):  # record how much token-to-token variation the reference's SVR output carries
+            x = m.svt_module.attention_network(v)
+            x = x.reshape(-1, x.shape[-1])
+            extra["svr_diversity"] = (x - x.mean(0, keepdim=True)).pow(2).mean().sqrt() / x.pow(2).mean().sqrt()
+            # the same reference module in float64: selective softmaxes amplify fp32 summation-order noise to ~1e-4,
+            # the fp64 run pins the ALGORITHM to 1e-10 (tests/test_oracle_golden.py compares the oracle in fp64)
+            extra["out64"] = m.double()(v_token=v.double(), t_token=t.double())
+            m.float()
         save(f"tokenizer_{name}", out=out, **extra)
 
 
@@ -177,4 +187,7 @@ def gen_keys():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["tokenizer", "spp", "vit", "full"]
     for w in which:
-        globals()["gen_" + w]()
+        if w.startswith("tokenizer:"):  # tokenizer:case1,case2 -> only those cases
+            gen_tokenizer(set(w.split(":", 1)[1].split(",")))
+        else:
+            globals()["gen_" + w]()

@@ -21,10 +21,20 @@ def tok_cfg(c) -> O.PathConfig:
                         enable_diffts=c["enable_diffts"], enable_dmtp=c["enable_dmtp"], max_seq_len=c["max_seq_len"])
 
 
-def module_sd(module, prefix, seed, dtype=torch.float32):
+def module_sd(module, prefix, seed, dtype=torch.float32, lively=False):
     """Name-seeded synthetic state dict for `module` (keys prefixed), in `dtype`."""
-    return {prefix + k: synth.synth_tensor(prefix + k, v.shape, seed).to(dtype)
-            for k, v in module.state_dict().items() if v.is_floating_point()}
+    sd = {}
+    for k, v in module.state_dict().items():
+        if v.is_floating_point():
+            t = synth.synth_tensor(prefix + k, v.shape, seed)
+            sd[prefix + k] = (synth.lively_(prefix + k, t) if lively else t).to(dtype)
+    return sd
+
+
+def diversity(x: torch.Tensor) -> float:
+    """RMS of the token-to-token variation relative to the RMS of the tensor (0 = all tokens identical)."""
+    x = x.double().reshape(-1, x.shape[-1])
+    return ((x - x.mean(0, keepdim=True)).pow(2).mean().sqrt() / x.pow(2).mean().sqrt().clamp_min(1e-30)).item()
 
 
 def err_stats(a: torch.Tensor, b: torch.Tensor):

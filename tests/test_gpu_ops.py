@@ -44,13 +44,9 @@ def close_f32(got, ref):
 D = "cuda"
 
 
-@pytest.mark.parametrize("glds", [0, 1])
 @pytest.mark.parametrize("tile", [64, 128])
-@pytest.mark.parametrize("bk", [32, 64])
-def test_gemm_shapes_and_epilogues(ops, glds, tile, bk):
-    ops.set_option("gemm_glds", glds)
+def test_gemm_shapes_and_epilogues(ops, tile):
     ops.set_option("gemm_tile", tile)
-    ops.set_option("gemm_bk", bk)
     try:
         for (M, N, K) in [(128, 128, 64), (300, 200, 136), (77, 520, 72), (1, 8, 8), (2049, 768, 768)]:
             a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
@@ -68,8 +64,6 @@ def test_gemm_shapes_and_epilogues(ops, glds, tile, bk):
         close_f32(ops.gemm(a3.to(D), b3.to(D), out_f32=True), torch.einsum("zmk,znk->zmn", a3.float(), b3.float()))
     finally:
         ops.set_option("gemm_tile", 0)
-        ops.set_option("gemm_glds", 1)
-        ops.set_option("gemm_bk", 64)
 
 
 def test_gemm_full_size_is_exact_on_integer_data(ops):
@@ -200,7 +194,7 @@ def test_rope(ops):
 
 
 @pytest.mark.parametrize("B,T,N,H,d", [(1, 8, 6, 8, 512), (2, 4, 5, 8, 256), (1, 2, 16, 8, 64), (1, 3, 7, 4, 128),
-                                       (1, 16, 3, 2, 64), (1, 1, 4, 2, 64)])
+                                       (1, 16, 3, 2, 64), (1, 1, 4, 2, 64)])  # T > 16 / other head dims: pipeline path
 def test_temporal_attention(ops, B, T, N, H, d):
     E = H * d
     qkv, tbl = rnd(B * T * N, 3 * E, seed=d), rnd(1023, H, scale=0.5, seed=3)
@@ -221,10 +215,10 @@ def _sdpa_ref(qkv, nb, S, H):
 
 @pytest.mark.parametrize("nb,S,H,scale", [(1, 64, 1, 1.0), (2, 129, 3, 1.0), (1, 513, 12, 1.0), (1, 2049, 2, 1.0),
                                           (3, 100, 12, 1.0), (1, 300, 2, 3.0), (1, 1, 1, 1.0)])
-@pytest.mark.parametrize("mode", [1, 2, 4, 5])
+@pytest.mark.parametrize("mode", [1, 5])
 def test_flash_attention(ops, nb, S, H, scale, mode):
-    """scale 3.0 makes the logits spiky so the online-softmax rescale branch does real work.  mode = rows per
-    workgroup unit (128: one 32-row block per wave, 256: two)."""
+    """scale 3.0 makes the logits spiky so the online-softmax rescale branch does real work.  mode 1 = plain 128-row
+    units, mode 5 = the double pipeline (256-row units, generated asm KV loop)."""
     qkv = rnd(nb, S, 3 * H * 64, scale=scale, seed=S)
     ops.set_option("flash_mode", mode)
     try:
@@ -234,16 +228,16 @@ def test_flash_attention(ops, nb, S, H, scale, mode):
     close_bf16(got, _sdpa_ref(qkv, nb, S, H))
 
 
-@pytest.mark.parametrize("nb,S,H,scale,mode", [(2, 129, 3, 1.0, 1), (1, 513, 12, 1.0, 2), (3, 257, 2, 1.0, 3),
-                                               (1, 2049, 3, 1.0, 0), (1, 2049, 3, 1.0, 1), (1, 2049, 3, 1.0, 2),
-                                               (1, 2049, 3, 1.0, 4), (2, 321, 3, 3.0, 4), (1, 66, 2, 1.0, 4),
-                                               (3, 101, 12, 3.0, 0), (1, 2, 1, 1.0, 0), (1, 2, 1, 1.0, 4),
+@pytest.mark.parametrize("nb,S,H,scale,mode", [(2, 129, 3, 1.0, 1), (1, 513, 12, 1.0, 1), (3, 257, 2, 1.0, 1),
+                                               (1, 2049, 3, 1.0, 0), (1, 2049, 3, 1.0, 1),
+                                               (3, 101, 12, 3.0, 0), (1, 2, 1, 1.0, 0),
                                                (1, 2049, 3, 1.0, 5), (2, 321, 3, 3.0, 5), (1, 66, 2, 1.0, 5), (1, 2, 1, 1.0, 5),
-                                               (2, 577, 3, 1.0, 5), (1, 34, 1, 3.0, 5), (1, 97, 2, 3.0, 5)])
+                                               (2, 577, 3, 1.0, 5), (1, 34, 1, 3.0, 5), (1, 97, 2, 3.0, 5),
+                                               (1, 2049, 3, 1.0, 6), (2, 513, 6, 1.0, 6), (1, 257, 3, 3.0, 6)])
 def test_flash_attention_extra_row(ops, nb, S, H, scale, mode):
     """The ViT path: S - 1 tiled main rows + one "extra" row per batch (the cls token) as key AND query.  The result
-    must equal plain attention over all S rows.  mode 3 (one 256-row + one 128-row unit per workgroup) needs
-    (S - 1) % 256 == 0 and nb * H % 3 == 0; the launcher falls back to mode 1 otherwise."""
+    must equal plain attention over all S rows.  mode 6 (double pipeline + split-KV second pass) needs (S - 1) % 256 == 0
+    and nb * H % 3 == 0; the launcher falls back to mode 5 otherwise."""
     qkv = rnd(nb, S, 3 * H * 64, scale=scale, seed=S + 1)
     ops.set_option("flash_mode", mode)
     try:
@@ -327,21 +321,22 @@ def test_gemm_ktile_major_weights(ops):
         torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 20, 21])
-def test_gemm_pingpong_variants(ops, variant):
-    """gemm_pp.hip (persistent 256 x BN ping-pong kernel) forced on shapes with row / column / K tails, several
-    tiles per workgroup, every fused epilogue, batches; each product is launched 3 times and must repeat bit for
-    bit (a race between the LDS-DMA ring and the fragment reads would not)."""
-    ops.set_option("gemm_pp", variant)
+@pytest.mark.parametrize("variant", [20, 21])
+def test_gemm_big_tile_variants(ops, variant):
+    """gemm_bt.hip (persistent 256 x 256 / 256 x 192 big-tile kernel, asm K loop) forced on shapes with row / column
+    tails, several tiles per workgroup, every fused epilogue, batches; each product is launched 3 times and must
+    repeat bit for bit (a race between the LDS-DMA ring and the fragment reads would not).  Shapes the kernel cannot
+    take (K % 64 != 0, K < 128) fall through to the small-tile kernel."""
+    ops.set_option("gemm_big", variant)
     try:
-        for (M, N, K) in [(256, 256, 64), (300, 200, 136), (77, 520, 72), (1000, 768, 1024), (2049, 768, 768),
+        for (M, N, K) in [(256, 256, 128), (300, 200, 136), (77, 520, 192), (1000, 768, 1024), (2049, 768, 768),
                           (5000, 1536, 256)]:
             a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
             ad, bd = a.to(D), b.to(D)
             outs = [ops.gemm(ad, bd).clone() for _ in range(3)]
             assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
             close_bf16(outs[0], a.float() @ b.float().t())
-        M, N, K = 515, 264, 200
+        M, N, K = 515, 264, 192
         a, b, bias, res = rnd(M, K, seed=3), rnd(N, K, seed=4), rnd(N, seed=5), rnd(M, N, seed=6)
         base = a.float() @ b.float().t()
         ad, bd, biasd, resd = a.to(D), b.to(D), bias.to(D), res.to(D)
@@ -351,14 +346,14 @@ def test_gemm_pingpong_variants(ops, variant):
         close_bf16(ops.gemm(ad, bd, residual=resd), base + res.float())
         close_f32(ops.gemm(ad, bd, bias=biasd, out_f32=True, alpha=0.5), 0.5 * base + bias.float())
         close_f32(ops.gemm(ad, bd, out_f32=True), base)
-        a3, b3 = rnd(6, 300, 64, seed=10), rnd(6, 96, 64, seed=11)
+        a3, b3 = rnd(6, 300, 128, seed=10), rnd(6, 96, 128, seed=11)
         close_f32(ops.gemm(a3.to(D), b3.to(D), out_f32=True), torch.einsum("zmk,znk->zmn", a3.float(), b3.float()))
     finally:
-        ops.set_option("gemm_pp", 0)
+        ops.set_option("gemm_big", 0)
 
 
 def test_gemm_heuristic_split_rows(ops):
-    """M = 8 * 2049 (the ViT's row count): the launcher sends 16384 rows to the ping-pong kernel and the 8 leftover
+    """M = 8 * 2049 (the ViT's row count): the launcher sends 16384 rows to the big-tile kernel and the 8 leftover
     rows to the small-tile kernel; the seam must be invisible."""
     M, N, K = 16392, 768, 768
     a, b, bias, res = rnd(M, K, seed=21), rnd(N, K, seed=22), rnd(N, seed=23), rnd(M, N, seed=24)

@@ -45,7 +45,7 @@ def _mk_tok(c):
     m = u2Tokenizer(embed_size=c["E"], num_heads=c["heads"], num_layers=c["layers"], top_k=c["top_k"],
                     use_multi_scale=c["use_multi_scale"], num_3d_query_token=c["Q"], hidden_size=c["E"],
                     attn_type=c["attn_type"], enable_diffts=c["enable_diffts"], enable_dmtp=c["enable_dmtp"])
-    synth.fill_module_(m, seed=c["seed"], prefix="u2tokenizer.")
+    synth.fill_module_(m, seed=c["seed"], prefix="u2tokenizer.", lively=c.get("lively", False))
     return m
 
 
@@ -54,21 +54,25 @@ def test_tokenizer_vs_reference(name):
     c = TOKENIZER_CASES[name]
     g = load_golden(f"tokenizer_{name}")
     m = _mk_tok(c)
-    sd16 = module_sd(m, "u2tokenizer.", c["seed"], bf)
+    sd16 = module_sd(m, "u2tokenizer.", c["seed"], bf, lively=c.get("lively", False))
     m = m.to(bf).to(D)
     m.capture_svr_tokens = True
     v, t = tokenizer_inputs(c)
     got = m(v_token=v.to(bf).to(D), t_token=t.to(bf).to(D))
-    o16, _ = O.tokenizer_forward(sd16, "u2tokenizer", v.to(bf), t.to(bf), tok_cfg(c))
+    o16, oidx16 = O.tokenizer_forward(sd16, "u2tokenizer", v.to(bf), t.to(bf), tok_cfg(c))
     check_vs_reference(got, g["out"], o16, name)
     if not c["enable_diffts"]:
         # index gate: replay the oracle's selection on the tokens the HIP selection stage actually saw
         svr = m.last_svr_tokens.cpu().view(c["B"], c["T"], c["N"], c["E"])
         _, oidx = O.token_selection(sd16, "u2tokenizer.svt_module.token_selection", svr, c["top_k"])
         assert torch.equal(m.last_topk_indices.cpu(), oidx)
-        # and, informational for the end-to-end order: overlap with the fp32 reference's set
-        ref_set, got_set = set(g["ref_topk_idx"][0].tolist()), set(m.last_topk_indices[0].tolist())
-        assert len(ref_set & got_set) >= int(0.8 * c["top_k"])
+        # end to end against the fp32 reference's indices: at least as close as the reference's own bf16 run is
+        # (minus one index of slack per 32 -- both are perturbations of the same fp32 scores by bf16 rounding)
+        for r in range(c["B"]):
+            ref_set = set(g["ref_topk_idx"][r].tolist())
+            hip_ov = len(ref_set & set(m.last_topk_indices[r].tolist()))
+            orc_ov = len(ref_set & set(oidx16[r].tolist()))
+            assert hip_ov >= orc_ov - max(1, c["top_k"] // 32), (hip_ov, orc_ov, c["top_k"])
 
 
 @pytest.mark.parametrize("name", list(SPP_CASES))
@@ -247,38 +251,3 @@ def test_vit_full_size_properties():
         ops.set_option("vit_flash", 1)
     e = err_stats(b.float().cpu(), a[:2].float().cpu())
     assert e["rel_rms"] < 2e-2, e
-
-
-def test_config2_geometry_vs_oracle():
-    """BASELINE configs[1]: 3-scale tokenizer at E = 2048 (Qwen3-1.7B width), 128^3 volumes = 4 chunks of (32,128,128)
-    -> 512 patches (+cls) per chunk, 64 pooled tokens per chunk, batch 4, rma + DiffTS(1024) + DMTP, 256 queries,
-    text 1024.  Whole path ViT -> SPP -> u2Tokenizer against the oracle run in fp32 and in bf16 on the same
-    synthetic parameters (name-seeded), same bar as the golden cases."""
-    from u2tokenizer_amd.projector import SpatialPoolingProjector
-    from u2tokenizer_amd.tokenizer import u2Tokenizer
-    from u2tokenizer_amd.vit import ViT3DTower
-    E, B, C, img = 2048, 4, 4, [32, 128, 128]
-    vit = ViT3DTower(NS(vision_select_layer=-1, vision_select_feature="patch", image_channel=1, image_size=img,
-                        patch_size=[4, 16, 16]))
-    spp = SpatialPoolingProjector(img, [4, 16, 16], 768, E, "mlp", 2, "spatial", 2)
-    tok = u2Tokenizer(E, 8, 4, 1024, True, 256, E, "rma", True, True)
-    sd32, sd16 = {}, {}
-    for prefix, m in (("model.vision_tower.", vit), ("model.mm_projector.", spp), ("model.u2tokenizer.", tok)):
-        synth.fill_module_(m, seed=61, prefix=prefix)
-        for k, v in m.state_dict().items():
-            sd32[prefix + k], sd16[prefix + k] = v.clone(), v.to(bf)
-    vol = synth.synth_volume(B, C, img, seed=61, dtype=torch.float16)
-    t = 0.25 * synth.synth_tensor("t_token", (B, 1024, E), 61)
-    cfg = O.PathConfig(image_size=img, hidden_size=E)
-
-    def oracle(sd, dt):
-        f = O.vit_tower_forward(sd, "model.vision_tower.vision_tower", vol.to(dt).view(B * C, 1, *img), cfg)
-        f = O.spp_forward(sd, "model.mm_projector", f, cfg)
-        return O.tokenizer_forward(sd, "model.u2tokenizer", f.view(B, C, f.shape[-2], E), t.to(dt), cfg)[0]
-
-    ref32, ref16 = oracle(sd32, torch.float32), oracle(sd16, bf)
-    vit, spp, tok = vit.to(bf).to(D), spp.to(bf).to(D), tok.to(bf).to(D)
-    f = spp(vit(vol.to(D).view(B * C, 1, *img)))
-    got = tok(v_token=f.view(B, C, f.shape[-2], E), t_token=t.to(bf).to(D))
-    assert got.shape == (B, 256, E)
-    check_vs_reference(got, ref32, ref16, "config 2 geometry")

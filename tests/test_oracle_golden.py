@@ -27,11 +27,23 @@ def _mk_tok(c):
 def test_tokenizer_matches_reference(name):
     c = TOKENIZER_CASES[name]
     g = load_golden(f"tokenizer_{name}")
-    sd = module_sd(_mk_tok(c), "u2tokenizer.", c["seed"])
+    sd = module_sd(_mk_tok(c), "u2tokenizer.", c["seed"], lively=c.get("lively", False))
     v, t = tokenizer_inputs(c)
     out, idx = O.tokenizer_forward(sd, "u2tokenizer", v, t, tok_cfg(c))
-    e = err_stats(out, g["out"])
-    assert e["max_abs"] <= TOL * max(e["ref_rms"], 1e-3) * 10 and e["rel_rms"] <= TOL, e
+    if c.get("lively"):
+        # the fixture really carries token-dependent data (see cases.py); its selective softmaxes amplify fp32
+        # summation-order differences (BLAS shapes differ: e.g. the reference's 1024-iteration DiffTS loop vs one
+        # product), so the fp32 vectors agree to 3e-4 and the ALGORITHM is pinned in float64 to 1e-9
+        assert float(g["svr_diversity"]) > 0.5
+        sd64 = {k: v.double() for k, v in sd.items()}
+        out64, _ = O.tokenizer_forward(sd64, "u2tokenizer", v.double(), t.double(), tok_cfg(c))
+        e64 = err_stats(out64, g["out64"])
+        assert e64["rel_rms"] <= 1e-9, e64
+        e = err_stats(out, g["out"])
+        assert e["rel_rms"] <= 3e-4, e
+    else:
+        e = err_stats(out, g["out"])
+        assert e["max_abs"] <= TOL * max(e["ref_rms"], 1e-3) * 10 and e["rel_rms"] <= TOL, e
     if not c["enable_diffts"]:
         # index gate: canonical (exact-score, stable) order == the reference's torch.topk order on these seeds
         assert torch.equal(idx, g["ref_topk_idx"]), (idx, g["ref_topk_idx"])

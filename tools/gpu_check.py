@@ -54,11 +54,10 @@ def timeit(fn, iters=10, warm=3):
 
 # ------------------------------------------------------------------------------------------- gemm
 def sec_gemm():
-    for glds in (0, 1):
+    for glds in (1,):
         for tile in (64, 128):
-            ops.set_option("gemm_glds", glds)
             ops.set_option("gemm_tile", tile)
-            print(f"[gemm] glds={glds} tile={tile}", flush=True)
+            print(f"[gemm] tile={tile}", flush=True)
             for (M, N, K) in [(128, 128, 64), (256, 256, 256), (300, 200, 136), (77, 520, 72), (1000, 768, 1024),
                               (2049, 2304, 768)]:
                 a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
@@ -289,10 +288,10 @@ def _pp_cases():
 
 
 def sec_ppc(v=None):
-    """correctness + repeatability of one forced ping-pong variant (python tools/gpu_check.py ppc:<v>)"""
-    vs = [int(x) for x in str(v).split(",")] if v else list(range(1, 8))
+    """correctness + repeatability of one forced big-tile variant (python tools/gpu_check.py ppc:<20|21>)"""
+    vs = [int(x) for x in str(v).split(",")] if v else [20, 21]
     for v in vs:
-        ops.set_option("gemm_pp", v)
+        ops.set_option("gemm_big", v)
         print(f"[pp correctness] variant {v}", flush=True)
         for (M, N, K, kw) in _pp_cases():
             a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
@@ -315,7 +314,7 @@ def sec_ppc(v=None):
         a3, b3 = rnd(6, 300, 64, seed=10), rnd(6, 96, 64, seed=11)
         got = ops.gemm(a3.to(dev), b3.to(dev), out_f32=True)
         stats(f"v{v} batched 6x(300x96x64)", got, torch.einsum("zmk,znk->zmn", a3.float(), b3.float()))
-    ops.set_option("gemm_pp", 0)
+    ops.set_option("gemm_big", 0)
 
 
 PP_PERF_VARIANTS = (-1, 20, 21)
@@ -336,7 +335,7 @@ def sec_coldperf():
         cfgs = [("classic", -1, -1, 0), ("classic split 4", -1, 4, 0), ("heuristic", 0, 0, 0), ("K-tile-major classic", -1, -1, 1),
                 ("K-tile-major split 4", -1, 4, 1), ("K-tile-major split 8", -1, 8, 1)]
         for name, pp, sk, kt in cfgs:
-            ops.set_option("gemm_pp", pp)
+            ops.set_option("gemm_big", pp)
             ops.set_option("gemm_splitk", sk)
             it = [0]
 
@@ -350,7 +349,7 @@ def sec_coldperf():
             line += f" | {name}: {ms * 1e3:6.1f}"
         print(line, flush=True)
         del ws, wt
-    ops.set_option("gemm_pp", 0)
+    ops.set_option("gemm_big", 0)
     ops.set_option("gemm_splitk", 0)
     ops.set_gemm_scratch(None)
 
@@ -389,14 +388,14 @@ def sec_ppperf(shapes_sel=None):
         out = torch.empty((1, M, N), dtype=bf, device=dev)
         line = f"  {M:5d}x{N:5d}x{K:4d} {'+'.join(sorted(kw)) or '-':18s}"
         for v in PP_PERF_VARIANTS:
-            ops.set_option("gemm_pp", v)
+            ops.set_option("gemm_big", v)
             try:
                 ms = timeit(lambda: ops.gemm(a, b, bias=bias, residual=res, gelu=bool(kw.get("gelu")), out=out), iters=8, warm=2)
                 line += f" | {'c' if v < 0 else ('a' if v == 0 else v)} {ms * 1e3:6.1f} {2 * M * N * K / ms / 1e9:5.0f}"
             except Exception as e:  # noqa: BLE001
                 line += f" | {v} ERR"
         print(line, flush=True)
-    ops.set_option("gemm_pp", 0)
+    ops.set_option("gemm_big", 0)
 
 
 def sec_flashperf():
@@ -404,7 +403,7 @@ def sec_flashperf():
     for (nb, S, H, extra) in [(8, 2049, 12, True), (8, 2049, 12, False), (8, 2048, 12, False), (16, 513, 12, True)]:
         qkv = rnd(nb, S, 3 * H * 64, seed=3).to(dev)
         fl = 4 * nb * H * S * S * 64
-        for mode in (2, 3, 5):
+        for mode in (5, 6):
             ops.set_option("flash_mode", mode)
             ms = timeit(lambda: ops.flash_attention_d64(qkv, H, 0.125, extra_last=extra), iters=10)
             # the transpose alone
@@ -427,29 +426,6 @@ def _flash_ref(qkv, H):
     return (p @ x[2]).permute(0, 2, 1, 3).reshape(nb, S, H * 64)
 
 
-def sec_pptime():
-    """s_memtime breakdown of the SB-scheduled ping-pong GEMM (variants 14..17), per group, cycles per segment"""
-    from u2tokenizer_amd import _lib
-    h = _lib.load_library()
-    buf = torch.zeros(256 * 8 * 8, dtype=torch.int64, device=dev)
-    _lib.check(h.u2tok_debug_buffer(buf.data_ptr()), "debug_buffer")
-    for (M, N, K) in [(4096, 4096, 4096), (8192, 8192, 8192), (16384, 3072, 768)]:
-        a, b = rnd(M, K, seed=1).to(dev), rnd(N, K, seed=2).to(dev)
-        out = torch.empty((1, M, N), dtype=bf, device=dev)
-        for v, name in [(14, "SB"), (16, "SB, no setprio"), (15, "SB, no MFMA"), (17, "SB, no DMA")]:
-            ops.set_option("gemm_pp", v)
-            buf.zero_()
-            ms = timeit(lambda: ops.gemm(a, b, out=out), iters=3, warm=1)
-            r = buf.view(256, 2, 4, 8).double()  # [block][group][wave][Lvm, waitL, M, waitM, nseg, Lissue, Lreads, -]
-            n = r[..., 4].clamp_min(1)
-            per = r / n[..., None]
-            g0, g1 = per[:, 0].mean((0, 1)), per[:, 1].mean((0, 1))
-            fmt = lambda g: f"Lissue {g[5]:5.0f} Lreads {g[6]:5.0f} Lvm {g[0]:5.0f} wL {g[1]:5.0f} M {g[2]:5.0f} wM {g[3]:5.0f}"  # noqa: E731
-            print(f"  {M}x{N}x{K} v{v} {name:18s} {ms * 1e3:8.1f} us | G0 {fmt(g0)} | G1 {fmt(g1)}", flush=True)
-    ops.set_option("gemm_pp", 0)
-    h.u2tok_debug_buffer(None)
-
-
 def sec_flashtime():
     """s_memtime phase breakdown of the flash attention kernel (cycles per KV tile per wave)"""
     from u2tokenizer_amd import _lib
@@ -457,7 +433,7 @@ def sec_flashtime():
     nb, S, H = 8, 2049, 12
     qkv = rnd(nb, S, 3 * H * 64, seed=3).to(dev)
     names = ["gload", "QK^T", "softmax", "PV", "wait+lstore", "-", "barrier"]
-    for mode in (3, 5):
+    for mode in (5, 6):
         ops.set_option("flash_mode", mode)
         ms0 = timeit(lambda: ops.flash_attention_d64(qkv, H, 0.125, extra_last=True), iters=5)
         buf = torch.zeros(4096 * 4 * 8, dtype=torch.int64, device=dev)
@@ -468,7 +444,7 @@ def sec_flashtime():
         r = buf.view(-1, 8).double()
         r = r[r[:, 7] > 0]
         per = r[:, :7].sum(0) / r[:, 7].sum()
-        if mode % 10 == 5:
+        if mode % 10 in (5, 6):
             print(f"  mode {mode}: {ms0 * 1e3:7.1f} us untimed | per 64-key tile per wave (2 blocks): phases u=2t {per[0]:6.0f}  dma wait {per[1]:6.0f}  "
                   f"barrier {per[2]:6.0f}  dma issue {per[3]:6.0f}  phases u=2t+1 {per[4]:6.0f}  total {per[:5].sum():6.0f}", flush=True)
             continue
@@ -479,33 +455,6 @@ def sec_flashtime():
         print(f"  mode {mode}: {ms0 * 1e3:7.1f} us untimed | per KV tile per wave: " +
               "  ".join(f"{n} {v:6.0f}" for n, v in zip(names, per.tolist()) if n != "-") + f"  total {per.sum():6.0f}", flush=True)
     ops.set_option("flash_mode", 0)
-
-
-def sec_cperf():
-    """classic GEMM kernel: DMA burst (glds 1) vs DMA pieces between the MFMAs (glds 2), BK 64 vs 32"""
-    ops.set_option("gemm_pp", -1)
-    shapes = [(16384, 2304, 768, {}), (16384, 768, 768, dict(bias=True, residual=True)),
-              (16384, 3072, 768, dict(bias=True, gelu=True)), (16384, 768, 3072, dict(bias=True, residual=True)),
-              (2048, 4096, 4096, dict(bias=True)), (2048, 12288, 4096, dict(bias=True)), (1792, 8192, 4096, dict(bias=True)),
-              (1024, 8192, 4096, dict(bias=True)), (256, 4096, 4096, dict(bias=True)), (256, 12288, 4096, dict(bias=True)),
-              (1024, 2048, 4096, {}), (8192, 8192, 8192, {})]
-    print("[classic perf] us (TF/s) per configuration glds/bk", flush=True)
-    for (M, N, K, kw) in shapes:
-        a, b = rnd(M, K, seed=1).to(dev), rnd(N, K, seed=2).to(dev)
-        bias = rnd(N, seed=3).to(dev) if kw.get("bias") else None
-        res = rnd(M, N, seed=4).to(dev) if kw.get("residual") else None
-        out = torch.empty((1, M, N), dtype=bf, device=dev)
-        line = f"  {M:5d}x{N:5d}x{K:4d} {'+'.join(sorted(kw)) or '-':14s}"
-        for glds in (1, 2):
-            for bk in (64, 32):
-                ops.set_option("gemm_glds", glds)
-                ops.set_option("gemm_bk", bk)
-                ms = timeit(lambda: ops.gemm(a, b, bias=bias, residual=res, gelu=bool(kw.get("gelu")), out=out), iters=8, warm=2)
-                line += f" | g{glds} bk{bk} {ms * 1e3:7.1f} ({2 * M * N * K / ms / 1e9:4.0f})"
-        print(line, flush=True)
-    ops.set_option("gemm_glds", 1)
-    ops.set_option("gemm_bk", 64)
-    ops.set_option("gemm_pp", 0)
 
 
 def sec_preperf():
@@ -536,8 +485,7 @@ def sec_perf():
     shapes = [(16392, 2304, 768), (16392, 768, 768), (16392, 3072, 768), (16392, 768, 3072), (16384, 768, 1024),
               (2048, 4096, 4096), (2048, 2048, 2048), (256, 4096, 4096), (1792, 4096, 4096), (1024, 4096, 4096),
               (4096, 4096, 4096), (8192, 8192, 8192)]
-    for bk in (64, 32):
-        ops.set_option("gemm_bk", bk)
+    for bk in (64,):
         for (M, N, K) in shapes:
             a, b = rnd(M, K, seed=1).to(dev), rnd(N, K, seed=2).to(dev)
             out = torch.empty((1, M, N), dtype=bf, device=dev)
@@ -547,7 +495,6 @@ def sec_perf():
                 print(f"  gemm bk={bk} tile={tile:3d} {M}x{N}x{K}: {ms * 1e3:9.1f} us  {2 * M * N * K / ms / 1e9:8.1f} TF/s",
                       flush=True)
     ops.set_option("gemm_tile", 0)
-    ops.set_option("gemm_glds", 1)
     for (nb, S, H) in [(8, 2049, 12), (16, 513, 12)]:
         qkv = rnd(nb, S, 3 * H * 64, seed=3).to(dev)
         ms = timeit(lambda: ops.flash_attention_d64(qkv, H, 0.125), iters=10)
@@ -561,8 +508,7 @@ def sec_perf():
     synth.fill_module_(vit, seed=0, prefix="vision_tower.")
     vit = vit.to(bf).to(dev)
     vol = synth.synth_volume(1, 8, [32, 256, 256], dtype=torch.float16).view(8, 1, 32, 256, 256).to(dev)
-    for bk in (64, 32):
-        ops.set_option("gemm_bk", bk)
+    for bk in (64,):
         ms = timeit(lambda: vit(vol), iters=5, warm=2)
         print(f"  ViT tower 256^3 (8 chunks) bk={bk}: {ms:8.3f} ms  {4.048e12 / ms / 1e9:8.1f} TF/s", flush=True)
     feats = vit(vol)
@@ -581,8 +527,7 @@ def sec_perf():
                 p.data.normal_(0, 0.02)
         v = spp(feats).view(1, 8, 256, E)
         t = (torch.randn(1, 1024, E, device=dev) * 0.05).to(bf)
-        for bk in (64, 32):
-            ops.set_option("gemm_bk", bk)
+        for bk in (64,):
             ms = timeit(lambda: tok(v_token=v, t_token=t), iters=5, warm=2)
             fl = {2048: 0.888e12, 4096: 3.43e12}[E]
             print(f"  u2Tokenizer E={E} bk={bk}: {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TF/s  "

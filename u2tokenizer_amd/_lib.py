@@ -59,10 +59,13 @@ SIGNATURES = {
     "u2tok_version": (_i32, []),
     "u2tok_arch": (C.c_char_p, []),
     "u2tok_device_check": (_i32, []),
+    "u2tok_ctx_create": (_i32, [C.POINTER(_vp)]),
+    "u2tok_ctx_destroy": (_i32, [_vp]),
+    "u2tok_ctx_set_current": (_i32, [_vp]),
+    "u2tok_ctx_get_current": (_vp, []),
     "u2tok_set_option": (_i32, [C.c_char_p, _i32]),
     "u2tok_profile_collect": (_i32, [_vp, _vp, _vp, _i32]),
     "u2tok_profile_collect2": (_i32, [_vp, _vp, _vp, _vp, _i32]),
-    "u2tok_debug_buffer": (_i32, [_vp]),
     "u2tok_set_gemm_scratch": (_i32, [_vp, _sz, _vp]),
     "u2tok_flash_debug_buffer": (_i32, [_vp]),
     "u2tok_vit_workspace_bytes": (_sz, [C.POINTER(VitConfig)]),

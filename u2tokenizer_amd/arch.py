@@ -99,18 +99,31 @@ class u2MetaForCausalLM(ABC):
         vision_tower = self.get_vision_tower()
         if vision_tower is None or images is None or input_ids.shape[1] == 1:
             return input_ids, position_ids, attention_mask, past_key_values, None, labels
-        embed_w = self.get_model().embed_tokens.weight
+        embed = self.get_model().embed_tokens
+        embed_w = embed.weight
         dev = embed_w.device
-        with torch.no_grad() if not torch.is_grad_enabled() else _nullctx():
-            if self.config.enable_u2tokenizer:
-                B, C, D, H, W = images.shape
-                images = images.to(dev).view(B * C, 1, D, H, W)
-                image_features = self.encode_images(images)
-                v_tokens = image_features.view(B, C, image_features.shape[-2], image_features.shape[-1])
-                t_tokens = ops.embed_splice(embed_w, question_ids.to(dev))
-                image_features = self.get_u2tokenizer()(v_token=v_tokens, t_token=t_tokens)
-            else:
-                image_features = self.encode_images(images.to(dev))
+        # Training with a trainable embedding table (initialize_vision_tokenizer turns it on for the new tokens,
+        # u2_arch.py:131-135): lookup and splice go through autograd (nn.Embedding + cat, as in the reference) so the
+        # table receives its gradient; otherwise the fused HIP gather / splice kernel.
+        track = torch.is_grad_enabled() and embed_w.requires_grad
+
+        def lookup(ids):
+            return embed(ids) if track else ops.embed_splice(embed_w, ids)
+
+        if self.config.enable_u2tokenizer:
+            B, C, D, H, W = images.shape
+            images = images.to(dev).view(B * C, 1, D, H, W)
+            image_features = self.encode_images(images)
+            v_tokens = image_features.view(B, C, image_features.shape[-2], image_features.shape[-1])
+            t_tokens = lookup(question_ids.to(dev))
+            image_features = self.get_u2tokenizer()(v_token=v_tokens, t_token=t_tokens)
+        else:
+            image_features = self.encode_images(images.to(dev))
+        if track or (torch.is_grad_enabled() and image_features.requires_grad):
+            emb = embed(input_ids.to(dev))
+            inputs_embeds = torch.cat((emb[:, :1, :], image_features.to(emb.dtype),
+                                       emb[:, image_features.shape[1] + 1:, :]), dim=1)  # u2_arch.py:113-116
+        else:
             inputs_embeds = ops.embed_splice(embed_w, input_ids.to(dev), image_features)
         return None, position_ids, attention_mask, past_key_values, inputs_embeds, labels
 
@@ -138,11 +151,3 @@ class u2MetaForCausalLM(ABC):
             else:
                 raise ValueError(f"Unexpected embed_tokens_weight shape. Pretrained: {embed_tokens_weight.shape}. "
                                  f"Current: {input_embeddings.shape}. Numer of new tokens: {num_new_tokens}.")
-
-
-class _nullctx:
-    def __enter__(self):
-        return None
-
-    def __exit__(self, *a):
-        return False

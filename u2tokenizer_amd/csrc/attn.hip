@@ -1,6 +1,7 @@
 // Attention cores that do not go through the batched-GEMM path:
 //   * temporal_attention : the across-chunk half of SpatioTemporalAttentionLayer (svr.py:31-36), sequence
-//     length T = number of chunks (<= 16), head dim d = E/8 (256/512).  Reads q/k/v in the (b t n) row
+//     length T = number of chunks (<= 16 here; longer sequences take the batched-GEMM path, pipeline.hip),
+//     head dim d = E/8 in {64, 128, 256, 512}.  Reads q/k/v in the (b t n) row
 //     order the projections produced them in, so neither of the reference's two permute().contiguous()
 //     round trips (svr.py:32,36) touches HBM.
 //   * flash_attention_d64: MONAI SABlock attention of the ViT blocks (vit.py:100-105): S = 2049 tokens,
@@ -164,9 +165,9 @@ int temporal_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t
 //   The online-softmax rescale is lane-local (O^T keeps q = lane&31 per lane) and deferred until some row's
 //   running max grows by more than 2^8 (wave-uniform branch); the softmax scale is folded into one FMA per score;
 //   key masking only in a partial last tile; the extra key is one VALU step after the tile loop.
-// Work split ("mode"): 1 = uniform QB = 1 (128-row units), 2 = uniform QB = 2 (256-row units), 3 = every
-//   workgroup runs one 256-row unit (QB = 2) and then one 128-row unit (QB = 1).  At the ViT's 96 heads x 2048
-//   rows mode 3 is exactly one full wave of 512 workgroups (2 per CU); modes 1 / 2 need 3 / 1.5 rounds.
+// This plain pass (QB = 1, "mode 1") serves short sequences; S >= 512 takes the double pipeline further down
+// ("mode 5").  The QB = 2 / mixed-unit / 8-wave ping-pong forms measured in round 1 (profiles/r01_flash_study.log) were
+// removed from the product in round 2 (history: fc1ca7f).
 // Extra query rows (one per head) are handled by small VALU workgroups at the end of the grid.
 // LDS tiles ([64][64] bf16, 128 B rows): 16-byte chunks XOR-swizzled with (row>>1)&7 -> conflict-free
 // ds_read_b128 for the 32x32 fragment pattern.
@@ -537,9 +538,9 @@ __device__ __forceinline__ void flash_extra_row(const FlashArgs& a, char* lds_ra
   }
 }
 
-// MODE as in FlashArgs::mode; WPS = waves per SIMD the register allocation is held to (workgroups per CU)
-template <int MODE, int WPS, bool TIMED>
-__global__ __launch_bounds__(256, WPS) void flash_d64_kernel(const FlashArgs a) {
+// Plain form (mode 1): 128-row units, 4 waves x 32 query rows, three workgroups per CU.  Used below S = 512, where the
+// double pipeline's 256-row units leave most of the machine idle.
+__global__ __launch_bounds__(256, 3) void flash_d64_kernel(const FlashArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[2][16384];  // [stage][K tile 8 KB | V^T tile 8 KB]
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= a.n_main) {  // extra query rows: one workgroup per (batch, head)
@@ -555,307 +556,10 @@ __global__ __launch_bounds__(256, WPS) void flash_d64_kernel(const FlashArgs a) 
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
   }
-  const int nbh = a.nb * a.H;
-  if constexpr (MODE == 3) {
-    // heads [0, 2 nbh / 3) are cut into 256-row units, heads [2 nbh / 3, nbh) into 128-row units: one of each
-    const int upa = a.S >> 8, upb = a.S >> 7;
-    const int ha = bid / upa, hb = 2 * (nbh / 3) + bid / upb;
-    flash_pass<2, TIMED>(a, lds, ha / a.H, ha % a.H, (bid % upa) * 256, tid);
-    flash_pass<1, TIMED>(a, lds, hb / a.H, hb % a.H, (bid % upb) * 128, tid);
-  } else if constexpr (MODE == 2) {
-    const int nqt = (a.S + 255) >> 8;
-    const int hh = bid / nqt;
-    flash_pass<2, TIMED>(a, lds, hh / a.H, hh % a.H, (bid % nqt) * 256, tid);
-  } else {
-    const int nqt = (a.S + 127) >> 7;
-    const int hh = bid / nqt;
-    flash_pass<1, TIMED>(a, lds, hh / a.H, hh % a.H, (bid % nqt) * 128, tid);
-  }
+  const int nqt = (a.S + 127) >> 7;
+  const int hh = bid / nqt;
+  flash_pass<1, false>(a, lds, hh / a.H, hh % a.H, (bid % nqt) * 128, tid);
 }
-
-// ----------------------------------------------------------------------------------------------------------------
-// Ping-pong form (mode 4).  Measured with s_memtime on MI355X (tools/gpu_check.py flashtime): in the kernel above a
-// 64-key tile costs a wave ~510 cycles of MFMA issue and ~450-900 cycles of softmax VALU (v_exp_f32 is quarter
-// rate: at head dim 64 the VALU work per score is as long as its MFMA work), run one after the other, and the two
-// waves of a SIMD -- from unrelated workgroups -- overlap them only by chance: the matrix pipe is busy ~1/3 of the
-// time.  Here a workgroup is 8 waves = 2 groups of 4 x 32 query rows, waves w and w+4 share a SIMD, and every wave
-// alternates between a matrix-only segment M(t) = { O += P(t) V(t) ;  S(t+1) = K(t+1) Q^T } and a VALU-only segment
-// V(t) = { P(t) = softmax step on S(t) } with an s_barrier after each; group 1 runs one barrier behind group 0, so
-// each SIMD always has one wave in M and one in V.  K / V^T tiles arrive by LDS-DMA (2 x 1 KiB pieces per wave and
-// tile, issued from the V segments) into a ring of 6 slots, 4 tiles ahead, with counted vmcnt waits.
-constexpr int FPP_SLOTS = 6, FPP_AHEAD = 4;
-
-// PRIO: 0 = no s_setprio, 1 = priority on the M segments, 2 = priority on the V segments
-template <bool TIMED, int PRIO>
-__global__ __launch_bounds__(512) void flash_pp_kernel(const FlashArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[FPP_SLOTS][16384];  // [slot][K tile 8 KB | V^T tile 8 KB]
-  const int tid = threadIdx.x;
-  if ((int)blockIdx.x >= a.n_main) {
-    const int e = blockIdx.x - a.n_main;
-    flash_extra_row<512>(a, &lds[0][0], e / a.H, e % a.H, tid);
-    return;
-  }
-  int bid;
-  {
-    const int nwg = a.n_main, qn = nwg >> 3, rn = nwg & 7;
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
-  }
-  const int nqt = (a.S + 255) >> 8;
-  const int hh = bid / nqt, b = hh / a.H, h = hh % a.H, row0 = (bid % nqt) * 256;
-  const int lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7
-  const int grp = wv >> 2;
-  const int hi = lane >> 5, l31 = lane & 31;
-  const int S = a.S, S_pad = a.S_pad;
-  const int64_t ld_qk = a.ld_qk;
-  const float scale_log2e = a.scale_log2e;
-  const bf16_t* qb_ = a.q + (int64_t)b * a.q_bs + h * 64;
-  const bf16_t* kb_ = a.k + (int64_t)b * a.q_bs + h * 64;
-  const bf16_t* vb_ = a.vt + ((int64_t)b * a.H + h) * 64 * S_pad;
-  const int wrow0 = row0 + wv * 32;
-  const int qrow = wrow0 + l31;
-  const int ntile = (S + 63) >> 6;
-
-  bf16x8 qf[4];
-  {
-    const bf16_t* qp = qb_ + (int64_t)min(qrow, S - 1) * ld_qk + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
-  }
-  // DMA pieces of this wave: rows [8 wv, 8 wv + 8) of the K tile and of the V^T tile; lane -> (row, 16-B position);
-  // position p of LDS row r holds global chunk p ^ ((r >> 1) & 7)  (kt_off)
-  const int prow = wv * 8 + (lane >> 3);
-  const int pchunk = (lane & 7) ^ ((prow >> 1) & 7);
-  const bf16_t* vsrc = vb_ + (int64_t)prow * S_pad + pchunk * 8;
-  int t_issue = 0;
-#define FPP_ISSUE_K()                                                                                                 \
-  {                                                                                                                   \
-    const bf16_t* ks_ = kb_ + (int64_t)min(t_issue * 64 + prow, S - 1) * ld_qk + pchunk * 8;                          \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks_,                              \
-                                     (__attribute__((address_space(3))) void*)(lds[t_issue % FPP_SLOTS] + wv * 1024), \
-                                     16, 0, 0);                                                                       \
-  }
-#define FPP_ISSUE_V()                                                                                                 \
-  {                                                                                                                   \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + t_issue * 64),            \
-                                     (__attribute__((address_space(3))) void*)(lds[t_issue % FPP_SLOTS] + 8192 +      \
-                                                                               wv * 1024), 16, 0, 0);                 \
-    ++t_issue;                                                                                                        \
-  }
-#define FPP_ISSUE() \
-  {                 \
-    FPP_ISSUE_K()   \
-    FPP_ISSUE_V()   \
-  }
-#define FPP_BARRIER()                        \
-  do {                                       \
-    __builtin_amdgcn_sched_barrier(0);       \
-    __builtin_amdgcn_s_barrier();            \
-    __builtin_amdgcn_sched_barrier(0);       \
-  } while (0)
-#define FPP_WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
-
-  f32x16 oacc[2], sc[2];
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { oacc[nb][r] = 0.f; sc[nb][r] = 0.f; }
-  float m_run = -INFINITY, l_run = 0.f;
-  union { bf16x8 v; uint32_t u[4]; } pf[4];  // P(t) packed: step (kbk, ks2) = pf[kbk * 2 + ks2]
-
-  // fragments are read in the V segments (under the partner's MFMAs); the M segments are MFMA-only
-  bf16x8 kfr[8], vfr[8];  // K(t+1): [kbk * 4 + ks];  V^T(t): [step * 2 + nb]
-#define FPP_READ_K(t_)                                                                                   \
-  {                                                                                                      \
-    const char* sK_ = lds[(t_) % FPP_SLOTS];                                                             \
-    _Pragma("unroll") for (int kbk = 0; kbk < 2; ++kbk)                                                  \
-      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                   \
-        kfr[kbk * 4 + ks] = *reinterpret_cast<const bf16x8*>(sK_ + kt_off(kbk * 32 + l31, ks * 2 + hi)); \
-  }
-#define FPP_READ_V(t_)                                                                                   \
-  {                                                                                                      \
-    const char* sV_ = lds[(t_) % FPP_SLOTS] + 8192;                                                      \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
-      _Pragma("unroll") for (int nb = 0; nb < 2; ++nb)                                                   \
-        vfr[i * 2 + nb] = *reinterpret_cast<const bf16x8*>(sV_ + kt_off(nb * 32 + l31, i * 2 + hi));     \
-  }
-  // S^T = K Q^T from the fragments in registers
-#define FPP_QK()                                                                                         \
-  {                                                                                                      \
-    _Pragma("unroll") for (int kbk = 0; kbk < 2; ++kbk) {                                                \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) sc[kbk][r] = 0.f;                                   \
-      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                   \
-        sc[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kbk * 4 + ks], qf[ks], sc[kbk], 0, 0, 0);  \
-    }                                                                                                    \
-  }
-
-  unsigned long long ts[4] = {0, 0, 0, 0}, tprev = 0;
-#define FPP_STAMP(i_)                                                  \
-  if constexpr (TIMED) {                                               \
-    const unsigned long long t_ = __builtin_amdgcn_s_memtime();        \
-    ts[i_] += t_ - tprev;                                              \
-    tprev = t_;                                                        \
-  }
-
-  // ---------------- prologue: FPP_AHEAD tiles in flight, tile 0 landed; group 1 starts one barrier later
-#pragma unroll
-  for (int i = 0; i < FPP_AHEAD; ++i)
-    if (i < ntile) FPP_ISSUE()
-  if (ntile >= FPP_AHEAD) FPP_WAIT_VM(2 * (FPP_AHEAD - 1));
-  else FPP_WAIT_VM(0);
-  FPP_BARRIER();
-  if (grp == 1) FPP_BARRIER();
-  if constexpr (TIMED) tprev = __builtin_amdgcn_s_memtime();
-  // segment "P": S(0)
-  FPP_READ_K(0)
-  FPP_QK()
-  FPP_BARRIER();
-
-  for (int t = 0; t < ntile; ++t) {
-    FPP_STAMP(3)
-    // ================= V(t): one online-softmax step on S(t) -> P(t); VALU only (the partner wave is in M)
-    if (t == ntile - 1 && (S & 63)) {
-      const int kvb = t * 64 + 4 * hi;
-#pragma unroll
-      for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (kvb + kbk * 32 + (r & 3) + 8 * (r >> 2) >= S) sc[kbk][r] = -INFINITY;
-    }
-    {
-      float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-      for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx[r & 3] = fmaxf(mx[r & 3], sc[kbk][r]);
-      float mt = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
-      mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale_log2e;
-      if (__any(mt > m_run + FLASH_RESCALE_THR)) {
-        const float m_new = fmaxf(m_run, mt);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        l_run *= alpha;
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[nb][r] *= alpha;
-      }
-      float ps[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-        for (int ks2 = 0; ks2 < 2; ++ks2)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kbk][ks2 * 8 + 2 * j], scale_log2e, -m_run));
-            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kbk][ks2 * 8 + 2 * j + 1], scale_log2e, -m_run));
-            ps[j] += p0 + p1;
-            pf[kbk * 2 + ks2].u[j] = pack2_bf16(p0, p1);
-          }
-      l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
-    }
-    // fragments of the coming M segment; the K half of the DMA for tile t + AHEAD (slot last read 2 segments ago)
-    FPP_READ_V(t)
-    if (t + 1 < ntile) FPP_READ_K(t + 1)
-    const bool more = t_issue < ntile;
-    if (more) {
-      FPP_ISSUE_K()
-      FPP_WAIT_VM(1);  // everything older than that piece (i.e. all of tile t + AHEAD - 1) has landed
-    } else {
-      FPP_WAIT_VM(0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    FPP_STAMP(0)
-    FPP_BARRIER();
-    FPP_STAMP(1)
-    // ================= M(t): O^T += V^T(t) P^T(t), then S(t+1) = K(t+1) Q^T; MFMAs on registers only
-    if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);
-    if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-        oacc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[i * 2 + nb], pf[i].v, oacc[nb], 0, 0, 0);
-    if (t + 1 < ntile) FPP_QK()
-    if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
-    if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(1);
-    if (more) FPP_ISSUE_V()  // the V^T half of the DMA, behind the last MFMA
-    FPP_STAMP(2)
-    FPP_BARRIER();
-  }
-  if (grp == 0) FPP_BARRIER();
-  if constexpr (TIMED) {
-    if (lane == 0 && g_flash_dbg) {
-      unsigned long long* o = g_flash_dbg + ((size_t)blockIdx.x * 8 + wv) * 8;
-      o[0] += ts[0]; o[1] += ts[1]; o[2] += ts[2]; o[3] += ts[3]; o[7] += (unsigned long long)ntile;
-    }
-  }
-#undef FPP_ISSUE
-#undef FPP_ISSUE_K
-#undef FPP_ISSUE_V
-#undef FPP_READ_K
-#undef FPP_READ_V
-#undef FPP_QK
-#undef FPP_STAMP
-  if (wrow0 >= S) return;
-  // ---- the extra key (one per batch), as in flash_pass
-  if (a.n_extra) {
-    const bf16_t* kxp = a.kx + (int64_t)b * a.x_bs + h * 64 + hi * 8;
-    const bf16_t* vxp = a.vx + (int64_t)b * a.x_bs + h * 64 + 4 * hi;
-    float part = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const uint4 kc = *reinterpret_cast<const uint4*>(kxp + ks * 16);
-      union { bf16x8 v; uint32_t u[4]; } qq;
-      qq.v = qf[ks];
-      const uint32_t kw[4] = {kc.x, kc.y, kc.z, kc.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        part = __builtin_fmaf(bf16lo(qq.u[j]), bf16lo(kw[j]), part);
-        part = __builtin_fmaf(bf16hi(qq.u[j]), bf16hi(kw[j]), part);
-      }
-    }
-    const float mt = (part + __shfl_xor(part, 32, 64)) * scale_log2e;
-    if (__any(mt > m_run + FLASH_RESCALE_THR)) {
-      const float m_new = fmaxf(m_run, mt);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
-      l_run *= alpha;
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[nb][r] *= alpha;
-    }
-    const float p = __builtin_amdgcn_exp2f(mt - m_run);
-    l_run += 0.5f * p;
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const uint2 vc = *reinterpret_cast<const uint2*>(vxp + nb * 32 + 8 * g);
-        oacc[nb][4 * g + 0] = __builtin_fmaf(p, bf16lo(vc.x), oacc[nb][4 * g + 0]);
-        oacc[nb][4 * g + 1] = __builtin_fmaf(p, bf16hi(vc.x), oacc[nb][4 * g + 1]);
-        oacc[nb][4 * g + 2] = __builtin_fmaf(p, bf16lo(vc.y), oacc[nb][4 * g + 2]);
-        oacc[nb][4 * g + 3] = __builtin_fmaf(p, bf16hi(vc.y), oacc[nb][4 * g + 3]);
-      }
-  }
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.f / l_tot;
-  if (qrow < S) {
-    bf16_t* op = a.out + (int64_t)b * a.out_bs + (int64_t)qrow * a.ld_out + h * 64;
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d0 = nb * 32 + 8 * g + 4 * hi;
-        *reinterpret_cast<uint2*>(op + d0) = uint2{pack2_bf16(oacc[nb][4 * g] * inv, oacc[nb][4 * g + 1] * inv),
-                                                   pack2_bf16(oacc[nb][4 * g + 2] * inv, oacc[nb][4 * g + 3] * inv)};
-      }
-  }
-}
-#undef FPP_BARRIER
-#undef FPP_WAIT_VM
 
 // ----------------------------------------------------------------------------------------------------------------
 // Double-pipeline form (mode 5).  The measurements behind it (profiles/r01_flash_study.log, tools/ubench/
@@ -1036,9 +740,7 @@ __global__ __launch_bounds__(256, 2) void flash_dp_kernel(const FlashArgs a) {
   fdp_finish(a, x1, qf[1], b, h, wrow0 + 32 + l31, hi);
 }
 
-static int g_flash_mode = 0;  // 0: pick, 1 / 2 / 3: force where legal; + 10 * (workgroups per CU) for mode 1
 static bool g_flash_timed = false;
-void flash_set_mode(int m) { g_flash_mode = m; }
 int flash_set_debug_buffer(void* p) {  // >= grid * 4 * 8 uint64, zeroed by the caller; null detaches
   unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
   g_flash_timed = q != nullptr;
@@ -1063,46 +765,21 @@ int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16
   a.ld_qk = ld_qk; a.q_bs = q_bs; a.ld_out = ld_out; a.out_bs = out_bs; a.x_bs = x_bs; a.ox_bs = ox_bs;
   a.scale_log2e = scale * 1.44269504088896340736f;
   const int64_t nbh = (int64_t)nb * H;
-  const bool mixed_ok = (S % 256 == 0) && (nbh % 3 == 0);
-  int mode = g_flash_mode % 10;
-  const int wps = g_flash_mode / 10;
-  if (mode == 3 && !mixed_ok) mode = 0;
-  if (mode < 1 || mode > 5) mode = S >= 512 ? 5 : (mixed_ok ? 3 : 1);  // measured: mode 5 wins from S = 513 up
-  int64_t blocks;
-  if (mode == 4 || mode == 5) blocks = nbh * ((S + 255) / 256);
-  else if (mode == 3) blocks = nbh * (S / 128) / 3;
-  else if (mode == 2) blocks = nbh * ((S + 255) / 256);
-  else blocks = nbh * ((S + 127) / 128);
+  int mode = opts().flash_mode;
+  if (mode != 1 && mode != 5) mode = S >= 512 ? 5 : 1;  // measured: the double pipeline wins from S = 513 up
+  const int64_t blocks = mode == 5 ? nbh * ((S + 255) / 256) : nbh * ((S + 127) / 128);
   a.mode = mode;
   a.n_main = (int)blocks;
   const int64_t grid = blocks + (n_extra ? nbh : 0);
   if (grid > 0x7fffffff) return U2_ERR_ARG;
   ProfScope ps(PROF_FLASH, 4.0 * nbh * (double)(S + n_extra) * (S + n_extra) * 64, stream,
                4.0 * nbh * (double)(S + n_extra) * 64 * 2.0);  // q, k, v^T read + o written, once
-#define U2_FLASH_LAUNCH(M_, W_)                                                                                    \
-  do {                                                                                                             \
-    if (g_flash_timed) hipLaunchKernelGGL((flash_d64_kernel<M_, W_, true>), dim3((unsigned)grid), dim3(256), 0, stream, a); \
-    else hipLaunchKernelGGL((flash_d64_kernel<M_, W_, false>), dim3((unsigned)grid), dim3(256), 0, stream, a);     \
-  } while (0)
   if (mode == 5) {
     if (g_flash_timed) hipLaunchKernelGGL((flash_dp_kernel<true>), dim3((unsigned)grid), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((flash_dp_kernel<false>), dim3((unsigned)grid), dim3(256), 0, stream, a);
-  } else if (mode == 4) {
-#define U2_FPP_LAUNCH(P_)                                                                                          \
-  do {                                                                                                             \
-    if (g_flash_timed) hipLaunchKernelGGL((flash_pp_kernel<true, P_>), dim3((unsigned)grid), dim3(512), 0, stream, a); \
-    else hipLaunchKernelGGL((flash_pp_kernel<false, P_>), dim3((unsigned)grid), dim3(512), 0, stream, a);          \
-  } while (0)
-    if (wps == 1) U2_FPP_LAUNCH(1);
-    else if (wps == 2) U2_FPP_LAUNCH(2);
-    else U2_FPP_LAUNCH(0);
-#undef U2_FPP_LAUNCH
-  } else if (mode == 3) U2_FLASH_LAUNCH(3, 2);
-  else if (mode == 2) U2_FLASH_LAUNCH(2, 2);
-  else if (wps == 4) U2_FLASH_LAUNCH(1, 4);
-  else if (wps == 2) U2_FLASH_LAUNCH(1, 2);
-  else U2_FLASH_LAUNCH(1, 3);
-#undef U2_FLASH_LAUNCH
+  } else {
+    hipLaunchKernelGGL(flash_d64_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
+  }
   return launch_status();
 }
 

@@ -1,5 +1,6 @@
 // extern "C" surface of libu2tok_hip.so (declared in include/u2tok.h).  Thin: argument marshalling only.
 #include <string.h>
+#include <new>
 #include "pipeline.h"
 
 using namespace u2;
@@ -25,52 +26,54 @@ int u2tok_device_check(void) {
   return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? U2_OK : U2_ERR_DEVICE;
 }
 
+// ---- contexts (ctx.h)
+int u2tok_ctx_create(u2tok_ctx_t* out) {
+  if (!out) return U2_ERR_ARG;
+  *out = reinterpret_cast<u2tok_ctx_t>(new (std::nothrow) Context());
+  return *out ? U2_OK : U2_ERR_ARG;
+}
+int u2tok_ctx_destroy(u2tok_ctx_t c) {
+  if (!c) return U2_ERR_ARG;
+  Context* cx = reinterpret_cast<Context*>(c);
+  if (ctx_bound() == cx) ctx_bind(nullptr);
+  delete cx;
+  return U2_OK;
+}
+int u2tok_ctx_set_current(u2tok_ctx_t c) {
+  ctx_bind(reinterpret_cast<Context*>(c));
+  return U2_OK;
+}
+u2tok_ctx_t u2tok_ctx_get_current(void) { return reinterpret_cast<u2tok_ctx_t>(ctx_bound()); }
+
 int u2tok_set_option(const char* name, int value) {
   if (!name) return U2_ERR_ARG;
-  if (!strcmp(name, "gemm_glds")) {
-    if (value < 0 || value > 2) return U2_ERR_ARG;
-    gemm_set_options(value, -1, -1);
-    return U2_OK;
-  }
+  Options& o = ctx().opt;
+  struct Opt { const char* name; int Options::*field; int lo, hi; };
+  static const Opt table[] = {
+      {"gemm_splitk", &Options::gemm_splitk, -1, 16},   {"gemm_big", &Options::gemm_big, -1, 21},
+      {"gemm_big_grid", &Options::gemm_big_grid, 1, 4096}, {"gemm_big_gelu", &Options::gemm_big_gelu, 0, 1},
+      {"gemm_skinny", &Options::gemm_skinny, -1, 1},    {"flash_mode", &Options::flash_mode, 0, 6},
+      {"vit_flash", &Options::vit_flash, 0, 1},         {"tta_overlap", &Options::tta_overlap, 0, 1},
+  };
   if (!strcmp(name, "gemm_tile")) {
     if (value != 0 && value != 64 && value != 128) return U2_ERR_ARG;
-    gemm_set_options(-1, value, -1);
+    o.gemm_tile = value;
     return U2_OK;
   }
-  if (!strcmp(name, "gemm_bk")) {
-    if (value != 32 && value != 64) return U2_ERR_ARG;
-    gemm_set_options(-1, -1, value);
-    return U2_OK;
-  }
-  if (!strcmp(name, "gemm_splitk")) {
-    if (value < -1 || value > 16) return U2_ERR_ARG;
-    gemm_set_splitk(value);
-    return U2_OK;
-  }
-  if (!strcmp(name, "gemm_pp")) {
-    if (value < -1 || value > 21) return U2_ERR_ARG;
-    gemm_pp_set_options(value, -1);
-    return U2_OK;
-  }
-  if (!strcmp(name, "gemm_pp_grid")) {
-    if (value < 1 || value > 4096) return U2_ERR_ARG;
-    gemm_pp_set_options(-2, value);
-    return U2_OK;
-  }
-  if (!strcmp(name, "flash_mode")) {
-    if (value < 0 || value > 45 || value % 10 > 5) return U2_ERR_ARG;
-    flash_set_mode(value);
-    return U2_OK;
-  }
-  if (!strcmp(name, "vit_flash")) { pipeline_set_vit_flash(value); return U2_OK; }
-  if (!strcmp(name, "tta_overlap")) { pipeline_set_tta_overlap(value); return U2_OK; }
   if (!strcmp(name, "profile")) { prof_enable(value != 0); return U2_OK; }
+  for (const Opt& t : table)
+    if (!strcmp(name, t.name)) {
+      if (value < t.lo || value > t.hi) return U2_ERR_ARG;
+      if (t.field == &Options::gemm_big && value > 0 && value != 20 && value != 21) return U2_ERR_ARG;
+      if (t.field == &Options::flash_mode && value != 0 && value != 1 && value != 5 && value != 6) return U2_ERR_ARG;
+      o.*(t.field) = value;
+      return U2_OK;
+    }
   return U2_ERR_ARG;
 }
 
-int u2tok_debug_buffer(void* device_ptr) { return gemm_pp_set_debug_buffer(device_ptr); }
 int u2tok_set_gemm_scratch(void* device_ptr, size_t bytes, void* stream) {
-  gemm_set_scratch(reinterpret_cast<hipStream_t>(stream), device_ptr, device_ptr ? bytes : 0);
+  ctx().set_scratch(reinterpret_cast<hipStream_t>(stream), device_ptr, device_ptr ? bytes : 0);
   return U2_OK;
 }
 int u2tok_flash_debug_buffer(void* device_ptr) { return flash_set_debug_buffer(device_ptr); }

@@ -1,0 +1,69 @@
+// Execution contexts of the u2tok HIP library.
+//
+// Everything the launchers used to keep in process-wide variables lives in a Context: the tuning / diagnostics options,
+// the side streams + events of the tokenizer forward (one set per caller stream), the split-K scratch registrations and
+// the profiling records.  A host thread works on its CURRENT context (thread-local binding, like a HIP device):
+// u2tok_ctx_set_current(ctx), or the process default context when none is bound.  Two models, or two host threads, each
+// with their own context never share mutable state; one context shared by several threads is safe for launches (its
+// tables are mutex-protected) as long as nobody changes its options concurrently.
+#pragma once
+#include <mutex>
+#include <vector>
+#include "common.h"
+
+namespace u2 {
+
+struct Options {
+  int gemm_tile = 0;        // 0 heuristic, 64 / 128 force the small-tile kernel's tile
+  int gemm_splitk = 0;      // -1 never, 0 heuristic, 2..16 force that many K slices where scratch allows
+  int gemm_big = 0;         // -1 never, 0 heuristic, 20 / 21 force the 256x256 / 256x192 big-tile kernel
+  int gemm_big_grid = 256;  // persistent workgroups of the big-tile kernel
+  int gemm_big_gelu = 0;    // 1: GELU products may take the big-tile kernel too
+  int gemm_skinny = 0;      // -1 never, 0 heuristic, 1 force the weight-streaming kernel for M <= 256 products
+  int flash_mode = 0;       // 0 pick, 1 plain 128-row units, 5 double pipeline, 6 double pipeline + split-KV second pass
+  int vit_flash = 1;        // 0: unfused ViT attention (debug)
+  int tta_overlap = 1;      // k | v projections of the TTA cross attentions on a side stream
+  int profile = 0;          // bracket every launch with hipEvents (u2tok_profile_collect)
+};
+
+struct SideStream {  // created lazily, one per caller stream that ever ran a tokenizer forward on this context
+  hipStream_t owner = nullptr;
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr;
+  hipEvent_t done[16] = {};
+};
+
+struct Scratch {
+  hipStream_t st;
+  void* p;
+  size_t bytes;
+};
+
+struct ProfRec {
+  hipEvent_t a, b;
+  int cat;
+  double flops, bytes;
+};
+
+struct Context {
+  Options opt;
+  std::mutex mu;
+  std::vector<SideStream*> sides;
+  std::vector<Scratch> scratch;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+
+  SideStream* side_for(hipStream_t owner);  // null if the stream / events cannot be created
+  void set_scratch(hipStream_t st, void* p, size_t bytes);
+  Scratch scratch_of(hipStream_t st);
+  void release();  // destroys the side streams / events (no work may be in flight on them)
+  ~Context() { release(); }
+};
+
+Context& ctx();                 // the calling thread's current context
+void ctx_bind(Context* c);      // null = back to the process default context
+Context* ctx_bound();           // null if the thread uses the default context
+inline const Options& opts() { return ctx().opt; }
+
+}  // namespace u2

@@ -14,14 +14,13 @@
 //    n of one output row m -> 8-byte bf16 / 16-byte fp32 stores and vector bias/residual loads.
 //  * LDS tile = [rows][64 bf16] (128 B per row), 16-byte chunks XOR-swizzled with (row & 7) so the
 //    ds_read_b128 fragment reads of a 16-lane group touch 16 distinct 16-B slots (conflict-free).
-//  * Two LDS stages; global->LDS either through registers (global_load_dwordx4 + ds_write_b128, issued
-//    before the MFMA block, written after it) or by LDS-DMA (global_load_lds_dwordx4, swizzle applied
-//    on the per-lane SOURCE address because the DMA destination is lane-linear).
+//  * Two LDS stages; global->LDS by LDS-DMA (global_load_lds_dwordx4, swizzle applied on the per-lane
+//    SOURCE address because the DMA destination is lane-linear), issued as one burst ahead of the MFMAs
+//    of the current K tile.  (Register staging, DMA pieces spread between the MFMAs and 64-byte rows
+//    (BK = 32) were measured 10-25 % slower in round 1 -- profiles/r01_gemm_pp_study.log -- and removed.)
 //  * XCD-aware, M-grouped tile order so that the 8 private L2s each see a compact band of tiles.
 #include <type_traits>
 #include <cstdio>
-#include <mutex>
-#include <vector>
 #include <algorithm>
 #include <cstdlib>
 #include "kernels.h"
@@ -30,20 +29,16 @@ namespace u2 {
 
 __device__ uint4 g_zero16;  // zero-initialised; K-tail chunks of the LDS-DMA path read from here
 
-// LDS chunk swizzle: XOR value for the 16-byte chunk index of `row` (see the conflict analysis in DESIGN.md):
-// BK = 64 (128-B rows, 8 chunks): row & 7;  BK = 32 (64-B rows, 4 chunks): (-(row >> 2)) & 3.
+// LDS chunk swizzle: XOR value for the 16-byte chunk index of `row` (128-B rows, 8 chunks): row & 7.
 template <int BK>
 __device__ __forceinline__ int lds_swz(int row) {
-  if constexpr (BK == 64) return row & 7;
-  else return (4 - ((row >> 2) & 3)) & 3;
+  static_assert(BK == 64, "BK");
+  return row & 7;
 }
 
-// GLDS: 0 = register staging, 1 = LDS-DMA issued as one burst ahead of the MFMAs, 2 = LDS-DMA pieces spread between
-// the MFMAs of the K tile (a global_load_lds blocks its wave for 100-180 cycles: spread out, the co-resident wave of
-// the other workgroup finds the matrix pipe free far more often than behind an 8-piece burst).
-template <int BM, int BN, int BK, int GLDS>
+template <int BM, int BN>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
-  static_assert(BK == 32 || BK == 64, "BK");
+  constexpr int BK = 64;
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MI = WM / 16, NI = WN / 16;
   constexpr int CPR = BK / 8;                              // 16-B chunks per tile row
@@ -117,24 +112,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
   const int nkt_all = (d.K + BK - 1) / BK;
   const int kt0 = (d.ksplit > 1) ? (int)blockIdx.z * d.kt_per : 0;   // split-K: this slice's K tiles
   const int nkt = (d.ksplit > 1) ? min(nkt_all, kt0 + d.kt_per) : nkt_all;
-  uint4 ra[CA], rb[CB];
-
-  auto gload = [&](int kt) {
-    const int k0 = kt * BK;
-#pragma unroll
-    for (int i = 0; i < CA; ++i)
-      ra[i] = (k0 + ka[i] < d.K) ? *reinterpret_cast<const uint4*>(pa[i] + k0) : uint4{0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < CB; ++i)
-      rb[i] = (k0 + kb[i] < d.K) ? *reinterpret_cast<const uint4*>(pb[i] + (int64_t)kt * kadv_b) : uint4{0, 0, 0, 0};
-  };
-  auto lstore = [&](int buf) {
-    char* s = lds + buf * STAGE;
-#pragma unroll
-    for (int i = 0; i < CA; ++i) *reinterpret_cast<uint4*>(s + (i * 256 + tid) * 16) = ra[i];
-#pragma unroll
-    for (int i = 0; i < CB; ++i) *reinterpret_cast<uint4*>(s + BM * ROWB + (i * 256 + tid) * 16) = rb[i];
-  };
   auto dma = [&](int kt, int buf) {
     const int k0 = kt * BK;
     char* s = lds + buf * STAGE;
@@ -171,84 +148,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
     }
   };
 
-  // one DMA piece of K tile kt into stage buf (i < CA: activation rows, else weight rows)
-  auto dma_piece = [&](int kt, int buf, int i) {
-    const int k0 = kt * BK;
-    char* s = lds + buf * STAGE;
-    if (i < CA) {
-      const void* src = (k0 + ka[i] < d.K) ? (const void*)(pa[i] + k0) : (const void*)&g_zero16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(s + (i * 256 + wave * 64) * 16),
-                                       16, 0, 0);
-    } else {
-      const int jj = i - CA;
-      const void* src = (k0 + kb[jj] < d.K) ? (const void*)(pb[jj] + (int64_t)kt * kadv_b) : (const void*)&g_zero16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(s + BM * ROWB + (jj * 256 + wave * 64) * 16),
-                                       16, 0, 0);
-    }
-  };
-  // MFMAs of stage `buf` with the DMA pieces of K tile kt_next spread between them
-  auto compute_dma = [&](int buf, int kt_next, bool more) {
-    const char* sA = lds + buf * STAGE + (wm * WM) * ROWB + frow;
-    const char* sB = lds + buf * STAGE + BM * ROWB + (wn * WN) * ROWB + frow;
-    constexpr int NM = KSTEPS * MI * NI, NPC = CA + CB;
-    constexpr int EVERY = NM / NPC > 0 ? NM / NPC : 1;
-#pragma unroll
-    for (int kk = 0; kk < KSTEPS; ++kk) {
-      bf16x8 xf[MI], wf[NI];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) xf[mi] = *reinterpret_cast<const bf16x8*>(sA + mi * 16 * ROWB + foff[kk]);
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const bf16x8*>(sB + ni * 16 * ROWB + foff[kk]);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[mi][ni], 0, 0, 0);
-          const int m_idx = (kk * MI + mi) * NI + ni;
-          if (m_idx % EVERY == EVERY - 1 && m_idx / EVERY < NPC) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) dma_piece(kt_next, buf ^ 1, m_idx / EVERY);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-    }
-    if (more) {
-#pragma unroll
-      for (int i = NM / EVERY; i < NPC; ++i) dma_piece(kt_next, buf ^ 1, i);
-    }
-  };
-
-  if constexpr (GLDS == 2) {
-    dma(kt0, kt0 & 1);
+  dma(kt0, kt0 & 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = kt0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) dma(kt + 1, (kt + 1) & 1);
+    compute(kt & 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int kt = kt0; kt < nkt; ++kt) {
-      compute_dma(kt & 1, kt + 1, kt + 1 < nkt);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-  } else if constexpr (GLDS == 1) {
-    dma(kt0, kt0 & 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int kt = kt0; kt < nkt; ++kt) {
-      if (kt + 1 < nkt) dma(kt + 1, (kt + 1) & 1);
-      compute(kt & 1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-  } else {
-    gload(kt0);
-    lstore(kt0 & 1);
-    __syncthreads();
-    for (int kt = kt0; kt < nkt; ++kt) {
-      if (kt + 1 < nkt) gload(kt + 1);
-      compute(kt & 1);
-      if (kt + 1 < nkt) lstore((kt + 1) & 1);
-      __syncthreads();
-    }
   }
 
   // ---- epilogue: lane holds C[m][n0..n0+3], m = tile row (lane & 15), n0 = 4 * (lane >> 4) ----
@@ -391,50 +298,13 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmDesc d) {
   }
 }
 
-static int g_gemm_splitk = 0;    // -1 never, 0 heuristic, s > 1 force
-void gemm_set_splitk(int mode) { g_gemm_splitk = mode; }
-
-// split-K scratch per stream (a handful of streams at most: linear search under a mutex)
-namespace {
-struct Scratch { hipStream_t st; void* p; size_t bytes; };
-std::mutex g_scratch_mu;
-std::vector<Scratch> g_scratch;
-}  // namespace
-void gemm_set_scratch(hipStream_t stream, void* p, size_t bytes) {
-  std::lock_guard<std::mutex> lk(g_scratch_mu);
-  for (auto& s : g_scratch)
-    if (s.st == stream) { s.p = p; s.bytes = bytes; return; }
-  g_scratch.push_back({stream, p, bytes});
-}
-static Scratch scratch_of(hipStream_t stream) {
-  std::lock_guard<std::mutex> lk(g_scratch_mu);
-  for (auto& s : g_scratch)
-    if (s.st == stream) return s;
-  return {stream, nullptr, 0};
-}
-
-static int g_gemm_glds = 1;      // 0: register staging, 1: LDS-DMA burst, 2: LDS-DMA pieces between the MFMAs
-static int g_gemm_force_tile = 0;  // 0: heuristic, 64 / 128: force
-static int g_gemm_bk = 64;       // K depth of one LDS stage: 64 (2 blocks/CU at 128^2) or 32 (4 blocks/CU)
-
-void gemm_set_options(int glds, int force_tile, int bk) {
-  if (glds >= 0) g_gemm_glds = glds;
-  if (force_tile >= 0) g_gemm_force_tile = force_tile;
-  if (bk == 32 || bk == 64) g_gemm_bk = bk;
-}
-
-template <int BM, int BN, int BK>
+template <int BM, int BN>
 static int launch_tile(GemmDesc d, hipStream_t stream) {
   d.tiles_m = (int)cdiv(d.M, BM);
   d.tiles_n = (int)cdiv(d.N, BN);
   dim3 grid(d.tiles_m * d.tiles_n, d.nz, d.ksplit > 1 ? d.ksplit : 1);
-  constexpr int smem = 2 * (BM + BN) * BK * 2;
-  if (g_gemm_glds == 2)
-    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, BK, 2>), grid, dim3(256), smem, stream, d);
-  else if (g_gemm_glds)
-    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, BK, 1>), grid, dim3(256), smem, stream, d);
-  else
-    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, BK, 0>), grid, dim3(256), smem, stream, d);
+  constexpr int smem = 2 * (BM + BN) * 64 * 2;
+  hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN>), grid, dim3(256), smem, stream, d);
   return launch_status();
 }
 
@@ -463,15 +333,16 @@ int gemm_bf16(GemmDesc d, hipStream_t stream) {
                2.0 * d.M * d.K * zA + 2.0 * d.N * d.K * zB +
                    d.nz * ((out_f32 ? 4.0 : 2.0) * d.M * d.N + ((d.flags & GEMM_RESIDUAL) ? 2.0 * d.M * d.N : 0.0)));
   if (d.ldbk == 0) {  // (the 256-wide-tile kernels read row-major B only)
-    const int pp = gemm_pp_try(d, stream);  // large products: big-tile / ping-pong kernels (gemm_pp.hip)
-    if (pp != 0) return pp > 0 ? U2_OK : pp;
+    const int big = gemm_big_try(d, stream);  // large products: the big-tile kernel (gemm_bt.hip)
+    if (big != 0) return big > 0 ? U2_OK : big;
   }
   return gemm_classic(d, stream);
 }
 
 // 128^2 / 64^2 tile kernel above; `d` already validated (GEMM_VEC_OK resolved).
 int gemm_classic(GemmDesc d, hipStream_t stream) {
-  int tile = g_gemm_force_tile;
+  const Options& o = opts();
+  int tile = o.gemm_tile;
   if (tile != 64 && tile != 128) {
     const int64_t big = cdiv(d.M, 128) * cdiv(d.N, 128) * d.nz;
     tile = (big >= 192) ? 128 : 64;  // fill 256 CUs; small-M weight-streaming shapes get 64^2 tiles
@@ -479,16 +350,16 @@ int gemm_classic(GemmDesc d, hipStream_t stream) {
   // split-K: a product with fewer workgroups than ~2 per CU runs one single-stage-prefetch K loop per CU and is
   // latency-bound (M = 256, N = K = 4096: 36 us, 0.24 PF/s).  Slicing K puts several workgroups on every CU.
   d.ksplit = 1;
-  if (g_gemm_splitk >= 0 && g_gemm_bk != 32) {
+  if (o.gemm_splitk >= 0) {
     const int64_t wgs = cdiv(d.M, tile) * cdiv(d.N, tile) * d.nz;
     const int nkt = (int)cdiv(d.K, 64);
-    int s = g_gemm_splitk > 1 ? g_gemm_splitk : 0;
+    int s = o.gemm_splitk > 1 ? o.gemm_splitk : 0;
     if (s == 0 && d.nz == 1 && wgs <= 320 && nkt >= 16)
       s = (int)std::min<int64_t>(8, std::min<int64_t>(nkt / 4, cdiv(1024, wgs)));
     if (s > 1) {
-      const Scratch sc = scratch_of(stream);
+      const Scratch sc = ctx().scratch_of(stream);
       const size_t slice = (size_t)d.nz * d.M * d.N * sizeof(float);
-      if (g_gemm_splitk <= 1) s = (int)std::min<size_t>(s, std::min<size_t>(sc.bytes, 24u << 20) / slice);  // partial sums cost HBM traffic
+      if (o.gemm_splitk <= 1) s = (int)std::min<size_t>(s, std::min<size_t>(sc.bytes, 24u << 20) / slice);  // partial sums cost HBM traffic
       const size_t need = (size_t)s * slice;
       if (s > 1 && sc.p && need <= sc.bytes && d.nz <= 65535) {
         d.ksplit = s;
@@ -499,9 +370,7 @@ int gemm_classic(GemmDesc d, hipStream_t stream) {
     }
     if (d.ksplit <= 1) d.ksplit = 1;
   }
-  int e;
-  if (g_gemm_bk == 32) e = tile == 128 ? launch_tile<128, 128, 32>(d, stream) : launch_tile<64, 64, 32>(d, stream);
-  else e = tile == 128 ? launch_tile<128, 128, 64>(d, stream) : launch_tile<64, 64, 64>(d, stream);
+  const int e = tile == 128 ? launch_tile<128, 128>(d, stream) : launch_tile<64, 64>(d, stream);
   if (e != U2_OK || d.ksplit == 1) return e;
   const int64_t total = (int64_t)d.nz * d.M * ((d.N + 3) >> 2);
   hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, d);

@@ -1,0 +1,340 @@
+// Big-tile bf16 MFMA GEMM for the large products of the hot path (same contract as gemm.hip:
+//   C[z][m][n] = epilogue(alpha * sum_k A[z][m][k] * B[z][n][k]),  A = activations [M][K], B = nn.Linear weight [N][K]).
+//
+// 256 x 256 x 64 (NJ = 4) or 256 x 192 x 64 (NJ = 3) tiles, ONE persistent workgroup of 4 waves per CU, each wave a
+// 128 x (32 NJ) output tile = 4 x NJ accumulators of v_mfma_f32_32x32x16_bf16 in AccVGPRs; the K loop is one generated
+// asm block (gemm_bt_asm.inc, written by tools/gen_gemm_bt_asm.py, which documents the slot schedule).  With one wave
+// per SIMD and a hand-placed instruction stream the matrix pipe only drains at the single barrier per K tile, every
+// LDS-DMA piece and fragment read sits in the shadow of an MFMA, and a 256^2 tile needs half the LDS fill bandwidth
+// per flop of the 128^2 kernel (the measured limit of the CU's L2 -> LDS path, ~50 B/clk, profiles/r01_stage_bw.log).
+// The 8-wave "ping-pong" kernels this file grew out of (measured slower on every shape, profiles/r01_gemm_pp_study.log)
+// were removed from the product in round 2; they are in the history at fc1ca7f.
+//  * XCD-aware tile order (workgroup b runs on XCD b % 8): every XCD gets a compact band of tiles per round.
+//  * persistent: grid = min(#tiles, #CUs); a workgroup walks tiles b, b + grid, ... and its K loop runs on from one
+//    output tile into the next (the last iterations stage the next tile's first K tiles).
+// Requirements checked by the launcher: K % 64 == 0, operands addressable with 32-bit byte offsets.
+#include <algorithm>
+#include <type_traits>
+#include "kernels.h"
+
+namespace u2 {
+
+// tile geometry handed to the epilogue
+template <int BN_>
+struct BTCfg {
+  static constexpr int BN = BN_;
+  static constexpr int NI = BN / 64;  // 32-wide n fragments per wave (wave tile 128 x BN/2 as two 64-row halves)
+};
+
+// round r of workgroup `bid` -> (z, bm0, bn0).  Tiles of one round are remapped so that XCD x (= bid & 7) works
+// on a contiguous range of logical ids; logical ids walk groups of 8 m-tiles column by column.
+template <int BN>
+__device__ __forceinline__ void pp_tile(const GemmDesc& d, int round, int gd, int bid, int total, int tiles_mn, int& z,
+                                        int& bm0, int& bn0) {
+  const int base = round * gd;
+  const int n_r = min(gd, total - base);
+  const int q = n_r >> 3, r = n_r & 7, xcd = bid & 7, idx = bid >> 3;
+  const int pid = base + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  z = pid / tiles_mn;
+  const int rem = pid - z * tiles_mn;
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * d.tiles_n;
+  const int group = rem / per_group, in_g = rem - group * per_group;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(d.tiles_m - first_m, GROUP_M);
+  bm0 = (first_m + in_g % gsz) * 256;
+  bn0 = (in_g / gsz) * BN;
+}
+
+// Epilogue of one 256 x BN tile for the calling wave.  The accumulator fragment of v_mfma_f32_32x32x16 leaves a lane
+// with 4 consecutive n (register quad q) and its partner lane (+32) with the next 4; v_permlane32_swap exchanges
+// quads between the half-waves so that every lane owns 8 CONSECUTIVE n of one row m: 16-byte bias / residual loads
+// and bf16 stores, two float4 stores for fp32 output.
+//   lane (l31, hi), pair t of fragment (mi, ni):  m = m_base + 32 mi,  n = n_tile + 32 ni + 16 t + 8 hi + [0, 8)
+template <class CFG, int G>
+__device__ __forceinline__ void pp_epilogue(const GemmDesc& d, f32x16 (&acc)[2][CFG::NI], int z, int bm0, int bn0, int wm2,
+                                            int wn2, int lane) {
+  constexpr int NI = CFG::NI, BN = CFG::BN;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const bool out_f32 = d.flags & GEMM_OUT_F32;
+  const int zb = z / d.nbh, zh = z - zb * d.nbh;
+  char* Cz = reinterpret_cast<char*>(d.C) + (zb * d.sCb + zh * d.sCh) * (out_f32 ? 4 : 2);
+  const bf16_t* Rz = (d.flags & GEMM_RESIDUAL) ? d.R + zb * d.sRb + zh * d.sRh : nullptr;
+  const int m_base = bm0 + G * 128 + wm2 * 64 + l31;
+  const int n_base = bn0 + wn2 * (BN / 2) + 8 * hi;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mi][ni][8 * t + e]),
+                                                          __float_as_uint(acc[mi][ni][8 * t + 4 + e]), false, false);
+          acc[mi][ni][8 * t + e] = __uint_as_float(r[0]);
+          acc[mi][ni][8 * t + 4 + e] = __uint_as_float(r[1]);
+        }
+  // FULL: the tile lies inside C (no row / column predicates); flags resolved at compile time.
+  auto body = [&](auto FULL_, auto BIAS_, auto GELU_, auto RES_, auto F32_) {
+    constexpr bool FULL = decltype(FULL_)::value;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int n0 = n_base + ni * 32 + t * 16;
+        if (!FULL && n0 >= d.N) continue;
+        float bv[8];
+        if constexpr (decltype(BIAS_)::value) {
+          const uint4 b4 = *reinterpret_cast<const uint4*>(d.bias + n0);
+          bv[0] = bf16lo(b4.x); bv[1] = bf16hi(b4.x); bv[2] = bf16lo(b4.y); bv[3] = bf16hi(b4.y);
+          bv[4] = bf16lo(b4.z); bv[5] = bf16hi(b4.z); bv[6] = bf16lo(b4.w); bv[7] = bf16hi(b4.w);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int m = m_base + mi * 32;
+          if (!FULL && m >= d.M) continue;
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = acc[mi][ni][8 * t + e] * d.alpha;
+          if constexpr (decltype(BIAS_)::value) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bv[e];
+          }
+          if constexpr (decltype(GELU_)::value) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+          }
+          if constexpr (decltype(RES_)::value) {
+            const uint4 r4 = *reinterpret_cast<const uint4*>(Rz + (int64_t)m * d.ldr + n0);
+            v[0] += bf16lo(r4.x); v[1] += bf16hi(r4.x); v[2] += bf16lo(r4.y); v[3] += bf16hi(r4.y);
+            v[4] += bf16lo(r4.z); v[5] += bf16hi(r4.z); v[6] += bf16lo(r4.w); v[7] += bf16hi(r4.w);
+          }
+          if constexpr (decltype(F32_)::value) {
+            float* cp = reinterpret_cast<float*>(Cz) + (int64_t)m * d.ldc + n0;
+            *reinterpret_cast<float4*>(cp) = float4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<float4*>(cp + 4) = float4{v[4], v[5], v[6], v[7]};
+          } else {
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(Cz) + (int64_t)m * d.ldc + n0) =
+                uint4{pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])};
+          }
+        }
+      }
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  const int ef = d.flags & (GEMM_BIAS_N | GEMM_GELU | GEMM_RESIDUAL | GEMM_OUT_F32);
+  if (bm0 + 256 <= d.M && bn0 + BN <= d.N) {
+    switch (ef) {
+      case 0: body(T_{}, F_{}, F_{}, F_{}, F_{}); break;
+      case GEMM_OUT_F32: body(T_{}, F_{}, F_{}, F_{}, T_{}); break;
+      case GEMM_BIAS_N: body(T_{}, T_{}, F_{}, F_{}, F_{}); break;
+      case GEMM_BIAS_N | GEMM_OUT_F32: body(T_{}, T_{}, F_{}, F_{}, T_{}); break;
+      case GEMM_BIAS_N | GEMM_GELU: body(T_{}, T_{}, T_{}, F_{}, F_{}); break;
+      case GEMM_BIAS_N | GEMM_RESIDUAL: body(T_{}, T_{}, F_{}, T_{}, F_{}); break;
+      case GEMM_RESIDUAL: body(T_{}, F_{}, F_{}, T_{}, F_{}); break;
+      default: break;  // the launcher never sends other combinations here
+    }
+  } else {
+    switch (ef) {  // border tiles: same bodies with row / column predicates
+      case 0: body(F_{}, F_{}, F_{}, F_{}, F_{}); break;
+      case GEMM_OUT_F32: body(F_{}, F_{}, F_{}, F_{}, T_{}); break;
+      case GEMM_BIAS_N: body(F_{}, T_{}, F_{}, F_{}, F_{}); break;
+      case GEMM_BIAS_N | GEMM_OUT_F32: body(F_{}, T_{}, F_{}, F_{}, T_{}); break;
+      case GEMM_BIAS_N | GEMM_GELU: body(F_{}, T_{}, T_{}, F_{}, F_{}); break;
+      case GEMM_BIAS_N | GEMM_RESIDUAL: body(F_{}, T_{}, F_{}, T_{}, F_{}); break;
+      case GEMM_RESIDUAL: body(F_{}, F_{}, F_{}, T_{}, F_{}); break;
+      default: break;
+    }
+  }
+}
+
+// "Big tile" kernel (variant 20): 256 x 256 x 64 tiles, ONE workgroup of 4 waves per CU, each wave a 128 x 128 output
+// tile (4 x 4 MFMA accumulators = 256 AccVGPRs), its K loop one generated asm block (gemm_bt_asm.inc, written by
+// tools/gen_gemm_bt_asm.py, which documents the slot schedule).  What it is after: with one wave per SIMD and a
+// hand-placed instruction stream the matrix pipe only drains at the single barrier per K tile, every LDS-DMA piece
+// and fragment read sits in the shadow of an MFMA, and a 256^2 tile needs half the LDS fill bandwidth per flop of
+// the 128^2 kernel (the measured limit of the CU's L2 -> LDS path, ~50 B/clk, profiles/r01_stage_bw.log).
+// Requirements checked by the launcher: K % 64 == 0, operands addressable with 32-bit byte offsets.
+#include "gemm_bt_asm.inc"
+typedef int bt_i32x4 __attribute__((ext_vector_type(4)));
+
+template <int NJ>  // 32-column blocks per wave: tile = 256 x (64 NJ)
+__global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
+  constexpr int BN = 64 * NJ;
+  using CFG = BTCfg<BN>;
+  __shared__ __attribute__((aligned(1024))) char lds[131072];  // [stage][A tile 32 KB | B tile <= 32 KB]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int tiles_mn = d.tiles_m * d.tiles_n;
+  const int total = tiles_mn * d.nz;
+  const int gd = gridDim.x, bid = blockIdx.x;
+  const int my_tiles = (total - bid + gd - 1) / gd;  // >= 1: grid <= total
+  // DMA pieces of this wave: rows [64 w, 64 w + 64) of the A tile and [16 NJ w, ..) of the B tile, 8 rows x 128 B per
+  // piece; LDS position p of row r holds global chunk p ^ ((r >> 1) & 7): even / odd pieces differ by 4 in that term.
+  // Lane offsets are relative to the tile origin; the origin (and the K tile) travel in the scalar offset.
+  const int pr = lane >> 3, sw0 = (lane >> 4) & 3, pc = lane & 7;
+  const int ra = wave * 64 + pr, rb = wave * (16 * NJ) + pr;
+  const int va0 = (ra * (int)d.lda + ((pc ^ sw0) << 3)) * 2;
+  const int va1 = ((ra + 8) * (int)d.lda + ((pc ^ sw0 ^ 4) << 3)) * 2;
+  const int vb0 = (rb * (int)d.ldb + ((pc ^ sw0) << 3)) * 2;
+  const int vb1 = ((rb + 8) * (int)d.ldb + ((pc ^ sw0 ^ 4) << 3)) * 2;
+  const uint32_t lds_u32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&lds[0];  // 0: the only LDS object
+  const uint32_t abk0 = (uint32_t)(l31 * 128 + ((hi ^ ((l31 >> 1) & 7)) << 4));
+  const int lda16 = 16 * (int)d.lda * 2, ldb16 = 16 * (int)d.ldb * 2;
+  const int nkt = d.K >> 6;
+  const bool chain = d.nz == 1;  // one K loop runs on from tile to tile (same descriptors)
+  uint32_t st0 = 0;              // LDS stage that holds K tile 0 of the current output tile
+  int z, bm0, bn0;
+  pp_tile<BN>(d, 0, gd, bid, total, tiles_mn, z, bm0, bn0);
+  for (int r = 0; r < my_tiles; ++r) {
+    int zn = z, bm0n = bm0, bn0n = bn0;  // next output tile of this workgroup (itself after the last one: its K
+    if (r + 1 < my_tiles) pp_tile<BN>(d, r + 1, gd, bid, total, tiles_mn, zn, bm0n, bn0n);  // loop prefetches in-bounds garbage)
+    const int zb = z / d.nbh, zh = z - zb * d.nbh;
+    const bf16_t* A = d.A + zb * d.sAb + zh * d.sAh;
+    const bf16_t* B = d.B + zb * d.sBb + zh * d.sBh;
+    // MUBUF descriptors: rows past M / N read as zero
+    const uint64_t aaddr = (uint64_t)(uintptr_t)A, baddr = (uint64_t)(uintptr_t)B;
+    bt_i32x4 rsa, rsb;
+    rsa[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)aaddr);
+    rsa[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(aaddr >> 32));
+    rsa[2] = (int)((((int64_t)d.M - 1) * d.lda + d.K) * 2);
+    rsa[3] = 0x00020000;
+    rsb[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)baddr);
+    rsb[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(baddr >> 32));
+    rsb[2] = (int)((((int64_t)d.N - 1) * d.ldb + d.K) * 2);
+    rsb[3] = 0x00020000;
+    const int first = (r == 0 || !chain) ? 1 : 0;
+    if (first) st0 = 0;
+    const uint32_t aa0 = (lds_u32 + wm * 16384 + abk0) ^ st0, ab0 = (lds_u32 + 32768 + wn * (NJ * 4096) + abk0) ^ st0;
+    // (readfirstlane: the values are uniform, but hipcc keeps loop-carried tile coordinates in VGPRs)
+    const int base_a = __builtin_amdgcn_readfirstlane(bm0 * (int)d.lda * 2);
+    const int base_b = __builtin_amdgcn_readfirstlane(bn0 * (int)d.ldb * 2);
+    const int nbase_a = __builtin_amdgcn_readfirstlane((chain ? bm0n : bm0) * (int)d.lda * 2);
+    const int nbase_b = __builtin_amdgcn_readfirstlane((chain ? bn0n : bn0) * (int)d.ldb * 2);
+    const int st0_s = __builtin_amdgcn_readfirstlane((int)st0), first_s = __builtin_amdgcn_readfirstlane(first);
+    f32x16 acc[2][2][NJ];  // [64-row half of the wave tile][32-row block][32-column block]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NJ; ++ni)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[h][mi][ni][q] = 0.f;
+#define BT_ACC3(h_, m_) [c##h_##m_##0] "+a"(acc[h_][m_][0]), [c##h_##m_##1] "+a"(acc[h_][m_][1]), [c##h_##m_##2] "+a"(acc[h_][m_][2])
+#define BT_IN                                                                                                         \
+  [va0] "v"(va0), [va1] "v"(va1), [vb0] "v"(vb0), [vb1] "v"(vb1), [aa0] "v"(aa0), [ab0] "v"(ab0), [rsa] "s"(rsa),     \
+      [rsb] "s"(rsb), [lda16] "s"(lda16), [ldb16] "s"(ldb16), [nkt] "s"(nkt), [wave] "s"(wave), [st0] "s"(st0_s),     \
+      [first] "s"(first_s), [base_a] "s"(base_a), [base_b] "s"(base_b), [nbase_a] "s"(nbase_a), [nbase_b] "s"(nbase_b)
+    if constexpr (NJ == 4) {
+      asm volatile(GEMM_BT_ASM_TEXT_NJ4
+                   : BT_ACC3(0, 0), [c003] "+a"(acc[0][0][3]), BT_ACC3(0, 1), [c013] "+a"(acc[0][1][3]), BT_ACC3(1, 0),
+                     [c103] "+a"(acc[1][0][3]), BT_ACC3(1, 1), [c113] "+a"(acc[1][1][3])
+                   : BT_IN
+                   : GEMM_BT_ASM_CLOBBERS);
+    } else {
+      asm volatile(GEMM_BT_ASM_TEXT_NJ3 : BT_ACC3(0, 0), BT_ACC3(0, 1), BT_ACC3(1, 0), BT_ACC3(1, 1) : BT_IN : GEMM_BT_ASM_CLOBBERS);
+    }
+#undef BT_ACC3
+#undef BT_IN
+    // pp_epilogue's row base is bm0 + 128 G + 64 wm2: G = 0 with the wave's 128-row offset folded into bm0 (its "tile
+    // inside C" fast-path test then only errs towards the predicated path)
+    pp_epilogue<CFG, 0>(d, acc[0], z, bm0 + wm * 128, bn0, 0, wn, lane);
+    pp_epilogue<CFG, 0>(d, acc[1], z, bm0 + wm * 128, bn0, 1, wn, lane);
+    st0 ^= (uint32_t)(nkt & 1) << 16;
+    z = zn; bm0 = bm0n; bn0 = bn0n;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last K loop's prefetch into LDS
+}
+
+template <int NJ>
+static int bt_launch(GemmDesc d, hipStream_t stream) {
+  d.tiles_m = (int)cdiv(d.M, 256);
+  d.tiles_n = (int)cdiv(d.N, 64 * NJ);
+  const int64_t total = (int64_t)d.tiles_m * d.tiles_n * d.nz;
+  if (total > 0x3fffffff) return U2_ERR_ARG;
+  const int grid = (int)std::min<int64_t>(total, opts().gemm_big_grid);
+  hipLaunchKernelGGL(gemm_bt_kernel<NJ>, dim3(grid), dim3(256), 0, stream, d);
+  return launch_status();
+}
+
+// 64-wide K tiles only (at least two); 32-bit byte offsets into A and B (per z)
+static bool bt_legal(const GemmDesc& d) {
+  return !(d.K & 63) && d.K >= 128 && (int64_t)d.M * d.lda < (1ll << 30) && (int64_t)d.N * d.ldb < (1ll << 30);
+}
+
+static int bt_launch_variant(int v, const GemmDesc& d, hipStream_t stream) {
+  return v == 20 ? bt_launch<4>(d, stream) : bt_launch<3>(d, stream);  // 256x256 / 256x192 tiles
+}
+
+// Which tile (tools/gpu_check.py ppperf on MI355X, random operands; DESIGN.md section 3 has the tables): the kernel
+// runs its K loop at ~50 % of the MFMA peak (8192^3: 1.23-1.29 PF/s; gemm.hip's 128 x 128 tiles: 0.9) but nothing
+// overlaps its prologue and epilogue, and a product is as slow as its last round of tiles: it is taken when the tiles
+// fill their rounds of 256 workgroups to >= 70 %, with the tile width that needs the fewest (work-weighted) rounds --
+// the ViT's N = 2304 / 768 projections are exactly 3 / 1 rounds of 192-wide tiles, N = 3072 exactly 3 rounds of
+// 256-wide ones.
+static int bt_pick(const GemmDesc& d) {
+  if (!bt_legal(d) || d.K < 256) return 0;
+  // the GELU epilogue is 256 values per lane of VALU work that the 128 x 128 kernel hides under its second workgroup
+  // per CU (fc1 of the ViT: 112 us there, 120 us here in round 1); option "gemm_big_gelu" = 1 sends it here anyway
+  if ((d.flags & GEMM_GELU) && !opts().gemm_big_gelu) return 0;
+  const int gmax = opts().gemm_big_grid;
+  const int64_t tm = cdiv(d.M, 256) * d.nz;
+  const int64_t t4 = tm * cdiv(d.N, 256), t3 = tm * cdiv(d.N, 192);
+  const int64_t r4 = cdiv(t4, gmax), r3 = cdiv(t3, gmax);
+  const double fill4 = (double)d.M * d.N * d.nz / ((double)r4 * gmax * 65536.0);
+  const double fill3 = (double)d.M * d.N * d.nz / ((double)r3 * gmax * 49152.0);
+  const double c4 = (double)r4, c3 = 0.9 * (double)r3;  // a 192-wide tile takes ~0.9 of the time of a 256-wide one
+  if (c3 < c4) return fill3 >= 0.7 ? 21 : (fill4 >= 0.7 ? 20 : 0);
+  return fill4 >= 0.7 ? 20 : (fill3 >= 0.7 ? 21 : 0);
+}
+
+// Returns 1 when the product was launched here, 0 when the caller should use gemm.hip's kernel, < 0 on error.
+// `d` has been validated by gemm_bf16 (alignment of A / B, GEMM_VEC_OK resolved).
+int gemm_big_try(const GemmDesc& d, hipStream_t stream) {
+  const int mode = opts().gemm_big;
+  if (mode < 0) return 0;
+  if (!(d.flags & GEMM_VEC_OK) || (d.flags & GEMM_BIAS_M) || (d.N & 7)) return 0;
+  switch (d.flags & (GEMM_BIAS_N | GEMM_GELU | GEMM_RESIDUAL | GEMM_OUT_F32)) {
+    case 0: case GEMM_OUT_F32: case GEMM_BIAS_N: case GEMM_BIAS_N | GEMM_OUT_F32: case GEMM_BIAS_N | GEMM_GELU:
+    case GEMM_BIAS_N | GEMM_RESIDUAL: case GEMM_RESIDUAL: break;
+    default: return 0;
+  }
+  // 16-byte epilogue accesses (8 consecutive n per lane)
+  const bool f32 = d.flags & GEMM_OUT_F32;
+  if (((uintptr_t)d.C & 15) || (d.ldc & (f32 ? 3 : 7)) || (d.sCb & (f32 ? 3 : 7)) || (d.sCh & (f32 ? 3 : 7))) return 0;
+  if ((d.flags & GEMM_BIAS_N) && ((uintptr_t)d.bias & 15)) return 0;
+  if ((d.flags & GEMM_RESIDUAL) && (((uintptr_t)d.R & 15) || (d.ldr & 7) || (d.sRb & 7) || (d.sRh & 7))) return 0;
+  if (mode > 0) {  // forced (tests, measurements)
+    if (!bt_legal(d)) return 0;
+    const int e = bt_launch_variant(mode, d, stream);
+    return e == U2_OK ? 1 : e;
+  }
+  if (d.M < 512 || d.N < 256 || d.K < 128) return 0;
+  // A few rows past a multiple of 256 (the ViT's 8 cls rows: M = 8 * 2049) would cost a whole extra round of
+  // 256-row tiles: run them through the small-tile kernel instead.
+  const int rem = d.M & 255;
+  if (d.nz == 1 && rem != 0 && rem <= 64) {
+    GemmDesc main = d, tail = d;
+    main.M = d.M - rem;
+    const int v = bt_pick(main);
+    if (v == 0) return 0;
+    tail.M = rem;
+    tail.A = d.A + (int64_t)main.M * d.lda;
+    tail.C = reinterpret_cast<char*>(d.C) + (int64_t)main.M * d.ldc * (f32 ? 4 : 2);
+    if (d.flags & GEMM_RESIDUAL) tail.R = d.R + (int64_t)main.M * d.ldr;
+    int e = bt_launch_variant(v, main, stream);
+    if (e != U2_OK) return e;
+    e = gemm_classic(tail, stream);
+    return e == U2_OK ? 1 : e;
+  }
+  const int v = bt_pick(d);
+  if (v == 0) return 0;
+  const int e = bt_launch_variant(v, d, stream);
+  return e == U2_OK ? 1 : e;
+}
+
+}  // namespace u2

@@ -3,20 +3,22 @@
 #pragma once
 #include <algorithm>
 #include "common.h"
+#include "ctx.h"
 
 namespace u2 {
 
-// ------------------------------------------------------------------ profiling (prof.hip)
+// ------------------------------------------------------------------ profiling (ctx.hip)
 enum : int { PROF_GEMM = 0, PROF_FLASH = 1, PROF_TEMPORAL = 2, PROF_ROWOP = 3, PROF_MOVE = 4, PROF_NCAT = 5 };
 void prof_enable(bool on);
 bool prof_enabled();
 int prof_collect(double* ms, double* flops, double* bytes, int64_t* count, int ncat);  // bytes may be null
-struct ProfScope {  // brackets one launch with hipEvents on `st` when profiling is on; free otherwise
+struct ProfScope {  // brackets one launch with hipEvents on `st` when the current context profiles; free otherwise
   // flops / bytes: ALGORITHMIC work of the launch (2MNK; operands + results once), for the roofline lines of bench.py
   ProfScope(int cat, double flops, hipStream_t st, double bytes = 0.0);
   ~ProfScope();
   int idx_;
   hipStream_t st_;
+  Context* c_;
 };
 
 // ------------------------------------------------------------------ GEMM (gemm.hip)
@@ -51,17 +53,12 @@ struct GemmDesc {
   float* partial = nullptr;
 };
 
+// Options (tile, split-K, big-tile selection) and the split-K scratch registration of the launch stream come from the
+// calling thread's current Context (ctx.h).  Without a registered scratch, products run unsplit.
 int gemm_bf16(GemmDesc d, hipStream_t stream);
-void gemm_set_options(int glds, int force_tile, int bk);
-// Scratch for split-K partial sums, one registration per stream (the forwards in pipeline.hip carve it from their
-// workspace; u2tok_set_gemm_scratch for direct callers).  Without one, products run unsplit.
-void gemm_set_scratch(hipStream_t stream, void* p, size_t bytes);
-void gemm_set_splitk(int mode);  // -1 never, 0 heuristic, s > 1 force s slices where legal
-// internal: the two kernels behind gemm_bf16 (descriptor already validated there)
-int gemm_classic(GemmDesc d, hipStream_t stream);       // gemm.hip: 128^2 / 64^2 tiles, 2 workgroups per CU
-int gemm_pp_try(const GemmDesc& d, hipStream_t stream);  // gemm_pp.hip: 1 launched, 0 not applicable, < 0 error
-void gemm_pp_set_options(int mode, int max_grid);
-int gemm_pp_set_debug_buffer(void* p);                   // diagnostics: >= 256*8*5 uint64 (see gemm_pp.hip), or null        // mode: -1 never, 0 heuristic, v > 0 force variant v
+// internal: the kernels behind gemm_bf16 (descriptor already validated there)
+int gemm_classic(GemmDesc d, hipStream_t stream);        // gemm.hip: 128^2 / 64^2 tiles, 2+ workgroups per CU
+int gemm_big_try(const GemmDesc& d, hipStream_t stream);  // gemm_bt.hip: 1 launched, 0 not applicable, < 0 error
 
 // ------------------------------------------------------------------ row ops (rowops.hip)
 // y[b][r][:] = LayerNorm(x[b][r][:] (+ res[b][r][:])) * w + bias   (bf16 in/out, fp32 math)
@@ -138,8 +135,8 @@ int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16
                         int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs, int S_pad, float scale,
                         const bf16_t* qx, const bf16_t* kx, const bf16_t* vx, bf16_t* outx, int64_t x_bs, int64_t ox_bs,
                         int n_extra, hipStream_t stream);
-int flash_set_debug_buffer(void* p);  // diagnostics: s_memtime phase sums per (workgroup, wave); see attn.hip
-void flash_set_mode(int mode);  // 0 pick (5 for S >= 512), 1: 128-row units, 2: 256-row units, 3: one of each per workgroup,
-                                // 4: 8-wave ping-pong, 5: double pipeline with the generated asm KV loop
+// Diagnostics only (process-wide, not for concurrent use): s_memtime phase sums per (workgroup, wave) of the double
+// pipeline kernel; while a buffer is attached the kernel runs its instrumented build.  See attn.hip.
+int flash_set_debug_buffer(void* p);
 
 }  // namespace u2

@@ -18,7 +18,5 @@ int spp_forward(const SppConfig& c, const void* const* W, const bf16_t* x, bf16_
 int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_token, const bf16_t* t_token,
                       bf16_t* out, int64_t* topk_idx_out, bf16_t* svr_out, void* ws, size_t ws_bytes, bool dry,
                       size_t* peak, hipStream_t st);
-void pipeline_set_vit_flash(int v);
-void pipeline_set_tta_overlap(int v);
 
 }  // namespace u2

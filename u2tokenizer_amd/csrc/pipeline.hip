@@ -103,35 +103,28 @@ int attention_core(Arena& ar, const AttnCore& a, bool dry, hipStream_t st) {
   return U2_OK;
 }
 
-int g_vit_flash = 1;
-int g_tta_overlap = 1;
-
-// Side stream of the tokenizer: the k | v projections of the TTA cross attentions depend only on the selected visual
-// tokens and the text tokens, not on the query chain.  They are large, throughput-bound GEMMs; the query chain is
-// a string of M = 256 GEMMs and small attention launches that cannot fill the machine.  Forked onto a second HIP
-// stream (event-ordered, no host synchronisation) the two overlap on the CUs.  One stream + event set per process:
-// the library is driven from one host thread per GPU (SURVEY 8b "Threading").
-struct SideStream {
-  hipStream_t s = nullptr;
-  hipEvent_t fork = nullptr;
-  hipEvent_t done[16] = {};
-  bool ok = false;
-  bool init() {
-    if (ok) return true;
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return false;
-    if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
-    for (auto& e : done)
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
-    ok = true;
-    return true;
+// attention over the CHUNK axis of rows laid out (b, t, n) [leading dim 3E for q | k | v, E for the output]: Bx * Nx * H
+// independent sequences of Tx rows that are Nx rows apart (svr.py:31-36 without its two permute().contiguous() copies).
+// Tx <= 16 and a head dim the wave kernel is built for: one launch; otherwise the batched-GEMM core, one batch entry
+// at a time (sequence rows are Nx * 3E elements apart, the Nx positions and H heads are the GEMM batch).
+int chunk_axis_attention(Arena& ar, const bf16_t* qkv, bf16_t* out, int Bx, int Tx, int Nx, int H, int d, float scale,
+                         const bf16_t* rel_bias, int max_len, bool dry, hipStream_t st) {
+  const int E = H * d;
+  if (Tx <= 16 && (d == 64 || d == 128 || d == 256 || d == 512)) {
+    U2_RUN(temporal_attention(qkv, qkv + E, qkv + 2 * E, out, Bx, Tx, Nx, H, d, 3 * E, E, scale, rel_bias, max_len, st));
+    return U2_OK;
   }
-};
-SideStream g_side;
+  for (int b = 0; b < Bx; ++b) {
+    const bf16_t* base = qkv + (int64_t)b * Tx * Nx * 3 * E;
+    AttnCore a{base, base + E, base + 2 * E, (int64_t)Nx * 3 * E, (int64_t)Nx * 3 * E, (int64_t)Nx * 3 * E, 3 * E, 3 * E,
+               3 * E, out + (int64_t)b * Tx * Nx * E, (int64_t)Nx * E, E, Nx, Tx, Tx, H, d, scale, rel_bias, max_len};
+    const int e = attention_core(ar, a, dry, st);
+    if (e != U2_OK) return e;
+  }
+  return U2_OK;
+}
 
 }  // namespace
-
-void pipeline_set_vit_flash(int v) { g_vit_flash = v ? 1 : 0; }
-void pipeline_set_tta_overlap(int v) { g_tta_overlap = v ? 1 : 0; }
 
 // =========================================================================== ViT3DTower
 // Row layout of the residual stream: the nc * ntok PATCH rows first (chunk-major), then the nc cls rows.  The
@@ -184,7 +177,7 @@ int vit_forward(const VitConfig& c, const void* const* W, const void* volume, bf
     // x = x + out_proj(attn(qkv(norm1(x))))   (MONAI TransformerBlock / SABlock)
     U2_RUN(layernorm_bf16(x, nullptr, w(b0 + 0), w(b0 + 1), xn, 1, (int)rows, Hd, 0, Hd, 0, 0, 0, Hd, c.ln_eps, st));
     U2_RUN(linear(xn, Hd, w(b0 + 2), nullptr, qkv, 3 * Hd, rows, Hd, 3 * Hd, 0, nullptr, 0, st));
-    if (g_vit_flash) {
+    if (opts().vit_flash) {
       U2_RUN(transpose_bf16(qkv + 2 * Hd, vt, nc, ntok, Hd, 3 * Hd, S_pad, (int64_t)ntok * 3 * Hd, (int64_t)Hd * S_pad, 1, st));
       const bf16_t* xq = qkv + prow * 3 * Hd;  // q | k | v of the cls rows
       U2_RUN(flash_attention_d64(qkv, qkv + Hd, vt, att, nc, ntok, c.heads, 3 * Hd, (int64_t)ntok * 3 * Hd, Hd,
@@ -307,15 +300,14 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
   if (c.E % c.num_heads || (c.E / c.num_heads) % 8 || c.top_k <= 0 || c.num_query <= 0) return U2_ERR_ARG;
   if (c.attn_type < 0 || c.attn_type > 2) return U2_ERR_ARG;
   // attn_type 2 = nn.MultiheadAttention read sequence-first (svr.py:16-18,28-35): attention runs across whatever sits
-  // in dim 0, including the batch entries -- implemented for B = 1, where "spatial" = across the T chunks and
-  // "temporal" = across the N tokens of a chunk, and the TTA self-attention sees a sequence of length 1.
-  if (c.attn_type == 2 && c.B != 1) return U2_ERR_ARG;
+  // in dim 0, INCLUDING the batch entries: "spatial" = across the B*T (batch, chunk) pairs at a token position,
+  // "temporal" = across the B*N (batch, token) pairs of a chunk index, TTA self-attention = across the B batch entries
+  // of a query index (a sequence of one key for B = 1).
   if (!dry && (!W || !v_token || !t_token || !out)) return U2_ERR_ARG;
   const int B = c.B, T = c.T, N = c.N, E = c.E, H = c.num_heads, d = E / H, L = c.num_layers, Q = c.num_query;
   const int TN = T * N, k = c.top_k;
   if (!c.enable_diffts && k > TN) return U2_ERR_ARG;                       // torch.topk would raise
   if (N > c.max_seq_len || T > c.max_seq_len || Q > c.max_seq_len) return U2_ERR_ARG;  // rma.py:64-68 index range
-  if (T > 16) return U2_ERR_ARG;  // temporal kernel limit (round 1)
   const float scale = 1.0f / sqrtf((float)d);
   auto wp = [&](int i) { return dry ? nullptr : reinterpret_cast<const bf16_t*>(W[i]); };
   auto att_at = [&](int i) {
@@ -331,12 +323,14 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
   constexpr size_t kSplitK = 24u << 20;
   char* skw = ar.get<char>(kSplitK);
   U2_CHECK_WS(ar);
+  Context& cx = ctx();
   struct ScratchGuard {
+    Context& cx;
     hipStream_t st;
     bool on;
-    ~ScratchGuard() { if (on) gemm_set_scratch(st, nullptr, 0); }
-  } scratch_guard{st, !dry};
-  if (!dry) gemm_set_scratch(st, skw, kSplitK);
+    ~ScratchGuard() { if (on) cx.set_scratch(st, nullptr, 0); }
+  } scratch_guard{cx, st, !dry};
+  if (!dry) cx.set_scratch(st, skw, kSplitK);
   const int64_t rows = (int64_t)B * TN;
   bf16_t* xa = ar.get<bf16_t>((size_t)rows * E);
   bf16_t* xb = ar.get<bf16_t>((size_t)rows * E);
@@ -355,8 +349,9 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
       U2_RUN(rope_apply(qkv, (int64_t)B * T, N, 1, H, d, 3 * E, c.max_seq_len, st));
       U2_RUN(rope_apply(qkv + E, (int64_t)B * T, N, 1, H, d, 3 * E, c.max_seq_len, st));
     }
-    if (c.attn_type == 2) {  // sequence = the T chunks, batch = token position
-      U2_RUN(temporal_attention(qkv, qkv + E, qkv + 2 * E, ctx, B, T, N, H, d, 3 * E, E, scale, nullptr, c.max_seq_len, st));
+    if (c.attn_type == 2) {  // sequence = the B*T (batch, chunk) pairs, batch = token position
+      const int e = chunk_axis_attention(ar, qkv, ctx, 1, B * T, N, H, d, scale, nullptr, c.max_seq_len, dry, st);
+      if (e != U2_OK) return e;
     } else {
       AttnCore a{qkv, qkv + E, qkv + 2 * E, 3 * E, 3 * E, 3 * E, (int64_t)N * 3 * E, (int64_t)N * 3 * E,
                  (int64_t)N * 3 * E, ctx, E, (int64_t)N * E, B * T, N, N, H, d, scale, sp.rb, c.max_seq_len};
@@ -371,13 +366,36 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
       U2_RUN(rope_apply(qkv, B, T, N, H, d, 3 * E, c.max_seq_len, st));
       U2_RUN(rope_apply(qkv + E, B, T, N, H, d, 3 * E, c.max_seq_len, st));
     }
-    if (c.attn_type == 2) {  // sequence = the N tokens of a chunk, batch = chunk
+    if (c.attn_type == 2 && B == 1) {  // sequence = the N tokens of a chunk, batch = chunk
       AttnCore a{qkv, qkv + E, qkv + 2 * E, 3 * E, 3 * E, 3 * E, (int64_t)N * 3 * E, (int64_t)N * 3 * E,
-                 (int64_t)N * 3 * E, ctx, E, (int64_t)N * E, B * T, N, N, H, d, scale, nullptr, 0};
+                 (int64_t)N * 3 * E, ctx, E, (int64_t)N * E, T, N, N, H, d, scale, nullptr, 0};
       const int e = attention_core(ar, a, dry, st);
       if (e != U2_OK) return e;
+    } else if (c.attn_type == 2) {
+      // sequence = the B*N (batch, token) pairs of one chunk index: gather rows (b, t, n) -> (t, b, n), attend, scatter
+      const size_t mark = ar.off;
+      bf16_t* g = ar.get<bf16_t>((size_t)rows * 3 * E);
+      bf16_t* gc = ar.get<bf16_t>((size_t)rows * E);
+      U2_CHECK_WS(ar);
+      if (!dry)
+        for (int b = 0; b < B; ++b)
+          if (hipMemcpy2DAsync(g + (size_t)b * N * 3 * E, (size_t)B * N * 3 * E * 2, qkv + (size_t)b * T * N * 3 * E,
+                               (size_t)N * 3 * E * 2, (size_t)N * 3 * E * 2, T, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return U2_ERR_LAUNCH;
+      const int64_t S2 = (int64_t)B * N;
+      AttnCore a{g, g + E, g + 2 * E, 3 * E, 3 * E, 3 * E, S2 * 3 * E, S2 * 3 * E, S2 * 3 * E, gc, E, S2 * E,
+                 T, (int)S2, (int)S2, H, d, scale, nullptr, 0};
+      const int e = attention_core(ar, a, dry, st);
+      if (e != U2_OK) return e;
+      if (!dry)
+        for (int b = 0; b < B; ++b)
+          if (hipMemcpy2DAsync(ctx + (size_t)b * T * N * E, (size_t)N * E * 2, gc + (size_t)b * N * E, (size_t)B * N * E * 2,
+                               (size_t)N * E * 2, T, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return U2_ERR_LAUNCH;
+      ar.off = mark;
     } else {
-      U2_RUN(temporal_attention(qkv, qkv + E, qkv + 2 * E, ctx, B, T, N, H, d, 3 * E, E, scale, tp.rb, c.max_seq_len, st));
+      const int e = chunk_axis_attention(ar, qkv, ctx, B, T, N, H, d, scale, tp.rb, c.max_seq_len, dry, st);
+      if (e != U2_OK) return e;
     }
     U2_RUN(linear(ctx, E, tp.wd, tp.bd, y2, E, rows, E, E, 0, nullptr, 0, st));
     x = y2;
@@ -453,7 +471,8 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
   bf16_t* qctx = ar.get<bf16_t>((size_t)qrows * E);
   bf16_t* qo = ar.get<bf16_t>((size_t)qrows * E);
   // k | v of the two cross attentions of every layer: one buffer each, filled on the side stream (or in line)
-  const bool overlap = g_tta_overlap && L > 0 && L <= 7 && (dry || g_side.init());
+  SideStream* side = (!dry && opts().tta_overlap && L > 0 && L <= 7) ? cx.side_for(st) : nullptr;
+  const bool overlap = dry ? (L > 0 && L <= 7) : side != nullptr;  // dry: size for the larger (overlapped) layout
   const int Lmax = Lv > c.Lt ? Lv : c.Lt;
   bf16_t* kv_inline = overlap ? nullptr : ar.get<bf16_t>((size_t)B * Lmax * 2 * E);
   bf16_t* kv_v[8] = {};
@@ -476,19 +495,19 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
   };
   if (overlap && !dry) {
     // fork: everything `st` has enqueued so far (V and t_token are final) precedes the side stream's work
-    if (hipEventRecord(g_side.fork, st) != hipSuccess || hipStreamWaitEvent(g_side.s, g_side.fork, 0) != hipSuccess)
+    if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess)
       return U2_ERR_LAUNCH;
     for (int l = 0; l < L; ++l) {
       const int base = i_tta + 33 * l;
       Att va = att_at(base + 9), ta = att_at(base + 18);
-      { const int e = kv_proj(va, V, Lv, kv_v[l], g_side.s); if (e != U2_OK) return e; }
-      if (hipEventRecord(g_side.done[2 * l], g_side.s) != hipSuccess) return U2_ERR_LAUNCH;
-      { const int e = kv_proj(ta, t_token, c.Lt, kv_t[l], g_side.s); if (e != U2_OK) return e; }
-      if (hipEventRecord(g_side.done[2 * l + 1], g_side.s) != hipSuccess) return U2_ERR_LAUNCH;
+      { const int e = kv_proj(va, V, Lv, kv_v[l], side->s); if (e != U2_OK) return e; }
+      if (hipEventRecord(side->done[2 * l], side->s) != hipSuccess) return U2_ERR_LAUNCH;
+      { const int e = kv_proj(ta, t_token, c.Lt, kv_t[l], side->s); if (e != U2_OK) return e; }
+      if (hipEventRecord(side->done[2 * l + 1], side->s) != hipSuccess) return U2_ERR_LAUNCH;
     }
     const Att la = att_at(i_lin);
-    U2_RUN(linear(V, E, la.wk, la.bk, k_lin, E, (int64_t)B * Lv, E, E, 0, nullptr, 0, g_side.s));
-    if (hipEventRecord(g_side.done[2 * L], g_side.s) != hipSuccess) return U2_ERR_LAUNCH;
+    U2_RUN(linear(V, E, la.wk, la.bk, k_lin, E, (int64_t)B * Lv, E, E, 0, nullptr, 0, side->s));
+    if (hipEventRecord(side->done[2 * L], side->s) != hipSuccess) return U2_ERR_LAUNCH;
   }
   U2_RUN(fill_rows(wp(0), qa, B, (int64_t)Q * E, (int64_t)Q * E, st));  // query_tokens.expand(B,-1,-1)
   bf16_t* qcur = qa;
@@ -501,7 +520,7 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
       const int e = kv_proj(a, src, Ls, kv, st);
       if (e != U2_OK) return e;
     } else if (!dry) {
-      if (hipStreamWaitEvent(st, g_side.done[kv_ready], 0) != hipSuccess) return U2_ERR_LAUNCH;
+      if (hipStreamWaitEvent(st, side->done[kv_ready], 0) != hipSuccess) return U2_ERR_LAUNCH;
     }
     AttnCore ac{qproj, kv, kv + E, E, 2 * E, 2 * E, (int64_t)Q * E, (int64_t)Ls * 2 * E, (int64_t)Ls * 2 * E,
                 qctx, E, (int64_t)Q * E, B, Q, Ls, H, d, scale, nullptr, 0};
@@ -520,10 +539,15 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
     bf16_t* s1 = (qcur == qa) ? qb : qa;
     bf16_t* s2 = qc;
     // self attention on the query tokens + post-LN residual (tta.py:94-96)
-    if (c.attn_type == 2) {
+    if (c.attn_type == 2 && B == 1) {
       // (B = 1, Q, E) read sequence-first: every query token is a batch entry with a sequence of ONE key, whose
       // softmax weight is exactly 1 -> the context is the value projection itself (tta.py:84,94)
       U2_RUN(linear(qcur, E, sa.wv, sa.bv, qctx, E, qrows, E, E, 0, nullptr, 0, st));
+    } else if (c.attn_type == 2) {
+      // (B, Q, E) read sequence-first: the sequence is the B batch entries of one query index
+      { const int e = qkv_proj(qcur, sa, qproj, qrows, E, dry, st); if (e != U2_OK) return e; }
+      const int e = chunk_axis_attention(ar, qproj, qctx, 1, B, Q, H, d, scale, nullptr, c.max_seq_len, dry, st);
+      if (e != U2_OK) return e;
     } else {
       { const int e = qkv_proj(qcur, sa, qproj, qrows, E, dry, st); if (e != U2_OK) return e; }
       if (c.attn_type == 1) {
@@ -552,7 +576,7 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
     if (!overlap) {
       U2_RUN(linear(V, E, la.wk, la.bk, k_lin, E, (int64_t)B * Lv, E, E, 0, nullptr, 0, st));
     } else if (!dry) {
-      if (hipStreamWaitEvent(st, g_side.done[2 * L], 0) != hipSuccess) return U2_ERR_LAUNCH;
+      if (hipStreamWaitEvent(st, side->done[2 * L], 0) != hipSuccess) return U2_ERR_LAUNCH;
     }
     AttnCore ac{qproj, k_lin, V, E, E, E, (int64_t)Q * E, (int64_t)Lv * E, (int64_t)Lv * E,
                 out, E, (int64_t)Q * E, B, Q, Lv, H, d, scale, nullptr, 0};

@@ -2,7 +2,10 @@
 stream only; every computation below happens in libu2tok_hip.so."""
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import functools
+import threading
 from typing import Optional
 
 import torch
@@ -13,8 +16,98 @@ GEMM_BIAS_N, GEMM_BIAS_M, GEMM_GELU, GEMM_RESIDUAL, GEMM_OUT_F32 = 1, 2, 4, 8, 1
 _VOL_DTYPE = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
 
 
+# ---------------------------------------------------------------------------------- contexts / device guard
+class Context:
+    """One execution context of the library (include/u2tok.h, "execution contexts"): its own option set, tokenizer side
+    streams + events, split-K scratch table and profiling records.  Every GPU gets a default context on first use;
+    `with ops.Context() as c:` runs the enclosed calls of this thread on a private one (e.g. a second model with other
+    options, or a worker thread)."""
+
+    def __init__(self):
+        h = _lib.load_library()
+        handle = C.c_void_p()
+        _lib.check(h.u2tok_ctx_create(C.byref(handle)), "u2tok_ctx_create")
+        self.handle = handle
+
+    def close(self) -> None:
+        if self.handle:
+            _lib.load_library().u2tok_ctx_destroy(self.handle)
+            self.handle = None
+
+    def set_option(self, name: str, value: int) -> None:
+        h = _lib.load_library()
+        prev = h.u2tok_ctx_get_current()
+        h.u2tok_ctx_set_current(self.handle)
+        try:
+            _lib.check(h.u2tok_set_option(name.encode(), int(value)), f"u2tok_set_option({name})")
+        finally:
+            h.u2tok_ctx_set_current(prev)
+
+    def __enter__(self):
+        stack = getattr(_tls, "stack", None)
+        if stack is None:
+            stack = _tls.stack = []
+        stack.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        _tls.stack.pop()
+        return False
+
+
+_tls = threading.local()
+_default_ctx = {}  # device index -> Context
+_default_lock = threading.Lock()
+
+
+def active_context(device=None) -> Context:
+    """Innermost `with Context()` of the calling thread, else the default context of `device` (current device if None)."""
+    stack = getattr(_tls, "stack", None)
+    if stack:
+        return stack[-1]
+    idx = torch.cuda.current_device() if device is None or device.index is None else device.index
+    with _default_lock:
+        c = _default_ctx.get(idx)
+        if c is None:
+            c = _default_ctx[idx] = Context()
+    return c
+
+
+@contextlib.contextmanager
+def on_device(t: torch.Tensor):
+    """Entry guard of every wrapper: makes the tensor's GPU the current HIP device (the library launches on the current
+    device; a model on cuda:1 must not launch on cuda:0), binds the active context and yields (library handle, the
+    current torch stream OF THAT DEVICE)."""
+    if not t.is_cuda:
+        raise RuntimeError("expected a GPU tensor (the u2tok HIP path has no CPU fallback)")
+    h = _lib.load_library()
+    with torch.cuda.device(t.device):
+        h.u2tok_ctx_set_current(active_context(t.device).handle)
+        yield h, torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _guarded(fn):
+    """Runs a building-block wrapper under on_device(first tensor argument); _stream() is that device's stream."""
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        t = next((a for a in list(args) + list(kwargs.values()) if torch.is_tensor(a)), None)
+        if t is None or not t.is_cuda:
+            raise RuntimeError(f"{fn.__name__}: expected GPU tensors (the u2tok HIP path has no CPU fallback)")
+        with on_device(t) as (_, st):
+            prev = getattr(_tls, "stream", None)
+            _tls.stream = st
+            try:
+                return fn(*args, **kwargs)
+            finally:
+                _tls.stream = prev
+
+    return wrapper
+
+
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    st = getattr(_tls, "stream", None)
+    return st if st is not None else torch.cuda.current_stream().cuda_stream
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -30,7 +123,8 @@ def _need(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
 
 
 def set_option(name: str, value: int) -> None:
-    _lib.check(_lib.load_library().u2tok_set_option(name.encode(), int(value)), f"u2tok_set_option({name})")
+    """Option of the active context (the current device's default context unless inside `with Context()`)."""
+    active_context().set_option(name, value)
 
 
 def device_check() -> None:
@@ -54,6 +148,7 @@ def pack_ktile_major(w: torch.Tensor) -> torch.Tensor:
     return w.view(N, K // 64, 64).permute(1, 0, 2).contiguous()
 
 
+@_guarded
 def gemm(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, bias_m=False, gelu=False, out_f32=False,
          alpha=1.0, out: Optional[torch.Tensor] = None, b_ktile: bool = False) -> torch.Tensor:
     """C = epi(alpha * A B^T) for A (..., M, K), B (N, K) or batched (Z, N, K); b_ktile: B = pack_ktile_major(weight)."""
@@ -103,10 +198,15 @@ def set_gemm_scratch(buf: Optional[torch.Tensor]) -> None:
     """Registers `buf` (any dtype, on the GPU) as split-K scratch for gemm() calls on the current stream; None removes
     it.  The caller keeps the tensor alive while products may be in flight."""
     h = _lib.load_library()
-    st = h.u2tok_set_gemm_scratch(_ptr(buf), 0 if buf is None else buf.numel() * buf.element_size(), _stream())
+    dev = buf.device if buf is not None else torch.device("cuda", torch.cuda.current_device())
+    with torch.cuda.device(dev):
+        h.u2tok_ctx_set_current(active_context(dev).handle)
+        st = h.u2tok_set_gemm_scratch(_ptr(buf), 0 if buf is None else buf.numel() * buf.element_size(),
+                                      torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(st, "u2tok_set_gemm_scratch")
 
 
+@_guarded
 def layernorm(x, w, b, residual=None, eps=1e-5):
     h = _lib.load_library()
     x = _need(x, torch.bfloat16, "x").contiguous()
@@ -119,6 +219,7 @@ def layernorm(x, w, b, residual=None, eps=1e-5):
     return y
 
 
+@_guarded
 def softmax_rows(s: torch.Tensor, scale=1.0, rel_bias=None, heads=1, max_len=0, ldp=None):
     """s: (Z, R, n) fp32 -> (Z, R, ldp) bf16 (columns >= n are zero)."""
     h = _lib.load_library()
@@ -131,6 +232,7 @@ def softmax_rows(s: torch.Tensor, scale=1.0, rel_bias=None, heads=1, max_len=0, 
     return p
 
 
+@_guarded
 def transpose(x: torch.Tensor, ld_out=None, perm16=False):
     """x: (Z, R, C) bf16 -> (Z, C, ld_out) with zero padding."""
     h = _lib.load_library()
@@ -143,6 +245,7 @@ def transpose(x: torch.Tensor, ld_out=None, perm16=False):
     return y
 
 
+@_guarded
 def im2col(vol: torch.Tensor, patch):
     h = _lib.load_library()
     vol = vol.contiguous()
@@ -156,6 +259,7 @@ def im2col(vol: torch.Tensor, patch):
     return out
 
 
+@_guarded
 def avgpool3d_tokens(x: torch.Tensor, grid, window):
     h = _lib.load_library()
     x = _need(x, torch.bfloat16, "x").contiguous()
@@ -168,6 +272,7 @@ def avgpool3d_tokens(x: torch.Tensor, grid, window):
     return y
 
 
+@_guarded
 def embed_splice(table: torch.Tensor, ids: torch.Tensor, feats: Optional[torch.Tensor] = None):
     """embed_tokens(ids) with feats (B, nfeat, E) spliced over positions 1..nfeat (u2_arch.py:109,113-116)."""
     h = _lib.load_library()
@@ -187,6 +292,7 @@ def embed_splice(table: torch.Tensor, ids: torch.Tensor, feats: Optional[torch.T
     return out
 
 
+@_guarded
 def score_gemv(x, w, bias):
     h = _lib.load_library()
     x = _need(x, torch.bfloat16, "x").contiguous()
@@ -197,6 +303,7 @@ def score_gemv(x, w, bias):
     return s
 
 
+@_guarded
 def topk_sorted(scores: torch.Tensor, k: int):
     h = _lib.load_library()
     scores = _need(scores, torch.float32, "scores").contiguous()
@@ -206,6 +313,7 @@ def topk_sorted(scores: torch.Tensor, k: int):
     return idx
 
 
+@_guarded
 def gather_rows(x, idx):
     h = _lib.load_library()
     x = _need(x, torch.bfloat16, "x").contiguous()
@@ -217,6 +325,7 @@ def gather_rows(x, idx):
     return out
 
 
+@_guarded
 def multiscale_pool(x, gate_w=None, gate_b=None):
     h = _lib.load_library()
     x = _need(x, torch.bfloat16, "x").contiguous()
@@ -228,6 +337,7 @@ def multiscale_pool(x, gate_w=None, gate_b=None):
     return out
 
 
+@_guarded
 def temporal_attention(q, k, v, B, T, N, H, scale, rel_bias=None, max_len=512):
     """q/k/v: (B*T*N, E) rows in (b t n) order."""
     h = _lib.load_library()
@@ -239,6 +349,7 @@ def temporal_attention(q, k, v, B, T, N, H, scale, rel_bias=None, max_len=512):
     return out
 
 
+@_guarded
 def flash_attention_d64(qkv: torch.Tensor, heads: int, scale: float, extra_last: bool = False):
     """qkv: (nb, S, 3*heads*64) bf16 in MONAI SABlock column order (q | k | v).  extra_last=True runs the last row of
     every batch through the kernel's "extra row" path (how the ViT tower feeds its cls token); same result."""
@@ -267,6 +378,7 @@ def flash_attention_d64(qkv: torch.Tensor, heads: int, scale: float, extra_last:
     return out
 
 
+@_guarded
 def rope_apply(x: torch.Tensor, n_outer, S, n_inner, H, d, max_len=512):
     h = _lib.load_library()
     _lib.check(h.u2tok_rope_apply(_ptr(x), n_outer, S, n_inner, H, d, x.stride(-2), max_len, _stream()),
@@ -283,7 +395,7 @@ class _Workspace:
         self.bufs = {}
 
     def get(self, nbytes: int, device) -> torch.Tensor:
-        key = (str(device), _stream())
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream)
         buf = self.bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(nbytes, dtype=torch.uint8, device=device)

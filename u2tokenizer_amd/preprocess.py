@@ -47,14 +47,15 @@ class u2Transform:
         if padding_size % 32:
             raise RuntimeError("padding_size must be a multiple of 32 (the path consumes 32-slice chunks)")
         D, H, W = vol.shape
-        ws = self._ws.get(h.u2tok_preprocess_workspace_bytes(D, H, W), vol.device)
-        out = torch.empty((padding_size // 32, 32, target_image_size, target_image_size), dtype=self.out_dtype,
-                          device=vol.device)
-        info = torch.empty(12, dtype=torch.int32, device=vol.device)
-        _lib.check(h.u2tok_preprocess_volume(vol.data_ptr(), out.data_ptr(), info.data_ptr(), D, H, W, target_image_size,
-                                             padding_size, float(self.lower), float(self.upper), _DT[self.out_dtype],
-                                             ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
-                   "u2tok_preprocess_volume")
+        with ops.on_device(vol) as (h, stream):
+            ws = self._ws.get(h.u2tok_preprocess_workspace_bytes(D, H, W), vol.device)
+            out = torch.empty((padding_size // 32, 32, target_image_size, target_image_size), dtype=self.out_dtype,
+                              device=vol.device)
+            info = torch.empty(12, dtype=torch.int32, device=vol.device)
+            _lib.check(h.u2tok_preprocess_volume(vol.data_ptr(), out.data_ptr(), info.data_ptr(), D, H, W,
+                                                 target_image_size, padding_size, float(self.lower), float(self.upper),
+                                                 _DT[self.out_dtype], ws.data_ptr(), ws.numel(), stream),
+                       "u2tok_preprocess_volume")
         self.last_info = info
         return out
 

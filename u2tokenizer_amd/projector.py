@@ -59,11 +59,12 @@ class SpatialPoolingProjector(nn.Module):
         nbytes = h.u2tok_spp_workspace_bytes(C.byref(cfg))
         if nbytes == 0:
             raise RuntimeError("u2tok_spp_workspace_bytes rejected the configuration")
-        ws = self._ws.get(nbytes, x.device)
         n_out = self.proj_out_num if self.pooling_type == "spatial" else n // self.pooling_size ** 3
-        out = torch.empty((nchunk, n_out, self.out_dim), dtype=torch.bfloat16, device=x.device)
-        _lib.check(h.u2tok_spp_forward(C.byref(cfg), table, x.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                       torch.cuda.current_stream().cuda_stream), "u2tok_spp_forward")
+        with ops.on_device(x) as (h, stream):
+            ws = self._ws.get(nbytes, x.device)
+            out = torch.empty((nchunk, n_out, self.out_dim), dtype=torch.bfloat16, device=x.device)
+            _lib.check(h.u2tok_spp_forward(C.byref(cfg), table, x.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                           stream), "u2tok_spp_forward")
         return out
 
     @property

@@ -42,17 +42,39 @@ def synth_tensor(name: str, shape: Sequence[int], seed: int = 0) -> torch.Tensor
     return 0.02 * x
 
 
+def lively_(name: str, t: torch.Tensor, qk_gain: float = 4.0, sel_gain: float = 16.0) -> torch.Tensor:
+    """The "lively" parameter set (in place on `t`, returned).  The SVR is a stack of attention layers WITHOUT
+    residuals or norms (svr.py:29,35): with unit-scale projections its softmaxes are near-uniform and every token
+    collapses onto the token mean after two layers (token diversity 1e-5 after four), which would let any downstream
+    comparison pass trivially.  Scaling the query / key projections (attention logits x qk_gain^2) and the DiffTS
+    score net keeps the attention selective, so the parity tests carry token-dependent data end to end."""
+    if "u2tokenizer" not in name:
+        return t
+    if name.endswith(".wq.weight") or name.endswith(".wk.weight"):
+        t.mul_(qk_gain)
+    elif name.endswith(".in_proj_weight"):  # nn.MultiheadAttention: rows [q | k | v]; synth_tensor drew it at 0.02
+        t.mul_(1.0 / (0.02 * math.sqrt(t.shape[1])))
+        t[: 2 * t.shape[0] // 3].mul_(qk_gain)
+    elif name.endswith("token_selection.score_net.weight") and t.shape[0] > 1:  # DiffTS heads (svr.py:96)
+        t.mul_(sel_gain)
+    return t
+
+
 def synth_state_dict(shapes: Mapping[str, Sequence[int]], seed: int = 0) -> Dict[str, torch.Tensor]:
     return {k: synth_tensor(k, s, seed) for k, s in shapes.items()}
 
 
-def fill_module_(module: torch.nn.Module, seed: int = 0, prefix: str = "") -> None:
-    """In-place: module.state_dict()[k] <- synth_tensor(prefix + k) cast to the parameter's dtype."""
+def fill_module_(module: torch.nn.Module, seed: int = 0, prefix: str = "", lively: bool = False) -> None:
+    """In-place: module.state_dict()[k] <- synth_tensor(prefix + k) cast to the parameter's dtype
+    (through lively_() when `lively`)."""
     sd = module.state_dict()
     with torch.no_grad():
         for k, v in sd.items():
             if v.is_floating_point():
-                v.copy_(synth_tensor(prefix + k, v.shape, seed).to(v.dtype))
+                t = synth_tensor(prefix + k, v.shape, seed)
+                if lively:
+                    lively_(prefix + k, t)
+                v.copy_(t.to(v.dtype))
 
 
 def synth_volume(B: int, C: int, image_size: Sequence[int], seed: int = 1, dtype=torch.float16) -> torch.Tensor:

@@ -246,17 +246,44 @@ class u2Tokenizer(nn.Module):
         return w
 
     def pack_weights(self) -> None:
-        """Idempotent; re-run automatically after .to() moved the parameters to fresh (unpacked) storage."""
+        """Idempotent.  Runs eagerly whenever the parameters move (.to() / .cuda() / .bfloat16() go through _apply) and
+        as a safety net at the head of forward().  Packing re-points wq / wk / wv at freshly written buffers, so it ends
+        with a device-wide synchronisation: every stream sees the packed weights, and the old storages are idle when
+        the caching allocator takes them back (forward calls may be issued on several non-blocking streams)."""
         key = (self.query_tokens.data_ptr(), self.query_tokens.dtype)
         if self._packed_key == key:
             return
-        for layer in self.svt_module.attention_network.layers:
-            _pack_qkv(layer.spatial_attention)
-            _pack_qkv(layer.temporal_attention)
-        for layer in self.tta_module.layers_vt:
-            for m in (layer.self_attention, layer.visual_cross_attention, layer.text_cross_attention):
-                _pack_qkv(m)
+        with torch.no_grad():
+            for layer in self.svt_module.attention_network.layers:
+                _pack_qkv(layer.spatial_attention)
+                _pack_qkv(layer.temporal_attention)
+            for layer in self.tta_module.layers_vt:
+                for m in (layer.self_attention, layer.visual_cross_attention, layer.text_cross_attention):
+                    _pack_qkv(m)
+        if self.query_tokens.is_cuda:
+            torch.cuda.synchronize(self.query_tokens.device)
         self._packed_key = key
+
+    def _apply(self, fn, *args, **kwargs):
+        r = super()._apply(fn, *args, **kwargs)
+        self._packed_key = None
+        if self.query_tokens.is_cuda:
+            self.pack_weights()
+        return r
+
+    # The envelope of the HIP path, checked here so that a violation names the limit instead of a bare U2TOK_ERR_ARG.
+    def _check_envelope(self, B, T, N, E, Lt):
+        H = self.num_heads
+        if E % H or (E // H) % 8:
+            raise RuntimeError(f"head dim {E}/{H} must be a multiple of 8 (16-byte fragment loads)")
+        if max(N, T, self.num_query) > 512:
+            raise RuntimeError(f"sequence lengths N={N}, T={T}, queries={self.num_query} must be <= max_seq_len = 512 "
+                               "(relative-bias table / RoPE cache of the reference, rma.py:6,64-68, rope.py:19)")
+        if not self.enable_diffts:
+            if self.top_k > T * N:
+                raise RuntimeError(f"top_k={self.top_k} > T*N={T * N}: torch.topk would raise in the reference (svr.py:82)")
+            if T * N > 8192:
+                raise RuntimeError(f"hard top-k sorts T*N={T * N} scores in one workgroup's LDS: limit 8192")
 
     def forward(self, v_token, t_token):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
@@ -267,13 +294,9 @@ class u2Tokenizer(nn.Module):
         v_token = ops._need(v_token, torch.bfloat16, "v_token").contiguous()
         t_token = ops._need(t_token, torch.bfloat16, "t_token").contiguous()
         (B, T, N, E) = v_token.size()
-        if self.attn_type not in _ATTN_TYPES and B != 1:
-            raise NotImplementedError(
-                "attn_type outside {'rma', 'rope'}: nn.MultiheadAttention reads (b*t, n, e) sequence-first, i.e. it "
-                "attends ACROSS the batch entries (svr.py:28-35, tta.py:94); the HIP path implements that variant for "
-                "B = 1 only")
         if E != self.embed_size or t_token.shape[0] != B or t_token.shape[2] != E:
             raise RuntimeError(f"shape mismatch: v_token {tuple(v_token.shape)}, t_token {tuple(t_token.shape)}")
+        self._check_envelope(B, T, N, E, t_token.shape[1])
         cfg = _lib.TokConfig(B=B, T=T, N=N, E=E, Lt=t_token.shape[1], num_heads=self.num_heads,
                              num_layers=self.num_layers, top_k=self.top_k, num_query=self.num_query,
                              use_multi_scale=int(self.use_multi_scale), attn_type=_ATTN_TYPES.get(self.attn_type, 2),
@@ -285,18 +308,18 @@ class u2Tokenizer(nn.Module):
         if nbytes == 0:
             raise RuntimeError("u2tok_tokenizer_workspace_bytes rejected the configuration "
                                f"(B={B}, T={T}, N={N}, E={E}, heads={self.num_heads}, top_k={self.top_k})")
-        ws = self._ws.get(nbytes, v_token.device)
-        out = torch.empty((B, self.num_query, E), dtype=torch.bfloat16, device=v_token.device)
-        idx = None
-        if not self.enable_diffts:
-            idx = torch.empty((B, self.top_k), dtype=torch.int64, device=v_token.device)
-        svr = None
-        if self.capture_svr_tokens:
-            svr = torch.empty((B, T * N, E), dtype=torch.bfloat16, device=v_token.device)
-        _lib.check(h.u2tok_tokenizer_forward(C.byref(cfg), table, v_token.data_ptr(), t_token.data_ptr(),
-                                             out.data_ptr(), None if idx is None else idx.data_ptr(),
-                                             None if svr is None else svr.data_ptr(), ws.data_ptr(), ws.numel(),
-                                             torch.cuda.current_stream().cuda_stream), "u2tok_tokenizer_forward")
+        idx = svr = None
+        with ops.on_device(v_token) as (h, stream):
+            ws = self._ws.get(nbytes, v_token.device)
+            out = torch.empty((B, self.num_query, E), dtype=torch.bfloat16, device=v_token.device)
+            if not self.enable_diffts:
+                idx = torch.empty((B, self.top_k), dtype=torch.int64, device=v_token.device)
+            if self.capture_svr_tokens:
+                svr = torch.empty((B, T * N, E), dtype=torch.bfloat16, device=v_token.device)
+            _lib.check(h.u2tok_tokenizer_forward(C.byref(cfg), table, v_token.data_ptr(), t_token.data_ptr(),
+                                                 out.data_ptr(), None if idx is None else idx.data_ptr(),
+                                                 None if svr is None else svr.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                 stream), "u2tok_tokenizer_forward")
         self.last_topk_indices = idx
         self.last_svr_tokens = svr
         return out

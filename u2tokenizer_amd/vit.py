@@ -126,6 +126,8 @@ class ViT(nn.Module):
         h = _lib.load_library()
         if x.dim() != 5 or x.shape[1] != 1 or list(x.shape[2:]) != self.img_size:
             raise RuntimeError(f"expected images of shape (N,1,{self.img_size}), got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise RuntimeError("images: expected a GPU tensor (the u2tok HIP path has no CPU fallback)")
         x = x.contiguous()
         nchunk = x.shape[0]
         cfg = _lib.VitConfig(nchunk=nchunk, img=(C.c_int32 * 3)(*self.img_size),
@@ -136,11 +138,12 @@ class ViT(nn.Module):
         nbytes = h.u2tok_vit_workspace_bytes(C.byref(cfg))
         if nbytes == 0:
             raise RuntimeError("u2tok_vit_workspace_bytes rejected the configuration")
-        ws = self._ws.get(nbytes, x.device)
         ntok = self.patch_embedding.n_patches + (1 if keep_cls else 0)
-        out = torch.empty((nchunk, ntok, self.hidden_size), dtype=torch.bfloat16, device=x.device)
-        _lib.check(h.u2tok_vit_forward(C.byref(cfg), table, x.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                       torch.cuda.current_stream().cuda_stream), "u2tok_vit_forward")
+        with ops.on_device(x) as (h, stream):
+            ws = self._ws.get(nbytes, x.device)
+            out = torch.empty((nchunk, ntok, self.hidden_size), dtype=torch.bfloat16, device=x.device)
+            _lib.check(h.u2tok_vit_forward(C.byref(cfg), table, x.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                           stream), "u2tok_vit_forward")
         return out
 
     def forward(self, x):
