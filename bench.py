@@ -248,6 +248,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-iters", type=int, default=3)
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="library tuning switch for A/B measurements (u2tok_set_option), e.g. --option flash_mode=5")
     ap.add_argument("--stub-cpu", action="store_true",
                     help="TEST PLUMBING ONLY (tests/test_bench_launcher.py): replace the step by a host no-op and use the "
                          "gloo backend, so that the launcher / barrier / MAX-over-ranks / JSON path can run on a box "
@@ -281,6 +283,9 @@ def main():
         dist, rank, world = replicas.init_from_env("nccl", device)
         from u2tokenizer_amd import _lib, ops
         ops.device_check()  # fails loudly off gfx950 / without the HIP library
+        for kv in args.option:
+            k, _, v = kv.partition("=")
+            ops.set_option(k, int(v))
         torch.set_grad_enabled(False)
         vocab = 151936  # Qwen3 vocabulary
         path, cfg = build_path(E, vocab, device)
@@ -336,7 +341,8 @@ def main():
         "path_tflops": round(value * fl["total"] / 1e12, 1),
         "path_frac_of_bf16_mfma_peak": round(value * fl["total"] / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
         "config": {"workload": WORKLOAD, "hidden_size": E, "batch_per_gpu": B, "streams_per_gpu": args.streams,
-                   "flop_per_volume": fl["total"], "parallelism": f"replicas x{world}"},
+                   "flop_per_volume": fl["total"], "parallelism": f"replicas x{world}",
+                   **({"options": args.option} if args.option else {})},
     }
     if args.stub_cpu:
         line.update({"data": "stub (launcher self-test, no GPU work)", "valid": False})

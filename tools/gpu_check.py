@@ -398,6 +398,23 @@ def sec_ppperf(shapes_sel=None):
     ops.set_option("gemm_big", 0)
 
 
+def sec_geluperf():
+    """fc1 of the ViT (bias + GELU): small-tile kernel vs the big-tile kernel with the GELU epilogue"""
+    M, N, K = 16384, 3072, 768
+    a, b, bias = rnd(M, K, seed=1).to(dev), rnd(N, K, seed=2).to(dev), rnd(N, seed=3).to(dev)
+    out = torch.empty((1, M, N), dtype=bf, device=dev)
+    for name, big, bg in (("128^2 kernel", -1, 0), ("heuristic", 0, 0), ("big tile + GELU (heuristic pick)", 0, 1),
+                          ("big tile 256x256 + GELU", 20, 1), ("big tile 256x192 + GELU", 21, 1)):
+        ops.set_option("gemm_big", big)
+        ops.set_option("gemm_big_gelu", bg)
+        ms = timeit(lambda: ops.gemm(a, b, bias=bias, gelu=True, out=out), iters=10, warm=3)
+        ms2 = timeit(lambda: ops.gemm(a, b, bias=bias, out=out), iters=10, warm=3)
+        print(f"  fc1 {M}x{N}x{K} {name:34s}: gelu {ms * 1e3:7.1f} us ({2 * M * N * K / ms / 1e9:5.0f} TF/s)   bias only "
+              f"{ms2 * 1e3:7.1f} us", flush=True)
+    ops.set_option("gemm_big", 0)
+    ops.set_option("gemm_big_gelu", 0)
+
+
 def sec_flashperf():
     print("[flash perf] nb=8 H=12 (the ViT-B block at 256^3): us per launch incl. the V transpose, TF/s, MFMA util of 2.5 PF", flush=True)
     for (nb, S, H, extra) in [(8, 2049, 12, True), (8, 2049, 12, False), (8, 2048, 12, False), (16, 513, 12, True)]:
