@@ -55,8 +55,7 @@ u2tok_ctx_t u2tok_ctx_get_current(void);     /* NULL when the thread uses the de
     that many K slices where scratch allows}, "gemm_big" {-1 never, 0 heuristic, 20 / 21 force the 256x256 / 256x192
     big-tile kernel}, "gemm_big_grid" {persistent workgroups}, "gemm_big_gelu" {0, 1: GELU products may take the
     big-tile kernel}, "gemm_skinny" {-1 never, 0 heuristic, 1 force the weight-streaming kernel for M <= 256},
-    "flash_mode" {0 pick, 1 plain 128-row units, 5 double pipeline (asm KV loop), 6 double pipeline + split-KV second
-    pass}, "vit_flash" {0 unfused attention, 1}, "tta_overlap" {0, 1: side stream for the TTA k|v projections},
+    "flash_mode" {0 pick, 1 plain 128-row units, 5 double pipeline (asm KV loop)}, "vit_flash" {0 unfused attention, 1}, "tta_overlap" {0, 1: side stream for the TTA k|v projections},
     "profile" {0, 1} */
 int u2tok_set_option(const char* name, int value);
 /* Scratch for split-K partial sums of u2tok_gemm_bf16 calls on `stream` (fp32, slices x M x N), registered on the

@@ -177,24 +177,22 @@ def run_full_config(name, c, B, C, S, Lt, seed, vocab=4096):
            "host_threads": torch.get_num_threads(), "stages": {}}
     for st in ("vit", "spp", "tokenizer", "inputs_embeds"):
         rep["stages"][st] = three_way(hip[st], o32[st], o16[st])
-    # The ViT features of a noise volume share a large common component (token diversity ~0.45), which makes the
-    # residual-free SVR attention query-independent: the chain above reaches the aggregation stages with nearly
-    # identical tokens.  The tokenizer is therefore ALSO compared at this configuration's size on synthetic visual
-    # tokens without a common mode, where every stage sees token-dependent data (diversity asserted).
-    E, N = c["hidden_size"], o32["spp"].shape[1]
-    v = synth.synth_tensor("v_token", (B, C, N, E), seed)
-    tt = 0.25 * synth.synth_tensor("t_token", (B, Lt, E), seed)
-    l32, _ = O.tokenizer_forward(sd32, "model.u2tokenizer", v, tt, oc)
-    l16, _ = O.tokenizer_forward(sd16, "model.u2tokenizer", v.to(bf), tt.to(bf), oc)
-    lh = path.holder.u2tokenizer(v_token=v.to(bf).to(D), t_token=tt.to(bf).to(D))
-    rep["stages"]["tokenizer_on_synthetic_tokens"] = three_way(lh, l32, l16)
     record(name, rep)
     for st in rep["stages"]:
-        gate(rep["stages"][st], f"{name}:{st}")
-    for st in ("vit", "spp", "tokenizer", "inputs_embeds"):
         assert torch.isfinite(hip[st].float()).all(), st
-    assert rep["stages"]["tokenizer_on_synthetic_tokens"]["diversity_o32"] > 0.2, "degenerate (collapsed) test data"
+        gate(rep["stages"][st], f"{name}:{st}")
     return rep
+
+
+# NOTE on what the chained tests can and cannot see.  The SVR is a stack of attention layers without residuals or norms
+# (svr.py:29,35).  With random weights it is either contractive -- the ViT features of a noise volume share a large
+# common component, attention becomes query-independent and the 4-layer chain reaches the aggregation stages with nearly
+# identical tokens (token diversity ~0 at the tokenizer output, recorded per stage) -- or, with query / key gains large
+# enough to keep it selective, chaotic: the reference's own bf16 run then differs from its fp32 run by 50-140 % after
+# four layers (measured: profiles/r02_parity.json, tests/cases.py "live" cases), and hard top-k indices agree at chance
+# level.  The chained tests below therefore pin scales / biases / layouts / the ViT tightly (errors ~1e-2, HIP <= the
+# bf16 reference's own error), and token-dependent data flow is pinned by test_tokenizer_one_layer_full_width: ONE
+# selective layer at full width, where bf16 noise is 5-20 % and any indexing mistake is 100 %.
 
 
 def test_config3_full_path_vs_oracle():
@@ -260,6 +258,40 @@ def test_config1_survey_size_through_qwen3():
     if rep["fp32_top2_margin_step0"] > 4 * rep["logits_last"]["o16_vs_o32"]["max_abs"]:
         assert gen[0, 0] == gen32[0, 0], (gen, gen32)
     assert gen.shape == gen32.shape
+
+
+@pytest.mark.parametrize("E", [2048, 4096])
+def test_tokenizer_one_layer_full_width(E):
+    """One selective SVR layer + DiffTS(1024) + DMTP pooling + one TTA layer + aggregation at the width, token counts and
+    text length of BASELINE configs 2 / 3, on synthetic visual tokens without a common mode (query / key gain 3: the
+    attention picks specific keys, yet one layer keeps the reference's bf16 run within tens of percent of its fp32 run).
+    Besides the usual bar, the HIP output must be far closer to the fp32 reference than the same reference with its
+    query rows permuted is -- i.e. the comparison is not vacuous."""
+    from helpers import module_sd
+    from u2tokenizer_amd.tokenizer import u2Tokenizer
+    seed, args = 77, (E, 8, 1, 1024, True, 256, E, "rma", True, True)
+    sd32 = module_sd(u2Tokenizer(*args), "u2tokenizer.", seed)
+    for name, t in sd32.items():
+        synth.lively_(name, t, qk_gain=3.0)
+    sd16 = {k: v.to(bf) for k, v in sd32.items()}
+    with torch.device("meta"):
+        tok = u2Tokenizer(*args)
+    tok = tok.to(bf).to_empty(device=D)
+    tok.load_state_dict({k[len("u2tokenizer."):]: v for k, v in sd16.items()})
+    B = 2
+    v = synth.synth_tensor("v_token", (B, 8, 256, E), seed)
+    t = 0.25 * synth.synth_tensor("t_token", (B, 1024, E), seed)
+    oc = O.PathConfig(hidden_size=E, u2t_num_layers=1)
+    o32, _ = O.tokenizer_forward(sd32, "u2tokenizer", v, t, oc)
+    o16, _ = O.tokenizer_forward(sd16, "u2tokenizer", v.to(bf), t.to(bf), oc)
+    got = tok(v_token=v.to(bf).to(D), t_token=t.to(bf).to(D))
+    d = three_way(got, o32, o16)
+    d["permuted_rows_vs_o32"] = err_stats(o32.roll(1, dims=1), o32)
+    record(f"tokenizer_one_layer_E{E}", d)
+    gate(d, f"one layer E={E}")
+    assert d["diversity_o32"] > 0.3, d["diversity_o32"]
+    assert d["o16_vs_o32"]["rel_rms"] < 0.6, "chaotic regime: the comparison would be vacuous"
+    assert d["hip_vs_o32"]["rel_rms"] < 0.5 * d["permuted_rows_vs_o32"]["rel_rms"], d
 
 
 def test_cls_patch_feature_selection():

@@ -232,12 +232,10 @@ def test_flash_attention(ops, nb, S, H, scale, mode):
                                                (1, 2049, 3, 1.0, 0), (1, 2049, 3, 1.0, 1),
                                                (3, 101, 12, 3.0, 0), (1, 2, 1, 1.0, 0),
                                                (1, 2049, 3, 1.0, 5), (2, 321, 3, 3.0, 5), (1, 66, 2, 1.0, 5), (1, 2, 1, 1.0, 5),
-                                               (2, 577, 3, 1.0, 5), (1, 34, 1, 3.0, 5), (1, 97, 2, 3.0, 5),
-                                               (1, 2049, 3, 1.0, 6), (2, 513, 6, 1.0, 6), (3, 513, 2, 3.0, 6), (1, 257, 3, 3.0, 6)])
+                                               (2, 577, 3, 1.0, 5), (1, 34, 1, 3.0, 5), (1, 97, 2, 3.0, 5)])
 def test_flash_attention_extra_row(ops, nb, S, H, scale, mode):
     """The ViT path: S - 1 tiled main rows + one "extra" row per batch (the cls token) as key AND query.  The result
-    must equal plain attention over all S rows.  mode 6 (double pipeline + split-KV second pass) needs (S - 1) % 256 == 0
-    and nb * H % 3 == 0; the launcher falls back to mode 5 otherwise."""
+    must equal plain attention over all S rows."""
     qkv = rnd(nb, S, 3 * H * 64, scale=scale, seed=S + 1)
     ops.set_option("flash_mode", mode)
     try:
@@ -245,22 +243,6 @@ def test_flash_attention_extra_row(ops, nb, S, H, scale, mode):
     finally:
         ops.set_option("flash_mode", 0)
     close_bf16(got, _sdpa_ref(qkv, nb, S, H))
-
-
-@pytest.mark.parametrize("nb,S,H,scale", [(1, 512, 3, 1.0), (2, 1024, 6, 1.0), (1, 2048, 12, 1.0), (1, 768, 3, 3.0)])
-def test_flash_attention_split_kv(ops, nb, S, H, scale):
-    """mode 6: every workgroup runs one full 256-row pass and one 128-row pass whose keys are split between its wave
-    pairs and merged through LDS (S % 256 == 0, nb * H % 3 == 0).  Bit-repeatable; equal to plain attention; a key
-    spiked in the SECOND half of the sequence forces the rescale branch and the merge to disagree about the max."""
-    qkv = rnd(nb, S, 3 * H * 64, scale=scale, seed=S + 7)
-    qkv[0, S - 37, 64 * H:64 * H + 64] = (qkv[0, :, :64].float().mean(0) * 40).to(bf)  # k row S - 37 of head 0
-    ops.set_option("flash_mode", 6)
-    try:
-        outs = [ops.flash_attention_d64(qkv.to(D), H, 0.125).clone() for _ in range(3)]
-    finally:
-        ops.set_option("flash_mode", 0)
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
-    close_bf16(outs[0], _sdpa_ref(qkv, nb, S, H))
 
 
 def test_flash_attention_extra_key_forces_rescale(ops):

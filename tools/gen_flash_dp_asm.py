@@ -11,21 +11,11 @@ flash study).  Here every register of the loop is fixed by hand and the compiler
 Layout of the fixed registers (all clobbered): see REG below.  The block zeroes its state, runs prologue / tile loop /
 epilogue, and leaves the four O^T accumulator tuples in LDS (the K/V ring is dead by then) for the C++ epilogue.
 
-Two loop texts are emitted:
-  FLASH_DP_ASM_TEXT[_TIMED]  the full pass: one 256-row unit (4 waves x 2 x 32 rows) against ALL keys, 64-key tiles;
-  FLASH_DP2_ASM_TEXT         the split-KV pass of "mode 6": 128 rows, waves 0,1 take keys [0, S/2) and waves 2,3 keys
-                             [S/2, S) of the same two 64-row blocks.  A ring slot then holds one 32-key half tile of
-                             EACH side (K rows 0-31 | 32-63, V^T chunks 0-3 | 4-7, gathered by the DMA offsets the kernel
-                             computes), so the DMA, ring and barrier protocol are those of the full pass and every wave
-                             runs ONE phase pair per tile on its own half (operand %[side]: 0 / 1).  The two sides are
-                             merged by the kernel's C++ epilogue through LDS.
-
-    python tools/gen_flash_dp_asm.py > u2tokenizer_amd/csrc/flash_dp_asm.inc      (add --timed for the _TIMED text only)
+    python tools/gen_flash_dp_asm.py > u2tokenizer_amd/csrc/flash_dp_asm.inc
 """
 import sys
 
 TIMED = "--timed" in sys.argv   # diagnostics build: s_memtime deltas of the loop sections -> 5 x uint64 at %[dbg]
-HALF = "--half" in sys.argv     # the split-KV pass text (FLASH_DP2_ASM_TEXT)
 PF = 3          # fragment reads in flight
 NSLOT = 4       # LDS ring slots (16 KB each: K tile 8 KB | V^T tile 8 KB)
 AHEAD = 3       # tiles in flight
@@ -97,9 +87,6 @@ def stamp(i):
     e(f"s_mov_b64 s[{S_PREV}:{S_PREV + 1}], s[{S_NOW}:{S_NOW + 1}]")
 
 
-VSHIFT = 6 if HALF else 7  # log2(bytes between consecutive tiles in a V^T row): 32 keys (split-KV pass) / 64 keys
-
-
 def issue(label):
     """DMA of tile S_ISSUE (if < ntile) into its ring slot: 2 K pieces + 2 V^T pieces of 1 KB per wave."""
     e(f"s_cmp_ge_u32 {s(S_ISSUE)}, %[ntile]")
@@ -108,7 +95,7 @@ def issue(label):
     e(f"s_lshl_b32 {s(S_A)}, {s(S_A)}, 14")
     e(f"s_add_u32 {s(S_DST)}, {s(S_A)}, %[dma_base]")
     e(f"s_mul_i32 {s(S_KOFF)}, {s(S_ISSUE)}, %[ktile]")
-    e(f"s_lshl_b32 {s(S_VOFF)}, {s(S_ISSUE)}, {VSHIFT}")
+    e(f"s_lshl_b32 {s(S_VOFF)}, {s(S_ISSUE)}, 7")
     for (off, vo, rs, so) in [(0, "%[ko0]", "%[rsk]", S_KOFF), (1024, "%[ko1]", "%[rsk]", S_KOFF),
                               (8192, "%[vo0]", "%[rsv]", S_VOFF), (9216, "%[vo1]", "%[rsv]", S_VOFF)]:
         if off:
@@ -341,128 +328,15 @@ def gen():
         e("s_waitcnt vmcnt(0)")
 
 
-def init_state():
-    for k in (1, 2, 3):
-        e(f"v_xor_b32 {v(AB[k])}, {32 * k}, %[ab0]")  # kt_off: ab[k] = ab[0] ^ (k << 5)
-    e(f"v_mov_b32 {v(NEG)}, 0xff800000")
-    for key in O:
-        for r in range(16):
-            e(f"v_mov_b32 {v(O[key] + r)}, 0")
-    for b in range(2):
-        e(f"v_mov_b32 {m_run(b)}, 0xff800000")
-        e(f"v_mov_b32 {l_run(b)}, 0")
-    e(f"s_mov_b32 {s(S_T)}, 0")
-    e(f"s_mov_b32 {s(S_ISSUE)}, 0")
-
-
-def wait_first_tile():
-    e("s_cmp_ge_u32 %[ntile], 3")
-    e("s_cbranch_scc1 .Lfdp_w3_%=")
-    e("s_cmp_eq_u32 %[ntile], 2")
-    e("s_cbranch_scc1 .Lfdp_w2_%=")
-    e("s_waitcnt vmcnt(0)")
-    e("s_branch .Lfdp_w_%=")
-    e(".Lfdp_w2_%=:")
-    e("s_waitcnt vmcnt(4)")
-    e("s_branch .Lfdp_w_%=")
-    e(".Lfdp_w3_%=:")
-    e("s_waitcnt vmcnt(8)")
-    e(".Lfdp_w_%=:")
-    e("s_barrier")
-
-
-def dump_state():
-    """leave O^T in LDS: all waves are done with the ring first"""
-    e("s_waitcnt lgkmcnt(0)")
-    e("s_barrier")
-    q = 0
-    for key in [(0, 0), (0, 1), (1, 0), (1, 1)]:
-        for j in range(4):
-            e(f"ds_write_b128 %[dump], {vr(O[key] + 4 * j, 4)} offset:{q * 1024}")
-            q += 1
-    e("s_waitcnt vmcnt(0) lgkmcnt(0)")
-
-
-def half_body(side):
-    """split-KV pass, one side: per tile ONE phase pair on the side's 32-key half (K rows 32*side.., V^T chunks 4*side..).
-    Tile t+1's K half feeds S(t+1), tile t's V^T half feeds O += V P(t)."""
-    L = f"h{side}"
-    koff = 4096 * side
-    e(f"s_add_u32 {s(S_AK)}, %[lds], {koff}")  # (+ 0 for side 0: both sides are the same instruction sequence)
-    e(f"s_mov_b32 {s(S_NV)}, 64")          # S/2 is a multiple of 32 (launcher): never a partial half
-    phase(0, True, False, False, side)
-    max_rescale(0, L + "p0")
-    phase(1, True, False, True, side)
-    max_rescale(1, L + "p1")
-    e(f".Lfdp_{L}loop_%=:")
-    e(f"s_add_u32 {s(S_A)}, {s(S_T)}, 1")
-    e(f"s_cmp_eq_u32 {s(S_A)}, %[ntile]")
-    e(f"s_cbranch_scc1 .Lfdp_{L}epi_%=")
-    # tile t+1 must have landed; behind the barrier tile t-1 is dead and its slot takes tile t+AHEAD
-    e(f"s_add_u32 {s(S_A)}, {s(S_T)}, 2")
-    e(f"s_cmp_lt_u32 {s(S_A)}, %[ntile]")
-    e(f"s_cbranch_scc1 .Lfdp_{L}lw4_%=")
-    e("s_waitcnt vmcnt(0)")
-    e(f"s_branch .Lfdp_{L}lw_%=")
-    e(f".Lfdp_{L}lw4_%=:")
-    e("s_waitcnt vmcnt(4)")
-    e(f".Lfdp_{L}lw_%=:")
-    e("s_barrier")
-    issue(L + "loop")
-    e(f"s_add_u32 {s(S_A)}, {s(S_T)}, 1")
-    e(f"s_and_b32 {s(S_A)}, {s(S_A)}, {NSLOT - 1}")
-    e(f"s_lshl_b32 {s(S_A)}, {s(S_A)}, 14")
-    e(f"s_add_u32 {s(S_AK)}, {s(S_A)}, %[lds]")          # K half of tile t+1
-    e(f"s_add_u32 {s(S_AK)}, {s(S_AK)}, {koff}")
-    e(f"s_and_b32 {s(S_A)}, {s(S_T)}, {NSLOT - 1}")
-    e(f"s_lshl_b32 {s(S_A)}, {s(S_A)}, 14")
-    e(f"s_add_u32 {s(S_AV)}, {s(S_A)}, %[lds]")
-    e(f"s_add_u32 {s(S_AV)}, {s(S_AV)}, 8192")           # V^T tile t
-    phase(0, True, True, True, side)
-    max_rescale(0, L + "a0")
-    phase(1, True, True, True, side)
-    max_rescale(1, L + "a1")
-    e(f"s_add_u32 {s(S_T)}, {s(S_T)}, 1")
-    e(f"s_branch .Lfdp_{L}loop_%=")
-    e(f".Lfdp_{L}epi_%=:")
-    e(f"s_and_b32 {s(S_A)}, {s(S_T)}, {NSLOT - 1}")
-    e(f"s_lshl_b32 {s(S_A)}, {s(S_A)}, 14")
-    e(f"s_add_u32 {s(S_AV)}, {s(S_A)}, %[lds]")
-    e(f"s_add_u32 {s(S_AV)}, {s(S_AV)}, 8192")
-    phase(0, False, True, True, side)
-    phase(1, False, True, False, side)
-
-
-def gen_half():
-    e("// GENERATED by tools/gen_flash_dp_asm.py --half -- do not edit")
-    init_state()
-    for i in range(AHEAD):
-        issue(f"pro{i}")
-    wait_first_tile()
-    e("s_cmp_eq_u32 %[side], 0")
-    e("s_cbranch_scc0 .Lfdp_side1_%=")
-    half_body(0)
-    e("s_branch .Lfdp_sides_done_%=")
-    e(".Lfdp_side1_%=:")
-    half_body(1)
-    e(".Lfdp_sides_done_%=:")
-    dump_state()
-
-
-if HALF:
-    gen_half()
-    NAME = "FLASH_DP2_ASM"
-else:
-    gen()
-    NAME = "FLASH_DP_ASM"
+gen()
 print("// clang-format off")
-print(f"#define {NAME}_TEXT" + ("_TIMED" if TIMED else "") + " \\")
+print("#define FLASH_DP_ASM_TEXT" + ("_TIMED" if TIMED else "") + " \\")
 body = [l for l in out if not l.startswith("//")]
 for i, line in enumerate(body):
     print(f'  "{line}\\n"' + (" \\" if i + 1 < len(body) else ""))
 print("// clang-format on")
 clob = [f'"v{i}"' for i in range(VLO, VHI + 1)] + [f'"s{i}"' for i in range(SLO, SHI + 1)] + ['"vcc"', '"scc"', '"memory"']
-print(f"#define {NAME}_CLOBBERS" + ("_TIMED" if TIMED else "") + " \\")
+print("#define FLASH_DP_ASM_CLOBBERS" + ("_TIMED" if TIMED else "") + " \\")
 for i in range(0, len(clob), 12):
     tail = ", \\" if i + 12 < len(clob) else ""
     print("  " + ", ".join(clob[i:i + 12]) + tail)

@@ -420,7 +420,7 @@ def sec_flashperf():
     for (nb, S, H, extra) in [(8, 2049, 12, True), (8, 2049, 12, False), (8, 2048, 12, False), (16, 513, 12, True)]:
         qkv = rnd(nb, S, 3 * H * 64, seed=3).to(dev)
         fl = 4 * nb * H * S * S * 64
-        for mode in (5, 6):
+        for mode in (5,):
             ops.set_option("flash_mode", mode)
             ms = timeit(lambda: ops.flash_attention_d64(qkv, H, 0.125, extra_last=extra), iters=10)
             # the transpose alone
@@ -450,7 +450,7 @@ def sec_flashtime():
     nb, S, H = 8, 2049, 12
     qkv = rnd(nb, S, 3 * H * 64, seed=3).to(dev)
     names = ["gload", "QK^T", "softmax", "PV", "wait+lstore", "-", "barrier"]
-    for mode in (5, 6):
+    for mode in (5,):
         ops.set_option("flash_mode", mode)
         ms0 = timeit(lambda: ops.flash_attention_d64(qkv, H, 0.125, extra_last=True), iters=5)
         buf = torch.zeros(4096 * 4 * 8, dtype=torch.int64, device=dev)
@@ -461,7 +461,7 @@ def sec_flashtime():
         r = buf.view(-1, 8).double()
         r = r[r[:, 7] > 0]
         per = r[:, :7].sum(0) / r[:, 7].sum()
-        if mode % 10 in (5, 6):
+        if mode % 10 == 5:
             print(f"  mode {mode}: {ms0 * 1e3:7.1f} us untimed | per 64-key tile per wave (2 blocks): phases u=2t {per[0]:6.0f}  dma wait {per[1]:6.0f}  "
                   f"barrier {per[2]:6.0f}  dma issue {per[3]:6.0f}  phases u=2t+1 {per[4]:6.0f}  total {per[:5].sum():6.0f}", flush=True)
             continue

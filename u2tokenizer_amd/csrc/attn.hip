@@ -650,10 +650,23 @@ __device__ __forceinline__ void fdp_finish(const FlashArgs& a, FdpBlock& x, cons
 #include "flash_dp_asm.inc"
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 
-// One full pass of the double pipeline: the 256-row unit [row0, row0 + 256) of head (b, h) against all keys.
 template <bool TIMED>
-__device__ __forceinline__ void fdp_full_pass(const FlashArgs& a, char* lds, const int b, const int h, const int row0,
-                                              const int tid) {
+__global__ __launch_bounds__(256, 2) void flash_dp_kernel(const FlashArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[FDP_SLOTS][16384];  // [slot][K tile 8 KB | V^T tile 8 KB]
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= a.n_main) {
+    const int e = blockIdx.x - a.n_main;
+    flash_extra_row(a, &lds[0][0], e / a.H, e % a.H, tid);
+    return;
+  }
+  int bid;
+  {
+    const int nwg = a.n_main, qn = nwg >> 3, rn = nwg & 7;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+  }
+  const int nqt = (a.S + 255) >> 8;
+  const int hh = bid / nqt, b = hh / a.H, h = hh % a.H, row0 = (bid % nqt) * 256;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
@@ -672,9 +685,7 @@ __device__ __forceinline__ void fdp_full_pass(const FlashArgs& a, char* lds, con
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
   }
-  // DMA pieces of this wave: rows [16 wv, 16 wv + 16) of the K tile and of the V^T tile, 8 rows x 128 B per piece; LDS
-  // position p of row r holds global chunk p ^ ((r >> 1) & 7) (kt_off).  MUBUF descriptors built by hand -- K rows past S
-  // read as zero
+  // DMA pieces of this wave (as in flash_dp_kernel): MUBUF descriptors built by hand -- K rows past S read as zero
   const int prow = wv * 16 + (lane >> 3);
   const int pch0 = (lane & 7) ^ ((prow >> 1) & 7), pch1 = pch0 ^ 4;
   const int ko0 = (prow * (int)ld_qk + pch0 * 8) * 2, ko1 = ((prow + 8) * (int)ld_qk + pch1 * 8) * 2;
@@ -690,7 +701,7 @@ __device__ __forceinline__ void fdp_full_pass(const FlashArgs& a, char* lds, con
   rsv[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(vaddr >> 32));
   rsv[2] = 64 * S_pad * 2;
   rsv[3] = 0x00020000;
-  const uint32_t lds_u32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  const uint32_t lds_u32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&lds[0][0];
   const uint32_t dma_base = lds_u32 + wv * 2048;
   const uint32_t ab0 = kt_off(l31, hi);
   const uint32_t dump = lds_u32 + wv * 16384 + lane * 16;
@@ -714,7 +725,7 @@ __device__ __forceinline__ void fdp_full_pass(const FlashArgs& a, char* lds, con
 #undef FDP_OPERANDS
   // the block left O^T in LDS: tuple T = 2 * block + nb, 16-byte quarter j at [wave][T * 4 + j][lane]
   FdpBlock x0, x1;
-  const char* dp = lds + wv * 16384 + lane * 16;
+  const char* dp = &lds[0][0] + wv * 16384 + lane * 16;
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -727,142 +738,6 @@ __device__ __forceinline__ void fdp_full_pass(const FlashArgs& a, char* lds, con
   x0.m_run = mr0; x0.l_run = lr0; x1.m_run = mr1; x1.l_run = lr1;
   fdp_finish(a, x0, qf[0], b, h, wrow0 + l31, hi);
   fdp_finish(a, x1, qf[1], b, h, wrow0 + 32 + l31, hi);
-}
-
-// The split-KV pass of mode 6: the 128 rows [row0, row0 + 128) of head (b, h); waves 0,1 (side 0) take keys [0, S/2),
-// waves 2,3 (side 1) keys [S/2, S) of the two 64-row blocks, one 32-key half tile per side and ring slot (the DMA
-// offsets below gather them: K rows 0-31 | 32-63 and V^T chunks 0-3 | 4-7 of a slot); the sides are merged through LDS
-// (O^T dumps of the asm block + `ml`, 2 KB behind the ring, for the running max / sum of side 1).  S % 256 == 0.
-__device__ __forceinline__ void fdp_half_pass(const FlashArgs& a, char* lds, float* ml, const int b, const int h,
-                                              const int row0, const int tid) {
-  const int lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int side = wv >> 1, blk = wv & 1;
-  const int hi = lane >> 5, l31 = lane & 31;
-  const int S = a.S, S_pad = a.S_pad, Sh = S >> 1;
-  const int64_t ld_qk = a.ld_qk;
-  const bf16_t* qb_ = a.q + (int64_t)b * a.q_bs + h * 64;
-  const bf16_t* kb_ = a.k + (int64_t)b * a.q_bs + h * 64;
-  const bf16_t* vb_ = a.vt + ((int64_t)b * a.H + h) * 64 * S_pad;
-  const int wrow0 = row0 + blk * 64;
-  const int ntile = Sh >> 5;  // 32-key steps per side
-
-  bf16x8 qf[2][4];
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const bf16_t* qp = qb_ + (int64_t)(wrow0 + qb * 32 + l31) * ld_qk + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
-  }
-  const int prow = wv * 16 + (lane >> 3);  // LDS row of this lane's pieces: K rows 0-31 = side 0 keys, 32-63 = side 1
-  const int pch0 = (lane & 7) ^ ((prow >> 1) & 7), pch1 = pch0 ^ 4;
-  const int krow = prow + (side ? Sh - 32 : 0);
-  const int ko0 = (krow * (int)ld_qk + pch0 * 8) * 2, ko1 = ((krow + 8) * (int)ld_qk + pch1 * 8) * 2;
-  // V^T chunk c of a slot: c < 4 -> keys 32 t + 8 c.. of side 0, c >= 4 -> keys S/2 + 32 t + 8 (c - 4).. of side 1
-  const int kv0 = pch0 < 4 ? 8 * pch0 : Sh - 32 + 8 * pch0, kv1 = pch1 < 4 ? 8 * pch1 : Sh - 32 + 8 * pch1;
-  const int vo0 = (prow * S_pad + kv0) * 2, vo1 = ((prow + 8) * S_pad + kv1) * 2;
-  const int k_tile_bytes = 32 * (int)ld_qk * 2;
-  const uint64_t kaddr = (uint64_t)(uintptr_t)kb_, vaddr = (uint64_t)(uintptr_t)vb_;
-  i32x4_t rsk, rsv;
-  rsk[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)kaddr);
-  rsk[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(kaddr >> 32));
-  rsk[2] = (int)((((int64_t)S - 1) * ld_qk + 64) * 2);
-  rsk[3] = 0x00020000;
-  rsv[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)vaddr);
-  rsv[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(vaddr >> 32));
-  rsv[2] = 64 * S_pad * 2;
-  rsv[3] = 0x00020000;
-  const uint32_t lds_u32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
-  const uint32_t dma_base = lds_u32 + wv * 2048;
-  const uint32_t ab0 = kt_off(l31, hi);
-  const uint32_t dump = lds_u32 + wv * 16384 + lane * 16;
-  const int hi4 = 4 * hi;  // (only the never-taken key-mask branch of the shared phase code reads it)
-  const float scale_log2e = a.scale_log2e;
-  float mr0, lr0, mr1, lr1;
-  asm volatile(FLASH_DP2_ASM_TEXT
-               : [mr0] "=&v"(mr0), [lr0] "=&v"(lr0), [mr1] "=&v"(mr1), [lr1] "=&v"(lr1)
-               : [qf00] "v"(qf[0][0]), [qf01] "v"(qf[0][1]), [qf02] "v"(qf[0][2]), [qf03] "v"(qf[0][3]),
-                 [qf10] "v"(qf[1][0]), [qf11] "v"(qf[1][1]), [qf12] "v"(qf[1][2]), [qf13] "v"(qf[1][3]),
-                 [ab0] "v"(ab0), [ko0] "v"(ko0), [ko1] "v"(ko1), [vo0] "v"(vo0), [vo1] "v"(vo1), [hi4] "v"(hi4),
-                 [dump] "v"(dump), [rsk] "s"(rsk), [rsv] "s"(rsv), [lds] "s"(lds_u32), [dma_base] "s"(dma_base),
-                 [ktile] "s"(k_tile_bytes), [ntile] "s"(ntile), [scale] "s"(scale_log2e), [side] "s"(side)
-               : FLASH_DP2_ASM_CLOBBERS);
-  // side 1 publishes its running max / sum; its O^T dump is already in LDS (the asm block ends behind a barrier + dump)
-  if (side) {
-    float* p = ml + blk * 256 + lane;
-    p[0] = mr0; p[64] = lr0; p[128] = mr1; p[192] = lr1;
-  }
-  __syncthreads();
-  if (side) return;
-  const float* pm = ml + blk * 256 + lane;
-  const char* dpa = lds + wv * 16384 + lane * 16;
-  const char* dpb = lds + (wv + 2) * 16384 + lane * 16;
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const float ma = qb ? mr1 : mr0, la = qb ? lr1 : lr0;
-    const float mb = pm[128 * qb], lb = pm[128 * qb + 64];
-    const float m = fmaxf(ma, mb);
-    const float fa = __builtin_amdgcn_exp2f(ma - m), fb = __builtin_amdgcn_exp2f(mb - m);
-    FdpBlock x;
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 ua = *reinterpret_cast<const float4*>(dpa + ((2 * qb + nb) * 4 + j) * 1024);
-        const float4 ub = *reinterpret_cast<const float4*>(dpb + ((2 * qb + nb) * 4 + j) * 1024);
-        x.oacc[nb][4 * j] = fa * ua.x + fb * ub.x; x.oacc[nb][4 * j + 1] = fa * ua.y + fb * ub.y;
-        x.oacc[nb][4 * j + 2] = fa * ua.z + fb * ub.z; x.oacc[nb][4 * j + 3] = fa * ua.w + fb * ub.w;
-      }
-    x.m_run = m;
-    x.l_run = fa * la + fb * lb;
-    fdp_finish(a, x, qf[qb], b, h, wrow0 + 32 * qb + l31, hi);
-  }
-}
-
-// XCD-aware order: workgroup w runs on XCD w % 8 (observed dispatch rule); give every XCD a contiguous range of logical
-// ids so that the units of one (batch, head) share that XCD's L2 copy of K and V^T.
-__device__ __forceinline__ int fdp_logical_id(const int n_main) {
-  const int qn = n_main >> 3, rn = n_main & 7;
-  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  return (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
-}
-
-template <bool TIMED>
-__global__ __launch_bounds__(256, 2) void flash_dp_kernel(const FlashArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[FDP_SLOTS * 16384];  // [slot][K tile 8 KB | V^T tile 8 KB]
-  const int tid = threadIdx.x;
-  if ((int)blockIdx.x >= a.n_main) {
-    const int e = blockIdx.x - a.n_main;
-    flash_extra_row(a, lds, e / a.H, e % a.H, tid);
-    return;
-  }
-  const int bid = fdp_logical_id(a.n_main);
-  const int nqt = (a.S + 255) >> 8;
-  const int hh = bid / nqt;
-  fdp_full_pass<TIMED>(a, lds, hh / a.H, hh % a.H, (bid % nqt) * 256, tid);
-}
-
-// Mode 6.  768 equal units on 512 workgroup slots (the ViT: 96 heads x 2048 rows, 2 workgroups per CU) run as two
-// rounds for 1.5 rounds of work.  Here every workgroup runs 1.5 units: one full 256-row pass, then a 128-row pass whose
-// KEY range is split between its wave pairs -- heads come in groups of three, the 2 S/256 workgroups of a group cover
-// heads 3g and 3g + 1 with their full passes and head 3g + 2 with their split passes: (nb H / 3) (2 S / 256) workgroups,
-// exactly one round at the ViT's shape.  Needs S % 256 == 0 and nb H % 3 == 0 (the launcher falls back to mode 5).
-__global__ __launch_bounds__(256, 2) void flash_dp2_kernel(const FlashArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[FDP_SLOTS * 16384 + 2048];
-  const int tid = threadIdx.x;
-  if ((int)blockIdx.x >= a.n_main) {
-    const int e = blockIdx.x - a.n_main;
-    flash_extra_row(a, lds, e / a.H, e % a.H, tid);
-    return;
-  }
-  const int bid = fdp_logical_id(a.n_main);
-  const int upa = a.S >> 8;  // 256-row units per head
-  const int g = bid / (2 * upa), i = bid - g * (2 * upa);
-  const int h1 = 3 * g + i / upa;
-  fdp_full_pass<false>(a, lds, h1 / a.H, h1 % a.H, (i % upa) * 256, tid);
-  __syncthreads();  // every wave has read its O^T dump back: the ring may be refilled
-  const int h2 = 3 * g + 2;
-  fdp_half_pass(a, lds, reinterpret_cast<float*>(lds + FDP_SLOTS * 16384), h2 / a.H, h2 % a.H, i * 128, tid);
 }
 
 static bool g_flash_timed = false;
@@ -891,19 +766,15 @@ int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16
   a.scale_log2e = scale * 1.44269504088896340736f;
   const int64_t nbh = (int64_t)nb * H;
   int mode = opts().flash_mode;
-  const bool split_ok = (S % 256 == 0) && (nbh % 3 == 0) && S >= 512;
-  if (mode == 6 && !split_ok) mode = 5;
-  if (mode != 1 && mode != 5 && mode != 6) mode = S >= 512 ? 5 : 1;  // measured: the double pipeline wins from S = 513 up
-  const int64_t blocks = mode == 6 ? (nbh / 3) * 2 * (S / 256) : mode == 5 ? nbh * ((S + 255) / 256) : nbh * ((S + 127) / 128);
+  if (mode != 1 && mode != 5) mode = S >= 512 ? 5 : 1;  // measured: the double pipeline wins from S = 513 up
+  const int64_t blocks = mode == 5 ? nbh * ((S + 255) / 256) : nbh * ((S + 127) / 128);
   a.mode = mode;
   a.n_main = (int)blocks;
   const int64_t grid = blocks + (n_extra ? nbh : 0);
   if (grid > 0x7fffffff) return U2_ERR_ARG;
   ProfScope ps(PROF_FLASH, 4.0 * nbh * (double)(S + n_extra) * (S + n_extra) * 64, stream,
                4.0 * nbh * (double)(S + n_extra) * 64 * 2.0);  // q, k, v^T read + o written, once
-  if (mode == 6) {
-    hipLaunchKernelGGL(flash_dp2_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
-  } else if (mode == 5) {
+  if (mode == 5) {
     if (g_flash_timed) hipLaunchKernelGGL((flash_dp_kernel<true>), dim3((unsigned)grid), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((flash_dp_kernel<false>), dim3((unsigned)grid), dim3(256), 0, stream, a);
   } else {

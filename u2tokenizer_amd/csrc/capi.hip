@@ -52,7 +52,7 @@ int u2tok_set_option(const char* name, int value) {
   static const Opt table[] = {
       {"gemm_splitk", &Options::gemm_splitk, -1, 16},   {"gemm_big", &Options::gemm_big, -1, 21},
       {"gemm_big_grid", &Options::gemm_big_grid, 1, 4096}, {"gemm_big_gelu", &Options::gemm_big_gelu, 0, 1},
-      {"gemm_skinny", &Options::gemm_skinny, -1, 1},    {"flash_mode", &Options::flash_mode, 0, 6},
+      {"gemm_skinny", &Options::gemm_skinny, -1, 1},    {"flash_mode", &Options::flash_mode, 0, 5},
       {"vit_flash", &Options::vit_flash, 0, 1},         {"tta_overlap", &Options::tta_overlap, 0, 1},
   };
   if (!strcmp(name, "gemm_tile")) {
@@ -65,7 +65,7 @@ int u2tok_set_option(const char* name, int value) {
     if (!strcmp(name, t.name)) {
       if (value < t.lo || value > t.hi) return U2_ERR_ARG;
       if (t.field == &Options::gemm_big && value > 0 && value != 20 && value != 21) return U2_ERR_ARG;
-      if (t.field == &Options::flash_mode && value != 0 && value != 1 && value != 5 && value != 6) return U2_ERR_ARG;
+      if (t.field == &Options::flash_mode && value != 0 && value != 1 && value != 5) return U2_ERR_ARG;
       o.*(t.field) = value;
       return U2_OK;
     }
