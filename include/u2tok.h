@@ -228,9 +228,36 @@ int u2tok_flash_attention_d64(const void* q, const void* k, const void* vt, void
                               int32_t H, int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs, int32_t S_pad,
                               float scale, const void* qx, const void* kx, const void* vx, void* outx, int64_t x_bs,
                               int64_t ox_bs, int32_t n_extra, u2tok_stream_t stream);
-/* in-place rotate-half RoPE (rope.py:6-13,77-80): rows indexed (outer, s, inner), position = s */
+/* in-place rotate-half RoPE (rope.py:6-13,77-80): rows indexed (outer, s, inner), position = s; inverse != 0 rotates
+ * the other way (the backward of the rotation) */
 int u2tok_rope_apply(void* x, int64_t n_outer, int32_t S, int32_t n_inner, int32_t H, int32_t d, int64_t ld,
-                     int32_t max_len, u2tok_stream_t stream);
+                     int32_t max_len, int32_t inverse, u2tok_stream_t stream);
+
+/* ---- backward-pass building blocks ("next" row f1: training through the path) ---------------------------------------
+ * The GEMM-shaped parts of the backward (dX = dY W, dW = dY^T X, dQ / dK / dV / dP of the attention cores) are
+ * u2tok_gemm_bf16 calls on (transposed) operands; these are the rest.  The host side (u2tokenizer_amd/autograd.py)
+ * sequences them behind torch.autograd.Function so that the drop-in modules train (train_stage1.py:244-251). */
+int u2tok_gelu_fwd(const void* z, void* y, int64_t n, u2tok_stream_t stream);                  /* y = gelu(z) (erf) */
+int u2tok_gelu_bwd(const void* z, const void* dy, void* dz, int64_t n, u2tok_stream_t stream); /* dz = dy gelu'(z) */
+/* out[c] (+)= sum_r x[r][c] (* y[r][c] when y != NULL) in fp32, fixed summation order (bit-repeatable); out (fp32)
+ * and / or out_bf16 receive the result; workspace: u2tok_colsum_workspace_bytes. */
+size_t u2tok_colsum_workspace_bytes(int32_t rows, int32_t C);
+int u2tok_colsum_bf16(const void* x, const void* y, float* out, void* out_bf16, int32_t rows, int32_t C, int64_t ldx,
+                      int64_t ldy, void* workspace, int32_t accumulate, u2tok_stream_t stream);
+/* Backward of y = LayerNorm(x (+ res)) * w + b (rows x C, dense): dv = gradient w.r.t. x (== w.r.t. res), dw / db:
+ * fp32 [C] (overwritten, or added to when accumulate != 0). */
+size_t u2tok_layernorm_bwd_workspace_bytes(int32_t rows, int32_t C);
+int u2tok_layernorm_bwd(const void* x, const void* res, const void* w, const void* dy, void* dv, float* dw, float* db,
+                        int32_t rows, int32_t C, float eps, void* workspace, int32_t accumulate, u2tok_stream_t stream);
+/* dS = P * (dP - rowsum(P * dP)) per row; P, dS bf16 [nrows][ldp] (columns >= n of dS zeroed), dP fp32 [nrows][lddp] */
+int u2tok_softmax_bwd(const void* P, const float* dP, void* dS, int64_t nrows, int32_t n, int64_t ldp, int64_t lddp,
+                      u2tok_stream_t stream);
+/* gradient of the relative-bias table (rma.py:64-70): dtable[d + max_len - 1][h] += sum over z % H == h and the
+ * diagonal j - i = d of dS[z][i][j];  dS: bf16 [nz][S][ldp];  dtable: fp32 [2 max_len - 1][H] */
+int u2tok_relbias_grad(const void* dS, float* dtable, int32_t nz, int32_t S, int32_t H, int64_t ldp, int32_t max_len,
+                       u2tok_stream_t stream);
+int u2tok_rowdot_bf16(const void* a, const void* b, float* out, int64_t rows, int32_t C, int64_t lda, int64_t ldb,
+                      u2tok_stream_t stream);
 
 #ifdef __cplusplus
 }

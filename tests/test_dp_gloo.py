@@ -1,0 +1,97 @@
+"""CPU, world_size 2 over gloo: the training-time exchange of the replicas (u2tokenizer_amd/dp.py, ZeRO-1 semantics of
+config/ds_config.json:27-39).  Two ranks with DIFFERENT micro-batches must end every step with identical parameters,
+equal to a single process running torch.optim.AdamW on the MEAN gradient; buckets smaller than the model force several
+reduce-scatter / all-gather rounds (a bucket is cut into world_size pieces regardless of parameter boundaries)."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(24, 40), torch.nn.GELU(), torch.nn.Linear(40, 40), torch.nn.LayerNorm(40),
+                               torch.nn.Linear(40, 7))
+
+
+def _data(rank, step):
+    g = torch.Generator().manual_seed(100 * step + rank)
+    return torch.randn(5, 24, generator=g), torch.randn(5, 7, generator=g)
+
+
+def _worker(rank, world, port, q, overlap, bucket):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from u2tokenizer_amd.dp import Zero1AdamW
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _model()
+    opt = Zero1AdamW(m.parameters(), lr=1e-2, weight_decay=0.1, reduce_bucket_size=bucket, allgather_bucket_size=bucket,
+                     overlap_comm=overlap)
+    for step in range(3):
+        x, y = _data(rank, step)
+        torch.nn.functional.mse_loss(m(x), y).backward()
+        opt.step()
+        opt.zero_grad()
+    q.put((rank, [p.detach().clone() for p in m.parameters()], len(opt.buckets), opt.state_bytes_per_rank()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _reference(world):
+    m = _model()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-2, weight_decay=0.1)
+    for step in range(3):
+        opt.zero_grad()
+        for rank in range(world):
+            x, y = _data(rank, step)
+            (torch.nn.functional.mse_loss(m(x), y) / world).backward()
+        opt.step()
+    return [p.detach().clone() for p in m.parameters()]
+
+
+def _run(overlap, bucket):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, overlap, bucket)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_zero1_matches_single_process_adamw():
+    ref = _reference(2)
+    nparam = sum(p.numel() for p in ref)
+    for overlap, bucket in ((False, 10 ** 9), (True, 700), (True, 10 ** 9)):
+        (r0, p0, nb0, sb0), (r1, p1, nb1, sb1) = _run(overlap, bucket)
+        for a, b, c in zip(p0, p1, ref):
+            assert torch.equal(a, b)                                  # replicas stay bit-identical
+            assert torch.allclose(a, c, rtol=2e-5, atol=2e-6), (a - c).abs().max()
+        assert nb0 == nb1 and (nb0 > 1) == (bucket == 700)
+        # the optimiser state is sharded: ~half of 12 bytes per parameter on each of the two ranks
+        assert abs(sb0 - 6 * nparam) <= 12 * 2 * nb0 and sb0 == sb1
+
+
+def test_single_process_zero1_is_plain_adamw():
+    from u2tokenizer_amd.dp import Zero1AdamW
+    m1, m2 = _model(), _model()
+    o1, o2 = Zero1AdamW(m1.parameters(), lr=1e-2, weight_decay=0.1), torch.optim.AdamW(m2.parameters(), lr=1e-2, weight_decay=0.1)
+    for step in range(3):
+        x, y = _data(0, step)
+        for m, o in ((m1, o1), (m2, o2)):
+            o.zero_grad()
+            torch.nn.functional.mse_loss(m(x), y).backward()
+            o.step()
+    for a, b in zip(m1.parameters(), m2.parameters()):
+        assert torch.allclose(a, b, rtol=2e-5, atol=2e-6)

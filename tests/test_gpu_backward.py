@@ -1,0 +1,374 @@
+"""GPU: the training path (u2tokenizer_amd/autograd.py -- HIP forward AND backward behind torch.autograd.Function) against
+torch.autograd over the CPU oracle.
+
+Every op-level test differentiates a plain fp32 torch expression of the same bf16 inputs; the module-level tests
+differentiate oracle/u2_oracle.py (the restatement of the reference's modules) with name-seeded parameters and compare
+the gradient of EVERY parameter.  Tolerance: a gradient may be no further from the fp32 reference gradient than 1.5x the
+distance of the reference's own bf16 run (same oracle, bf16 tensors, CPU autograd) plus 2 % of that tensor's gradient
+scale; gradients that are tiny relative to the largest one of the module are compared against that largest scale.
+"""
+import math
+from types import SimpleNamespace as NS
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import module_sd
+from oracle import u2_oracle as O
+from u2tokenizer_amd import synth
+
+pytestmark = pytest.mark.gpu
+bf = torch.bfloat16
+D = "cuda"
+
+
+@pytest.fixture(autouse=True)
+def _grad_on():
+    assert torch.cuda.is_available()
+    prev = torch.is_grad_enabled()
+    torch.set_grad_enabled(True)
+    yield
+    torch.set_grad_enabled(prev)
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed * 7919 + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(bf)
+
+
+def rel(a, b, floor=0.0):
+    a, b = a.detach().double().cpu().flatten(), b.detach().double().cpu().flatten()
+    return ((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + floor)).item()
+
+
+def leaf(t, dev=None):
+    t = t.detach().clone()
+    if dev:
+        t = t.to(dev)
+    return t.requires_grad_(True)
+
+
+def check_grads(got: dict, ref32: dict, ref16: dict = None, what=""):
+    """got / ref32 / ref16: name -> gradient tensor."""
+    top = max(v.double().pow(2).mean().sqrt().item() for v in ref32.values())
+    worst = {}
+    for k, g32 in ref32.items():
+        assert k in got and got[k] is not None, f"{what}: no gradient for {k}"
+        assert torch.isfinite(got[k].float()).all(), (what, k)
+        floor = 2e-3 * top
+        e = rel(got[k].float(), g32, floor)
+        bar = 2e-2 + (1.5 * rel(ref16[k].float(), g32, floor) if ref16 is not None else 1e-2)
+        worst[k] = (e, bar)
+    bad = {k: v for k, v in worst.items() if v[0] > v[1]}
+    assert not bad, (what, bad)
+    # all gradients as one vector: the direction of the step must agree with the fp32 reference as well as the
+    # reference's own bf16 run does (parameters whose exact gradient is zero -- e.g. key biases -- are pure rounding noise
+    # in any bf16 run and only matter here through their tiny norm)
+    keys = sorted(ref32)
+
+    def cos(a, b):
+        va = torch.cat([a[k].detach().double().cpu().flatten() for k in keys])
+        vb = torch.cat([b[k].detach().double().cpu().flatten() for k in keys])
+        return (va @ vb / (va.norm() * vb.norm()).clamp_min(1e-30)).item()
+
+    c_hip = cos(got, ref32)
+    c_ref = cos(ref16, ref32) if ref16 is not None else 0.999
+    assert c_hip >= c_ref - 0.02, (what, c_hip, c_ref)
+    worst["cosine_vs_fp32"] = (c_hip, c_ref)
+    return worst
+
+
+# ------------------------------------------------------------------------------------------------ op level
+@pytest.mark.parametrize("gelu,res,bias", [(False, False, True), (True, False, True), (False, True, True), (False, False, False)])
+def test_linear_fn(gelu, res, bias):
+    from u2tokenizer_amd import autograd as AG
+    M, N, K = 300, 264, 200
+    x, w, b, r, g = rnd(M, K, seed=1), rnd(N, K, scale=K ** -0.5, seed=2), rnd(N, seed=3), rnd(M, N, seed=4), rnd(M, N, seed=5)
+    xr, wr, br, rr = leaf(x.float()), leaf(w.float()), leaf(b.float()), leaf(r.float())
+    y = F.linear(xr, wr, br if bias else None)
+    y = F.gelu(y) if gelu else y
+    y = y + rr if res else y
+    (y * g.float()).sum().backward()
+    xd, wd, bd, rd = leaf(x, D), leaf(w, D), leaf(b, D), leaf(r, D)
+    yd = AG.linear(xd, wd, bd if bias else None, rd if res else None, gelu)
+    assert rel(yd.float(), y) < 1e-2
+    (yd.float() * g.to(D).float()).sum().backward()
+    got = {"x": xd.grad, "w": wd.grad}
+    ref = {"x": xr.grad, "w": wr.grad}
+    if bias:
+        got["b"], ref["b"] = bd.grad, br.grad
+    if res:
+        got["r"], ref["r"] = rd.grad, rr.grad
+    check_grads(got, ref, what=f"linear gelu={gelu} res={res}")
+
+
+@pytest.mark.parametrize("C,res", [(768, False), (768, True), (4096, True), (512, False)])
+def test_layernorm_fn(C, res):
+    from u2tokenizer_amd import autograd as AG
+    R = 150
+    x, r, w, b, g = rnd(R, C, seed=1), rnd(R, C, seed=2), (1 + 0.1 * rnd(C, seed=3).float()).to(bf), rnd(C, seed=4), rnd(R, C, seed=5)
+    xr, rr, wr, br = leaf(x.float()), leaf(r.float()), leaf(w.float()), leaf(b.float())
+    y = F.layer_norm(xr + rr if res else xr, (C,), wr, br)
+    (y * g.float()).sum().backward()
+    xd, rd, wd, bd = leaf(x, D), leaf(r, D), leaf(w, D), leaf(b, D)
+    yd = AG.layernorm(xd, wd, bd, rd if res else None)
+    (yd.float() * g.to(D).float()).sum().backward()
+    got, ref = {"x": xd.grad, "w": wd.grad, "b": bd.grad}, {"x": xr.grad, "w": wr.grad, "b": br.grad}
+    if res:
+        got["r"], ref["r"] = rd.grad, rr.grad
+    check_grads(got, ref, what=f"layernorm C={C}")
+
+
+def _attn_ref(q, k, v, H, scale, bias_tbl=None, L=512):
+    nb, Sq, E = q.shape
+    d = E // H
+
+    def heads(t):
+        return t.view(nb, -1, H, d).permute(0, 2, 1, 3)
+
+    s = heads(q) @ heads(k).transpose(-1, -2) * scale
+    if bias_tbl is not None:
+        pos = torch.arange(Sq)
+        s = s + bias_tbl[pos[None, :] - pos[:, None] + L - 1].permute(2, 0, 1).unsqueeze(0)
+    return (s.softmax(-1) @ heads(v)).permute(0, 2, 1, 3).reshape(nb, Sq, E)
+
+
+@pytest.mark.parametrize("nb,S,H,d,bias", [(3, 40, 4, 64, True), (2, 37, 8, 32, True), (2, 24, 2, 128, False)])
+def test_self_attention_fn(nb, S, H, d, bias):
+    from u2tokenizer_amd import autograd as AG
+    E, L = H * d, 512
+    qkv, tbl, g = rnd(nb, S, 3 * E, seed=1), rnd(2 * L - 1, H, scale=0.5, seed=2), rnd(nb, S, E, seed=3)
+    qr, tr = leaf(qkv.float()), leaf(tbl.float())
+    y = _attn_ref(qr[..., :E], qr[..., E:2 * E], qr[..., 2 * E:], H, d ** -0.5, tr if bias else None, L)
+    (y * g.float()).sum().backward()
+    qd, td = leaf(qkv, D), leaf(tbl, D)
+    yd = AG.SelfAttnFn.apply(qd, td if bias else None, H, d ** -0.5, L, False)
+    assert rel(yd.float(), y) < 1.5e-2
+    (yd.float() * g.to(D).float()).sum().backward()
+    got, ref = {"qkv": qd.grad}, {"qkv": qr.grad}
+    if bias:
+        got["table"], ref["table"] = td.grad, tr.grad
+    check_grads(got, ref, what="self attention")
+
+
+def test_flash_self_attention_fn_recomputes_for_backward():
+    """ViT form: flash forward (last row = the kernel's extra row), probabilities rebuilt in the backward."""
+    from u2tokenizer_amd import autograd as AG
+    nb, S, H, d = 2, 129, 3, 64
+    E = H * d
+    qkv, g = rnd(nb, S, 3 * E, seed=7), rnd(nb, S, E, seed=8)
+    qr = leaf(qkv.float())
+    y = _attn_ref(qr[..., :E], qr[..., E:2 * E], qr[..., 2 * E:], H, 0.125)
+    (y * g.float()).sum().backward()
+    qd = leaf(qkv, D)
+    yd = AG.SelfAttnFn.apply(qd, None, H, 0.125, 0, True)
+    assert rel(yd.float(), y) < 1.5e-2
+    (yd.float() * g.to(D).float()).sum().backward()
+    check_grads({"qkv": qd.grad}, {"qkv": qr.grad}, what="flash self attention")
+
+
+def test_cross_and_plain_attention_fns():
+    from u2tokenizer_amd import autograd as AG
+    nb, Sq, Skv, H, d = 2, 24, 50, 4, 64
+    E = H * d
+    q, kv, g = rnd(nb, Sq, E, seed=1), rnd(nb, Skv, 2 * E, seed=2), rnd(nb, Sq, E, seed=3)
+    qr, kvr = leaf(q.float()), leaf(kv.float())
+    y = _attn_ref(qr, kvr[..., :E], kvr[..., E:], H, d ** -0.5)
+    (y * g.float()).sum().backward()
+    qd, kvd = leaf(q, D), leaf(kv, D)
+    yd = AG.CrossAttnFn.apply(qd, kvd, H, d ** -0.5)
+    (yd.float() * g.to(D).float()).sum().backward()
+    check_grads({"q": qd.grad, "kv": kvd.grad}, {"q": qr.grad, "kv": kvr.grad}, what="cross attention")
+    k, v = kv[..., :E].contiguous(), kv[..., E:].contiguous()
+    q2, k2, v2 = leaf(q, D), leaf(k, D), leaf(v, D)
+    y2 = AG.AttnFn.apply(q2, k2, v2, H, d ** -0.5)
+    (y2.float() * g.to(D).float()).sum().backward()
+    check_grads({"q": q2.grad, "k": k2.grad, "v": v2.grad},
+                {"q": qr.grad, "k": kvr.grad[..., :E], "v": kvr.grad[..., E:]}, what="plain attention")
+
+
+def test_selection_and_pooling_fns():
+    from u2tokenizer_amd import autograd as AG
+    B, TN, E, k = 2, 96, 256, 40
+    x, w, b, g = rnd(B, TN, E, seed=1), rnd(k, E, scale=4 * E ** -0.5, seed=2), rnd(k, scale=0.1, seed=3), rnd(B, k, E, seed=4)
+    xr, wr, br = leaf(x.float()), leaf(w.float()), leaf(b.float())
+    sc = F.linear(xr, wr, br)                                   # (B, TN, k)
+    y = torch.softmax(sc / 0.7, dim=1).transpose(1, 2) @ xr     # svr.py:105-117
+    (y * g.float()).sum().backward()
+    xd, wd, bd = leaf(x, D), leaf(w, D), leaf(b, D)
+    yd = AG.DiffTSFn.apply(xd, wd, bd, 0.7)
+    assert rel(yd.float(), y) < 1.5e-2
+    (yd.float() * g.to(D).float()).sum().backward()
+    check_grads({"x": xd.grad, "w": wd.grad, "b": bd.grad}, {"x": xr.grad, "w": wr.grad, "b": br.grad}, what="DiffTS")
+    # multi-scale pooling, fixed and gated
+    for gated in (False, True):
+        xs, gw, gb = rnd(2, 30, 256, seed=5), rnd(1, 256, scale=0.3, seed=6), rnd(1, seed=7)
+        go = rnd(2, 30 + 15 + 7, 256, seed=8)
+        xr, gwr, gbr = leaf(xs.float()), leaf(gw.float()), leaf(gb.float())
+        sd = {"p.gate_fc.weight": gwr, "p.gate_fc.bias": gbr}
+        y = O.multi_scale_pool(sd, "p" if gated else None, xr)
+        (y * go.float()).sum().backward()
+        xd, gwd, gbd = leaf(xs, D), leaf(gw, D), leaf(gb, D)
+        yd = AG.MultiScalePoolFn.apply(xd, gwd if gated else None, gbd if gated else None)
+        (yd.float() * go.to(D).float()).sum().backward()
+        got, ref = {"x": xd.grad}, {"x": xr.grad}
+        if gated:
+            got.update(w=gwd.grad, b=gbd.grad)
+            ref.update(w=gwr.grad, b=gbr.grad)
+        check_grads(got, ref, what=f"multi-scale pool gated={gated}")
+    # hard top-k: the gather's gradient lands on the selected rows only
+    x, w, b = rnd(2, 64, 256, seed=9), rnd(1, 256, scale=0.1, seed=10), rnd(1, seed=11)
+    xd = leaf(x, D)
+    sel, idx = AG.HardTopKFn.apply(xd, w.to(D), b.to(D), 16)
+    go = rnd(2, 16, 256, seed=12).to(D)
+    (sel.float() * go.float()).sum().backward()
+    want = torch.zeros(2, 64, 256)
+    want[torch.arange(2)[:, None], idx.cpu()] = go.float().cpu()
+    assert torch.equal(xd.grad.float().cpu(), want)
+
+
+# ------------------------------------------------------------------------------------------------ module level
+def _oracle_grads(sd32, dt, fn):
+    """gradients of sum(out * G) w.r.t. every floating tensor of the state dict, oracle on the host in dtype dt."""
+    sd = {k: leaf(v.to(dt)) for k, v in sd32.items()}
+    out, G = fn(sd)
+    (out.float() * G).sum().backward()
+    return out.detach(), {k: v.grad for k, v in sd.items() if v.grad is not None}
+
+
+TOK_TRAIN_CASES = {
+    "mu2_2l": dict(E=512, layers=2, B=2, T=4, N=32, Lt=40, Q=32, top_k=64, ms=True, attn="rma", diffts=True, dmtp=True,
+                   lively=False, seed=81),
+    "mu2_1l_live": dict(E=512, layers=1, B=2, T=4, N=32, Lt=24, Q=16, top_k=64, ms=True, attn="rma", diffts=True, dmtp=True,
+                        lively=True, seed=82),
+    "hard_rope_1l": dict(E=512, layers=1, B=1, T=3, N=24, Lt=16, Q=16, top_k=32, ms=True, attn="rope", diffts=False,
+                         dmtp=False, lively=False, seed=83),
+}
+
+
+@pytest.mark.parametrize("name", list(TOK_TRAIN_CASES))
+def test_tokenizer_gradients_vs_oracle(name):
+    from u2tokenizer_amd.tokenizer import u2Tokenizer
+    c = TOK_TRAIN_CASES[name]
+    E = c["E"]
+    tok = u2Tokenizer(E, 8, c["layers"], c["top_k"], c["ms"], c["Q"], E, c["attn"], c["diffts"], c["dmtp"])
+    sd32 = module_sd(tok, "u2tokenizer.", c["seed"])
+    if c["lively"]:
+        for n, t in sd32.items():
+            synth.lively_(n, t, qk_gain=2.0)
+    tok.load_state_dict({k[len("u2tokenizer."):]: v for k, v in sd32.items()})
+    v = synth.synth_tensor("v_token", (c["B"], c["T"], c["N"], E), c["seed"]).to(bf)
+    t = (0.25 * synth.synth_tensor("t_token", (c["B"], c["Lt"], E), c["seed"])).to(bf)
+    G = synth.synth_tensor("grad_out", (c["B"], c["Q"], E), c["seed"])
+    oc = O.PathConfig(hidden_size=E, u2t_num_layers=c["layers"], u2t_top_k=c["top_k"], use_multi_scale=c["ms"],
+                      num_3d_query_token=c["Q"], attn_type=c["attn"], enable_diffts=c["diffts"], enable_dmtp=c["dmtp"])
+    grads = {}
+    for dt in (torch.float32, bf):
+        vin, tin = leaf(v.to(dt)), leaf(t.to(dt))
+
+        def run(sd, vin=vin, tin=tin):
+            return O.tokenizer_forward(sd, "u2tokenizer", vin, tin, oc)[0], G
+
+        out, g = _oracle_grads(sd32, dt, run)
+        g["v_token"], g["t_token"] = vin.grad, tin.grad
+        grads[dt] = (out, g)
+    tok = tok.to(bf).to(D).train()
+    vd, td = leaf(v, D), leaf(t, D)
+    got_out = tok(v_token=vd, t_token=td)
+    assert rel(got_out.float(), grads[torch.float32][0]) <= 1.5 * rel(grads[bf][0].float(), grads[torch.float32][0]) + 1e-3
+    (got_out.float() * G.to(D)).sum().backward()
+    got = {"u2tokenizer." + k: p.grad for k, p in tok.named_parameters() if p.grad is not None}
+    got["v_token"], got["t_token"] = vd.grad, td.grad
+    ref32, ref16 = grads[torch.float32][1], grads[bf][1]
+    # parameters the reference never reaches (linear_aggregator.wv / dense: tta.py:47-48,62-65; score_net of the hard
+    # top-k) have no gradient on either side
+    assert set(got) == set(ref32), set(got) ^ set(ref32)
+    check_grads(got, ref32, ref16, what=name)
+
+
+def test_vit_and_projector_gradients_vs_oracle():
+    from u2tokenizer_amd.projector import SpatialPoolingProjector
+    from u2tokenizer_amd.vit import ViT3DTower
+    img, E, seed = [32, 64, 64], 256, 84
+    vit = ViT3DTower(NS(vision_select_layer=-1, vision_select_feature="patch", image_channel=1, image_size=img,
+                        patch_size=[4, 16, 16]))
+    spp = SpatialPoolingProjector(img, [4, 16, 16], 768, E, "mlp", 2, "spatial", 2)
+    sd32 = {**module_sd(vit, "vision_tower.", seed), **module_sd(spp, "mm_projector.", seed)}
+    vit.load_state_dict({k[len("vision_tower."):]: v for k, v in sd32.items() if k.startswith("vision_tower.")})
+    spp.load_state_dict({k[len("mm_projector."):]: v for k, v in sd32.items() if k.startswith("mm_projector.")})
+    vol = synth.synth_volume(1, 2, img, seed=seed, dtype=torch.float16).view(2, 1, *img)
+    G = synth.synth_tensor("grad_out", (2, 16, E), seed)
+    oc = O.PathConfig(image_size=img, hidden_size=E)
+    grads = {}
+    for dt in (torch.float32, bf):
+        def run(sd, dt=dt):
+            f = O.vit_tower_forward(sd, "vision_tower.vision_tower", vol.to(dt), oc)
+            return O.spp_forward(sd, "mm_projector", f, oc), G
+        grads[dt] = _oracle_grads(sd32, dt, run)
+    vit, spp = vit.to(bf).to(D).train(), spp.to(bf).to(D).train()
+    out = spp(vit(vol.to(D)))
+    assert rel(out.float(), grads[torch.float32][0]) <= 1.5 * rel(grads[bf][0].float(), grads[torch.float32][0]) + 1e-3
+    (out.float() * G.to(D)).sum().backward()
+    got = {"vision_tower." + k: p.grad for k, p in vit.named_parameters()}
+    got.update({"mm_projector." + k: p.grad for k, p in spp.named_parameters()})
+    assert set(got) == set(grads[torch.float32][1])
+    check_grads(got, grads[torch.float32][1], grads[bf][1], what="vit + spp")
+
+
+def test_training_step_through_the_hf_model():
+    """stage-1 style step (train_stage1.py:244-251): model(images, input_ids, labels, attention_mask, question_ids) on the
+    GPU with HIP forward + backward; loss and the gradients of the path's parameters (and of the embedding table rows)
+    against oracle + the same HF decoder on the host in fp32."""
+    from cases import FULL_CASES
+    from test_oracle_golden import _full_model, full_path_cfg
+    c = FULL_CASES["cfg1"]
+    m, cfg = _full_model(c)
+    m.train()
+    vol = synth.synth_volume(c["B"], c["C"], c["mm"]["image_size"], seed=c["seed"], dtype=torch.float16)
+    ids = synth.synth_ids(c["B"], c["S"], c["n_real"], cfg.vocab_size, seed=c["seed"], name="input_ids")
+    qids = synth.synth_ids(c["B"], c["Lt"], c["n_q"], cfg.vocab_size, seed=c["seed"], name="question_ids")
+    labels = ids.clone()
+    labels[:, :20] = -100
+    # host reference: oracle path (differentiated) -> the HF decoder in fp32
+    sd = {k: leaf(v) for k, v in m.state_dict().items() if v.is_floating_point()}
+    emb, _ = O.prepare_inputs_for_multimodal(sd, sd["model.embed_tokens.weight"], ids, vol.float(), qids, full_path_cfg(c))
+    dec = {k: v for k, v in sd.items() if not any(s in k for s in ("vision_tower", "mm_projector", "u2tokenizer"))}
+    loss32 = torch.func.functional_call(m, {k: v for k, v in dec.items()}, args=(),
+                                        kwargs=dict(inputs_embeds=emb, labels=labels)).loss
+    loss32.backward()
+    ref = {k: v.grad for k, v in sd.items() if v.grad is not None
+           and any(s in k for s in ("vision_tower", "mm_projector", "u2tokenizer", "embed_tokens"))}
+    mg = m.to(bf).to(D)
+    for p in mg.parameters():
+        p.requires_grad_(True)
+    out = mg(images=vol.to(D), input_ids=ids.to(D), labels=labels.to(D), question_ids=qids.to(D))
+    assert abs(out.loss.item() - loss32.item()) < 3e-2 * abs(loss32.item()), (out.loss.item(), loss32.item())
+    out.loss.backward()
+    got = {k: p.grad for k, p in mg.named_parameters() if k in ref}
+    check_grads(got, ref, what="training step")
+
+
+def test_dpo_duplicate_image_batch_is_deduplicated():
+    """cat([images, images]) with the same question (dpo_u2trainer.py:160-162): the path runs once per distinct
+    (image, question); results and gradients equal the plain run."""
+    from cases import FULL_CASES
+    from test_oracle_golden import _full_model
+    c = FULL_CASES["cfg1"]
+    m, cfg = _full_model(c)
+    mg = m.to(bf).to(D).train()
+    vol = synth.synth_volume(1, c["C"], c["mm"]["image_size"], seed=c["seed"], dtype=torch.float16).to(D)
+    ids = synth.synth_ids(2, c["S"], c["n_real"], cfg.vocab_size, seed=c["seed"], name="input_ids").to(D)
+    qids = synth.synth_ids(1, c["Lt"], c["n_q"], cfg.vocab_size, seed=c["seed"], name="question_ids").to(D)
+    vol2, qids2 = torch.cat([vol, vol]), torch.cat([qids, qids])
+    res = {}
+    for flag in (True, False):
+        mg.config.u2_dedup_duplicate_images = flag
+        mg.zero_grad(set_to_none=True)
+        emb = mg.prepare_inputs_for_multimodal(ids, None, None, None, None, vol2, qids2)[4]
+        emb.float().square().sum().backward()
+        res[flag] = (emb.detach(), {k: p.grad.clone() for k, p in mg.named_parameters() if p.grad is not None})
+    assert torch.equal(res[True][0][0, 1:17], res[True][0][1, 1:17])
+    assert rel(res[True][0].float(), res[False][0].float()) < 1e-3
+    for k, g in res[False][1].items():
+        assert rel(res[True][1][k].float(), g.float(), 1e-3 * g.float().abs().max().item()) < 5e-2, k

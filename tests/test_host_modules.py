@@ -56,7 +56,7 @@ def test_no_cpu_fallback():
     tok = U.build_u2tokenizer_tower(_cfg()).bfloat16()
     with torch.no_grad(), pytest.raises(RuntimeError, match="GPU tensor"):
         tok(v_token=torch.zeros(1, 2, 16, 512, dtype=torch.bfloat16), t_token=torch.zeros(1, 8, 512, dtype=torch.bfloat16))
-    with torch.enable_grad(), pytest.raises(RuntimeError, match="forward-only"):
+    with torch.enable_grad(), pytest.raises(RuntimeError, match="GPU tensor"):  # the training path has no CPU fallback either
         tok(v_token=torch.zeros(1, 2, 16, 512, dtype=torch.bfloat16), t_token=torch.zeros(1, 8, 512, dtype=torch.bfloat16))
 
 

@@ -92,7 +92,16 @@ SIGNATURES = {
                                         _i32, _vp]),
     "u2tok_flash_attention_d64": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _f32,
                                          _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
-    "u2tok_rope_apply": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i64, _i32, _vp]),
+    "u2tok_rope_apply": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i64, _i32, _i32, _vp]),
+    "u2tok_gelu_fwd": (_i32, [_vp, _vp, _i64, _vp]),
+    "u2tok_gelu_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "u2tok_colsum_workspace_bytes": (_sz, [_i32, _i32]),
+    "u2tok_colsum_bf16": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp, _i32, _vp]),
+    "u2tok_layernorm_bwd_workspace_bytes": (_sz, [_i32, _i32]),
+    "u2tok_layernorm_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _i32, _vp]),
+    "u2tok_softmax_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _vp]),
+    "u2tok_relbias_grad": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp]),
+    "u2tok_rowdot_bf16": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _vp]),
 }
 
 ERRORS = {-1: "U2TOK_ERR_ARG (bad dimension / null pointer / unsupported combination)",

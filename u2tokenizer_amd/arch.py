@@ -112,11 +112,23 @@ class u2MetaForCausalLM(ABC):
 
         if self.config.enable_u2tokenizer:
             B, C, D, H, W = images.shape
-            images = images.to(dev).view(B * C, 1, D, H, W)
+            images, question_ids = images.to(dev), question_ids.to(dev)
+            # The DPO trainer feeds every image twice -- cat([images, images]) for the chosen / rejected completions
+            # (dpo_u2trainer.py:160-162) with the same question: the two halves of the vision batch are byte-identical.
+            # The path is a deterministic function of (image, question): run one half and repeat the result (autograd
+            # sums the two halves' gradients, as it would have).  Costs one comparison of the halves per call.
+            dup = (getattr(self.config, "u2_dedup_duplicate_images", True) and B >= 2 and B % 2 == 0
+                   and torch.equal(question_ids[:B // 2], question_ids[B // 2:])
+                   and torch.equal(images[:B // 2], images[B // 2:]))
+            if dup:
+                B, images, question_ids = B // 2, images[:B // 2], question_ids[:B // 2]
+            images = images.reshape(B * C, 1, D, H, W)
             image_features = self.encode_images(images)
-            v_tokens = image_features.view(B, C, image_features.shape[-2], image_features.shape[-1])
-            t_tokens = lookup(question_ids.to(dev))
+            v_tokens = image_features.reshape(B, C, image_features.shape[-2], image_features.shape[-1])
+            t_tokens = lookup(question_ids)
             image_features = self.get_u2tokenizer()(v_token=v_tokens, t_token=t_tokens)
+            if dup:
+                image_features = image_features.repeat(2, 1, 1)
         else:
             image_features = self.encode_images(images.to(dev))
         if track or (torch.is_grad_enabled() and image_features.requires_grad):

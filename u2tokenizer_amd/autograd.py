@@ -1,0 +1,540 @@
+"""Training path of the drop-in modules: torch.autograd.Functions over the C-ABI building blocks.
+
+Inference (torch.no_grad) runs each module as ONE fused launch sequence inside libu2tok_hip.so (pipeline.hip).  Under
+autograd the same kernels are sequenced from here, op by op, so that every op can save what its backward needs:
+
+  * GEMM-shaped work -- forward AND backward -- runs on the library's MFMA kernels: y = x W^T (+ b, + residual) through
+    u2tok_gemm_bf16; dX = dY W and dW = dY^T X as the same NT product on transposed operands (u2tok_transpose_bf16);
+    the attention cores' dP = dO V^T, dV = P^T dO, dQ = dS K, dK = dS^T Q likewise, batched over (batch, head);
+  * attention backward is recompute-based for the ViT: the forward is the flash kernel (no S x S tensor), the backward
+    rebuilds the probabilities of one layer at a time with the unfused core (scores GEMM + row softmax);
+  * the non-GEMM pieces are the kernels of csrc/backward.hip (GELU, LayerNorm, softmax, relative-bias table, column
+    sums);
+  * torch itself only moves data (views, permutes, cat / split, residual adds, the scatter of the hard top-k gather)
+    and differentiates those moves.
+
+Reference being differentiated: src/model/multimodal_encoder/vit.py (MONAI blocks), multimodal_projector/
+spatial_pooling_projector.py, u2tokenizer/{svr,tta,rma,rope}.py.  The gradient tests differentiate the CPU restatement
+of those files with torch.autograd on the host and compare every parameter's gradient (tests/test_gpu_backward.py).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+BF = torch.bfloat16
+
+
+def _r8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+def _t2(x: torch.Tensor) -> torch.Tensor:
+    """(R, C) dense bf16 -> (C, R rounded up to 8) transposed, zero padded."""
+    R, C = x.shape
+    return ops.transpose_ex(x, 1, R, C, C, 0)[0]
+
+
+_scratch = {}
+
+
+def ensure_gemm_scratch(device: torch.device) -> None:
+    """Split-K scratch for the skinny products of the training path (dW of small layers has K = rows), one buffer per
+    (device, stream), registered on the active context."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, id(ops.active_context(device)))
+    if key not in _scratch:
+        buf = torch.empty(64 << 20, dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            ops.set_gemm_scratch(buf)
+        _scratch[key] = buf
+
+
+# ------------------------------------------------------------------------------------------------ Linear (+GELU, +residual)
+class LinearFn(Function):
+    """y = x W^T (+ b) (-> GELU) (+ residual), bias / residual fused in the GEMM epilogue as in the inference path."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, res, gelu: bool):
+        K, N = x.shape[-1], w.shape[0]
+        if N % 8 or K % 8:
+            raise RuntimeError(f"LinearFn: in / out features must be multiples of 8 (got {K}, {N})")
+        x2 = x.reshape(-1, K).contiguous()
+        z = None
+        if gelu:
+            if res is not None:
+                raise RuntimeError("LinearFn: GELU with a residual is not used by the path")
+            z = ops.gemm(x2, w, bias=b)
+            y = ops.gelu_fwd(z)
+        else:
+            y = ops.gemm(x2, w, bias=b, residual=None if res is None else res.reshape(-1, N))
+        ctx.save_for_backward(x2, w, z)
+        ctx.has_b, ctx.has_res, ctx.xshape = b is not None, res is not None, x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, z = ctx.saved_tensors
+        N, K = w.shape
+        dy2 = dy.reshape(-1, N).contiguous()
+        dz = ops.gelu_bwd(z, dy2) if z is not None else dy2
+        dx = dw = db = dres = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(dz, _t2(w)).view(ctx.xshape)          # (M, N) (K, N)^T
+        if ctx.needs_input_grad[1]:
+            dw = ops.gemm(_t2(dz), _t2(x2))                      # (N, M) (K, M)^T
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = ops.colsum(dz)
+        if ctx.has_res and ctx.needs_input_grad[3]:
+            dres = dy
+        return dx, dw, db, dres, None
+
+
+def linear(x, w, b=None, res=None, gelu=False):
+    return LinearFn.apply(x, w, b, res, gelu)
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm (+residual)
+class LayerNormFn(Function):
+    """y = LayerNorm(x (+ res)) * w + b  (tta.py:96,100,103; MONAI TransformerBlock norm1 / norm2; ViT.norm)."""
+
+    @staticmethod
+    def forward(ctx, x, res, w, b, eps: float):
+        y = ops.layernorm(x, w, b, residual=res, eps=eps)
+        ctx.save_for_backward(x, res, w)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, res, w = ctx.saved_tensors
+        dv, dw, db = ops.layernorm_bwd(x, res, w, dy, ctx.eps)
+        return dv, (dv if res is not None else None), dw.to(w.dtype), db.to(w.dtype), None
+
+
+def layernorm(x, w, b, res=None, eps=1e-5):
+    return LayerNormFn.apply(x, res, w, b, eps)
+
+
+# ------------------------------------------------------------------------------------------------ attention cores
+def _rowstride(t):  # (nb, S, E) view with unit feature stride -> (batch stride, row stride)
+    assert t.stride(2) == 1, "attention operands must be feature-contiguous"
+    return t.stride(0), t.stride(1)
+
+
+def _attn_probs(q, k, H, scale, rel_bias, max_len):
+    """softmax(q k^T * scale + bias) per (batch, head): q (nb, Sq, E), k (nb, Skv, E) views -> P (nb*H, Sq, ldp) bf16."""
+    nb, Sq, E = q.shape
+    Skv, d = k.shape[1], E // H
+    qb, ql = _rowstride(q)
+    kb, kl = _rowstride(k)
+    S = torch.empty((nb * H, Sq, Skv), dtype=torch.float32, device=q.device)
+    ops.gemm_strided(q, k, S, M=Sq, N=Skv, K=d, lda=ql, ldb=kl, ldc=Skv, nz=nb * H, nbh=H, sAb=qb, sAh=d, sBb=kb, sBh=d,
+                     sCb=H * Sq * Skv, sCh=Sq * Skv, out_f32=True)
+    return ops.softmax_rows(S, scale=scale, rel_bias=rel_bias, heads=H, max_len=max_len, ldp=_r8(Skv))
+
+
+def _attn_pv(P, v, H, Sq):
+    """out (nb, Sq, E) = P V per (batch, head); v (nb, Skv, E) view."""
+    nb, Skv, E = v.shape
+    d, ldp = E // H, P.shape[-1]
+    vb, vl = _rowstride(v)
+    Vt = ops.transpose_ex(v, nb, Skv, E, vl, vb, ld_out=ldp)                      # (nb, E, ldp)
+    out = torch.empty((nb, Sq, E), dtype=BF, device=v.device)
+    ops.gemm_strided(P, Vt, out, M=Sq, N=d, K=ldp, lda=ldp, ldb=ldp, ldc=E, nz=nb * H, nbh=H, sAb=H * Sq * ldp,
+                     sAh=Sq * ldp, sBb=E * ldp, sBh=d * ldp, sCb=Sq * E, sCh=d)
+    return out
+
+
+def _attn_backward(q, k, v, P, dO, H, scale, dq, dk, dv, dtable, max_len):
+    """Gradients of out = softmax(q k^T scale + bias) v written into the (nb, S, E) views dq / dk / dv (any may be None);
+    dtable: fp32 relative-bias gradient table to accumulate into, or None."""
+    nb, Sq, E = q.shape
+    Skv, d, Z = k.shape[1], E // H, nb * H
+    ldp, Sqp = P.shape[-1], _r8(Sq)
+    dO = dO.contiguous()
+    vb, vl = _rowstride(v)
+    dP = torch.empty((Z, Sq, Skv), dtype=torch.float32, device=q.device)
+    ops.gemm_strided(dO, v, dP, M=Sq, N=Skv, K=d, lda=E, ldb=vl, ldc=Skv, nz=Z, nbh=H, sAb=Sq * E, sAh=d, sBb=vb, sBh=d,
+                     sCb=H * Sq * Skv, sCh=Sq * Skv, out_f32=True)
+    dS = ops.softmax_bwd(P, dP, Skv)                                              # (Z, Sq, ldp), pad columns zero
+    del dP
+    if dtable is not None:
+        ops.relbias_grad(dS, dtable, Sq, H, max_len)
+    if dv is not None:
+        Pt = ops.transpose_ex(P, Z, Sq, Skv, ldp, Sq * ldp, ld_out=Sqp)           # (Z, Skv, Sqp)
+        dOt = ops.transpose_ex(dO, nb, Sq, E, E, Sq * E, ld_out=Sqp)              # (nb, E, Sqp)
+        b_, l_ = _rowstride(dv)
+        ops.gemm_strided(Pt, dOt, dv, M=Skv, N=d, K=Sqp, lda=Sqp, ldb=Sqp, ldc=l_, nz=Z, nbh=H, sAb=H * Skv * Sqp,
+                         sAh=Skv * Sqp, sBb=E * Sqp, sBh=d * Sqp, sCb=b_, sCh=d)
+        del Pt, dOt
+    if dq is not None:
+        kb, kl = _rowstride(k)
+        Kt = ops.transpose_ex(k, nb, Skv, E, kl, kb, ld_out=ldp)                  # (nb, E, ldp)
+        b_, l_ = _rowstride(dq)
+        ops.gemm_strided(dS, Kt, dq, M=Sq, N=d, K=ldp, lda=ldp, ldb=ldp, ldc=l_, nz=Z, nbh=H, sAb=H * Sq * ldp,
+                         sAh=Sq * ldp, sBb=E * ldp, sBh=d * ldp, sCb=b_, sCh=d, alpha=scale)
+    if dk is not None:
+        qb, ql = _rowstride(q)
+        dSt = ops.transpose_ex(dS, Z, Sq, Skv, ldp, Sq * ldp, ld_out=Sqp)         # (Z, Skv, Sqp)
+        Qt = ops.transpose_ex(q, nb, Sq, E, ql, qb, ld_out=Sqp)                   # (nb, E, Sqp)
+        b_, l_ = _rowstride(dk)
+        ops.gemm_strided(dSt, Qt, dk, M=Skv, N=d, K=Sqp, lda=Sqp, ldb=Sqp, ldc=l_, nz=Z, nbh=H, sAb=H * Skv * Sqp,
+                         sAh=Skv * Sqp, sBb=E * Sqp, sBh=d * Sqp, sCb=b_, sCh=d, alpha=scale)
+
+
+class SelfAttnFn(Function):
+    """Self-attention core on a packed q | k | v buffer (nb, S, 3E) -> (nb, S, E).  rel_bias: (2 max_len - 1, H) table of
+    RelativeMultiheadAttention (rma.py:64-70) or None.  flash=True (head dim 64, no bias): the forward is the ViT flash
+    kernel with the LAST row of every batch as its "extra" row; the backward rebuilds the probabilities."""
+
+    @staticmethod
+    def forward(ctx, qkv, rel_bias, H: int, scale: float, max_len: int, flash: bool):
+        nb, S, E3 = qkv.shape
+        E = E3 // 3
+        qkv = qkv.contiguous()
+        P = None
+        if flash:
+            out = ops.flash_attention_d64(qkv, H, scale, extra_last=S > 1)
+        else:
+            P = _attn_probs(qkv[..., :E], qkv[..., E:2 * E], H, scale, rel_bias, max_len)
+            out = _attn_pv(P, qkv[..., 2 * E:], H, S)
+        ctx.save_for_backward(qkv, rel_bias, P)
+        ctx.cfg = (H, scale, max_len)
+        return out
+
+    @staticmethod
+    def backward(ctx, dO):
+        qkv, rel_bias, P = ctx.saved_tensors
+        H, scale, max_len = ctx.cfg
+        E = qkv.shape[-1] // 3
+        q, k, v = qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:]
+        if P is None:
+            P = _attn_probs(q, k, H, scale, rel_bias, max_len)
+        dqkv = torch.empty_like(qkv)
+        dtable = None
+        if rel_bias is not None and ctx.needs_input_grad[1]:
+            dtable = torch.zeros(rel_bias.shape, dtype=torch.float32, device=qkv.device)
+        _attn_backward(q, k, v, P, dO, H, scale, dqkv[..., :E], dqkv[..., E:2 * E], dqkv[..., 2 * E:], dtable, max_len)
+        return dqkv, (None if dtable is None else dtable.to(rel_bias.dtype)), None, None, None, None
+
+
+class CrossAttnFn(Function):
+    """MultiHeadCrossAttention core (tta.py:55-61): q (nb, Sq, E), packed k | v (nb, Skv, 2E) -> (nb, Sq, E)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, H: int, scale: float):
+        E = q.shape[-1]
+        q, kv = q.contiguous(), kv.contiguous()
+        P = _attn_probs(q, kv[..., :E], H, scale, None, 0)
+        out = _attn_pv(P, kv[..., E:], H, q.shape[1])
+        ctx.save_for_backward(q, kv, P)
+        ctx.cfg = (H, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dO):
+        q, kv, P = ctx.saved_tensors
+        H, scale = ctx.cfg
+        E = q.shape[-1]
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        _attn_backward(q, kv[..., :E], kv[..., E:], P, dO, H, scale, dq, dkv[..., :E], dkv[..., E:], None, 0)
+        return dq, dkv, None, None
+
+
+class AttnFn(Function):
+    """Attention core on separate q, k, v (nb, S, E) -- the un-projected aggregation of LinearAggregation (tta.py:109-116)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, H: int, scale: float):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        P = _attn_probs(q, k, H, scale, None, 0)
+        out = _attn_pv(P, v, H, q.shape[1])
+        ctx.save_for_backward(q, k, v, P)
+        ctx.cfg = (H, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dO):
+        q, k, v, P = ctx.saved_tensors
+        H, scale = ctx.cfg
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        _attn_backward(q, k, v, P, dO, H, scale, dq, dk, dv, None, 0)
+        return dq, dk, dv, None, None
+
+
+class RopeFn(Function):
+    """rotate-half RoPE on the q and k thirds of a packed (nb, S, 3E) buffer (rope.py:77-80); position = row index."""
+
+    @staticmethod
+    def forward(ctx, qkv, H: int, max_len: int):
+        nb, S, E3 = qkv.shape
+        E = E3 // 3
+        out = qkv.clone()
+        ops.rope_apply(out[..., :E], nb, S, 1, H, E // H, max_len)
+        ops.rope_apply(out[..., E:2 * E], nb, S, 1, H, E // H, max_len)
+        ctx.cfg = (H, max_len)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        H, max_len = ctx.cfg
+        nb, S, E3 = d.shape
+        E = E3 // 3
+        g = d.clone()
+        ops.rope_apply(g[..., :E], nb, S, 1, H, E // H, max_len, inverse=True)
+        ops.rope_apply(g[..., E:2 * E], nb, S, 1, H, E // H, max_len, inverse=True)
+        return g, None, None
+
+
+# ------------------------------------------------------------------------------------------------ selection / pooling
+class DiffTSFn(Function):
+    """DifferentiableTokenSelection (svr.py:101-117): out[r] = sum_tok softmax_tok(score_net(x) / tau)[tok, r] x[tok],
+    computed operand-swapped as in the inference path: raw^T = W X^T + b (k x TN), row softmax, P X."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, tau: float):
+        B, TN, E = x.shape
+        k = w.shape[0]
+        x = x.contiguous()
+        raw = torch.empty((B, k, TN), dtype=torch.float32, device=x.device)
+        ops.gemm_strided(w, x, raw, M=k, N=TN, K=E, lda=E, ldb=E, ldc=TN, nz=B, sBb=TN * E, sCb=k * TN, out_f32=True,
+                         bias=b, bias_m=True)
+        P = ops.softmax_rows(raw, scale=1.0 / tau, ldp=_r8(TN))                   # (B, k, ldp)
+        ldp = P.shape[-1]
+        Xt = ops.transpose_ex(x, B, TN, E, E, TN * E, ld_out=ldp)                 # (B, E, ldp)
+        out = torch.empty((B, k, E), dtype=BF, device=x.device)
+        ops.gemm_strided(P, Xt, out, M=k, N=E, K=ldp, lda=ldp, ldb=ldp, ldc=E, nz=B, sAb=k * ldp, sBb=E * ldp, sCb=k * E)
+        ctx.save_for_backward(x, w, P, Xt)
+        ctx.tau = tau
+        return out
+
+    @staticmethod
+    def backward(ctx, dsel):
+        x, w, P, Xt = ctx.saved_tensors
+        B, TN, E = x.shape
+        k, ldp = w.shape[0], P.shape[-1]
+        dsel = dsel.contiguous()
+        dP = torch.empty((B, k, TN), dtype=torch.float32, device=x.device)
+        ops.gemm_strided(dsel, x, dP, M=k, N=TN, K=E, lda=E, ldb=E, ldc=TN, nz=B, sAb=k * E, sBb=TN * E, sCb=k * TN,
+                         out_f32=True)
+        dS = ops.softmax_bwd(P, dP, TN)                                            # d logits; d raw = dS / tau
+        inv = 1.0 / ctx.tau
+        kp = _r8(k)
+        # dX = P^T dsel + (dS^T W) / tau
+        Pt = ops.transpose_ex(P, B, k, TN, ldp, k * ldp, ld_out=kp)               # (B, TN, kp)
+        dselT = ops.transpose_ex(dsel, B, k, E, E, k * E, ld_out=kp)              # (B, E, kp)
+        dX = torch.empty_like(x)
+        ops.gemm_strided(Pt, dselT, dX, M=TN, N=E, K=kp, lda=kp, ldb=kp, ldc=E, nz=B, sAb=TN * kp, sBb=E * kp, sCb=TN * E)
+        dSt = ops.transpose_ex(dS, B, k, TN, ldp, k * ldp, ld_out=kp)             # (B, TN, kp)
+        Wt = ops.transpose_ex(w, 1, k, E, E, 0, ld_out=kp)                        # (1, E, kp)
+        dX2 = torch.empty_like(x)
+        ops.gemm_strided(dSt, Wt, dX2, M=TN, N=E, K=kp, lda=kp, ldb=kp, ldc=E, nz=B, sAb=TN * kp, sCb=TN * E, alpha=inv)
+        dX = dX + dX2
+        # dW = sum_b dS_b X_b / tau : (k, E) = [dS_0 | dS_1 | ...] (k, B*ldp) [Xt_0 | Xt_1 | ...]^T
+        dS_cat = dS.permute(1, 0, 2).reshape(k, B * ldp).contiguous()
+        Xt_cat = Xt.permute(1, 0, 2).reshape(E, B * ldp).contiguous()
+        dW = ops.gemm(dS_cat, Xt_cat, alpha=inv)
+        db = (dS.float().sum(dim=(0, 2)) * inv).to(w.dtype)
+        return dX, dW, db, None
+
+
+class MultiScalePoolFn(Function):
+    """{1,2,4} average pooling along the token axis (svr.py:176-184), optionally gated by DynamicMultiScalePooling
+    (svr.py:126-151).  Forward: the HIP kernel of the inference path; backward: the few thousand-element gate algebra
+    and the pooling transposes in torch (fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, gate_w, gate_b):
+        out = ops.multiscale_pool(x, gate_w, gate_b)
+        ctx.save_for_backward(x, gate_w, gate_b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, gw, gb = ctx.saved_tensors
+        B, k, E = x.shape
+        xf, d = x.float(), dout.float()
+        sizes = [k, k // 2, k // 4]
+        pools = [xf, xf[:, :2 * sizes[1]].view(B, sizes[1], 2, E).mean(2), xf[:, :4 * sizes[2]].view(B, sizes[2], 4, E).mean(2)]
+        douts = list(d.split(sizes, dim=1))
+        dpools, dgw, dgb = douts, None, None
+        if gw is not None:
+            means = torch.stack([p.mean(1) for p in pools], 1)                     # (B, 3, E)
+            logits = means @ gw.float().reshape(-1) + gb.float().reshape(())       # (B, 3)
+            g = torch.softmax(logits, dim=1)
+            dg = torch.stack([(douts[i] * pools[i]).sum((1, 2)) for i in range(3)], 1)   # (B, 3)
+            dlog = g * (dg - (g * dg).sum(1, keepdim=True))
+            dgw = torch.einsum("bs,bse->e", dlog, means).reshape(gw.shape).to(gw.dtype)
+            dgb = dlog.sum().reshape(gb.shape).to(gb.dtype)
+            dmeans = dlog.unsqueeze(-1) * gw.float().reshape(1, 1, E)              # (B, 3, E)
+            dpools = [g[:, i, None, None] * douts[i] + dmeans[:, i, None, :] / sizes[i] for i in range(3)]
+        dx = dpools[0].clone()
+        dx[:, :2 * sizes[1]] += dpools[1].repeat_interleave(2, dim=1) / 2
+        dx[:, :4 * sizes[2]] += dpools[2].repeat_interleave(4, dim=1) / 4
+        return dx.to(x.dtype), dgw, dgb
+
+
+class HardTopKFn(Function):
+    """TokenSelection (svr.py:75-91): indices are not differentiable (score_net receives no gradient, exactly as in the
+    reference -- hence its find_unused_parameters=True, train_stage1.py:21-22); the gather scatters its gradient back."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, k: int):
+        B, TN, E = x.shape
+        scores = ops.score_gemv(x.contiguous(), w, b)
+        idx = ops.topk_sorted(scores.view(B, TN), k)
+        ctx.save_for_backward(idx)
+        ctx.shape = x.shape
+        ctx.mark_non_differentiable(idx)
+        return ops.gather_rows(x.contiguous(), idx), idx
+
+    @staticmethod
+    def backward(ctx, dsel, _didx):
+        (idx,) = ctx.saved_tensors
+        B, TN, E = ctx.shape
+        dx = torch.zeros((B, TN, E), dtype=dsel.dtype, device=dsel.device)
+        dx.scatter_(1, idx.unsqueeze(-1).expand(-1, -1, E), dsel.contiguous())     # top-k indices are distinct
+        return dx, None, None, None
+
+
+class AvgPool3dFn(Function):
+    """SpatialPoolingProjector pooling (spatial_pooling_projector.py:38-41) over the (g1, g2, g3) token grid."""
+
+    @staticmethod
+    def forward(ctx, x, grid, window):
+        ctx.grid, ctx.window = tuple(grid), tuple(window)
+        return ops.avgpool3d_tokens(x, grid, window)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (g1, g2, g3), (w1, w2, w3) = ctx.grid, ctx.window
+        p1, p2, p3 = g1 // w1, g2 // w2, g3 // w3
+        nb, _, C = dy.shape
+        d = (dy / (w1 * w2 * w3)).view(nb, p1, 1, p2, 1, p3, 1, C).expand(nb, p1, w1, p2, w2, p3, w3, C)
+        dx = torch.zeros((nb, g1, g2, g3, C), dtype=dy.dtype, device=dy.device)
+        dx[:, :p1 * w1, :p2 * w2, :p3 * w3] = d.reshape(nb, p1 * w1, p2 * w2, p3 * w3, C)
+        return dx.view(nb, g1 * g2 * g3, C), None, None
+
+
+# ================================================================================================ module forwards
+def _qkv_params(m):
+    """(W (3E, E), b (3E,)) of an attention module: cat of wq | wk | wv -- autograd routes the gradient back."""
+    return torch.cat([m.wq.weight, m.wk.weight, m.wv.weight], 0), torch.cat([m.wq.bias, m.wk.bias, m.wv.bias], 0)
+
+
+def _self_attention(m, x, attn_type: str, H: int):
+    """RelativeMultiheadAttention / RotaryMultiheadAttention forward on x (nb, S, E) (rma.py:46-83, rope.py:62-91)."""
+    E = x.shape[-1]
+    W, b = _qkv_params(m)
+    qkv = linear(x, W, b)
+    scale = 1.0 / math.sqrt(E // H)
+    if attn_type == "rope":
+        qkv = RopeFn.apply(qkv, H, m.max_seq_len)
+        ctxv = SelfAttnFn.apply(qkv, None, H, scale, 0, False)
+    else:
+        ctxv = SelfAttnFn.apply(qkv, m.relative_bias, H, scale, m.max_seq_len, False)
+    return linear(ctxv, m.dense.weight, m.dense.bias)
+
+
+def _cross_attention(m, query, value, H: int):
+    """MultiHeadCrossAttention forward (tta.py:42-69), is_compress = False."""
+    E = query.shape[-1]
+    q = linear(query, m.wq.weight, m.wq.bias)
+    kv = linear(value, torch.cat([m.wk.weight, m.wv.weight], 0), torch.cat([m.wk.bias, m.wv.bias], 0))
+    ctxv = CrossAttnFn.apply(q, kv, H, 1.0 / math.sqrt(E // H))
+    return linear(ctxv, m.dense.weight, m.dense.bias)
+
+
+def tokenizer_forward(tok, v_token: torch.Tensor, t_token: torch.Tensor) -> torch.Tensor:
+    """u2Tokenizer.forward under autograd (u2Tokenizer.py:40-47 = svr.py:166-188 + tta.py:126-140)."""
+    if tok.attn_type not in ("rma", "rope"):
+        raise NotImplementedError("training the nn.MultiheadAttention ('linvt') ablation is not supported by the HIP path")
+    B, T, N, E = v_token.shape
+    H = tok.num_heads
+    ensure_gemm_scratch(v_token.device)
+    x = v_token.to(BF)
+    t_token = t_token.to(BF)
+    # ---- SVR: x = attn(x), spatial then temporal, no residual / norm (svr.py:23-40)
+    for layer in tok.svt_module.attention_network.layers:
+        xs = _self_attention(layer.spatial_attention, x.reshape(B * T, N, E), tok.attn_type, H)
+        xt = xs.view(B, T, N, E).permute(0, 2, 1, 3).reshape(B * N, T, E)
+        xt = _self_attention(layer.temporal_attention, xt, tok.attn_type, H)
+        x = xt.view(B, N, T, E).permute(0, 2, 1, 3).contiguous()
+    flat = x.reshape(B, T * N, E)
+    sel_m = tok.svt_module.token_selection
+    if tok.enable_diffts:
+        sel = DiffTSFn.apply(flat, sel_m.score_net.weight, sel_m.score_net.bias, float(sel_m.tau))
+    else:
+        sel, idx = HardTopKFn.apply(flat, sel_m.score_net.weight, sel_m.score_net.bias, tok.top_k)
+        tok.last_topk_indices = idx
+    if tok.use_multi_scale:
+        if tok.enable_dmtp:
+            g = tok.svt_module.dynamic_pool.gate_fc
+            V = MultiScalePoolFn.apply(sel, g.weight, g.bias)
+        else:
+            V = MultiScalePoolFn.apply(sel, None, None)
+    else:
+        V = sel
+    # ---- TTA (tta.py:93-107,126-140)
+    q = tok.query_tokens.expand(B, -1, -1)
+    for layer in tok.tta_module.layers_vt:
+        so = _self_attention(layer.self_attention, q, tok.attn_type, H)
+        q1 = layernorm(q.contiguous(), layer.norm_self.weight, layer.norm_self.bias, res=so)
+        co = _cross_attention(layer.visual_cross_attention, q1, V, H)
+        q2 = layernorm(q1, layer.norm_cross_v.weight, layer.norm_cross_v.bias, res=co)
+        ct = _cross_attention(layer.text_cross_attention, q2, t_token, H)
+        q = layernorm(q2, layer.norm_cross_t.weight, layer.norm_cross_t.bias, res=ct)
+    la = tok.tta_module.layer_linagg.linear_aggregator
+    qq = linear(q, la.wq.weight, la.wq.bias)
+    kk = linear(V, la.wk.weight, la.wk.bias)
+    return AttnFn.apply(qq, kk, V, H, 1.0 / math.sqrt(E // H))
+
+
+def spp_forward(m, x: torch.Tensor) -> torch.Tensor:
+    """SpatialPoolingProjector.forward under autograd (spatial_pooling_projector.py:34-52)."""
+    import torch.nn as nn
+    ensure_gemm_scratch(x.device)
+    g = m.num_patches_pre
+    ps = m.pooling_size
+    x = x.to(BF).contiguous()
+    if m.pooling_type == "spatial":
+        x = AvgPool3dFn.apply(x, tuple(g), (ps, ps, ps))
+    else:
+        x = AvgPool3dFn.apply(x, (1, 1, g[0] * g[1] * g[2]), (1, 1, ps ** 3))
+    lins = [l for l in m.projector if isinstance(l, nn.Linear)]
+    for i, lin in enumerate(lins):
+        last = i == len(lins) - 1
+        x = linear(x, lin.weight, lin.bias, gelu=(not last and m.layer_type == "mlp"))
+    return x
+
+
+def vit_forward(vit, images: torch.Tensor, keep_cls: bool) -> torch.Tensor:
+    """ViT.forward + feature selection under autograd (vit.py:114-126,148-164, MONAI blocks).  Rows of a chunk are kept
+    as [patches | cls] (the attention kernel's "extra row" is the last one); the reference order is restored on exit."""
+    ensure_gemm_scratch(images.device)
+    pe = vit.patch_embedding
+    nc = images.shape[0]
+    Hd, heads = vit.hidden_size, vit.num_heads
+    patches = ops.im2col(images.contiguous(), tuple(vit.patch_size))              # (nc, ntok, p1 p2 p3); not differentiated
+    lin = pe.patch_embeddings[1]
+    x = linear(patches, lin.weight, lin.bias) + pe.position_embeddings.to(BF)
+    x = torch.cat((x, vit.cls_token.to(BF).expand(nc, -1, -1)), dim=1).contiguous()   # (nc, ntok + 1, Hd)
+    ntok = pe.n_patches
+    scale = 1.0 / math.sqrt(Hd // heads)
+    for blk in vit.blocks:
+        h = layernorm(x, blk.norm1.weight, blk.norm1.bias, eps=blk.norm1.eps)
+        qkv = linear(h, blk.attn.qkv.weight, None)
+        att = SelfAttnFn.apply(qkv, None, heads, scale, 0, True)
+        x = linear(att, blk.attn.out_proj.weight, blk.attn.out_proj.bias, res=x)
+        h = layernorm(x, blk.norm2.weight, blk.norm2.bias, eps=blk.norm2.eps)
+        h = linear(h, blk.mlp.linear1.weight, blk.mlp.linear1.bias, gelu=True)
+        x = linear(h, blk.mlp.linear2.weight, blk.mlp.linear2.bias, res=x)
+    x = layernorm(x, vit.norm.weight, vit.norm.bias, eps=vit.norm.eps)
+    if keep_cls:
+        return torch.cat((x[:, ntok:], x[:, :ntok]), dim=1)
+    return x[:, :ntok]

@@ -220,8 +220,38 @@ int u2tok_flash_attention_d64(const void* q, const void* k, const void* vt, void
 }
 
 int u2tok_rope_apply(void* x, int64_t n_outer, int32_t S, int32_t n_inner, int32_t H, int32_t d, int64_t ld,
-                     int32_t max_len, u2tok_stream_t stream) {
-  return rope_apply(BFW(x), n_outer, S, n_inner, H, d, ld, max_len, ST(stream));
+                     int32_t max_len, int32_t inverse, u2tok_stream_t stream) {
+  return rope_apply(BFW(x), n_outer, S, n_inner, H, d, ld, max_len, inverse, ST(stream));
+}
+
+// ---- backward-pass building blocks (backward.hip)
+int u2tok_gelu_fwd(const void* z, void* y, int64_t n, u2tok_stream_t stream) { return gelu_fwd(BF(z), BFW(y), n, ST(stream)); }
+int u2tok_gelu_bwd(const void* z, const void* dy, void* dz, int64_t n, u2tok_stream_t stream) {
+  return gelu_bwd(BF(z), BF(dy), BFW(dz), n, ST(stream));
+}
+size_t u2tok_colsum_workspace_bytes(int32_t rows, int32_t C) { return colsum_workspace_bytes(rows, C); }
+int u2tok_colsum_bf16(const void* x, const void* y, float* out, void* out_bf16, int32_t rows, int32_t C, int64_t ldx,
+                      int64_t ldy, void* workspace, int32_t accumulate, u2tok_stream_t stream) {
+  return colsum_bf16(BF(x), BF(y), out, BFW(out_bf16), rows, C, ldx, ldy, reinterpret_cast<float*>(workspace), accumulate,
+                     ST(stream));
+}
+size_t u2tok_layernorm_bwd_workspace_bytes(int32_t rows, int32_t C) { return layernorm_bwd_workspace_bytes(rows, C); }
+int u2tok_layernorm_bwd(const void* x, const void* res, const void* w, const void* dy, void* dv, float* dw, float* db,
+                        int32_t rows, int32_t C, float eps, void* workspace, int32_t accumulate, u2tok_stream_t stream) {
+  return layernorm_bwd(BF(x), BF(res), BF(w), BF(dy), BFW(dv), dw, db, rows, C, eps, reinterpret_cast<float*>(workspace),
+                       accumulate, ST(stream));
+}
+int u2tok_softmax_bwd(const void* P, const float* dP, void* dS, int64_t nrows, int32_t n, int64_t ldp, int64_t lddp,
+                      u2tok_stream_t stream) {
+  return softmax_bwd(BF(P), dP, BFW(dS), nrows, n, ldp, lddp, ST(stream));
+}
+int u2tok_relbias_grad(const void* dS, float* dtable, int32_t nz, int32_t S, int32_t H, int64_t ldp, int32_t max_len,
+                       u2tok_stream_t stream) {
+  return relbias_grad(BF(dS), dtable, nz, S, H, ldp, max_len, ST(stream));
+}
+int u2tok_rowdot_bf16(const void* a, const void* b, float* out, int64_t rows, int32_t C, int64_t lda, int64_t ldb,
+                      u2tok_stream_t stream) {
+  return rowdot_bf16(BF(a), BF(b), out, rows, C, lda, ldb, ST(stream));
 }
 
 }  // extern "C"

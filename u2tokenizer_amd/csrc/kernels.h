@@ -90,7 +90,7 @@ int avgpool3d_tokens(const bf16_t* x, bf16_t* y, int nb, int g1, int g2, int g3,
 // dst[b*dst_bs + e] = src[e] for e < n  (cls token / query token broadcast)
 int fill_rows(const bf16_t* src, bf16_t* dst, int nb, int64_t n, int64_t dst_bs, hipStream_t stream);
 // in-place rotate-half RoPE on rows indexed (outer, s, inner), position = s, heads = d-wide column slices
-int rope_apply(bf16_t* x, int64_t n_outer, int S, int n_inner, int H, int d, int64_t ld, int max_len,
+int rope_apply(bf16_t* x, int64_t n_outer, int S, int n_inner, int H, int d, int64_t ld, int max_len, int inverse,
                hipStream_t stream);
 
 // out[b][s] = (s == 0 || s > nfeat) ? table[ids[b][s]] : feats[b][s-1]   (embedding lookup + splice)
@@ -119,6 +119,25 @@ int gather_rows(const bf16_t* x, const int64_t* idx, bf16_t* out, int B, int n, 
 // out: [B][k + k/2 + k/4][E].  gate_w/gate_b null -> fixed pooling.  ws: >= B*3*ceil(E/256) floats.
 int multiscale_pool(const bf16_t* x, bf16_t* out, int B, int k, int E, const bf16_t* gate_w,
                     const bf16_t* gate_b, float* ws, hipStream_t stream);
+
+// ------------------------------------------------------------------ backward-pass kernels (backward.hip)
+int gelu_fwd(const bf16_t* z, bf16_t* y, int64_t n, hipStream_t stream);                      // y = gelu(z), n % 8 == 0
+int gelu_bwd(const bf16_t* z, const bf16_t* dy, bf16_t* dz, int64_t n, hipStream_t stream);  // dz = dy gelu'(z)
+// out[c] (+)= sum_r x[r][c] (* y[r][c] when y != null), fp32, fixed summation order; ws: colsum_workspace_bytes
+size_t colsum_workspace_bytes(int rows, int C);
+int colsum_bf16(const bf16_t* x, const bf16_t* y, float* out, bf16_t* out_bf16, int rows, int C, int64_t ldx, int64_t ldy,
+                float* ws, int accumulate, hipStream_t stream);
+// LayerNorm backward of y = LN(x (+ res)) w + b: dv = gradient w.r.t. x (and res), dw / db fp32 [C]
+size_t layernorm_bwd_workspace_bytes(int rows, int C);
+int layernorm_bwd(const bf16_t* x, const bf16_t* res, const bf16_t* w, const bf16_t* dy, bf16_t* dv, float* dw, float* db,
+                  int rows, int C, float eps, float* ws, int accumulate, hipStream_t stream);
+// dS = P (dP - rowsum(P dP)); pad columns [n, ldp) zeroed
+int softmax_bwd(const bf16_t* P, const float* dP, bf16_t* dS, int64_t nrows, int n, int64_t ldp, int64_t lddp,
+                hipStream_t stream);
+// dtable[d + max_len - 1][h] += sum over z % H == h and the diagonal j - i = d of dS[z][i][j]   (dS: [nz][S][ldp])
+int relbias_grad(const bf16_t* dS, float* dtable, int nz, int S, int H, int64_t ldp, int max_len, hipStream_t stream);
+int rowdot_bf16(const bf16_t* a, const bf16_t* b, float* out, int64_t rows, int C, int64_t lda, int64_t ldb,
+                hipStream_t stream);
 
 // ------------------------------------------------------------------ attention (attn.hip)
 // Temporal attention of SpatioTemporalAttentionLayer: sequences of length T <= 16 that run ACROSS

@@ -346,8 +346,8 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
     // spatial: sequences of N tokens inside each chunk (svr.py:27-30)
     { const int e = qkv_proj(x, sp, qkv, rows, E, dry, st); if (e != U2_OK) return e; }
     if (c.attn_type == 1) {
-      U2_RUN(rope_apply(qkv, (int64_t)B * T, N, 1, H, d, 3 * E, c.max_seq_len, st));
-      U2_RUN(rope_apply(qkv + E, (int64_t)B * T, N, 1, H, d, 3 * E, c.max_seq_len, st));
+      U2_RUN(rope_apply(qkv, (int64_t)B * T, N, 1, H, d, 3 * E, c.max_seq_len, 0, st));
+      U2_RUN(rope_apply(qkv + E, (int64_t)B * T, N, 1, H, d, 3 * E, c.max_seq_len, 0, st));
     }
     if (c.attn_type == 2) {  // sequence = the B*T (batch, chunk) pairs, batch = token position
       const int e = chunk_axis_attention(ar, qkv, ctx, 1, B * T, N, H, d, scale, nullptr, c.max_seq_len, dry, st);
@@ -363,8 +363,8 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
     bf16_t* y2 = (y == xa) ? xb : xa;
     { const int e = qkv_proj(y, tp, qkv, rows, E, dry, st); if (e != U2_OK) return e; }
     if (c.attn_type == 1) {
-      U2_RUN(rope_apply(qkv, B, T, N, H, d, 3 * E, c.max_seq_len, st));
-      U2_RUN(rope_apply(qkv + E, B, T, N, H, d, 3 * E, c.max_seq_len, st));
+      U2_RUN(rope_apply(qkv, B, T, N, H, d, 3 * E, c.max_seq_len, 0, st));
+      U2_RUN(rope_apply(qkv + E, B, T, N, H, d, 3 * E, c.max_seq_len, 0, st));
     }
     if (c.attn_type == 2 && B == 1) {  // sequence = the N tokens of a chunk, batch = chunk
       AttnCore a{qkv, qkv + E, qkv + 2 * E, 3 * E, 3 * E, 3 * E, (int64_t)N * 3 * E, (int64_t)N * 3 * E,
@@ -551,8 +551,8 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
     } else {
       { const int e = qkv_proj(qcur, sa, qproj, qrows, E, dry, st); if (e != U2_OK) return e; }
       if (c.attn_type == 1) {
-        U2_RUN(rope_apply(qproj, B, Q, 1, H, d, 3 * E, c.max_seq_len, st));
-        U2_RUN(rope_apply(qproj + E, B, Q, 1, H, d, 3 * E, c.max_seq_len, st));
+        U2_RUN(rope_apply(qproj, B, Q, 1, H, d, 3 * E, c.max_seq_len, 0, st));
+        U2_RUN(rope_apply(qproj + E, B, Q, 1, H, d, 3 * E, c.max_seq_len, 0, st));
       }
       AttnCore ac{qproj, qproj + E, qproj + 2 * E, 3 * E, 3 * E, 3 * E, (int64_t)Q * 3 * E, (int64_t)Q * 3 * E,
                   (int64_t)Q * 3 * E, qctx, E, (int64_t)Q * E, B, Q, Q, H, d, scale, sa.rb, c.max_seq_len};

@@ -135,8 +135,9 @@ int fill_rows(const bf16_t* src, bf16_t* dst, int nb, int64_t n, int64_t dst_bs,
 // ---------------------------------------------------------------- rotary position embedding
 // Reference: rope.py:6-13,33-40,77-80 (rotate-half form, base 10000, cos/sin cached in fp32 and cast to
 // the activation dtype).  Rows are indexed (outer, s, inner) with position s; heads are d-wide column slices.
+// sgn = -1 applies the inverse rotation: the backward of y = x cos + rotate_half(x) sin is dx = dy cos - rotate_half(dy) sin.
 __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ x, int64_t n_outer, int S, int n_inner, int H, int d,
-                                                   int64_t ld) {
+                                                   int64_t ld, float sgn) {
   const int half = d >> 1;
   const int64_t total = n_outer * S * n_inner * H * half;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ x, int64
     const int s = (int)((row / n_inner) % S);
     const float inv_freq = 1.0f / powf(10000.0f, (float)(2 * j) / (float)d);
     const float ang = (float)s * inv_freq;
-    const float c = bf16_to_f32(f32_to_bf16(cosf(ang))), sn = bf16_to_f32(f32_to_bf16(sinf(ang)));
+    const float c = bf16_to_f32(f32_to_bf16(cosf(ang))), sn = sgn * bf16_to_f32(f32_to_bf16(sinf(ang)));
     bf16_t* p = x + row * ld + (int64_t)h * d + j;
     const float a = bf16_to_f32(p[0]), b = bf16_to_f32(p[half]);
     p[0] = f32_to_bf16(a * c - b * sn);
@@ -155,13 +156,13 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ x, int64
   }
 }
 
-int rope_apply(bf16_t* x, int64_t n_outer, int S, int n_inner, int H, int d, int64_t ld, int max_len,
+int rope_apply(bf16_t* x, int64_t n_outer, int S, int n_inner, int H, int d, int64_t ld, int max_len, int inverse,
                hipStream_t stream) {
   if (!x || n_outer <= 0 || S <= 0 || n_inner <= 0 || H <= 0 || d <= 0 || (d & 1) || S > max_len) return U2_ERR_ARG;
   const int64_t total = n_outer * S * n_inner * H * (d >> 1);
   const unsigned blocks = (unsigned)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
   ProfScope ps(PROF_ROWOP, 0, stream);
-  hipLaunchKernelGGL(rope_kernel, dim3(blocks), dim3(256), 0, stream, x, n_outer, S, n_inner, H, d, ld);
+  hipLaunchKernelGGL(rope_kernel, dim3(blocks), dim3(256), 0, stream, x, n_outer, S, n_inner, H, d, ld, inverse ? -1.0f : 1.0f);
   return launch_status();
 }
 

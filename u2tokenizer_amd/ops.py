@@ -379,11 +379,118 @@ def flash_attention_d64(qkv: torch.Tensor, heads: int, scale: float, extra_last:
 
 
 @_guarded
-def rope_apply(x: torch.Tensor, n_outer, S, n_inner, H, d, max_len=512):
+def rope_apply(x: torch.Tensor, n_outer, S, n_inner, H, d, max_len=512, inverse=False):
     h = _lib.load_library()
-    _lib.check(h.u2tok_rope_apply(_ptr(x), n_outer, S, n_inner, H, d, x.stride(-2), max_len, _stream()),
+    _lib.check(h.u2tok_rope_apply(_ptr(x), n_outer, S, n_inner, H, d, x.stride(-2), max_len, int(inverse), _stream()),
                "u2tok_rope_apply")
     return x
+
+
+# ---------------------------------------------------------------------------------- strided GEMM / backward blocks
+@_guarded
+def gemm_strided(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, M, N, K, lda, ldb, ldc, nz=1, nbh=1,
+                 sAb=0, sAh=0, sBb=0, sBh=0, sCb=0, sCh=0, alpha=1.0, out_f32=False, bias=None, bias_m=False,
+                 a_off=0, b_off=0, c_off=0) -> torch.Tensor:
+    """C[z] = alpha * A[z] B[z]^T with explicit element strides (z = zb * nbh + zh): the descriptor of u2tok_gemm_bf16.
+    a / b / out are the STORAGES (any shape); *_off are element offsets into them."""
+    h = _lib.load_library()
+    _need(a, torch.bfloat16, "A"), _need(b, torch.bfloat16, "B")
+    flags = GEMM_OUT_F32 if out_f32 else 0
+    if bias is not None:
+        flags |= GEMM_BIAS_M if bias_m else GEMM_BIAS_N
+    st = h.u2tok_gemm_bf16(a.data_ptr() + 2 * a_off, b.data_ptr() + 2 * b_off,
+                           out.data_ptr() + (4 if out_f32 else 2) * c_off, _ptr(bias), None, M, N, K, lda, ldb, ldc, 0,
+                           nz, nbh, sAb, sAh, sBb, sBh, sCb, sCh, 0, 0, float(alpha), flags, _stream())
+    _lib.check(st, "u2tok_gemm_bf16")
+    return out
+
+
+@_guarded
+def transpose_ex(x: torch.Tensor, nz: int, R: int, Cc: int, ld_in: int, in_zs: int, ld_out: int = None,
+                 x_off: int = 0) -> torch.Tensor:
+    """out[z][c][r] = x[z][r][c] for a strided source (row stride ld_in, batch stride in_zs, elements); out is dense
+    (nz, Cc, ld_out) with ld_out = R rounded up to 8, padding zeroed."""
+    h = _lib.load_library()
+    ld_out = ld_out or (R + 7) // 8 * 8
+    y = torch.empty((nz, Cc, ld_out), dtype=torch.bfloat16, device=x.device)
+    _lib.check(h.u2tok_transpose_bf16(x.data_ptr() + 2 * x_off, _ptr(y), nz, R, Cc, ld_in, ld_out, in_zs, Cc * ld_out, 0,
+                                      _stream()), "u2tok_transpose_bf16")
+    return y
+
+
+@_guarded
+def gelu_fwd(z: torch.Tensor) -> torch.Tensor:
+    h = _lib.load_library()
+    z = _need(z, torch.bfloat16, "z").contiguous()
+    y = torch.empty_like(z)
+    _lib.check(h.u2tok_gelu_fwd(_ptr(z), _ptr(y), z.numel(), _stream()), "u2tok_gelu_fwd")
+    return y
+
+
+@_guarded
+def gelu_bwd(z: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    h = _lib.load_library()
+    z, dy = _need(z, torch.bfloat16, "z").contiguous(), _need(dy, torch.bfloat16, "dy").contiguous()
+    dz = torch.empty_like(z)
+    _lib.check(h.u2tok_gelu_bwd(_ptr(z), _ptr(dy), _ptr(dz), z.numel(), _stream()), "u2tok_gelu_bwd")
+    return dz
+
+
+@_guarded
+def colsum(x: torch.Tensor, y: Optional[torch.Tensor] = None, out_dtype=torch.bfloat16) -> torch.Tensor:
+    """sum over rows of x (* y): x (rows, C) bf16 -> (C,) in out_dtype (bf16 or fp32); fp32 accumulation, fixed order."""
+    h = _lib.load_library()
+    x = _need(x, torch.bfloat16, "x").contiguous()
+    rows, Cc = x.shape
+    if y is not None:
+        y = _need(y, torch.bfloat16, "y").contiguous()
+    ws = torch.empty(h.u2tok_colsum_workspace_bytes(rows, Cc), dtype=torch.uint8, device=x.device)
+    out = torch.empty(Cc, dtype=out_dtype, device=x.device)
+    f32 = out_dtype == torch.float32
+    _lib.check(h.u2tok_colsum_bf16(_ptr(x), _ptr(y), _ptr(out) if f32 else None, None if f32 else _ptr(out), rows, Cc, Cc,
+                                   Cc, _ptr(ws), 0, _stream()), "u2tok_colsum_bf16")
+    return out
+
+
+@_guarded
+def layernorm_bwd(x: torch.Tensor, residual: Optional[torch.Tensor], w: torch.Tensor, dy: torch.Tensor, eps=1e-5):
+    """-> (dv bf16 like x, dw fp32 (C,), db fp32 (C,)) for y = LN(x (+ residual)) * w + b."""
+    h = _lib.load_library()
+    x, dy = _need(x, torch.bfloat16, "x").contiguous(), _need(dy, torch.bfloat16, "dy").contiguous()
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    if residual is not None:
+        residual = residual.contiguous()
+    dv = torch.empty_like(x)
+    dw = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    db = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    ws = torch.empty(h.u2tok_layernorm_bwd_workspace_bytes(rows, Cc), dtype=torch.uint8, device=x.device)
+    _lib.check(h.u2tok_layernorm_bwd(_ptr(x), _ptr(residual), _ptr(w), _ptr(dy), _ptr(dv), _ptr(dw), _ptr(db), rows, Cc,
+                                     float(eps), _ptr(ws), 0, _stream()), "u2tok_layernorm_bwd")
+    return dv, dw, db
+
+
+@_guarded
+def softmax_bwd(p: torch.Tensor, dp: torch.Tensor, n: int) -> torch.Tensor:
+    """p: (..., ldp) bf16 probabilities (pad columns >= n), dp: (..., lddp) fp32 -> dS (..., ldp) bf16."""
+    h = _lib.load_library()
+    p, dp = _need(p, torch.bfloat16, "P").contiguous(), _need(dp, torch.float32, "dP").contiguous()
+    ldp, lddp = p.shape[-1], dp.shape[-1]
+    ds = torch.empty_like(p)
+    _lib.check(h.u2tok_softmax_bwd(_ptr(p), _ptr(dp), _ptr(ds), p.numel() // ldp, n, ldp, lddp, _stream()),
+               "u2tok_softmax_bwd")
+    return ds
+
+
+@_guarded
+def relbias_grad(ds: torch.Tensor, dtable: torch.Tensor, S: int, H: int, max_len: int) -> None:
+    """ds: (nz, S, ldp) bf16; dtable: (2 * max_len - 1, H) fp32, accumulated into."""
+    h = _lib.load_library()
+    ds = _need(ds, torch.bfloat16, "dS").contiguous()
+    _need(dtable, torch.float32, "dtable")
+    nz = ds.numel() // (S * ds.shape[-1])
+    _lib.check(h.u2tok_relbias_grad(_ptr(ds), _ptr(dtable), nz, S, H, ds.shape[-1], max_len, _stream()),
+               "u2tok_relbias_grad")
 
 
 # ---------------------------------------------------------------------------------- pipelines

@@ -42,8 +42,11 @@ class SpatialPoolingProjector(nn.Module):
         self._ws = ops._Workspace()
 
     def forward(self, x):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise RuntimeError("the HIP projector is forward-only in this round: call under torch.no_grad()")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from . import autograd as AG  # training: the same kernels behind torch.autograd.Function
+            ops._need(x, torch.bfloat16, "image_features")
+            with ops.on_device(x):
+                return AG.spp_forward(self, x)
         h = _lib.load_library()
         x = ops._need(x, torch.bfloat16, "image_features").contiguous()
         nchunk, n, dim = x.shape

@@ -286,8 +286,15 @@ class u2Tokenizer(nn.Module):
                 raise RuntimeError(f"hard top-k sorts T*N={T * N} scores in one workgroup's LDS: limit 8192")
 
     def forward(self, v_token, t_token):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise RuntimeError("the HIP u2Tokenizer is forward-only in this round: call under torch.no_grad()")
+        if torch.is_grad_enabled() and (v_token.requires_grad or t_token.requires_grad
+                                        or any(p.requires_grad for p in self.parameters())):
+            # training: the same kernels sequenced op by op behind torch.autograd.Function (autograd.py)
+            from . import autograd as AG
+            ops._need(v_token, torch.bfloat16, "v_token"), ops._need(t_token, torch.bfloat16, "t_token")
+            (B, T, N, E) = v_token.size()
+            self._check_envelope(B, T, N, E, t_token.shape[1])
+            with ops.on_device(v_token):
+                return AG.tokenizer_forward(self, v_token, t_token)
         h = _lib.load_library()
         if self.query_tokens.is_cuda:
             self.pack_weights()

@@ -121,8 +121,13 @@ class ViT(nn.Module):
     def forward_features(self, x: torch.Tensor, keep_cls: bool) -> torch.Tensor:
         """x: (nchunk, 1, D, H, W) fp16/bf16/fp32 on the GPU -> (nchunk, ntok[+1], hidden) bf16."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise RuntimeError("the HIP ViT tower is forward-only in this round: wrap the call in torch.no_grad() "
-                               "or freeze the tower (model_args.freeze_vision_tower, train_stage1.py:56)")
+            # training (train_stage1.py:42 runs with freeze_vision_tower False): autograd path, same kernels (autograd.py)
+            from . import autograd as AG
+            if x.dim() != 5 or x.shape[1] != 1 or list(x.shape[2:]) != self.img_size or not x.is_cuda:
+                raise RuntimeError(f"expected GPU images of shape (N,1,{self.img_size}), got {tuple(x.shape)} on {x.device}")
+            self._weights()  # (raises for the variant without a cls token)
+            with ops.on_device(x):
+                return AG.vit_forward(self, x, keep_cls)
         h = _lib.load_library()
         if x.dim() != 5 or x.shape[1] != 1 or list(x.shape[2:]) != self.img_size:
             raise RuntimeError(f"expected images of shape (N,1,{self.img_size}), got {tuple(x.shape)}")
