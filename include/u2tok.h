@@ -189,6 +189,20 @@ int u2tok_preprocess_volume(const float* vol, void* out, int32_t* info, int32_t 
                             int32_t depth_pad, float lower_pct, float upper_pct, int32_t out_dtype, void* workspace,
                             size_t workspace_bytes, u2tok_stream_t stream);
 
+/* Same with the training-time branch of u2Transform (u2Transform.py:32-44): between CropForeground and the resize the
+ * volume is rotated by rot90_k quarter turns in the (H, W) plane (RandRotate90(spatial_axes=(1,2)), torch.rot90
+ * convention), flipped along D / H / W (RandFlip x3), multiplied by (1 + scale_factor) (RandScaleIntensity) and shifted by
+ * shift_offset (RandShiftIntensity).  The random draws are the CALLER's (host struct): the library is deterministic. */
+typedef struct {
+  int32_t rot90_k;       /* 0..3 */
+  int32_t flip[3];       /* bool per spatial axis (d, h, w) */
+  float scale_factor;    /* RandScaleIntensity factor in [-0.1, 0.1] in the reference; 0 = off */
+  float shift_offset;    /* RandShiftIntensity offset in [-0.1, 0.1] in the reference; 0 = off */
+} u2tok_augment;
+int u2tok_preprocess_volume_aug(const float* vol, void* out, int32_t* info, int32_t D, int32_t H, int32_t W, int32_t target,
+                                int32_t depth_pad, float lower_pct, float upper_pct, int32_t out_dtype,
+                                const u2tok_augment* aug, void* workspace, size_t workspace_bytes, u2tok_stream_t stream);
+
 /* ---- building blocks (exported for the parity tests; same kernels the pipelines launch) -------- */
 
 /* C[z] = epi(alpha * A[z] B[z]^T): A (M,K) lda, B (N,K) ldb, C (M,N) ldc; z = zb*nbh + zh with element strides.

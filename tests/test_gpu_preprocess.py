@@ -56,6 +56,29 @@ def test_adaptive_resize_matches_oracle_fp32(shape, T, pad):
     assert (g[d:] == 0).all() and (g[:, h:] == 0).all() and (g[:, :, w:] == 0).all()
 
 
+@pytest.mark.parametrize("aug", [dict(rot90_k=1, flip=[False, False, False], scale_factor=0.0, shift_offset=0.0),
+                                 dict(rot90_k=3, flip=[True, False, True], scale_factor=0.07, shift_offset=-0.04),
+                                 dict(rot90_k=2, flip=[False, True, False], scale_factor=-0.1, shift_offset=0.1),
+                                 dict(rot90_k=0, flip=[True, True, True], scale_factor=0.03, shift_offset=0.0)])
+def test_training_augmentations_match_oracle(aug):
+    """data_type="training" (u2Transform.py:32-44) with explicit draws: rotation / flips are pure index maps (they also
+    swap the H and W extents the resize geometry is computed from), the intensity jitter is one multiply-add."""
+    from u2tokenizer_amd.preprocess import u2Transform
+    vol = _ct_like(90, 70, 40, seed=17)
+    ref, ri = P.adaptive_resize(vol, 64, 64, aug=aug)
+    tr = u2Transform(data_type="training", device=D, out_dtype=torch.float32, seed=0)
+    got = tr.from_array(vol, 64, 64, aug=aug).cpu()
+    info = tr.last_info.cpu()
+    assert info[0].item() == 0 and info[7:10].tolist() == ri["out_size"]
+    assert (got - ref).abs().max().item() <= 2e-5
+    # and the sampler: parameters inside MONAI's documented ranges, reproducible from the seed
+    a, b = u2Transform(data_type="training", device=D, seed=3), u2Transform(data_type="training", device=D, seed=3)
+    draws = [a.sample_augmentation() for _ in range(200)]
+    assert draws == [b.sample_augmentation() for _ in range(200)]
+    assert all(d["rot90_k"] in (0, 1, 2, 3) and abs(d["scale_factor"]) <= 0.1 and abs(d["shift_offset"]) <= 0.1 for d in draws)
+    assert 60 < sum(d["rot90_k"] > 0 for d in draws) < 140 and 0 < sum(any(d["flip"]) for d in draws) < 110
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_adaptive_resize_half_outputs(dtype):
     vol = _ct_like(120, 100, 50, seed=5)

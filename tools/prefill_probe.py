@@ -1,0 +1,39 @@
+#!/usr/bin/env python
+"""What comes AFTER the path: the decoder prefill over the spliced embeddings.  Times a Qwen3-8B-
+shaped stock HF decoder (random init, bf16) on inputs_embeds (1, 1024, 4096) -- the consumer of the 256 aligned tokens --
+next to the tokenizer path itself, to size the next bottleneck.  Measurement only; nothing here is on the product path.
+
+    python tools/prefill_probe.py [layers]
+"""
+import sys
+import time
+
+import torch
+from transformers import Qwen3Config, Qwen3ForCausalLM
+
+layers = int(sys.argv[1]) if len(sys.argv) > 1 else 36
+cfg = Qwen3Config(vocab_size=151936, hidden_size=4096, intermediate_size=12288, num_hidden_layers=layers,
+                  num_attention_heads=32, num_key_value_heads=8, head_dim=128, max_position_embeddings=4096,
+                  tie_word_embeddings=False)
+torch.set_grad_enabled(False)
+dev = torch.device("cuda", 0)
+with torch.device("meta"):
+    m = Qwen3ForCausalLM(cfg)
+m = m.to(torch.bfloat16).to_empty(device=dev)
+for p in m.parameters():
+    p.normal_(0, 0.02)
+m.model.rotary_emb.__init__(config=cfg, device=dev)  # buffers of a meta-built module are uninitialised
+x = (torch.randn(1, 1024, 4096, device=dev) * 0.05).to(torch.bfloat16)
+nparam = sum(p.numel() for p in m.parameters())
+for _ in range(2):
+    m(inputs_embeds=x, use_cache=True)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = 5
+for _ in range(n):
+    out = m(inputs_embeds=x, use_cache=True)
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / n * 1e3
+flop = 2.0 * (nparam - cfg.vocab_size * cfg.hidden_size) * 1024 + 4.0 * layers * 1024 * 1024 * 4096
+print(f"Qwen3-8B-shaped prefill, {layers} layers, S=1024, bf16, stock HF on PyTorch-ROCm: {ms:.2f} ms "
+      f"({flop / ms / 1e9:.0f} TFLOP/s of {flop / 1e12:.1f} TFLOP); logits {tuple(out.logits.shape)}; {nparam / 1e9:.2f} B params")

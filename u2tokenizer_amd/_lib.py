@@ -52,6 +52,10 @@ class TokConfig(C.Structure):
                 ("ln_eps", C.c_float)]
 
 
+class Augment(C.Structure):
+    _fields_ = [("rot90_k", C.c_int32), ("flip", C.c_int32 * 3), ("scale_factor", C.c_float), ("shift_offset", C.c_float)]
+
+
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
 # name -> (restype, argtypes); must list every symbol include/u2tok.h declares (tests/test_abi.py checks it)
@@ -76,6 +80,8 @@ SIGNATURES = {
     "u2tok_tokenizer_forward": (_i32, [C.POINTER(TokConfig), C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "u2tok_preprocess_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "u2tok_preprocess_volume": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp, _sz, _vp]),
+    "u2tok_preprocess_volume_aug": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32,
+                                           C.POINTER(Augment), _vp, _sz, _vp]),
     "u2tok_embed_splice": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _vp]),
     "u2tok_gemm_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _i32,
                                _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _i32, _vp]),

@@ -131,7 +131,19 @@ size_t u2tok_preprocess_workspace_bytes(int32_t D, int32_t H, int32_t W) { retur
 int u2tok_preprocess_volume(const float* vol, void* out, int32_t* info, int32_t D, int32_t H, int32_t W, int32_t target,
                             int32_t depth_pad, float lower_pct, float upper_pct, int32_t out_dtype, void* workspace,
                             size_t workspace_bytes, u2tok_stream_t stream) {
-  return preprocess_volume(vol, out, info, D, H, W, target, depth_pad, lower_pct, upper_pct, out_dtype, workspace,
+  return preprocess_volume(vol, out, info, D, H, W, target, depth_pad, lower_pct, upper_pct, out_dtype, nullptr, workspace,
+                           workspace_bytes, ST(stream));
+}
+int u2tok_preprocess_volume_aug(const float* vol, void* out, int32_t* info, int32_t D, int32_t H, int32_t W, int32_t target,
+                                int32_t depth_pad, float lower_pct, float upper_pct, int32_t out_dtype,
+                                const u2tok_augment* aug, void* workspace, size_t workspace_bytes, u2tok_stream_t stream) {
+  if (!aug) return U2_ERR_ARG;
+  PreAugment a;
+  a.rot_k = aug->rot90_k;
+  for (int i = 0; i < 3; ++i) a.flip[i] = aug->flip[i];
+  a.mul = 1.0f + aug->scale_factor;
+  a.add = aug->shift_offset;
+  return preprocess_volume(vol, out, info, D, H, W, target, depth_pad, lower_pct, upper_pct, out_dtype, &a, workspace,
                            workspace_bytes, ST(stream));
 }
 

@@ -102,9 +102,17 @@ int embed_splice(const bf16_t* table, const int64_t* ids, const bf16_t* feats, b
 // u2Transform.adaptive_resize on the GPU: vol [D][H][W] fp32 (the tensor of u2Transform.py:68-69 without its channel
 // axis) -> out [depth_pad][target][target] (== (depth_pad/32, 32, target, target)) in out_dtype (VOL_*).
 // info (optional, device, 12 x int32): status, crop box lo[3], hi[3], resized size[3], then a_min, a_max as float.
+// aug (may be null): the training-time augmentations of u2Transform.py:37-42 with their random draws made by the caller
+struct PreAugment {
+  int rot_k = 0;              // RandRotate90(spatial_axes=(1, 2)): quarter turns of the (h, w) plane, torch.rot90 convention
+  int flip[3] = {0, 0, 0};    // RandFlip(spatial_axis = 0 / 1 / 2) on the rotated volume
+  float mul = 1.f;            // RandScaleIntensity: v * (1 + factor)
+  float add = 0.f;            // RandShiftIntensity: v + offset
+};
 size_t preprocess_workspace_bytes(int D, int H, int W);
 int preprocess_volume(const float* vol, void* out, int32_t* info, int D, int H, int W, int target, int depth_pad,
-                      float lower_pct, float upper_pct, int out_dtype, void* ws, size_t ws_bytes, hipStream_t stream);
+                      float lower_pct, float upper_pct, int out_dtype, const PreAugment* aug, void* ws, size_t ws_bytes,
+                      hipStream_t stream);
 
 // ------------------------------------------------------------------ selection / pooling (select.hip)
 // scores[b][i] = fp32( sum_e x[b][i][e] * w[e] + bias ), accumulated in fp64.

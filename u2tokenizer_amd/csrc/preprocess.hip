@@ -38,6 +38,11 @@ struct PreParams {  // device-side parameter block
   int tail[3];
   float taps[3][2 * PP_MAX_TAIL + 1];
   int status;                      // 0 ok, 1 empty foreground, 2 filter too wide
+  // --- training-time augmentation (u2Transform.py:37-42), applied to the cropped volume before the resize
+  int crop_sz[3];                  // foreground box size (d, h, w); in_sz = the same after the rotation
+  int rot_k;                       // RandRotate90 over (h, w): 0..3 quarter turns (torch.rot90)
+  int flip[3];                     // RandFlip along d / h / w of the rotated volume
+  float aug_mul, aug_add;          // RandScaleIntensity (1 + factor), RandShiftIntensity offset
 };
 
 __device__ __forceinline__ unsigned sortable(float f) {
@@ -109,8 +114,13 @@ __global__ __launch_bounds__(256) void pre_select_kernel(PreParams* pp, unsigned
   for (int i = threadIdx.x; i < 4 * 2048; i += 256) hist[i] = 0;  // ready for the next pass
 }
 
-__global__ void pre_init_kernel(PreParams* pp, unsigned* hist, int64_t n, double lower, double upper, int D, int H, int W) {
+__global__ void pre_init_kernel(PreParams* pp, unsigned* hist, int64_t n, double lower, double upper, int D, int H, int W,
+                                PreAugment aug) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
+    pp->rot_k = aug.rot_k & 3;
+    for (int a = 0; a < 3; ++a) pp->flip[a] = aug.flip[a] != 0;
+    pp->aug_mul = aug.mul;
+    pp->aug_add = aug.add;
     // np.percentile(method="linear"): virtual index q/100 * (n - 1), neighbours floor / floor + 1 (clamped)
     const double qs[2] = {lower, upper};
     for (int i = 0; i < 2; ++i) {
@@ -184,8 +194,9 @@ __global__ __launch_bounds__(256) void pre_bbox_kernel(const float* __restrict__
 __global__ void pre_geometry_kernel(PreParams* pp, int target, int depth_pad) {
   if (threadIdx.x || blockIdx.x) return;
   PreParams& p = *pp;
-  for (int a = 0; a < 3; ++a) p.in_sz[a] = p.box_hi[a] - p.box_lo[a];
+  for (int a = 0; a < 3; ++a) p.crop_sz[a] = p.in_sz[a] = p.box_hi[a] - p.box_lo[a];
   if (p.in_sz[0] <= 0 || p.in_sz[1] <= 0 || p.in_sz[2] <= 0) { p.status = 1; return; }
+  if (p.rot_k & 1) { p.in_sz[1] = p.crop_sz[2]; p.in_sz[2] = p.crop_sz[1]; }  // a quarter turn swaps h and w
   // ratio = min(target / H, target / W); scaling_shape = [int(H * ratio), int(W * ratio)]   (u2Transform.py:75-76)
   const double rh = (double)target / (double)p.in_sz[1], rw = (double)target / (double)p.in_sz[2];
   const double ratio = rh < rw ? rh : rw;
@@ -203,11 +214,11 @@ __global__ void pre_geometry_kernel(PreParams* pp, int target, int depth_pad) {
       const float f = (float)p.in_sz[a] / (float)p.out_sz[a];
       sigma = fmaxf(0.f, (f - 1.f) / 2.f);
     }
-    // gaussian_1d(sigma, truncated=4.0, approx="erf"), normalised
+    // gaussian_1d(sigma, truncated=4.0, approx="erf", normalize=False): MONAI's GaussianFilter.forward calls it with the
+    // default normalize=False, so the taps are NOT divided by their sum (they miss the truncated tail mass, ~6e-5)
     const int tail = (int)(fmaxf(sigma * 4.0f, 0.5f) + 0.5f);
     if (tail > PP_MAX_TAIL) { p.status = 2; return; }
     p.tail[a] = aa ? tail : 0;
-    float sum = 0.f;
     if (!aa) {
       p.taps[a][0] = 1.f;
       continue;
@@ -218,9 +229,7 @@ __global__ void pre_geometry_kernel(PreParams* pp, int target, int depth_pad) {
       float v = 0.5f * (erff(t * (xx + 0.5f)) - erff(t * (xx - 0.5f)));
       v = v < 0.f ? 0.f : v;
       p.taps[a][i] = v;
-      sum += v;
     }
-    for (int i = 0; i <= 2 * tail; ++i) p.taps[a][i] /= sum;
   }
 }
 
@@ -232,8 +241,23 @@ __global__ __launch_bounds__(256) void pre_scale_crop_kernel(const float* __rest
   const int64_t n = (int64_t)D * H * W;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int w = (int)(i % W), h = (int)((i / W) % H), d = (int)(i / ((int64_t)W * H));
-    if (d >= p.box_lo[0] && d < p.box_hi[0] && h >= p.box_lo[1] && h < p.box_hi[1] && w >= p.box_lo[2] && w < p.box_hi[2])
-      y[((int64_t)(d - p.box_lo[0]) * p.in_sz[1] + (h - p.box_lo[1])) * p.in_sz[2] + (w - p.box_lo[2])] = pre_scale(x[i], *pp);
+    if (d >= p.box_lo[0] && d < p.box_hi[0] && h >= p.box_lo[1] && h < p.box_hi[1] && w >= p.box_lo[2] && w < p.box_hi[2]) {
+      // cropped coordinates -> torch.rot90(k, (h, w)) -> flips: r = rot90(x): k = 1: r[i][j] = x[j][W-1-i], k = 2:
+      // r[i][j] = x[H-1-i][W-1-j], k = 3: r[i][j] = x[H-1-j][i]  (H, W = cropped sizes)
+      const int Hc = p.crop_sz[1], Wc = p.crop_sz[2];
+      const int is = h - p.box_lo[1], js = w - p.box_lo[2];
+      int dd = d - p.box_lo[0], ii, jj;
+      switch (p.rot_k) {
+        case 1: ii = Wc - 1 - js; jj = is; break;
+        case 2: ii = Hc - 1 - is; jj = Wc - 1 - js; break;
+        case 3: ii = js; jj = Hc - 1 - is; break;
+        default: ii = is; jj = js; break;
+      }
+      if (p.flip[0]) dd = p.in_sz[0] - 1 - dd;
+      if (p.flip[1]) ii = p.in_sz[1] - 1 - ii;
+      if (p.flip[2]) jj = p.in_sz[2] - 1 - jj;
+      y[((int64_t)dd * p.in_sz[1] + ii) * p.in_sz[2] + jj] = pre_scale(x[i], *pp) * p.aug_mul + p.aug_add;
+    }
   }
 }
 
@@ -313,7 +337,13 @@ size_t preprocess_workspace_bytes(int D, int H, int W) {
 }
 
 int preprocess_volume(const float* vol, void* out, int32_t* info, int D, int H, int W, int target, int depth_pad,
-                      float lower_pct, float upper_pct, int out_dtype, void* ws, size_t ws_bytes, hipStream_t st) {
+                      float lower_pct, float upper_pct, int out_dtype, const PreAugment* aug_in, void* ws, size_t ws_bytes,
+                      hipStream_t st) {
+  PreAugment aug;  // identity unless the caller asks for the training-time augmentations
+  if (aug_in) {
+    aug = *aug_in;
+    if (aug.rot_k < 0 || aug.rot_k > 3) return U2_ERR_ARG;
+  }
   if (!vol || !out || !ws || D <= 0 || H <= 0 || W <= 0 || target <= 0 || depth_pad <= 0) return U2_ERR_ARG;
   if (!(lower_pct >= 0.f && lower_pct < upper_pct && upper_pct <= 100.f)) return U2_ERR_ARG;
   if (out_dtype != VOL_F16 && out_dtype != VOL_BF16 && out_dtype != VOL_F32) return U2_ERR_ARG;
@@ -327,7 +357,7 @@ int preprocess_volume(const float* vol, void* out, int32_t* info, int D, int H, 
   PreParams* pp = reinterpret_cast<PreParams*>(base + 2 * nb + 4 * 2048 * 4);
   const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(n, 256), 256 * 16);
   ProfScope ps(PROF_MOVE, 0, st, (double)n * 4.0 * 9.0 + (double)depth_pad * target * target * 2.0);
-  hipLaunchKernelGGL(pre_init_kernel, dim3(32), dim3(256), 0, st, pp, hist, n, (double)lower_pct, (double)upper_pct, D, H, W);
+  hipLaunchKernelGGL(pre_init_kernel, dim3(32), dim3(256), 0, st, pp, hist, n, (double)lower_pct, (double)upper_pct, D, H, W, aug);
   hipLaunchKernelGGL(pre_hist_kernel<0>, dim3(blocks), dim3(256), 0, st, vol, n, pp, hist);
   hipLaunchKernelGGL(pre_select_kernel<0>, dim3(1), dim3(256), 0, st, pp, hist);
   hipLaunchKernelGGL(pre_hist_kernel<1>, dim3(blocks), dim3(256), 0, st, vol, n, pp, hist);

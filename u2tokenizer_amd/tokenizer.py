@@ -202,6 +202,17 @@ def _att_ptrs(m):
             getattr(m, "relative_bias", None)]
 
 
+def _unshare_packed(module, state_dict, prefix, local_metadata):
+    """state_dict hook: parameters that pack_weights() turned into views of one q | k | v buffer are handed out as
+    unshared copies, so that safetensors / save_pretrained (which refuse tensors sharing storage) and any consumer that
+    expects independent tensors see what the reference's checkpoint holds.  Unpacked (CPU) modules are untouched."""
+    for k, v in list(state_dict.items()):
+        if k.startswith(prefix) and torch.is_tensor(v) and \
+                v.untyped_storage().nbytes() > v.numel() * v.element_size() + v.storage_offset() * v.element_size():
+            state_dict[k] = v.detach().clone() if not v.requires_grad else v.clone().detach()
+    return state_dict
+
+
 class u2Tokenizer(nn.Module):
     """Same constructor and forward as the reference (u2Tokenizer.py:6-47)."""
 
@@ -223,6 +234,7 @@ class u2Tokenizer(nn.Module):
         self.enable_diffts, self.enable_dmtp = bool(enable_diffts), bool(enable_dmtp)
         self._ws = ops._Workspace()
         self._packed_key = None
+        self._register_state_dict_hook(_unshare_packed)
         self.last_topk_indices = None  # (B, top_k) int64 -- set by forward() when hard top-k selection is on
         self.capture_svr_tokens = False  # True: forward() also keeps the refined tokens in last_svr_tokens
         self.last_svr_tokens = None
