@@ -312,7 +312,16 @@ def main():
     def rmax(x):
         return replicas.max_over_ranks(dist, x, device)
 
+    # Two volumes in flight already overlap one volume's small launches with the other's large GEMMs; the tokenizer's own
+    # side stream (TTA k|v projections, there for the latency of a volume running alone) then only adds event traffic:
+    # +2.2 % with it off (tools/ab_bench.py, interleaved on one box, profiles/r02_ab_options.log).  The one-stream run
+    # below keeps it on.  An explicit --option tta_overlap=... wins.
+    auto_side = streams is not None and not args.stub_cpu and not any(o.startswith("tta_overlap=") for o in args.option)
+    if auto_side:
+        ops.set_option("tta_overlap", 0)
     times, out = timed_repeats(step, args.steps, args.warmup, args.repeats, sync, rmax)
+    if auto_side:
+        ops.set_option("tta_overlap", 1)
     if not args.stub_cpu:
         assert out.shape == (B, S, E) and bool(torch.isfinite(out.float()).all())
     elapsed = statistics.median(times)
@@ -342,6 +351,7 @@ def main():
         "path_frac_of_bf16_mfma_peak": round(value * fl["total"] / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
         "config": {"workload": WORKLOAD, "hidden_size": E, "batch_per_gpu": B, "streams_per_gpu": args.streams,
                    "flop_per_volume": fl["total"], "parallelism": f"replicas x{world}",
+                   "tta_side_stream": "off in the multi-stream run, on in the one-stream run" if streams is not None else "on",
                    **({"options": args.option} if args.option else {})},
     }
     if args.stub_cpu:

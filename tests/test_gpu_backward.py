@@ -200,7 +200,11 @@ def test_diffts_fn():
     yd = AG.DiffTSFn.apply(xd, wd, bd, 0.7)
     assert rel(yd.float(), y) < 3e-2, rel(yd.float(), y)
     (yd.float() * g.to(D).float()).sum().backward()
-    check_grads({"x": xd.grad, "w": wd.grad, "b": bd.grad}, {"x": xr.grad, "w": wr.grad, "b": br.grad}, what="DiffTS")
+    check_grads({"x": xd.grad, "w": wd.grad}, {"x": xr.grad, "w": wr.grad}, what="DiffTS")
+    # the softmax runs over TOKENS, so a per-head constant cancels: the exact gradient of the score bias is zero and any
+    # bf16 run produces rounding noise there (the fp32 reference itself: ~1e-9) -- it only has to be small
+    assert br.grad.abs().max() < 1e-5 * wr.grad.abs().max()
+    assert bd.grad.float().abs().max().item() < 0.05 * wr.grad.abs().max().item()
 
 
 def test_multiscale_pool_fn():
@@ -347,6 +351,10 @@ def test_training_step_through_the_hf_model():
     loss32.backward()
     ref = {k: v.grad for k, v in sd.items() if v.grad is not None
            and any(s in k for s in ("vision_tower", "mm_projector", "u2tokenizer", "embed_tokens"))}
+    # the model's embed_tokens is nn.Embedding(padding_idx=pad_token_id): its backward leaves the pad row without a
+    # gradient (the reference looks tokens up through that module, u2_arch.py:109,113); the oracle's F.embedding has no
+    # padding_idx -- same forward, so drop the pad row from the reference gradient
+    ref["model.embed_tokens.weight"][cfg.pad_token_id] = 0
     mg = m.to(bf).to(D)
     for p in mg.parameters():
         p.requires_grad_(True)
