@@ -30,15 +30,12 @@ FR = 228                                                     # fragment ring: 4 
 T0, T1, T2 = 244, 245, 246
 PS = [247, 248, 249, 250]
 MX, TM, TN, NEG, TA = 251, 252, 253, 254, 255
-MR = {0: 108, 1: 110}               # running max of block 0 / 1 (exp2 units): even registers, read as the low half of a
-                                    # 64-bit pair by v_pk_fma_f32 (op_sel_hi 0); 109 / 111 are never read
-VLO, VHI = 108, 255
+VLO, VHI = 112, 255
 
 # ---- fixed SGPRs -------------------------------------------------------------------------------------------------
 S_T, S_ISSUE, S_SLOT_T, S_SLOT_N, S_AK, S_AV, S_NV, S_A, S_B, S_KOFF, S_VOFF, S_DST = range(36, 48)
 S_NOW, S_PREV, S_ACC = 48, 50, 52   # 64-bit pairs: now, prev, 5 accumulators (52..61)
-S_SC2 = 34                          # s[34:35]: softmax scale as a 64-bit pair for v_pk_fma_f32 (low half used twice)
-SLO, SHI = 34, 61 if TIMED else 47
+SLO, SHI = 36, 61 if TIMED else 47
 
 out = []
 
@@ -68,7 +65,7 @@ def ab(k):
 
 
 def m_run(b):
-    return v(MR[b])
+    return f"%[mr{b}]"
 
 
 def l_run(b):
@@ -115,15 +112,14 @@ def softmax_pair(y, i):
     """the 7 VALU of score pair i (scores 2i, 2i+1 of block y's half) -> packed P word i, partial sum"""
     s0, s1 = SC[y] + 2 * i, SC[y] + 2 * i + 1
     pk = PFR[y] + i  # pf[i >> 2].u[i & 3] = consecutive registers
-    # (t0, t1) = (s0, s1) * scale - m in ONE packed fp32 FMA (4.2 issue cycles against 2 x 3.7: tools/ubench/valu_rate):
-    # the scale pair and the running max are read through their low halves for both lanes
-    e(f"v_pk_fma_f32 {vr(T0, 2)}, {vr(s0, 2)}, s[{S_SC2}:{S_SC2 + 1}], {vr(MR[y], 2)} op_sel_hi:[1,0,0] neg_lo:[0,0,1] neg_hi:[0,0,1]")
+    e(f"v_fma_f32 {v(T0)}, {v(s0)}, %[scale], -{m_run(y)}")
+    e(f"v_fma_f32 {v(T1)}, {v(s1)}, %[scale], -{m_run(y)}")
     e(f"v_exp_f32 {v(T0)}, {v(T0)}")
     e(f"v_exp_f32 {v(T1)}, {v(T1)}")
-    # every reader of a transcendental result sits one instruction behind it (no s_nop needed)
-    e(f"v_add_f32 {v(PS[(2 * i) & 3])}, {v(PS[(2 * i) & 3])}, {v(T0)}")
+    e("s_nop 0")
+    e(f"v_add_f32 {v(T2)}, {v(T0)}, {v(T1)}")
     e(f"v_cvt_pk_bf16_f32 {v(pk)}, {v(T0)}, {v(T1)}")
-    e(f"v_add_f32 {v(PS[(2 * i + 1) & 3])}, {v(PS[(2 * i + 1) & 3])}, {v(T1)}")
+    e(f"v_add_f32 {v(PS[i & 3])}, {v(PS[i & 3])}, {v(T2)}")
 
 
 def phase(x, do_q, do_p, do_s, vh):
@@ -233,10 +229,7 @@ def gen():
             e(f"v_mov_b32 {v(O[key] + r)}, 0")
     for b in range(2):
         e(f"v_mov_b32 {m_run(b)}, 0xff800000")
-        e(f"v_mov_b32 {v(MR[b] + 1)}, 0")
         e(f"v_mov_b32 {l_run(b)}, 0")
-    e(f"s_mov_b32 {s(S_SC2)}, %[scale]")
-    e(f"s_mov_b32 {s(S_SC2 + 1)}, %[scale]")
     e(f"s_mov_b32 {s(S_T)}, 0")
     e(f"s_mov_b32 {s(S_ISSUE)}, 0")
     # ---- prologue DMA, wait for tile 0
@@ -326,8 +319,6 @@ def gen():
             e(f"ds_write_b128 %[dump], {vr(O[key] + 4 * j, 4)} offset:{q * 1024}")
             q += 1
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    for b in range(2):
-        e(f"v_mov_b32 %[mr{b}], {m_run(b)}")     # the running maxima leave through the output operands
     if TIMED:
         for i in range(5):
             a = S_ACC + 2 * i
