@@ -60,7 +60,8 @@ u2tok_ctx_t u2tok_ctx_get_current(void);     /* NULL when the thread uses the de
 int u2tok_set_option(const char* name, int value);
 /* Scratch for split-K partial sums of u2tok_gemm_bf16 calls on `stream` (fp32, slices x M x N), registered on the
  * current context: skinny products (few output tiles, long K) are cut along K when a scratch is registered; NULL / 0
- * removes it.  The module forwards below carve their own from their workspace and do not need this. */
+ * removes it.  Its first 4 KB are zeroed (on `stream`) and kept as arrival counters of the in-kernel K-slice reduction.
+ * The module forwards below carve their own from their workspace and do not need this. */
 int u2tok_set_gemm_scratch(void* device_ptr, size_t bytes, void* stream);
 /* Diagnostics only, process-wide (not for concurrent use): device buffer (>= grid*4*8 uint64, zeroed by the caller)
  * for the flash attention kernel; while attached the kernel runs its s_memtime-instrumented build and ADDS per-phase
@@ -228,7 +229,7 @@ int u2tok_score_gemv(const void* x, const void* w, const void* bias, float* scor
 int u2tok_topk_sorted(const float* scores, int64_t* idx, int32_t B, int32_t n, int32_t k, u2tok_stream_t stream);
 int u2tok_gather_rows(const void* x, const int64_t* idx, void* out, int32_t B, int32_t n, int32_t k, int32_t E,
                       u2tok_stream_t stream);
-/* ws: B*3*ceil(E/256) floats (only read/written when gate_w != null) */
+/* ws: B*3*16*ceil(E/256) floats (only read/written when gate_w != null) */
 int u2tok_multiscale_pool(const void* x, void* out, int32_t B, int32_t k, int32_t E, const void* gate_w,
                           const void* gate_b, float* ws, u2tok_stream_t stream);
 int u2tok_temporal_attention(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t T,

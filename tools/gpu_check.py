@@ -408,7 +408,7 @@ def sec_skinnyperf():
         ws = [rnd(N, K, seed=10 + i).to(dev) for i in range(nw)]
         out = torch.empty((1, M, N), dtype=bf, device=dev)
         line = f"  {M:5d}x{N:5d}x{K:4d} bias, cold weights"
-        for name, sk, split in (("tile kernels", -1, 0), ("skinny", 1, 0), ("skinny split 2", 1, 2), ("skinny split 4", 1, 4),
+        for name, sk, split in (("tile kernels", -1, 0), ("skinny", 1, 0), ("skinny split 4", 1, 4), ("skinny split 8", 1, 8),
                                 ("skinny no split", 1, -1)):
             ops.set_option("gemm_skinny", sk)
             ops.set_option("gemm_splitk", split)

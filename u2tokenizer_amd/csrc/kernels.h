@@ -124,7 +124,7 @@ int topk_sorted(const float* scores, int64_t* idx, int B, int n, int k, hipStrea
 int gather_rows(const bf16_t* x, const int64_t* idx, bf16_t* out, int B, int n, int k, int E,
                 hipStream_t stream);
 // Multi-scale pooling {1,2,4} along the token axis (+ optional DMTP gates).  x: [B][k][E];
-// out: [B][k + k/2 + k/4][E].  gate_w/gate_b null -> fixed pooling.  ws: >= B*3*ceil(E/256) floats.
+// out: [B][k + k/2 + k/4][E].  gate_w/gate_b null -> fixed pooling.  ws: >= B*3*16*ceil(E/256) floats.
 int multiscale_pool(const bf16_t* x, bf16_t* out, int B, int k, int E, const bf16_t* gate_w,
                     const bf16_t* gate_b, float* ws, hipStream_t stream);
 

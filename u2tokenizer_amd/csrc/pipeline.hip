@@ -320,7 +320,7 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
   Arena ar(ws, ws_bytes, dry);
   // split-K scratch for the skinny linear layers of this forward (M = 256 queries against E x E weights); registered
   // for this stream only while the launches below are being enqueued
-  constexpr size_t kSplitK = 24u << 20;
+  constexpr size_t kSplitK = 40u << 20;
   char* skw = ar.get<char>(kSplitK);
   U2_CHECK_WS(ar);
   Context& cx = ctx();
@@ -455,7 +455,7 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
   if (c.use_multi_scale) {
     Lv = k + k / 2 + k / 4;
     bf16_t* pooled = ar.get<bf16_t>((size_t)B * Lv * E);
-    float* gws = ar.get<float>((size_t)B * 3 * cdiv(E, 256));
+    float* gws = ar.get<float>((size_t)B * 3 * 16 * cdiv(E, 256));
     U2_CHECK_WS(ar);
     U2_RUN(multiscale_pool(sel, pooled, B, k, E, c.enable_dmtp ? wp(i_gate) : nullptr,
                            c.enable_dmtp ? wp(i_gate + 1) : nullptr, gws, st));

@@ -122,20 +122,26 @@ int gather_rows(const bf16_t* x, const int64_t* idx, bf16_t* out, int B, int n, 
 // gate_s = gate_fc(mean_tokens(avg_pool1d(x, s)))  (svr.py:133-138).  The token mean of the pooled block
 // equals the mean of the first floor(k/s)*s tokens, accumulated here in fp32 per column.
 // ws[(b*3 + s)*ncg + cg] = sum over the 256 columns of group cg of colmean_s[e] * gate_w[e].
+constexpr int DMTP_SLABS = 16;  // token slabs of the gate reduction (ws: B * 3 * DMTP_SLABS * ceil(E / 256) floats)
+
 __global__ __launch_bounds__(256) void dmtp_gate_partial_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gate_w,
                                                                 float* __restrict__ ws, int k, int E, int ncg) {
-  // block = 256 columns of one batch element; thread (cgp = tid & 31, ty = tid >> 5) sums 8 columns over tokens
-  // ty, ty + 8, ...: every wave reads 2 x 512 contiguous bytes per token row.
+  // block = 256 columns x one of DMTP_SLABS token slabs of one batch element (round 1 ran one block per 256 columns: 16
+  // workgroups for 8 MB, 0.19 TB/s); thread (cgp = tid & 31, ty = tid >> 5) sums 8 columns over the slab's tokens
+  // ty, ty + 8, ...: every wave reads 2 x 512 contiguous bytes per token row.  The three gate logits are linear in the
+  // column sums, so every block leaves its own partial logits; multiscale_pool_kernel adds them in a fixed order.
   __shared__ float red[8][32][9];
   __shared__ float fin[3][4];
-  const int b = blockIdx.y, cg = blockIdx.x;
+  const int b = blockIdx.y, cg = blockIdx.x, slab = blockIdx.z;
   const int cgp = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int e0 = cg * 256 + cgp * 8;
   const int lim2 = (k / 2) * 2, lim4 = (k / 4) * 4;
+  const int per = (lim4 + DMTP_SLABS - 1) / DMTP_SLABS;
+  const int t_begin = slab * per, t_end = min(lim4, t_begin + per);
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const bf16_t* xb = x + (int64_t)b * k * E;
   if (e0 < E) {
-    for (int t = ty; t < lim4; t += 8) {
+    for (int t = t_begin + ty; t < t_end; t += 8) {
       const uint4 u = *reinterpret_cast<const uint4*>(xb + (int64_t)t * E + e0);
       acc[0] += bf16lo(u.x); acc[1] += bf16hi(u.x); acc[2] += bf16lo(u.y); acc[3] += bf16hi(u.y);
       acc[4] += bf16lo(u.z); acc[5] += bf16hi(u.z); acc[6] += bf16lo(u.w); acc[7] += bf16hi(u.w);
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(256) void dmtp_gate_partial_kernel(const bf16_t* __
 #pragma unroll
     for (int y = 0; y < 8; ++y) c4 += red[y][col >> 3][col & 7];
     float c2 = c4, c1 = c4;
-    for (int t = lim4; t < k; ++t) {
+    for (int t = lim4; t < k && slab == 0; ++t) {  // the (<= 3) tail tokens belong to slab 0
       const float v = bf16_to_f32(xb[(int64_t)t * E + e]);
       c1 += v;
       if (t < lim2) c2 += v;
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(256) void dmtp_gate_partial_kernel(const bf16_t* __
   __syncthreads();
   if (threadIdx.x < 3) {
     const float* r = fin[threadIdx.x];
-    ws[((int64_t)b * 3 + threadIdx.x) * ncg + cg] = (r[0] + r[1]) + (r[2] + r[3]);
+    ws[(((int64_t)b * 3 + threadIdx.x) * DMTP_SLABS + slab) * ncg + cg] = (r[0] + r[1]) + (r[2] + r[3]);
   }
 }
 
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(256) void multiscale_pool_kernel(const bf16_t* __re
       float m = -INFINITY;
       for (int s = 0; s < ns; ++s) {
         float a = 0.f;
-        for (int c = 0; c < ncg; ++c) a += ws[((int64_t)b * 3 + s) * ncg + c];
+        for (int c = 0; c < ncg * DMTP_SLABS; ++c) a += ws[((int64_t)b * 3 + s) * ncg * DMTP_SLABS + c];
         g[s] = a + bf16_to_f32(gate_b[0]);
         m = fmaxf(m, g[s]);
       }
@@ -231,7 +237,7 @@ int multiscale_pool(const bf16_t* x, bf16_t* out, int B, int k, int E, const bf1
   ProfScope ps(PROF_ROWOP, 0, stream);
   if (use_gate) {
     if (!gate_b || !ws) return U2_ERR_ARG;
-    hipLaunchKernelGGL(dmtp_gate_partial_kernel, dim3(ncg, B), dim3(256), 0, stream, x, gate_w, ws, k, E, ncg);
+    hipLaunchKernelGGL(dmtp_gate_partial_kernel, dim3(ncg, B, DMTP_SLABS), dim3(256), 0, stream, x, gate_w, ws, k, E, ncg);
     if (launch_status() != U2_OK) return U2_ERR_LAUNCH;
   }
   const int Lout = k + k / 2 + k / 4;

@@ -331,7 +331,7 @@ def multiscale_pool(x, gate_w=None, gate_b=None):
     x = _need(x, torch.bfloat16, "x").contiguous()
     B, k, E = x.shape
     out = torch.empty((B, k + k // 2 + k // 4, E), dtype=torch.bfloat16, device=x.device)
-    ws = torch.empty((B * 3 * ((E + 255) // 256),), dtype=torch.float32, device=x.device)
+    ws = torch.empty((B * 3 * 16 * ((E + 255) // 256),), dtype=torch.float32, device=x.device)
     _lib.check(h.u2tok_multiscale_pool(_ptr(x), _ptr(out), B, k, E, _ptr(gate_w), _ptr(gate_b), _ptr(ws), _stream()),
                "u2tok_multiscale_pool")
     return out
