@@ -369,7 +369,7 @@ def main():
         ms, flops, byts, cnt = (C.c_double * 5)(), (C.c_double * 5)(), (C.c_double * 5)(), (C.c_int64 * 5)()
         _lib.check(h.u2tok_profile_collect2(ms, flops, byts, cnt, 5), "u2tok_profile_collect2")
         ops.set_option("profile", 0)
-        names = ["gemm_bf16 (gemm_bt_kernel + gemm_bf16_nt_kernel + gemm_skinny_kernel + split-K reduce)",
+        names = ["gemm_bf16 (gemm_bt_kernel + gemm_bf16_nt_kernel + gemm_splitk_reduce_kernel)",
                  "flash_d64 (flash_dp_kernel)", "temporal_attention_kernel", "row_ops", "data_movement"]
         # per class: time, launches, algorithmic TFLOP/s and algorithmic GB/s (operands + results once) of its launches
         classes = {n: {"ms_per_step": round(ms[i] / nprof, 4), "launches_per_step": cnt[i] // nprof,
@@ -402,7 +402,7 @@ def main():
                                 "instrumented pass of 3 steps after the timed region"}
 
         line["roofline"] = roof(0, "gemm_bf16", "bf16 MFMA GEMM, all launches of one step (gemm_bt_kernel 256x256 / 256x192 "
-                                                "tiles, gemm_bf16_nt_kernel 128^2 / 64^2 tiles, skinny / split-K kernels)")
+                                                "tiles, gemm_bf16_nt_kernel 128^2 / 64^2 tiles, split-K reduce)")
         line["roofline"]["classes"] = classes
         if ms[1] > 0:
             line["roofline_attention"] = roof(1, "flash_d64", "flash_dp_kernel: ViT attention, 8 chunks x 12 heads x 2049 "

@@ -54,14 +54,13 @@ u2tok_ctx_t u2tok_ctx_get_current(void);     /* NULL when the thread uses the de
     "gemm_tile" {0 heuristic, 64, 128: tile of the small-tile kernel}, "gemm_splitk" {-1 never, 0 heuristic, 2..16 force
     that many K slices where scratch allows}, "gemm_big" {-1 never, 0 heuristic, 20 / 21 force the 256x256 / 256x192
     big-tile kernel}, "gemm_big_grid" {persistent workgroups}, "gemm_big_gelu" {0, 1: GELU products may take the
-    big-tile kernel}, "gemm_skinny" {-1 never, 0 heuristic, 1 force the weight-streaming kernel for M <= 256},
+    big-tile kernel},
     "flash_mode" {0 pick, 1 plain 128-row units, 5 double pipeline (asm KV loop)}, "vit_flash" {0 unfused attention, 1}, "tta_overlap" {0, 1: side stream for the TTA k|v projections},
     "profile" {0, 1} */
 int u2tok_set_option(const char* name, int value);
 /* Scratch for split-K partial sums of u2tok_gemm_bf16 calls on `stream` (fp32, slices x M x N), registered on the
  * current context: skinny products (few output tiles, long K) are cut along K when a scratch is registered; NULL / 0
- * removes it.  Its first 4 KB are zeroed (on `stream`) and kept as arrival counters of the in-kernel K-slice reduction.
- * The module forwards below carve their own from their workspace and do not need this. */
+ * removes it.  The module forwards below carve their own from their workspace and do not need this. */
 int u2tok_set_gemm_scratch(void* device_ptr, size_t bytes, void* stream);
 /* Diagnostics only, process-wide (not for concurrent use): device buffer (>= grid*4*8 uint64, zeroed by the caller)
  * for the flash attention kernel; while attached the kernel runs its s_memtime-instrumented build and ADDS per-phase

@@ -44,6 +44,7 @@ def _worker(rank, world, port, q, overlap, bucket):
     dist.destroy_process_group()
 
 
+@torch.enable_grad()  # (other test modules of the suite switch autograd off process-wide at import)
 def _reference(world):
     m = _model()
     opt = torch.optim.AdamW(m.parameters(), lr=1e-2, weight_decay=0.1)
@@ -83,6 +84,7 @@ def test_zero1_matches_single_process_adamw():
         assert abs(sb0 - 6 * nparam) <= 12 * 2 * nb0 and sb0 == sb1
 
 
+@torch.enable_grad()
 def test_single_process_zero1_is_plain_adamw():
     from u2tokenizer_amd.dp import Zero1AdamW
     m1, m2 = _model(), _model()

@@ -298,42 +298,6 @@ def test_gemm_split_k(ops, split):
         torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("split", [-1, 0, 3])
-def test_gemm_skinny_weight_streaming_kernel(ops, split):
-    """gemm_skinny_kernel (M <= 256 against a large weight: one workgroup owns all rows of a 64-column slab, weight ring 7
-    K tiles ahead): forced on shapes with row / column tails and short / long K loops, every epilogue, with K slices
-    (fp32 partial sums + the fixed-order reduce) and without; bit-repeatable; exact on integer data."""
-    scratch = torch.empty(48 << 20, dtype=torch.uint8, device=D)
-    ops.set_gemm_scratch(scratch)
-    ops.set_option("gemm_skinny", 1)
-    ops.set_option("gemm_splitk", split)
-    try:
-        for (M, N, K) in [(256, 2048, 1024), (200, 4096, 4096), (256, 1000, 512), (77, 520, 1152), (256, 12288, 4096),
-                          (8, 768, 768), (1, 64, 64)]:
-            a, b = rnd(M, K, seed=1), rnd(N, K, scale=K ** -0.5, seed=2)
-            ad, bd = a.to(D), b.to(D)
-            outs = [ops.gemm(ad, bd).clone() for _ in range(3)]
-            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
-            close_bf16(outs[0], a.float() @ b.float().t())
-        M, N, K = 256, 1024, 2048
-        g = torch.Generator().manual_seed(5)
-        ai, bi = torch.randint(-3, 4, (M, K), generator=g).to(bf), torch.randint(-3, 4, (N, K), generator=g).to(bf)
-        assert torch.equal(ops.gemm(ai.to(D), bi.to(D), out_f32=True).cpu(), ai.float() @ bi.float().t())
-        M, N, K = 200, 264, 2048
-        a, b, bias, res = rnd(M, K, seed=3), rnd(N, K, scale=K ** -0.5, seed=4), rnd(N, seed=5), rnd(M, N, seed=6)
-        base = a.float() @ b.float().t()
-        ad, bd, biasd, resd = a.to(D), b.to(D), bias.to(D), res.to(D)
-        close_bf16(ops.gemm(ad, bd, bias=biasd), base + bias.float())
-        close_bf16(ops.gemm(ad, bd, bias=biasd, gelu=True), F.gelu(base + bias.float()))
-        close_bf16(ops.gemm(ad, bd, bias=biasd, residual=resd), base + bias.float() + res.float())
-        close_f32(ops.gemm(ad, bd, bias=biasd, out_f32=True, alpha=0.5), 0.5 * base + bias.float())
-    finally:
-        ops.set_option("gemm_skinny", 0)
-        ops.set_option("gemm_splitk", 0)
-        ops.set_gemm_scratch(None)
-        torch.cuda.synchronize()
-
-
 def test_gemm_ktile_major_weights(ops):
     """B handed over K-tile-major ([K/64][N][64], ops.pack_ktile_major): same products as the row-major weight, with and
     without split-K, tails in M and N."""

@@ -398,34 +398,6 @@ def sec_ppperf(shapes_sel=None):
     ops.set_option("gemm_big", 0)
 
 
-def sec_skinnyperf():
-    """M = 256 products of the TTA query side with COLD weights (16 matrices in rotation): tile kernels vs the skinny kernel"""
-    scratch = torch.empty(48 << 20, dtype=torch.uint8, device=dev)
-    ops.set_gemm_scratch(scratch)
-    for (M, N, K) in [(256, 4096, 4096), (256, 12288, 4096), (256, 2048, 2048)]:
-        nw = 16
-        a, bias = rnd(M, K, seed=1).to(dev), rnd(N, seed=3).to(dev)
-        ws = [rnd(N, K, seed=10 + i).to(dev) for i in range(nw)]
-        out = torch.empty((1, M, N), dtype=bf, device=dev)
-        line = f"  {M:5d}x{N:5d}x{K:4d} bias, cold weights"
-        for name, sk, split in (("tile kernels", -1, 0), ("skinny", 1, 0), ("skinny split 4", 1, 4), ("skinny split 8", 1, 8),
-                                ("skinny no split", 1, -1)):
-            ops.set_option("gemm_skinny", sk)
-            ops.set_option("gemm_splitk", split)
-            it = [0]
-
-            def f():
-                ops.gemm(a, ws[it[0] % nw], bias=bias, out=out)
-                it[0] += 1
-            ms = timeit(f, iters=32, warm=4)
-            line += f" | {name}: {ms * 1e3:6.1f} us ({2 * N * K / ms / 1e9 * 1e3 / 1e3:5.2f} TB/s)"
-        print(line, flush=True)
-        del ws
-    ops.set_option("gemm_skinny", 0)
-    ops.set_option("gemm_splitk", 0)
-    ops.set_gemm_scratch(None)
-
-
 def sec_geluperf():
     """fc1 of the ViT (bias + GELU): small-tile kernel vs the big-tile kernel with the GELU epilogue"""
     M, N, K = 16384, 3072, 768

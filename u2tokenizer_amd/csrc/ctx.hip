@@ -35,9 +35,6 @@ SideStream* Context::side_for(hipStream_t owner) {
 }
 
 void Context::set_scratch(hipStream_t st, void* p, size_t bytes) {
-  // the first 4 KB are arrival counters of the skinny GEMM's in-kernel K-slice reduction: zero at registration (on the
-  // stream the products will run on), reset by the kernel after every use
-  if (p && bytes > 4096) (void)hipMemsetAsync(p, 0, 4096, st);
   std::lock_guard<std::mutex> lk(mu);
   for (auto& s : scratch)
     if (s.st == st) { s.p = p; s.bytes = bytes; return; }

@@ -298,226 +298,6 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmDesc d) {
   }
 }
 
-// ----------------------------------------------------------------------------------------------------------------
-// Weight-streaming kernel for SKINNY products: M <= 256 activation rows against a large weight, C (M x N) = A W^T with
-// N, K in the thousands -- the M = 256 query side of the TTA (tta.py:93-103: q / dense projections of every attention,
-// 25 products per volume against 4096 x 4096 or 12288 x 4096 weights).  Such a product is 33 MB of weights for 8.6
-// GFLOP: HBM-bound (4 us at 8 TB/s), and what the tile kernels above lack for it is BYTES IN FLIGHT -- their K loop
-// waits for one 16 KB stage at a time and the four M tiles of a weight tile fetch the same bytes (round 1: 26 us + a 9 us
-// reduce, latency-bound at ~2 MB of unique weight bytes in flight chip-wide).  Here a workgroup owns ALL rows of a
-// 64-column slab over a K slice:
-//  * every weight byte is fetched exactly once, by LDS-DMA into a ring of SK_NW 8 KB stages that runs SK_NW - 1 K tiles
-//    ahead (56 KB of unique weight bytes in flight per workgroup);
-//  * the activations never touch LDS: wave w owns rows [64 w, 64 w + 64) and nobody else reads them, so each lane loads
-//    its MFMA fragments straight from global memory (16 bytes of one row per load; the four k steps of a K tile share the
-//    row's 128-byte line), double-buffered in registers one K tile ahead.  (First version, profiles/r02_skinny_v1.log:
-//    activations staged through LDS = 8 extra DMA instructions per wave and K tile, each stalling its wave ~150 cycles
-//    with one wave per SIMD -- slower than the tile kernels.);
-//  * 4 waves x (64 rows x 64 columns) of v_mfma_f32_32x32x16_bf16, activation fragment as the A operand so a lane owns
-//    one output column of 16 rows (stores coalesce along n); one barrier per K tile; 64 KB of LDS = two workgroups per CU;
-//  * K slices leave fp32 partial sums; the LAST slice of a slab to finish (a counter per slab in the scratch, bumped
-//    behind a __threadfence) adds the slices IN SLICE ORDER, applies the epilogue and resets the counter -- no separate
-//    reduce launch, and the result does not depend on which workgroup came last.
-constexpr int SK_NW = 8;                       // weight ring stages
-constexpr int SK_LDS = SK_NW * 64 * 128;       // 64 KB
-
-__device__ __forceinline__ uint32_t sk_off(int row, int chunk) {  // 128-byte rows, chunk ^ ((row >> 1) & 7): 32x32 fragments
-  return (uint32_t)(row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-}
-
-__global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(GemmDesc d, unsigned* __restrict__ counters) {
-  __shared__ __attribute__((aligned(16))) char ldsW[SK_LDS];  // [SK_NW][64 rows][128 B]
-  __shared__ int s_last;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5, l31 = lane & 31;
-  const int bn0 = blockIdx.x * 64;
-  const int nkt_all = d.K >> 6;
-  const int kt0 = (d.ksplit > 1) ? (int)blockIdx.z * d.kt_per : 0;
-  const int kt1 = (d.ksplit > 1) ? min(nkt_all, kt0 + d.kt_per) : nkt_all;
-  const int nkt = kt1 - kt0;
-
-  // weight DMA pieces (1 KB = 8 rows x 8 chunks per wave instruction): lane -> (row r0 + (lane >> 3), LDS position
-  // lane & 7), which holds global chunk (lane & 7) ^ ((row >> 1) & 7); wave w stages slab rows [16 w, 16 w + 16).
-  // Rows past N are clamped (their columns are not stored).
-  const int pr = lane >> 3, pp = lane & 7;
-  const bf16_t* pw[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = wave * 16 + i * 8 + pr;
-    pw[i] = d.B + (int64_t)min(bn0 + row, d.N - 1) * d.ldb + ((pp ^ ((row >> 1) & 7)) << 3) + (int64_t)kt0 * 64;
-  }
-  auto issue_w = [&](int t) {  // weight tile t (relative to kt0) -> ring slot t % SK_NW
-    char* dst = ldsW + (t % SK_NW) * (64 * 128) + (wave * 16) * 128;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pw[i] + (int64_t)t * 64),
-                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
-  };
-  // activation fragments of this lane: rows 64 w + 32 mi + l31 (clamped), k = 16 kk + 8 hi .. + 7 of the K tile
-  const bf16_t* pa[2];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-    pa[mi] = d.A + (int64_t)min(wave * 64 + mi * 32 + l31, d.M - 1) * d.lda + hi * 8 + (int64_t)kt0 * 64;
-  bf16x8 xa[2][2][4];  // [buffer][mi][kk]
-  auto load_a = [&](int t, int buf) {
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
-        xa[buf][mi][kk] = *reinterpret_cast<const bf16x8*>(pa[mi] + (int64_t)t * 64 + kk * 16);
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-  // prologue: the weight ring runs SK_NW - 1 tiles ahead, the activations one
-#pragma unroll
-  for (int t = 0; t < SK_NW - 1; ++t)
-    if (t < nkt) issue_w(t);
-  load_a(0, 0);
-  // The loop is unrolled by two so that the register buffers are compile-time indices.
-  auto step = [&](int t, auto BUF) {
-    constexpr int buf = decltype(BUF)::value;
-    const bool more_a = t + 1 < nkt;
-    if (more_a) load_a(t + 1, buf ^ 1);
-    // everything up to and including activation tile t must have landed (weight tile t is older); younger loads of this
-    // wave, in issue order: weight tile t + SK_NW - 2 (2, issued behind the barrier of the previous step), activation
-    // tile t + 1 (8)
-    if (t == 0) {
-      if (more_a) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else if (more_a && t + SK_NW - 2 < nkt) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if (more_a) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // weight tile t is complete for every wave; every wave is done with tile t - 1
-    const char* sW = ldsW + (t % SK_NW) * (64 * 128);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      bf16x8 wf[2];
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) wf[ni] = *reinterpret_cast<const bf16x8*>(sW + sk_off(ni * 32 + l31, kk * 2 + hi));
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[buf][mi][kk], wf[ni], acc[mi][ni], 0, 0, 0);
-      if (kk == 0 && t + SK_NW - 1 < nkt) issue_w(t + SK_NW - 1);  // slot (t - 1) % SK_NW: free behind the barrier above
-    }
-  };
-  for (int t = 0; t < nkt; t += 2) {
-    step(t, std::integral_constant<int, 0>{});
-    if (t + 1 < nkt) step(t + 1, std::integral_constant<int, 1>{});
-  }
-
-  // lane: column n = bn0 + 32 ni + l31, rows m = 64 wave + 32 mi + (r & 3) + 8 (r >> 2) + 4 hi
-  const bool split = d.ksplit > 1;
-  const bool out_f32 = d.flags & GEMM_OUT_F32;
-  if (split) {
-    float* P = d.partial + (int64_t)blockIdx.z * d.M * d.N;
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int n = bn0 + ni * 32 + l31;
-      if (n >= d.N) continue;
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = wave * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (m < d.M) P[(int64_t)m * d.N + n] = acc[mi][ni][r];
-        }
-    }
-    // last slice of this slab to arrive reduces it
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) {
-      const unsigned prev = atomicAdd(&counters[blockIdx.x], 1u);
-      s_last = (prev == (unsigned)d.ksplit - 1);
-      if (s_last) counters[blockIdx.x] = 0;  // ready for the next launch on this stream
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    for (int sidx = 0; sidx < d.ksplit; ++sidx) {  // slice order: the sum does not depend on who came last
-      const float* Q = d.partial + (int64_t)sidx * d.M * d.N;
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int n = bn0 + ni * 32 + l31;
-        if (n >= d.N) continue;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = wave * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (m < d.M) acc[mi][ni][r] += __builtin_nontemporal_load(Q + (int64_t)m * d.N + n);
-          }
-      }
-    }
-  }
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int n = bn0 + ni * 32 + l31;
-    if (n >= d.N) continue;
-    const float bias = (d.flags & GEMM_BIAS_N) ? bf16_to_f32(d.bias[n]) : 0.f;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = wave * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (m >= d.M) continue;
-        float x = acc[mi][ni][r] * d.alpha + bias;
-        if (d.flags & GEMM_GELU) x = gelu_erf(x);
-        if (d.flags & GEMM_RESIDUAL) x += bf16_to_f32(d.R[(int64_t)m * d.ldr + n]);
-        if (out_f32) reinterpret_cast<float*>(d.C)[(int64_t)m * d.ldc + n] = x;
-        else reinterpret_cast<bf16_t*>(d.C)[(int64_t)m * d.ldc + n] = f32_to_bf16(x);
-      }
-  }
-}
-
-// 1 launched, 0 not applicable.  `d` validated by gemm_bf16.  K slices need a registered scratch: its first 4 KB hold the
-// per-slab arrival counters (zero between launches: zeroed at registration, reset by the kernel), the rest the partials.
-static int gemm_skinny_try(GemmDesc d, hipStream_t stream) {
-  const Options& o = opts();
-  if (o.gemm_skinny < 0) return 0;
-  if (d.nz != 1 || d.M > 256 || (d.K & 63) || d.ldbk || (d.flags & GEMM_BIAS_M)) return 0;
-  if (o.gemm_skinny == 0 && (d.M < 128 || d.N < 2048 || d.K < 1024)) return 0;  // heuristic: the TTA query-side products
-  const int nkt = d.K >> 6, slabs = (int)cdiv(d.N, 64);
-  // K slices: two workgroups per CU (one round of <= 512), each slice >= 8 K tiles, partial sums within the scratch
-  int s = 1;
-  if (o.gemm_splitk >= 0) {
-    s = (int)std::min<int64_t>(std::max<int64_t>(1, 512 / slabs), std::max(1, nkt / 8));
-    if (o.gemm_splitk > 1) s = std::min(o.gemm_splitk, nkt);
-  }
-  d.ksplit = 1;
-  unsigned* counters = nullptr;
-  if (s > 1) {
-    const Scratch sc = ctx().scratch_of(stream);
-    const size_t slice = (size_t)d.M * d.N * sizeof(float);
-    if (!sc.p || sc.bytes <= 4096 || slabs > 1024) s = 1;
-    else s = (int)std::min<size_t>(s, (sc.bytes - 4096) / slice);
-    if (s > 1) {
-      d.kt_per = (int)cdiv(nkt, s);
-      d.ksplit = (int)cdiv(nkt, d.kt_per);
-      counters = reinterpret_cast<unsigned*>(sc.p);
-      d.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(sc.p) + 4096);
-    }
-  }
-  hipLaunchKernelGGL(gemm_skinny_kernel, dim3(slabs, 1, d.ksplit), dim3(256), 0, stream, d, counters);
-  const int e = launch_status();
-  return e == U2_OK ? 1 : e;
-}
-
 template <int BM, int BN>
 static int launch_tile(GemmDesc d, hipStream_t stream) {
   d.tiles_m = (int)cdiv(d.M, BM);
@@ -556,10 +336,6 @@ int gemm_bf16(GemmDesc d, hipStream_t stream) {
     const int big = gemm_big_try(d, stream);  // large products: the big-tile kernel (gemm_bt.hip)
     if (big != 0) return big > 0 ? U2_OK : big;
   }
-  {
-    const int sk = gemm_skinny_try(d, stream);  // M <= 256 against a large weight: the weight-streaming kernel
-    if (sk != 0) return sk > 0 ? U2_OK : sk;
-  }
   return gemm_classic(d, stream);
 }
 
@@ -581,14 +357,7 @@ int gemm_classic(GemmDesc d, hipStream_t stream) {
     if (s == 0 && d.nz == 1 && wgs <= 320 && nkt >= 16)
       s = (int)std::min<int64_t>(8, std::min<int64_t>(nkt / 4, cdiv(1024, wgs)));
     if (s > 1) {
-      Scratch sc = ctx().scratch_of(stream);
-      if (sc.p && sc.bytes > 4096) {  // (the first 4 KB of a scratch are the skinny kernel's slab counters)
-        sc.p = reinterpret_cast<char*>(sc.p) + 4096;
-        sc.bytes -= 4096;
-      } else {
-        sc.p = nullptr;
-        sc.bytes = 0;
-      }
+      const Scratch sc = ctx().scratch_of(stream);
       const size_t slice = (size_t)d.nz * d.M * d.N * sizeof(float);
       if (o.gemm_splitk <= 1) s = (int)std::min<size_t>(s, std::min<size_t>(sc.bytes, 24u << 20) / slice);  // partial sums cost HBM traffic
       const size_t need = (size_t)s * slice;

@@ -320,7 +320,7 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
   Arena ar(ws, ws_bytes, dry);
   // split-K scratch for the skinny linear layers of this forward (M = 256 queries against E x E weights); registered
   // for this stream only while the launches below are being enqueued
-  constexpr size_t kSplitK = 40u << 20;
+  constexpr size_t kSplitK = 24u << 20;
   char* skw = ar.get<char>(kSplitK);
   U2_CHECK_WS(ar);
   Context& cx = ctx();
