@@ -1,6 +1,7 @@
 #!/bin/bash
-# rocprofv3 counter passes (counters + kernel trace only) for the hot kernels of this round (-> profiles/r01_kernel_pmc.json):
-#   flash attention (mode 5), big-tile GEMM on the ViT qkv shape (256x192 tiles) and on 8192^3 (256x256), 128^2 GEMM.
+# rocprofv3 counter passes (counters + kernel trace only) for the hot kernels (-> profiles/rNN_kernel_pmc.json): flash
+#   attention (double pipeline), big-tile GEMM on the ViT qkv shape (256x192 tiles), the 128^2 kernel on the fc1 shape, and
+#   the 64^2 split-K kernel on the M = 256 query-side product of the TTA with cold weights.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/pmc2; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 run() {  # name, driver args..., then counter sets come from PASSES
   name=$1; shift
@@ -16,10 +17,9 @@ PASSES=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MF
 # Lessons of round 1 (25 GPU-minutes): "GRBM_GUI_ACTIVE FETCH_SIZE WRITE_SIZE" in ONE pass aborts rocprofv3 (signal 6) --
 # collect them one per pass as tools/gpu_round.sh does; with SQ_INSTS_VALU added to the LDS set the profiled process
 # never exited and every pass ran into its timeout (the counters were still written).  Keep the per-pass timeout short.
+PASSES+=("FETCH_SIZE" "WRITE_SIZE")
 run flash5 flash 3 0 5
-run flash3 flash 3 0 3
 run qkv_bt192 gemm 3 21
-run qkv_classic gemm 3 -1
-run g8k_bt256 gemm8k 3 20
-run g8k_classic gemm8k 3 -1
+run fc1_gelu128 gemmmlp 3 -1
+run skinny64 gemm256 16 0
 cd $R && python tools/pmc_kernels.py $O > $R/gpurun_out/kernel_pmc.json && cat $R/gpurun_out/kernel_pmc.json | head -80

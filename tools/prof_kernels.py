@@ -1,4 +1,7 @@
-"""Tiny driver for rocprofv3 counter passes: python tools/prof_kernels.py flash|gemm|gemm4k|gemm256|gemm8k [iters] [gemm_pp variant] [flash_mode]"""
+"""Tiny driver for rocprofv3 counter passes:
+    python tools/prof_kernels.py flash|gemm|gemm4k|gemm256|gemm8k|gemmmlp [iters] [gemm_big: -1 | 0 | 20 | 21] [flash_mode]
+gemm256 = the M = 256 query-side product of the TTA with 16 COLD weight matrices in rotation and split-K scratch, as the
+pipeline runs it (64 x 64 tiles, 4 K slices + reduce)."""
 import sys
 from pathlib import Path
 
@@ -18,11 +21,17 @@ if what == "flash":
     for _ in range(iters):
         ops.flash_attention_d64(qkv, 12, 0.125, extra_last=True)
 elif what.startswith("gemm"):
-    ops.set_option("gemm_pp", variant)
+    ops.set_option("gemm_big", variant)
     M, N, K = {"gemm": (16384, 2304, 768), "gemm4k": (2048, 4096, 4096), "gemm256": (256, 4096, 4096),
                "gemm8k": (8192, 8192, 8192), "gemmmlp": (16384, 3072, 768)}[what]
-    a, b = torch.randn(M, K, device="cuda").to(bf), torch.randn(N, K, device="cuda").to(bf)
+    a = torch.randn(M, K, device="cuda").to(bf)
+    nw = 16 if what == "gemm256" else 1
+    ws = [torch.randn(N, K, device="cuda").to(bf) for _ in range(nw)]
+    bias = torch.randn(N, device="cuda").to(bf)
     out = torch.empty((1, M, N), dtype=bf, device="cuda")
-    for _ in range(iters):
-        ops.gemm(a, b, out=out)
+    if what == "gemm256":
+        scratch = torch.empty(24 << 20, dtype=torch.uint8, device="cuda")
+        ops.set_gemm_scratch(scratch)
+    for i in range(iters):
+        ops.gemm(a, ws[i % nw], bias=bias if what == "gemm256" else None, out=out)
 torch.cuda.synchronize()
