@@ -213,6 +213,31 @@ def test_tta_side_stream_is_invisible():
         assert torch.equal(tok(v_token=v, t_token=t), ref)
 
 
+def test_forwards_ignore_an_ambient_split_k_scratch():
+    """A split-K scratch some other caller registered on the stream (a direct u2tok_gemm_bf16 user, the training path)
+    must not change what a module forward computes: the split alters the summation order of skinny products (the cls
+    tails of the ViT, the projector at few chunks).  Round 2 found this as a test-order artefact at config 3."""
+    from u2tokenizer_amd import ops
+    from u2tokenizer_amd.projector import SpatialPoolingProjector
+    from u2tokenizer_amd.vit import ViT3DTower
+    img = [32, 128, 128]
+    vit = ViT3DTower(NS(vision_select_layer=-1, vision_select_feature="patch", image_channel=1, image_size=img,
+                        patch_size=[4, 16, 16]))
+    spp = SpatialPoolingProjector(img, [4, 16, 16], 768, 4096, "mlp", 2, "spatial", 2)
+    synth.fill_module_(vit, seed=4, prefix="vision_tower.")
+    synth.fill_module_(spp, seed=4, prefix="mm_projector.")
+    vit, spp = vit.to(bf).to(D), spp.to(bf).to(D)
+    vol = synth.synth_volume(1, 2, img, seed=4, dtype=torch.float16).view(2, 1, *img).to(D)
+    a = spp(vit(vol))
+    scratch = torch.empty(64 << 20, dtype=torch.uint8, device=D)
+    ops.set_gemm_scratch(scratch)
+    try:
+        b = spp(vit(vol))
+    finally:
+        ops.set_gemm_scratch(None)
+    assert torch.equal(a, b)
+
+
 def test_hard_topk_full_size_replay():
     """Hard top-k at BASELINE size inside the pipeline: indices == oracle selection on the same refined tokens."""
     E = 2048

@@ -27,6 +27,22 @@ struct Arena {
   bool ok() const { return dry || peak <= cap; }
 };
 
+// The split-K scratch registration of `st` for the duration of one module forward, the previous one restored on exit:
+// what a forward computes must not depend on a registration some other caller left behind (a direct u2tok_gemm_bf16
+// user, the training path) -- the split changes the summation order.  The ViT and the projector run without one.
+struct ScratchScope {
+  Context& cx;
+  hipStream_t st;
+  Scratch prev;
+  bool on;
+  ScratchScope(Context& c, hipStream_t s, void* p, size_t bytes, bool enable) : cx(c), st(s), prev{s, nullptr, 0}, on(enable) {
+    if (!on) return;
+    prev = cx.scratch_of(st);
+    cx.set_scratch(st, p, bytes);
+  }
+  ~ScratchScope() { if (on) cx.set_scratch(st, prev.p, prev.bytes); }
+};
+
 #define U2_RUN(expr)                  \
   do {                                \
     if (!dry) {                       \
@@ -145,6 +161,7 @@ int vit_forward(const VitConfig& c, const void* const* W, const void* volume, bf
   const int S_pad = (int)round_up(ntok, 64);
   auto w = [&](int i) { return dry ? nullptr : reinterpret_cast<const bf16_t*>(W[i]); };
 
+  ScratchScope scratch_scope(ctx(), st, nullptr, 0, !dry);
   Arena ar(ws, ws_bytes, dry);
   bf16_t* x = ar.get<bf16_t>((size_t)rows * Hd);
   bf16_t* xn = ar.get<bf16_t>((size_t)rows * Hd);
@@ -246,6 +263,7 @@ int spp_forward(const SppConfig& c, const void* const* W, const bf16_t* x, bf16_
   const int np = (g1 / w1) * (g2 / w2) * (g3 / w3);
   const int64_t rows = (int64_t)c.nchunk * np;
   auto w = [&](int i) { return dry ? nullptr : reinterpret_cast<const bf16_t*>(W[i]); };
+  ScratchScope scratch_scope(ctx(), st, nullptr, 0, !dry);
   Arena ar(ws, ws_bytes, dry);
   bf16_t* pooled = ar.get<bf16_t>((size_t)rows * c.in_dim);
   bf16_t* ha = ar.get<bf16_t>((size_t)rows * c.out_dim);
@@ -324,13 +342,7 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
   char* skw = ar.get<char>(kSplitK);
   U2_CHECK_WS(ar);
   Context& cx = ctx();
-  struct ScratchGuard {
-    Context& cx;
-    hipStream_t st;
-    bool on;
-    ~ScratchGuard() { if (on) cx.set_scratch(st, nullptr, 0); }
-  } scratch_guard{cx, st, !dry};
-  if (!dry) cx.set_scratch(st, skw, kSplitK);
+  ScratchScope scratch_scope(cx, st, skw, kSplitK, !dry);
   const int64_t rows = (int64_t)B * TN;
   bf16_t* xa = ar.get<bf16_t>((size_t)rows * E);
   bf16_t* xb = ar.get<bf16_t>((size_t)rows * E);
