@@ -201,6 +201,53 @@ def cpu_baseline(E, Lt, iters=3, sample_chunks=1):
                        f"and 1/4 TTA layers (x4), DiffTS + DMTP pooling + linear aggregation in full; E={E}, text {Lt}")
 
 
+# ---------------------------------------------------------------------------------------------------- HBM traffic (PMC)
+PMC_CLASSES = [("gemm_bf16_nt_kernel", "gemm_bf16"), ("gemm_bt_kernel", "gemm_bf16"), ("gemm_splitk", "gemm_bf16"),
+               ("flash_", "flash_d64")]
+
+
+def measure_traffic(E, timeout=240):
+    """HBM-side bytes per volume of the GEMM class and of the flash kernel, LIVE: a process cannot read its own
+    counters, so two short rocprofv3 passes of THIS command (one counter each: FETCH_SIZE, WRITE_SIZE -- combined passes
+    abort rocprofv3 on this pool; counters + kernel trace only) run as subprocesses, 3 volumes on one stream each.
+    Corrections per MI355X_MICROARCH.md (HBM section): the counters are in KiB; FETCH_SIZE reports half of the bytes of wide
+    coalesced reads on gfx950 -> the read side is doubled.  Returns {class: bytes per volume} or None if rocprofv3 is
+    unavailable / fails (bench.py then cites the newest profiles/rNN_traffic.json instead)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    nvol = 3
+    agg = {}
+    tmp = tempfile.mkdtemp(prefix="u2tok_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, ctr), "-o", "p", "--",
+                   sys.executable, str(Path(__file__).resolve()), "--steps", "2", "--warmup", "1", "--repeats", "1",
+                   "--streams", "1", "--hidden", str(E), "--no-cpu-baseline", "--no-roofline"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True,
+                               timeout=timeout)
+            if r.returncode != 0:
+                return None
+            for f in glob.glob(os.path.join(tmp, ctr, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        name = next((lab for key, lab in PMC_CLASSES if key in row.get("Kernel_Name", "")), None)
+                        if name and row["Counter_Name"] == ctr:
+                            agg.setdefault(name, {}).setdefault(ctr, 0.0)
+                            agg[name][ctr] += float(row["Counter_Value"])
+        if not agg:
+            return None
+        return {k: (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0 / nvol for k, v in agg.items()}
+    except (OSError, subprocess.SubprocessError, ValueError, KeyError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 # ---------------------------------------------------------------------------------------------------- launcher
 def free_port():
     with socket.socket() as s:
@@ -247,6 +294,7 @@ def main():
                          "launches of one volume's tokenizer fill the machine under the other volume's large GEMMs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two live rocprofv3 PMC passes behind roofline.traffic")
     ap.add_argument("--cpu-baseline-iters", type=int, default=3)
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="library tuning switch for A/B measurements (u2tok_set_option), e.g. --option flash_mode=5")
@@ -376,11 +424,19 @@ def main():
                        "tflops": round(flops[i] / ms[i] / 1e9, 1) if ms[i] > 0 and flops[i] > 0 else None,
                        "algorithmic_gbytes_per_s": round(byts[i] / ms[i] / 1e6, 1) if ms[i] > 0 and byts[i] > 0 else None}
                    for i, n in enumerate(names)}
-        # HBM-side bytes of the kernel classes come from rocprofv3 PMC passes of THIS command (a process cannot read
-        # its own counters): tools/gpu_round.sh -> tools/pmc_traffic.py -> profiles/rNN_traffic.json (newest round)
+        # HBM-side bytes of the kernel classes: measured live by two rocprofv3 PMC passes of this command (measure_traffic);
+        # if rocprofv3 cannot run here, the newest profiles/rNN_traffic.json (tools/gpu_round.sh -> tools/pmc_traffic.py)
         traffic = {}
+        live = measure_traffic(E) if (B == 1 and not args.no_traffic) else None
+        if live:
+            for key, idx in (("gemm_bf16", 0), ("flash_d64", 1)):
+                if key in live and cnt[idx]:
+                    traffic[key] = (round(live[key] / max(cnt[idx] // nprof, 1)),
+                                    "live: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per volume / calls per volume, two rocprofv3 "
+                                    "--pmc passes of this command started by bench.py itself (3 volumes, one stream); "
+                                    "fabric-side requests (Infinity Cache hits included)")
         tfiles = sorted((ROOT / "profiles").glob("r*_traffic.json"))
-        if tfiles and E == 4096 and B == 1:
+        if not traffic and tfiles and E == 4096 and B == 1:
             tj = json.loads(tfiles[-1].read_text())["kernels"]
             for key, idx in (("gemm_bf16", 0), ("flash_d64", 1)):
                 if key in tj and cnt[idx]:
