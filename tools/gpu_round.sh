@@ -10,12 +10,13 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf $O/prof $O/pmc_bench
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline > $O/rocprof.log 2>&1
 echo "rocprof exit $?" >> $O/rocprof.log
+# volumes profiled per pass below: 2-stream run 1 warm-up + 5 repeats x 3 steps, one-stream run 1 + 2 x 3 = 23
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_bench/$c -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_$c.log 2>&1
   echo "pmc $c exit $?" >> $O/rocprof.log
 done
 cd $R
-python tools/pmc_traffic.py $O/pmc_bench 8 > $O/traffic.json 2> $O/traffic.err
+python tools/pmc_traffic.py $O/pmc_bench 23 > $O/traffic.json 2> $O/traffic.err
 find $O/prof $O/pmc_bench -name "*kernel_trace*" -size +8M -delete 2>/dev/null
 find $O/pmc_bench -name "*counter_collection*" -size +8M -delete 2>/dev/null
 tail -4 $O/pytest_gpu.log; tail -2 $O/smoke.log; tail -2 $O/bench.log; tail -4 $O/rocprof.log; head -c 1500 $O/traffic.json
