@@ -273,6 +273,19 @@ int u2tok_relbias_grad(const void* dS, float* dtable, int32_t nz, int32_t S, int
 int u2tok_rowdot_bf16(const void* a, const void* b, float* out, int64_t rows, int32_t C, int64_t lda, int64_t ldb,
                       u2tok_stream_t stream);
 
+/* Fused backward of the ViT attention core (MONAI SABlock, vit.py:100-105; head dim 64, no bias):
+ *   out = softmax(q k^T * scale) v   ->   dq, dk, dv   from q, k, v, out and d_out,
+ * replacing what torch.autograd does for the reference (softmax / matmul backward through the (S x S) probabilities, 1.6 GB
+ * fp32 per layer at S = 2049) by two flash-style kernels that rebuild the probabilities tile by tile.  All S rows of a batch
+ * in one row-major bf16 view: q, k, v row r of batch b at + b*bs_qkv + r*ld_qkv, head h at column h*64 (16-byte aligned
+ * bases, strides % 8 == 0); out / d_out with ld_o / bs_o; dq, dk, dv with ld_d / bs_d (may be slices of one packed
+ * buffer).  workspace: u2tok_flash_attention_d64_bwd_workspace_bytes(), 256-byte aligned.  No atomics: bit-repeatable. */
+size_t u2tok_flash_attention_d64_bwd_workspace_bytes(int32_t nb, int32_t S, int32_t H);
+int32_t u2tok_flash_attention_d64_bwd(const void* q, const void* k, const void* v, int64_t ld_qkv, int64_t bs_qkv,
+                                      const void* out, const void* d_out, int64_t ld_o, int64_t bs_o, void* dq, void* dk,
+                                      void* dv, int64_t ld_d, int64_t bs_d, int32_t nb, int32_t S, int32_t H, float scale,
+                                      void* workspace, size_t workspace_bytes, u2tok_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -153,7 +153,7 @@ def test_self_attention_fn(nb, S, H, d, bias):
 
 
 def test_flash_self_attention_fn_recomputes_for_backward():
-    """ViT form: flash forward (last row = the kernel's extra row), probabilities rebuilt in the backward."""
+    """ViT form: flash forward (last row = the kernel's extra row), default backward (fused kernels since round 2)."""
     from u2tokenizer_amd import autograd as AG
     nb, S, H, d = 2, 129, 3, 64
     E = H * d
@@ -166,6 +166,38 @@ def test_flash_self_attention_fn_recomputes_for_backward():
     assert rel(yd.float(), y) < 1.5e-2
     (yd.float() * g.to(D).float()).sum().backward()
     check_grads({"qkv": qd.grad}, {"qkv": qr.grad}, what="flash self attention")
+
+
+@pytest.mark.parametrize("nb,S,H,gain", [(2, 129, 3, 1.0), (1, 64, 2, 1.0), (1, 1, 1, 1.0), (2, 200, 4, 2.0), (1, 2049, 2, 1.0),
+                                         (3, 127, 1, 1.0), (1, 448, 12, 0.5)])
+def test_flash_attention_backward_kernels(nb, S, H, gain):
+    """u2tok_flash_attention_d64_bwd (attn_bwd.hip) per component against fp32 torch.autograd, against the unfused chain
+    (flash = 1: probabilities rebuilt in HBM), and bit-repeatable.  S covers ragged / single-tile / multi-workgroup sizes and
+    the ViT's own 2049."""
+    from u2tokenizer_amd import autograd as AG
+    E = H * 64
+    qkv, g = rnd(nb, S, 3 * E, scale=gain, seed=11), rnd(nb, S, E, seed=12)
+    qr = leaf(qkv.float())
+    y = _attn_ref(qr[..., :E], qr[..., E:2 * E], qr[..., 2 * E:], H, 0.125)
+    (y * g.float()).sum().backward()
+    grads = {}
+    for mode in (2, 1, 2):
+        qd = leaf(qkv, D)
+        yd = AG.SelfAttnFn.apply(qd, None, H, 0.125, 0, mode)
+        (yd.float() * g.to(D).float()).sum().backward()
+        grads.setdefault(mode, []).append(qd.grad)
+    assert torch.equal(grads[2][0], grads[2][1]), "fused attention backward is not bit-repeatable"
+    assert torch.isfinite(grads[2][0].float()).all()
+    top = qr.grad.double().pow(2).mean().sqrt().item()
+    report = {}
+    for i, name in enumerate(("dq", "dk", "dv")):
+        ref = qr.grad[..., i * E:(i + 1) * E]
+        fused, unfused = grads[2][0][..., i * E:(i + 1) * E].float(), grads[1][0][..., i * E:(i + 1) * E].float()
+        e_f, e_u = rel(fused, ref, 2e-3 * top), rel(unfused, ref, 2e-3 * top)
+        report[name] = (e_f, e_u)
+        # bf16 gradients: the unfused chain rounds P and dS to bf16 exactly as the fused kernels do
+        assert e_f <= max(1.5 * e_u, 0.0) + 1e-2, (name, report)
+    check_grads({"qkv": grads[2][0]}, {"qkv": qr.grad}, what="fused flash attention backward")
 
 
 def test_cross_and_plain_attention_fns():

@@ -189,29 +189,36 @@ def _attn_backward(q, k, v, P, dO, H, scale, dq, dk, dv, dtable, max_len):
 
 class SelfAttnFn(Function):
     """Self-attention core on a packed q | k | v buffer (nb, S, 3E) -> (nb, S, E).  rel_bias: (2 max_len - 1, H) table of
-    RelativeMultiheadAttention (rma.py:64-70) or None.  flash=True (head dim 64, no bias): the forward is the ViT flash
-    kernel with the LAST row of every batch as its "extra" row; the backward rebuilds the probabilities."""
+    RelativeMultiheadAttention (rma.py:64-70) or None.  flash (head dim 64, no bias): the forward is the ViT flash
+    kernel with the LAST row of every batch as its "extra" row; flash = 2 (True): the backward is the fused kernel pair of
+    attn_bwd.hip (probabilities rebuilt tile by tile from q, k and the saved output, which the out-projection keeps alive
+    anyway); flash = 1: the backward rebuilds the probabilities in HBM and runs the unfused chain (kept as the cross-check
+    of the fused kernels, tests/test_gpu_backward.py)."""
 
     @staticmethod
-    def forward(ctx, qkv, rel_bias, H: int, scale: float, max_len: int, flash: bool):
+    def forward(ctx, qkv, rel_bias, H: int, scale: float, max_len: int, flash):
         nb, S, E3 = qkv.shape
         E = E3 // 3
         qkv = qkv.contiguous()
-        P = None
+        flash = 2 if flash is True else int(flash)
+        P = out_saved = None
         if flash:
             out = ops.flash_attention_d64(qkv, H, scale, extra_last=S > 1)
+            out_saved = out if flash == 2 else None
         else:
             P = _attn_probs(qkv[..., :E], qkv[..., E:2 * E], H, scale, rel_bias, max_len)
             out = _attn_pv(P, qkv[..., 2 * E:], H, S)
-        ctx.save_for_backward(qkv, rel_bias, P)
+        ctx.save_for_backward(qkv, rel_bias, P, out_saved)
         ctx.cfg = (H, scale, max_len)
         return out
 
     @staticmethod
     def backward(ctx, dO):
-        qkv, rel_bias, P = ctx.saved_tensors
+        qkv, rel_bias, P, out = ctx.saved_tensors
         H, scale, max_len = ctx.cfg
         E = qkv.shape[-1] // 3
+        if out is not None:
+            return ops.flash_attention_d64_bwd(qkv, out, dO, H, scale), None, None, None, None, None
         q, k, v = qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:]
         if P is None:
             P = _attn_probs(q, k, H, scale, rel_bias, max_len)

@@ -265,5 +265,15 @@ int u2tok_rowdot_bf16(const void* a, const void* b, float* out, int64_t rows, in
                       u2tok_stream_t stream) {
   return rowdot_bf16(BF(a), BF(b), out, rows, C, lda, ldb, ST(stream));
 }
+size_t u2tok_flash_attention_d64_bwd_workspace_bytes(int32_t nb, int32_t S, int32_t H) {
+  return flash_attention_d64_bwd_workspace_bytes(nb, S, H);
+}
+int32_t u2tok_flash_attention_d64_bwd(const void* q, const void* k, const void* v, int64_t ld_qkv, int64_t bs_qkv,
+                                      const void* out, const void* d_out, int64_t ld_o, int64_t bs_o, void* dq, void* dk,
+                                      void* dv, int64_t ld_d, int64_t bs_d, int32_t nb, int32_t S, int32_t H, float scale,
+                                      void* workspace, size_t workspace_bytes, u2tok_stream_t stream) {
+  return flash_attention_d64_bwd(BF(q), BF(k), BF(v), ld_qkv, bs_qkv, BF(out), BF(d_out), ld_o, bs_o, BFW(dq), BFW(dk), BFW(dv),
+                                 ld_d, bs_d, nb, S, H, scale, workspace, workspace_bytes, ST(stream));
+}
 
 }  // extern "C"

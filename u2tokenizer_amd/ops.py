@@ -379,6 +379,30 @@ def flash_attention_d64(qkv: torch.Tensor, heads: int, scale: float, extra_last:
 
 
 @_guarded
+def flash_attention_d64_bwd(qkv: torch.Tensor, out: torch.Tensor, d_out: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+    """Gradient of flash_attention_d64 w.r.t. its packed input: qkv (nb, S, 3*heads*64), out / d_out (nb, S, heads*64), all
+    bf16 -> d_qkv like qkv (u2tok_flash_attention_d64_bwd: two flash-style kernels, no (S x S) tensor in HBM)."""
+    h = _lib.load_library()
+    qkv = _need(qkv, torch.bfloat16, "qkv").contiguous()
+    out = _need(out, torch.bfloat16, "out").contiguous()
+    d_out = _need(d_out, torch.bfloat16, "d_out").contiguous()
+    nb, S, three = qkv.shape
+    Hd = three // 3
+    if Hd != heads * 64 or out.shape != (nb, S, Hd) or d_out.shape != out.shape:
+        raise RuntimeError("flash_attention_d64_bwd: head dim 64 and out / d_out of shape (nb, S, heads * 64) required")
+    dqkv = torch.empty_like(qkv)
+    nbytes = h.u2tok_flash_attention_d64_bwd_workspace_bytes(nb, S, heads)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=qkv.device)
+    es = qkv.element_size()
+    _lib.check(h.u2tok_flash_attention_d64_bwd(qkv.data_ptr(), qkv.data_ptr() + Hd * es, qkv.data_ptr() + 2 * Hd * es,
+                                               3 * Hd, S * 3 * Hd, _ptr(out), _ptr(d_out), Hd, S * Hd,
+                                               dqkv.data_ptr(), dqkv.data_ptr() + Hd * es, dqkv.data_ptr() + 2 * Hd * es,
+                                               3 * Hd, S * 3 * Hd, nb, S, heads, float(scale), _ptr(ws), nbytes, _stream()),
+               "u2tok_flash_attention_d64_bwd")
+    return dqkv
+
+
+@_guarded
 def rope_apply(x: torch.Tensor, n_outer, S, n_inner, H, d, max_len=512, inverse=False):
     h = _lib.load_library()
     _lib.check(h.u2tok_rope_apply(_ptr(x), n_outer, S, n_inner, H, d, x.stride(-2), max_len, int(inverse), _stream()),
