@@ -70,15 +70,61 @@ int gelu_bwd(const bf16_t* z, const bf16_t* dy, bf16_t* dz, int64_t n, hipStream
 
 // ------------------------------------------------------------------------------------------------ column sums
 // out[c] = sum_r x[r][c] (optionally of x[r][c] * y[r][c]) in fp32, in a fixed order: slab s sums rows
-// [s * rows_per, ...) into part[s][c]; the finish kernel adds the slabs in order.  A thread owns 2 columns.
-constexpr int COLSUM_ROWS = 128;
+// [s * R, (s + 1) * R) into part[s][c]; the finish kernel adds the slabs in a fixed order.  R is chosen per call so that
+// ~1000 workgroups are in flight (16392 x 768: 37 + 50 us with 128-row slabs and a serial finish -> see DESIGN section 7).
+static int colsum_slab_rows(int rows, int C) {
+  const int64_t groups = cdiv(C, 512);
+  int64_t R = (int64_t)rows * groups / 1024;
+  R = (R / 4) * 4;
+  return (int)std::max<int64_t>(4, std::min<int64_t>(128, R));
+}
+
+// Vector form (C % 8 == 0, 16-byte aligned rows): a lane owns 8 columns, wave w of the workgroup walks rows r0 + w, + 4, ...
+// of the slab with four rows in flight; the four waves combine through LDS in a fixed order.
+__global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ y,
+                                                                 float* __restrict__ part, int rows, int C, int64_t ldx,
+                                                                 int64_t ldy, int R) {
+  __shared__ float red[3][512];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int chunk = blockIdx.x * 64 + lane;
+  const bool on = chunk * 8 < C;
+  const int r0 = blockIdx.y * R, r1 = min(rows, r0 + R);
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (on) {
+    const bf16_t* xp = x + chunk * 8;
+    const bf16_t* yp = y ? y + chunk * 8 : nullptr;
+#pragma unroll 4
+    for (int r = r0 + wv; r < r1; r += 4) {
+      float v[8];
+      unpack8(*reinterpret_cast<const uint4*>(xp + (int64_t)r * ldx), v);
+      if (yp) {
+        float q[8];
+        unpack8(*reinterpret_cast<const uint4*>(yp + (int64_t)r * ldy), q);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= q[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += v[j];
+    }
+  }
+  if (wv > 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[wv - 1][lane * 8 + j] = a[j];
+  }
+  __syncthreads();
+  if (wv == 0 && on) {
+    float* p = part + (int64_t)blockIdx.y * C + chunk * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p[j] = ((a[j] + red[0][lane * 8 + j]) + red[1][lane * 8 + j]) + red[2][lane * 8 + j];
+  }
+}
 
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ y,
                                                              float* __restrict__ part, int rows, int C, int64_t ldx,
-                                                             int64_t ldy) {
+                                                             int64_t ldy, int R) {
   const int c2 = blockIdx.x * 256 + threadIdx.x;  // column pair
   if (c2 * 2 >= C) return;
-  const int r0 = blockIdx.y * COLSUM_ROWS, r1 = min(rows, r0 + COLSUM_ROWS);
+  const int r0 = blockIdx.y * R, r1 = min(rows, r0 + R);
   float a0 = 0.f, a1 = 0.f;
   for (int r = r0; r < r1; ++r) {
     const uint32_t u = *reinterpret_cast<const uint32_t*>(x + (int64_t)r * ldx + c2 * 2);
@@ -96,46 +142,71 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __res
   p[1] = a1;
 }
 
-// out[c] (+)= sum_s part[s][c]; out_bf16 (optional) receives the rounded result as well
+// out[c] (+)= sum_s part[s][c]; out_bf16 (optional) receives the rounded result as well.  A workgroup owns 32 columns;
+// its 8 thread groups add slabs g, g + 8, ... and the eight partial sums are added in order (bit-repeatable).
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                             bf16_t* __restrict__ out_bf16, int nslab, int C, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float a = 0.f;
-  for (int s = 0; s < nslab; ++s) a += part[(int64_t)s * C + c];
-  if (accumulate) a += out[c];
-  if (out) out[c] = a;
-  if (out_bf16) out_bf16[c] = f32_to_bf16(a);
+  if (c < C)
+    for (int s = g; s < nslab; s += 8) a += part[(int64_t)s * C + c];
+  red[g][cl] = a;
+  __syncthreads();
+  if (g == 0 && c < C) {
+    float t = red[0][cl];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) t += red[i][cl];
+    if (accumulate) t += out[c];
+    if (out) out[c] = t;
+    if (out_bf16) out_bf16[c] = f32_to_bf16(t);
+  }
 }
 
-size_t colsum_workspace_bytes(int rows, int C) { return (size_t)cdiv(rows, COLSUM_ROWS) * C * sizeof(float); }
+static void colsum_finish(const float* part, float* out, bf16_t* out_bf16, int nslab, int C, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)cdiv(C, 32)), dim3(256), 0, st, part, out, out_bf16, nslab, C,
+                     accumulate);
+}
+
+size_t colsum_workspace_bytes(int rows, int C) {
+  if (rows <= 0 || C <= 0) return 0;
+  return (size_t)cdiv(rows, colsum_slab_rows(rows, C)) * C * sizeof(float);
+}
 
 int colsum_bf16(const bf16_t* x, const bf16_t* y, float* out, bf16_t* out_bf16, int rows, int C, int64_t ldx, int64_t ldy,
                 float* ws, int accumulate, hipStream_t st) {
   if (!x || (!out && !out_bf16) || !ws || rows <= 0 || C <= 0 || (C & 1) || (ldx & 1) || (y && (ldy & 1))) return U2_ERR_ARG;
   if ((((uintptr_t)x | (uintptr_t)y) & 3) || (accumulate && !out)) return U2_ERR_ARG;
-  const int nslab = (int)cdiv(rows, COLSUM_ROWS);
+  const int R = colsum_slab_rows(rows, C);
+  const int nslab = (int)cdiv(rows, R);
   if (nslab > 65535) return U2_ERR_ARG;
   ProfScope ps(PROF_ROWOP, 0, st, (double)rows * C * (y ? 4.0 : 2.0));
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)cdiv(C / 2, 256), nslab), dim3(256), 0, st, x, y, ws, rows, C,
-                     ldx, ldy);
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, st, ws, out, out_bf16, nslab, C,
-                     accumulate);
+  const bool vec = !(C & 7) && !(ldx & 7) && !(y && (ldy & 7)) && !(((uintptr_t)x | (uintptr_t)y) & 15);
+  if (vec)
+    hipLaunchKernelGGL(colsum_partial_vec_kernel, dim3((unsigned)cdiv(C, 512), nslab), dim3(256), 0, st, x, y, ws, rows, C,
+                       ldx, ldy, R);
+  else
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)cdiv(C / 2, 256), nslab), dim3(256), 0, st, x, y, ws, rows, C,
+                       ldx, ldy, R);
+  colsum_finish(ws, out, out_bf16, nslab, C, accumulate, st);
   return launch_status();
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm backward
 // v = x (+ res);  xhat = (v - mean) rstd;  y = xhat w + b.   g = dy w;
 //   dv = rstd (g - mean_c(g) - xhat mean_c(g xhat));   dw += dy xhat;   db += dy   (per-slab partial sums, fp32)
-// One wave per row, the row in registers (as the forward kernel); a workgroup walks LNB_ROWS rows so that each lane can
-// keep its columns' dw / db partials in registers; waves combine through LDS, one partial row per workgroup.
-constexpr int LNB_ROWS = 64;  // rows per workgroup (16 per wave)
+// One wave per row, the row in registers (as the forward kernel); a workgroup walks 4 x rpw rows so that each lane can
+// keep its columns' dw / db partials in registers; waves combine through LDS, one partial row per workgroup.  Rows per wave
+// (1..16) are chosen per call so that >= ~512 workgroups are in flight (2048 x 4096 with 64 rows per workgroup = 32
+// workgroups: 205 us, latency-bound).
+static int lnb_rows_per_wave(int rows) { return std::max(1, std::min(16, rows / 2048)); }
 
 template <int NC>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res,
                                                             const bf16_t* __restrict__ w, const bf16_t* __restrict__ dy,
                                                             bf16_t* __restrict__ dv, float* __restrict__ part_w,
-                                                            float* __restrict__ part_b, int rows, int C, float eps) {
+                                                            float* __restrict__ part_b, int rows, int C, float eps, int rpw) {
   __shared__ float red[3][NC * 512];  // waves 1..3 -> wave 0
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nchunk = C >> 3;
@@ -154,8 +225,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
       for (int j = 0; j < 8; ++j) wr[i][j] = 0.f;
     }
   }
-  const int r_begin = blockIdx.x * LNB_ROWS + wv * (LNB_ROWS / 4);
-  for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
+  const int r_begin = (blockIdx.x * 4 + wv) * rpw;
+  for (int rr = 0; rr < rpw; ++rr) {
     const int r = r_begin + rr;
     if (r >= rows) break;  // wave-uniform
     const bf16_t* xp = x + (int64_t)r * C;
@@ -249,27 +320,29 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
   }
 }
 
-size_t layernorm_bwd_workspace_bytes(int rows, int C) { return (size_t)2 * cdiv(rows, LNB_ROWS) * C * sizeof(float); }
+size_t layernorm_bwd_workspace_bytes(int rows, int C) {
+  if (rows <= 0 || C <= 0) return 0;
+  return (size_t)2 * cdiv(rows, 4 * lnb_rows_per_wave(rows)) * C * sizeof(float);
+}
 
 // dv: gradient w.r.t. x (and, identically, w.r.t. res); dw / db (fp32, C each) are overwritten unless accumulate.
 int layernorm_bwd(const bf16_t* x, const bf16_t* res, const bf16_t* w, const bf16_t* dy, bf16_t* dv, float* dw, float* db,
                   int rows, int C, float eps, float* ws, int accumulate, hipStream_t st) {
   if (!x || !w || !dy || !dv || !dw || !db || !ws || rows <= 0 || C <= 0 || (C & 7) || C > 4096) return U2_ERR_ARG;
   if (((uintptr_t)x | (uintptr_t)res | (uintptr_t)w | (uintptr_t)dy | (uintptr_t)dv) & 15) return U2_ERR_ARG;
-  const int nwg = (int)cdiv(rows, LNB_ROWS);
+  const int rpw = lnb_rows_per_wave(rows);
+  const int nwg = (int)cdiv(rows, 4 * rpw);
   float* pw = ws;
   float* pb = ws + (size_t)nwg * C;
   ProfScope ps(PROF_ROWOP, 0, st, (double)rows * C * 2.0 * (res ? 4.0 : 3.0));
 #define U2_LNB(NC)                                                                                                   \
-  hipLaunchKernelGGL((layernorm_bwd_kernel<NC>), dim3(nwg), dim3(256), 0, st, x, res, w, dy, dv, pw, pb, rows, C, eps)
+  hipLaunchKernelGGL((layernorm_bwd_kernel<NC>), dim3(nwg), dim3(256), 0, st, x, res, w, dy, dv, pw, pb, rows, C, eps, rpw)
   if (C <= 1024) U2_LNB(2);
   else if (C <= 2048) U2_LNB(4);
   else U2_LNB(8);
 #undef U2_LNB
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, st, pw, dw, (bf16_t*)nullptr, nwg, C,
-                     accumulate);
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, st, pb, db, (bf16_t*)nullptr, nwg, C,
-                     accumulate);
+  colsum_finish(pw, dw, nullptr, nwg, C, accumulate, st);
+  colsum_finish(pb, db, nullptr, nwg, C, accumulate, st);
   return launch_status();
 }
 

@@ -343,9 +343,17 @@ int gemm_bf16(GemmDesc d, hipStream_t stream) {
 int gemm_classic(GemmDesc d, hipStream_t stream) {
   const Options& o = opts();
   int tile = o.gemm_tile;
+  // "long K": weight-gradient products of the training path (dW = dY^T X: a small output, K = the 16392 token rows of the
+  // ViT).  64 x 64 tiles fill the CUs there but run at ~0.35-0.4 PF/s (197 us for 3072 x 768 x 16392); 128 x 128 tiles with
+  // K sliced over 5-8 workgroups keep the better tile and fill the machine.  No inference product has K >= 8192.
+  bool longk = false;
   if (tile != 64 && tile != 128) {
     const int64_t big = cdiv(d.M, 128) * cdiv(d.N, 128) * d.nz;
     tile = (big >= 192) ? 128 : 64;  // fill 256 CUs; small-M weight-streaming shapes get 64^2 tiles
+    if (tile == 64 && o.gemm_splitk == 0 && d.nz == 1 && d.M >= 512 && d.N >= 512 && d.K >= 8192) {
+      tile = 128;
+      longk = true;
+    }
   }
   // split-K: a product with fewer workgroups than ~2 per CU runs one single-stage-prefetch K loop per CU and is
   // latency-bound (M = 256, N = K = 4096: 36 us, 0.24 PF/s).  Slicing K puts several workgroups on every CU.
@@ -354,12 +362,13 @@ int gemm_classic(GemmDesc d, hipStream_t stream) {
     const int64_t wgs = cdiv(d.M, tile) * cdiv(d.N, tile) * d.nz;
     const int nkt = (int)cdiv(d.K, 64);
     int s = o.gemm_splitk > 1 ? o.gemm_splitk : 0;
-    if (s == 0 && d.nz == 1 && wgs <= 320 && nkt >= 16)
-      s = (int)std::min<int64_t>(8, std::min<int64_t>(nkt / 4, cdiv(1024, wgs)));
+    if (s == 0 && d.nz == 1 && (wgs <= 320 || longk) && nkt >= 16)
+      s = (int)std::min<int64_t>(8, std::min<int64_t>(nkt / 4, cdiv(longk ? 640 : 1024, wgs)));
     if (s > 1) {
       const Scratch sc = ctx().scratch_of(stream);
       const size_t slice = (size_t)d.nz * d.M * d.N * sizeof(float);
-      if (o.gemm_splitk <= 1) s = (int)std::min<size_t>(s, std::min<size_t>(sc.bytes, 24u << 20) / slice);  // partial sums cost HBM traffic
+      // partial sums cost HBM traffic: capped at 24 MB unless the K loop is long enough to dwarf it
+      if (o.gemm_splitk <= 1) s = (int)std::min<size_t>(s, (longk ? sc.bytes : std::min<size_t>(sc.bytes, 24u << 20)) / slice);
       const size_t need = (size_t)s * slice;
       if (s > 1 && sc.p && need <= sc.bytes && d.nz <= 65535) {
         d.ksplit = s;
@@ -370,6 +379,7 @@ int gemm_classic(GemmDesc d, hipStream_t stream) {
     }
     if (d.ksplit <= 1) d.ksplit = 1;
   }
+  if (longk && d.ksplit == 1) tile = 64;  // no scratch for the slices: the tile that fills the CUs
   const int e = tile == 128 ? launch_tile<128, 128>(d, stream) : launch_tile<64, 64>(d, stream);
   if (e != U2_OK || d.ksplit == 1) return e;
   const int64_t total = (int64_t)d.nz * d.M * ((d.N + 3) >> 2);
