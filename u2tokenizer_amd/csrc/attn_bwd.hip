@@ -27,7 +27,7 @@ struct FlashBwdArgs {
   const bf16_t *kt, *qt, *dot;         // permuted transposes (nb, H*64, S_pad)
   bf16_t *dq, *dk, *dv;
   float *lse, *dsum;  // (nb*H, S_pad)
-  int S, H, S_pad;
+  int S, H, S_pad, nblk, nwg;  // nblk: 128-row blocks per (batch, head); nwg = nb * H * nblk
   int64_t ld_qkv, bs_qkv, ld_o, bs_o, ld_d, bs_d;
   float scale, scale_log2e;
 };
@@ -47,6 +47,16 @@ __device__ __forceinline__ float dot8(const uint4 a, const uint4 b) {
   return s;
 }
 
+// XCD-aware order (as attn.hip): workgroup w runs on XCD w % 8; every XCD gets a contiguous range of logical ids so that
+// the blocks of one (batch, head) share that XCD's L2 copy of the operands they all stream (K, V, K^T resp. Q, dO, Q^T,
+// dO^T): with the plain (block, head) grid every head was fetched by all eight L2s -- 0.93 GB of fabric-side reads per
+// launch against 0.15 GB of operands (profiles/r02_kernel_pmc.json).
+__device__ __forceinline__ int xcd_order(int w, int nwg) {
+  const int qn = nwg >> 3, rn = nwg & 7;
+  const int xcd = w & 7, idx = w >> 3;
+  return (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+}
+
 union Frag {
   bf16x8 v;
   uint4 q;
@@ -61,9 +71,10 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const FlashBwdArgs
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
   const int S = a.S, S_pad = a.S_pad;
-  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int vid = xcd_order(blockIdx.x, a.nwg);
+  const int bh = vid / a.nblk, b = bh / a.H, h = bh - b * a.H;
   const float c = a.scale_log2e;
-  const int wrow0 = blockIdx.x * 128 + wv * 32;
+  const int wrow0 = (vid - bh * a.nblk) * 128 + wv * 32;
   const bool wave_active = wrow0 < S;
   const int qrow = min(wrow0 + l31, S - 1);
   const bf16_t* kb_ = a.k + (int64_t)b * a.bs_qkv + h * 64;
@@ -273,9 +284,10 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const FlashBwdArg
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
   const int S = a.S, S_pad = a.S_pad;
-  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int vid = xcd_order(blockIdx.x, a.nwg);
+  const int bh = vid / a.nblk, b = bh / a.H, h = bh - b * a.H;
   const float c = a.scale_log2e;
-  const int wkey0 = blockIdx.x * 128 + wv * 32;
+  const int wkey0 = (vid - bh * a.nblk) * 128 + wv * 32;
   const bool wave_active = wkey0 < S;
   const int krow = min(wkey0 + l31, S - 1);
   const int64_t ld = a.ld_qkv;
@@ -442,6 +454,7 @@ int flash_attention_d64_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, i
                             hipStream_t stream) {
   if (!q || !k || !v || !o || !dout || !dq || !dk || !dv || !workspace) return U2_ERR_ARG;
   if (nb <= 0 || S <= 0 || H <= 0 || !(scale > 0.f) || (int64_t)nb * H > 65535) return U2_ERR_ARG;
+  if ((int64_t)nb * H * ((S + 127) / 128) > 0x7fffffff) return U2_ERR_ARG;
   if ((ld_qkv & 7) || (bs_qkv & 7) || (ld_o & 7) || (bs_o & 7) || (ld_d & 3) || (bs_d & 3)) return U2_ERR_ARG;
   if (ld_qkv < (int64_t)H * 64 || ld_o < (int64_t)H * 64 || ld_d < (int64_t)H * 64) return U2_ERR_ARG;
   if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)dout) & 15) ||
@@ -471,7 +484,9 @@ int flash_attention_d64_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, i
   a.ld_qkv = ld_qkv; a.bs_qkv = bs_qkv; a.ld_o = ld_o; a.bs_o = bs_o; a.ld_d = ld_d; a.bs_d = bs_d;
   a.scale = scale;
   a.scale_log2e = scale * 1.44269504088896340736f;
-  const dim3 grid((unsigned)((S + 127) / 128), (unsigned)(nb * H));
+  a.nblk = (S + 127) / 128;
+  a.nwg = nb * H * a.nblk;
+  const dim3 grid((unsigned)a.nwg);
   const double unit = 2.0 * (double)nb * H * (double)S * S * 64;
   {
     ProfScope ps(PROF_FLASH, 4.0 * unit, stream, (double)nb * S * E * 2.0 * 6.0);
