@@ -54,7 +54,7 @@ u2tok_ctx_t u2tok_ctx_get_current(void);     /* NULL when the thread uses the de
     "gemm_tile" {0 heuristic, 64, 128: tile of the small-tile kernel}, "gemm_splitk" {-1 never, 0 heuristic, 2..16 force
     that many K slices where scratch allows}, "gemm_big" {-1 never, 0 heuristic, 20 / 21 force the 256x256 / 256x192
     big-tile kernel}, "gemm_big_grid" {persistent workgroups}, "gemm_big_gelu" {0, 1: GELU products may take the
-    big-tile kernel}, "gemm_ring" {-1 never, 0 heuristic, 1 always: 4-stage ring form of the 128 x 128 kernel},
+    big-tile kernel},
     "flash_mode" {0 pick, 1 plain 128-row units, 5 double pipeline (asm KV loop)}, "vit_flash" {0 unfused attention, 1}, "tta_overlap" {0, 1: side stream for the TTA k|v projections},
     "profile" {0, 1} */
 int u2tok_set_option(const char* name, int value);

@@ -298,41 +298,6 @@ def test_gemm_split_k(ops, split):
         torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("split", [-1, 0, 4])
-def test_gemm_ring_form(ops, split):
-    """The 4-stage ring form of the 128 x 128 kernel (three K tiles in flight, bare barrier behind a counted vmcnt wait):
-    forced on every shape incl. 1, 2, 3, 4, 5 and many K tiles (ring shorter than / equal to / longer than the K loop), K tails,
-    row / column tails, batched, every epilogue, with and without K slices; bit-repeatable."""
-    scratch = torch.empty(48 << 20, dtype=torch.uint8, device=D)
-    ops.set_gemm_scratch(scratch)
-    ops.set_option("gemm_tile", 128)
-    ops.set_option("gemm_ring", 1)
-    ops.set_option("gemm_splitk", split)
-    ops.set_option("gemm_big", -1)
-    try:
-        for (M, N, K) in [(128, 128, 64), (128, 128, 128), (130, 140, 192), (77, 520, 256), (300, 200, 328), (256, 2048, 2048),
-                          (256, 1000, 4096), (1, 8, 8), (2049, 768, 768), (256, 4096, 4096)]:
-            a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
-            ad, bd = a.to(D), b.to(D)
-            outs = [ops.gemm(ad, bd).clone() for _ in range(3)]
-            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (M, N, K)
-            close_bf16(outs[0], a.float() @ b.float().t())
-        M, N, K = 300, 264, 1096
-        a, b, bias, res, bm = rnd(M, K, seed=3), rnd(N, K, seed=4), rnd(N, seed=5), rnd(M, N, seed=6), rnd(M, seed=7)
-        base = a.float() @ b.float().t()
-        close_bf16(ops.gemm(a.to(D), b.to(D), bias=bias.to(D), residual=res.to(D), gelu=True),
-                   F.gelu(base + bias.float()) + res.float(), rounds=3)
-        close_f32(ops.gemm(a.to(D), b.to(D), bias=bias.to(D), out_f32=True, alpha=0.5), 0.5 * base + bias.float())
-        close_f32(ops.gemm(a.to(D), b.to(D), bias=bm.to(D), bias_m=True, out_f32=True), base + bm.float()[:, None])
-        a3, b3 = rnd(6, 100, 448, seed=10), rnd(6, 90, 448, seed=11)
-        close_f32(ops.gemm(a3.to(D), b3.to(D), out_f32=True), torch.einsum("zmk,znk->zmn", a3.float(), b3.float()))
-    finally:
-        for k in ("gemm_tile", "gemm_ring", "gemm_splitk", "gemm_big"):
-            ops.set_option(k, 0)
-        ops.set_gemm_scratch(None)
-        torch.cuda.synchronize()
-
-
 def test_gemm_ktile_major_weights(ops):
     """B handed over K-tile-major ([K/64][N][64], ops.pack_ktile_major): same products as the row-major weight, with and
     without split-K, tails in M and N."""

@@ -20,18 +20,16 @@ bf = torch.bfloat16
 scratch = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
 ops.set_gemm_scratch(scratch)
 g = torch.Generator(device=dev).manual_seed(0)
-for (M, N, K) in ((256, 4096, 4096), (256, 12288, 4096), (1024, 2048, 4096), (2048, 4096, 4096)):
+for (M, N, K) in ((256, 4096, 4096), (256, 12288, 4096)):
     a = torch.randn(M, K, device=dev, generator=g).to(bf)
     ws = [torch.randn(N, K, device=dev, generator=g).to(bf) for _ in range(16)]
     bias = torch.randn(N, device=dev, generator=g).to(bf)
     out = torch.empty((1, M, N), dtype=bf, device=dev)
     ref = None
     print(f"M={M} N={N} K={K}  (weights {N * K * 2 / 1e6:.0f} MB each, HBM floor at 5 TB/s {N * K * 2 / 5e6:.1f} us)")
-    for tile, sk, ring in ((0, 0, -1), (0, 0, 0), (64, 4, -1), (128, -1, -1), (128, 2, -1), (128, 4, -1), (128, 8, -1),
-                           (128, -1, 1), (128, 2, 1), (128, 4, 1), (128, 8, 1)):
+    for tile, sk in ((0, 0), (64, -1), (64, 2), (64, 4), (64, 8), (128, -1), (128, 2), (128, 4), (128, 8), (128, 16)):
         ops.set_option("gemm_tile", tile)
         ops.set_option("gemm_splitk", sk)
-        ops.set_option("gemm_ring", ring)
         ops.set_option("gemm_big", 0 if tile == 0 else -1)
         for i in range(16):
             ops.gemm(a, ws[i], bias=bias, out=out)
@@ -47,8 +45,6 @@ for (M, N, K) in ((256, 4096, 4096), (256, 12288, 4096), (1024, 2048, 4096), (20
         if ref is None:
             ref = out.float().clone()
         err = (out.float() - ref).abs().max().item()
-        name = ("heuristic" + (" (no ring)" if ring < 0 else "")) if tile == 0 else \
-            f"tile {tile} splitk {sk if sk > 0 else 1}" + (" ring" if ring > 0 else "")
+        name = "heuristic" if tile == 0 else f"tile {tile} splitk {sk if sk > 0 else 1}"
         print(f"   {name:22s} {us:7.1f} us  {2.0 * M * N * K / us / 1e6:6.0f} TF/s   max|diff vs heuristic| {err:.3e}")
-for k in ("gemm_tile", "gemm_splitk", "gemm_big", "gemm_ring"):
-    ops.set_option(k, 0)
+ops.set_option("gemm_tile", 0); ops.set_option("gemm_splitk", 0); ops.set_option("gemm_big", 0)

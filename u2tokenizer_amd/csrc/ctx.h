@@ -19,7 +19,6 @@ struct Options {
   int gemm_big = 0;         // -1 never, 0 heuristic, 20 / 21 force the 256x256 / 256x192 big-tile kernel
   int gemm_big_grid = 256;  // persistent workgroups of the big-tile kernel
   int gemm_big_gelu = 0;    // 1: GELU products may take the big-tile kernel too
-  int gemm_ring = 0;        // -1 never, 0 heuristic, 1 always: 4-stage ring form of the 128 x 128 kernel (one workgroup per CU)
   int flash_mode = 0;       // 0 pick, 1 plain 128-row units, 5 double pipeline (asm KV loop)
   int vit_flash = 1;        // 0: unfused ViT attention (debug)
   int tta_overlap = 1;      // k | v projections of the TTA cross attentions on a side stream

@@ -22,7 +22,6 @@
 #include <type_traits>
 #include <cstdio>
 #include <algorithm>
-#include <atomic>
 #include <cstdlib>
 #include "kernels.h"
 
@@ -37,7 +36,7 @@ __device__ __forceinline__ int lds_swz(int row) {
   return row & 7;
 }
 
-template <int BM, int BN, int STAGES = 2>
+template <int BM, int BN>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
   constexpr int BK = 64;
   constexpr int WM = BM / 2, WN = BN / 2;
@@ -149,34 +148,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
     }
   };
 
-  if constexpr (STAGES == 2) {
-    dma(kt0, kt0 & 1);
+  dma(kt0, kt0 & 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = kt0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) dma(kt + 1, (kt + 1) & 1);
+    compute(kt & 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int kt = kt0; kt < nkt; ++kt) {
-      if (kt + 1 < nkt) dma(kt + 1, (kt + 1) & 1);
-      compute(kt & 1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-  } else {
-    // Ring of STAGES tiles, STAGES - 1 of them in flight (the latency-bound K slices of skinny products: one workgroup per
-    // CU keeps 3 x 32 KB in flight instead of 2 workgroups x 1 tile).  vmcnt retires in order: tile kt has landed when at
-    // most the (STAGES - 2) tiles issued after it are outstanding; __syncthreads() would drain them all (its fence waits for
-    // vmcnt(0)), so the barrier is issued bare behind the counted wait.  The tile written in iteration kt was computed on in
-    // iteration kt - 1, which every wave has left once it passes this iteration's barrier.
-    constexpr int NPT = CA + CB;
-    static_assert((STAGES - 2) * NPT < 64, "vmcnt range");
-#pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
-      if (kt0 + s < nkt) dma(kt0 + s, s);
-    for (int kt = kt0; kt < nkt; ++kt) {
-      const int rel = kt - kt0;
-      if (kt + STAGES - 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((STAGES - 2) * NPT) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-      if (kt + STAGES - 1 < nkt) dma(kt + STAGES - 1, (rel + STAGES - 1) % STAGES);
-      compute(rel % STAGES);
-    }
   }
 
   // ---- epilogue: lane holds C[m][n0..n0+3], m = tile row (lane & 15), n0 = 4 * (lane >> 4) ----
@@ -319,24 +298,13 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmDesc d) {
   }
 }
 
-template <int BM, int BN, int STAGES = 2>
+template <int BM, int BN>
 static int launch_tile(GemmDesc d, hipStream_t stream) {
   d.tiles_m = (int)cdiv(d.M, BM);
   d.tiles_n = (int)cdiv(d.N, BN);
   dim3 grid(d.tiles_m * d.tiles_n, d.nz, d.ksplit > 1 ? d.ksplit : 1);
-  constexpr int smem = STAGES * (BM + BN) * 64 * 2;
-  if constexpr (smem > 65536) {  // more dynamic LDS than the default limit: raised once per device (idempotent)
-    static std::atomic<bool> raised[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return U2_ERR_LAUNCH;
-    if (!raised[dev].load(std::memory_order_acquire)) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_kernel<BM, BN, STAGES>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-        return U2_ERR_LAUNCH;
-      raised[dev].store(true, std::memory_order_release);
-    }
-  }
-  hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, STAGES>), grid, dim3(256), smem, stream, d);
+  constexpr int smem = 2 * (BM + BN) * 64 * 2;
+  hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN>), grid, dim3(256), smem, stream, d);
   return launch_status();
 }
 
@@ -412,34 +380,7 @@ int gemm_classic(GemmDesc d, hipStream_t stream) {
     if (d.ksplit <= 1) d.ksplit = 1;
   }
   if (longk && d.ksplit == 1) tile = 64;  // no scratch for the slices: the tile that fills the CUs
-  // Ring form: a product with at most ~one 128 x 128 tile (x K slice) per CU is latency-bound with two-stage buffering --
-  // every workgroup has ONE K tile in flight (M = 256, N = K = 4096: 16.8 MB across the chip against ~1 us of latency under
-  // cold weights, whatever the tile / slice combination: profiles/r02_skinny_probe.log).  One workgroup per CU with three
-  // 32 KB tiles in flight, and K sliced only as far as it takes to give every CU a workgroup.
-  bool ring = false;
-  if (o.gemm_ring > 0) {
-    ring = tile == 128;
-  } else if (o.gemm_ring == 0 && o.gemm_tile == 0 && o.gemm_splitk == 0 && d.nz == 1 && !longk) {
-    const int64_t t128 = cdiv(d.M, 128) * cdiv(d.N, 128);
-    const int nkt = (int)cdiv(d.K, 64);
-    if (t128 <= 288 && nkt >= 16) {
-      int s = (int)std::max<int64_t>(1, std::min<int64_t>(8, 288 / t128));
-      s = std::min(s, nkt / 8);
-      const Scratch sc = ctx().scratch_of(stream);
-      const size_t slice = (size_t)d.M * d.N * sizeof(float);
-      if (s > 1) s = sc.p ? (int)std::min<size_t>(s, std::min<size_t>(sc.bytes, 24u << 20) / slice) : 1;
-      tile = 128;
-      ring = true;
-      d.ksplit = 1;
-      if (s > 1) {
-        d.kt_per = (int)cdiv(nkt, s);
-        d.ksplit = (int)cdiv(nkt, d.kt_per);
-        d.partial = reinterpret_cast<float*>(sc.p);
-      }
-    }
-  }
-  const int e = ring ? launch_tile<128, 128, 4>(d, stream)
-                     : (tile == 128 ? launch_tile<128, 128>(d, stream) : launch_tile<64, 64>(d, stream));
+  const int e = tile == 128 ? launch_tile<128, 128>(d, stream) : launch_tile<64, 64>(d, stream);
   if (e != U2_OK || d.ksplit == 1) return e;
   const int64_t total = (int64_t)d.nz * d.M * ((d.N + 3) >> 2);
   hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, d);
