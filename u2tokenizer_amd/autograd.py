@@ -6,8 +6,9 @@ autograd the same kernels are sequenced from here, op by op, so that every op ca
   * GEMM-shaped work -- forward AND backward -- runs on the library's MFMA kernels: y = x W^T (+ b, + residual) through
     u2tok_gemm_bf16; dX = dY W and dW = dY^T X as the same NT product on transposed operands (u2tok_transpose_bf16);
     the attention cores' dP = dO V^T, dV = P^T dO, dQ = dS K, dK = dS^T Q likewise, batched over (batch, head);
-  * attention backward is recompute-based for the ViT: the forward is the flash kernel (no S x S tensor), the backward
-    rebuilds the probabilities of one layer at a time with the unfused core (scores GEMM + row softmax);
+  * the ViT attention is flash both ways: the forward kernel keeps no S x S tensor, the backward is the fused kernel pair
+    of csrc/attn_bwd.hip, which rebuilds the probabilities tile by tile from q, k and the saved output (the unfused chain
+    -- scores GEMM + row softmax + batched products -- serves the tokenizer's d = E/8 cores and as the cross-check);
   * the non-GEMM pieces are the kernels of csrc/backward.hip (GELU, LayerNorm, softmax, relative-bias table, column
     sums);
   * torch itself only moves data (views, permutes, cat / split, residual adds, the scatter of the hard top-k gather)
@@ -429,9 +430,43 @@ class AvgPool3dFn(Function):
 
 
 # ================================================================================================ module forwards
+class _AliasCatFn(Function):
+    """torch.cat(parts, 0) for parameters that ALREADY lie back to back in one storage (u2Tokenizer.pack_weights() points
+    wq | wk | wv at slices of one packed buffer): the forward is a zero-copy view of that storage, the backward hands every
+    part its rows of the gradient.  (torch.cat copied 100 MB per attention module and step at E = 4096.)"""
+
+    @staticmethod
+    def forward(ctx, *parts):
+        ctx.rows = [p.shape[0] for p in parts]
+        base = parts[0].detach()
+        shape = (sum(ctx.rows),) + tuple(base.shape[1:])
+        return base.as_strided(shape, base.stride())
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g.split(ctx.rows, 0))
+
+
+def _cat_rows(parts):
+    """Rows of `parts` stacked: a view when they are contiguous neighbours in one storage, torch.cat otherwise."""
+    p0 = parts[0]
+    adjacent = all(p.is_contiguous() and p.dtype == p0.dtype and p.device == p0.device and p.shape[1:] == p0.shape[1:]
+                   for p in parts)
+    if adjacent:
+        end = p0.data_ptr() + p0.numel() * p0.element_size()
+        for p in parts[1:]:
+            adjacent = adjacent and p.data_ptr() == end
+            end = p.data_ptr() + p.numel() * p.element_size()
+        if adjacent:
+            st = p0.untyped_storage()
+            adjacent = end <= st.data_ptr() + st.nbytes() and all(
+                p.untyped_storage().data_ptr() == st.data_ptr() for p in parts[1:])
+    return _AliasCatFn.apply(*parts) if adjacent else torch.cat(list(parts), 0)
+
+
 def _qkv_params(m):
-    """(W (3E, E), b (3E,)) of an attention module: cat of wq | wk | wv -- autograd routes the gradient back."""
-    return torch.cat([m.wq.weight, m.wk.weight, m.wv.weight], 0), torch.cat([m.wq.bias, m.wk.bias, m.wv.bias], 0)
+    """(W (3E, E), b (3E,)) of an attention module: wq | wk | wv stacked -- autograd routes the gradient back."""
+    return _cat_rows((m.wq.weight, m.wk.weight, m.wv.weight)), _cat_rows((m.wq.bias, m.wk.bias, m.wv.bias))
 
 
 def _self_attention(m, x, attn_type: str, H: int):
@@ -452,7 +487,7 @@ def _cross_attention(m, query, value, H: int):
     """MultiHeadCrossAttention forward (tta.py:42-69), is_compress = False."""
     E = query.shape[-1]
     q = linear(query, m.wq.weight, m.wq.bias)
-    kv = linear(value, torch.cat([m.wk.weight, m.wv.weight], 0), torch.cat([m.wk.bias, m.wv.bias], 0))
+    kv = linear(value, _cat_rows((m.wk.weight, m.wv.weight)), _cat_rows((m.wk.bias, m.wv.bias)))
     ctxv = CrossAttnFn.apply(q, kv, H, 1.0 / math.sqrt(E // H))
     return linear(ctxv, m.dense.weight, m.dense.bias)
 

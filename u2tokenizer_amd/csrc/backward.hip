@@ -143,16 +143,26 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __res
 }
 
 // out[c] (+)= sum_s part[s][c]; out_bf16 (optional) receives the rounded result as well.  A workgroup owns 32 columns;
-// its 8 thread groups add slabs g, g + 8, ... and the eight partial sums are added in order (bit-repeatable).
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ out,
+// its 8 thread groups add slabs g, g + 8, ... (two interleaved chains each) and the partial sums are added in a fixed order
+// (bit-repeatable).  blockIdx.y selects one of up to two problems of the same shape (dw and db of a LayerNorm backward).
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part_a, float* __restrict__ out_a,
+                                                            const float* __restrict__ part_b, float* __restrict__ out_b,
                                                             bf16_t* __restrict__ out_bf16, int nslab, int C, int accumulate) {
   __shared__ float red[8][32];
+  const float* __restrict__ part = blockIdx.y ? part_b : part_a;
+  float* __restrict__ out = blockIdx.y ? out_b : out_a;
   const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
-  float a = 0.f;
-  if (c < C)
-    for (int s = g; s < nslab; s += 8) a += part[(int64_t)s * C + c];
-  red[g][cl] = a;
+  float a0 = 0.f, a1 = 0.f;
+  if (c < C) {
+    int s = g;
+    for (; s + 8 < nslab; s += 16) {
+      a0 += part[(int64_t)s * C + c];
+      a1 += part[(int64_t)(s + 8) * C + c];
+    }
+    if (s < nslab) a0 += part[(int64_t)s * C + c];
+  }
+  red[g][cl] = a0 + a1;
   __syncthreads();
   if (g == 0 && c < C) {
     float t = red[0][cl];
@@ -160,13 +170,18 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
     for (int i = 1; i < 8; ++i) t += red[i][cl];
     if (accumulate) t += out[c];
     if (out) out[c] = t;
-    if (out_bf16) out_bf16[c] = f32_to_bf16(t);
+    if (out_bf16 && blockIdx.y == 0) out_bf16[c] = f32_to_bf16(t);
   }
 }
 
 static void colsum_finish(const float* part, float* out, bf16_t* out_bf16, int nslab, int C, int accumulate, hipStream_t st) {
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)cdiv(C, 32)), dim3(256), 0, st, part, out, out_bf16, nslab, C,
-                     accumulate);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)cdiv(C, 32), 1), dim3(256), 0, st, part, out,
+                     (const float*)nullptr, (float*)nullptr, out_bf16, nslab, C, accumulate);
+}
+static void colsum_finish2(const float* part_a, float* out_a, const float* part_b, float* out_b, int nslab, int C,
+                           int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)cdiv(C, 32), 2), dim3(256), 0, st, part_a, out_a, part_b, out_b,
+                     (bf16_t*)nullptr, nslab, C, accumulate);
 }
 
 size_t colsum_workspace_bytes(int rows, int C) {
@@ -341,8 +356,7 @@ int layernorm_bwd(const bf16_t* x, const bf16_t* res, const bf16_t* w, const bf1
   else if (C <= 2048) U2_LNB(4);
   else U2_LNB(8);
 #undef U2_LNB
-  colsum_finish(pw, dw, nullptr, nwg, C, accumulate, st);
-  colsum_finish(pb, db, nullptr, nwg, C, accumulate, st);
+  colsum_finish2(pw, dw, pb, db, nwg, C, accumulate, st);
   return launch_status();
 }
 
