@@ -206,7 +206,10 @@ int u2tok_preprocess_volume_aug(const float* vol, void* out, int32_t* info, int3
 /* ---- building blocks (exported for the parity tests; same kernels the pipelines launch) -------- */
 
 /* C[z] = epi(alpha * A[z] B[z]^T): A (M,K) lda, B (N,K) ldb, C (M,N) ldc; z = zb*nbh + zh with element strides.
- * flags: 1 bias[n], 2 bias[m], 4 GELU(erf), 8 + R[m][n], 16 C is fp32 (else bf16). */
+ * flags: 1 bias[n], 2 bias[m], 4 GELU(erf), 8 + R[m][n], 16 C is fp32 (else bf16), 64 B is K-tile-major [K/64][N][64],
+ * 256 B is stored K-major, (K,N) with ldb >= N (C = A B: the input-gradient product dX = dY W without a transposed W),
+ * 128 | 256 A is stored K-major too, (K,M) with lda >= M (C = A^T B: the weight-gradient product dW = dY^T X without
+ * transposed activations); the K-major dimension (M resp. N) must be a multiple of 8. */
 int u2tok_gemm_bf16(const void* A, const void* B, void* C, const void* bias, const void* R, int32_t M, int32_t N,
                     int32_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int32_t nz, int32_t nbh,
                     int64_t sAb, int64_t sAh, int64_t sBb, int64_t sBh, int64_t sCb, int64_t sCh, int64_t sRb,

@@ -298,6 +298,39 @@ def test_gemm_split_k(ops, split):
         torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("tile", [0, 64, 128])
+def test_gemm_kmajor_operands(ops, tile):
+    """K-major operand forms (ds_read_b64_tr_b16 fragments): C = A B with B (K, N) and C = A^T B with A (K, M), B (K, N) --
+    the dX / dW products of the training path -- on random (transpose-detecting) data: row / column tails of both tile
+    sizes, K that is no multiple of the K tile (and, with both operands K-major, of nothing), K slices, bit-repeatable."""
+    scratch = torch.empty(64 << 20, dtype=torch.uint8, device=D)
+    ops.set_gemm_scratch(scratch)
+    ops.set_option("gemm_tile", tile)
+    try:
+        for sk in (-1, 0, 3):
+            ops.set_option("gemm_splitk", sk)
+            for (M, N, K) in [(128, 128, 64), (200, 72, 136), (8, 520, 1160), (264, 8, 72), (2049, 768, 768), (256, 1000, 2048)]:
+                a, bk = rnd(M, K, seed=1), rnd(K, N, seed=2)
+                got = ops.gemm_kmajor(a.to(D), bk.to(D), a_kmajor=False)
+                close_bf16(got, a.float() @ bk.float())
+                assert torch.equal(got, ops.gemm_kmajor(a.to(D), bk.to(D), a_kmajor=False))
+            for (M, N, K) in [(128, 128, 64), (72, 200, 131), (520, 8, 1157), (8, 264, 77), (768, 2304, 2049), (1000, 256, 4100),
+                              (768, 768, 16392)]:
+                ak, bk = rnd(K, M, seed=3), rnd(K, N, seed=4)
+                got = ops.gemm_kmajor(ak.to(D), bk.to(D), a_kmajor=True)
+                close_bf16(got, ak.float().t() @ bk.float())
+                assert torch.equal(got, ops.gemm_kmajor(ak.to(D), bk.to(D), a_kmajor=True))
+        ak, bk = rnd(300, 264, seed=5), rnd(300, 200, seed=6)
+        close_f32(ops.gemm_kmajor(ak.to(D), bk.to(D), a_kmajor=True, alpha=0.5, out_f32=True), 0.5 * ak.float().t() @ bk.float())
+        with pytest.raises(RuntimeError):
+            ops.gemm_kmajor(rnd(64, 64, seed=7).to(D), rnd(64, 12, seed=8).to(D), a_kmajor=False)   # N % 8 != 0
+    finally:
+        ops.set_option("gemm_tile", 0)
+        ops.set_option("gemm_splitk", 0)
+        ops.set_gemm_scratch(None)
+        torch.cuda.synchronize()
+
+
 def test_gemm_ktile_major_weights(ops):
     """B handed over K-tile-major ([K/64][N][64], ops.pack_ktile_major): same products as the row-major weight, with and
     without split-K, tails in M and N."""

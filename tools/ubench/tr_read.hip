@@ -21,7 +21,8 @@ __global__ void k(unsigned short* out, int pattern) {
   for (int i = threadIdx.x; i < 8192; i += 64) lds[i] = (unsigned short)i;
   __syncthreads();
   const int l = threadIdx.x;
-  const unsigned addr = pattern_addr(pattern, l);
+  // the LDS base goes through the asm operand: an array whose address never escapes may lose its stores
+  const unsigned addr = (unsigned)(uintptr_t)(&lds[0]) + pattern_addr(pattern, l);
   unsigned long long r;
   asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(addr) : "memory");
   for (int j = 0; j < 4; ++j) out[l * 4 + j] = (unsigned short)(r >> (16 * j));

@@ -4,8 +4,9 @@ Inference (torch.no_grad) runs each module as ONE fused launch sequence inside l
 autograd the same kernels are sequenced from here, op by op, so that every op can save what its backward needs:
 
   * GEMM-shaped work -- forward AND backward -- runs on the library's MFMA kernels: y = x W^T (+ b, + residual) through
-    u2tok_gemm_bf16; dX = dY W and dW = dY^T X as the same NT product on transposed operands (u2tok_transpose_bf16);
-    the attention cores' dP = dO V^T, dV = P^T dO, dQ = dS K, dK = dS^T Q likewise, batched over (batch, head);
+    u2tok_gemm_bf16; dX = dY W and dW = dY^T X through the same kernel's K-major operand forms (LDS transpose reads: no
+    transposed copy of W, dY or X in HBM); the tokenizer attention cores' dP = dO V^T, dV = P^T dO, dQ = dS K,
+    dK = dS^T Q as NT products on operands transposed by u2tok_transpose_bf16, batched over (batch, head);
   * the ViT attention is flash both ways: the forward kernel keeps no S x S tensor, the backward is the fused kernel pair
     of csrc/attn_bwd.hip, which rebuilds the probabilities tile by tile from q, k and the saved output (the unfused chain
     -- scores GEMM + row softmax + batched products -- serves the tokenizer's d = E/8 cores and as the cross-check);
@@ -33,12 +34,6 @@ BF = torch.bfloat16
 
 def _r8(n: int) -> int:
     return (n + 7) // 8 * 8
-
-
-def _t2(x: torch.Tensor) -> torch.Tensor:
-    """(R, C) dense bf16 -> (C, R rounded up to 8) transposed, zero padded."""
-    R, C = x.shape
-    return ops.transpose_ex(x, 1, R, C, C, 0)[0]
 
 
 _scratch = {}
@@ -84,10 +79,11 @@ class LinearFn(Function):
         dy2 = dy.reshape(-1, N).contiguous()
         dz = ops.gelu_bwd(z, dy2) if z is not None else dy2
         dx = dw = db = dres = None
+        # K-major operand forms of the GEMM kernel (LDS transpose reads): no transposed copies of W, dY or X in HBM
         if ctx.needs_input_grad[0]:
-            dx = ops.gemm(dz, _t2(w)).view(ctx.xshape)          # (M, N) (K, N)^T
+            dx = ops.gemm_kmajor(dz, w, a_kmajor=False).view(ctx.xshape)     # (M, N_out) @ (N_out, K_in)
         if ctx.needs_input_grad[1]:
-            dw = ops.gemm(_t2(dz), _t2(x2))                      # (N, M) (K, M)^T
+            dw = ops.gemm_kmajor(dz, x2, a_kmajor=True)                      # (M, N_out)^T @ (M, K_in)
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = ops.colsum(dz)
         if ctx.has_res and ctx.needs_input_grad[3]:

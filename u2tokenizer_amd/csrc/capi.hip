@@ -162,7 +162,7 @@ int u2tok_gemm_bf16(const void* A, const void* B, void* C, const void* bias, con
   g.nz = nz; g.nbh = nbh;
   g.sAb = sAb; g.sAh = sAh; g.sBb = sBb; g.sBh = sBh; g.sCb = sCb; g.sCh = sCh; g.sRb = sRb; g.sRh = sRh;
   g.alpha = alpha;
-  g.flags = flags & (GEMM_BIAS_N | GEMM_BIAS_M | GEMM_GELU | GEMM_RESIDUAL | GEMM_OUT_F32);
+  g.flags = flags & (GEMM_BIAS_N | GEMM_BIAS_M | GEMM_GELU | GEMM_RESIDUAL | GEMM_OUT_F32 | GEMM_A_KMAJOR | GEMM_B_KMAJOR);
   if (flags & GEMM_B_KTILE) {
     if ((K & 63) || nz != 1) return U2_ERR_ARG;
     g.ldb = 64;

@@ -36,7 +36,24 @@ __device__ __forceinline__ int lds_swz(int row) {
   return row & 7;
 }
 
-template <int BM, int BN>
+// K-major operands (TA / TB; the weight-gradient and input-gradient products of the training path, whose operands would
+// otherwise be transposed in HBM first): the operand is stored [K][rows] (row index = k, the M resp. N index contiguous).
+// Its LDS tile is [64 k][BX] with 16-byte chunks (8 consecutive m) rotated inside the k row by kmaj_rot(k), and the MFMA
+// fragment (8 consecutive k of one m) is gathered by two ds_read_b64_tr_b16: a 16-lane group reads a [4 k][16 m] block --
+// lane a supplies the address of row a >> 2, 8-byte piece a & 3 and receives column a of the four rows
+// (tools/ubench/tr_read.hip prints the instruction's mapping) -- so a lane ends up with k = 8 (lane >> 4) + {0..7} of column
+// lane & 15, the same k-slot order as a K-contiguous fragment (the two forms mix freely as A and B).
+// The rotation keeps the 16 chunks that the two 16-lane groups of a half wave touch (rows k..k+3 and k+8..k+11, two chunks
+// each) in 16 different 16-byte slots of the 256-byte bank row.
+template <int CPRX>  // chunks per k row: 16 (128-wide tile) or 8 (64-wide tile, two k rows per bank row)
+__device__ __forceinline__ int kmaj_rot(int k) {
+  if constexpr (CPRX == 16) return 2 * (k & 3) + 8 * ((k >> 3) & 1);
+  else return 2 * ((k >> 1) & 1) + 4 * ((k >> 3) & 1);
+}
+
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+
+template <int BM, int BN, bool TA = false, bool TB = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
   constexpr int BK = 64;
   constexpr int WM = BM / 2, WN = BN / 2;
@@ -76,22 +93,45 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
   const bf16_t* __restrict__ B = d.B + zb * d.sBb + zh * d.sBh;
 
   // ---- per-thread global source pointers (row clamped, swizzled chunk folded in) ----
+  // K-contiguous operand: chunk c of the tile = (row c / 8, k chunk c % 8); K-major operand: (k row c / CPRX, slot c % CPRX)
+  // holding the 8 columns  ((slot - rot(k)) mod CPRX) * 8.  ka / kb: k offset inside a K tile (tail mask); oka / okb: the
+  // chunk exists at all (columns past M / N of a K-major operand read the zero chunk).
+  constexpr int CPRA = BM / 8, CPRB = BN / 8;
   const bf16_t* pa[CA];
   const bf16_t* pb[CB];
-  int ka[CA], kb[CB];  // k offset of the thread's chunk inside a K tile
+  int ka[CA], kb[CB];
+  bool oka[CA], okb[CB];
 #pragma unroll
   for (int i = 0; i < CA; ++i) {
-    const int c = i * 256 + tid, row = c / CPR, gc = (c % CPR) ^ lds_swz<BK>(row);
-    const int grow = min(bm0 + row, d.M - 1);
-    ka[i] = gc * 8;
-    pa[i] = A + (int64_t)grow * d.lda + gc * 8;
+    const int c = i * 256 + tid;
+    if constexpr (TA) {
+      const int krow = c / CPRA, cc = ((c % CPRA) - kmaj_rot<CPRA>(krow)) & (CPRA - 1);
+      ka[i] = krow;
+      oka[i] = bm0 + cc * 8 < d.M;
+      pa[i] = A + (int64_t)krow * d.lda + bm0 + cc * 8;
+    } else {
+      const int row = c / CPR, gc = (c % CPR) ^ lds_swz<BK>(row);
+      const int grow = min(bm0 + row, d.M - 1);
+      ka[i] = gc * 8;
+      oka[i] = true;
+      pa[i] = A + (int64_t)grow * d.lda + gc * 8;
+    }
   }
 #pragma unroll
   for (int i = 0; i < CB; ++i) {
-    const int c = i * 256 + tid, row = c / CPR, gc = (c % CPR) ^ lds_swz<BK>(row);
-    const int grow = min(bn0 + row, d.N - 1);
-    kb[i] = gc * 8;
-    pb[i] = B + (int64_t)grow * d.ldb + gc * 8;
+    const int c = i * 256 + tid;
+    if constexpr (TB) {
+      const int krow = c / CPRB, cc = ((c % CPRB) - kmaj_rot<CPRB>(krow)) & (CPRB - 1);
+      kb[i] = krow;
+      okb[i] = bn0 + cc * 8 < d.N;
+      pb[i] = B + (int64_t)krow * d.ldb + bn0 + cc * 8;
+    } else {
+      const int row = c / CPR, gc = (c % CPR) ^ lds_swz<BK>(row);
+      const int grow = min(bn0 + row, d.N - 1);
+      kb[i] = gc * 8;
+      okb[i] = true;
+      pb[i] = B + (int64_t)grow * d.ldb + gc * 8;
+    }
   }
 
   f32x4 acc[MI][NI];
@@ -105,10 +145,32 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
   int foff[KSTEPS];
 #pragma unroll
   for (int kk = 0; kk < KSTEPS; ++kk) foff[kk] = (((kk * 4 + (lane >> 4)) ^ lds_swz<BK>(lane & 15)) << 4);
+  // K-major fragments: lane a = lane & 15 of its 16-lane group addresses k row 8 (lane >> 4) + (a >> 2) (+ 4 for the second
+  // read, + 32 per k step), 8-byte piece a & 3 of the fragment's two chunks; rot() of that row does not depend on the +4 /
+  // +32, so the per-lane part is one offset per fragment.
+  int fta[TA ? MI : 1], ftb[TB ? NI : 1];
+  {
+    const int a = lane & 15, krow = 8 * (lane >> 4) + (a >> 2);
+    if constexpr (TA) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int cc = (wm * WM + mi * 16) / 8 + ((a & 3) >> 1);
+        fta[mi] = (krow * CPRA + ((cc + kmaj_rot<CPRA>(krow)) & (CPRA - 1))) * 16 + (a & 1) * 8;
+      }
+    }
+    if constexpr (TB) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int cc = (wn * WN + ni * 16) / 8 + ((a & 3) >> 1);
+        ftb[ni] = (krow * CPRB + ((cc + kmaj_rot<CPRB>(krow)) & (CPRB - 1))) * 16 + (a & 1) * 8;
+      }
+    }
+  }
 
   // elements between consecutive K tiles of a B row: BK for row-major weights, N * BK for "K-tile-major" packed ones
-  // ([K / 64][N][64]: the 64 x 64 tile a workgroup stages per K step is one contiguous 8 KB block)
-  const int64_t kadv_b = d.ldbk ? d.ldbk : BK;
+  // ([K / 64][N][64]: the 64 x 64 tile a workgroup stages per K step is one contiguous 8 KB block); K-major: BK rows
+  [[maybe_unused]] const int64_t kadv_a = BK * d.lda;
+  const int64_t kadv_b = TB ? BK * d.ldb : (d.ldbk ? d.ldbk : BK);
   const int nkt_all = (d.K + BK - 1) / BK;
   const int kt0 = (d.ksplit > 1) ? (int)blockIdx.z * d.kt_per : 0;   // split-K: this slice's K tiles
   const int nkt = (d.ksplit > 1) ? min(nkt_all, kt0 + d.kt_per) : nkt_all;
@@ -117,29 +179,54 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
     char* s = lds + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < CA; ++i) {
-      const void* src = (k0 + ka[i] < d.K) ? (const void*)(pa[i] + k0) : (const void*)&g_zero16;
+      const void* src;
+      if constexpr (TA) src = (oka[i] && k0 + ka[i] < d.K) ? (const void*)(pa[i] + (int64_t)kt * kadv_a) : (const void*)&g_zero16;
+      else src = (k0 + ka[i] < d.K) ? (const void*)(pa[i] + k0) : (const void*)&g_zero16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(s + (i * 256 + wave * 64) * 16),
                                        16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < CB; ++i) {
-      const void* src = (k0 + kb[i] < d.K) ? (const void*)(pb[i] + (int64_t)kt * kadv_b) : (const void*)&g_zero16;
+      const void* src;
+      if constexpr (TB) src = (okb[i] && k0 + kb[i] < d.K) ? (const void*)(pb[i] + (int64_t)kt * kadv_b) : (const void*)&g_zero16;
+      else src = (k0 + kb[i] < d.K) ? (const void*)(pb[i] + (int64_t)kt * kadv_b) : (const void*)&g_zero16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(s + BM * ROWB + (i * 256 + wave * 64) * 16),
                                        16, 0, 0);
     }
   };
   auto compute = [&](int buf) {
-    const char* sA = lds + buf * STAGE + (wm * WM) * ROWB + frow;
-    const char* sB = lds + buf * STAGE + BM * ROWB + (wn * WN) * ROWB + frow;
+    const char* tA = lds + buf * STAGE;                    // A tile base ([BM][64] or [64][BM])
+    const char* tB = lds + buf * STAGE + BM * ROWB;        // B tile base (both forms are (BM resp. BN) * 128 bytes)
+    const char* sA = tA + (wm * WM) * ROWB + frow;
+    const char* sB = tB + (wn * WN) * ROWB + frow;
+    typedef __attribute__((address_space(3))) v4s_t* lds_v4;
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; ++kk) {
       bf16x8 xf[MI], wf[NI];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) xf[mi] = *reinterpret_cast<const bf16x8*>(sA + mi * 16 * ROWB + foff[kk]);
+      for (int mi = 0; mi < MI; ++mi) {
+        if constexpr (TA) {
+          const char* q = tA + fta[mi] + kk * (32 * CPRA * 16);
+          const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)q);
+          const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(q + 4 * CPRA * 16));
+          xf[mi] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        } else {
+          xf[mi] = *reinterpret_cast<const bf16x8*>(sA + mi * 16 * ROWB + foff[kk]);
+        }
+      }
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const bf16x8*>(sB + ni * 16 * ROWB + foff[kk]);
+      for (int ni = 0; ni < NI; ++ni) {
+        if constexpr (TB) {
+          const char* q = tB + ftb[ni] + kk * (32 * CPRB * 16);
+          const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)q);
+          const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(q + 4 * CPRB * 16));
+          wf[ni] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        } else {
+          wf[ni] = *reinterpret_cast<const bf16x8*>(sB + ni * 16 * ROWB + foff[kk]);
+        }
+      }
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -304,7 +391,10 @@ static int launch_tile(GemmDesc d, hipStream_t stream) {
   d.tiles_n = (int)cdiv(d.N, BN);
   dim3 grid(d.tiles_m * d.tiles_n, d.nz, d.ksplit > 1 ? d.ksplit : 1);
   constexpr int smem = 2 * (BM + BN) * 64 * 2;
-  hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN>), grid, dim3(256), smem, stream, d);
+  const bool ta = d.flags & GEMM_A_KMAJOR, tb = d.flags & GEMM_B_KMAJOR;
+  if (ta) hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, true, true>), grid, dim3(256), smem, stream, d);
+  else if (tb) hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, false, true>), grid, dim3(256), smem, stream, d);
+  else hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN>), grid, dim3(256), smem, stream, d);
   return launch_status();
 }
 
@@ -314,9 +404,14 @@ int gemm_bf16(GemmDesc d, hipStream_t stream) {
   if (d.nbh <= 0) d.nbh = 1;
   static const bool trace = getenv("U2TOK_GEMM_TRACE") != nullptr;  // diagnostics: one line per product on stderr
   if (trace) fprintf(stderr, "gemm M=%d N=%d K=%d nz=%d flags=0x%x lda=%d ldb=%d ldc=%d\n", d.M, d.N, d.K, d.nz, d.flags, (int)d.lda, (int)d.ldb, (int)d.ldc);
-  // 16-byte chunked K loads: K, leading dims and batch strides must keep every chunk aligned
-  if ((d.K & 7) || (d.lda & 7) || (d.ldb & 7) || (d.sAb & 7) || (d.sAh & 7) || (d.sBb & 7) || (d.sBh & 7))
-    return U2_ERR_ARG;
+  // 16-byte chunked loads along the contiguous dimension of each operand (K, or M / N of a K-major one): that dimension,
+  // leading dims and batch strides must keep every chunk aligned
+  const bool ta = d.flags & GEMM_A_KMAJOR, tb = d.flags & GEMM_B_KMAJOR;
+  if ((ta && !tb) || (tb && d.ldbk)) return U2_ERR_ARG;
+  if ((ta ? d.M : d.K) & 7) return U2_ERR_ARG;
+  if ((tb ? d.N : d.K) & 7) return U2_ERR_ARG;
+  if ((ta && d.lda < d.M) || (tb && d.ldb < d.N)) return U2_ERR_ARG;
+  if ((d.lda & 7) || (d.ldb & 7) || (d.sAb & 7) || (d.sAh & 7) || (d.sBb & 7) || (d.sBh & 7)) return U2_ERR_ARG;
   if (((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15)) return U2_ERR_ARG;
   if ((d.flags & (GEMM_BIAS_N | GEMM_BIAS_M)) && !d.bias) return U2_ERR_ARG;
   if ((d.flags & GEMM_RESIDUAL) && !d.R) return U2_ERR_ARG;

@@ -297,7 +297,7 @@ static int bt_pick(const GemmDesc& d) {
 int gemm_big_try(const GemmDesc& d, hipStream_t stream) {
   const int mode = opts().gemm_big;
   if (mode < 0) return 0;
-  if (!(d.flags & GEMM_VEC_OK) || (d.flags & GEMM_BIAS_M) || (d.N & 7)) return 0;
+  if (!(d.flags & GEMM_VEC_OK) || (d.flags & (GEMM_BIAS_M | GEMM_A_KMAJOR | GEMM_B_KMAJOR)) || (d.N & 7)) return 0;
   switch (d.flags & (GEMM_BIAS_N | GEMM_GELU | GEMM_RESIDUAL | GEMM_OUT_F32)) {
     case 0: case GEMM_OUT_F32: case GEMM_BIAS_N: case GEMM_BIAS_N | GEMM_OUT_F32: case GEMM_BIAS_N | GEMM_GELU:
     case GEMM_BIAS_N | GEMM_RESIDUAL: case GEMM_RESIDUAL: break;

@@ -30,11 +30,13 @@ enum : int {
   GEMM_OUT_F32 = 16,   // C is float32 instead of bf16
   GEMM_VEC_OK = 32,    // internal: vector epilogue legal (set by the launcher)
   GEMM_B_KTILE = 64,   // C-ABI only: B is K-tile-major [K/64][N][64] (pack_ktile_major); K % 64 == 0, nz == 1
+  GEMM_A_KMAJOR = 128, // A is stored [K][M] (leading dim lda >= M, M % 8 == 0): C = A^T B^T-form products without a transpose
+  GEMM_B_KMAJOR = 256, // B is stored [K][N] (leading dim ldb >= N, N % 8 == 0); A K-major requires B K-major too
 };
 
 struct GemmDesc {
-  const bf16_t* A = nullptr;  // [M][K] row-major, leading dim lda
-  const bf16_t* B = nullptr;  // [N][K] row-major, leading dim ldb
+  const bf16_t* A = nullptr;  // [M][K] row-major, leading dim lda ([K][M] with GEMM_A_KMAJOR)
+  const bf16_t* B = nullptr;  // [N][K] row-major, leading dim ldb ([K][N] with GEMM_B_KMAJOR)
   void* C = nullptr;          // [M][N] bf16 or f32, leading dim ldc
   const bf16_t* bias = nullptr;
   const bf16_t* R = nullptr;  // [M][N] bf16, leading dim ldr

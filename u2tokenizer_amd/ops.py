@@ -138,6 +138,7 @@ def vol_dtype_code(dtype) -> int:
 
 
 GEMM_B_KTILE = 64
+GEMM_A_KMAJOR, GEMM_B_KMAJOR = 128, 256
 
 
 def pack_ktile_major(w: torch.Tensor) -> torch.Tensor:
@@ -192,6 +193,27 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, bias_m=F
                            _stream())
     _lib.check(st, "u2tok_gemm_bf16")
     return out.reshape(*a.shape[:-1], N) if b.dim() == 2 else out
+
+
+@_guarded
+def gemm_kmajor(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool, alpha=1.0, out_f32=False) -> torch.Tensor:
+    """Products with K-major operands (no transposes in HBM; u2tok_gemm_bf16 flags 128 / 256):
+         a_kmajor = False:  C (M, N) = A (M, K) @ B (K, N)          -- dX = dY W
+         a_kmajor = True:   C (M, N) = A (K, M)^T @ B (K, N)        -- dW = dY^T X
+    Dense 2-D bf16 operands; the K-major dimensions (N, and M when a_kmajor) must be multiples of 8."""
+    h = _lib.load_library()
+    a = _need(a, torch.bfloat16, "A").contiguous()
+    b = _need(b, torch.bfloat16, "B").contiguous()
+    K, N = b.shape
+    M = a.shape[1] if a_kmajor else a.shape[0]
+    if (a.shape[0] if a_kmajor else a.shape[1]) != K:
+        raise RuntimeError(f"gemm_kmajor: contraction sizes differ ({tuple(a.shape)}, {tuple(b.shape)}, a_kmajor={a_kmajor})")
+    out = torch.empty((M, N), dtype=torch.float32 if out_f32 else torch.bfloat16, device=a.device)
+    flags = GEMM_B_KMAJOR | (GEMM_A_KMAJOR if a_kmajor else 0) | (GEMM_OUT_F32 if out_f32 else 0)
+    st = h.u2tok_gemm_bf16(_ptr(a), _ptr(b), _ptr(out), None, None, M, N, K, a.shape[1], N, N, N, 1, 1,
+                           0, 0, 0, 0, 0, 0, 0, 0, float(alpha), flags, _stream())
+    _lib.check(st, "u2tok_gemm_bf16")
+    return out
 
 
 def set_gemm_scratch(buf: Optional[torch.Tensor]) -> None:
