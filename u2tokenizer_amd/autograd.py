@@ -79,9 +79,14 @@ class LinearFn(Function):
         dy2 = dy.reshape(-1, N).contiguous()
         dz = ops.gelu_bwd(z, dy2) if z is not None else dy2
         dx = dw = db = dres = None
-        # K-major operand forms of the GEMM kernel (LDS transpose reads): no transposed copies of W, dY or X in HBM
+        # K-major operand forms of the GEMM kernel (LDS transpose reads): no transposed copies of W, dY or X in HBM.
+        # Exception: many rows against a small weight (the ViT: 16392 x {768, 2304, 3072}) -- transposing W costs ~5 us and
+        # lets the product take the 256-wide-tile kernel (fc2's dX: 86 us against 133 us in the K-major form).
         if ctx.needs_input_grad[0]:
-            dx = ops.gemm_kmajor(dz, w, a_kmajor=False).view(ctx.xshape)     # (M, N_out) @ (N_out, K_in)
+            if dz.shape[0] >= 4096 and w.numel() <= (1 << 23):
+                dx = ops.gemm(dz, ops.transpose_ex(w, 1, N, K, K, 0)[0]).view(ctx.xshape)   # (M, N_out) (K_in, N_out)^T
+            else:
+                dx = ops.gemm_kmajor(dz, w, a_kmajor=False).view(ctx.xshape)                 # (M, N_out) @ (N_out, K_in)
         if ctx.needs_input_grad[1]:
             dw = ops.gemm_kmajor(dz, x2, a_kmajor=True)                      # (M, N_out)^T @ (M, K_in)
         if ctx.has_b and ctx.needs_input_grad[2]:
