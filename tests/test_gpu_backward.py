@@ -359,6 +359,69 @@ def test_vit_and_projector_gradients_vs_oracle():
     check_grads(got, grads[torch.float32][1], grads[bf][1], what="vit + spp")
 
 
+def test_gradients_at_full_width():
+    """The training path at the real WIDTH of BASELINE configs 3 / 4 (reduced depth so that torch.autograd over the CPU oracle
+    stays within seconds): two ViT blocks on two 32 x 256 x 256 chunks (2049 tokens per chunk: the fused attention backward,
+    the K-major weight-gradient products with K = 4098 token rows, LayerNorm / bias reductions over them) and one
+    SVR + DiffTS + DMTP + TTA layer of the tokenizer at E = 4096 with 8 x 256 visual and 1024 text tokens.  Every
+    parameter's gradient against the fp32 oracle, with the bf16 oracle's own distance as the bar."""
+    from u2tokenizer_amd.tokenizer import u2Tokenizer
+    from u2tokenizer_amd.vit import ViT
+    img, seed = [32, 256, 256], 91
+    vit = ViT(1, img, [4, 16, 16], num_layers=2, pos_embed="perceptron", classification=True)
+    sd32 = module_sd(vit, "vision_tower.vision_tower.", seed)
+    vit.load_state_dict({k[len("vision_tower.vision_tower."):]: v for k, v in sd32.items()})
+    vol = synth.synth_volume(1, 2, img, seed=seed, dtype=torch.float16).view(2, 1, *img)
+    G = synth.synth_tensor("grad_out", (2, 2048, 768), seed)
+    oc = O.PathConfig(image_size=img, vit_layers=2)
+    grads = {}
+    for dt in (torch.float32, bf):
+        def run(sd, dt=dt):
+            return O.vit_tower_forward(sd, "vision_tower.vision_tower", vol.to(dt), oc), G
+        grads[dt] = _oracle_grads(sd32, dt, run)
+    vit = vit.to(bf).to(D).train()
+    out = vit.forward_features(vol.to(D), keep_cls=False)
+    assert rel(out.float(), grads[torch.float32][0]) <= 1.5 * rel(grads[bf][0].float(), grads[torch.float32][0]) + 1e-3
+    (out.float() * G.to(D)).sum().backward()
+    got = {"vision_tower.vision_tower." + k: p.grad for k, p in vit.named_parameters()}
+    assert set(got) == set(grads[torch.float32][1])
+    check_grads(got, grads[torch.float32][1], grads[bf][1], what="2-block ViT at 2049 tokens")
+    del vit, got, grads, out
+
+    E, seed = 4096, 92
+    args = (E, 8, 1, 1024, True, 256, E, "rma", True, True)
+    sd32 = module_sd(u2Tokenizer(*args), "u2tokenizer.", seed)
+    for n, t in sd32.items():
+        synth.lively_(n, t, qk_gain=2.0)
+    v = synth.synth_tensor("v_token", (1, 8, 256, E), seed).to(bf)
+    t = (0.25 * synth.synth_tensor("t_token", (1, 1024, E), seed)).to(bf)
+    G = synth.synth_tensor("grad_out", (1, 256, E), seed)
+    oc = O.PathConfig(hidden_size=E, u2t_num_layers=1)
+    grads = {}
+    for dt in (torch.float32, bf):
+        vin, tin = leaf(v.to(dt)), leaf(t.to(dt))
+
+        def run(sd, vin=vin, tin=tin):
+            return O.tokenizer_forward(sd, "u2tokenizer", vin, tin, oc)[0], G
+
+        out, g = _oracle_grads(sd32, dt, run)
+        g["v_token"], g["t_token"] = vin.grad, tin.grad
+        grads[dt] = (out, g)
+    with torch.device("meta"):
+        tok = u2Tokenizer(*args)
+    tok = tok.to(bf).to_empty(device=D)
+    tok.load_state_dict({k[len("u2tokenizer."):]: val.to(bf) for k, val in sd32.items()})
+    tok.train()
+    vd, td = leaf(v, D), leaf(t, D)
+    got_out = tok(v_token=vd, t_token=td)
+    assert rel(got_out.float(), grads[torch.float32][0]) <= 1.5 * rel(grads[bf][0].float(), grads[torch.float32][0]) + 1e-3
+    (got_out.float() * G.to(D)).sum().backward()
+    got = {"u2tokenizer." + k: p.grad for k, p in tok.named_parameters() if p.grad is not None}
+    got["v_token"], got["t_token"] = vd.grad, td.grad
+    assert set(got) == set(grads[torch.float32][1]), set(got) ^ set(grads[torch.float32][1])
+    check_grads(got, grads[torch.float32][1], grads[bf][1], what="one tokenizer layer at E = 4096")
+
+
 def test_training_step_through_the_hf_model():
     """stage-1 style step (train_stage1.py:244-251): model(images, input_ids, labels, attention_mask, question_ids) on the
     GPU with HIP forward + backward; loss and the gradients of the path's parameters (and of the embedding table rows)
