@@ -88,7 +88,10 @@ int attention_core(Arena& ar, const AttnCore& a, bool dry, hipStream_t st) {
   if (nz > 65535) return U2_ERR_ARG;
   float* S = ar.get<float>((size_t)nz * a.Sq * ldS);
   bf16_t* P = ar.get<bf16_t>((size_t)nz * a.Sq * ldp);
-  bf16_t* Vt = ar.get<bf16_t>((size_t)a.nb * a.H * a.d * ldp);
+  // P V: V is read in place as a K-major B operand (rows = keys; GEMM_B_KMAJOR, LDS transpose reads) when the key count
+  // keeps the 16-byte chunks of P whole; otherwise through a transposed copy
+  const bool v_in_place = opts().kmajor_b && !(a.Skv & 7) && !(a.d & 7) && !(a.ldv & 7) && !(a.v_bs & 7) && !((uintptr_t)a.v & 15);
+  bf16_t* Vt = v_in_place ? nullptr : ar.get<bf16_t>((size_t)a.nb * a.H * a.d * ldp);
   U2_CHECK_WS(ar);
   {
     GemmDesc g;
@@ -103,16 +106,23 @@ int attention_core(Arena& ar, const AttnCore& a, bool dry, hipStream_t st) {
   }
   U2_RUN(softmax_rows(S, P, (int)nz, a.Sq, a.Skv, ldS, ldp, (int64_t)a.Sq * ldS, (int64_t)a.Sq * ldp, a.scale,
                       a.rel_bias, a.H, a.max_len, st));
-  U2_RUN(transpose_bf16(a.v, Vt, a.nb, a.Skv, a.H * a.d, a.ldv, ldp, a.v_bs, (int64_t)a.H * a.d * ldp, 0, st));
   {
     GemmDesc g;
-    g.A = P; g.B = Vt; g.C = a.out;
-    g.M = a.Sq; g.N = a.d; g.K = (int)ldp;
-    g.lda = ldp; g.ldb = ldp; g.ldc = a.ldo;
+    g.A = P; g.C = a.out;
+    g.M = a.Sq; g.N = a.d;
+    g.lda = ldp; g.ldc = a.ldo;
     g.nz = (int)nz; g.nbh = a.H;
     g.sAb = (int64_t)a.H * a.Sq * ldp; g.sAh = (int64_t)a.Sq * ldp;
-    g.sBb = (int64_t)a.H * a.d * ldp; g.sBh = (int64_t)a.d * ldp;
     g.sCb = a.o_bs; g.sCh = a.d;
+    if (v_in_place) {
+      g.B = a.v; g.K = a.Skv; g.ldb = a.ldv;
+      g.sBb = a.v_bs; g.sBh = a.d;
+      g.flags = GEMM_B_KMAJOR;
+    } else {
+      U2_RUN(transpose_bf16(a.v, Vt, a.nb, a.Skv, a.H * a.d, a.ldv, ldp, a.v_bs, (int64_t)a.H * a.d * ldp, 0, st));
+      g.B = Vt; g.K = (int)ldp; g.ldb = ldp;
+      g.sBb = (int64_t)a.H * a.d * ldp; g.sBh = (int64_t)a.d * ldp;
+    }
     U2_RUN(gemm_bf16(g, st));
   }
   ar.off = mark;
@@ -428,7 +438,8 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
     const int64_t ldS = round_up(TN, 8);
     float* scT = ar.get<float>((size_t)B * k * ldS);
     bf16_t* P = ar.get<bf16_t>((size_t)B * k * ldS);
-    bf16_t* Xt = ar.get<bf16_t>((size_t)B * E * ldS);
+    const bool x_in_place = opts().kmajor_b && !(TN & 7);  // the aggregation reads X as a K-major B operand (rows = tokens)
+    bf16_t* Xt = x_in_place ? nullptr : ar.get<bf16_t>((size_t)B * E * ldS);
     U2_CHECK_WS(ar);
     {
       GemmDesc g;
@@ -440,12 +451,18 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
     }
     U2_RUN(softmax_rows(scT, P, B, k, TN, ldS, ldS, (int64_t)k * ldS, (int64_t)k * ldS, 1.0f / c.diffts_tau, nullptr, 1,
                         0, st));
-    U2_RUN(transpose_bf16(x, Xt, B, TN, E, E, ldS, (int64_t)TN * E, (int64_t)E * ldS, 0, st));
     {
       GemmDesc g;
-      g.A = P; g.B = Xt; g.C = sel;
-      g.M = k; g.N = E; g.K = (int)ldS; g.lda = ldS; g.ldb = ldS; g.ldc = E;
-      g.nz = B; g.sAb = (int64_t)k * ldS; g.sBb = (int64_t)E * ldS; g.sCb = (int64_t)k * E;
+      g.A = P; g.C = sel;
+      g.M = k; g.N = E; g.lda = ldS; g.ldc = E;
+      g.nz = B; g.sAb = (int64_t)k * ldS; g.sCb = (int64_t)k * E;
+      if (x_in_place) {
+        g.B = x; g.K = TN; g.ldb = E; g.sBb = (int64_t)TN * E;
+        g.flags = GEMM_B_KMAJOR;
+      } else {
+        U2_RUN(transpose_bf16(x, Xt, B, TN, E, E, ldS, (int64_t)TN * E, (int64_t)E * ldS, 0, st));
+        g.B = Xt; g.K = (int)ldS; g.ldb = ldS; g.sBb = (int64_t)E * ldS;
+      }
       U2_RUN(gemm_bf16(g, st));
     }
     ar.off = mark;
