@@ -228,8 +228,11 @@ def measure_traffic(E, timeout=240):
             cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, ctr), "-o", "p", "--",
                    sys.executable, str(Path(__file__).resolve()), "--steps", "2", "--warmup", "1", "--repeats", "1",
                    "--streams", "1", "--hidden", str(E), "--no-cpu-baseline", "--no-roofline"]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True,
-                               timeout=timeout)
+            env = {k: v for k, v in os.environ.items()
+                   if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                                "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+            env["TMPDIR"] = "/tmp"
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
             if r.returncode != 0:
                 return None
             for f in glob.glob(os.path.join(tmp, ctr, "**", "*counter_collection.csv"), recursive=True):
@@ -427,7 +430,7 @@ def main():
         # HBM-side bytes of the kernel classes: measured live by two rocprofv3 PMC passes of this command (measure_traffic);
         # if rocprofv3 cannot run here, the newest profiles/rNN_traffic.json (tools/gpu_round.sh -> tools/pmc_traffic.py)
         traffic = {}
-        live = measure_traffic(E) if (B == 1 and not args.no_traffic) else None
+        live = measure_traffic(E) if (B == 1 and world == 1 and not args.no_traffic) else None
         if live:
             for key, idx in (("gemm_bf16", 0), ("flash_d64", 1)):
                 if key in live and cnt[idx]:
