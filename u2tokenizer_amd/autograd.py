@@ -140,13 +140,23 @@ def _attn_probs(q, k, H, scale, rel_bias, max_len):
     return ops.softmax_rows(S, scale=scale, rel_bias=rel_bias, heads=H, max_len=max_len, ldp=_r8(Skv))
 
 
+def _kmajor_ok(Skv: int, *views) -> bool:
+    """The K-major operand forms of the GEMM need the key count (their contiguous dimension) and every stride in whole
+    16-byte chunks; other shapes go through transposed copies."""
+    return Skv % 8 == 0 and all(s % 8 == 0 for t in views for s in _rowstride(t))
+
+
 def _attn_pv(P, v, H, Sq):
-    """out (nb, Sq, E) = P V per (batch, head); v (nb, Skv, E) view."""
+    """out (nb, Sq, E) = P V per (batch, head); v (nb, Skv, E) view, read in place as a K-major operand."""
     nb, Skv, E = v.shape
     d, ldp = E // H, P.shape[-1]
     vb, vl = _rowstride(v)
-    Vt = ops.transpose_ex(v, nb, Skv, E, vl, vb, ld_out=ldp)                      # (nb, E, ldp)
     out = torch.empty((nb, Sq, E), dtype=BF, device=v.device)
+    if _kmajor_ok(Skv, v):
+        ops.gemm_strided(P, v, out, M=Sq, N=d, K=Skv, lda=ldp, ldb=vl, ldc=E, nz=nb * H, nbh=H, sAb=H * Sq * ldp,
+                         sAh=Sq * ldp, sBb=vb, sBh=d, sCb=Sq * E, sCh=d, b_kmajor=True)
+        return out
+    Vt = ops.transpose_ex(v, nb, Skv, E, vl, vb, ld_out=ldp)                      # (nb, E, ldp)
     ops.gemm_strided(P, Vt, out, M=Sq, N=d, K=ldp, lda=ldp, ldb=ldp, ldc=E, nz=nb * H, nbh=H, sAb=H * Sq * ldp,
                      sAh=Sq * ldp, sBb=E * ldp, sBh=d * ldp, sCb=Sq * E, sCh=d)
     return out
@@ -154,7 +164,9 @@ def _attn_pv(P, v, H, Sq):
 
 def _attn_backward(q, k, v, P, dO, H, scale, dq, dk, dv, dtable, max_len):
     """Gradients of out = softmax(q k^T scale + bias) v written into the (nb, S, E) views dq / dk / dv (any may be None);
-    dtable: fp32 relative-bias gradient table to accumulate into, or None."""
+    dtable: fp32 relative-bias gradient table to accumulate into, or None.  The products that contract over queries
+    (dV = P^T dO, dK = dS^T Q) and over keys against a row-major operand (dQ = dS K) read P / dS / dO / Q / K in place through
+    the K-major forms of the GEMM; key counts that are no multiple of 8 go through transposed copies."""
     nb, Sq, E = q.shape
     Skv, d, Z = k.shape[1], E // H, nb * H
     ldp, Sqp = P.shape[-1], _r8(Sq)
@@ -167,26 +179,40 @@ def _attn_backward(q, k, v, P, dO, H, scale, dq, dk, dv, dtable, max_len):
     del dP
     if dtable is not None:
         ops.relbias_grad(dS, dtable, Sq, H, max_len)
+    km = _kmajor_ok(Skv, q, k)
+    pz = dict(lda=ldp, nz=Z, nbh=H, sAb=H * Sq * ldp, sAh=Sq * ldp)             # P / dS as the A operand
     if dv is not None:
-        Pt = ops.transpose_ex(P, Z, Sq, Skv, ldp, Sq * ldp, ld_out=Sqp)           # (Z, Skv, Sqp)
-        dOt = ops.transpose_ex(dO, nb, Sq, E, E, Sq * E, ld_out=Sqp)              # (nb, E, Sqp)
         b_, l_ = _rowstride(dv)
-        ops.gemm_strided(Pt, dOt, dv, M=Skv, N=d, K=Sqp, lda=Sqp, ldb=Sqp, ldc=l_, nz=Z, nbh=H, sAb=H * Skv * Sqp,
-                         sAh=Skv * Sqp, sBb=E * Sqp, sBh=d * Sqp, sCb=b_, sCh=d)
-        del Pt, dOt
+        if km:   # dV (Skv, d) = P^T (Skv, Sq) dO (Sq, d): both operands K-major, K = Sq
+            ops.gemm_strided(P, dO, dv, M=Skv, N=d, K=Sq, ldb=E, ldc=l_, sBb=Sq * E, sBh=d, sCb=b_, sCh=d,
+                             a_kmajor=True, b_kmajor=True, **pz)
+        else:
+            Pt = ops.transpose_ex(P, Z, Sq, Skv, ldp, Sq * ldp, ld_out=Sqp)       # (Z, Skv, Sqp)
+            dOt = ops.transpose_ex(dO, nb, Sq, E, E, Sq * E, ld_out=Sqp)          # (nb, E, Sqp)
+            ops.gemm_strided(Pt, dOt, dv, M=Skv, N=d, K=Sqp, lda=Sqp, ldb=Sqp, ldc=l_, nz=Z, nbh=H, sAb=H * Skv * Sqp,
+                             sAh=Skv * Sqp, sBb=E * Sqp, sBh=d * Sqp, sCb=b_, sCh=d)
+            del Pt, dOt
     if dq is not None:
         kb, kl = _rowstride(k)
-        Kt = ops.transpose_ex(k, nb, Skv, E, kl, kb, ld_out=ldp)                  # (nb, E, ldp)
         b_, l_ = _rowstride(dq)
-        ops.gemm_strided(dS, Kt, dq, M=Sq, N=d, K=ldp, lda=ldp, ldb=ldp, ldc=l_, nz=Z, nbh=H, sAb=H * Sq * ldp,
-                         sAh=Sq * ldp, sBb=E * ldp, sBh=d * ldp, sCb=b_, sCh=d, alpha=scale)
+        if km:   # dQ (Sq, d) = dS (Sq, Skv) K (Skv, d): B K-major
+            ops.gemm_strided(dS, k, dq, M=Sq, N=d, K=Skv, ldb=kl, ldc=l_, sBb=kb, sBh=d, sCb=b_, sCh=d, alpha=scale,
+                             b_kmajor=True, **pz)
+        else:
+            Kt = ops.transpose_ex(k, nb, Skv, E, kl, kb, ld_out=ldp)              # (nb, E, ldp)
+            ops.gemm_strided(dS, Kt, dq, M=Sq, N=d, K=ldp, ldb=ldp, ldc=l_, sBb=E * ldp, sBh=d * ldp, sCb=b_, sCh=d,
+                             alpha=scale, **pz)
     if dk is not None:
         qb, ql = _rowstride(q)
-        dSt = ops.transpose_ex(dS, Z, Sq, Skv, ldp, Sq * ldp, ld_out=Sqp)         # (Z, Skv, Sqp)
-        Qt = ops.transpose_ex(q, nb, Sq, E, ql, qb, ld_out=Sqp)                   # (nb, E, Sqp)
         b_, l_ = _rowstride(dk)
-        ops.gemm_strided(dSt, Qt, dk, M=Skv, N=d, K=Sqp, lda=Sqp, ldb=Sqp, ldc=l_, nz=Z, nbh=H, sAb=H * Skv * Sqp,
-                         sAh=Skv * Sqp, sBb=E * Sqp, sBh=d * Sqp, sCb=b_, sCh=d, alpha=scale)
+        if km:   # dK (Skv, d) = dS^T (Skv, Sq) Q (Sq, d): both operands K-major, K = Sq
+            ops.gemm_strided(dS, q, dk, M=Skv, N=d, K=Sq, ldb=ql, ldc=l_, sBb=qb, sBh=d, sCb=b_, sCh=d, alpha=scale,
+                             a_kmajor=True, b_kmajor=True, **pz)
+        else:
+            dSt = ops.transpose_ex(dS, Z, Sq, Skv, ldp, Sq * ldp, ld_out=Sqp)     # (Z, Skv, Sqp)
+            Qt = ops.transpose_ex(q, nb, Sq, E, ql, qb, ld_out=Sqp)               # (nb, E, Sqp)
+            ops.gemm_strided(dSt, Qt, dk, M=Skv, N=d, K=Sqp, lda=Sqp, ldb=Sqp, ldc=l_, nz=Z, nbh=H, sAb=H * Skv * Sqp,
+                             sAh=Skv * Sqp, sBb=E * Sqp, sBh=d * Sqp, sCb=b_, sCh=d, alpha=scale)
 
 
 class SelfAttnFn(Function):

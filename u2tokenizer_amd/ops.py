@@ -436,12 +436,13 @@ def rope_apply(x: torch.Tensor, n_outer, S, n_inner, H, d, max_len=512, inverse=
 @_guarded
 def gemm_strided(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, M, N, K, lda, ldb, ldc, nz=1, nbh=1,
                  sAb=0, sAh=0, sBb=0, sBh=0, sCb=0, sCh=0, alpha=1.0, out_f32=False, bias=None, bias_m=False,
-                 a_off=0, b_off=0, c_off=0) -> torch.Tensor:
+                 a_off=0, b_off=0, c_off=0, a_kmajor=False, b_kmajor=False) -> torch.Tensor:
     """C[z] = alpha * A[z] B[z]^T with explicit element strides (z = zb * nbh + zh): the descriptor of u2tok_gemm_bf16.
-    a / b / out are the STORAGES (any shape); *_off are element offsets into them."""
+    a / b / out are the STORAGES (any shape); *_off are element offsets into them.  b_kmajor: B[z] is stored (K, N) with
+    row stride ldb; a_kmajor (with b_kmajor): A[z] is stored (K, M) with row stride lda."""
     h = _lib.load_library()
     _need(a, torch.bfloat16, "A"), _need(b, torch.bfloat16, "B")
-    flags = GEMM_OUT_F32 if out_f32 else 0
+    flags = (GEMM_OUT_F32 if out_f32 else 0) | (GEMM_A_KMAJOR if a_kmajor else 0) | (GEMM_B_KMAJOR if b_kmajor else 0)
     if bias is not None:
         flags |= GEMM_BIAS_M if bias_m else GEMM_BIAS_N
     st = h.u2tok_gemm_bf16(a.data_ptr() + 2 * a_off, b.data_ptr() + 2 * b_off,
