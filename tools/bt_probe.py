@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Big-tile GEMM kernel on the hot shapes of the path under launcher options (start stagger): microseconds per product,
-warm operands.  Measurement only.      python tools/bt_probe.py"""
+"""Big-tile GEMM kernel on the hot shapes of the path, warm operands: microseconds per product (TF/s).  The start-stagger
+experiment this was written for (profiles/r02_bt_stagger_probe.log) is gone; pass option values to sweep another switch.
+Measurement only.      python tools/bt_probe.py [option_name v0 v1 ...]"""
 import sys
 from pathlib import Path
 
@@ -14,6 +15,8 @@ torch.cuda.set_device(dev)
 ops.device_check()
 bf = torch.bfloat16
 g = torch.Generator(device=dev).manual_seed(0)
+OPT = sys.argv[1] if len(sys.argv) > 2 else None
+SWEEP = [int(v) for v in sys.argv[2:]] if OPT else [0]
 shapes = ((16384, 2304, 768, False), (16384, 3072, 768, False), (16384, 3072, 768, True), (16384, 768, 3072, False),
           (2048, 12288, 4096, False), (1792, 8192, 4096, False))
 for (M, N, K, gelu) in shapes:
@@ -22,8 +25,9 @@ for (M, N, K, gelu) in shapes:
     bias = torch.randn(N, device=dev, generator=g).to(bf)
     out = torch.empty((1, M, N), dtype=bf, device=dev)
     row = f"{M}x{N}x{K}{' gelu' if gelu else ''}:"
-    for stag in (0, 1, 2, 4, 8, 16):
-        ops.set_option("gemm_big_stagger", stag)
+    for stag in SWEEP:
+        if OPT:
+            ops.set_option(OPT, stag)
         ops.set_option("gemm_big_gelu", 1)
         for _ in range(3):
             ops.gemm(a, w, bias=bias, gelu=gelu, out=out)
@@ -37,5 +41,6 @@ for (M, N, K, gelu) in shapes:
         us = e0.elapsed_time(e1) / 20 * 1e3
         row += f"  s{stag}: {us:6.1f} us ({2.0 * M * N * K / us / 1e6:5.0f})"
     print(row)
-ops.set_option("gemm_big_stagger", 0)
+if OPT:
+    ops.set_option(OPT, 0)
 ops.set_option("gemm_big_gelu", 0)
