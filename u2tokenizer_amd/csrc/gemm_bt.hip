@@ -172,10 +172,6 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
   const int total = tiles_mn * d.nz;
   const int gd = gridDim.x, bid = blockIdx.x;
   const int my_tiles = (total - bid + gd - 1) / gd;  // >= 1: grid <= total
-  // Start stagger (experiment, option gemm_big_stagger): identical workgroups run in lockstep, so all 256 of them reach
-  // their epilogue together and the chip alternates between a read-only K loop and a 33 MB store burst.
-  if (d.bt_stagger > 0)
-    for (int i = (bid & 3) * d.bt_stagger; i > 0; --i) __builtin_amdgcn_s_sleep(8);
   // DMA pieces of this wave: rows [64 w, 64 w + 64) of the A tile and [16 NJ w, ..) of the B tile, 8 rows x 128 B per
   // piece; LDS position p of row r holds global chunk p ^ ((r >> 1) & 7): even / odd pieces differ by 4 in that term.
   // Lane offsets are relative to the tile origin; the origin (and the K tile) travel in the scalar offset.
@@ -261,7 +257,6 @@ static int bt_launch(GemmDesc d, hipStream_t stream) {
   const int64_t total = (int64_t)d.tiles_m * d.tiles_n * d.nz;
   if (total > 0x3fffffff) return U2_ERR_ARG;
   const int grid = (int)std::min<int64_t>(total, opts().gemm_big_grid);
-  d.bt_stagger = total >= 2 * (int64_t)grid ? opts().gemm_big_stagger : 0;
   hipLaunchKernelGGL(gemm_bt_kernel<NJ>, dim3(grid), dim3(256), 0, stream, d);
   return launch_status();
 }

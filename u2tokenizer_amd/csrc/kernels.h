@@ -53,7 +53,6 @@ struct GemmDesc {
   // fp32 sums in partial[s][z][m][n] (dense, ld = N); gemm_splitk_reduce_kernel applies the epilogue
   int ksplit = 1, kt_per = 0;
   float* partial = nullptr;
-  int bt_stagger = 0;  // big-tile kernel (filled by its launcher): workgroup w starts (w & 3) * bt_stagger * 512 cycles late
 };
 
 // Options (tile, split-K, big-tile selection) and the split-K scratch registration of the launch stream come from the
