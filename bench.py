@@ -227,7 +227,7 @@ def measure_traffic(E, timeout=240):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, ctr), "-o", "p", "--",
                    sys.executable, str(Path(__file__).resolve()), "--steps", "2", "--warmup", "1", "--repeats", "1",
-                   "--streams", "1", "--hidden", str(E), "--no-cpu-baseline", "--no-roofline"]
+                   "--streams", "1", "--hidden", str(E), "--no-cpu-baseline", "--no-roofline", "--no-train-step"]
             env = {k: v for k, v in os.environ.items()
                    if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
                                 "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
@@ -249,6 +249,50 @@ def measure_traffic(E, timeout=240):
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+# ---------------------------------------------------------------------------------------------------- training step
+def train_step(path, ids, qids, vol, E, iters=3):
+    """Forward under autograd + backward of the path (ViT, projector, tokenizer, embedding table) on the benchmark
+    configuration with a dummy loss on the spliced embeddings (the decoder and the optimiser are not part
+    of it): milliseconds per phase (best of `iters`) and peak HBM.  Leaves the parameters as it found them."""
+    import torch
+    params = list(path.holder.parameters())
+    was = [p.requires_grad for p in params]
+    for p in params:
+        p.requires_grad_(True)
+    g = torch.Generator(device=vol.device).manual_seed(7)
+    w = torch.randn(ids.shape[0], ids.shape[1], E, device=vol.device, generator=g)
+
+    def one():
+        t0 = time.perf_counter()
+        emb = path.prepare_inputs_for_multimodal(ids, None, None, None, None, vol, qids)[4]
+        loss = (emb.float() * w).sum()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        loss.backward()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for p in params:
+            p.grad = None
+        return (t1 - t0) * 1e3, (t2 - t1) * 1e3
+
+    try:
+        with torch.enable_grad():
+            one()
+            torch.cuda.reset_peak_memory_stats()
+            ts = [one() for _ in range(iters)]
+        return {"ms_forward": round(min(t[0] for t in ts), 2), "ms_backward": round(min(t[1] for t in ts), 2),
+                "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+                "parameters": sum(p.numel() for p in params),
+                "what": "autograd forward + backward of prepare_inputs_for_multimodal (ViT, SPP, u2Tokenizer, embedding "
+                        "table) at the benchmark configuration, batch 1, dummy loss on inputs_embeds; HIP kernels both ways "
+                        "(u2tokenizer_amd/autograd.py); decoder and optimiser not included; not part of `value`"}
+    finally:
+        for p, r in zip(params, was):
+            p.requires_grad_(r)
+            p.grad = None
+        torch.cuda.empty_cache()
 
 
 # ---------------------------------------------------------------------------------------------------- launcher
@@ -297,6 +341,7 @@ def main():
                          "launches of one volume's tokenizer fill the machine under the other volume's large GEMMs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the forward + backward timing of the training path")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two live rocprofv3 PMC passes behind roofline.traffic")
     ap.add_argument("--cpu-baseline-iters", type=int, default=3)
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
@@ -466,6 +511,12 @@ def main():
         if ms[1] > 0:
             line["roofline_attention"] = roof(1, "flash_d64", "flash_dp_kernel: ViT attention, 8 chunks x 12 heads x 2049 "
                                                                "tokens x head dim 64 (MONAI SABlock, vit.py:100-105)")
+    if rank == 0 and world == 1 and not args.no_train_step and not args.stub_cpu and B == 1:
+        # SURVEY 8f rank 1 (built in round 2): a measured line for the training form of the path, after the timed region
+        try:
+            line["train_step"] = train_step(path, ids, qids, vols[0], E)
+        except Exception as e:  # never lose the inference line to the extra
+            line["train_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stub_cpu:
         line["cpu_baseline"] = cpu_baseline(E, Lt, iters=args.cpu_baseline_iters)
     if rank == 0:

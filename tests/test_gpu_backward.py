@@ -460,6 +460,49 @@ def test_training_step_through_the_hf_model():
     check_grads(got, ref, what="training step")
 
 
+def test_zero1_adamw_on_the_gpu_keeps_packed_weights_in_sync():
+    """Two optimiser steps of dp.Zero1AdamW (one rank: no collective) on a GPU tokenizer trained through the HIP path: the
+    parameters follow torch.optim.AdamW on an fp32 copy fed with the same gradients, the in-place updates land in the packed
+    q | k | v buffers (the fused inference forward reads them), and the loss goes down."""
+    from u2tokenizer_amd import dp
+    from u2tokenizer_amd.tokenizer import u2Tokenizer
+    E, seed = 512, 93
+    tok = u2Tokenizer(E, 8, 1, 64, True, 16, E, "rma", True, True)
+    sd32 = module_sd(tok, "u2tokenizer.", seed)
+    tok.load_state_dict({k[len("u2tokenizer."):]: v for k, v in sd32.items()})
+    tok = tok.to(bf).to(D).train()
+    ref = {n: p.detach().float().clone().requires_grad_(True) for n, p in tok.named_parameters()}
+    opt = dp.Zero1AdamW(tok.parameters(), lr=2e-3, weight_decay=0.01)
+    ropt = torch.optim.AdamW(list(ref.values()), lr=2e-3, weight_decay=0.01)
+    v = synth.synth_tensor("v_token", (2, 4, 32, E), seed).to(bf).to(D)
+    t = (0.25 * synth.synth_tensor("t_token", (2, 24, E), seed)).to(bf).to(D)
+    target = synth.synth_tensor("target", (2, 16, E), seed).to(D)
+    losses = []
+    for _ in range(3):
+        out = tok(v_token=v, t_token=t)
+        loss = (out.float() - target).pow(2).mean()
+        losses.append(loss.item())
+        loss.backward()
+        for n, p in tok.named_parameters():
+            ref[n].grad = None if p.grad is None else p.grad.detach().float().clone()
+        opt.step()
+        ropt.step()
+        opt.zero_grad()
+        for n, p in tok.named_parameters():
+            if ref[n].grad is None:
+                continue
+            # Zero1AdamW keeps an fp32 master and writes its bf16 rounding; the reference's bf16 rounding may differ by an ulp
+            assert torch.allclose(p.detach().float(), ref[n].detach().to(bf).float(), rtol=2 ** -7, atol=1e-6), n
+        m = tok.svt_module.attention_network.layers[0].spatial_attention
+        es = m.wq.weight.element_size()
+        assert m.wk.weight.data_ptr() == m.wq.weight.data_ptr() + m.wq.weight.numel() * es, "packing lost by the update"
+        with torch.no_grad():
+            fused = tok(v_token=v, t_token=t)            # inference path: reads the packed buffers inside the library
+        again = tok(v_token=v, t_token=t)                # autograd path: reads the parameters
+        assert rel(fused.float(), again.detach().float()) < 2e-2
+    assert losses[-1] < losses[0], losses
+
+
 def test_dpo_duplicate_image_batch_is_deduplicated():
     """cat([images, images]) with the same question (dpo_u2trainer.py:160-162): the path runs once per distinct
     (image, question); results and gradients equal the plain run."""

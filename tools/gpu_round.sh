@@ -8,11 +8,11 @@ timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>
 timeout 900 python bench.py --steps 20 --warmup 3 > $O/bench.log 2>&1; echo "bench exit $?" >> $O/bench.log
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/prof $O/pmc_bench
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline > $O/rocprof.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-train-step > $O/rocprof.log 2>&1
 echo "rocprof exit $?" >> $O/rocprof.log
 # volumes profiled per pass below: 2-stream run 1 warm-up + 5 repeats x 3 steps, one-stream run 1 + 2 x 3 = 23
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_bench/$c -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_$c.log 2>&1
+  timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_bench/$c -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-train-step > $O/pmc_$c.log 2>&1
   echo "pmc $c exit $?" >> $O/rocprof.log
 done
 cd $R

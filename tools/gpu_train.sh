@@ -1,5 +1,5 @@
 #!/bin/bash
-# fused attention backward: parity tests, probe at the ViT shape, train-step probe + its kernel breakdown
+# Training path visit: backward parity tests, fused attention backward probe at the ViT shape, train-step probe + its kernel breakdown
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out
 mkdir -p $O; cd $R
 timeout 900 python -m pytest tests/test_gpu_backward.py -q -x 2>&1 | tail -15 > $O/v11_pytest.log

@@ -21,34 +21,14 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 ops.device_check()
 path, _ = bench.build_path(E, 32768, dev)
-for p in path.holder.parameters():
-    p.requires_grad_(True)
 g = torch.Generator(device=dev).manual_seed(1)
 vol = torch.rand((1, 8, 32, 256, 256), device=dev, generator=g).half()
 ids = torch.randint(1, 32768, (1, 1024), device=dev, generator=g)
 qids = torch.zeros((1, 1024), dtype=torch.int64, device=dev)
 qids[:, :40] = torch.randint(1, 32768, (1, 40), device=dev, generator=g)
-w = torch.randn(1, 1024, E, device=dev, generator=g)
-
-
-def step():
-    t0 = time.perf_counter()
-    emb = path.prepare_inputs_for_multimodal(ids, None, None, None, None, vol, qids)[4]
-    loss = (emb.float() * w).sum()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    loss.backward()
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    for p in path.holder.parameters():
-        p.grad = None
-    return (t1 - t0) * 1e3, (t2 - t1) * 1e3
-
-
-step()
-torch.cuda.reset_peak_memory_stats()
-ts = [step() for _ in range(3)]
-fw, bw = min(t[0] for t in ts), min(t[1] for t in ts)
+r = bench.train_step(path, ids, qids, vol, E)
+fw, bw = r["ms_forward"], r["ms_backward"]
+peak = r["peak_hbm_gib"]
 with torch.no_grad():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -58,5 +38,5 @@ with torch.no_grad():
     inf = (time.perf_counter() - t0) / 5 * 1e3
 nparam = sum(p.numel() for p in path.holder.parameters())
 print(f"path fwd+bwd at E={E}, 256^3, batch 1 ({nparam / 1e9:.2f} B parameters incl. a 32768-row embedding table): forward "
-      f"(autograd path) {fw:.1f} ms, backward {bw:.1f} ms, peak HBM {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB; "
+      f"(autograd path) {fw:.1f} ms, backward {bw:.1f} ms, peak HBM {peak:.1f} GiB; "
       f"the fused inference forward of the same path: {inf:.1f} ms")
