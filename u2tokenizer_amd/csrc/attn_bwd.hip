@@ -8,14 +8,18 @@
 //                         D = rowsum(d_out * out); sweep 2 computes  S^T = K Q^T,  dP^T = V dO^T,
 //                         dS^T = P^T (dP^T - D)  and  dQ^T += K^T dS^T.  A lane owns one QUERY (column of the 32x32 MFMA
 //                         result) and 16 keys per block, so lse / D are lane scalars and dS^T feeds the next MFMA from
-//                         the lane's own registers (the k-slot permutation trick of attn.hip: K^T is stored with the
-//                         keys of a 16-group in the order [0-3, 8-11, 4-7, 12-15]).
+//                         the lane's own registers: its k slots carry the keys of a 16-group in the order
+//                         [0-3, 8-11 | 4-7, 12-15] (lane halves), and the K^T fragment of the other operand is gathered
+//                         in exactly that order from the row-major K tile by two ds_read_b64_tr_b16 (a 16-lane group
+//                         reads a [4 keys][16 d] block; lane a supplies row a >> 2, piece a & 3, receives column a).
 //   flash_bwd_dkv_kernel  one workgroup per (batch, head, 128 keys), 4 waves x 32 keys, one sweep over the queries in the
 //                         other orientation: S = Q K^T, dP = dO V^T with a lane owning one KEY and 16 queries per block;
-//                         dV^T += dO^T P,  dK^T += Q^T dS  again from registers, Q^T / dO^T permuted like K^T above.
-//                         lse / D come from the first kernel through the workspace.
+//                         dV^T += dO^T P,  dK^T += Q^T dS  again from registers, the Q^T / dO^T fragments transpose-read
+//                         from the same row-major Q / dO tiles that feed S and dP.  lse / D come from the first kernel
+//                         through the workspace.
 //
-// Cost: 8 matmul units of 2 S^2 64 flop per head (the unfused form has 5 plus ~16 GB of HBM traffic per ViT layer).
+// Cost: 8 matmul units of 2 S^2 64 flop per head (the unfused form has 5 plus ~16 GB of HBM traffic per ViT layer);
+// HBM: q, k, v, out, d_out read, dq, dk, dv written, 2 x 4 bytes per (head, row) of statistics -- no transposed copies.
 #include "kernels.h"
 
 namespace u2 {
@@ -24,7 +28,6 @@ namespace {
 
 struct FlashBwdArgs {
   const bf16_t *q, *k, *v, *o, *dout;  // row-major views, head h at column h*64
-  const bf16_t *kt, *qt, *dot;         // permuted transposes (nb, H*64, S_pad)
   bf16_t *dq, *dk, *dv;
   float *lse, *dsum;  // (nb*H, S_pad)
   int S, H, S_pad, nblk, nwg;  // nblk: 128-row blocks per (batch, head); nwg = nb * H * nblk
@@ -63,9 +66,26 @@ union Frag {
   uint32_t u[4];
 };
 
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+
+// A operand "X^T" (32 d rows x 16 k) of v_mfma_f32_32x32x16_bf16 from a row-major [64 rows][64 d] tile (rows = keys or
+// queries = the contraction index), in the k-slot order of an accumulator fed back as the B operand: lane (d = lane & 31,
+// hi = lane >> 5) needs rows r0 + 4 hi + {0..3} and r0 + 8 + 4 hi + {0..3} of column d.  Two transpose reads; `lane_off` is
+// trf_lane_off() (the part that depends on the lane and on nb only), r0 = 32 blk + 16 ks2 a compile-time constant.
+__device__ __forceinline__ int trf_row(int lane) { return 4 * (lane >> 5) + ((lane & 15) >> 2); }
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int lane, int nb, int r0) {
+  typedef __attribute__((address_space(3))) v4s_t* lds_v4;
+  const int a = lane & 15;
+  const int chunk = 4 * nb + 2 * ((lane >> 4) & 1) + ((a & 3) >> 1), sub = (a & 1) * 8;
+  const int row1 = r0 + trf_row(lane), row2 = row1 + 8;
+  const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(tile + tile_off(row1, chunk) + sub));
+  const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(tile + tile_off(row2, chunk) + sub));
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
 // ----------------------------------------------------------------------------------------------------------- dQ
 __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const FlashBwdArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[2][3][8192];  // [stage][K | V | K^T permuted]
+  __shared__ __attribute__((aligned(16))) char lds[2][2][8192];  // [stage][K | V]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -79,7 +99,6 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const FlashBwdArgs
   const int qrow = min(wrow0 + l31, S - 1);
   const bf16_t* kb_ = a.k + (int64_t)b * a.bs_qkv + h * 64;
   const bf16_t* vb_ = a.v + (int64_t)b * a.bs_qkv + h * 64;
-  const bf16_t* ktb_ = a.kt + (int64_t)bh * 64 * S_pad;
   const int64_t ld = a.ld_qkv;
 
   // Q / dO fragments (B operands: lane = query column, 8 d values per k16 step) and D = rowsum(dO * O)
@@ -101,10 +120,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const FlashBwdArgs
 
   const int srow0 = tid >> 3, srow1 = 32 + (tid >> 3), sch = tid & 7;
   const uint32_t soff0 = tile_off(srow0, sch), soff1 = tile_off(srow1, sch);
-  const bf16_t* ktsrc0 = ktb_ + (int64_t)srow0 * S_pad + sch * 8;
-  const bf16_t* ktsrc1 = ktb_ + (int64_t)srow1 * S_pad + sch * 8;
-  uint4 rk0, rk1, rv0, rv1, rt0, rt1;
-  rv0 = rv1 = rt0 = rt1 = uint4{0u, 0u, 0u, 0u};
+  uint4 rk0, rk1, rv0, rv1;
+  rv0 = rv1 = uint4{0u, 0u, 0u, 0u};
 #define U2_DQ_GLOAD(t_, full_)                                                                  \
   do {                                                                                          \
     const int kv0_ = (t_) * 64;                                                                 \
@@ -115,8 +132,6 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const FlashBwdArgs
     if (full_) {                                                                                \
       rv0 = *reinterpret_cast<const uint4*>(vb_ + r0_);                                         \
       rv1 = *reinterpret_cast<const uint4*>(vb_ + r1_);                                         \
-      rt0 = *reinterpret_cast<const uint4*>(ktsrc0 + kv0_);                                     \
-      rt1 = *reinterpret_cast<const uint4*>(ktsrc1 + kv0_);                                     \
     }                                                                                           \
   } while (0)
 #define U2_DQ_LSTORE(st_, full_)                                       \
@@ -126,8 +141,6 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const FlashBwdArgs
     if (full_) {                                                       \
       *reinterpret_cast<uint4*>(&lds[st_][1][soff0]) = rv0;            \
       *reinterpret_cast<uint4*>(&lds[st_][1][soff1]) = rv1;            \
-      *reinterpret_cast<uint4*>(&lds[st_][2][soff0]) = rt0;            \
-      *reinterpret_cast<uint4*>(&lds[st_][2][soff1]) = rt1;            \
     }                                                                  \
   } while (0)
 
@@ -210,7 +223,6 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const FlashBwdArgs
     if (wave_active) {
       const char* sK = lds[st][0];
       const char* sV = lds[st][1];
-      const char* sT = lds[st][2];
       f32x16 sc[2], dp[2];
 #pragma unroll
       for (int kbk = 0; kbk < 2; ++kbk) {
@@ -240,8 +252,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const FlashBwdArgs
           const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kbk][r], c, -lse));
           sc[kbk][r] = p * (dp[kbk][r] - Dq);
         }
-      // dQ^T += K^T dS^T: k-slots jj of step (kbk, ks2) carry keys kbk*32 + 16*ks2 + 8*(jj>>2) + 4*hi + (jj&3) = chunk
-      // (kbk*2 + ks2)*2 + hi of the permuted K^T row
+      // dQ^T += K^T dS^T: k-slots jj of step (kbk, ks2) carry keys kbk*32 + 16*ks2 + 8*(jj>>2) + 4*hi + (jj&3); the K^T
+      // fragment is transpose-read from the row-major K tile in that order
 #pragma unroll
       for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
@@ -251,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const FlashBwdArgs
           for (int j = 0; j < 4; ++j) pf.u[j] = pack2_bf16(sc[kbk][ks2 * 8 + 2 * j], sc[kbk][ks2 * 8 + 2 * j + 1]);
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb) {
-            const bf16x8 tf = *reinterpret_cast<const bf16x8*>(sT + tile_off(nb * 32 + l31, (kbk * 2 + ks2) * 2 + hi));
+            const bf16x8 tf = tr_frag(sK, lane, nb, kbk * 32 + ks2 * 16);
             acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, pf.v, acc[nb], 0, 0, 0);
           }
         }
@@ -277,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const FlashBwdArgs
 
 // ----------------------------------------------------------------------------------------------------------- dK, dV
 __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const FlashBwdArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[2][4][8192];  // [stage][Q | dO | Q^T permuted | dO^T permuted]
+  __shared__ __attribute__((aligned(16))) char lds[2][2][8192];  // [stage][Q | dO]
   __shared__ __attribute__((aligned(16))) float stat[2][2][64];  // [stage][lse | D][query of the tile]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -305,14 +317,12 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const FlashBwdArg
   }
   const bf16_t* qb_ = a.q + (int64_t)b * a.bs_qkv + h * 64;
   const bf16_t* gb_ = a.dout + (int64_t)b * a.bs_o + h * 64;
-  const bf16_t* qtb_ = a.qt + (int64_t)bh * 64 * S_pad;
-  const bf16_t* gtb_ = a.dot + (int64_t)bh * 64 * S_pad;
   const float* lseb_ = a.lse + (int64_t)bh * S_pad;
   const float* dsb_ = a.dsum + (int64_t)bh * S_pad;
 
   const int srow0 = tid >> 3, srow1 = 32 + (tid >> 3), sch = tid & 7;
   const uint32_t soff0 = tile_off(srow0, sch), soff1 = tile_off(srow1, sch);
-  uint4 rq0, rq1, rg0, rg1, rqt0, rqt1, rgt0, rgt1;
+  uint4 rq0, rq1, rg0, rg1;
   float4 rs = {0.f, 0.f, 0.f, 0.f};
 #define U2_DKV_GLOAD(t_)                                                                                   \
   do {                                                                                                     \
@@ -322,10 +332,6 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const FlashBwdArg
     rq1 = *reinterpret_cast<const uint4*>(qb_ + (int64_t)qr1_ * ld + sch * 8);                             \
     rg0 = *reinterpret_cast<const uint4*>(gb_ + (int64_t)qr0_ * a.ld_o + sch * 8);                         \
     rg1 = *reinterpret_cast<const uint4*>(gb_ + (int64_t)qr1_ * a.ld_o + sch * 8);                         \
-    rqt0 = *reinterpret_cast<const uint4*>(qtb_ + (int64_t)srow0 * S_pad + q0_ + sch * 8);                 \
-    rqt1 = *reinterpret_cast<const uint4*>(qtb_ + (int64_t)srow1 * S_pad + q0_ + sch * 8);                 \
-    rgt0 = *reinterpret_cast<const uint4*>(gtb_ + (int64_t)srow0 * S_pad + q0_ + sch * 8);                 \
-    rgt1 = *reinterpret_cast<const uint4*>(gtb_ + (int64_t)srow1 * S_pad + q0_ + sch * 8);                 \
     if (tid < 32) {                                                                                        \
       const int qq_ = q0_ + (tid & 15) * 4;                                                                \
       rs = *reinterpret_cast<const float4*>((tid < 16 ? lseb_ : dsb_) + qq_);                              \
@@ -343,10 +349,6 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const FlashBwdArg
     *reinterpret_cast<uint4*>(&lds[st_][0][soff1]) = rq1;                                      \
     *reinterpret_cast<uint4*>(&lds[st_][1][soff0]) = rg0;                                      \
     *reinterpret_cast<uint4*>(&lds[st_][1][soff1]) = rg1;                                      \
-    *reinterpret_cast<uint4*>(&lds[st_][2][soff0]) = rqt0;                                     \
-    *reinterpret_cast<uint4*>(&lds[st_][2][soff1]) = rqt1;                                     \
-    *reinterpret_cast<uint4*>(&lds[st_][3][soff0]) = rgt0;                                     \
-    *reinterpret_cast<uint4*>(&lds[st_][3][soff1]) = rgt1;                                     \
     if (tid < 32) *reinterpret_cast<float4*>(&stat[st_][tid >> 4][(tid & 15) * 4]) = rs;      \
   } while (0)
 
@@ -368,8 +370,6 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const FlashBwdArg
     if (wave_active) {
       const char* sQ = lds[st][0];
       const char* sG = lds[st][1];
-      const char* sQT = lds[st][2];
-      const char* sGT = lds[st][3];
 #pragma unroll
       for (int qbk = 0; qbk < 2; ++qbk) {
         // S = Q K^T, dP = dO V^T: lane = key column, rows = queries qbk*32 + (r&3) + 8*(r>>2) + 4*hi
@@ -395,8 +395,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const FlashBwdArg
             dp[4 * g + e] = p * (dp[4 * g + e] - de[e]);
           }
         }
-        // dV^T += dO^T P, dK^T += Q^T dS: k-slots jj of step ks2 carry queries qbk*32 + 16*ks2 + 8*(jj>>2) + 4*hi + (jj&3)
-        // = chunk (qbk*2 + ks2)*2 + hi of the permuted rows
+        // dV^T += dO^T P, dK^T += Q^T dS: k-slots jj of step ks2 carry queries qbk*32 + 16*ks2 + 8*(jj>>2) + 4*hi + (jj&3);
+        // the dO^T / Q^T fragments are transpose-read from the row-major tiles in that order
 #pragma unroll
         for (int ks2 = 0; ks2 < 2; ++ks2) {
           Frag pp, ps;
@@ -407,9 +407,9 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const FlashBwdArg
           }
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb) {
-            const bf16x8 gt = *reinterpret_cast<const bf16x8*>(sGT + tile_off(nb * 32 + l31, (qbk * 2 + ks2) * 2 + hi));
+            const bf16x8 gt = tr_frag(sG, lane, nb, qbk * 32 + ks2 * 16);
             accV[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gt, pp.v, accV[nb], 0, 0, 0);
-            const bf16x8 qt = *reinterpret_cast<const bf16x8*>(sQT + tile_off(nb * 32 + l31, (qbk * 2 + ks2) * 2 + hi));
+            const bf16x8 qt = tr_frag(sQ, lane, nb, qbk * 32 + ks2 * 16);
             accK[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, ps.v, accK[nb], 0, 0, 0);
           }
         }
@@ -445,7 +445,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 size_t flash_attention_d64_bwd_workspace_bytes(int nb, int S, int H) {
   if (nb <= 0 || S <= 0 || H <= 0) return 0;
   const size_t S_pad = ((size_t)S + 63) & ~(size_t)63;
-  return 3 * align256((size_t)nb * H * 64 * S_pad * 2) + 2 * align256((size_t)nb * H * S_pad * 4);
+  return 2 * align256((size_t)nb * H * S_pad * 4);
 }
 
 int flash_attention_d64_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld_qkv, int64_t bs_qkv, const bf16_t* o,
@@ -464,21 +464,12 @@ int flash_attention_d64_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, i
   const int S_pad = (S + 63) & ~63;
   const int E = H * 64;
   char* w = static_cast<char*>(workspace);
-  const size_t tb = align256((size_t)nb * E * S_pad * 2), sb = align256((size_t)nb * H * S_pad * 4);
-  bf16_t* kt = reinterpret_cast<bf16_t*>(w);
-  bf16_t* qt = reinterpret_cast<bf16_t*>(w + tb);
-  bf16_t* dot = reinterpret_cast<bf16_t*>(w + 2 * tb);
-  float* lse = reinterpret_cast<float*>(w + 3 * tb);
-  float* dsum = reinterpret_cast<float*>(w + 3 * tb + sb);
-  // (nb, S, E) views -> (nb, E, S_pad), the rows of a 16-group in the order [0-3, 8-11, 4-7, 12-15], pad columns zero
-  int e = transpose_bf16(k, kt, nb, S, E, ld_qkv, S_pad, bs_qkv, (int64_t)E * S_pad, 1, stream);
-  if (e != U2_OK) return e;
-  e = transpose_bf16(q, qt, nb, S, E, ld_qkv, S_pad, bs_qkv, (int64_t)E * S_pad, 1, stream);
-  if (e != U2_OK) return e;
-  e = transpose_bf16(dout, dot, nb, S, E, ld_o, S_pad, bs_o, (int64_t)E * S_pad, 1, stream);
-  if (e != U2_OK) return e;
+  const size_t sb = align256((size_t)nb * H * S_pad * 4);
+  float* lse = reinterpret_cast<float*>(w);
+  float* dsum = reinterpret_cast<float*>(w + sb);
+  int e = U2_OK;
   FlashBwdArgs a;
-  a.q = q; a.k = k; a.v = v; a.o = o; a.dout = dout; a.kt = kt; a.qt = qt; a.dot = dot;
+  a.q = q; a.k = k; a.v = v; a.o = o; a.dout = dout;
   a.dq = dq; a.dk = dk; a.dv = dv; a.lse = lse; a.dsum = dsum;
   a.S = S; a.H = H; a.S_pad = S_pad;
   a.ld_qkv = ld_qkv; a.bs_qkv = bs_qkv; a.ld_o = ld_o; a.bs_o = bs_o; a.ld_d = ld_d; a.bs_d = bs_d;
