@@ -246,6 +246,13 @@ int u2tok_flash_attention_d64(const void* q, const void* k, const void* vt, void
                               int32_t H, int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs, int32_t S_pad,
                               float scale, const void* qx, const void* kx, const void* vx, void* outx, int64_t x_bs,
                               int64_t ox_bs, int32_t n_extra, u2tok_stream_t stream);
+/* Same, and lse[(b * H + h) * lse_ld + row] = log2 sum_k exp2(q_row . k scale log2 e) for every query row (the extra row at
+ * index S; lse_ld >= S + n_extra): the row statistics u2tok_flash_attention_d64_bwd takes instead of rebuilding them. */
+int u2tok_flash_attention_d64_lse(const void* q, const void* k, const void* vt, void* out, int32_t nb, int32_t S,
+                              int32_t H, int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs, int32_t S_pad,
+                              float scale, const void* qx, const void* kx, const void* vx, void* outx, int64_t x_bs,
+                              int64_t ox_bs, int32_t n_extra, float* lse, int64_t lse_ld,
+                                  u2tok_stream_t stream);
 /* in-place rotate-half RoPE (rope.py:6-13,77-80): rows indexed (outer, s, inner), position = s; inverse != 0 rotates
  * the other way (the backward of the rotation) */
 int u2tok_rope_apply(void* x, int64_t n_outer, int32_t S, int32_t n_inner, int32_t H, int32_t d, int64_t ld,
@@ -283,12 +290,15 @@ int u2tok_rowdot_bf16(const void* a, const void* b, float* out, int64_t rows, in
  * fp32 per layer at S = 2049) by two flash-style kernels that rebuild the probabilities tile by tile.  All S rows of a batch
  * in one row-major bf16 view: q, k, v row r of batch b at + b*bs_qkv + r*ld_qkv, head h at column h*64 (16-byte aligned
  * bases, strides % 8 == 0); out / d_out with ld_o / bs_o; dq, dk, dv with ld_d / bs_d (may be slices of one packed
- * buffer).  workspace: u2tok_flash_attention_d64_bwd_workspace_bytes(), 256-byte aligned.  No atomics: bit-repeatable. */
+ * buffer).  lse: the row statistics of u2tok_flash_attention_d64_lse ((nb * H, lse_ld) floats), or NULL -- the backward then
+ * rebuilds them in an extra sweep over the keys.  workspace: u2tok_flash_attention_d64_bwd_workspace_bytes(), 256-byte
+ * aligned.  No atomics: bit-repeatable. */
 size_t u2tok_flash_attention_d64_bwd_workspace_bytes(int32_t nb, int32_t S, int32_t H);
 int32_t u2tok_flash_attention_d64_bwd(const void* q, const void* k, const void* v, int64_t ld_qkv, int64_t bs_qkv,
                                       const void* out, const void* d_out, int64_t ld_o, int64_t bs_o, void* dq, void* dk,
                                       void* dv, int64_t ld_d, int64_t bs_d, int32_t nb, int32_t S, int32_t H, float scale,
-                                      void* workspace, size_t workspace_bytes, u2tok_stream_t stream);
+                                      const float* lse, int64_t lse_ld, void* workspace, size_t workspace_bytes,
+                                      u2tok_stream_t stream);
 
 #ifdef __cplusplus
 }

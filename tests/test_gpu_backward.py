@@ -198,6 +198,15 @@ def test_flash_attention_backward_kernels(nb, S, H, gain):
         # bf16 gradients: the unfused chain rounds P and dS to bf16 exactly as the fused kernels do
         assert e_f <= max(1.5 * e_u, 0.0) + 1e-2, (name, report)
     check_grads({"qkv": grads[2][0]}, {"qkv": qr.grad}, what="fused flash attention backward")
+    # the forward's row statistics: log2-sum-exp2 of the scaled scores, and the backward with / without them
+    from u2tokenizer_amd import ops
+    out, lse = ops.flash_attention_d64(qkv.to(D), H, 0.125, extra_last=S > 1, return_lse=True)
+    x = qkv.float().view(nb, S, 3, H, 64).permute(2, 0, 3, 1, 4)
+    want = torch.logsumexp(x[0] @ x[1].transpose(-1, -2) * 0.125, dim=-1) / math.log(2.0)       # (nb, H, S)
+    assert (lse[:, :S].cpu().view(nb, H, S) - want).abs().max() < 2e-3
+    with_lse = ops.flash_attention_d64_bwd(qkv.to(D), out, g.to(D), H, 0.125, lse=lse)
+    without = ops.flash_attention_d64_bwd(qkv.to(D), out, g.to(D), H, 0.125)
+    assert rel(with_lse.float(), without.float()) < 2e-3
 
 
 def test_cross_and_plain_attention_fns():

@@ -98,6 +98,8 @@ SIGNATURES = {
                                         _i32, _vp]),
     "u2tok_flash_attention_d64": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _f32,
                                          _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
+    "u2tok_flash_attention_d64_lse": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _f32,
+                                             _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp]),
     "u2tok_rope_apply": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i64, _i32, _i32, _vp]),
     "u2tok_gelu_fwd": (_i32, [_vp, _vp, _i64, _vp]),
     "u2tok_gelu_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp]),
@@ -110,7 +112,7 @@ SIGNATURES = {
     "u2tok_rowdot_bf16": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _vp]),
     "u2tok_flash_attention_d64_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "u2tok_flash_attention_d64_bwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64,
-                                             _i32, _i32, _i32, _f32, _vp, _sz, _vp]),
+                                             _i32, _i32, _i32, _f32, _vp, _i64, _vp, _sz, _vp]),
 }
 
 ERRORS = {-1: "U2TOK_ERR_ARG (bad dimension / null pointer / unsupported combination)",

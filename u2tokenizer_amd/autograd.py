@@ -229,24 +229,26 @@ class SelfAttnFn(Function):
         E = E3 // 3
         qkv = qkv.contiguous()
         flash = 2 if flash is True else int(flash)
-        P = out_saved = None
-        if flash:
+        P = out_saved = lse = None
+        if flash == 2:
+            out, lse = ops.flash_attention_d64(qkv, H, scale, extra_last=S > 1, return_lse=True)
+            out_saved = out
+        elif flash:
             out = ops.flash_attention_d64(qkv, H, scale, extra_last=S > 1)
-            out_saved = out if flash == 2 else None
         else:
             P = _attn_probs(qkv[..., :E], qkv[..., E:2 * E], H, scale, rel_bias, max_len)
             out = _attn_pv(P, qkv[..., 2 * E:], H, S)
-        ctx.save_for_backward(qkv, rel_bias, P, out_saved)
+        ctx.save_for_backward(qkv, rel_bias, P, out_saved, lse)
         ctx.cfg = (H, scale, max_len)
         return out
 
     @staticmethod
     def backward(ctx, dO):
-        qkv, rel_bias, P, out = ctx.saved_tensors
+        qkv, rel_bias, P, out, lse = ctx.saved_tensors
         H, scale, max_len = ctx.cfg
         E = qkv.shape[-1] // 3
         if out is not None:
-            return ops.flash_attention_d64_bwd(qkv, out, dO, H, scale), None, None, None, None, None
+            return ops.flash_attention_d64_bwd(qkv, out, dO, H, scale, lse=lse), None, None, None, None, None
         q, k, v = qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:]
         if P is None:
             P = _attn_probs(q, k, H, scale, rel_bias, max_len)

@@ -183,6 +183,8 @@ struct FlashArgs {
   int S, H, nb, S_pad, n_extra, mode, n_main;
   int64_t ld_qk, q_bs, ld_out, out_bs, x_bs, ox_bs;
   float scale_log2e;
+  float* lse;      // optional: lse[(b * H + h) * lse_ld + row] = log2 sum_k exp2(s_k scale log2e) per query row (the extra
+  int64_t lse_ld;  // row at index S), what the fused backward (attn_bwd.hip) would otherwise rebuild in a sweep of its own
 };
 
 constexpr float FLASH_RESCALE_THR = 8.0f;
@@ -442,6 +444,7 @@ __device__ __forceinline__ void flash_pass(const FlashArgs& a, char (*lds)[16384
     const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
     const float inv = 1.f / l_tot;
     const int qrow = wrow0 + qb * 32 + l31;
+    if (a.lse && hi == 0 && qrow < S) a.lse[((int64_t)b * a.H + h) * a.lse_ld + qrow] = m_run[qb] + __builtin_log2f(l_tot);
     if (qrow < S) {
       bf16_t* op = a.out + (int64_t)b * a.out_bs + (int64_t)qrow * a.ld_out + h * 64;
 #pragma unroll
@@ -513,6 +516,7 @@ __device__ __forceinline__ void flash_extra_row(const FlashArgs& a, char* lds_ra
   float l_tot = px;
 #pragma unroll
   for (int w = 0; w < NW; ++w) l_tot += red[NW + w];
+  if (a.lse && tid == 0) a.lse[((int64_t)b * a.H + h) * a.lse_ld + S] = m + __builtin_log2f(l_tot);
   if (tid >= 256) return;  // the P V walk below uses 4 lanes per output column = 256 threads
   // O[d] = sum_j p_j V[j][d]: thread (d = tid >> 2, part = tid & 3) walks 16-byte pieces of row d of V^T; inside a
   // group of 16 keys the stored order is [0-3, 8-11, 4-7, 12-15], i.e. piece (G, hh) holds keys 16G + 4hh + {0..3}
@@ -633,6 +637,7 @@ __device__ __forceinline__ void fdp_finish(const FlashArgs& a, FdpBlock& x, cons
   }
   const float l_tot = x.l_run + __shfl_xor(x.l_run, 32, 64);
   const float inv = 1.f / l_tot;
+  if (a.lse && hi == 0 && qrow < a.S) a.lse[((int64_t)b * a.H + h) * a.lse_ld + qrow] = x.m_run + __builtin_log2f(l_tot);
   if (qrow < a.S) {
     bf16_t* op = a.out + (int64_t)b * a.out_bs + (int64_t)qrow * a.ld_out + h * 64;
 #pragma unroll
@@ -750,8 +755,9 @@ int flash_set_debug_buffer(void* p) {  // >= grid * 4 * 8 uint64, zeroed by the 
 int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int nb, int S, int H,
                         int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs, int S_pad, float scale,
                         const bf16_t* qx, const bf16_t* kx, const bf16_t* vx, bf16_t* outx, int64_t x_bs, int64_t ox_bs,
-                        int n_extra, hipStream_t stream) {
+                        int n_extra, float* lse, int64_t lse_ld, hipStream_t stream) {
   if (!q || !k || !vt || !out || nb <= 0 || S <= 0 || H <= 0 || n_extra < 0 || n_extra > 1) return U2_ERR_ARG;
+  if (lse && lse_ld < S + n_extra) return U2_ERR_ARG;
   if ((S_pad & 63) || S_pad < ((S + 63) & ~63)) return U2_ERR_ARG;
   if ((ld_qk & 7) || (q_bs & 7) || (ld_out & 3) || (out_bs & 3)) return U2_ERR_ARG;
   if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15) || ((uintptr_t)out & 7)) return U2_ERR_ARG;
@@ -764,6 +770,7 @@ int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16
   a.S = S; a.H = H; a.nb = nb; a.S_pad = S_pad; a.n_extra = n_extra;
   a.ld_qk = ld_qk; a.q_bs = q_bs; a.ld_out = ld_out; a.out_bs = out_bs; a.x_bs = x_bs; a.ox_bs = ox_bs;
   a.scale_log2e = scale * 1.44269504088896340736f;
+  a.lse = lse; a.lse_ld = lse_ld;
   const int64_t nbh = (int64_t)nb * H;
   int mode = opts().flash_mode;
   if (mode != 1 && mode != 5) mode = S >= 512 ? 5 : 1;  // measured: the double pipeline wins from S = 513 up

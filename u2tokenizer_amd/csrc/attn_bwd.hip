@@ -30,6 +30,8 @@ struct FlashBwdArgs {
   const bf16_t *q, *k, *v, *o, *dout;  // row-major views, head h at column h*64
   bf16_t *dq, *dk, *dv;
   float *lse, *dsum;  // (nb*H, S_pad)
+  const float* lse_in;  // optional row statistics of the forward kernel, (nb*H, lse_ld)
+  int64_t lse_ld;
   int S, H, S_pad, nblk, nwg;  // nblk: 128-row blocks per (batch, head); nwg = nb * H * nblk
   int64_t ld_qkv, bs_qkv, ld_o, bs_o, ld_d, bs_d;
   float scale, scale_log2e;
@@ -84,6 +86,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int lane, int nb, in
 }
 
 // ----------------------------------------------------------------------------------------------------------- dQ
+template <bool HAVE_LSE>  // the forward kernel's row statistics are given: no sweep 1
 __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const FlashBwdArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[2][2][8192];  // [stage][K | V]
   const int tid = threadIdx.x;
@@ -147,65 +150,69 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const FlashBwdArgs
   const int ntile = (S + 63) >> 6;
   const bool ragged = (S & 63) != 0;
 
-  // ---------------- sweep 1: lse (log2 units) of the lane's query row
   float m_run = -INFINITY, l_run = 0.f;
-  U2_DQ_GLOAD(0, false);
-  U2_DQ_LSTORE(0, false);
-  __syncthreads();
+  if constexpr (!HAVE_LSE) {
+    // ---------------- sweep 1: lse (log2 units) of the lane's query row
+    U2_DQ_GLOAD(0, false);
+    U2_DQ_LSTORE(0, false);
+    __syncthreads();
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks].v), "+v"(dof[ks].v));  // loads done before the loops
-  for (int t = 0; t < ntile; ++t) {
-    const int st = t & 1;
-    if (t + 1 < ntile) U2_DQ_GLOAD(t + 1, false);
-    if (wave_active) {
-      const char* sK = lds[st][0];
-      f32x16 sc[2];
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks].v), "+v"(dof[ks].v));  // loads done before the loops
+    for (int t = 0; t < ntile; ++t) {
+      const int st = t & 1;
+      if (t + 1 < ntile) U2_DQ_GLOAD(t + 1, false);
+      if (wave_active) {
+        const char* sK = lds[st][0];
+        f32x16 sc[2];
 #pragma unroll
-      for (int kbk = 0; kbk < 2; ++kbk) {
+        for (int kbk = 0; kbk < 2; ++kbk) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sc[kbk][r] = 0.f;
+          for (int r = 0; r < 16; ++r) sc[kbk][r] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + tile_off(kbk * 32 + l31, ks * 2 + hi));
-          sc[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks].v, sc[kbk], 0, 0, 0);
+          for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + tile_off(kbk * 32 + l31, ks * 2 + hi));
+            sc[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks].v, sc[kbk], 0, 0, 0);
+          }
         }
-      }
-      // lane owns keys t*64 + kbk*32 + (r&3) + 8*(r>>2) + 4*hi
-      if (ragged && t == ntile - 1) {
-        const int kvb = t * 64 + 4 * hi;
+        // lane owns keys t*64 + kbk*32 + (r&3) + 8*(r>>2) + 4*hi
+        if (ragged && t == ntile - 1) {
+          const int kvb = t * 64 + 4 * hi;
+#pragma unroll
+          for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (kvb + kbk * 32 + (r & 3) + 8 * (r >> 2) >= S) sc[kbk][r] = -INFINITY;
+        }
+        float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
         for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (kvb + kbk * 32 + (r & 3) + 8 * (r >> 2) >= S) sc[kbk][r] = -INFINITY;
+          for (int r = 0; r < 16; ++r) mx[r & 3] = fmaxf(mx[r & 3], sc[kbk][r]);
+        float mt = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * c;  // scale > 0
+        const float m_new = fmaxf(m_run, mt);        // finite from tile 0 on: every tile but the last is full, S >= 1
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ps[r & 3] += __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kbk][r], c, -m_new));
+        l_run = l_run * __builtin_amdgcn_exp2f(m_run - m_new) + ((ps[0] + ps[1]) + (ps[2] + ps[3]));
+        m_run = m_new;
       }
-      float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-      for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx[r & 3] = fmaxf(mx[r & 3], sc[kbk][r]);
-      float mt = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
-      mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * c;  // scale > 0
-      const float m_new = fmaxf(m_run, mt);        // finite from tile 0 on: every tile but the last is full, S >= 1
-      float ps[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ps[r & 3] += __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kbk][r], c, -m_new));
-      l_run = l_run * __builtin_amdgcn_exp2f(m_run - m_new) + ((ps[0] + ps[1]) + (ps[2] + ps[3]));
-      m_run = m_new;
+      if (t + 1 < ntile) U2_DQ_LSTORE((t + 1) & 1, false);
+      __syncthreads();
     }
-    if (t + 1 < ntile) U2_DQ_LSTORE((t + 1) & 1, false);
-    __syncthreads();
   }
   float lse = 0.f;
-  if (wave_active) {
+  if constexpr (HAVE_LSE) {
+    lse = a.lse_in[(int64_t)bh * a.lse_ld + qrow];
+  } else if (wave_active) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     lse = m_run + __builtin_log2f(l_tot);
-    if (hi == 0 && wrow0 + l31 < S) {
-      a.lse[(int64_t)bh * S_pad + wrow0 + l31] = lse;
-      a.dsum[(int64_t)bh * S_pad + wrow0 + l31] = Dq;
-    }
+  }
+  if (wave_active && hi == 0 && wrow0 + l31 < S) {  // for the dK / dV kernel
+    a.lse[(int64_t)bh * S_pad + wrow0 + l31] = lse;
+    a.dsum[(int64_t)bh * S_pad + wrow0 + l31] = Dq;
   }
 
   // ---------------- sweep 2: dQ^T
@@ -217,6 +224,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const FlashBwdArgs
   U2_DQ_GLOAD(0, true);
   U2_DQ_LSTORE(0, true);
   __syncthreads();
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks].v), "+v"(dof[ks].v));  // loads done before the loop
   for (int t = 0; t < ntile; ++t) {
     const int st = t & 1;
     if (t + 1 < ntile) U2_DQ_GLOAD(t + 1, true);
@@ -450,8 +459,8 @@ size_t flash_attention_d64_bwd_workspace_bytes(int nb, int S, int H) {
 
 int flash_attention_d64_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld_qkv, int64_t bs_qkv, const bf16_t* o,
                             const bf16_t* dout, int64_t ld_o, int64_t bs_o, bf16_t* dq, bf16_t* dk, bf16_t* dv, int64_t ld_d,
-                            int64_t bs_d, int nb, int S, int H, float scale, void* workspace, size_t workspace_bytes,
-                            hipStream_t stream) {
+                            int64_t bs_d, int nb, int S, int H, float scale, const float* lse_in, int64_t lse_ld,
+                            void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!q || !k || !v || !o || !dout || !dq || !dk || !dv || !workspace) return U2_ERR_ARG;
   if (nb <= 0 || S <= 0 || H <= 0 || !(scale > 0.f) || (int64_t)nb * H > 65535) return U2_ERR_ARG;
   if ((int64_t)nb * H * ((S + 127) / 128) > 0x7fffffff) return U2_ERR_ARG;
@@ -460,6 +469,7 @@ int flash_attention_d64_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, i
   if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)dout) & 15) ||
       (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 7) || ((uintptr_t)workspace & 255))
     return U2_ERR_ARG;
+  if (lse_in && (lse_ld < S || ((uintptr_t)lse_in & 3))) return U2_ERR_ARG;
   if (workspace_bytes < flash_attention_d64_bwd_workspace_bytes(nb, S, H)) return U2_ERR_WORKSPACE;
   const int S_pad = (S + 63) & ~63;
   const int E = H * 64;
@@ -471,6 +481,7 @@ int flash_attention_d64_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, i
   FlashBwdArgs a;
   a.q = q; a.k = k; a.v = v; a.o = o; a.dout = dout;
   a.dq = dq; a.dk = dk; a.dv = dv; a.lse = lse; a.dsum = dsum;
+  a.lse_in = lse_in; a.lse_ld = lse_ld;
   a.S = S; a.H = H; a.S_pad = S_pad;
   a.ld_qkv = ld_qkv; a.bs_qkv = bs_qkv; a.ld_o = ld_o; a.bs_o = bs_o; a.ld_d = ld_d; a.bs_d = bs_d;
   a.scale = scale;
@@ -480,8 +491,9 @@ int flash_attention_d64_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, i
   const dim3 grid((unsigned)a.nwg);
   const double unit = 2.0 * (double)nb * H * (double)S * S * 64;
   {
-    ProfScope ps(PROF_FLASH, 4.0 * unit, stream, (double)nb * S * E * 2.0 * 6.0);
-    hipLaunchKernelGGL(flash_bwd_dq_kernel, grid, dim3(256), 0, stream, a);
+    ProfScope ps(PROF_FLASH, (lse_in ? 3.0 : 4.0) * unit, stream, (double)nb * S * E * 2.0 * 6.0);
+    if (lse_in) hipLaunchKernelGGL(flash_bwd_dq_kernel<true>, grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(flash_bwd_dq_kernel<false>, grid, dim3(256), 0, stream, a);
   }
   e = launch_status();
   if (e != U2_OK) return e;

@@ -229,7 +229,15 @@ int u2tok_flash_attention_d64(const void* q, const void* k, const void* vt, void
                               float scale, const void* qx, const void* kx, const void* vx, void* outx, int64_t x_bs,
                               int64_t ox_bs, int32_t n_extra, u2tok_stream_t stream) {
   return flash_attention_d64(BF(q), BF(k), BF(vt), BFW(out), nb, S, H, ld_qk, q_bs, ld_out, out_bs, S_pad, scale,
-                             BF(qx), BF(kx), BF(vx), BFW(outx), x_bs, ox_bs, n_extra, ST(stream));
+                             BF(qx), BF(kx), BF(vx), BFW(outx), x_bs, ox_bs, n_extra, nullptr, 0, ST(stream));
+}
+int u2tok_flash_attention_d64_lse(const void* q, const void* k, const void* vt, void* out, int32_t nb, int32_t S,
+                                  int32_t H, int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs, int32_t S_pad,
+                                  float scale, const void* qx, const void* kx, const void* vx, void* outx, int64_t x_bs,
+                                  int64_t ox_bs, int32_t n_extra, float* lse, int64_t lse_ld, u2tok_stream_t stream) {
+  if (!lse) return U2_ERR_ARG;
+  return flash_attention_d64(BF(q), BF(k), BF(vt), BFW(out), nb, S, H, ld_qk, q_bs, ld_out, out_bs, S_pad, scale,
+                             BF(qx), BF(kx), BF(vx), BFW(outx), x_bs, ox_bs, n_extra, lse, lse_ld, ST(stream));
 }
 
 int u2tok_rope_apply(void* x, int64_t n_outer, int32_t S, int32_t n_inner, int32_t H, int32_t d, int64_t ld,
@@ -272,9 +280,10 @@ size_t u2tok_flash_attention_d64_bwd_workspace_bytes(int32_t nb, int32_t S, int3
 int32_t u2tok_flash_attention_d64_bwd(const void* q, const void* k, const void* v, int64_t ld_qkv, int64_t bs_qkv,
                                       const void* out, const void* d_out, int64_t ld_o, int64_t bs_o, void* dq, void* dk,
                                       void* dv, int64_t ld_d, int64_t bs_d, int32_t nb, int32_t S, int32_t H, float scale,
-                                      void* workspace, size_t workspace_bytes, u2tok_stream_t stream) {
+                                      const float* lse, int64_t lse_ld, void* workspace, size_t workspace_bytes,
+                                      u2tok_stream_t stream) {
   return flash_attention_d64_bwd(BF(q), BF(k), BF(v), ld_qkv, bs_qkv, BF(out), BF(d_out), ld_o, bs_o, BFW(dq), BFW(dk), BFW(dv),
-                                 ld_d, bs_d, nb, S, H, scale, workspace, workspace_bytes, ST(stream));
+                                 ld_d, bs_d, nb, S, H, scale, lse, lse_ld, workspace, workspace_bytes, ST(stream));
 }
 
 }  // extern "C"

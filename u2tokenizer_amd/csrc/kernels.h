@@ -163,15 +163,15 @@ int temporal_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t
 int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int nb, int S, int H,
                         int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs, int S_pad, float scale,
                         const bf16_t* qx, const bf16_t* kx, const bf16_t* vx, bf16_t* outx, int64_t x_bs, int64_t ox_bs,
-                        int n_extra, hipStream_t stream);
+                        int n_extra, float* lse, int64_t lse_ld, hipStream_t stream);  // lse: optional row statistics out
 // Backward of the same attention (attn_bwd.hip): dq / dk / dv of out = softmax(q k^T scale) v for head dim 64, all S rows
 // of a batch in ONE row-major view (q, k, v: row r of batch b at + b*bs_qkv + r*ld_qkv, head h at column h*64; o / dout with
 // ld_o / bs_o; dq / dk / dv with ld_d / bs_d).  Workspace: three permuted transposes + the row statistics.
 size_t flash_attention_d64_bwd_workspace_bytes(int nb, int S, int H);
 int flash_attention_d64_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld_qkv, int64_t bs_qkv, const bf16_t* o,
                             const bf16_t* dout, int64_t ld_o, int64_t bs_o, bf16_t* dq, bf16_t* dk, bf16_t* dv, int64_t ld_d,
-                            int64_t bs_d, int nb, int S, int H, float scale, void* workspace, size_t workspace_bytes,
-                            hipStream_t stream);
+                            int64_t bs_d, int nb, int S, int H, float scale, const float* lse, int64_t lse_ld,
+                            void* workspace, size_t workspace_bytes, hipStream_t stream);
 // Diagnostics only (process-wide, not for concurrent use): s_memtime phase sums per (workgroup, wave) of the double
 // pipeline kernel; while a buffer is attached the kernel runs its instrumented build.  See attn.hip.
 int flash_set_debug_buffer(void* p);

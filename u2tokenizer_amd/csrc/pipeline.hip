@@ -209,7 +209,7 @@ int vit_forward(const VitConfig& c, const void* const* W, const void* volume, bf
       const bf16_t* xq = qkv + prow * 3 * Hd;  // q | k | v of the cls rows
       U2_RUN(flash_attention_d64(qkv, qkv + Hd, vt, att, nc, ntok, c.heads, 3 * Hd, (int64_t)ntok * 3 * Hd, Hd,
                                  (int64_t)ntok * Hd, S_pad, scale, xq, xq + Hd, xq + 2 * Hd, att + prow * Hd, 3 * Hd, Hd,
-                                 1, st));
+                                 1, nullptr, 0, st));
     } else {
       // unfused reference path (debug option "vit_flash" = 0): gather [cls | patches] per chunk, two GEMMs + softmax
       const size_t mark = ar.off;

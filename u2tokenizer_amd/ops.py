@@ -372,9 +372,10 @@ def temporal_attention(q, k, v, B, T, N, H, scale, rel_bias=None, max_len=512):
 
 
 @_guarded
-def flash_attention_d64(qkv: torch.Tensor, heads: int, scale: float, extra_last: bool = False):
+def flash_attention_d64(qkv: torch.Tensor, heads: int, scale: float, extra_last: bool = False, return_lse: bool = False):
     """qkv: (nb, S, 3*heads*64) bf16 in MONAI SABlock column order (q | k | v).  extra_last=True runs the last row of
-    every batch through the kernel's "extra row" path (how the ViT tower feeds its cls token); same result."""
+    every batch through the kernel's "extra row" path (how the ViT tower feeds its cls token); same result.
+    return_lse: also the row statistics (nb * heads, S rounded up to 64) fp32 that flash_attention_d64_bwd takes."""
     h = _lib.load_library()
     qkv = _need(qkv, torch.bfloat16, "qkv").contiguous()
     nb, S, three = qkv.shape
@@ -390,20 +391,25 @@ def flash_attention_d64(qkv: torch.Tensor, heads: int, scale: float, extra_last:
     out = torch.empty((nb, S, Hd), dtype=torch.bfloat16, device=qkv.device)
     es = qkv.element_size()
     x0 = qkv.data_ptr() + (S - 1) * 3 * Hd * es
-    _lib.check(h.u2tok_flash_attention_d64(qkv.data_ptr(), qkv.data_ptr() + Hd * es, _ptr(vt), _ptr(out), nb, Sm, heads,
-                                           3 * Hd, S * 3 * Hd, Hd, S * Hd, S_pad, float(scale),
-                                           x0 if extra_last else None, x0 + Hd * es if extra_last else None,
-                                           x0 + 2 * Hd * es if extra_last else None,
-                                           out.data_ptr() + (S - 1) * Hd * es if extra_last else None,
-                                           S * 3 * Hd, S * Hd, 1 if extra_last else 0, _stream()),
-               "u2tok_flash_attention_d64")
+    args = (qkv.data_ptr(), qkv.data_ptr() + Hd * es, _ptr(vt), _ptr(out), nb, Sm, heads, 3 * Hd, S * 3 * Hd, Hd, S * Hd,
+            S_pad, float(scale), x0 if extra_last else None, x0 + Hd * es if extra_last else None,
+            x0 + 2 * Hd * es if extra_last else None, out.data_ptr() + (S - 1) * Hd * es if extra_last else None,
+            S * 3 * Hd, S * Hd, 1 if extra_last else 0)
+    if return_lse:
+        lse_ld = (S + 63) // 64 * 64
+        lse = torch.empty((nb * heads, lse_ld), dtype=torch.float32, device=qkv.device)
+        _lib.check(h.u2tok_flash_attention_d64_lse(*args, _ptr(lse), lse_ld, _stream()), "u2tok_flash_attention_d64_lse")
+        return out, lse
+    _lib.check(h.u2tok_flash_attention_d64(*args, _stream()), "u2tok_flash_attention_d64")
     return out
 
 
 @_guarded
-def flash_attention_d64_bwd(qkv: torch.Tensor, out: torch.Tensor, d_out: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+def flash_attention_d64_bwd(qkv: torch.Tensor, out: torch.Tensor, d_out: torch.Tensor, heads: int, scale: float,
+                            lse: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Gradient of flash_attention_d64 w.r.t. its packed input: qkv (nb, S, 3*heads*64), out / d_out (nb, S, heads*64), all
-    bf16 -> d_qkv like qkv (u2tok_flash_attention_d64_bwd: two flash-style kernels, no (S x S) tensor in HBM)."""
+    bf16 -> d_qkv like qkv (u2tok_flash_attention_d64_bwd: two flash-style kernels, no (S x S) tensor in HBM).  lse: the
+    forward's row statistics (flash_attention_d64(..., return_lse=True)); without them the backward rebuilds them."""
     h = _lib.load_library()
     qkv = _need(qkv, torch.bfloat16, "qkv").contiguous()
     out = _need(out, torch.bfloat16, "out").contiguous()
@@ -412,6 +418,10 @@ def flash_attention_d64_bwd(qkv: torch.Tensor, out: torch.Tensor, d_out: torch.T
     Hd = three // 3
     if Hd != heads * 64 or out.shape != (nb, S, Hd) or d_out.shape != out.shape:
         raise RuntimeError("flash_attention_d64_bwd: head dim 64 and out / d_out of shape (nb, S, heads * 64) required")
+    if lse is not None:
+        lse = _need(lse, torch.float32, "lse").contiguous()
+        if lse.dim() != 2 or lse.shape[0] != nb * heads or lse.shape[1] < S:
+            raise RuntimeError("flash_attention_d64_bwd: lse must be (nb * heads, >= S) fp32")
     dqkv = torch.empty_like(qkv)
     nbytes = h.u2tok_flash_attention_d64_bwd_workspace_bytes(nb, S, heads)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=qkv.device)
@@ -419,7 +429,8 @@ def flash_attention_d64_bwd(qkv: torch.Tensor, out: torch.Tensor, d_out: torch.T
     _lib.check(h.u2tok_flash_attention_d64_bwd(qkv.data_ptr(), qkv.data_ptr() + Hd * es, qkv.data_ptr() + 2 * Hd * es,
                                                3 * Hd, S * 3 * Hd, _ptr(out), _ptr(d_out), Hd, S * Hd,
                                                dqkv.data_ptr(), dqkv.data_ptr() + Hd * es, dqkv.data_ptr() + 2 * Hd * es,
-                                               3 * Hd, S * 3 * Hd, nb, S, heads, float(scale), _ptr(ws), nbytes, _stream()),
+                                               3 * Hd, S * 3 * Hd, nb, S, heads, float(scale), _ptr(lse),
+                                               0 if lse is None else lse.shape[-1], _ptr(ws), nbytes, _stream()),
                "u2tok_flash_attention_d64_bwd")
     return dqkv
 
