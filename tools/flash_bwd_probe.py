@@ -22,11 +22,15 @@ AG.ensure_gemm_scratch(dev)
 g = torch.Generator(device=dev).manual_seed(0)
 qkv = torch.randn(nb, S, 3 * H * 64, device=dev, generator=g).to(torch.bfloat16)
 dO = torch.randn(nb, S, H * 64, device=dev, generator=g).to(torch.bfloat16)
-out = ops.flash_attention_d64(qkv, H, 0.125, extra_last=S > 1)
+out, lse = ops.flash_attention_d64(qkv, H, 0.125, extra_last=S > 1, return_lse=True)
 E = H * 64
 
 
 def fused():
+    return ops.flash_attention_d64_bwd(qkv, out, dO, H, 0.125, lse=lse)
+
+
+def fused_own_stats():
     return ops.flash_attention_d64_bwd(qkv, out, dO, H, 0.125)
 
 
@@ -51,10 +55,12 @@ def timeit(fn, n=5):
 
 
 tf, df = timeit(fused)
+ts, _ = timeit(fused_own_stats)
 tu, du = timeit(unfused)
-flop = 16.0 * nb * H * S * S * 64
-print(f"attention backward nb={nb} S={S} H={H}: fused {tf:.1f} us ({flop / tf / 1e6:.0f} TF/s over its 8 matmul units), "
-      f"unfused chain {tu:.1f} us, x{tu / tf:.2f}")
+unit = 2.0 * nb * H * S * S * 64
+print(f"attention backward nb={nb} S={S} H={H}: fused with the forward's row statistics {tf:.1f} us ({7 * unit / tf / 1e6:.0f} "
+      f"TF/s over its 7 matmul units), rebuilding them {ts:.1f} us ({8 * unit / ts / 1e6:.0f} TF/s over 8), unfused chain "
+      f"{tu:.1f} us, x{tu / tf:.2f}")
 for i, n in enumerate(("dq", "dk", "dv")):
     a, b = df[..., i * E:(i + 1) * E].float(), du[..., i * E:(i + 1) * E].float()
     print(f"  {n}: rel rms fused vs unfused {((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item():.3e}, "
