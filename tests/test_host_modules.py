@@ -92,3 +92,37 @@ def test_hf_surface_and_early_outs():
                                                num_hidden_layers=1, num_attention_heads=4, num_key_value_heads=2,
                                                head_dim=16))
     assert q.get_vision_tower() is None
+
+
+def test_packed_weight_alias_is_a_view_and_routes_gradients():
+    """autograd._cat_rows: parameters that lie back to back in one storage (pack_weights) are stacked WITHOUT a copy and the
+    gradient of the stacked matrix is handed back row block by row block; anything else falls back to torch.cat."""
+    from u2tokenizer_amd import autograd as AG
+    prev = torch.is_grad_enabled()
+    torch.set_grad_enabled(True)
+    try:
+        buf = torch.arange(3 * 4 * 6, dtype=torch.float32).view(12, 6).clone()
+        parts = [torch.nn.Parameter(torch.empty(0)) for _ in range(3)]
+        for i, p in enumerate(parts):
+            p.data = buf[4 * i:4 * (i + 1)]
+        W = AG._cat_rows(parts)
+        assert W.shape == (12, 6) and W.data_ptr() == buf.data_ptr(), "adjacent parameters must alias, not copy"
+        assert torch.equal(W.detach(), buf)
+        G = torch.randn(12, 6)
+        (W * G).sum().backward()
+        for i, p in enumerate(parts):
+            assert torch.equal(p.grad, G[4 * i:4 * (i + 1)])
+        # a gap between the parts, or separate storages: plain torch.cat (a copy) with the same values and gradients
+        loose = [torch.nn.Parameter(torch.randn(4, 6)) for _ in range(3)]
+        W2 = AG._cat_rows(loose)
+        assert W2.data_ptr() not in [p.data_ptr() for p in loose]
+        assert torch.equal(W2.detach(), torch.cat([p.detach() for p in loose], 0))
+        gap = [torch.nn.Parameter(torch.empty(0)) for _ in range(2)]
+        gap[0].data, gap[1].data = buf[0:4], buf[8:12]
+        assert AG._cat_rows(gap).data_ptr() != buf.data_ptr()
+        # in-place optimiser updates stay visible through the alias
+        with torch.no_grad():
+            parts[1].add_(1.0)
+        assert torch.equal(AG._cat_rows(parts).detach()[4:8], parts[1].detach())
+    finally:
+        torch.set_grad_enabled(prev)
