@@ -55,8 +55,7 @@ u2tok_ctx_t u2tok_ctx_get_current(void);     /* NULL when the thread uses the de
     that many K slices where scratch allows}, "gemm_big" {-1 never, 0 heuristic, 20 / 21 force the 256x256 / 256x192
     big-tile kernel}, "gemm_big_grid" {persistent workgroups}, "gemm_big_gelu" {0, 1: GELU products may take the
     big-tile kernel}, "kmajor_b" {1: P V and the DiffTS aggregation read V / X in place as K-major operands, 0: through
-    transposed copies}, "fuse_reduce_ln" {1: the TTA's dense + residual LayerNorm reduce split-K partial sums inside the
-    LayerNorm kernel, 0: separate reduce launch},
+    transposed copies},
     "flash_mode" {0 pick, 1 plain 128-row units, 5 double pipeline (asm KV loop)}, "vit_flash" {0 unfused attention, 1}, "tta_overlap" {0, 1: side stream for the TTA k|v projections},
     "profile" {0, 1} */
 int u2tok_set_option(const char* name, int value);

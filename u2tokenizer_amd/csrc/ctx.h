@@ -19,7 +19,6 @@ struct Options {
   int gemm_big = 0;         // -1 never, 0 heuristic, 20 / 21 force the 256x256 / 256x192 big-tile kernel
   int gemm_big_grid = 256;  // persistent workgroups of the big-tile kernel
   int gemm_big_gelu = 0;    // 1: GELU products may take the big-tile kernel too
-  int fuse_reduce_ln = 1;   // 1: TTA dense + residual LayerNorm reduce the split-K partial sums inside the LayerNorm kernel
   int kmajor_b = 1;         // 1: P V / DiffTS aggregation read V / X in place as K-major B operands; 0: transposed copies
   int flash_mode = 0;       // 0 pick, 1 plain 128-row units, 5 double pipeline (asm KV loop)
   int vit_flash = 1;        // 0: unfused ViT attention (debug)

@@ -429,10 +429,7 @@ int gemm_bf16(GemmDesc d, hipStream_t stream) {
                    d.nz * ((out_f32 ? 4.0 : 2.0) * d.M * d.N + ((d.flags & GEMM_RESIDUAL) ? 2.0 * d.M * d.N : 0.0)));
   if (d.ldbk == 0) {  // (the 256-wide-tile kernels read row-major B only)
     const int big = gemm_big_try(d, stream);  // large products: the big-tile kernel (gemm_bt.hip)
-    if (big != 0) {
-      if (d.deferred_ksplit) *d.deferred_ksplit = 1;
-      return big > 0 ? U2_OK : big;
-    }
+    if (big != 0) return big > 0 ? U2_OK : big;
   }
   return gemm_classic(d, stream);
 }
@@ -479,11 +476,6 @@ int gemm_classic(GemmDesc d, hipStream_t stream) {
   }
   if (longk && d.ksplit == 1) tile = 64;  // no scratch for the slices: the tile that fills the CUs
   const int e = tile == 128 ? launch_tile<128, 128>(d, stream) : launch_tile<64, 64>(d, stream);
-  if (d.deferred_ksplit) {
-    *d.deferred_ksplit = e == U2_OK ? d.ksplit : 1;
-    *d.deferred_partial = d.partial;
-    if (e != U2_OK || d.ksplit > 1) return e;  // the caller reduces
-  }
   if (e != U2_OK || d.ksplit == 1) return e;
   const int64_t total = (int64_t)d.nz * d.M * ((d.N + 3) >> 2);
   hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, d);

@@ -53,11 +53,6 @@ struct GemmDesc {
   // fp32 sums in partial[s][z][m][n] (dense, ld = N); gemm_splitk_reduce_kernel applies the epilogue
   int ksplit = 1, kt_per = 0;
   float* partial = nullptr;
-  // Deferred reduction (optional, both or neither): a caller that consumes the split-K partial sums itself (the fused
-  // reduce + LayerNorm of the TTA chain) gets the slice count (1 = C is complete, nothing deferred) and the partial buffer
-  // ([slice][M][N] fp32, bias / alpha NOT applied) instead of the reduce launch.
-  int* deferred_ksplit = nullptr;
-  float** deferred_partial = nullptr;
 };
 
 // Options (tile, split-K, big-tile selection) and the split-K scratch registration of the launch stream come from the
@@ -72,13 +67,6 @@ int gemm_big_try(const GemmDesc& d, hipStream_t stream);  // gemm_bt.hip: 1 laun
 int layernorm_bf16(const bf16_t* x, const bf16_t* res, const bf16_t* w, const bf16_t* bias, bf16_t* y,
                    int nb, int rows, int C, int64_t x_bs, int64_t x_ld, int64_t res_bs, int64_t res_ld,
                    int64_t y_bs, int64_t y_ld, float eps, hipStream_t stream);
-
-// y[r][:] = LayerNorm( bf16( alpha * sum_s partial[s][r][:] + gbias ) + res[r][:] ) * w + bias: the split-K reduction of a
-// GEMM (gemm_bf16 with deferred_ksplit) fused with the residual LayerNorm that follows it; same roundings as the two
-// separate kernels (the reduced row is rounded to bf16 before the residual is added).
-int layernorm_splitk_bf16(const float* partial, int ksplit, int64_t slice_stride, const bf16_t* gbias, float alpha,
-                          const bf16_t* res, const bf16_t* w, const bf16_t* bias, bf16_t* y, int rows, int C, int64_t res_ld,
-                          int64_t y_ld, float eps, hipStream_t stream);
 
 // P[z][r][c] = softmax_c( S[z][r][c] * scale + rel_bias[(c - r) + max_len - 1][z % H] ), bf16 out,
 // columns [n, ldp) of P are written as zero.  rel_bias may be null.

@@ -68,27 +68,6 @@ int linear(const bf16_t* x, int64_t ldx, const bf16_t* w, const bf16_t* b, bf16_
   return gemm_bf16(g, st);
 }
 
-// dst[rows][C] = LayerNorm(res + (x W^T + b)) * lw + lb -- the dense projection + post-LN residual of the TTA chain
-// (tta.py:96,100,103).  When the launcher slices the product along K (the M = 256 query rows), its fp32 partial sums go
-// straight into the LayerNorm kernel, which reduces them on the way (one launch instead of reduce + LayerNorm, no bf16 round
-// trip of the projection through HBM; same roundings).  `tmp` receives the projection when it is not sliced.
-int linear_residual_ln(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* tmp, const bf16_t* res, const bf16_t* lw,
-                       const bf16_t* lb, bf16_t* dst, int64_t rows, int in, int C, float eps, hipStream_t st) {
-  int ksplit = 1;
-  float* partial = nullptr;
-  GemmDesc g;
-  g.A = x; g.B = w; g.C = tmp; g.bias = b;
-  g.M = (int)rows; g.N = C; g.K = in;
-  g.lda = in; g.ldb = in; g.ldc = C;
-  g.flags = b ? GEMM_BIAS_N : 0;
-  if (opts().fuse_reduce_ln && C <= 4096) { g.deferred_ksplit = &ksplit; g.deferred_partial = &partial; }
-  int e = gemm_bf16(g, st);
-  if (e != U2_OK) return e;
-  if (ksplit > 1)
-    return layernorm_splitk_bf16(partial, ksplit, rows * C, b, 1.f, res, lw, lb, dst, (int)rows, C, C, C, eps, st);
-  return layernorm_bf16(res, tmp, lw, lb, dst, 1, (int)rows, C, 0, C, 0, C, 0, C, eps, st);
-}
-
 struct AttnCore {
   const bf16_t *q, *k, *v;
   int64_t ldq, ldk, ldv, q_bs, k_bs, v_bs;
@@ -562,7 +541,8 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
   U2_RUN(fill_rows(wp(0), qa, B, (int64_t)Q * E, (int64_t)Q * E, st));  // query_tokens.expand(B,-1,-1)
   bf16_t* qcur = qa;
   // kv_ready: index of the side-stream event that publishes `kv` (-1: compute it here)
-  auto cross = [&](const Att& a, const bf16_t* src, int Ls, const bf16_t* qin, bf16_t* kv, int kv_ready) -> int {
+  auto cross = [&](const Att& a, const bf16_t* src, int Ls, const bf16_t* qin, bf16_t* dst, bf16_t* kv,
+                   int kv_ready) -> int {
     // MultiHeadCrossAttention.forward (tta.py:42-69), is_compress = False
     U2_RUN(linear(qin, E, a.wq, a.bq, qproj, E, qrows, E, E, 0, nullptr, 0, st));
     if (kv_ready < 0) {
@@ -573,7 +553,10 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
     }
     AttnCore ac{qproj, kv, kv + E, E, 2 * E, 2 * E, (int64_t)Q * E, (int64_t)Ls * 2 * E, (int64_t)Ls * 2 * E,
                 qctx, E, (int64_t)Q * E, B, Q, Ls, H, d, scale, nullptr, 0};
-    return attention_core(ar, ac, dry, st);  // context in qctx; the caller runs dense + residual LayerNorm
+    const int e = attention_core(ar, ac, dry, st);
+    if (e != U2_OK) return e;
+    U2_RUN(linear(qctx, E, a.wd, a.bd, dst, E, qrows, E, E, 0, nullptr, 0, st));
+    return U2_OK;
   };
   for (int l = 0; l < L; ++l) {
     const int base = i_tta + 33 * l;
@@ -605,13 +588,14 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
       const int e = attention_core(ar, ac, dry, st);
       if (e != U2_OK) return e;
     }
-    U2_RUN(linear_residual_ln(qctx, sa.wd, sa.bd, qo, qcur, ns_w, ns_b, s1, qrows, E, E, c.ln_eps, st));
+    U2_RUN(linear(qctx, E, sa.wd, sa.bd, qo, E, qrows, E, E, 0, nullptr, 0, st));
+    U2_RUN(layernorm_bf16(qcur, qo, ns_w, ns_b, s1, 1, (int)qrows, E, 0, E, 0, E, 0, E, c.ln_eps, st));
     // visual cross attention (tta.py:97-100)
-    { const int e = cross(va, V, Lv, s1, overlap ? kv_v[l] : kv_inline, overlap ? 2 * l : -1); if (e != U2_OK) return e; }
-    U2_RUN(linear_residual_ln(qctx, va.wd, va.bd, qo, s1, nv_w, nv_b, s2, qrows, E, E, c.ln_eps, st));
+    { const int e = cross(va, V, Lv, s1, qo, overlap ? kv_v[l] : kv_inline, overlap ? 2 * l : -1); if (e != U2_OK) return e; }
+    U2_RUN(layernorm_bf16(s1, qo, nv_w, nv_b, s2, 1, (int)qrows, E, 0, E, 0, E, 0, E, c.ln_eps, st));
     // text cross attention (tta.py:101-103) -- no padding mask in the reference
-    { const int e = cross(ta, t_token, c.Lt, s2, overlap ? kv_t[l] : kv_inline, overlap ? 2 * l + 1 : -1); if (e != U2_OK) return e; }
-    U2_RUN(linear_residual_ln(qctx, ta.wd, ta.bd, qo, s2, nt_w, nt_b, s1, qrows, E, E, c.ln_eps, st));
+    { const int e = cross(ta, t_token, c.Lt, s2, qo, overlap ? kv_t[l] : kv_inline, overlap ? 2 * l + 1 : -1); if (e != U2_OK) return e; }
+    U2_RUN(layernorm_bf16(s2, qo, nt_w, nt_b, s1, 1, (int)qrows, E, 0, E, 0, E, 0, E, c.ln_eps, st));
     qcur = s1;
   }
   // ---------------- LinearAggregation (tta.py:109-116): is_compress=True -> V un-projected, no out-proj

@@ -95,110 +95,6 @@ int layernorm_bf16(const bf16_t* x, const bf16_t* res, const bf16_t* w, const bf
   return launch_status();
 }
 
-// Split-K reduction + residual LayerNorm in one pass (TTA chain: dense -> LN(q + dense), tta.py:96,100,103): the row is
-// rebuilt from the GEMM's fp32 partial sums (slices added in order, alpha, bias, ONE rounding to bf16 -- exactly what
-// gemm_splitk_reduce_kernel would have stored), the residual is added and the row normalised as in layernorm_kernel.
-template <int NC>
-__global__ __launch_bounds__(256) void layernorm_splitk_kernel(const float* __restrict__ partial, int ksplit,
-                                                               int64_t slice_stride, const bf16_t* __restrict__ gbias,
-                                                               float alpha, const bf16_t* __restrict__ res,
-                                                               const bf16_t* __restrict__ w, const bf16_t* __restrict__ bias,
-                                                               bf16_t* __restrict__ y, int rows, int C, int64_t res_ld,
-                                                               int64_t y_ld, float eps) {
-  const int lane = threadIdx.x & 63;
-  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= rows) return;
-  const float* pp = partial + r * C;
-  const bf16_t* rp = res ? res + r * res_ld : nullptr;
-  bf16_t* yp = y + r * y_ld;
-  const int nchunk = C >> 3;
-  float v[NC][8];
-  float sum = 0.f;
-#pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    const int c = i * 64 + lane;
-    if (c < nchunk) {
-      float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      for (int s = 0; s < ksplit; ++s) {
-        const float4 t0 = *reinterpret_cast<const float4*>(pp + s * slice_stride + c * 8);
-        const float4 t1 = *reinterpret_cast<const float4*>(pp + s * slice_stride + c * 8 + 4);
-        a[0] += t0.x; a[1] += t0.y; a[2] += t0.z; a[3] += t0.w;
-        a[4] += t1.x; a[5] += t1.y; a[6] += t1.z; a[7] += t1.w;
-      }
-      float gb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (gbias) {
-        const uint4 u = *reinterpret_cast<const uint4*>(gbias + c * 8);
-        gb[0] = bf16lo(u.x); gb[1] = bf16hi(u.x); gb[2] = bf16lo(u.y); gb[3] = bf16hi(u.y);
-        gb[4] = bf16lo(u.z); gb[5] = bf16hi(u.z); gb[6] = bf16lo(u.w); gb[7] = bf16hi(u.w);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float x = a[j] * alpha;
-        if (gbias) x += gb[j];
-        v[i][j] = bf16_to_f32(f32_to_bf16(x));
-      }
-      if (rp) {
-        const uint4 q = *reinterpret_cast<const uint4*>(rp + c * 8);
-        v[i][0] += bf16lo(q.x); v[i][1] += bf16hi(q.x); v[i][2] += bf16lo(q.y); v[i][3] += bf16hi(q.y);
-        v[i][4] += bf16lo(q.z); v[i][5] += bf16hi(q.z); v[i][6] += bf16lo(q.w); v[i][7] += bf16hi(q.w);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) sum += v[i][j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
-    }
-  }
-  const float mean = wave_sum(sum) / (float)C;
-  float sq = 0.f;
-#pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    if (i * 64 + lane < nchunk) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { const float dlt = v[i][j] - mean; sq += dlt * dlt; }
-    }
-  }
-  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
-#pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    const int c = i * 64 + lane;
-    if (c < nchunk) {
-      const uint4 uw = *reinterpret_cast<const uint4*>(w + c * 8);
-      const uint4 ub = *reinterpret_cast<const uint4*>(bias + c * 8);
-      float o[8];
-      o[0] = (v[i][0] - mean) * rstd * bf16lo(uw.x) + bf16lo(ub.x);
-      o[1] = (v[i][1] - mean) * rstd * bf16hi(uw.x) + bf16hi(ub.x);
-      o[2] = (v[i][2] - mean) * rstd * bf16lo(uw.y) + bf16lo(ub.y);
-      o[3] = (v[i][3] - mean) * rstd * bf16hi(uw.y) + bf16hi(ub.y);
-      o[4] = (v[i][4] - mean) * rstd * bf16lo(uw.z) + bf16lo(ub.z);
-      o[5] = (v[i][5] - mean) * rstd * bf16hi(uw.z) + bf16hi(ub.z);
-      o[6] = (v[i][6] - mean) * rstd * bf16lo(uw.w) + bf16lo(ub.w);
-      o[7] = (v[i][7] - mean) * rstd * bf16hi(uw.w) + bf16hi(ub.w);
-      *reinterpret_cast<uint4*>(yp + c * 8) =
-          uint4{pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]), pack2_bf16(o[4], o[5]), pack2_bf16(o[6], o[7])};
-    }
-  }
-}
-
-int layernorm_splitk_bf16(const float* partial, int ksplit, int64_t slice_stride, const bf16_t* gbias, float alpha,
-                          const bf16_t* res, const bf16_t* w, const bf16_t* bias, bf16_t* y, int rows, int C, int64_t res_ld,
-                          int64_t y_ld, float eps, hipStream_t stream) {
-  if (!partial || ksplit < 1 || !w || !bias || !y || rows <= 0 || C <= 0) return U2_ERR_ARG;
-  if ((C & 7) || (y_ld & 7) || C > 4096 || (res && (res_ld & 7)) || ((uintptr_t)partial & 15) || (slice_stride & 3))
-    return U2_ERR_ARG;
-  if (((uintptr_t)gbias | (uintptr_t)res | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)y) & 15) return U2_ERR_ARG;
-  dim3 grid((unsigned)cdiv(rows, 4));
-  ProfScope ps(PROF_ROWOP, 0, stream, (double)rows * C * (4.0 * ksplit + (res ? 4.0 : 2.0)));
-#define U2_LNS(NC)                                                                                                       \
-  hipLaunchKernelGGL((layernorm_splitk_kernel<NC>), grid, dim3(256), 0, stream, partial, ksplit, slice_stride, gbias, alpha, \
-                     res, w, bias, y, rows, C, res_ld, y_ld, eps)
-  if (C <= 1024) U2_LNS(2);
-  else if (C <= 2048) U2_LNS(4);
-  else U2_LNS(8);
-#undef U2_LNS
-  return launch_status();
-}
-
 // ---------------------------------------------------------------- row softmax
 // Reference: rma.py:60-72 (scores / sqrt(depth) + relative_bias[j - i + max_len - 1][head], softmax(-1)),
 // tta.py:55-57 (no bias), svr.py:108 (DiffTS softmax over tokens with temperature).
