@@ -238,6 +238,23 @@ def test_forwards_ignore_an_ambient_split_k_scratch():
     assert torch.equal(a, b)
 
 
+def test_in_place_kmajor_operands_do_not_change_a_bit():
+    """Reading V (P V) and X (DiffTS aggregation) in place as K-major GEMM operands is pure re-plumbing: with kmajor_b
+    switched off (transposed copies) the output is bit-identical (same products, same summation orders)."""
+    from u2tokenizer_amd import ops
+    E = 2048
+    tok = _big_tokenizer(E, diffts=True)
+    g = torch.Generator(device=D).manual_seed(5)
+    v = torch.randn(1, 8, 256, E, device=D, generator=g).to(bf)
+    t = (torch.randn(1, 128, E, device=D, generator=g) * 0.25).to(bf)
+    ref = tok(v_token=v, t_token=t)
+    ops.set_option("kmajor_b", 0)
+    try:
+        assert torch.equal(tok(v_token=v, t_token=t), ref)
+    finally:
+        ops.set_option("kmajor_b", 1)
+
+
 def test_hard_topk_full_size_replay():
     """Hard top-k at BASELINE size inside the pipeline: indices == oracle selection on the same refined tokens."""
     E = 2048
