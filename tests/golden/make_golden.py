@@ -122,6 +122,49 @@ def gen_tokenizer(only=None):
         save(f"tokenizer_{name}", out=out, **extra)
 
 
+GRAD_CASES = ("mu2_2l", "hard_2l_live", "rope_2l_live", "linvt_b2_live")
+
+
+def grad_probe(name, shape, seed):
+    """fixed direction a gradient is projected on (name-seeded, so the tests rebuild it)"""
+    return synth.synth_tensor(name + "/probe", tuple(shape), seed).double()
+
+
+def gen_grads():
+    """Backward of the REFERENCE's own u2Tokenizer (float64, torch.autograd): d sum(out * G) / d (every parameter, v_token,
+    t_token).  A fixture holds, per tensor, the gradient's norm and its projection on a name-seeded random direction (the
+    full gradients of a 2-layer tokenizer would be ~50 MB), plus every 8th column of the two input gradients and their norms.  tests/test_oracle_golden.py
+    checks torch.autograd over the ORACLE against them (1e-9), which pins the reference the GPU gradient tests compare with."""
+    from src.model.u2tokenizer.u2Tokenizer import u2Tokenizer
+    for name in GRAD_CASES:
+        c = TOKENIZER_CASES[name]
+        m = u2Tokenizer(embed_size=c["E"], num_heads=c["heads"], num_layers=c["layers"], top_k=c["top_k"],
+                        use_multi_scale=c["use_multi_scale"], num_3d_query_token=c["Q"], hidden_size=c["E"],
+                        attn_type=c["attn_type"], enable_diffts=c["enable_diffts"], enable_dmtp=c["enable_dmtp"]).eval()
+        fill(m, "u2tokenizer.", c["seed"], c.get("lively", False))
+        m = m.double()
+        v, t = tokenizer_inputs(c)
+        G = synth.synth_tensor("grad_out", (c["B"], c["Q"], c["E"]), c["seed"]).double()
+        with torch.enable_grad():
+            vin, tin = v.double().requires_grad_(True), t.double().requires_grad_(True)
+            for p in m.parameters():
+                p.requires_grad_(True)
+            out = m(v_token=vin, t_token=tin)
+            (out * G).sum().backward()
+        names, norms, probes = [], [], []
+        for k, p in m.named_parameters():
+            if p.grad is None:
+                continue
+            key = "u2tokenizer." + k
+            names.append(key)
+            norms.append(p.grad.norm().item())
+            probes.append((p.grad * grad_probe(key, p.shape, c["seed"])).sum().item())
+        save(f"tokenizer_{name}_grads", names=np.array(names), norms=np.array(norms, dtype=np.float64),
+             probes=np.array(probes, dtype=np.float64), d_v_token_s8=vin.grad[..., ::8].float(),
+             d_t_token_s8=tin.grad[..., ::8].float(), d_v_token_norm=vin.grad.norm().item(),
+             d_t_token_norm=tin.grad.norm().item())
+
+
 def gen_spp():
     from src.model.multimodal_projector.spatial_pooling_projector import SpatialPoolingProjector
     for name, c in SPP_CASES.items():

@@ -12,7 +12,7 @@ GOLDEN = Path(__file__).resolve().parent / "golden"
 
 def load_golden(name):
     with np.load(GOLDEN / f"{name}.npz") as z:
-        return {k: torch.from_numpy(z[k]) for k in z.files}
+        return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in "fiub" else z[k]) for k in z.files}   # (names stay numpy)
 
 
 def tok_cfg(c) -> O.PathConfig:

@@ -49,6 +49,47 @@ def test_tokenizer_matches_reference(name):
         assert torch.equal(idx, g["ref_topk_idx"]), (idx, g["ref_topk_idx"])
 
 
+GRAD_CASES = ("mu2_2l", "hard_2l_live", "rope_2l_live", "linvt_b2_live")
+
+
+def grad_probe(name, shape, seed):
+    return synth.synth_tensor(name + "/probe", tuple(shape), seed).double()
+
+
+@pytest.mark.parametrize("name", GRAD_CASES)
+def test_oracle_backward_matches_reference_backward(name):
+    """torch.autograd over the oracle (float64) against the REFERENCE modules' own backward (fixtures written by
+    tests/golden/make_golden.py grads): norm and a name-seeded random projection of every parameter's gradient, a column
+    sample of the input gradients.  This pins the function whose gradients tests/test_gpu_backward.py compares the HIP
+    backward with to the reference's, not just to the oracle's own forward."""
+    c = TOKENIZER_CASES[name]
+    g = load_golden(f"tokenizer_{name}_grads")
+    sd = module_sd(_mk_tok(c), "u2tokenizer.", c["seed"], lively=c.get("lively", False))
+    v, t = tokenizer_inputs(c)
+    G = synth.synth_tensor("grad_out", (c["B"], c["Q"], c["E"]), c["seed"]).double()
+    with torch.enable_grad():
+        sd64 = {k: val.double().requires_grad_(True) for k, val in sd.items()}
+        vin, tin = v.double().requires_grad_(True), t.double().requires_grad_(True)
+        out, _ = O.tokenizer_forward(sd64, "u2tokenizer", vin, tin, tok_cfg(c))
+        (out * G).sum().backward()
+    names = [str(n) for n in g["names"]]
+    got = {k: val.grad for k, val in sd64.items() if val.grad is not None}
+    # the same parameters receive a gradient (the aggregator's unused wv / dense, the hard top-k score net do not)
+    assert set(got) == set(names), set(got) ^ set(names)
+    top = float(g["norms"].max())
+    for k, n_ref, p_ref in zip(names, g["norms"], g["probes"]):
+        gk = got[k]
+        probe = grad_probe(k, gk.shape, c["seed"])
+        assert abs(gk.norm().item() - float(n_ref)) <= 1e-9 * max(float(n_ref), 1e-6 * top), k
+        assert abs((gk * probe).sum().item() - float(p_ref)) <= 1e-8 * max(float(n_ref), 1e-6 * top) * probe.norm().item(), k
+    for key, grad in (("d_v_token", vin.grad), ("d_t_token", tin.grad)):
+        ref = g[key + "_s8"].double()
+        # (the sample is stored as fp32; an input gradient that is pure rounding noise -- the collapsed, non-"lively"
+        # parameter sets: ~1e-12 against parameter gradients of order 1 -- is compared on the scale of the largest gradient)
+        assert (grad[..., ::8] - ref).abs().max().item() <= 1e-6 * ref.abs().max().item() + 1e-9 * top, key
+        assert abs(grad.norm().item() - float(g[key + "_norm"])) <= 1e-9 * max(float(g[key + "_norm"]), 1e-6 * top), key
+
+
 @pytest.mark.parametrize("name", list(SPP_CASES))
 def test_spp_matches_reference(name):
     c = SPP_CASES[name]
