@@ -363,15 +363,16 @@ def test_tokenizer_gradients_vs_reference_fixture():
     names = [str(n) for n in g["names"]]
     assert set(got) == set(names), set(got) ^ set(names)
     top = float(g["norms"].max())
-    worst = 0.0
+    bad = []
     for k, n_ref, p_ref in zip(names, g["norms"], g["probes"]):
         n_ref, p_ref = float(n_ref), float(p_ref)
         probe = synth.synth_tensor(k + "/probe", tuple(got[k].shape), c["seed"]).double()
         scale = max(n_ref, 2e-3 * top)            # gradients that are tiny next to the largest: absolute floor
         e_norm = abs(got[k].norm().item() - n_ref) / scale
         e_probe = abs((got[k] * probe).sum().item() - p_ref) / (scale * probe.norm().item())
-        worst = max(worst, e_norm, e_probe)
-        assert e_norm <= 6e-2 and e_probe <= 6e-2, (k, e_norm, e_probe)
+        if e_norm > 6e-2 or e_probe > 6e-2:
+            bad.append((k, round(e_norm, 4), round(e_probe, 4), n_ref / top))
+    assert not bad, sorted(bad, key=lambda b: -max(b[1], b[2]))[:8]
     ref_v = g["d_v_token_s8"].double()
     # the input gradient of this collapsed (non-lively) parameter set is rounding noise in the reference (1e-12): it only
     # has to stay negligible next to the parameter gradients
