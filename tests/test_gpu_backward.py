@@ -374,14 +374,14 @@ def test_tokenizer_gradients_vs_reference_fixture():
             bad.append((k, round(e_norm, 4), round(e_probe, 4), n_ref / top))
     assert not bad, sorted(bad, key=lambda b: -max(b[1], b[2]))[:8]
     ref_v = g["d_v_token_s8"].double()
-    # In exact arithmetic the visual input of this collapsed (non-"lively") parameter set has NO influence on the output: the
-    # reference's float64 gradient is 1e-12.  Any bf16 run -- the reference's as well, see the bar of
-    # test_tokenizer_gradients_vs_oracle -- breaks that cancellation with its rounding and leaves noise of a few percent of
-    # the largest gradient; it has to stay at that level.
-    assert ref_v.norm().item() <= 1e-6 * top and vd.grad.double().norm().item() <= 0.1 * top
-    ref_t = g["d_t_token_s8"].double()
-    got_t = td.grad.double().cpu()[..., ::8]
-    assert (got_t - ref_t).norm().item() <= 6e-2 * max(ref_t.norm().item(), 2e-3 * top / 8 ** 0.5)
+    got_v = vd.grad.double().cpu()[..., ::8]
+    e_v = (got_v - ref_v).norm().item() / ref_v.norm().item()
+    assert e_v <= 0.15, e_v
+    # In exact arithmetic the TEXT input of this parameter set has no influence on the output (the reference's float64
+    # gradient is 1e-12 of the others).  Any bf16 run -- the reference's as well, see the bar of
+    # test_tokenizer_gradients_vs_oracle -- breaks that cancellation with its rounding and leaves noise; it has to stay small
+    # next to the real gradients.
+    assert float(g["d_t_token_norm"]) <= 1e-6 * top and td.grad.double().norm().item() <= 0.1 * top
 
 
 def test_vit_and_projector_gradients_vs_oracle():
