@@ -11,13 +11,19 @@ order, so that running it with bf16 tensors rounds at the same points as the ref
 PINNING STATUS
   * tokenizer / projector / splice: pinned -- tests/golden/*.npz were produced by importing the
     reference's own modules (src/model/u2tokenizer/*, multimodal_projector/*) in the build container
-    (tests/golden/make_golden.py) and `tests/test_oracle_golden.py` checks this file against them.
+    (tests/golden/make_golden.py) and `tests/test_oracle_golden.py` checks this file against them:
+    forward in fp32 (and float64 to 1e-9 on the "lively" sets), and the BACKWARD of the tokenizer --
+    torch.autograd over this file against the reference modules' own float64 gradients
+    (tokenizer_*_grads.npz) to 1e-9, since the training-path tests differentiate this file.
   * ViT blocks: PARITY UNPINNED.  vit.py:19-20 imports MONAI 1.3.0 (requirements.txt:52), which is
     not installed and not vendored in /root/reference; `patch_embedding_block`, `sa_block`,
     `mlp_block` and `transformer_block` below restate MONAI's published semantics
     (monai/networks/blocks/{patchembedding,selfattention,mlp,transformerblock}.py @1.3.0).  The golden
     ViT vectors run the reference's own `ViT`/`ViT3DTower` classes on top of that same restatement,
     so they pin the composition (cls token, block loop, final norm, cls drop) but not the MONAI blocks.
+    tests/test_oracle_independent.py cross-checks the restated blocks against independent torch
+    formulations (nn.MultiheadAttention / scaled_dot_product_attention with permuted qkv weights,
+    Conv3d(kernel = stride = patch) for the perceptron patch embedding, nn.TransformerEncoderLayer).
   * hard top-k: the reference's tie order is torch.topk's unspecified one and its scores depend on
     the BLAS summation order; the canonical definition used here (and by the HIP kernels) is
     score = fp32(exact dot product), order = descending score, ties by ascending index.
