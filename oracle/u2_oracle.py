@@ -22,8 +22,8 @@ PINNING STATUS
     ViT vectors run the reference's own `ViT`/`ViT3DTower` classes on top of that same restatement,
     so they pin the composition (cls token, block loop, final norm, cls drop) but not the MONAI blocks.
     tests/test_oracle_independent.py cross-checks the restated blocks against independent torch
-    formulations (nn.MultiheadAttention / scaled_dot_product_attention with permuted qkv weights,
-    Conv3d(kernel = stride = patch) for the perceptron patch embedding, nn.TransformerEncoderLayer).
+    formulations (nn.MultiheadAttention with permuted qkv weights for SABlock, nn.TransformerEncoderLayer
+    for the block, Conv3d(kernel = stride = patch) for the perceptron patch embedding).
   * hard top-k: the reference's tie order is torch.topk's unspecified one and its scores depend on
     the BLAS summation order; the canonical definition used here (and by the HIP kernels) is
     score = fp32(exact dot product), order = descending score, ties by ascending index.
