@@ -215,6 +215,43 @@ def gen_full():
         save(f"full_{name}", inputs_embeds=embeds, logits_last=logits[:, -1], greedy_ids=gen)
 
 
+def gen_full_grads():
+    """Stage-1 style training step through the reference's u2LlamaForCausalLM in float64 (train_stage1.py:244-251):
+    loss = model(images, input_ids, labels, question_ids).loss, backward; norm + name-seeded projection of the gradient of
+    every parameter of the PATH (vision tower, projector, tokenizer, embedding table) and the loss itself."""
+    install_monai_stub()
+    from src.model.language_model.u2llama import u2LlamaForCausalLM, u2Config
+    from src.model.u2tokenizer.builder import build_u2tokenizer_tower
+    for name, c in FULL_CASES.items():
+        cfg = u2Config(**c["llama"])
+        for k, v in c["mm"].items():
+            setattr(cfg, k, v)
+        torch.manual_seed(0)
+        m = u2LlamaForCausalLM(cfg).eval()
+        m.model.u2tokenizer = build_u2tokenizer_tower(cfg)
+        fill(m, "", c["seed"])
+        m = m.double()
+        vol = synth.synth_volume(c["B"], c["C"], c["mm"]["image_size"], seed=c["seed"], dtype=torch.float32).double()
+        ids = synth.synth_ids(c["B"], c["S"], c["n_real"], cfg.vocab_size, seed=c["seed"], name="input_ids")
+        qids = synth.synth_ids(c["B"], c["Lt"], c["n_q"], cfg.vocab_size, seed=c["seed"], name="question_ids")
+        labels = ids.clone()
+        labels[:, :20] = -100
+        with torch.enable_grad():
+            for p in m.parameters():
+                p.requires_grad_(True)
+            loss = m(images=vol, input_ids=ids, labels=labels, question_ids=qids).loss
+            loss.backward()
+        names, norms, probes = [], [], []
+        for k, p in m.named_parameters():
+            if p.grad is None or not any(s in k for s in ("vision_tower", "mm_projector", "u2tokenizer", "embed_tokens")):
+                continue
+            names.append(k)
+            norms.append(p.grad.norm().item())
+            probes.append((p.grad * grad_probe(k, p.shape, c["seed"])).sum().item())
+        save(f"full_{name}_grads", names=np.array(names), norms=np.array(norms, dtype=np.float64),
+             probes=np.array(probes, dtype=np.float64), loss=loss.item())
+
+
 def gen_keys():
     """state_dict key / shape contract of the reference's u2Tokenizer variants (merged into state_dict_keys.json)."""
     import json

@@ -171,3 +171,41 @@ def test_full_path_matches_reference(name):
     from transformers import LlamaForCausalLM
     gen = LlamaForCausalLM.generate(m, inputs_embeds=emb, max_new_tokens=c["new_tokens"], do_sample=False)
     assert torch.equal(gen, g["greedy_ids"])
+
+
+@pytest.mark.parametrize("name", list(FULL_CASES))
+def test_full_path_backward_matches_reference_backward(name):
+    """The stage-1 training step (train_stage1.py:244-251) through the reference's u2LlamaForCausalLM in float64 (fixture
+    full_*_grads.npz): loss, and norm + name-seeded projection of the gradient of every path parameter the reference run
+    differentiates (tokenizer, projector, embedding table, cls token / final norm of the tower -- the MONAI stub of the
+    fixture generator does not expose its block parameters to autograd).  Here: torch.autograd over the oracle path + the same
+    HF decoder.  This is the reference side of tests/test_gpu_backward.py::test_training_step_through_the_hf_model."""
+    c = FULL_CASES[name]
+    g = load_golden(f"full_{name}_grads")
+    m, cfg = _full_model(c)
+    m = m.double()
+    vol = synth.synth_volume(c["B"], c["C"], c["mm"]["image_size"], seed=c["seed"], dtype=torch.float32).double()
+    ids = synth.synth_ids(c["B"], c["S"], c["n_real"], cfg.vocab_size, seed=c["seed"], name="input_ids")
+    qids = synth.synth_ids(c["B"], c["Lt"], c["n_q"], cfg.vocab_size, seed=c["seed"], name="question_ids")
+    labels = ids.clone()
+    labels[:, :20] = -100
+    with torch.enable_grad():
+        sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items() if v.is_floating_point()}
+        emb, _ = O.prepare_inputs_for_multimodal(sd, sd["model.embed_tokens.weight"], ids, vol, qids, full_path_cfg(c))
+        dec = {k: v for k, v in sd.items() if not any(s in k for s in ("vision_tower", "mm_projector", "u2tokenizer"))}
+        loss = torch.func.functional_call(m, dec, args=(), kwargs=dict(inputs_embeds=emb, labels=labels)).loss
+        loss.backward()
+    assert abs(loss.item() - float(g["loss"])) <= 1e-9 * abs(float(g["loss"])), (loss.item(), float(g["loss"]))
+    names = [str(n) for n in g["names"]]
+    top = float(g["norms"].max())
+    for k, n_ref, p_ref in zip(names, g["norms"], g["probes"]):
+        gk = sd[k].grad
+        assert gk is not None, k
+        if k == "model.embed_tokens.weight":
+            # nn.Embedding(padding_idx = pad_token_id) leaves the pad row without a gradient in the reference (u2_arch.py:109);
+            # the oracle's F.embedding has no padding_idx -- same forward
+            gk = gk.clone()
+            gk[cfg.pad_token_id] = 0
+        probe = grad_probe(k, gk.shape, c["seed"])
+        assert abs(gk.norm().item() - float(n_ref)) <= 1e-8 * max(float(n_ref), 1e-6 * top), k
+        assert abs((gk * probe).sum().item() - float(p_ref)) <= 1e-7 * max(float(n_ref), 1e-6 * top) * probe.norm().item(), k
