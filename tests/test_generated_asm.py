@@ -39,7 +39,7 @@ def test_gemm_bt_schedule_issues_every_piece_once():
 
 
 def _bt_layout(nj):
-    """LDS contents of one K tile as the DMA pieces of gemm_bt_kernel<NJ> write them (formulas of gemm_pp.hip):
+    """LDS contents of one K tile as the DMA pieces of gemm_bt_kernel<NJ> write them (formulas of gemm_bt.hip):
     byte address -> (matrix, tile row, 16-byte K chunk)."""
     lds = {}
     for wave in range(4):

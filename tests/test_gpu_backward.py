@@ -152,7 +152,7 @@ def test_self_attention_fn(nb, S, H, d, bias):
     check_grads(got, ref, what="self attention")
 
 
-def test_flash_self_attention_fn_recomputes_for_backward():
+def test_flash_self_attention_fn():
     """ViT form: flash forward (last row = the kernel's extra row), default backward (fused kernels since round 2)."""
     from u2tokenizer_amd import autograd as AG
     nb, S, H, d = 2, 129, 3, 64

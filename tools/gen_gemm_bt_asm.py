@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Generates u2tokenizer_amd/csrc/gemm_bt_asm.inc: the K loop of the 256 x (64 NJ) x 64 "big tile" bf16 GEMM
-(gemm_pp.hip, gemm_bt_kernel<NJ>, NJ = 4 or 3) as ONE inline-asm block for gfx950.
+(gemm_bt.hip, gemm_bt_kernel<NJ>, NJ = 4 or 3) as ONE inline-asm block for gfx950.
 
 One workgroup = 4 waves (2 x 2), one wave per SIMD, each wave a 128 x (32 NJ) output tile = 4 x NJ accumulators of
 v_mfma_f32_32x32x16_bf16 in AccVGPRs (asm operands "+a": the compiler zeroes them before and runs the epilogue after).
-LDS: 2 stages x (A tile 256 rows x 128 B | B tile 64 NJ rows x 128 B) <= 128 KB, rows XOR-swizzled as in gemm_pp.hip.
+LDS: 2 stages x (A tile 256 rows x 128 B | B tile 64 NJ rows x 128 B) <= 128 KB, rows XOR-swizzled as in gemm_bt.hip.
 Per K tile a wave issues 16 NJ MFMAs in four k16 blocks; an MFMA "slot" carries at most one LDS read and, in some
 slots, one LDS-DMA piece:
 

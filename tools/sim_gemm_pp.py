@@ -1,4 +1,4 @@
-"""CPU model of gemm_pp.hip's index arithmetic (no GPU needed): DMA piece -> LDS image (source-side swizzle),
+"""CPU model of gemm_bt.hip's index arithmetic (the file was gemm_pp.hip in round 1) (no GPU needed): DMA piece -> LDS image (source-side swizzle),
 fragment read addresses, v_mfma_f32_32x32x16_bf16 lane maps, accumulator -> C map.  Run: python tools/sim_gemm_pp.py"""
 import itertools
 import numpy as np

@@ -1,7 +1,7 @@
 // Microbenchmark: how fast can one workgroup per CU move GEMM-shaped operand tiles from L2/HBM into LDS?
 //   mode 0: global_load_lds_dwordx4 (LDS-DMA)         mode 1: global_load_dwordx4 -> VGPR -> ds_write_b128
 //   mode 2: global_load_dwordx4 -> VGPR only (no LDS)
-// Access pattern = gemm_pp.hip's: workgroup b streams K tiles of a [ROWS][BK] bf16 panel pair out of two
+// Access pattern = gemm_bt.hip's: workgroup b streams K tiles of a [ROWS][BK] bf16 panel pair out of two
 // [8192][8192] matrices, 16 bytes per lane, DEPTH K tiles in flight.  build: hipcc --offload-arch=gfx950 -O3
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(512) void stage_kernel(const unsigned short* __rest
       for (int i = 0; i < PW; ++i) {
         const int r = (i * NWAVES_ISSUE + wave) * RPP + lane / CPR;
         int gc = lane % CPR;
-        if (SWZ == 1) gc ^= (r >> 1) & 7;            // full 16-B chunk swizzle (gemm_pp.hip)
+        if (SWZ == 1) gc ^= (r >> 1) & 7;            // full 16-B chunk swizzle (gemm_bt.hip)
         if (SWZ == 2) gc ^= ((r >> 1) & 3) << 1;     // 32-B pairs stay together
         if (SWZ == 3) gc ^= ((r >> 1) & 1) << 2;     // swap 64-B halves only
         if (SWZ == 4) gc = (gc + (r & 7)) & 7;       // rotation

@@ -166,7 +166,7 @@ int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16
                         int n_extra, float* lse, int64_t lse_ld, hipStream_t stream);  // lse: optional row statistics out
 // Backward of the same attention (attn_bwd.hip): dq / dk / dv of out = softmax(q k^T scale) v for head dim 64, all S rows
 // of a batch in ONE row-major view (q, k, v: row r of batch b at + b*bs_qkv + r*ld_qkv, head h at column h*64; o / dout with
-// ld_o / bs_o; dq / dk / dv with ld_d / bs_d).  Workspace: three permuted transposes + the row statistics.
+// ld_o / bs_o; dq / dk / dv with ld_d / bs_d).  lse: optional row statistics of the forward kernel.  Workspace: the row statistics (lse, D).
 size_t flash_attention_d64_bwd_workspace_bytes(int nb, int S, int H);
 int flash_attention_d64_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ld_qkv, int64_t bs_qkv, const bf16_t* o,
                             const bf16_t* dout, int64_t ld_o, int64_t bs_o, bf16_t* dq, bf16_t* dk, bf16_t* dv, int64_t ld_d,
