@@ -1,5 +1,5 @@
 """Tiny driver for rocprofv3 counter passes:
-    python tools/prof_kernels.py flash|flashbwd|gemm|gemm4k|gemm256|gemm8k|gemmmlp [iters] [gemm_big: -1 | 0 | 20 | 21] [flash_mode]
+    python tools/prof_kernels.py flash|flashbwd|kmajor|gemm|gemm4k|gemm256|gemm8k|gemmmlp [iters] [gemm_big: -1 | 0 | 20 | 21] [flash_mode]
 gemm256 = the M = 256 query-side product of the TTA with 16 COLD weight matrices in rotation and split-K scratch, as the
 pipeline runs it (64 x 64 tiles, 4 K slices + reduce)."""
 import sys
@@ -26,6 +26,14 @@ elif what == "flashbwd":
     out = ops.flash_attention_d64(qkv, 12, 0.125, extra_last=True)
     for _ in range(iters):
         ops.flash_attention_d64_bwd(qkv, out, dout, 12, 0.125)
+elif what == "kmajor":
+    # the ViT's fc1 weight gradient: dW (3072, 768) = dY (16392, 3072)^T X (16392, 768), both operands K-major
+    scratch = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    ops.set_gemm_scratch(scratch)
+    dy = torch.randn(16392, 3072, device="cuda").to(bf)
+    x = torch.randn(16392, 768, device="cuda").to(bf)
+    for _ in range(iters):
+        ops.gemm_kmajor(dy, x, a_kmajor=True)
 elif what.startswith("gemm"):
     ops.set_option("gemm_big", variant)
     M, N, K = {"gemm": (16384, 2304, 768), "gemm4k": (2048, 4096, 4096), "gemm256": (256, 4096, 4096),
