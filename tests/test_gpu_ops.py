@@ -303,18 +303,10 @@ def test_gemm_kmajor_operands(ops, tile):
     """K-major operand forms (ds_read_b64_tr_b16 fragments): C = A B with B (K, N) and C = A^T B with A (K, M), B (K, N) --
     the dX / dW products of the training path -- on random (transpose-detecting) data: row / column tails of both tile
     sizes, K that is no multiple of the K tile (and, with both operands K-major, of nothing), K slices, bit-repeatable."""
-    scratch = torch.empty(96 << 20, dtype=torch.uint8, device=D)
+    scratch = torch.empty(64 << 20, dtype=torch.uint8, device=D)
     ops.set_gemm_scratch(scratch)
     ops.set_option("gemm_tile", tile)
     try:
-        if tile == 0:
-            # the heuristic's long-K form: eight K slices, slice s on XCD s (the ViT's fc1 weight gradient, and a product
-            # whose 8th slice is partial)
-            for (M, N, K) in [(3072, 768, 16392), (768, 520, 8200)]:
-                ak, bk = rnd(K, M, seed=9), rnd(K, N, seed=10)
-                got = ops.gemm_kmajor(ak.to(D), bk.to(D), a_kmajor=True)
-                close_bf16(got, ak.float().t() @ bk.float())
-                assert torch.equal(got, ops.gemm_kmajor(ak.to(D), bk.to(D), a_kmajor=True))
         for sk in (-1, 0, 3):
             ops.set_option("gemm_splitk", sk)
             for (M, N, K) in [(128, 128, 64), (200, 72, 136), (8, 520, 1160), (264, 8, 72), (2049, 768, 768), (256, 1000, 2048)]:

@@ -44,7 +44,7 @@ def ensure_gemm_scratch(device: torch.device) -> None:
     (device, stream), registered on the active context."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream, id(ops.active_context(device)))
     if key not in _scratch:
-        buf = torch.empty(96 << 20, dtype=torch.uint8, device=device)   # 8 fp32 slices of the ViT's 3072 x 768 weight gradients
+        buf = torch.empty(64 << 20, dtype=torch.uint8, device=device)
         with torch.cuda.device(device):
             ops.set_gemm_scratch(buf)
         _scratch[key] = buf

@@ -73,14 +73,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
   // ---- tile order: XCD-contiguous bands, then groups of 8 m-tiles ----
   const int ntiles = d.tiles_m * d.tiles_n;
   int pid = blockIdx.x;
-  int kslice = blockIdx.z;
-  if (d.xcd_slice) {
-    // long-K products (weight gradients): one K slice per XCD (workgroup w runs on XCD w % 8).  All tiles of an XCD then
-    // stream the SAME K range of both operands in near lock-step and share it through that L2 -- with tile bands per XCD
-    // every XCD fetched most of both operands (518 MB of fabric reads for 125 MB of operands, profiles/r02_kernel_pmc.json).
-    kslice = pid & 7;
-    pid >>= 3;
-  } else {
+  {
     const int q = ntiles >> 3, r = ntiles & 7;
     const int xcd = pid & 7, idx = pid >> 3;
     pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -179,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
   [[maybe_unused]] const int64_t kadv_a = BK * d.lda;
   const int64_t kadv_b = TB ? BK * d.ldb : (d.ldbk ? d.ldbk : BK);
   const int nkt_all = (d.K + BK - 1) / BK;
-  const int kt0 = (d.ksplit > 1) ? kslice * d.kt_per : 0;   // split-K: this slice's K tiles
+  const int kt0 = (d.ksplit > 1) ? (int)blockIdx.z * d.kt_per : 0;   // split-K: this slice's K tiles
   const int nkt = (d.ksplit > 1) ? min(nkt_all, kt0 + d.kt_per) : nkt_all;
   auto dma = [&](int kt, int buf) {
     const int k0 = kt * BK;
@@ -254,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
 
   // ---- epilogue: lane holds C[m][n0..n0+3], m = tile row (lane & 15), n0 = 4 * (lane >> 4) ----
   if (d.ksplit > 1) {  // split-K slice: raw fp32 sums, the reduce kernel does the rest
-    float* P = d.partial + ((int64_t)kslice * d.nz + z) * (int64_t)d.M * d.N;
+    float* P = d.partial + ((int64_t)blockIdx.z * d.nz + z) * (int64_t)d.M * d.N;
     const int m_b = bm0 + wm * WM + (lane & 15), n_b = bn0 + wn * WN + (lane >> 4) * 4;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -397,7 +390,6 @@ static int launch_tile(GemmDesc d, hipStream_t stream) {
   d.tiles_m = (int)cdiv(d.M, BM);
   d.tiles_n = (int)cdiv(d.N, BN);
   dim3 grid(d.tiles_m * d.tiles_n, d.nz, d.ksplit > 1 ? d.ksplit : 1);
-  if (d.xcd_slice) grid = dim3(d.tiles_m * d.tiles_n * 8, 1, 1);
   constexpr int smem = 2 * (BM + BN) * 64 * 2;
   const bool ta = d.flags & GEMM_A_KMAJOR, tb = d.flags & GEMM_B_KMAJOR;
   if (ta) hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, true, true>), grid, dim3(256), smem, stream, d);
@@ -472,19 +464,12 @@ int gemm_classic(GemmDesc d, hipStream_t stream) {
       const size_t slice = (size_t)d.nz * d.M * d.N * sizeof(float);
       // partial sums cost HBM traffic: capped at 24 MB unless the K loop is long enough to dwarf it
       if (o.gemm_splitk <= 1) s = (int)std::min<size_t>(s, (longk ? sc.bytes : std::min<size_t>(sc.bytes, 24u << 20)) / slice);
-      // long K: eight slices, one per XCD, when the scratch holds them and no slice comes out empty
-      if (longk && o.gemm_splitk == 0 && sc.p && 8 * slice <= sc.bytes && cdiv(nkt, cdiv(nkt, 8)) == 8) {
-        s = 8;
-        d.xcd_slice = 1;
-      }
       const size_t need = (size_t)s * slice;
       if (s > 1 && sc.p && need <= sc.bytes && d.nz <= 65535) {
         d.ksplit = s;
         d.kt_per = (int)cdiv(nkt, s);
         d.ksplit = (int)cdiv(nkt, d.kt_per);  // no empty slices
         d.partial = reinterpret_cast<float*>(sc.p);
-      } else {
-        d.xcd_slice = 0;
       }
     }
     if (d.ksplit <= 1) d.ksplit = 1;

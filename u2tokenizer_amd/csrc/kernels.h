@@ -53,7 +53,6 @@ struct GemmDesc {
   // fp32 sums in partial[s][z][m][n] (dense, ld = N); gemm_splitk_reduce_kernel applies the epilogue
   int ksplit = 1, kt_per = 0;
   float* partial = nullptr;
-  int xcd_slice = 0;  // launcher: 8 K slices, slice s on XCD s (1-D grid, workgroup w -> slice w & 7, tile w >> 3)
 };
 
 // Options (tile, split-K, big-tile selection) and the split-K scratch registration of the launch stream come from the
