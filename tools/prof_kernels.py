@@ -28,7 +28,7 @@ elif what == "flashbwd":
         ops.flash_attention_d64_bwd(qkv, out, dout, 12, 0.125)
 elif what == "kmajor":
     # the ViT's fc1 weight gradient: dW (3072, 768) = dY (16392, 3072)^T X (16392, 768), both operands K-major
-    scratch = torch.empty((96 if variant == 0 else 64) << 20, dtype=torch.uint8, device="cuda")   # 96 MB: 8 slices, 1 per XCD
+    scratch = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
     ops.set_gemm_scratch(scratch)
     dy = torch.randn(16392, 3072, device="cuda").to(bf)
     x = torch.randn(16392, 768, device="cuda").to(bf)
