@@ -37,10 +37,16 @@ struct FlashBwdArgs {
   float scale, scale_log2e;
 };
 
-// [64][64] bf16 tiles, 128-byte rows, 16-byte chunks XOR-swizzled with (row >> 1) & 7 (conflict-free ds_read_b128 for the
-// 32x32 fragment pattern; same layout as attn.hip)
+// [64][64] bf16 tiles, 128-byte rows, 16-byte chunks XOR-swizzled with the BIT-REVERSED row pair index rev3((row >> 1) & 7).
+// Two access patterns share a tile: the 32 x 32 row fragments (ds_read_b128: 16 consecutive rows at one chunk -> any
+// bijection of the 8 row pairs onto the 8 slots is conflict-free, as attn.hip's plain (row >> 1) & 7) and the transpose
+// reads (4 consecutive rows x 4 consecutive chunks per half wave): rows r and r + 2 must land in different 64-byte groups,
+// i.e. their XOR values must differ in bit 2 -- rev3(p) ^ rev3(p + 1) = 4 for even p.  With the plain swizzle the
+// transpose reads were 2-way conflicts (15-20 % of the LDS cycles, profiles/r02_kernel_pmc.json).
 __device__ __forceinline__ uint32_t tile_off(int row, int chunk) {
-  return (uint32_t)(row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+  const int p = (row >> 1) & 7;
+  const int x = ((p & 1) << 2) | (p & 2) | ((p >> 2) & 1);
+  return (uint32_t)(row * 128 + ((chunk ^ x) << 4));
 }
 
 __device__ __forceinline__ float dot8(const uint4 a, const uint4 b) {
