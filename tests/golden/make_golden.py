@@ -215,6 +215,33 @@ def gen_full():
         save(f"full_{name}", inputs_embeds=embeds, logits_last=logits[:, -1], greedy_ids=gen)
 
 
+def gen_spp_grads():
+    """Backward of the reference's SpatialPoolingProjector in float64: parameter gradients in full (they are small) and the
+    input gradient's norm + a column sample."""
+    from src.model.multimodal_projector.spatial_pooling_projector import SpatialPoolingProjector
+    for name, c in SPP_CASES.items():
+        m = SpatialPoolingProjector(image_size=c["image_size"], patch_size=c["patch_size"], in_dim=c["in_dim"],
+                                    out_dim=c["E"], layer_type=c["layer_type"], layer_num=c["layer_num"],
+                                    pooling_type=c["pooling_type"], pooling_size=c["pooling_size"]).eval()
+        fill(m, "mm_projector.", c["seed"])
+        m = m.double()
+        with torch.enable_grad():
+            x = spp_inputs(c).double().requires_grad_(True)
+            for p in m.parameters():
+                p.requires_grad_(True)
+            out = m(x)
+            G = synth.synth_tensor("grad_out", tuple(out.shape), c["seed"]).double()
+            (out * G).sum().backward()
+        names, norms, probes = [], [], []
+        for k, p in m.named_parameters():
+            key = "mm_projector." + k
+            names.append(key)
+            norms.append(p.grad.norm().item())
+            probes.append((p.grad * grad_probe(key, p.shape, c["seed"])).sum().item())
+        save(f"spp_{name}_grads", names=np.array(names), norms=np.array(norms, dtype=np.float64),
+             probes=np.array(probes, dtype=np.float64), d_x_s8=x.grad[..., ::8].float(), d_x_norm=x.grad.norm().item())
+
+
 def gen_full_grads():
     """Stage-1 style training step through the reference's u2LlamaForCausalLM in float64 (train_stage1.py:244-251):
     loss = model(images, input_ids, labels, question_ids).loss, backward; norm + name-seeded projection of the gradient of

@@ -209,3 +209,33 @@ def test_full_path_backward_matches_reference_backward(name):
         probe = grad_probe(k, gk.shape, c["seed"])
         assert abs(gk.norm().item() - float(n_ref)) <= 1e-8 * max(float(n_ref), 1e-6 * top), k
         assert abs((gk * probe).sum().item() - float(p_ref)) <= 1e-7 * max(float(n_ref), 1e-6 * top) * probe.norm().item(), k
+
+
+@pytest.mark.parametrize("name", list(SPP_CASES))
+def test_spp_backward_matches_reference_backward(name):
+    """torch.autograd over the oracle's projector against the reference module's own float64 backward (spp_*_grads.npz)."""
+    c = SPP_CASES[name]
+    g = load_golden(f"spp_{name}_grads")
+    m = SpatialPoolingProjector(c["image_size"], c["patch_size"], c["in_dim"], c["E"], c["layer_type"], c["layer_num"],
+                                c["pooling_type"], c["pooling_size"])
+    sd = module_sd(m, "mm_projector.", c["seed"])
+    oc = O.PathConfig(image_size=c["image_size"], patch_size=c["patch_size"], hidden_size=c["E"],
+                      proj_layer_type=c["layer_type"], proj_layer_num=c["layer_num"], proj_pooling_type=c["pooling_type"],
+                      proj_pooling_size=c["pooling_size"])
+    with torch.enable_grad():
+        sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+        x = spp_inputs(c).double().requires_grad_(True)
+        out = O.spp_forward(sd64, "mm_projector", x, oc)
+        G = synth.synth_tensor("grad_out", tuple(out.shape), c["seed"]).double()
+        (out * G).sum().backward()
+    names = [str(n) for n in g["names"]]
+    assert set(names) == {k for k, v in sd64.items() if v.grad is not None}
+    top = float(g["norms"].max())
+    for k, n_ref, p_ref in zip(names, g["norms"], g["probes"]):
+        gk = sd64[k].grad
+        probe = grad_probe(k, gk.shape, c["seed"])
+        assert abs(gk.norm().item() - float(n_ref)) <= 1e-9 * max(float(n_ref), 1e-6 * top), k
+        assert abs((gk * probe).sum().item() - float(p_ref)) <= 1e-8 * max(float(n_ref), 1e-6 * top) * probe.norm().item(), k
+    ref = g["d_x_s8"].double()
+    assert (x.grad[..., ::8] - ref).abs().max().item() <= 1e-6 * ref.abs().max().item() + 1e-9 * top
+    assert abs(x.grad.norm().item() - float(g["d_x_norm"])) <= 1e-9 * float(g["d_x_norm"])
