@@ -26,42 +26,47 @@ def _data(rank, step):
     return torch.randn(5, 24, generator=g), torch.randn(5, 7, generator=g)
 
 
-def _worker(rank, world, port, q, overlap, bucket):
+def _worker(rank, world, port, q, overlap, bucket, clip=None):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
     from u2tokenizer_amd.dp import Zero1AdamW
     dist.init_process_group("gloo", rank=rank, world_size=world)
     m = _model()
     opt = Zero1AdamW(m.parameters(), lr=1e-2, weight_decay=0.1, reduce_bucket_size=bucket, allgather_bucket_size=bucket,
-                     overlap_comm=overlap)
+                     overlap_comm=overlap, max_grad_norm=clip)
+    norms = []
     for step in range(3):
         x, y = _data(rank, step)
         torch.nn.functional.mse_loss(m(x), y).backward()
         opt.step()
+        norms.append(opt.last_grad_norm)
         opt.zero_grad()
-    q.put((rank, [p.detach().clone() for p in m.parameters()], len(opt.buckets), opt.state_bytes_per_rank()))
+    q.put((rank, [p.detach().clone() for p in m.parameters()], len(opt.buckets), opt.state_bytes_per_rank(), norms))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @torch.enable_grad()  # (other test modules of the suite switch autograd off process-wide at import)
-def _reference(world):
+def _reference(world, clip=None):
     m = _model()
     opt = torch.optim.AdamW(m.parameters(), lr=1e-2, weight_decay=0.1)
+    norms = []
     for step in range(3):
         opt.zero_grad()
         for rank in range(world):
             x, y = _data(rank, step)
             (torch.nn.functional.mse_loss(m(x), y) / world).backward()
+        if clip is not None:
+            norms.append(float(torch.nn.utils.clip_grad_norm_(m.parameters(), clip)))
         opt.step()
-    return [p.detach().clone() for p in m.parameters()]
+    return [p.detach().clone() for p in m.parameters()], norms
 
 
-def _run(overlap, bucket):
+def _run(overlap, bucket, clip=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, overlap, bucket)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, overlap, bucket, clip)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=180) for _ in range(2)), key=lambda t: t[0])
@@ -72,16 +77,32 @@ def _run(overlap, bucket):
 
 
 def test_zero1_matches_single_process_adamw():
-    ref = _reference(2)
+    ref, _ = _reference(2)
     nparam = sum(p.numel() for p in ref)
     for overlap, bucket in ((False, 10 ** 9), (True, 700), (True, 10 ** 9)):
-        (r0, p0, nb0, sb0), (r1, p1, nb1, sb1) = _run(overlap, bucket)
+        (r0, p0, nb0, sb0, _), (r1, p1, nb1, sb1, _) = _run(overlap, bucket)
         for a, b, c in zip(p0, p1, ref):
             assert torch.equal(a, b)                                  # replicas stay bit-identical
             assert torch.allclose(a, c, rtol=2e-5, atol=2e-6), (a - c).abs().max()
         assert nb0 == nb1 and (nb0 > 1) == (bucket == 700)
         # the optimiser state is sharded: ~half of 12 bytes per parameter on each of the two ranks
         assert abs(sb0 - 6 * nparam) <= 12 * 2 * nb0 and sb0 == sb1
+
+
+def test_zero1_global_gradient_clipping():
+    """max_grad_norm (ds_config.json:41 "gradient_clipping"): the norm of the MEAN gradient over all parameters is assembled
+    from the ranks' bucket pieces (one scalar all-reduce) and equals torch.nn.utils.clip_grad_norm_ on a single process; the
+    clipped steps agree and the replicas stay bit-identical."""
+    clip = 0.05                                        # well below the actual norms: every step is clipped
+    ref, ref_norms = _reference(2, clip)
+    assert min(ref_norms) > 2 * clip
+    (r0, p0, _, _, n0), (r1, p1, _, _, n1) = _run(True, 700, clip)
+    assert n0 == n1
+    for a, b in zip(n0, ref_norms):
+        assert abs(a - b) <= 1e-5 * b
+    for a, b, c in zip(p0, p1, ref):
+        assert torch.equal(a, b)
+        assert torch.allclose(a, c, rtol=2e-5, atol=2e-6), (a - c).abs().max()
 
 
 @torch.enable_grad()

@@ -49,11 +49,16 @@ class Zero1AdamW:
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
                  process_group=None, reduce_bucket_size: int = int(2e8), allgather_bucket_size: int = int(2e8),
-                 overlap_comm: bool = True):
+                 overlap_comm: bool = True, max_grad_norm: Optional[float] = None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        # global gradient-norm clipping ("gradient_clipping": "auto" of config/ds_config.json:41 = the trainer's max_grad_norm;
+        # torch.nn.utils.clip_grad_norm_ semantics on the MEAN gradient): every rank owns a piece of every bucket, so the
+        # squared norm is the sum of the pieces' squares, one scalar all-reduce per step
+        self.max_grad_norm = max_grad_norm
+        self.last_grad_norm: Optional[float] = None
         self.t = 0
         self.overlap = overlap_comm and self.world > 1
         # parameters are bucketed in REVERSE registration order: the backward produces gradients roughly last layer first,
@@ -148,7 +153,8 @@ class Zero1AdamW:
         self.t += 1
         b1, b2 = self.betas
         c1, c2 = 1 - b1 ** self.t, 1 - b2 ** self.t
-        for b, st in zip(self.buckets, self.state):
+        grads = []
+        for b in self.buckets:
             if b.ready != len(b.params):          # no overlap (or a parameter without a hook firing): pack + reduce now
                 for p, o in zip(b.params, b.offsets):
                     if p.grad is not None:
@@ -157,7 +163,16 @@ class Zero1AdamW:
                         b.flat_grad[o:o + p.numel()].zero_()
                 self._launch_reduce(b)
             self._finish_reduce(b)
-            g = b.my_grad.float() / self.world                           # mean over ranks
+            grads.append(b.my_grad.float() / self.world)                  # mean over ranks, this rank's piece
+        if self.max_grad_norm is not None:
+            sq = torch.stack([g.pow(2).sum() for g in grads]).sum()
+            if self.world > 1:
+                dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=self.group)
+            total = sq.sqrt()
+            self.last_grad_norm = float(total)
+            coef = torch.clamp(self.max_grad_norm / (total + 1e-6), max=1.0)
+            grads = [g * coef for g in grads]
+        for b, st, g in zip(self.buckets, self.state, grads):
             if self.wd:
                 st["master"].mul_(1 - self.lr * self.wd)                  # decoupled weight decay (AdamW)
             st["m"].mul_(b1).add_(g, alpha=1 - b1)
