@@ -195,5 +195,30 @@ class Zero1AdamW:
                 elif p.grad is not None:
                     p.grad.zero_()
 
+    # ------------------------------------------------------------------ checkpoint / resume of this rank's shard
+    def state_dict(self) -> dict:
+        """This rank's shard of the optimiser state (fp32 master pieces + moments, step count) -- what DeepSpeed writes per
+        rank as zero_pp_rank_*_optim_states.  Loading requires the same parameter order, bucket sizes and world size."""
+        return {"step": self.t, "world": self.world, "rank": self.rank,
+                "layout": [(b.numel, len(b.params)) for b in self.buckets],
+                "buckets": [{k: v.detach().cpu().clone() for k, v in st.items()} for st in self.state]}
+
+    def load_state_dict(self, sd: dict) -> None:
+        layout = [(b.numel, len(b.params)) for b in self.buckets]
+        if sd["world"] != self.world or sd["rank"] != self.rank or [tuple(x) for x in sd["layout"]] != layout:
+            raise ValueError("Zero1AdamW.load_state_dict: the shard was written for another world size / rank / bucket layout")
+        self.t = int(sd["step"])
+        with torch.no_grad():
+            for b, st, src in zip(self.buckets, self.state, sd["buckets"]):
+                for k in ("master", "m", "v"):
+                    st[k].copy_(src[k])
+                # the bf16 parameters follow the restored master weights (this rank's piece; the others arrive by all-gather)
+                mine = b.flat_param[self.rank * b.piece:(self.rank + 1) * b.piece]
+                mine.copy_(st["master"])
+                if self.world > 1:
+                    dist.all_gather_into_tensor(b.flat_param, mine.clone(), group=self.group)
+                for p, o in zip(b.params, b.offsets):
+                    p.copy_(b.flat_param[o:o + p.numel()].view_as(p))
+
     def state_bytes_per_rank(self) -> int:
         return sum(s["master"].numel() * 12 for s in self.state)
