@@ -203,7 +203,61 @@ def cpu_baseline(E, Lt, iters=3, sample_chunks=1):
 
 # ---------------------------------------------------------------------------------------------------- HBM traffic (PMC)
 PMC_CLASSES = [("gemm_bf16_nt_kernel", "gemm_bf16"), ("gemm_bt_kernel", "gemm_bf16"), ("gemm_splitk", "gemm_bf16"),
-               ("flash_", "flash_d64")]
+               ("flash_", "flash_d64"), ("tok_attn", "tok_attention")]
+# kernel name fragment -> class of the per-kernel table (order matters: first match)
+KERNEL_CLASSES = [("gemm_bf16_nt_kernel", "gemm_bf16"), ("gemm_bt_kernel", "gemm_bf16"), ("gemm_splitk", "gemm_bf16"),
+                  ("flash_", "flash_d64"), ("tok_attn", "tok_attention"), ("temporal_attention", "temporal_attention"),
+                  ("layernorm", "row_ops"), ("softmax", "row_ops"), ("rope", "row_ops"), ("score_gemv", "row_ops"),
+                  ("topk", "row_ops"), ("multiscale_pool", "row_ops"), ("dmtp_gate", "row_ops"), ("avgpool3d", "row_ops"),
+                  ("im2col", "data_movement"), ("transpose", "data_movement"), ("gather_rows", "data_movement"),
+                  ("embed_splice", "data_movement"), ("fill_rows", "data_movement"), ("copyBuffer", "data_movement")]
+
+
+def _child_env():
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                        "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    env["TMPDIR"] = "/tmp"
+    return env
+
+
+def measure_kernels(E, options, timeout=300):
+    """Per-kernel durations of the path from the profiler's own clock: ONE `rocprofv3 --kernel-trace --stats` child of THIS
+    command (6 timed + 1 warm-up volume on one stream, no counters, no HIP events in the stream), parsed into
+    {kernel name: (launches per volume, average microseconds)}.  Per-launch HIP events (the instrumented pass below) carry the
+    launch gaps of ~250 short launches and overstate kernel time by >= 10 %; this is what `rocprofv3 --stats` of the same
+    command reports, so the committed profiles/rNN_bench_kernel_stats.csv must agree with it.  None if rocprofv3 cannot run."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    nvol = 7
+    tmp = tempfile.mkdtemp(prefix="u2tok_kt_", dir="/tmp")
+    try:
+        cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "-o", "k", "--",
+               sys.executable, str(Path(__file__).resolve()), "--steps", "6", "--warmup", "1", "--repeats", "1",
+               "--streams", "1", "--hidden", str(E), "--no-cpu-baseline", "--no-roofline", "--no-train-step"]
+        for o in options:
+            cmd += ["--option", o]
+        r = subprocess.run(cmd, cwd="/tmp", env=_child_env(), capture_output=True, text=True, timeout=timeout)
+        if r.returncode != 0:
+            return None
+        out = {}
+        for f in glob.glob(os.path.join(tmp, "**", "*kernel_stats.csv"), recursive=True):
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    name = row["Name"]
+                    if "u2::" not in name and "copyBuffer" not in name:
+                        continue  # torch's own kernels: input / weight initialisation of the child, not the path
+                    out[name] = (int(row["Calls"]) / nvol, float(row["AverageNs"]) / 1e3)
+        return out or None
+    except (OSError, subprocess.SubprocessError, ValueError, KeyError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def measure_traffic(E, timeout=240):
@@ -228,11 +282,7 @@ def measure_traffic(E, timeout=240):
             cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, ctr), "-o", "p", "--",
                    sys.executable, str(Path(__file__).resolve()), "--steps", "2", "--warmup", "1", "--repeats", "1",
                    "--streams", "1", "--hidden", str(E), "--no-cpu-baseline", "--no-roofline", "--no-train-step"]
-            env = {k: v for k, v in os.environ.items()
-                   if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
-                                "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
-            env["TMPDIR"] = "/tmp"
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+            r = subprocess.run(cmd, cwd="/tmp", env=_child_env(), capture_output=True, text=True, timeout=timeout)
             if r.returncode != 0:
                 return None
             for f in glob.glob(os.path.join(tmp, ctr, "**", "*counter_collection.csv"), recursive=True):
@@ -462,11 +512,12 @@ def main():
         torch.cuda.synchronize()
         h = _lib.load_library()
         h.u2tok_ctx_set_current(ops.active_context(device).handle)
-        ms, flops, byts, cnt = (C.c_double * 5)(), (C.c_double * 5)(), (C.c_double * 5)(), (C.c_int64 * 5)()
-        _lib.check(h.u2tok_profile_collect2(ms, flops, byts, cnt, 5), "u2tok_profile_collect2")
+        ms, flops, byts, cnt = (C.c_double * 6)(), (C.c_double * 6)(), (C.c_double * 6)(), (C.c_int64 * 6)()
+        _lib.check(h.u2tok_profile_collect2(ms, flops, byts, cnt, 6), "u2tok_profile_collect2")
         ops.set_option("profile", 0)
         names = ["gemm_bf16 (gemm_bt_kernel + gemm_bf16_nt_kernel + gemm_splitk_reduce_kernel)",
-                 "flash_d64 (flash_dp_kernel)", "temporal_attention_kernel", "row_ops", "data_movement"]
+                 "flash_d64 (flash_dp_kernel)", "temporal_attention_kernel", "row_ops", "data_movement",
+                 "tok_attention (tok_attn_kernel + tok_attn_combine_kernel)"]
         # per class: time, launches, algorithmic TFLOP/s and algorithmic GB/s (operands + results once) of its launches
         classes = {n: {"ms_per_step": round(ms[i] / nprof, 4), "launches_per_step": cnt[i] // nprof,
                        "tflops": round(flops[i] / ms[i] / 1e9, 1) if ms[i] > 0 and flops[i] > 0 else None,
@@ -477,7 +528,7 @@ def main():
         traffic = {}
         live = measure_traffic(E) if (B == 1 and world == 1 and not args.no_traffic) else None
         if live:
-            for key, idx in (("gemm_bf16", 0), ("flash_d64", 1)):
+            for key, idx in (("gemm_bf16", 0), ("flash_d64", 1), ("tok_attention", 5)):
                 if key in live and cnt[idx]:
                     traffic[key] = (round(live[key] / max(cnt[idx] // nprof, 1)),
                                     "live: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per volume / calls per volume, two rocprofv3 "
@@ -494,16 +545,56 @@ def main():
                                     "calls per volume; rocprofv3 --pmc, separate passes of this command; fabric-side "
                                     "requests (Infinity Cache hits included)")
 
+        # per-kernel table from the profiler's clock (one rocprofv3 --kernel-trace --stats child of this command)
+        ktab = measure_kernels(E, args.option) if (B == 1 and world == 1 and not args.no_traffic) else None
+        cls_key = ["gemm_bf16", "flash_d64", "temporal_attention", "row_ops", "data_movement", "tok_attention"]
+        kt_ms = {}
+        if ktab:
+            table = []
+            for name, (calls, us) in sorted(ktab.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+                cl = next((lab for frag, lab in KERNEL_CLASSES if frag in name), "other")
+                kt_ms[cl] = kt_ms.get(cl, 0.0) + calls * us / 1e3
+                table.append({"kernel": name.replace("void u2::", "").replace("u2::", "")[:96], "class": cl,
+                              "launches_per_volume": round(calls, 2), "avg_us": round(us, 2),
+                              "ms_per_volume": round(calls * us / 1e3, 4)})
+            total_ms = sum(kt_ms.values())
+            wall_ms = 1e3 * (single if single else elapsed) / args.steps
+            line["kernel_table"] = {
+                "source": "rocprofv3 --kernel-trace --stats child of this command: 7 volumes, one stream, no counters",
+                "kernels": table[:24],
+                "classes": {k: {"ms_per_volume": round(v, 4),
+                                "tflops": (round(flops[cls_key.index(k)] / nprof / v / 1e9, 1)
+                                           if k in cls_key and flops[cls_key.index(k)] > 0 and v > 0 else None),
+                                "frac_of_bf16_mfma_peak": (round(flops[cls_key.index(k)] / nprof / v / 1e9 / PEAK_BF16_TFLOPS, 4)
+                                                           if k in cls_key and flops[cls_key.index(k)] > 0 and v > 0 else None)}
+                            for k, v in sorted(kt_ms.items(), key=lambda kv: -kv[1])},
+                "sum_ms_per_volume": round(total_ms, 4), "one_stream_wall_ms_per_volume": round(wall_ms, 4),
+                # kernels of one volume on one stream cannot add up to more than its wall time, except for what the tokenizer's
+                # side stream overlaps (TTA k|v projections) -- a sanity check on the bookkeeping, reported, not enforced
+                "sum_le_wall": bool(total_ms <= 1.03 * wall_ms)}
+
         def roof(idx, key, kernel):
-            ach = flops[idx] / ms[idx] / 1e9
+            ach_ev = flops[idx] / ms[idx] / 1e9
+            per_launch = max(cnt[idx], 1)
+            if key in kt_ms and kt_ms[key] > 0:  # profiler clock (what rocprofv3 --stats of this command reports)
+                ach = flops[idx] / nprof / kt_ms[key] / 1e9
+                us = 1e3 * kt_ms[key] / max(cnt[idx] // nprof, 1)
+                how = ("algorithmic FLOPs of the class's launches in one step (counted by the launchers) / their summed "
+                       "kernel durations per volume from a rocprofv3 --kernel-trace --stats child of this command (one "
+                       "stream, 7 volumes); `achieved_hip_events` = the same FLOPs / HIP-event durations around every launch "
+                       "(instrumented one-stream pass after the timed region; carries the launch gaps)")
+            else:
+                ach, us = ach_ev, 1e3 * ms[idx] / per_launch
+                how = ("HIP events on the launch stream around every launch of the class, one-stream instrumented pass of "
+                       "3 steps after the timed region")
             tr = traffic.get(key, (None, None))
             return {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": tr[0],
                     "traffic_unit": "bytes per launch (average)", "traffic_source": tr[1],
-                    "algorithmic_bytes_per_launch": round(byts[idx] / max(cnt[idx], 1)),
-                    "avg_launch_us": round(1e3 * ms[idx] / max(cnt[idx], 1), 2), "flop_per_step": flops[idx] / nprof,
-                    "measured": "HIP events on the launch stream around every launch of the class, one-stream "
-                                "instrumented pass of 3 steps after the timed region"}
+                    "algorithmic_bytes_per_launch": round(byts[idx] / per_launch),
+                    "avg_launch_us": round(us, 2), "flop_per_step": flops[idx] / nprof,
+                    "achieved_hip_events": round(ach_ev, 1), "avg_launch_us_hip_events": round(1e3 * ms[idx] / per_launch, 2),
+                    "measured": how}
 
         line["roofline"] = roof(0, "gemm_bf16", "bf16 MFMA GEMM, all launches of one step (gemm_bt_kernel 256x256 / 256x192 "
                                                 "tiles, gemm_bf16_nt_kernel 128^2 / 64^2 tiles, split-K reduce)")
@@ -511,6 +602,10 @@ def main():
         if ms[1] > 0:
             line["roofline_attention"] = roof(1, "flash_d64", "flash_dp_kernel: ViT attention, 8 chunks x 12 heads x 2049 "
                                                                "tokens x head dim 64 (MONAI SABlock, vit.py:100-105)")
+        if ms[5] > 0:
+            line["roofline_tokenizer_attention"] = roof(5, "tok_attention",
+                                                        "tok_attn_kernel (+ tok_attn_combine_kernel): the tokenizer's own attention "
+                                                        "cores, head dim E/8 = 512 (rma.py:60-75, tta.py:55-61)")
     if rank == 0 and world == 1 and not args.no_train_step and not args.stub_cpu and B == 1:
         # SURVEY 8f rank 1 (built in round 2): a measured line for the training form of the path, after the timed region
         try:

@@ -57,6 +57,7 @@ u2tok_ctx_t u2tok_ctx_get_current(void);     /* NULL when the thread uses the de
     big-tile kernel}, "kmajor_b" {1: P V and the DiffTS aggregation read V / X in place as K-major operands, 0: through
     transposed copies},
     "flash_mode" {0 pick, 1 plain 128-row units, 5 double pipeline (asm KV loop)}, "vit_flash" {0 unfused attention, 1}, "tta_overlap" {0, 1: side stream for the TTA k|v projections},
+    "tok_flash" {1: the tokenizer's attention cores run the fused kernel of u2tok_tok_attention, 0: GEMM -> softmax -> GEMM},
     "profile" {0, 1} */
 int u2tok_set_option(const char* name, int value);
 /* Scratch for split-K partial sums of u2tok_gemm_bf16 calls on `stream` (fp32, slices x M x N), registered on the
@@ -68,10 +69,11 @@ int u2tok_set_gemm_scratch(void* device_ptr, size_t bytes, void* stream);
  * cycle sums per (workgroup, wave). */
 int u2tok_flash_debug_buffer(void* device_ptr);
 
-/* With option "profile" = 1 every launch is bracketed by hipEvents on its stream.  Collect (HOST arrays of ncat <= 5
+/* With option "profile" = 1 every launch is bracketed by hipEvents on its stream.  Collect (HOST arrays of ncat <= 6
  * entries; synchronises on the recorded events, then resets): summed milliseconds, algorithmic FLOPs and launch
  * counts per kernel class 0 = MFMA GEMM, 1 = ViT flash attention, 2 = temporal attention, 3 = row ops
- * (LayerNorm / softmax / RoPE / scores / top-k / pooling), 4 = data movement (im2col, transposes, gathers, splice). */
+ * (LayerNorm / softmax / RoPE / scores / top-k / pooling), 4 = data movement (im2col, transposes, gathers, splice),
+ * 5 = fused tokenizer attention (u2tok_tok_attention). */
 int u2tok_profile_collect(double* ms_host, double* flops_host, int64_t* count_host, int32_t ncat);
 /* Same, plus the summed ALGORITHMIC bytes (every operand read once + every result written once) per class. */
 int u2tok_profile_collect2(double* ms_host, double* flops_host, double* bytes_host, int64_t* count_host, int32_t ncat);
@@ -172,6 +174,22 @@ int u2tok_tokenizer_forward(const u2tok_tokenizer_config* cfg, const void* const
                             const void* t_token, void* out, int64_t* topk_idx_out, void* svr_out, void* workspace,
                             size_t workspace_bytes, u2tok_stream_t stream);
 
+/* Same forward with PARITY TAPS (tests): any layer's input can be replaced by a caller buffer ("teacher forcing": each
+ * layer of the residual-free SVR stack / of the TTA is then compared on the reference's own fp32 input for that layer) and
+ * any layer's output copied out.  Every pointer, and every array entry, may be NULL.  Shapes: svr (B,T,N,E), visual
+ * (B,Lv,E) with Lv = top_k (+ top_k/2 + top_k/4 with multi-scale pooling), tta (B,num_query,E); all bf16. */
+typedef struct {
+  const void* const* svr_in;  /* [num_layers]: replaces the input of SVR layer l (svr.py:23-40) */
+  void* const* svr_out;       /* [num_layers]: receives the output of SVR layer l */
+  const void* visual_in;      /* replaces the visual tokens the TTA attends to (output of svr.py:171-184) */
+  void* visual_out;           /* receives them (before a replacement) */
+  const void* const* tta_in;  /* [num_layers]: replaces the query input of TTA layer l (tta.py:93-107) */
+  void* const* tta_out;       /* [num_layers]: receives the output of TTA layer l */
+} u2tok_tokenizer_taps;
+int u2tok_tokenizer_forward_taps(const u2tok_tokenizer_config* cfg, const void* const* weights, const void* v_token,
+                                 const void* t_token, void* out, int64_t* topk_idx_out, const u2tok_tokenizer_taps* taps,
+                                 void* workspace, size_t workspace_bytes, u2tok_stream_t stream);
+
 /* Replaces embed_tokens(ids) + the splice of u2_arch.py:109,113-116:
  * out[b][s] = (1 <= s <= nfeat) ? feats[b][s-1] : table[ids[b][s]].  nfeat = 0 / feats = null: plain lookup. */
 int u2tok_embed_splice(const void* table, const int64_t* ids, const void* feats, void* out, int32_t B, int32_t S,
@@ -253,6 +271,19 @@ int u2tok_flash_attention_d64_lse(const void* q, const void* k, const void* vt, 
                               float scale, const void* qx, const void* kx, const void* vx, void* outx, int64_t x_bs,
                               int64_t ox_bs, int32_t n_extra, float* lse, int64_t lse_ld,
                                   u2tok_stream_t stream);
+/* Fused attention core of the tokenizer's attention modules -- RelativeMultiheadAttention (rma.py:60-75: + relative_bias
+ * [j - i + max_len - 1][h], bf16 (2 max_len - 1, H)), RotaryMultiheadAttention (rope.py:82-86), MultiHeadCrossAttention /
+ * LinearAggregation (tta.py:55-61; rel_bias NULL):  out = softmax(q k^T scale + bias) v  per (batch, head), scores and
+ * probabilities never in HBM.  Row r of batch b at ptr + b*?_bs + r*ld?, head h at column h*d, d in {64, 128, 256, 512};
+ * q / k / v 16-byte aligned with strides % 8 == 0, out 8-byte aligned with strides % 4 == 0; with rel_bias: Sq, Skv <=
+ * max_len.  splits: 0 = heuristic, n > 0 = cut the keys into n ranges (fp32 partial sums in `workspace`:
+ * u2tok_tok_attention_workspace_bytes, 16-byte aligned; NULL = unsplit).  U2TOK_ERR_ARG for shapes it does not take. */
+size_t u2tok_tok_attention_workspace_bytes(int32_t nb, int32_t H, int32_t Sq, int32_t Skv, int32_t d);
+int u2tok_tok_attention(const void* q, const void* k, const void* v, void* out, int32_t nb, int32_t Sq, int32_t Skv, int32_t H,
+                        int32_t d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs,
+                        int64_t o_bs, float scale, const void* rel_bias, int32_t max_len, int32_t splits, void* workspace,
+                        size_t workspace_bytes, u2tok_stream_t stream);
+
 /* in-place rotate-half RoPE (rope.py:6-13,77-80): rows indexed (outer, s, inner), position = s; inverse != 0 rotates
  * the other way (the backward of the rotation) */
 int u2tok_rope_apply(void* x, int64_t n_outer, int32_t S, int32_t n_inner, int32_t H, int32_t d, int64_t ld,
@@ -283,6 +314,15 @@ int u2tok_relbias_grad(const void* dS, float* dtable, int32_t nz, int32_t S, int
                        u2tok_stream_t stream);
 int u2tok_rowdot_bf16(const void* a, const void* b, float* out, int64_t rows, int32_t C, int64_t lda, int64_t ldb,
                       u2tok_stream_t stream);
+
+/* One rank's shard of a ZeRO-1 AdamW step (config/ds_config.json:27-41; u2tokenizer_amd/dp.py): fp32 master weights and
+ * moments (n elements each) updated in place from the bf16 gradient piece scaled by grad_scale (1 / world size) and, when
+ * grad_coef != NULL, by the device scalar *grad_coef (the clipping coefficient); out_bf16 receives the rounded new master
+ * (the piece the all-gather sends).  torch.optim.AdamW arithmetic; step = 1-based step count (bias corrections).  group:
+ * optional per-element parameter-group index (uint8) into the host tables lr[ngroups] / weight_decay[ngroups], ngroups <= 8. */
+int u2tok_adamw_step(float* master, float* exp_avg, float* exp_avg_sq, const void* grad, const uint8_t* group, void* out_bf16,
+                     int64_t n, const float* lr, const float* weight_decay, int32_t ngroups, float beta1, float beta2, float eps,
+                     int32_t step, float grad_scale, const float* grad_coef, u2tok_stream_t stream);
 
 /* Fused backward of the ViT attention core (MONAI SABlock, vit.py:100-105; head dim 64, no bias):
  *   out = softmax(q k^T * scale) v   ->   dq, dk, dv   from q, k, v, out and d_out,

@@ -327,20 +327,24 @@ def svr_forward(sd: SD, p: str, x: torch.Tensor, cfg: PathConfig):
 
 
 # --------------------------------------------------------------------------- TTA
+def tta_layer(sd: SD, lp: str, query, visual, text, cfg: PathConfig) -> torch.Tensor:
+    """TextConditionTokenAttMap.forward (tta.py:93-107); lp = "...tta_module.layers_vt.N"."""
+    H = cfg.u2t_num_heads
+    e = query.shape[-1]
+    so = self_attention(sd, lp + ".self_attention", query, H, cfg.attn_type, cfg.max_seq_len)
+    so = F.layer_norm(query + so, (e,), sd[lp + ".norm_self.weight"], sd[lp + ".norm_self.bias"])
+    co = cross_attention(sd, lp + ".visual_cross_attention", so, visual, H)
+    cv = F.layer_norm(so + co, (e,), sd[lp + ".norm_cross_v.weight"], sd[lp + ".norm_cross_v.bias"])
+    ct = cross_attention(sd, lp + ".text_cross_attention", cv, text, H)
+    return F.layer_norm(cv + ct, (e,), sd[lp + ".norm_cross_t.weight"], sd[lp + ".norm_cross_t.bias"])
+
+
 def tta_forward(sd: SD, p: str, query, visual, text, cfg: PathConfig) -> torch.Tensor:
     """TextConditionTokenAggregatorModel.forward (tta.py:126-140) with TextConditionTokenAttMap.forward
     (tta.py:93-107) and LinearAggregation.forward (tta.py:114-116)."""
-    H = cfg.u2t_num_heads
-    e = query.shape[-1]
     for l in range(cfg.u2t_num_layers):
-        lp = f"{p}.layers_vt.{l}"
-        so = self_attention(sd, lp + ".self_attention", query, H, cfg.attn_type, cfg.max_seq_len)
-        so = F.layer_norm(query + so, (e,), sd[lp + ".norm_self.weight"], sd[lp + ".norm_self.bias"])
-        co = cross_attention(sd, lp + ".visual_cross_attention", so, visual, H)
-        cv = F.layer_norm(so + co, (e,), sd[lp + ".norm_cross_v.weight"], sd[lp + ".norm_cross_v.bias"])
-        ct = cross_attention(sd, lp + ".text_cross_attention", cv, text, H)
-        query = F.layer_norm(cv + ct, (e,), sd[lp + ".norm_cross_t.weight"], sd[lp + ".norm_cross_t.bias"])
-    return cross_attention(sd, p + ".layer_linagg.linear_aggregator", query, visual, H, is_compress=True)
+        query = tta_layer(sd, f"{p}.layers_vt.{l}", query, visual, text, cfg)
+    return cross_attention(sd, p + ".layer_linagg.linear_aggregator", query, visual, cfg.u2t_num_heads, is_compress=True)
 
 
 def tokenizer_forward(sd: SD, p: str, v_token: torch.Tensor, t_token: torch.Tensor, cfg: PathConfig):

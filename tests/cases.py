@@ -76,3 +76,7 @@ def tokenizer_inputs(c):
 def spp_inputs(c):
     g = [i // p for i, p in zip(c["image_size"], c["patch_size"])]
     return synth.synth_tensor("spp_in", (c["nchunk"], g[0] * g[1] * g[2], c["in_dim"]), c["seed"])
+
+# BASELINE configs[3] (stage-1 training step of the path at its real size): tests/golden/make_config4_grads.py differentiates
+# the oracle here, tests/test_gpu_backward.py::test_config4_full_depth_full_width_gradients the HIP path on the GPU
+CONFIG4_CASE = dict(E=4096, image_size=[32, 256, 256], vocab=4096, S=1024, Lt=1024, Q=256, seed=95)

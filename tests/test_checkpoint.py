@@ -4,6 +4,7 @@ bit, through torch.save and safetensors, including a tokenizer whose q | k | v p
 import json
 from pathlib import Path
 
+import pytest
 import torch
 
 import u2tokenizer_amd as U
@@ -64,3 +65,60 @@ def test_prefix_selection_like_the_reference_projector_load():
     CK.load_checkpoint(proj, whole, strict=True, prefix="mm_projector")       # u2_arch.py:74-78
     for k, v in proj.state_dict().items():
         assert torch.equal(v, whole["model.mm_projector." + k])
+
+
+@pytest.mark.gpu
+def test_reference_checkpoint_into_packed_gpu_model_forward_parity(tmp_path):
+    """SURVEY 8f-4 on the device: a reference-keyed `pytorch_model.bin` (what `u2Trainer._save` writes,
+    sft_u2Trainer.py:19-22) loaded into modules that already sit PACKED on the GPU (u2_arch.py:64-66,74-78 /
+    train_stage1.py:339 do strict loads into built models) -- the packed q | k | v buffers must receive it (the library
+    reads those, not the nn.Parameter objects), the forward must equal the oracle run on the file's weights, and saving
+    the GPU model again must reproduce the file bit for bit in both formats."""
+    import pytest as _pt  # noqa: F401
+    from types import SimpleNamespace as NS
+    from helpers import err_stats
+    from oracle import u2_oracle as O
+    assert torch.cuda.is_available()
+    bf, D = torch.bfloat16, "cuda"
+    c = _cfg(u2t_num_layers=2, u2t_top_k=32)
+    src = torch.nn.ModuleDict({"vision_tower": U.build_vision_tower(c), "mm_projector": U.build_mm_projector(c),
+                               "u2tokenizer": U.build_u2tokenizer_tower(c)})
+    synth.fill_module_(src, seed=11, lively=True, prefix="model.")
+    ref = {k: v.to(bf) for k, v in src.state_dict().items()}       # a bf16 checkpoint, as the trainer writes one
+    path = tmp_path / "ref_ckpt"
+    path.mkdir()
+    torch.save(ref, path / CK.WEIGHTS_NAME)
+
+    m = _modules().to(bf).to(D)                                    # other weights, packed on the GPU
+    before = CK.packing_report(m)
+    assert before["qkv_packed"] == before["attention_modules"] - 1 > 0
+    ptr_before = m.u2tokenizer.svt_module.attention_network.layers[0].spatial_attention.wq.weight.data_ptr()
+    res = CK.load_checkpoint(m, str(path), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert CK.packing_report(m) == before
+    assert m.u2tokenizer.svt_module.attention_network.layers[0].spatial_attention.wq.weight.data_ptr() == ptr_before
+
+    img = c.image_size
+    vol = synth.synth_volume(1, 2, img, seed=11, dtype=torch.float16)
+    t = (0.25 * synth.synth_tensor("t_token", (1, 24, c.hidden_size), 11)).to(bf)
+    with torch.no_grad():
+        f = m.mm_projector(m.vision_tower(vol.to(D).view(2, 1, *img)))
+        got = m.u2tokenizer(v_token=f.view(1, 2, -1, c.hidden_size), t_token=t.to(D))
+    sd32 = {"model." + k: v.float() for k, v in ref.items()}
+    sd16 = {"model." + k: v for k, v in ref.items()}
+    oc = O.PathConfig(image_size=img, hidden_size=c.hidden_size, u2t_num_layers=2, u2t_top_k=32, num_3d_query_token=16)
+
+    def oracle(sd, dt):
+        with torch.no_grad():
+            x = O.vit_tower_forward(sd, "model.vision_tower.vision_tower", vol.to(dt).view(2, 1, *img), oc)
+            x = O.spp_forward(sd, "model.mm_projector", x, oc)
+            return O.tokenizer_forward(sd, "model.u2tokenizer", x.view(1, 2, -1, c.hidden_size), t.to(dt), oc)[0]
+
+    o32, o16 = oracle(sd32, torch.float32), oracle(sd16, bf)
+    e_hip, e_orc = err_stats(got.float().cpu(), o32), err_stats(o16.float(), o32)
+    assert e_hip["rel_rms"] <= 1.5 * e_orc["rel_rms"] + 1e-3, (e_hip, e_orc)
+    for safe in (False, True):
+        out = CK.read_checkpoint(CK.save_checkpoint(m, str(tmp_path / f"out{int(safe)}"), safe_serialization=safe))
+        assert out.keys() == ref.keys()
+        for k in ref:
+            assert torch.equal(out[k], ref[k]), k

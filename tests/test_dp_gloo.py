@@ -15,10 +15,24 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _model():
+class _WithDead(torch.nn.Sequential):
+    """the plain model + a Linear that the forward never touches"""
+
+    def __init__(self, *mods):
+        super().__init__(*mods)
+        self.dead = torch.nn.Linear(11, 13)
+
+    def forward(self, x):
+        for name, mod in self.named_children():
+            if name != "dead":
+                x = mod(x)
+        return x
+
+
+def _model(variant="plain"):
     torch.manual_seed(0)
-    return torch.nn.Sequential(torch.nn.Linear(24, 40), torch.nn.GELU(), torch.nn.Linear(40, 40), torch.nn.LayerNorm(40),
-                               torch.nn.Linear(40, 7))
+    mods = [torch.nn.Linear(24, 40), torch.nn.GELU(), torch.nn.Linear(40, 40), torch.nn.LayerNorm(40), torch.nn.Linear(40, 7)]
+    return _WithDead(*mods) if variant == "unused" else torch.nn.Sequential(*mods)
 
 
 def _data(rank, step):
@@ -26,62 +40,88 @@ def _data(rank, step):
     return torch.randn(5, 24, generator=g), torch.randn(5, 7, generator=g)
 
 
-def _worker(rank, world, port, q, overlap, bucket, clip=None):
+def _worker(rank, world, port, q, overlap, bucket, clip=None, accum=1, variant="plain"):
+    """variant: "plain"; "unused" = a parameter that never receives a gradient sits in the model (linear_aggregator.wv / dense
+    of the reference, tta.py:47-48,62-65); "groups" = HF-style parameter groups (no decay on biases / LayerNorm); "none" = the
+    caller clears gradients with set_to_none=True (what HF Trainer's model.zero_grad() does)."""
+    import traceback
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
-    from u2tokenizer_amd.dp import Zero1AdamW
+    from u2tokenizer_amd.dp import Zero1AdamW, hf_param_groups
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    m = _model()
-    opt = Zero1AdamW(m.parameters(), lr=1e-2, weight_decay=0.1, reduce_bucket_size=bucket, allgather_bucket_size=bucket,
-                     overlap_comm=overlap, max_grad_norm=clip)
-    norms = []
-    for step in range(3):
-        x, y = _data(rank, step)
-        torch.nn.functional.mse_loss(m(x), y).backward()
-        opt.step()
-        norms.append(opt.last_grad_norm)
-        opt.zero_grad()
-    q.put((rank, [p.detach().clone() for p in m.parameters()], len(opt.buckets), opt.state_bytes_per_rank(), norms))
+    try:
+        m = _model(variant)
+        params = hf_param_groups(m, 0.1) if variant == "groups" else m.parameters()
+        opt = Zero1AdamW(params, lr=1e-2, weight_decay=0.1, reduce_bucket_size=bucket, allgather_bucket_size=bucket,
+                         overlap_comm=overlap, max_grad_norm=clip, gradient_accumulation_steps=accum)
+        norms, launched_early = [], []
+        for step in range(3):
+            for micro in range(accum):
+                x, y = _data(rank, step * accum + micro)
+                (torch.nn.functional.mse_loss(m(x), y) / accum).backward()
+                if micro < accum - 1:
+                    assert opt._next_launch == 0, "a bucket was reduced before the last micro-batch"
+            launched_early.append(opt._next_launch)   # buckets whose reduce-scatter was launched from a hook (overlap)
+            opt.step()
+            norms.append(opt.last_grad_norm)
+            if variant == "none":
+                m.zero_grad(set_to_none=True)
+            else:
+                opt.zero_grad()
+        q.put((rank, [p.detach().clone() for p in m.parameters()], len(opt.buckets), opt.state_bytes_per_rank(), norms,
+               launched_early))
+    except Exception:  # a failure of the exchange under test must surface as itself, not as a start-up hiccup
+        q.put((rank, "error", traceback.format_exc()))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @torch.enable_grad()  # (other test modules of the suite switch autograd off process-wide at import)
-def _reference(world, clip=None):
-    m = _model()
-    opt = torch.optim.AdamW(m.parameters(), lr=1e-2, weight_decay=0.1)
+def _reference(world, clip=None, accum=1, variant="plain"):
+    from u2tokenizer_amd.dp import hf_param_groups
+    m = _model(variant)
+    opt = torch.optim.AdamW(hf_param_groups(m, 0.1) if variant == "groups" else m.parameters(), lr=1e-2, weight_decay=0.1)
     norms = []
     for step in range(3):
         opt.zero_grad()
         for rank in range(world):
-            x, y = _data(rank, step)
-            (torch.nn.functional.mse_loss(m(x), y) / world).backward()
+            for micro in range(accum):
+                x, y = _data(rank, step * accum + micro)
+                (torch.nn.functional.mse_loss(m(x), y) / (world * accum)).backward()
+        if variant == "unused":
+            # a flat ZeRO partition has a (zero) gradient for every element, so AdamW's decoupled weight decay also shrinks
+            # parameters that received none -- DeepSpeed's behaviour, unlike torch.optim.AdamW skipping grad-less tensors
+            for p in m.dead.parameters():
+                p.grad = torch.zeros_like(p)
         if clip is not None:
             norms.append(float(torch.nn.utils.clip_grad_norm_(m.parameters(), clip)))
         opt.step()
     return [p.detach().clone() for p in m.parameters()], norms
 
 
-def _run(overlap, bucket, clip=None):
-    # one retry: process start-up of a spawned pair occasionally fails on a loaded host (port reuse, /dev/shm hiccups) --
-    # that is the launcher's environment, not the exchange under test
+def _run(overlap, bucket, clip=None, accum=1, variant="plain"):
+    # one retry, and only for what is the launcher's environment rather than the exchange under test: the result queue of a
+    # spawned pair breaking on a loaded host (EOFError / ConnectionError while unpickling shared-memory tensors).  A worker
+    # that raises reports its traceback through the queue and FAILS the test; so does a non-zero exit code.
     try:
-        return _run_once(overlap, bucket, clip)
-    except (EOFError, FileNotFoundError, ConnectionError, OSError, AssertionError):
-        return _run_once(overlap, bucket, clip)
+        return _run_once(overlap, bucket, clip, accum, variant)
+    except (EOFError, ConnectionError, FileNotFoundError):
+        return _run_once(overlap, bucket, clip, accum, variant)
 
 
-def _run_once(overlap, bucket, clip=None):
+def _run_once(overlap, bucket, clip=None, accum=1, variant="plain"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, overlap, bucket, clip)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, overlap, bucket, clip, accum, variant)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=180) for _ in range(2)), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
-        assert p.exitcode == 0
+    for r in res:
+        assert r[1] != "error", r[2]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     return res
 
 
@@ -89,7 +129,8 @@ def test_zero1_matches_single_process_adamw():
     ref, _ = _reference(2)
     nparam = sum(p.numel() for p in ref)
     for overlap, bucket in ((False, 10 ** 9), (True, 700), (True, 10 ** 9)):
-        (r0, p0, nb0, sb0, _), (r1, p1, nb1, sb1, _) = _run(overlap, bucket)
+        (r0, p0, nb0, sb0, _, early), (r1, p1, nb1, sb1, _, _) = _run(overlap, bucket)
+        assert all(e == (nb0 if overlap else 0) for e in early)      # with overlap_comm every bucket goes from its hook
         for a, b, c in zip(p0, p1, ref):
             assert torch.equal(a, b)                                  # replicas stay bit-identical
             assert torch.allclose(a, c, rtol=2e-5, atol=2e-6), (a - c).abs().max()
@@ -105,13 +146,35 @@ def test_zero1_global_gradient_clipping():
     clip = 0.05                                        # well below the actual norms: every step is clipped
     ref, ref_norms = _reference(2, clip)
     assert min(ref_norms) > 2 * clip
-    (r0, p0, _, _, n0), (r1, p1, _, _, n1) = _run(True, 700, clip)
+    (r0, p0, _, _, n0, _), (r1, p1, _, _, n1, _) = _run(True, 700, clip)
     assert n0 == n1
     for a, b in zip(n0, ref_norms):
         assert abs(a - b) <= 1e-5 * b
     for a, b, c in zip(p0, p1, ref):
         assert torch.equal(a, b)
         assert torch.allclose(a, c, rtol=2e-5, atol=2e-6), (a - c).abs().max()
+
+
+def test_zero1_gradient_accumulation_unused_parameters_and_groups():
+    """config/ds_config.json:40 gradient_accumulation_steps: the reduce-scatter of a bucket must wait for the LAST micro-batch
+    (the worker asserts nothing was launched earlier), gradients accumulate in the flat buckets, and the result equals one
+    process accumulating world x accum micro-batches.  A parameter that never receives a gradient costs the overlap only in
+    the first step (the bucket's expected hook count is learnt).  HF-style parameter groups (no decay on biases / LayerNorm)
+    and a caller that clears gradients with set_to_none=True give the same parameters as torch.optim.AdamW."""
+    for variant, accum, clip in (("plain", 3, None), ("unused", 2, 0.05), ("groups", 1, None), ("none", 2, None)):
+        ref, ref_norms = _reference(2, clip, accum, variant)
+        (r0, p0, nb, _, n0, early), (r1, p1, _, _, n1, _) = _run(True, 700, clip, accum, variant)
+        assert n0 == n1
+        for a, b, c in zip(p0, p1, ref):
+            assert torch.equal(a, b), variant
+            assert torch.allclose(a, c, rtol=2e-5, atol=2e-6), (variant, (a - c).abs().max())
+        if clip is not None:
+            for a, b in zip(n0, ref_norms):
+                assert abs(a - b) <= 1e-5 * b
+        if variant == "unused":
+            assert early[0] < nb and early[1] == nb and early[2] == nb, early   # learnt after the first step
+        else:
+            assert all(e == nb for e in early), (variant, early)
 
 
 @torch.enable_grad()

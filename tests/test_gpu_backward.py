@@ -581,3 +581,75 @@ def test_dpo_duplicate_image_batch_is_deduplicated():
     assert rel(res[True][0].float(), res[False][0].float()) < 1e-3
     for k, g in res[False][1].items():
         assert rel(res[True][1][k].float(), g.float(), 1e-3 * g.float().abs().max().item()) < 5e-2, k
+
+
+def test_config4_full_depth_full_width_gradients():
+    """BASELINE configs[3], the stage-1 training step of the path at its REAL size (train_stage1.py:244-251 with
+    freeze_vision_tower False): 12 ViT blocks on 8 chunks of (32,256,256) -> SPP -> the 4-layer rma + DiffTS + DMTP tokenizer
+    at E = 4096 -> embedding splice, HIP forward + backward, the gradient of EVERY parameter against torch.autograd over the
+    oracle in fp32.  The oracle side (3 minutes of host time and 45 GB) was run in the build container and is committed as
+    tests/golden/config4_grads.npz (tests/golden/make_config4_grads.py: per parameter the gradient norm, a strided sample of
+    1024 entries, and the distance of the reference's own bf16 run -- the yardstick of check_grads)."""
+    import sys
+    from pathlib import Path
+    from types import SimpleNamespace as NS
+    import numpy as np
+    sys.path.insert(0, str(Path(__file__).resolve().parent / "golden"))
+    import make_config4_grads as M
+    from cases import CONFIG4_CASE as c
+    from helpers import load_golden
+    from test_gpu_configs import PathHolder, mm_config, record
+    from u2tokenizer_amd.arch import u2MetaForCausalLM
+    g = load_golden("config4_grads")
+    names = [str(n) for n in g["names"]]
+    mc = mm_config(c["E"], c["image_size"])
+
+    class PathOnly(u2MetaForCausalLM):
+        def __init__(self, holder):
+            self.holder, self.config = holder, NS(**mc)
+
+        def get_model(self):
+            return self.holder
+
+    with torch.device("meta"):
+        holder = PathHolder(mc, c["vocab"])
+    sd = M.path_state_dict(c, bf)
+    sd[M.SPP_BIAS] = g["spp_bias"].to(bf)
+    holder = holder.to(bf).to_empty(device=D)
+    holder.load_state_dict({k[len("model."):]: v for k, v in sd.items()}, strict=True)
+    del sd
+    for p in holder.parameters():
+        p.requires_grad_(True)
+    holder.train()
+    vol, ids, qids, G = M.config4_inputs(c)
+    emb = PathOnly(holder).prepare_inputs_for_multimodal(ids.to(D), None, None, None, None, vol.to(D), qids.to(D))[4]
+    tok = slice(1, 1 + c["Q"])
+    ref_tok = g["out_tokens_s16"].double()
+    e_out = ((emb[0, tok, ::16].double().cpu() - ref_tok).norm() / ref_tok.norm()).item()
+    (emb.float() * G.to(D)).sum().backward()
+    got = {"model." + k: p.grad for k, p in holder.named_parameters() if p.grad is not None}
+    assert set(got) == set(names), set(got) ^ set(names)
+    floor = float(g["floor"])
+    rep, bad, dot, na, nb = {}, {}, 0.0, 0.0, 0.0
+    for i, k in enumerate(names):
+        gk = got[k].detach().float().flatten()
+        assert torch.isfinite(gk).all(), k
+        idx = M.sample_index(k, gk.numel()).to(D)
+        s_hip = gk[idx].double().cpu()
+        s_ref = g["samples"][i, : idx.numel()].double()
+        rms_ref = float(g["norms"][i]) / float(g["numels"][i]) ** 0.5
+        e = ((s_hip - s_ref).pow(2).mean().sqrt() / (rms_ref + floor)).item()
+        e_norm = abs(gk.double().norm().item() - float(g["norms"][i])) / (float(g["norms"][i]) + floor * float(g["numels"][i]) ** 0.5)
+        bar = 2e-2 + 1.5 * float(g["rel16"][i])
+        rep[k] = {"sample_rel": e, "norm_rel": e_norm, "bar": bar, "share_of_top": rms_ref / (floor / 2e-3)}
+        if e > bar + 0.03 or e_norm > bar + 0.03:   # (+ 3 %: a 1024-entry sample estimates the tensor's error to a few per cent)
+            bad[k] = rep[k]
+        dot, na, nb = dot + (s_hip @ s_ref).item(), na + (s_hip @ s_hip).item(), nb + (s_ref @ s_ref).item()
+    cos = dot / (na * nb) ** 0.5
+    record("config4_full_depth_gradients", {"out_tokens_rel_vs_fp32": e_out, "out_rel_bf16_oracle": float(g["out_rel16"]),
+                                            "cosine_hip_vs_fp32_on_samples": cos, "cosine_bf16_oracle_vs_fp32": float(g["cos16"]),
+                                            "parameters": len(names), "outside_bar": bad,
+                                            "worst": dict(sorted(rep.items(), key=lambda kv: kv[1]["sample_rel"] - kv[1]["bar"])[-8:])})
+    assert e_out <= 1.5 * float(g["out_rel16"]) + 1e-3, (e_out, float(g["out_rel16"]))
+    assert not bad, dict(list(bad.items())[:8])
+    assert cos >= float(g["cos16"]) - 0.02, (cos, float(g["cos16"]))

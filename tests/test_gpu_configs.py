@@ -3,7 +3,7 @@ host (same name-seeded "lively" parameters, same inputs), stage by stage.
 
 For every stage the three distances SURVEY.md section 8(d) asks for are computed -- |hip - oracle_fp32|,
 |hip - oracle_bf16|, |oracle_bf16 - oracle_fp32| -- gated with the bar of tests/test_gpu_path.py (the HIP path may be no
-further from the fp32 reference than 1.5x the bf16 reference run is) and written to gpurun_out/r02_parity.json, from
+further from the fp32 reference than 1.5x the bf16 reference run is) and written to gpurun_out/r03_parity.json, from
 where the round's copy under profiles/ is taken.
 """
 import json
@@ -35,11 +35,11 @@ def _gpu():
 
 
 def record(key, value):
-    """Merge {key: value} into gpurun_out/r02_parity.json (best effort: the numbers are also asserted)."""
+    """Merge {key: value} into gpurun_out/r03_parity.json (best effort: the numbers are also asserted)."""
     out = ROOT / "gpurun_out"
     try:
         out.mkdir(exist_ok=True)
-        p = out / "r02_parity.json"
+        p = out / "r03_parity.json"
         data = json.loads(p.read_text()) if p.exists() else {}
         data[key] = value
         p.write_text(json.dumps(data, indent=1, sort_keys=True))
@@ -292,6 +292,81 @@ def test_tokenizer_one_layer_full_width(E):
     assert d["diversity_o32"] > 0.3, d["diversity_o32"]
     assert d["o16_vs_o32"]["rel_rms"] < 0.6, "chaotic regime: the comparison would be vacuous"
     assert d["hip_vs_o32"]["rel_rms"] < 0.5 * d["permuted_rows_vs_o32"]["rel_rms"], d
+
+
+@pytest.mark.parametrize("E", [4096])
+def test_tokenizer_layers_teacher_forced_full_width(E):
+    """Every layer of the 4-layer tokenizer at full width on NON-collapsed inputs, in ONE forward of the product path.
+
+    The chained configuration tests cannot see layers 1-3: the SVR stack has no residuals or norms (svr.py:29,35), so its
+    fp32 chain is either contracted onto the token mean by the second layer (token diversity 7e-3 / 2e-4 / 1e-5 after
+    layers 1 / 2 / 3 at E = 4096, query / key gain 1) or chaotic (gain 3: the reference's own bf16 run is 40 % off after two
+    layers).  Here each SVR layer, the visual tokens of the aggregation stage and each TTA layer get an independent lively
+    input through the parity taps of u2tok_tokenizer_forward_taps (teacher forcing), the same tensors the oracle layer is
+    run on in fp32 and in bf16 -- so the weight-table offsets, scratch reuse and side-stream ordering of layers 1-3 are
+    exercised with token-dependent data.  Per layer: the usual three-distance gate AND the HIP output must be at least
+    twice as close to the fp32 reference as that reference with its rows rotated by one is."""
+    from helpers import module_sd
+    from u2tokenizer_amd.tokenizer import u2Tokenizer
+    seed, L, B, T, N, Q, Lt, k = 78, 4, 1, 8, 256, 256, 1024, 1024
+    args = (E, 8, L, k, True, Q, E, "rma", True, True)
+    sd32 = module_sd(u2Tokenizer(*args), "u2tokenizer.", seed)
+    for name, t in sd32.items():
+        synth.lively_(name, t, qk_gain=3.0)
+    sd16 = {kk: v.to(bf) for kk, v in sd32.items()}
+    with torch.device("meta"):
+        tok = u2Tokenizer(*args)
+    tok = tok.to(bf).to_empty(device=D)
+    tok.load_state_dict({kk[len("u2tokenizer."):]: v for kk, v in sd16.items()})
+    oc = O.PathConfig(hidden_size=E, u2t_num_layers=L)
+    Lv = k + k // 2 + k // 4
+    # teacher-forced inputs (bf16-representable, so fp32 oracle, bf16 oracle and the HIP path read identical values)
+    v = synth.synth_tensor("v_token", (B, T, N, E), seed).to(bf)
+    t = (0.25 * synth.synth_tensor("t_token", (B, Lt, E), seed)).to(bf)
+    svr_in = [v] + [(0.5 * synth.synth_tensor(f"svr_in_{l}", (B, T, N, E), seed)).to(bf) for l in range(1, L)]
+    visual_in = (0.3 * synth.synth_tensor("visual_in", (B, Lv, E), seed)).to(bf)
+    tta_in = [None] + [synth.synth_tensor(f"tta_in_{l}", (B, Q, E), seed).to(bf) for l in range(1, L)]
+    out, taps = tok.forward_with_taps(v.to(D), t.to(D), svr_in=[None] + [x.to(D) for x in svr_in[1:]],
+                                      visual_in=visual_in.to(D), tta_in=[None] + [x.to(D) for x in tta_in[1:]])
+    rep, p = {}, "u2tokenizer"
+
+    def check(name, hip, o32, o16, discriminate=True):
+        d = three_way(hip, o32, o16)
+        d["permuted_rows_vs_o32"] = err_stats(o32.roll(1, dims=-2), o32)
+        rep[name] = d
+        assert torch.isfinite(hip.float()).all(), name
+        gate(d, name)
+        if discriminate:  # (the attention layers; selection / aggregation outputs discriminate when they are diverse)
+            assert d["diversity_o32"] > 0.2, (name, d["diversity_o32"])
+        if d["diversity_o32"] > 0.2:
+            assert d["hip_vs_o32"]["rel_rms"] < 0.5 * d["permuted_rows_vs_o32"]["rel_rms"], (name, d)
+
+    last = {}
+    for l in range(L):
+        lp = f"{p}.svt_module.attention_network.layers.{l}"
+        o32 = O.st_attention_layer(sd32, lp, svr_in[l].float(), oc)
+        o16 = O.st_attention_layer(sd16, lp, svr_in[l], oc)
+        check(f"svr_layer_{l}", taps["svr_out"][l], o32, o16)
+        last = {"o32": o32, "o16": o16}
+    # selection + pooling on the last SVR layer's (teacher-forced) output
+    vis = {}
+    for key, sd_, dt in (("o32", sd32, torch.float32), ("o16", sd16, bf)):
+        x = O.diff_token_selection(sd_, f"{p}.svt_module.token_selection", last[key])
+        vis[key] = O.multi_scale_pool(sd_, f"{p}.svt_module.dynamic_pool", x)
+    check("selection_pooling", taps["visual_out"], vis["o32"], vis["o16"], discriminate=False)
+    q32, q16 = sd32[f"{p}.query_tokens"].expand(B, -1, -1), sd16[f"{p}.query_tokens"].expand(B, -1, -1)
+    for l in range(L):
+        lp = f"{p}.tta_module.layers_vt.{l}"
+        i32 = q32 if l == 0 else tta_in[l].float()
+        i16 = q16 if l == 0 else tta_in[l]
+        o32 = O.tta_layer(sd32, lp, i32, visual_in.float(), t.float(), oc)
+        o16 = O.tta_layer(sd16, lp, i16, visual_in, t, oc)
+        check(f"tta_layer_{l}", taps["tta_out"][l], o32, o16)
+        last = {"o32": o32, "o16": o16}
+    lin = f"{p}.tta_module.layer_linagg.linear_aggregator"
+    check("linear_aggregation", out, O.cross_attention(sd32, lin, last["o32"], visual_in.float(), 8, is_compress=True),
+          O.cross_attention(sd16, lin, last["o16"], visual_in, 8, is_compress=True), discriminate=False)
+    record(f"tokenizer_layers_teacher_forced_E{E}", rep)
 
 
 def test_cls_patch_feature_selection():

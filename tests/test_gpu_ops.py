@@ -267,6 +267,73 @@ def test_flash_attention_forced_rescale(ops):
     close_bf16(got, (p @ x[2]).permute(0, 2, 1, 3).reshape(nb, S, 64))
 
 
+def _tok_attn_ref(q, k, v, H, scale, tbl=None, L=512):
+    nb, Sq, E = q.shape
+    Skv, d = k.shape[1], E // H
+    qh, kh, vh = (t.float().view(nb, -1, H, d).permute(0, 2, 1, 3) for t in (q, k, v))
+    s = qh @ kh.transpose(-1, -2) * scale
+    if tbl is not None:
+        s = s + tbl.float()[torch.arange(Skv)[None, :] - torch.arange(Sq)[:, None] + L - 1].permute(2, 0, 1)[None]
+    return (F.softmax(s, dim=-1) @ vh).permute(0, 2, 1, 3).reshape(nb, Sq, E)
+
+
+@pytest.mark.parametrize("nb,Sq,Skv,H,d,bias,splits", [
+    (8, 256, 256, 8, 512, True, 0),     # SVR spatial attention of a 256^3 volume at E = 4096 (rma.py:60-75)
+    (1, 256, 256, 8, 512, True, 0),     # TTA self attention (key splits by heuristic)
+    (1, 256, 1792, 8, 512, False, 0),   # TTA visual cross attention / linear aggregation (tta.py:55-61)
+    (1, 256, 1792, 8, 512, False, 1),   # ... unsplit
+    (1, 256, 1792, 8, 512, False, 5),   # ... an uneven split (56 tiles over 5 -> 12, 12, 12, 12, 8)
+    (1, 256, 1024, 8, 256, False, 0),   # text cross attention at E = 2048
+    (4, 64, 64, 8, 256, True, 0),       # configuration-2 sized spatial attention
+    (2, 37, 53, 4, 64, True, 0),        # tails everywhere: partial query block, partial key tile, 128-byte tile rows
+    (2, 37, 53, 4, 64, True, 2),
+    (3, 100, 70, 2, 128, False, 3),
+    (1, 1, 1, 1, 64, True, 0), (1, 16, 33, 1, 128, False, 0), (1, 512, 512, 2, 64, True, 4)])
+def test_tok_attention(ops, nb, Sq, Skv, H, d, bias, splits):
+    """The fused attention core of the tokenizer (u2tok_tok_attention) against an fp32 softmax(q k^T scale + bias) v of the
+    same bf16 inputs; q / k / v are column slices of packed buffers, as the pipeline passes them; three launches must
+    agree bit for bit (the key-split merge has a fixed order)."""
+    E = H * d
+    qkv = rnd(nb, Sq, 3 * E, seed=Sq + d) if Sq == Skv else None
+    if qkv is not None:
+        q, k, v = qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:]
+        dq = qkv.to(D)
+        dq, dk, dv = dq[..., :E], dq[..., E:2 * E], dq[..., 2 * E:]
+    else:
+        q, kv = rnd(nb, Sq, E, seed=Sq), rnd(nb, Skv, 2 * E, seed=Skv)
+        k, v = kv[..., :E], kv[..., E:]
+        dq, dkv = q.to(D), kv.to(D)
+        dk, dv = dkv[..., :E], dkv[..., E:]
+    tbl = rnd(1023, H, scale=0.5, seed=3) if bias else None
+    scale = 2.0 / math.sqrt(d)  # a little spikier than 1 / sqrt(d): the softmax is not flat
+    got = [ops.tok_attention(dq, dk, dv, H, scale, None if tbl is None else tbl.to(D), 512, splits) for _ in range(3)]
+    assert torch.equal(got[0], got[1]) and torch.equal(got[0], got[2])
+    close_bf16(got[0], _tok_attn_ref(q, k, v, H, scale, tbl))
+
+
+def test_tok_attention_forced_rescale_and_split_merge(ops):
+    """One key row aligned with every query at a late tile (the running max jumps there: CDNA guide rule 26), and in the
+    split form that key sits in the last split, so the merge weights of all other splits are ~2^-100."""
+    nb, Sq, Skv, H, d = 1, 128, 480, 2, 256
+    q, kv = rnd(nb, Sq, H * d, seed=5), rnd(nb, Skv, 2 * H * d, seed=6)
+    for h in range(H):
+        kv[0, 433, h * d:(h + 1) * d] = (q[0, :, h * d:(h + 1) * d].float().mean(0) * 40 + 3 * q[0, 7, h * d:(h + 1) * d].float()).to(bf)
+    k, v = kv[..., :H * d], kv[..., H * d:]
+    ref = _tok_attn_ref(q, k, v, H, 1 / math.sqrt(d))
+    dkv = kv.to(D)
+    for splits in (1, 3, 5):
+        close_bf16(ops.tok_attention(q.to(D), dkv[..., :H * d], dkv[..., H * d:], H, 1 / math.sqrt(d), None, 512, splits), ref)
+
+
+def test_tok_attention_rejects_what_it_does_not_take(ops):
+    q = rnd(1, 8, 96, seed=1).to(D)  # head dim 48
+    with pytest.raises(RuntimeError):
+        ops.tok_attention(q, q, q, 2, 1.0)
+    big = rnd(1, 600, 64, seed=2).to(D)  # relative bias beyond the table
+    with pytest.raises(RuntimeError):
+        ops.tok_attention(big, big, big, 1, 1.0, rnd(1023, 1, seed=3).to(D), 512)
+
+
 @pytest.mark.parametrize("split", [0, 2, 3, 8])
 def test_gemm_split_k(ops, split):
     """Skinny products (few output tiles, long K) cut along K into fp32 partial sums + a reduce kernel that applies the

@@ -1,0 +1,78 @@
+#!/usr/bin/env python
+"""Timing of the fused tokenizer attention (u2tok_tok_attention) at the shapes of one 256^3 volume (E = 4096 and 2048), per
+key-split count, next to the GEMM -> softmax -> GEMM chain it replaces (same tensors, through the pipeline's building blocks)."""
+import math
+import sys
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+from u2tokenizer_amd import ops  # noqa: E402
+
+D = "cuda"
+bf = torch.bfloat16
+
+
+def timeit(fn, n=30):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+
+def chain(q, k, v, H, scale, tbl):
+    nb, Sq, E = q.shape
+    d = E // H
+    Skv = k.shape[1]
+    s = torch.empty((nb * H, Sq, Skv), dtype=torch.float32, device=D)
+    ops.gemm_strided(q, k, s, M=Sq, N=Skv, K=d, lda=q.stride(1), ldb=k.stride(1), ldc=Skv, nz=nb * H, nbh=H, sAb=q.stride(0),
+                     sAh=d, sBb=k.stride(0), sBh=d, sCb=H * Sq * Skv, sCh=Sq * Skv, out_f32=True,
+                     a_off=q.storage_offset(), b_off=k.storage_offset())
+    p = ops.softmax_rows(s, scale, tbl, H, 512)
+    o = torch.empty((nb, Sq, E), dtype=bf, device=D)
+    ops.gemm_strided(p, v, o, M=Sq, N=d, K=Skv, lda=Skv, ldb=v.stride(1), ldc=E, nz=nb * H, nbh=H, sAb=H * Sq * Skv, sAh=Sq * Skv,
+                     sBb=v.stride(0), sBh=d, sCb=Sq * E, sCh=d, b_kmajor=True, b_off=v.storage_offset())
+    return o
+
+
+def main():
+    ops.device_check()
+    torch.set_grad_enabled(False)
+    g = torch.Generator(device=D).manual_seed(0)
+    for E in (4096, 2048):
+        H, d = 8, E // 8
+        cases = [("svr spatial", 8, 256, 256, True), ("tta self", 1, 256, 256, True), ("tta visual", 1, 256, 1792, False),
+                 ("tta text", 1, 256, 1024, False)]
+        for name, nb, Sq, Skv, bias in cases:
+            if Sq == Skv:
+                qkv = torch.randn((nb, Sq, 3 * E), device=D, generator=g).to(bf)
+                q, k, v = qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:]
+            else:
+                q = torch.randn((nb, Sq, E), device=D, generator=g).to(bf)
+                kv = torch.randn((nb, Skv, 2 * E), device=D, generator=g).to(bf)
+                k, v = kv[..., :E], kv[..., E:]
+            tbl = (0.2 * torch.randn((1023, H), device=D, generator=g)).to(bf) if bias else None
+            scale = 1 / math.sqrt(d)
+            flops = 4.0 * nb * H * Sq * Skv * d
+            t_chain = timeit(lambda: chain(q, k, v, H, scale, tbl))
+            ref = chain(q, k, v, H, scale, tbl).float()
+            row = [f"E={E} {name:12s} chain {t_chain:7.1f} us"]
+            for ns in (0, 1, 2, 4, 8, 14):
+                if ns > (Skv + 31) // 32:
+                    continue
+                t = timeit(lambda: ops.tok_attention(q, k, v, H, scale, tbl, 512, ns))
+                err = (ops.tok_attention(q, k, v, H, scale, tbl, 512, ns).float() - ref).abs().max().item()
+                row.append(f"ns={ns}: {t:6.1f} us ({flops / t / 1e6:5.0f} TF/s, |d| {err:.1e})")
+            print("  ".join(row), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -52,6 +52,11 @@ class TokConfig(C.Structure):
                 ("ln_eps", C.c_float)]
 
 
+class TokTaps(C.Structure):
+    _fields_ = [("svr_in", C.POINTER(C.c_void_p)), ("svr_out", C.POINTER(C.c_void_p)), ("visual_in", C.c_void_p),
+                ("visual_out", C.c_void_p), ("tta_in", C.POINTER(C.c_void_p)), ("tta_out", C.POINTER(C.c_void_p))]
+
+
 class Augment(C.Structure):
     _fields_ = [("rot90_k", C.c_int32), ("flip", C.c_int32 * 3), ("scale_factor", C.c_float), ("shift_offset", C.c_float)]
 
@@ -78,6 +83,11 @@ SIGNATURES = {
     "u2tok_spp_forward": (_i32, [C.POINTER(SppConfig), C.POINTER(_vp), _vp, _vp, _vp, _sz, _vp]),
     "u2tok_tokenizer_workspace_bytes": (_sz, [C.POINTER(TokConfig)]),
     "u2tok_tokenizer_forward": (_i32, [C.POINTER(TokConfig), C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "u2tok_tokenizer_forward_taps": (_i32, [C.POINTER(TokConfig), C.POINTER(_vp), _vp, _vp, _vp, _vp, C.POINTER(TokTaps),
+                                            _vp, _sz, _vp]),
+    "u2tok_tok_attention_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    "u2tok_tok_attention": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
+                                   _i64, _f32, _vp, _i32, _i32, _vp, _sz, _vp]),
     "u2tok_preprocess_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "u2tok_preprocess_volume": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp, _sz, _vp]),
     "u2tok_preprocess_volume_aug": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32,
@@ -110,6 +120,8 @@ SIGNATURES = {
     "u2tok_softmax_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _vp]),
     "u2tok_relbias_grad": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp]),
     "u2tok_rowdot_bf16": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _vp]),
+    "u2tok_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(_f32), C.POINTER(_f32), _i32, _f32, _f32, _f32,
+                                _i32, _f32, _vp, _vp]),
     "u2tok_flash_attention_d64_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "u2tok_flash_attention_d64_bwd": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64,
                                              _i32, _i32, _i32, _f32, _vp, _i64, _vp, _sz, _vp]),

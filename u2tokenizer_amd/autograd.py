@@ -50,7 +50,31 @@ def ensure_gemm_scratch(device: torch.device) -> None:
         _scratch[key] = buf
 
 
+def _bind_context(cls):
+    """Class decorator: remember the execution context the forward ran on (ops.active_context: the innermost
+    `with ops.Context()` of the calling thread, else the device's default) and re-enter it in backward.  Function.backward
+    runs on the autograd engine's device thread, whose thread-local context stack is empty: without this the backward
+    kernels of a model used inside `with ops.Context():` would take the default context's options, miss the split-K scratch
+    registered on the private context and land their profiling records elsewhere."""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *args, **kwargs):
+        t = next((a for a in args if torch.is_tensor(a) and a.is_cuda), None)
+        ctx.u2ctx = ops.active_context(t.device) if t is not None else None
+        return fwd(ctx, *args, **kwargs)
+
+    def backward(ctx, *grads):
+        if ctx.u2ctx is None:
+            return bwd(ctx, *grads)
+        with ctx.u2ctx:
+            return bwd(ctx, *grads)
+
+    cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+    return cls
+
+
 # ------------------------------------------------------------------------------------------------ Linear (+GELU, +residual)
+@_bind_context
 class LinearFn(Function):
     """y = x W^T (+ b) (-> GELU) (+ residual), bias / residual fused in the GEMM epilogue as in the inference path."""
 
@@ -101,6 +125,7 @@ def linear(x, w, b=None, res=None, gelu=False):
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm (+residual)
+@_bind_context
 class LayerNormFn(Function):
     """y = LayerNorm(x (+ res)) * w + b  (tta.py:96,100,103; MONAI TransformerBlock norm1 / norm2; ViT.norm)."""
 
@@ -215,6 +240,7 @@ def _attn_backward(q, k, v, P, dO, H, scale, dq, dk, dv, dtable, max_len):
                              sAh=Skv * Sqp, sBb=E * Sqp, sBh=d * Sqp, sCb=b_, sCh=d, alpha=scale)
 
 
+@_bind_context
 class SelfAttnFn(Function):
     """Self-attention core on a packed q | k | v buffer (nb, S, 3E) -> (nb, S, E).  rel_bias: (2 max_len - 1, H) table of
     RelativeMultiheadAttention (rma.py:64-70) or None.  flash (head dim 64, no bias): the forward is the ViT flash
@@ -260,6 +286,7 @@ class SelfAttnFn(Function):
         return dqkv, (None if dtable is None else dtable.to(rel_bias.dtype)), None, None, None, None
 
 
+@_bind_context
 class CrossAttnFn(Function):
     """MultiHeadCrossAttention core (tta.py:55-61): q (nb, Sq, E), packed k | v (nb, Skv, 2E) -> (nb, Sq, E)."""
 
@@ -283,6 +310,7 @@ class CrossAttnFn(Function):
         return dq, dkv, None, None
 
 
+@_bind_context
 class AttnFn(Function):
     """Attention core on separate q, k, v (nb, S, E) -- the un-projected aggregation of LinearAggregation (tta.py:109-116)."""
 
@@ -304,6 +332,7 @@ class AttnFn(Function):
         return dq, dk, dv, None, None
 
 
+@_bind_context
 class RopeFn(Function):
     """rotate-half RoPE on the q and k thirds of a packed (nb, S, 3E) buffer (rope.py:77-80); position = row index."""
 
@@ -329,6 +358,7 @@ class RopeFn(Function):
 
 
 # ------------------------------------------------------------------------------------------------ selection / pooling
+@_bind_context
 class DiffTSFn(Function):
     """DifferentiableTokenSelection (svr.py:101-117): out[r] = sum_tok softmax_tok(score_net(x) / tau)[tok, r] x[tok],
     computed operand-swapped as in the inference path: raw^T = W X^T + b (k x TN), row softmax, P X."""
@@ -380,6 +410,7 @@ class DiffTSFn(Function):
         return dX, dW, db, None
 
 
+@_bind_context
 class MultiScalePoolFn(Function):
     """{1,2,4} average pooling along the token axis (svr.py:176-184), optionally gated by DynamicMultiScalePooling
     (svr.py:126-151).  Forward: the HIP kernel of the inference path; backward: the few thousand-element gate algebra
@@ -416,6 +447,7 @@ class MultiScalePoolFn(Function):
         return dx.to(x.dtype), dgw, dgb
 
 
+@_bind_context
 class HardTopKFn(Function):
     """TokenSelection (svr.py:75-91): indices are not differentiable (score_net receives no gradient, exactly as in the
     reference -- hence its find_unused_parameters=True, train_stage1.py:21-22); the gather scatters its gradient back."""
@@ -439,6 +471,7 @@ class HardTopKFn(Function):
         return dx, None, None, None
 
 
+@_bind_context
 class AvgPool3dFn(Function):
     """SpatialPoolingProjector pooling (spatial_pooling_projector.py:38-41) over the (g1, g2, g3) token grid."""
 

@@ -1,4 +1,5 @@
 // extern "C" surface of libu2tok_hip.so (declared in include/u2tok.h).  Thin: argument marshalling only.
+#include <math.h>
 #include <string.h>
 #include <new>
 #include "pipeline.h"
@@ -55,6 +56,7 @@ int u2tok_set_option(const char* name, int value) {
       {"kmajor_b", &Options::kmajor_b, 0, 1},
       {"flash_mode", &Options::flash_mode, 0, 5},
       {"vit_flash", &Options::vit_flash, 0, 1},         {"tta_overlap", &Options::tta_overlap, 0, 1},
+      {"tok_flash", &Options::tok_flash, 0, 1},
   };
   if (!strcmp(name, "gemm_tile")) {
     if (value != 0 && value != 64 && value != 128) return U2_ERR_ARG;
@@ -115,8 +117,8 @@ int u2tok_spp_forward(const u2tok_spp_config* cfg, const void* const* weights, c
 size_t u2tok_tokenizer_workspace_bytes(const u2tok_tokenizer_config* cfg) {
   if (!cfg) return 0;
   size_t peak = 0;
-  if (tokenizer_forward(*cfg, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, true, &peak, nullptr) !=
-      U2_OK)
+  if (tokenizer_forward(*cfg, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, true, &peak,
+                        nullptr) != U2_OK)
     return 0;
   return peak + 256;
 }
@@ -124,7 +126,14 @@ int u2tok_tokenizer_forward(const u2tok_tokenizer_config* cfg, const void* const
                             const void* t_token, void* out, int64_t* topk_idx_out, void* svr_out, void* workspace,
                             size_t workspace_bytes, u2tok_stream_t stream) {
   if (!cfg || !workspace || ((uintptr_t)workspace & 255)) return U2_ERR_ARG;
-  return tokenizer_forward(*cfg, weights, BF(v_token), BF(t_token), BFW(out), topk_idx_out, BFW(svr_out), workspace,
+  return tokenizer_forward(*cfg, weights, BF(v_token), BF(t_token), BFW(out), topk_idx_out, BFW(svr_out), nullptr, workspace,
+                           workspace_bytes, false, nullptr, ST(stream));
+}
+int u2tok_tokenizer_forward_taps(const u2tok_tokenizer_config* cfg, const void* const* weights, const void* v_token,
+                                 const void* t_token, void* out, int64_t* topk_idx_out, const u2tok_tokenizer_taps* taps,
+                                 void* workspace, size_t workspace_bytes, u2tok_stream_t stream) {
+  if (!cfg || !taps || !workspace || ((uintptr_t)workspace & 255)) return U2_ERR_ARG;
+  return tokenizer_forward(*cfg, weights, BF(v_token), BF(t_token), BFW(out), topk_idx_out, nullptr, taps, workspace,
                            workspace_bytes, false, nullptr, ST(stream));
 }
 
@@ -240,6 +249,17 @@ int u2tok_flash_attention_d64_lse(const void* q, const void* k, const void* vt, 
                              BF(qx), BF(kx), BF(vx), BFW(outx), x_bs, ox_bs, n_extra, lse, lse_ld, ST(stream));
 }
 
+size_t u2tok_tok_attention_workspace_bytes(int32_t nb, int32_t H, int32_t Sq, int32_t Skv, int32_t d) {
+  return tok_attention_workspace_bytes(nb, H, Sq, Skv, d);
+}
+int u2tok_tok_attention(const void* q, const void* k, const void* v, void* out, int32_t nb, int32_t Sq, int32_t Skv, int32_t H,
+                        int32_t d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs,
+                        int64_t o_bs, float scale, const void* rel_bias, int32_t max_len, int32_t splits, void* workspace,
+                        size_t workspace_bytes, u2tok_stream_t stream) {
+  return tok_attention(BF(q), BF(k), BF(v), BFW(out), nb, Sq, Skv, H, d, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, scale,
+                       BF(rel_bias), max_len, splits, workspace, workspace_bytes, ST(stream));
+}
+
 int u2tok_rope_apply(void* x, int64_t n_outer, int32_t S, int32_t n_inner, int32_t H, int32_t d, int64_t ld,
                      int32_t max_len, int32_t inverse, u2tok_stream_t stream) {
   return rope_apply(BFW(x), n_outer, S, n_inner, H, d, ld, max_len, inverse, ST(stream));
@@ -273,6 +293,18 @@ int u2tok_relbias_grad(const void* dS, float* dtable, int32_t nz, int32_t S, int
 int u2tok_rowdot_bf16(const void* a, const void* b, float* out, int64_t rows, int32_t C, int64_t lda, int64_t ldb,
                       u2tok_stream_t stream) {
   return rowdot_bf16(BF(a), BF(b), out, rows, C, lda, ldb, ST(stream));
+}
+int u2tok_adamw_step(float* master, float* exp_avg, float* exp_avg_sq, const void* grad, const uint8_t* group, void* out_bf16,
+                     int64_t n, const float* lr, const float* weight_decay, int32_t ngroups, float beta1, float beta2, float eps,
+                     int32_t step, float grad_scale, const float* grad_coef, u2tok_stream_t stream) {
+  if (!lr || !weight_decay || ngroups <= 0 || ngroups > 8 || step <= 0 || (ngroups > 1 && !group)) return U2_ERR_ARG;
+  AdamWArgs a;
+  for (int i = 0; i < 8; ++i) { a.lr[i] = lr[i < ngroups ? i : 0]; a.wd[i] = weight_decay[i < ngroups ? i : 0]; }
+  a.b1 = beta1; a.b2 = beta2; a.eps = eps;
+  a.inv_c1 = (float)(1.0 / (1.0 - pow((double)beta1, step)));
+  a.inv_sqrt_c2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, step)));
+  a.gscale = grad_scale; a.gcoef = grad_coef;
+  return adamw_step(master, exp_avg, exp_avg_sq, BF(grad), group, BFW(out_bf16), n, a, ST(stream));
 }
 size_t u2tok_flash_attention_d64_bwd_workspace_bytes(int32_t nb, int32_t S, int32_t H) {
   return flash_attention_d64_bwd_workspace_bytes(nb, S, H);

@@ -22,6 +22,7 @@ struct Options {
   int kmajor_b = 1;         // 1: P V / DiffTS aggregation read V / X in place as K-major B operands; 0: transposed copies
   int flash_mode = 0;       // 0 pick, 1 plain 128-row units, 5 double pipeline (asm KV loop)
   int vit_flash = 1;        // 0: unfused ViT attention (debug)
+  int tok_flash = 1;        // 1: fused attention kernel for the tokenizer's attention cores (tokattn.hip); 0: GEMM chain
   int tta_overlap = 1;      // k | v projections of the TTA cross attentions on a side stream
   int profile = 0;          // bracket every launch with hipEvents (u2tok_profile_collect)
 };

@@ -8,7 +8,7 @@
 namespace u2 {
 
 // ------------------------------------------------------------------ profiling (ctx.hip)
-enum : int { PROF_GEMM = 0, PROF_FLASH = 1, PROF_TEMPORAL = 2, PROF_ROWOP = 3, PROF_MOVE = 4, PROF_NCAT = 5 };
+enum : int { PROF_GEMM = 0, PROF_FLASH = 1, PROF_TEMPORAL = 2, PROF_ROWOP = 3, PROF_MOVE = 4, PROF_TOKATTN = 5, PROF_NCAT = 6 };
 void prof_enable(bool on);
 bool prof_enabled();
 int prof_collect(double* ms, double* flops, double* bytes, int64_t* count, int ncat);  // bytes may be null
@@ -148,6 +148,14 @@ int softmax_bwd(const bf16_t* P, const float* dP, bf16_t* dS, int64_t nrows, int
 int relbias_grad(const bf16_t* dS, float* dtable, int nz, int S, int H, int64_t ldp, int max_len, hipStream_t stream);
 int rowdot_bf16(const bf16_t* a, const bf16_t* b, float* out, int64_t rows, int C, int64_t lda, int64_t ldb,
                 hipStream_t stream);
+// sharded AdamW step (dp.py): see backward.hip
+struct AdamWArgs {
+  float lr[8], wd[8];  // per parameter group
+  float b1, b2, eps, inv_c1, inv_sqrt_c2, gscale;
+  const float* gcoef;  // optional device scalar multiplied into the gradient (clipping coefficient)
+};
+int adamw_step(float* master, float* m, float* v, const bf16_t* grad, const uint8_t* group, bf16_t* out, int64_t n,
+               const AdamWArgs& a, hipStream_t stream);
 
 // ------------------------------------------------------------------ attention (attn.hip)
 // Temporal attention of SpatioTemporalAttentionLayer: sequences of length T <= 16 that run ACROSS
@@ -172,6 +180,19 @@ int flash_attention_d64_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, i
                             const bf16_t* dout, int64_t ld_o, int64_t bs_o, bf16_t* dq, bf16_t* dk, bf16_t* dv, int64_t ld_d,
                             int64_t bs_d, int nb, int S, int H, float scale, const float* lse, int64_t lse_ld,
                             void* workspace, size_t workspace_bytes, hipStream_t stream);
+// Fused attention core of the tokenizer's attention modules (tokattn.hip; rma.py:60-75, tta.py:55-61, rope.py:82-86):
+// out = softmax(q k^T scale + rel_bias[j - i + max_len - 1][h]) v per (batch, head); row r of batch b at + b*?_bs + r*ld?, head
+// h at column h*d; d in {64, 128, 256, 512}.  Few (batch, head, 64-query) units -> the key range is cut into splits whose
+// fp32 partial results go through `ws` (tok_attention_workspace_bytes; may be null: unsplit).  force_splits > 0 overrides
+// the heuristic (tests).  tok_attention_supported: shapes / strides the kernel takes (callers fall back to the GEMM chain).
+size_t tok_attention_workspace_bytes(int nb, int H, int Sq, int Skv, int d);
+bool tok_attention_supported(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* out, int Sq, int Skv, int d,
+                             int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs,
+                             int64_t o_bs, const bf16_t* rel_bias, int max_len);
+int tok_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int nb, int Sq, int Skv, int H, int d,
+                  int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
+                  float scale, const bf16_t* rel_bias, int max_len, int force_splits, void* ws, size_t ws_bytes,
+                  hipStream_t stream);
 // Diagnostics only (process-wide, not for concurrent use): s_memtime phase sums per (workgroup, wave) of the double
 // pipeline kernel; while a buffer is attached the kernel runs its instrumented build.  See attn.hip.
 int flash_set_debug_buffer(void* p);

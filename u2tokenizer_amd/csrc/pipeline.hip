@@ -77,11 +77,29 @@ struct AttnCore {
   float scale;
   const bf16_t* rel_bias;
   int max_len;
+  bool unfused = false;  // force the GEMM chain (the ViT's debug path)
 };
 
-// softmax(Q K^T * scale + bias) V via two batched MFMA GEMMs, fp32 scores, bf16 probabilities.
-// Reference: rma.py:60-75 / tta.py:55-61 / rope.py:82-86 (which also materialise the probabilities).
+// softmax(Q K^T * scale + bias) V.  Reference: rma.py:60-75 / tta.py:55-61 / rope.py:82-86 (which also materialise the
+// probabilities).  Default: the fused kernel of tokattn.hip (scores and probabilities never leave the registers; few
+// (batch, head, 64-query) units -> key splits whose fp32 partial sums live in the arena).  Option "tok_flash" = 0, or a shape
+// that kernel does not take: two batched MFMA GEMMs around fp32 scores and bf16 probabilities in HBM.
 int attention_core(Arena& ar, const AttnCore& a, bool dry, hipStream_t st) {
+  if (!a.unfused && (dry || opts().tok_flash)) {
+    const size_t mark = ar.off;
+    const size_t wsb = tok_attention_workspace_bytes(a.nb, a.H, a.Sq, a.Skv, a.d);
+    char* tws = wsb ? ar.get<char>(wsb) : nullptr;
+    U2_CHECK_WS(ar);
+    // (a dry run sizes the arena for BOTH forms: which one a real call takes depends on pointers it does not have)
+    if (!dry && tok_attention_supported(a.q, a.k, a.v, a.out, a.Sq, a.Skv, a.d, a.ldq, a.ldk, a.ldv, a.ldo, a.q_bs, a.k_bs,
+                                        a.v_bs, a.o_bs, a.rel_bias, a.max_len)) {
+      const int e = tok_attention(a.q, a.k, a.v, a.out, a.nb, a.Sq, a.Skv, a.H, a.d, a.ldq, a.ldk, a.ldv, a.ldo, a.q_bs,
+                                  a.k_bs, a.v_bs, a.o_bs, a.scale, a.rel_bias, a.max_len, 0, tws, wsb, st);
+      ar.off = mark;
+      return e;
+    }
+    ar.off = mark;
+  }
   const size_t mark = ar.off;
   const int64_t ldS = round_up(a.Skv, 8), ldp = ldS;
   const int64_t nz = (int64_t)a.nb * a.H;
@@ -226,7 +244,7 @@ int vit_forward(const VitConfig& c, const void* const* W, const void* volume, bf
       }
       {
         AttnCore a{qc, qc + Hd, qc + 2 * Hd, 3 * Hd, 3 * Hd, 3 * Hd, (int64_t)S * 3 * Hd, (int64_t)S * 3 * Hd,
-                   (int64_t)S * 3 * Hd, ac, Hd, (int64_t)S * Hd, nc, S, S, c.heads, 64, scale, nullptr, 0};
+                   (int64_t)S * 3 * Hd, ac, Hd, (int64_t)S * Hd, nc, S, S, c.heads, 64, scale, nullptr, 0, true};
         const int e = attention_core(ar, a, dry, st);
         if (e != U2_OK) return e;
       }
@@ -322,8 +340,8 @@ int qkv_proj(const bf16_t* x, const Att& a, bf16_t* out, int64_t rows, int E, bo
 }  // namespace
 
 int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_token, const bf16_t* t_token,
-                      bf16_t* out, int64_t* topk_idx_out, bf16_t* svr_out, void* ws, size_t ws_bytes, bool dry,
-                      size_t* peak, hipStream_t st) {
+                      bf16_t* out, int64_t* topk_idx_out, bf16_t* svr_out, const TokTaps* taps, void* ws, size_t ws_bytes,
+                      bool dry, size_t* peak, hipStream_t st) {
   if (c.B <= 0 || c.T <= 0 || c.N <= 0 || c.E <= 0 || c.Lt <= 0 || c.num_heads <= 0 || c.num_layers < 0) return U2_ERR_ARG;
   if (c.E % c.num_heads || (c.E / c.num_heads) % 8 || c.top_k <= 0 || c.num_query <= 0) return U2_ERR_ARG;
   if (c.attn_type < 0 || c.attn_type > 2) return U2_ERR_ARG;
@@ -364,6 +382,7 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
   const bf16_t* x = v_token;
   for (int l = 0; l < L; ++l) {
     const Att sp = att_at(1 + 18 * l), tp = att_at(1 + 18 * l + 9);
+    if (taps && !dry && taps->svr_in && taps->svr_in[l]) x = reinterpret_cast<const bf16_t*>(taps->svr_in[l]);
     bf16_t* y = (x == xa) ? xb : xa;
     // spatial: sequences of N tokens inside each chunk (svr.py:27-30)
     { const int e = qkv_proj(x, sp, qkv, rows, E, dry, st); if (e != U2_OK) return e; }
@@ -421,6 +440,9 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
     }
     U2_RUN(linear(ctx, E, tp.wd, tp.bd, y2, E, rows, E, E, 0, nullptr, 0, st));
     x = y2;
+    if (taps && !dry && taps->svr_out && taps->svr_out[l] &&
+        hipMemcpyAsync(taps->svr_out[l], x, (size_t)rows * E * sizeof(bf16_t), hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return U2_ERR_LAUNCH;
   }
 
   if (svr_out && !dry) {  // optional tap: the refined tokens the selection stage sees (parity tests)
@@ -489,6 +511,12 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
     U2_RUN(multiscale_pool(sel, pooled, B, k, E, c.enable_dmtp ? wp(i_gate) : nullptr,
                            c.enable_dmtp ? wp(i_gate + 1) : nullptr, gws, st));
     V = pooled;
+  }
+  if (taps && !dry) {  // parity taps: the visual tokens the aggregation stage attends to
+    if (taps->visual_out &&
+        hipMemcpyAsync(taps->visual_out, V, (size_t)B * Lv * E * sizeof(bf16_t), hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return U2_ERR_LAUNCH;
+    if (taps->visual_in) V = reinterpret_cast<const bf16_t*>(taps->visual_in);
   }
 
   // ---------------- TTA: TextConditionTokenAggregatorModel (tta.py:126-140)
@@ -565,6 +593,7 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
     va.rb = ta.rb = nullptr;
     const bf16_t *ns_w = wp(base + 27), *ns_b = wp(base + 28), *nv_w = wp(base + 29), *nv_b = wp(base + 30),
                  *nt_w = wp(base + 31), *nt_b = wp(base + 32);
+    if (taps && !dry && taps->tta_in && taps->tta_in[l]) qcur = (bf16_t*)taps->tta_in[l];  // (only ever read)
     bf16_t* s1 = (qcur == qa) ? qb : qa;
     bf16_t* s2 = qc;
     // self attention on the query tokens + post-LN residual (tta.py:94-96)
@@ -597,6 +626,9 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
     { const int e = cross(ta, t_token, c.Lt, s2, qo, overlap ? kv_t[l] : kv_inline, overlap ? 2 * l + 1 : -1); if (e != U2_OK) return e; }
     U2_RUN(layernorm_bf16(s2, qo, nt_w, nt_b, s1, 1, (int)qrows, E, 0, E, 0, E, 0, E, c.ln_eps, st));
     qcur = s1;
+    if (taps && !dry && taps->tta_out && taps->tta_out[l] &&
+        hipMemcpyAsync(taps->tta_out[l], qcur, (size_t)qrows * E * sizeof(bf16_t), hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return U2_ERR_LAUNCH;
   }
   // ---------------- LinearAggregation (tta.py:109-116): is_compress=True -> V un-projected, no out-proj
   {

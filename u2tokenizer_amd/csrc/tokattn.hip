@@ -1,0 +1,368 @@
+// Fused attention core of the tokenizer's own attention modules:
+//   RelativeMultiheadAttention (rma.py:60-75): softmax(Q K^T / sqrt(d) + relative_bias[j - i + L - 1][h]) V
+//   RotaryMultiheadAttention   (rope.py:82-86), MultiHeadCrossAttention / LinearAggregation (tta.py:55-61): no bias
+// with S_q <= 512 query rows, S_kv up to a few thousand keys and a WIDE head (d = E / 8 = 256 or 512; 64 / 128 for the small
+// test configurations).  The reference materialises the (S_q x S_kv) scores and probabilities; the round-1/2 path did the
+// same in three launches (batched GEMM -> fp32 scores in HBM -> softmax_rows -> batched GEMM on 64 x 64 tiles).  Here one
+// flash-style kernel streams K and V tiles through LDS and keeps scores, probabilities and the running softmax state in
+// registers.
+//
+// Work decomposition.  A workgroup = 4 waves = 64 query rows of one (batch, head) x one contiguous range of keys
+// ("split"); a wave owns 16 query rows and the WHOLE head dim:
+//   S^T (16 keys x 16 q) = K Q^T : v_mfma_f32_16x16x32_bf16, A = K fragment (LDS), B = Q fragment (registers, loaded once);
+//                                  a lane (q = lane & 15, g = lane >> 4) then owns keys 4g..4g+3 of each 16-key block.
+//   O^T (16 d x 16 q) += V^T P^T  : A = V^T fragment gathered from the ROW-MAJOR V tile by two ds_read_b64_tr_b16 (4 keys
+//                                  x 1 d each), B = the lane's own exp'd scores of the tile's two key blocks packed to bf16
+//                                  -- the MFMA k-slot -> key map is a free permutation as long as A and B agree, so
+//                                  k-slot (g, j) carries key 16 (j >> 2) + 4 g + (j & 3) and P never leaves its lane.
+//   O^T accumulators: d / 16 blocks x 4 registers = 128 VGPRs at d = 512 (a 32-row MFMA shape would need 256).
+// With only nb * H * ceil(S_q / 64) workgroups for a whole call (32 for the query side of the TTA at batch 1) the key range
+// is cut into `ns` splits that run as separate workgroups (flash-decoding style); each leaves un-normalised fp32 partial
+// outputs + (running max, sum) per row, and tok_attn_combine_kernel merges them in a fixed order (bit-repeatable).
+//
+// LDS: one K tile and one V tile of 32 keys x d (row-major, 32 KB each at d = 512), filled by LDS-DMA
+// (global_load_lds_dwordx4, the swizzle applied on the per-lane SOURCE address because the DMA destination is
+// lane-linear).  The V tile of step t is in flight under Q K^T + softmax of step t, the K tile of step t + 1 under P V of
+// step t; two barriers per step; 64 KB per workgroup, two workgroups per CU cover each other's waits.
+//   K tile (fragment rows are K-contiguous: ds_read_b128 of chunk 4 ks + g of row 16 kb + (lane & 15)):
+//       16-byte chunk index XOR (row & 15)  [(row & 7) for 128-byte rows, as gemm.hip]  -> 16 distinct slots per lane group.
+//   V tile (transpose reads; a 16-lane group reads a [4 keys][16 d] block, lane a supplies row a >> 2 / 8-byte piece a & 3):
+//       chunks rotated inside each 256-byte segment by 2 (key & 3) + 8 ((key >> 2) & 1) so that the 8 rows x 32 bytes a
+//       half wave touches fall into 16 different 16-byte slots (the layout family of gemm.hip's K-major operands).
+#include "kernels.h"
+
+namespace u2 {
+
+struct TokAttnArgs {
+  const bf16_t *q, *k, *v;
+  bf16_t* out;
+  int64_t ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs;
+  int nb, H, Sq, Skv, nqb;
+  int ns, tps;  // key splits, 32-key tiles per split
+  float scale_log2e;
+  const bf16_t* rel_bias;
+  int max_len;
+  float* opart;  // ns > 1: [ns][nb][Sq][H * DH] fp32, un-normalised
+  float* ml;     // ns > 1: [ns][nb * H][Sq][2] = (running max in log2 units, row sum)
+};
+
+constexpr float TOKATTN_RESCALE_THR = 8.0f;
+constexpr int TOKATTN_BIAS_SLOTS = 640;
+
+template <int SEG>
+__device__ __forceinline__ int tv_rot(int k) {
+  if constexpr (SEG == 16) return 2 * (k & 3) + 8 * ((k >> 2) & 1);
+  else return 2 * ((k >> 1) & 1) + 4 * ((k >> 2) & 1);
+}
+
+typedef short ta_v4s_t __attribute__((ext_vector_type(4)));
+
+template <int DH>
+__global__ __launch_bounds__(256, 2) void tok_attn_kernel(const TokAttnArgs a) {
+  constexpr int BK = 32;              // keys per tile
+  constexpr int CPR = DH / 8;         // 16-byte chunks per tile row
+  constexpr int ROWB = DH * 2;        // bytes per tile row
+  constexpr int TILE = BK * ROWB;     // bytes per K (or V) tile
+  constexpr int SEG = CPR >= 16 ? 16 : 8;
+  constexpr int NP = BK * CPR / 256;  // DMA pieces per thread per tile
+  constexpr int KS = DH / 32;         // k steps of Q K^T
+  constexpr int DB = DH / 16;         // 16-wide d blocks of O^T
+  static_assert(NP >= 1 && BK * CPR % 256 == 0, "tile");
+  __shared__ __attribute__((aligned(16))) char lds[2 * TILE];
+  __shared__ float sbias[TOKATTN_BIAS_SLOTS];
+  char* const sK = lds;
+  char* const sV = lds + TILE;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+
+  // ---- unit of this workgroup.  XCD-aware order: workgroup i runs on XCD i % 8 (observed dispatch rule); every XCD gets a
+  // contiguous range of logical ids, and the query blocks of one (batch, head, split) are neighbours -> they stream the same
+  // K / V rows through one L2.
+  int bid;
+  {
+    const int nwg = gridDim.x, qn = nwg >> 3, rn = nwg & 7;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+  }
+  const int qblk = bid % a.nqb;
+  const int sp = (bid / a.nqb) % a.ns;
+  const int bh = bid / (a.nqb * a.ns);
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int q0 = qblk * 64;
+  const int Sq = a.Sq, Skv = a.Skv;
+  const int ntile_all = (Skv + BK - 1) / BK;
+  const int kt0 = sp * a.tps, kt1 = min(ntile_all, kt0 + a.tps);
+  const int kbeg = kt0 * BK;
+
+  const bf16_t* kb_ = a.k + (int64_t)b * a.k_bs + h * DH;
+  const bf16_t* vb_ = a.v + (int64_t)b * a.v_bs + h * DH;
+
+  // ---- Q fragments (B operand): Q[q][32 ks + 8 g .. + 7]
+  const int qrow = q0 + 16 * w + l15;
+  bf16x8 qf[KS];
+  {
+    const bf16_t* qp = a.q + (int64_t)b * a.q_bs + (int64_t)min(qrow, Sq - 1) * a.ldq + h * DH + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 32);
+  }
+  // ---- relative-bias window of this unit, pre-multiplied by log2 e: sbias[(j - kbeg) + (q0 + 63 - i)]
+  const bool has_bias = a.rel_bias != nullptr;
+  if (has_bias) {
+    const int tmin = kbeg - (q0 + 63) + a.max_len - 1;  // table row of slot 0
+    const int nslot = (kt1 - kt0) * BK + 63;
+    for (int t = tid; t < nslot; t += 256) {
+      const int row = tmin + t;
+      float v = 0.f;
+      if (row >= 0 && row < 2 * a.max_len - 1) v = bf16_to_f32(a.rel_bias[(int64_t)row * a.H + h]) * 1.44269504088896340736f;
+      sbias[t] = v;
+    }
+  }
+
+  // ---- LDS-DMA of one tile: piece i of this thread is LDS chunk c = i * 256 + tid = (row c / CPR, position c % CPR)
+  auto dma_k = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      // (a wave instruction covers 64 consecutive chunks: one row when CPR == 64 -- its row index is then scalar)
+      const int c = i * 256 + w * 64 + lane, row = CPR >= 64 ? (i * 256 + w * 64) / CPR : c / CPR, cp = c % CPR;
+      const int src_chunk = cp ^ (row & (SEG - 1));
+      const bf16_t* src = kb_ + (int64_t)min(kt * BK + row, Skv - 1) * a.ldk + src_chunk * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sK + (i * 256 + w * 64) * 16), 16, 0, 0);
+    }
+  };
+  auto dma_v = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int c = i * 256 + w * 64 + lane, row = CPR >= 64 ? (i * 256 + w * 64) / CPR : c / CPR, cp = c % CPR;
+      const int src_chunk = (cp & ~(SEG - 1)) | (((cp & (SEG - 1)) - tv_rot<SEG>(row)) & (SEG - 1));
+      const bf16_t* src = vb_ + (int64_t)min(kt * BK + row, Skv - 1) * a.ldv + src_chunk * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sV + (i * 256 + w * 64) * 16), 16, 0, 0);
+    }
+  };
+
+  // ---- per-lane fragment offsets
+  // K: row 16 kb + l15, chunk (4 ks + g) ^ (row & (SEG - 1)); the XOR value does not depend on kb (16 kb keeps the low bits)
+  const int k_row_off = l15 * ROWB;
+  const int k_swz = l15 & (SEG - 1);
+  // V: rows 4 g + (l15 >> 2) (+ 16 for the second read), chunk 2 db + ((l15 & 3) >> 1) rotated, 8-byte half l15 & 1
+  const int v_row = 4 * g + (l15 >> 2);
+  const int v_rot = tv_rot<SEG>(v_row);
+  const int v_base_off = v_row * ROWB + (l15 & 1) * 8;
+  const int v_cc = (l15 & 3) >> 1;
+
+  f32x4 o[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  const float c_scale = a.scale_log2e;
+  const int bias_q = q0 + 63 - qrow;  // (q0 + 63 - i); rows past Sq compute on a clamped copy and are not stored
+
+  typedef __attribute__((address_space(3))) ta_v4s_t* lds_v4;
+
+  if (kt0 < kt1) dma_k(kt0);
+  for (int kt = kt0; kt < kt1; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // K(kt) has landed for every wave; every wave is done with V(kt - 1)
+    dma_v(kt);
+    // ---- S^T = K Q^T, two 16-key blocks
+    f32x4 sc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      sc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const char* rowp = sK + kb * 16 * ROWB + k_row_off;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(rowp + (((ks * 4 + g) ^ k_swz) << 4));
+        sc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sc[kb], 0, 0, 0);
+        if constexpr (KS > 4) {  // keep hipcc from hoisting all fragment reads of a block in front of its MFMAs (registers)
+          if ((ks & 3) == 3) asm volatile("" ::: "memory");
+        }
+      }
+    }
+    // ---- online softmax: lane owns keys kt * 32 + 16 kb + 4 g + r of query row qrow
+    float x[8];
+    float mt = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = kt * BK + kb * 16 + 4 * g + r;
+        float s = sc[kb][r] * c_scale;
+        if (has_bias) s += sbias[(j - kbeg) + bias_q];
+        if (j >= Skv) s = -INFINITY;
+        x[kb * 4 + r] = s;
+        mt = fmaxf(mt, s);
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    if (__any(mt > m_run + TOKATTN_RESCALE_THR)) {  // wave-uniform; always taken on the first tile
+      const float m_new = fmaxf(m_run, mt);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        o[db][0] *= alpha; o[db][1] *= alpha; o[db][2] *= alpha; o[db][3] *= alpha;
+      }
+    }
+    float ps = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      x[i] = __builtin_amdgcn_exp2f(x[i] - m_run);
+      ps += x[i];
+    }
+    l_run += ps;
+    union { bf16x8 v; uint32_t u[4]; } pf;
+    pf.u[0] = pack2_bf16(x[0], x[1]);
+    pf.u[1] = pack2_bf16(x[2], x[3]);
+    pf.u[2] = pack2_bf16(x[4], x[5]);
+    pf.u[3] = pack2_bf16(x[6], x[7]);
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // V(kt) has landed; every wave is done with K(kt)
+    if (kt + 1 < kt1) dma_k(kt + 1);
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      const int cc = 2 * db + v_cc;
+      const int cp = (cc & ~(SEG - 1)) | (((cc & (SEG - 1)) + v_rot) & (SEG - 1));
+      const char* p = sV + v_base_off + cp * 16;
+      const ta_v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)p);
+      const ta_v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p + 16 * ROWB));
+      const bf16x8 vf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf.v, o[db], 0, 0, 0);
+      if constexpr (DB > 8) {
+        if ((db & 3) == 3) asm volatile("" ::: "memory");
+      }
+    }
+  }
+
+  // ---- epilogue: lane holds O^T[d = 16 db + 4 g + r][q = qrow]
+  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+  l_tot += __shfl_xor(l_tot, 32, 64);
+  if (qrow >= Sq) return;
+  if (a.ns == 1) {
+    const float inv = 1.f / l_tot;
+    bf16_t* op = a.out + (int64_t)b * a.o_bs + (int64_t)qrow * a.ldo + h * DH + 4 * g;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+      *reinterpret_cast<uint2*>(op + db * 16) =
+          uint2{pack2_bf16(o[db][0] * inv, o[db][1] * inv), pack2_bf16(o[db][2] * inv, o[db][3] * inv)};
+  } else {
+    const int E = a.H * DH;
+    float* pp = a.opart + (((int64_t)sp * a.nb + b) * Sq + qrow) * E + h * DH + 4 * g;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) *reinterpret_cast<float4*>(pp + db * 16) = float4{o[db][0], o[db][1], o[db][2], o[db][3]};
+    if (g == 0) {
+      float* mp = a.ml + ((((int64_t)sp * a.nb + b) * a.H + h) * Sq + qrow) * 2;
+      mp[0] = m_run;
+      mp[1] = l_tot;
+    }
+  }
+}
+
+// out[b][q][e] = sum_s 2^(m_s - m) O_s[b][q][e] / sum_s 2^(m_s - m) l_s over the key splits, s in ascending order
+__global__ __launch_bounds__(256) void tok_attn_combine_kernel(const TokAttnArgs a, int DH) {
+  const int E = a.H * DH, e4 = E >> 2;
+  const int64_t total = (int64_t)a.nb * a.Sq * e4;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int e = (int)(idx % e4) * 4;
+  const int64_t bq = idx / e4;
+  const int qrow = (int)(bq % a.Sq), b = (int)(bq / a.Sq);
+  const int h = e / DH;
+  float m = -INFINITY;
+  for (int s = 0; s < a.ns; ++s) m = fmaxf(m, a.ml[((((int64_t)s * a.nb + b) * a.H + h) * a.Sq + qrow) * 2]);
+  float L = 0.f, acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < a.ns; ++s) {
+    const float* mp = a.ml + ((((int64_t)s * a.nb + b) * a.H + h) * a.Sq + qrow) * 2;
+    const float wgt = __builtin_amdgcn_exp2f(mp[0] - m);
+    L += wgt * mp[1];
+    const float4 t = *reinterpret_cast<const float4*>(a.opart + (((int64_t)s * a.nb + b) * a.Sq + qrow) * E + e);
+    acc[0] += wgt * t.x; acc[1] += wgt * t.y; acc[2] += wgt * t.z; acc[3] += wgt * t.w;
+  }
+  const float inv = 1.f / L;
+  *reinterpret_cast<uint2*>(a.out + (int64_t)b * a.o_bs + (int64_t)qrow * a.ldo + e) =
+      uint2{pack2_bf16(acc[0] * inv, acc[1] * inv), pack2_bf16(acc[2] * inv, acc[3] * inv)};
+}
+
+// ns for a call: enough workgroups to cover the 256 CUs, at least two tiles per split, partial sums within the scratch.
+static int tok_attn_pick_splits(int nb, int H, int Sq, int Skv, int d, size_t ws_bytes) {
+  const int64_t base = (int64_t)nb * H * cdiv(Sq, 64);
+  const int ntile = (int)cdiv(Skv, 32);
+  if (base >= 192 || ntile < 4) return 1;
+  int ns = (int)std::min<int64_t>(cdiv(256, base), ntile / 2);
+  const size_t per = (size_t)nb * Sq * ((size_t)H * d * 4 + (size_t)H * 8);
+  if (per == 0 || ws_bytes / per < 2) return 1;
+  ns = (int)std::min<size_t>((size_t)ns, ws_bytes / per);
+  return std::max(ns, 1);
+}
+
+size_t tok_attention_workspace_bytes(int nb, int H, int Sq, int Skv, int d) {
+  const int64_t base = (int64_t)nb * H * cdiv(Sq, 64);
+  const int ntile = (int)cdiv(Skv, 32);
+  if (base >= 192 || ntile < 4) return 0;
+  const int ns = (int)std::min<int64_t>(cdiv(256, base), ntile / 2);
+  return (size_t)ns * nb * Sq * ((size_t)H * d * 4 + (size_t)H * 8);
+}
+
+bool tok_attention_supported(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* out, int Sq, int Skv, int d,
+                             int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs,
+                             int64_t o_bs, const bf16_t* rel_bias, int max_len) {
+  if (d != 64 && d != 128 && d != 256 && d != 512) return false;
+  if ((ldq | ldk | ldv | q_bs | k_bs | v_bs) & 7) return false;
+  if ((ldo | o_bs) & 3) return false;
+  if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) || ((uintptr_t)out & 7)) return false;
+  if (rel_bias && (Sq > max_len || Skv > max_len || (int)cdiv(Skv, 32) * 32 + 63 > TOKATTN_BIAS_SLOTS)) return false;
+  return true;
+}
+
+int tok_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int nb, int Sq, int Skv, int H, int d,
+                  int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
+                  float scale, const bf16_t* rel_bias, int max_len, int force_splits, void* ws, size_t ws_bytes,
+                  hipStream_t stream) {
+  if (!q || !k || !v || !out || nb <= 0 || Sq <= 0 || Skv <= 0 || H <= 0) return U2_ERR_ARG;
+  if (!tok_attention_supported(q, k, v, out, Sq, Skv, d, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, rel_bias, max_len))
+    return U2_ERR_ARG;
+  TokAttnArgs a;
+  a.q = q; a.k = k; a.v = v; a.out = out;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
+  a.nb = nb; a.H = H; a.Sq = Sq; a.Skv = Skv; a.nqb = (int)cdiv(Sq, 64);
+  a.scale_log2e = scale * 1.44269504088896340736f;
+  a.rel_bias = rel_bias; a.max_len = max_len;
+  const int ntile = (int)cdiv(Skv, 32);
+  int ns = force_splits > 0 ? std::min(force_splits, ntile) : tok_attn_pick_splits(nb, H, Sq, Skv, d, ws ? ws_bytes : 0);
+  const size_t per = (size_t)nb * Sq * ((size_t)H * d * 4 + (size_t)H * 8);
+  if (ns > 1 && (!ws || ws_bytes < (size_t)ns * per || ((uintptr_t)ws & 15))) {
+    if (force_splits > 0) return U2_ERR_WORKSPACE;
+    ns = 1;
+  }
+  a.tps = (int)cdiv(ntile, ns);
+  a.ns = (int)cdiv(ntile, a.tps);  // no empty splits
+  a.opart = nullptr; a.ml = nullptr;
+  if (a.ns > 1) {
+    a.opart = reinterpret_cast<float*>(ws);
+    a.ml = a.opart + (size_t)a.ns * nb * Sq * H * d;
+  }
+  const int64_t grid = (int64_t)nb * H * a.nqb * a.ns;
+  if (grid > 0x7fffffff) return U2_ERR_ARG;
+  ProfScope ps(PROF_TOKATTN, 4.0 * nb * H * (double)Sq * Skv * d, stream,
+               2.0 * nb * H * d * (2.0 * Sq + 2.0 * Skv));  // q, k, v read + o written, once
+#define U2_TA(D_) hipLaunchKernelGGL((tok_attn_kernel<D_>), dim3((unsigned)grid), dim3(256), 0, stream, a)
+  if (d == 512) U2_TA(512);
+  else if (d == 256) U2_TA(256);
+  else if (d == 128) U2_TA(128);
+  else U2_TA(64);
+#undef U2_TA
+  if (a.ns > 1) {
+    const int64_t total = (int64_t)nb * Sq * (H * d / 4);
+    hipLaunchKernelGGL(tok_attn_combine_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, a, d);
+  }
+  return launch_status();
+}
+
+}  // namespace u2

@@ -436,6 +436,34 @@ def flash_attention_d64_bwd(qkv: torch.Tensor, out: torch.Tensor, d_out: torch.T
 
 
 @_guarded
+def tok_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float, rel_bias=None, max_len=512,
+                  splits: int = 0) -> torch.Tensor:
+    """Fused attention core of the tokenizer's attention modules (u2tok_tok_attention; rma.py:60-75, tta.py:55-61):
+    q (nb, Sq, E), k / v (nb, Skv, E) bf16 -- any views whose last dim is contiguous (e.g. column slices of a packed q|k|v
+    buffer) -> softmax(q k^T scale + rel_bias[j - i + max_len - 1][h]) v as (nb, Sq, E).  splits: 0 = heuristic key split."""
+    h = _lib.load_library()
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _need(t, torch.bfloat16, n)
+        if t.dim() != 3 or t.stride(2) != 1:
+            raise RuntimeError(f"tok_attention: {n} must be (nb, S, E) with a contiguous last dim")
+    nb, Sq, E = q.shape
+    Skv = k.shape[1]
+    if k.shape != (nb, Skv, E) or v.shape != (nb, Skv, E) or E % heads:
+        raise RuntimeError(f"tok_attention: shapes {tuple(q.shape)}, {tuple(k.shape)}, {tuple(v.shape)}, heads {heads}")
+    d = E // heads
+    out = torch.empty((nb, Sq, E), dtype=torch.bfloat16, device=q.device)
+    nbytes = h.u2tok_tok_attention_workspace_bytes(nb, heads, Sq, Skv, d)
+    if splits > 1:
+        nbytes = max(nbytes, splits * nb * Sq * (E * 4 + heads * 8))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=q.device)
+    _lib.check(h.u2tok_tok_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(out), nb, Sq, Skv, heads, d, q.stride(1), k.stride(1),
+                                     v.stride(1), E, q.stride(0), k.stride(0), v.stride(0), Sq * E, float(scale),
+                                     _ptr(rel_bias), max_len, int(splits), _ptr(ws), ws.numel(), _stream()),
+               "u2tok_tok_attention")
+    return out
+
+
+@_guarded
 def rope_apply(x: torch.Tensor, n_outer, S, n_inner, H, d, max_len=512, inverse=False):
     h = _lib.load_library()
     _lib.check(h.u2tok_rope_apply(_ptr(x), n_outer, S, n_inner, H, d, x.stride(-2), max_len, int(inverse), _stream()),
@@ -549,6 +577,31 @@ def relbias_grad(ds: torch.Tensor, dtable: torch.Tensor, S: int, H: int, max_len
     nz = ds.numel() // (S * ds.shape[-1])
     _lib.check(h.u2tok_relbias_grad(_ptr(ds), _ptr(dtable), nz, S, H, ds.shape[-1], max_len, _stream()),
                "u2tok_relbias_grad")
+
+
+@_guarded
+def adamw_step(master: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, grad: torch.Tensor, out_bf16: torch.Tensor,
+               step: int, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, grad_coef: Optional[torch.Tensor] = None,
+               group: Optional[torch.Tensor] = None) -> None:
+    """One rank's shard of a ZeRO-1 AdamW step in ONE kernel (u2tok_adamw_step): fp32 master / moments in place, bf16 gradient
+    piece in, bf16 parameter piece out.  lr / weight_decay: floats, or per-group sequences with `group` (uint8 per element)."""
+    h = _lib.load_library()
+    n = master.numel()
+    for t, dt, name in ((master, torch.float32, "master"), (exp_avg, torch.float32, "exp_avg"),
+                        (exp_avg_sq, torch.float32, "exp_avg_sq"), (grad, torch.bfloat16, "grad"), (out_bf16, torch.bfloat16, "out")):
+        _need(t, dt, name)
+        if t.numel() != n or not t.is_contiguous():
+            raise RuntimeError(f"adamw_step: {name} must be contiguous with {n} elements")
+    lrs = [float(x) for x in (lr if isinstance(lr, (list, tuple)) else [lr])]
+    wds = [float(x) for x in (weight_decay if isinstance(weight_decay, (list, tuple)) else [weight_decay])]
+    if len(lrs) != len(wds) or len(lrs) > 8:
+        raise RuntimeError("adamw_step: lr / weight_decay must list the same <= 8 parameter groups")
+    if group is not None:
+        _need(group, torch.uint8, "group")
+    _lib.check(h.u2tok_adamw_step(_ptr(master), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(grad), _ptr(group), _ptr(out_bf16), n,
+                                  (C.c_float * len(lrs))(*lrs), (C.c_float * len(wds))(*wds), len(lrs), float(betas[0]),
+                                  float(betas[1]), float(eps), int(step), float(grad_scale), _ptr(grad_coef), _stream()),
+               "u2tok_adamw_step")
 
 
 # ---------------------------------------------------------------------------------- pipelines

@@ -208,7 +208,7 @@ def _unshare_packed(module, state_dict, prefix, local_metadata):
     expects independent tensors see what the reference's checkpoint holds.  Unpacked (CPU) modules are untouched."""
     for k, v in list(state_dict.items()):
         if k.startswith(prefix) and torch.is_tensor(v) and \
-                v.untyped_storage().nbytes() > v.numel() * v.element_size() + v.storage_offset() * v.element_size():
+                v.untyped_storage().nbytes() != v.numel() * v.element_size():  # (also the LAST view of a packed buffer)
             state_dict[k] = v.detach().clone() if not v.requires_grad else v.clone().detach()
     return state_dict
 
@@ -297,6 +297,63 @@ class u2Tokenizer(nn.Module):
             if T * N > 8192:
                 raise RuntimeError(f"hard top-k sorts T*N={T * N} scores in one workgroup's LDS: limit 8192")
 
+    def forward_with_taps(self, v_token, t_token, svr_in=None, visual_in=None, tta_in=None):
+        """Parity instrument (u2tok_tokenizer_forward_taps): the inference forward with any layer's input replaced
+        ("teacher forcing": svr_in / tta_in are lists of num_layers tensors or None entries, visual_in replaces the tokens
+        the aggregation stage attends to) and every layer's output copied out.  Returns (out, taps) with taps =
+        {"svr_out": [...], "visual_out": tensor, "tta_out": [...]}."""
+        h = _lib.load_library()
+        self.pack_weights()
+        v_token = ops._need(v_token, torch.bfloat16, "v_token").contiguous()
+        t_token = ops._need(t_token, torch.bfloat16, "t_token").contiguous()
+        (B, T, N, E) = v_token.size()
+        self._check_envelope(B, T, N, E, t_token.shape[1])
+        L, Q, dev = self.num_layers, self.num_query, v_token.device
+        Lv = self.top_k + (self.top_k // 2 + self.top_k // 4 if self.use_multi_scale else 0)
+        cfg = self._config(B, T, N, E, t_token.shape[1])
+        table = ops.weight_table(self._weights())
+        nbytes = h.u2tok_tokenizer_workspace_bytes(C.byref(cfg))
+        keep = []
+
+        def ptr_array(tensors, shape):
+            arr = (C.c_void_p * L)()
+            for i in range(L):
+                t = tensors[i] if tensors is not None and i < len(tensors) else None
+                if t is not None:
+                    t = ops._need(t, torch.bfloat16, "tap").contiguous()
+                    assert tuple(t.shape) == shape, (tuple(t.shape), shape)
+                    keep.append(t)
+                    arr[i] = t.data_ptr()
+            return arr
+
+        svr_out = [torch.empty((B, T, N, E), dtype=torch.bfloat16, device=dev) for _ in range(L)]
+        tta_out = [torch.empty((B, Q, E), dtype=torch.bfloat16, device=dev) for _ in range(L)]
+        visual_out = torch.empty((B, Lv, E), dtype=torch.bfloat16, device=dev)
+        if visual_in is not None:
+            visual_in = ops._need(visual_in, torch.bfloat16, "visual_in").contiguous()
+            assert tuple(visual_in.shape) == (B, Lv, E)
+        taps = _lib.TokTaps(svr_in=ptr_array(svr_in, (B, T, N, E)), svr_out=ptr_array(svr_out, (B, T, N, E)),
+                            visual_in=None if visual_in is None else visual_in.data_ptr(), visual_out=visual_out.data_ptr(),
+                            tta_in=ptr_array(tta_in, (B, Q, E)), tta_out=ptr_array(tta_out, (B, Q, E)))
+        with ops.on_device(v_token) as (h, stream):
+            ws = self._ws.get(nbytes, dev)
+            out = torch.empty((B, Q, E), dtype=torch.bfloat16, device=dev)
+            idx = None if self.enable_diffts else torch.empty((B, self.top_k), dtype=torch.int64, device=dev)
+            _lib.check(h.u2tok_tokenizer_forward_taps(C.byref(cfg), table, v_token.data_ptr(), t_token.data_ptr(),
+                                                      out.data_ptr(), None if idx is None else idx.data_ptr(),
+                                                      C.byref(taps), ws.data_ptr(), ws.numel(), stream),
+                       "u2tok_tokenizer_forward_taps")
+        self.last_topk_indices = idx
+        return out, {"svr_out": svr_out, "visual_out": visual_out, "tta_out": tta_out}
+
+    def _config(self, B, T, N, E, Lt):
+        return _lib.TokConfig(B=B, T=T, N=N, E=E, Lt=Lt, num_heads=self.num_heads,
+                              num_layers=self.num_layers, top_k=self.top_k, num_query=self.num_query,
+                              use_multi_scale=int(self.use_multi_scale), attn_type=_ATTN_TYPES.get(self.attn_type, 2),
+                              enable_diffts=int(self.enable_diffts), enable_dmtp=int(self.enable_dmtp),
+                              max_seq_len=512, diffts_tau=float(getattr(self.svt_module.token_selection, "tau", 1.0)),
+                              ln_eps=1e-5)
+
     def forward(self, v_token, t_token):
         if torch.is_grad_enabled() and (v_token.requires_grad or t_token.requires_grad
                                         or any(p.requires_grad for p in self.parameters())):
@@ -316,12 +373,7 @@ class u2Tokenizer(nn.Module):
         if E != self.embed_size or t_token.shape[0] != B or t_token.shape[2] != E:
             raise RuntimeError(f"shape mismatch: v_token {tuple(v_token.shape)}, t_token {tuple(t_token.shape)}")
         self._check_envelope(B, T, N, E, t_token.shape[1])
-        cfg = _lib.TokConfig(B=B, T=T, N=N, E=E, Lt=t_token.shape[1], num_heads=self.num_heads,
-                             num_layers=self.num_layers, top_k=self.top_k, num_query=self.num_query,
-                             use_multi_scale=int(self.use_multi_scale), attn_type=_ATTN_TYPES.get(self.attn_type, 2),
-                             enable_diffts=int(self.enable_diffts), enable_dmtp=int(self.enable_dmtp),
-                             max_seq_len=512, diffts_tau=float(getattr(self.svt_module.token_selection, "tau", 1.0)),
-                             ln_eps=1e-5)
+        cfg = self._config(B, T, N, E, t_token.shape[1])
         table = ops.weight_table(self._weights())
         nbytes = h.u2tok_tokenizer_workspace_bytes(C.byref(cfg))
         if nbytes == 0:
