@@ -68,6 +68,9 @@ int u2tok_set_gemm_scratch(void* device_ptr, size_t bytes, void* stream);
  * for the flash attention kernel; while attached the kernel runs its s_memtime-instrumented build and ADDS per-phase
  * cycle sums per (workgroup, wave). */
 int u2tok_flash_debug_buffer(void* device_ptr);
+/* Same for u2tok_tok_attention: >= grid*4*8 uint64; slots = cycles in {DMA wait, barrier, K DMA issue, Q K^T, softmax, V DMA
+ * issue, P V}, [7] = tiles. */
+int u2tok_tok_attention_debug_buffer(void* device_ptr);
 
 /* With option "profile" = 1 every launch is bracketed by hipEvents on its stream.  Collect (HOST arrays of ncat <= 6
  * entries; synchronises on the recorded events, then resets): summed milliseconds, algorithmic FLOPs and launch

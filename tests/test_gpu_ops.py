@@ -450,6 +450,20 @@ def test_gemm_big_tile_variants(ops, variant):
         ops.set_option("gemm_big", 0)
 
 
+@pytest.mark.parametrize("M,N,K", [(8, 2304, 768), (8, 768, 3072), (1, 40, 64), (16, 4096, 4096), (5, 24, 96), (8, 768, 768)])
+def test_gemm_few_rows(ops, M, N, K):
+    """M <= 16 (the ViT's 8 cls rows behind the big-tile launches): gemm_rows16_kernel -- waves split K, partial tiles are
+    added through LDS in a fixed order; every epilogue; three launches agree bit for bit."""
+    a, b, bias, res = rnd(M, K, seed=31), rnd(N, K, seed=32), rnd(N, seed=33), rnd(M, N, seed=34)
+    base = a.float() @ b.float().t()
+    got = [ops.gemm(a.to(D), b.to(D), bias=bias.to(D), residual=res.to(D)) for _ in range(3)]
+    assert torch.equal(got[0], got[1]) and torch.equal(got[0], got[2])
+    close_bf16(got[0], base + bias.float() + res.float())
+    close_bf16(ops.gemm(a.to(D), b.to(D)), base)
+    close_bf16(ops.gemm(a.to(D), b.to(D), bias=bias.to(D), gelu=True), F.gelu(base + bias.float()), rounds=3)
+    close_f32(ops.gemm(a.to(D), b.to(D), bias=bias.to(D), out_f32=True, alpha=0.5), 0.5 * base + bias.float())
+
+
 def test_gemm_heuristic_split_rows(ops):
     """M = 8 * 2049 (the ViT's row count): the launcher sends 16384 rows to the big-tile kernel and the 8 leftover
     rows to the small-tile kernel; the seam must be invisible."""

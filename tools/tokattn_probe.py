@@ -34,18 +34,63 @@ def chain(q, k, v, H, scale, tbl):
     Skv = k.shape[1]
     s = torch.empty((nb * H, Sq, Skv), dtype=torch.float32, device=D)
     ops.gemm_strided(q, k, s, M=Sq, N=Skv, K=d, lda=q.stride(1), ldb=k.stride(1), ldc=Skv, nz=nb * H, nbh=H, sAb=q.stride(0),
-                     sAh=d, sBb=k.stride(0), sBh=d, sCb=H * Sq * Skv, sCh=Sq * Skv, out_f32=True,
-                     a_off=q.storage_offset(), b_off=k.storage_offset())
+                     sAh=d, sBb=k.stride(0), sBh=d, sCb=H * Sq * Skv, sCh=Sq * Skv, out_f32=True)
     p = ops.softmax_rows(s, scale, tbl, H, 512)
     o = torch.empty((nb, Sq, E), dtype=bf, device=D)
     ops.gemm_strided(p, v, o, M=Sq, N=d, K=Skv, lda=Skv, ldb=v.stride(1), ldc=E, nz=nb * H, nbh=H, sAb=H * Sq * Skv, sAh=Sq * Skv,
-                     sBb=v.stride(0), sBh=d, sCb=Sq * E, sCh=d, b_kmajor=True, b_off=v.storage_offset())
+                     sBb=v.stride(0), sBh=d, sCb=Sq * E, sCh=d, b_kmajor=True)
     return o
 
 
-def main():
+def pmc(layout):
+    """20 launches of the SVR spatial shape at E = 4096 for a rocprofv3 --pmc pass"""
     ops.device_check()
     torch.set_grad_enabled(False)
+    ops.set_option("tok_flash", layout)
+    g = torch.Generator(device=D).manual_seed(0)
+    E, H = 4096, 8
+    qkv = torch.randn((8, 256, 3 * E), device=D, generator=g).to(bf)
+    tbl = (0.2 * torch.randn((1023, H), device=D, generator=g)).to(bf)
+    for _ in range(20):
+        ops.tok_attention(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], H, 1 / math.sqrt(E // H), tbl, 512, 0)
+    torch.cuda.synchronize()
+
+
+def timed():
+    """s_memtime phase breakdown (instrumented build) of the SVR spatial and the TTA visual shapes at E = 4096"""
+    from u2tokenizer_amd import _lib
+    ops.device_check()
+    torch.set_grad_enabled(False)
+    h = _lib.load_library()
+    g = torch.Generator(device=D).manual_seed(0)
+    E, H = 4096, 8
+    names = ["dma wait", "barrier", "K dma issue", "QK^T", "softmax", "V dma issue", "PV"]
+    for name, nb, Sq, Skv, ns in (("svr spatial", 8, 256, 256, 1), ("tta visual ns=8", 1, 256, 1792, 8), ("tta visual ns=1", 1, 256, 1792, 1)):
+        q = torch.randn((nb, Sq, E), device=D, generator=g).to(bf)
+        kv = torch.randn((nb, Skv, 2 * E), device=D, generator=g).to(bf)
+        grid = nb * H * ((Sq + 63) // 64) * ns
+        dbg = torch.zeros(grid * 4 * 8, dtype=torch.int64, device=D)
+        h.u2tok_tok_attention_debug_buffer(dbg.data_ptr())
+        ops.tok_attention(q, kv[..., :E], kv[..., E:], H, 1 / math.sqrt(E // H), None, 512, ns)
+        torch.cuda.synchronize()
+        h.u2tok_tok_attention_debug_buffer(None)
+        d = dbg.view(-1, 8).double().cpu()
+        tiles = d[:, 7].mean().item()
+        per = d[:, :7].mean(0) / tiles
+        print(f"{name}: tiles/wave {tiles:.1f}; cycles per tile: " + ", ".join(f"{n} {x:.0f}" for n, x in zip(names, per.tolist())) +
+              f"; sum {per.sum().item():.0f}", flush=True)
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "timed":
+        return timed()
+    if len(sys.argv) > 2 and sys.argv[1] == "pmc":
+        return pmc(int(sys.argv[2]))
+    ops.device_check()
+    torch.set_grad_enabled(False)
+    layout = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    ops.set_option("tok_flash", layout)
+    print("layout", layout)
     g = torch.Generator(device=D).manual_seed(0)
     for E in (4096, 2048):
         H, d = 8, E // 8

@@ -77,6 +77,7 @@ SIGNATURES = {
     "u2tok_profile_collect2": (_i32, [_vp, _vp, _vp, _vp, _i32]),
     "u2tok_set_gemm_scratch": (_i32, [_vp, _sz, _vp]),
     "u2tok_flash_debug_buffer": (_i32, [_vp]),
+    "u2tok_tok_attention_debug_buffer": (_i32, [_vp]),
     "u2tok_vit_workspace_bytes": (_sz, [C.POINTER(VitConfig)]),
     "u2tok_vit_forward": (_i32, [C.POINTER(VitConfig), C.POINTER(_vp), _vp, _vp, _vp, _sz, _vp]),
     "u2tok_spp_workspace_bytes": (_sz, [C.POINTER(SppConfig)]),

@@ -80,6 +80,7 @@ int u2tok_set_gemm_scratch(void* device_ptr, size_t bytes, void* stream) {
   return U2_OK;
 }
 int u2tok_flash_debug_buffer(void* device_ptr) { return flash_set_debug_buffer(device_ptr); }
+int u2tok_tok_attention_debug_buffer(void* device_ptr) { return tok_attention_set_debug_buffer(device_ptr); }
 
 int u2tok_profile_collect(double* ms, double* flops, int64_t* count, int32_t ncat) {
   if (!ms || !flops || !count || ncat <= 0 || ncat > PROF_NCAT) return U2_ERR_ARG;

@@ -385,6 +385,76 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmDesc d) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ M <= 16 rows
+// The ViT keeps its 8 cls rows behind the 16384 patch rows (pipeline.hip); the big-tile kernel takes the 64 full 256-row
+// tiles and leaves those 8 rows to a second launch -- 36 of them per volume (qkv, out-proj, fc2 of 12 blocks).  On the
+// 64 x 64 tile kernel such a product is a chain of K / 64 dependent stage-and-wait steps on a few dozen workgroups:
+// ~20 us each, latency-bound.  Here a workgroup owns 16 output columns; its NW waves split K, every wave loads its
+// weight fragments (the MFMA A operand: 16 rows x 64 contiguous bytes per instruction) and activation fragments straight
+// from memory -- all loads of a wave are issued before its first MFMA, so the whole product costs about one memory latency
+// -- and the waves' partial tiles are added through LDS in a fixed order (bit-repeatable).  v_mfma_f32_16x16x32_bf16 with
+// the weights as A: a lane ends up with 4 consecutive output columns of one row, as in the tile kernels.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_rows16_kernel(GemmDesc d) {
+  __shared__ float red[NW][64][4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int nsteps = d.K >> 5;  // K % 32 == 0 (launcher)
+  const int per = (nsteps + NW - 1) / NW, s0 = wv * per, s1 = min(nsteps, s0 + per);
+  const int nrow = min(n0 + l15, d.N - 1), mrow = min(l15, d.M - 1);
+  const bf16_t* wp = d.B + (int64_t)nrow * d.ldb + g * 8;
+  const bf16_t* xp = d.A + (int64_t)mrow * d.lda + g * 8;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 8;  // steps in flight per batch: 16 x 16-byte loads per lane
+  for (int sb = s0; sb < s1; sb += U) {
+    bf16x8 wf[U], xf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int st = min(sb + u, s1 - 1);
+      wf[u] = *reinterpret_cast<const bf16x8*>(wp + st * 32);
+      xf[u] = *reinterpret_cast<const bf16x8*>(xp + st * 32);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (sb + u < s1) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf[u], acc, 0, 0, 0);
+  }
+  // lane holds C[m = l15][n = n0 + 4 g + r]
+  red[wv][lane][0] = acc[0]; red[wv][lane][1] = acc[1]; red[wv][lane][2] = acc[2]; red[wv][lane][3] = acc[3];
+  __syncthreads();
+  if (wv != 0 || l15 >= d.M) return;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int w = 0; w < NW; ++w)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] += red[w][lane][r];
+  const bool out_f32 = d.flags & GEMM_OUT_F32;
+  const int m = l15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = n0 + 4 * g + r;
+    if (n >= d.N) break;
+    float x = v[r] * d.alpha;
+    if (d.flags & GEMM_BIAS_M) x += bf16_to_f32(d.bias[m]);
+    if (d.flags & GEMM_BIAS_N) x += bf16_to_f32(d.bias[n]);
+    if (d.flags & GEMM_GELU) x = gelu_fast(x);
+    if (d.flags & GEMM_RESIDUAL) x += bf16_to_f32(d.R[(int64_t)m * d.ldr + n]);
+    if (out_f32) reinterpret_cast<float*>(d.C)[(int64_t)m * d.ldc + n] = x;
+    else reinterpret_cast<bf16_t*>(d.C)[(int64_t)m * d.ldc + n] = f32_to_bf16(x);
+  }
+}
+
+// M <= 16, one batch entry, K-contiguous operands, K % 32 == 0: returns 1 when launched, 0 when not applicable
+static int gemm_rows16_try(const GemmDesc& d, hipStream_t stream) {
+  if (d.M > 16 || d.nz != 1 || (d.K & 31) || d.ldbk || (d.flags & (GEMM_A_KMAJOR | GEMM_B_KMAJOR))) return 0;
+  const int nsteps = d.K >> 5;
+  dim3 grid((unsigned)cdiv(d.N, 16));
+  if (nsteps >= 64) hipLaunchKernelGGL((gemm_rows16_kernel<16>), grid, dim3(1024), 0, stream, d);
+  else if (nsteps >= 16) hipLaunchKernelGGL((gemm_rows16_kernel<8>), grid, dim3(512), 0, stream, d);
+  else hipLaunchKernelGGL((gemm_rows16_kernel<4>), grid, dim3(256), 0, stream, d);
+  return launch_status() == U2_OK ? 1 : U2_ERR_LAUNCH;
+}
+
 template <int BM, int BN>
 static int launch_tile(GemmDesc d, hipStream_t stream) {
   d.tiles_m = (int)cdiv(d.M, BM);
@@ -437,6 +507,28 @@ int gemm_bf16(GemmDesc d, hipStream_t stream) {
 // 128^2 / 64^2 tile kernel above; `d` already validated (GEMM_VEC_OK resolved).
 int gemm_classic(GemmDesc d, hipStream_t stream) {
   const Options& o = opts();
+  if (o.gemm_tile == 0) {  // (a forced tile keeps the tile kernels: tests of their row tails)
+    const int r = gemm_rows16_try(d, stream);
+    if (r != 0) return r > 0 ? U2_OK : r;
+    // <= 16 rows past a multiple of 128 in a many-row product (the ViT's GELU product: M = 16384 + 8 cls rows, 24 column
+    // tiles): one more row of 128 x 128 tiles is 24 workgroups that start a SEVENTH round after six full ones (+ 16 %);
+    // the few-rows kernel takes them instead
+    const int rem = d.M & 127;
+    if (d.nz == 1 && d.M >= 2048 && rem != 0 && rem <= 16 && !(d.K & 31) && !d.ldbk &&
+        !(d.flags & (GEMM_A_KMAJOR | GEMM_B_KMAJOR | GEMM_BIAS_M))) {
+      const bool f32 = d.flags & GEMM_OUT_F32;
+      GemmDesc main = d, tail = d;
+      main.M = d.M - rem;
+      tail.M = rem;
+      tail.A = d.A + (int64_t)main.M * d.lda;
+      tail.C = reinterpret_cast<char*>(d.C) + (int64_t)main.M * d.ldc * (f32 ? 4 : 2);
+      if (d.flags & GEMM_RESIDUAL) tail.R = d.R + (int64_t)main.M * d.ldr;
+      const int e = gemm_classic(main, stream);
+      if (e != U2_OK) return e;
+      const int r2 = gemm_rows16_try(tail, stream);
+      return r2 > 0 ? U2_OK : (r2 < 0 ? r2 : U2_ERR_ARG);
+    }
+  }
   int tile = o.gemm_tile;
   // "long K": weight-gradient products of the training path (dW = dY^T X: a small output, K = the 16392 token rows of the
   // ViT).  64 x 64 tiles fill the CUs there but run at ~0.35-0.4 PF/s (197 us for 3072 x 768 x 16392); 128 x 128 tiles with

@@ -193,6 +193,7 @@ int tok_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out
                   int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
                   float scale, const bf16_t* rel_bias, int max_len, int force_splits, void* ws, size_t ws_bytes,
                   hipStream_t stream);
+int tok_attention_set_debug_buffer(void* p);  // diagnostics: >= grid * 4 * 8 uint64, zeroed; null detaches (instrumented build)
 // Diagnostics only (process-wide, not for concurrent use): s_memtime phase sums per (workgroup, wave) of the double
 // pipeline kernel; while a buffer is attached the kernel runs its instrumented build.  See attn.hip.
 int flash_set_debug_buffer(void* p);

@@ -20,10 +20,10 @@
 // is cut into `ns` splits that run as separate workgroups (flash-decoding style); each leaves un-normalised fp32 partial
 // outputs + (running max, sum) per row, and tok_attn_combine_kernel merges them in a fixed order (bit-repeatable).
 //
-// LDS: one K tile and one V tile of 32 keys x d (row-major, 32 KB each at d = 512), filled by LDS-DMA
-// (global_load_lds_dwordx4, the swizzle applied on the per-lane SOURCE address because the DMA destination is
-// lane-linear).  The V tile of step t is in flight under Q K^T + softmax of step t, the K tile of step t + 1 under P V of
-// step t; two barriers per step; 64 KB per workgroup, two workgroups per CU cover each other's waits.
+// LDS: two stages of one K tile and one V tile of 32 keys x d (row-major, 32 KB each at d = 512: 128 KB, one workgroup per
+// CU with the whole register file -- O^T alone is 128 registers; 64 KB and two workgroups per CU at d = 256), filled by
+// LDS-DMA (global_load_lds_dwordx4, the swizzle applied on the per-lane SOURCE address because the DMA destination is
+// lane-linear).  Tile t + 1 is in flight under the whole of step t (K issued before Q K^T, V before P V); one barrier per step.
 //   K tile (fragment rows are K-contiguous: ds_read_b128 of chunk 4 ks + g of row 16 kb + (lane & 15)):
 //       16-byte chunk index XOR (row & 15)  [(row & 7) for 128-byte rows, as gemm.hip]  -> 16 distinct slots per lane group.
 //   V tile (transpose reads; a 16-lane group reads a [4 keys][16 d] block, lane a supplies row a >> 2 / 8-byte piece a & 3):
@@ -44,6 +44,7 @@ struct TokAttnArgs {
   int max_len;
   float* opart;  // ns > 1: [ns][nb][Sq][H * DH] fp32, un-normalised
   float* ml;     // ns > 1: [ns][nb * H][Sq][2] = (running max in log2 units, row sum)
+  unsigned long long* dbg;  // diagnostics (tok_attention_set_debug_buffer): s_memtime sums per (workgroup, wave), 8 slots
 };
 
 constexpr float TOKATTN_RESCALE_THR = 8.0f;
@@ -57,8 +58,15 @@ __device__ __forceinline__ int tv_rot(int k) {
 
 typedef short ta_v4s_t __attribute__((ext_vector_type(4)));
 
-template <int DH>
-__global__ __launch_bounds__(256, 2) void tok_attn_kernel(const TokAttnArgs a) {
+template <int DH, bool TIMED = false>
+__global__ __launch_bounds__(256, DH >= 512 ? 1 : 2) void tok_attn_kernel(const TokAttnArgs a) {
+  unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#define U2_STAMP(i_)                                            \
+  if constexpr (TIMED) {                                        \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    ts[i_] += t_ - tprev;                                       \
+    tprev = t_;                                                 \
+  }
   constexpr int BK = 32;              // keys per tile
   constexpr int CPR = DH / 8;         // 16-byte chunks per tile row
   constexpr int ROWB = DH * 2;        // bytes per tile row
@@ -68,10 +76,8 @@ __global__ __launch_bounds__(256, 2) void tok_attn_kernel(const TokAttnArgs a) {
   constexpr int KS = DH / 32;         // k steps of Q K^T
   constexpr int DB = DH / 16;         // 16-wide d blocks of O^T
   static_assert(NP >= 1 && BK * CPR % 256 == 0, "tile");
-  __shared__ __attribute__((aligned(16))) char lds[2 * TILE];
-  __shared__ float sbias[TOKATTN_BIAS_SLOTS];
-  char* const sK = lds;
-  char* const sV = lds + TILE;
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // [stage][K tile | V tile] x 2, then the bias window
+  float* const sbias = reinterpret_cast<float*>(lds + 4 * TILE);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -122,7 +128,8 @@ __global__ __launch_bounds__(256, 2) void tok_attn_kernel(const TokAttnArgs a) {
   }
 
   // ---- LDS-DMA of one tile: piece i of this thread is LDS chunk c = i * 256 + tid = (row c / CPR, position c % CPR)
-  auto dma_k = [&](int kt) {
+  auto dma_k = [&](int kt, int stage) {
+    char* const sK = lds + stage * 2 * TILE;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       // (a wave instruction covers 64 consecutive chunks: one row when CPR == 64 -- its row index is then scalar)
@@ -133,7 +140,8 @@ __global__ __launch_bounds__(256, 2) void tok_attn_kernel(const TokAttnArgs a) {
                                        (__attribute__((address_space(3))) void*)(sK + (i * 256 + w * 64) * 16), 16, 0, 0);
     }
   };
-  auto dma_v = [&](int kt) {
+  auto dma_v = [&](int kt, int stage) {
+    char* const sV = lds + stage * 2 * TILE + TILE;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int c = i * 256 + w * 64 + lane, row = CPR >= 64 ? (i * 256 + w * 64) / CPR : c / CPR, cp = c % CPR;
@@ -163,26 +171,54 @@ __global__ __launch_bounds__(256, 2) void tok_attn_kernel(const TokAttnArgs a) {
 
   typedef __attribute__((address_space(3))) ta_v4s_t* lds_v4;
 
-  if (kt0 < kt1) dma_k(kt0);
+  if (kt0 < kt1) {
+    dma_k(kt0, 0);
+    dma_v(kt0, 0);
+  }
+  if constexpr (TIMED) tprev = __builtin_amdgcn_s_memtime();
   for (int kt = kt0; kt < kt1; ++kt) {
+    const int stage = (kt - kt0) & 1;
+    const char* const tK = lds + stage * 2 * TILE;
+    const char* const tV = tK + TILE;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // K(kt) has landed for every wave; every wave is done with V(kt - 1)
-    dma_v(kt);
-    // ---- S^T = K Q^T, two 16-key blocks
+    U2_STAMP(0)  // wait for the tile's DMA
+    __syncthreads();  // tile kt has landed for every wave; every wave is done with tile kt - 1 (the other stage)
+    U2_STAMP(1)  // barrier
+    if (kt + 1 < kt1) dma_k(kt + 1, stage ^ 1);
+    U2_STAMP(2)  // K DMA issue
+    // ---- S^T = K Q^T, two 16-key blocks.  Four independent accumulator chains (2 key blocks x even / odd k steps): a
+    // dependent v_mfma_f32_16x16x32 chain issues at its ~8-pass latency, not at the pipe rate
     f32x4 sc[2];
+    {
+      // software pipeline: the fragment of step i + PD is requested before the MFMA of step i is issued (the compiler
+      // barriers keep hipcc from clustering all reads in front of all MFMAs, which exposes the LDS latency once per phase
+      // AND from serialising read -> wait -> MFMA; the in-flight fragments live in the registers the one-wave-per-SIMD
+      // configuration has to spare)
+      constexpr int NQK = 2 * KS, PD = NQK < 8 ? NQK : 8;
+      f32x4 acc[2][2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      sc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const char* rowp = sK + kb * 16 * ROWB + k_row_off;
+      for (int kb = 0; kb < 2; ++kb) acc[kb][0] = acc[kb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      bf16x8 kf[NQK];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(rowp + (((ks * 4 + g) ^ k_swz) << 4));
-        sc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sc[kb], 0, 0, 0);
-        if constexpr (KS > 4) {  // keep hipcc from hoisting all fragment reads of a block in front of its MFMAs (registers)
-          if ((ks & 3) == 3) asm volatile("" ::: "memory");
-        }
+      for (int i = 0; i < NQK; ++i)  // step i = (ks = i >> 1, kb = i & 1)
+        kf[i] = *reinterpret_cast<const bf16x8*>(tK + (i & 1) * 16 * ROWB + k_row_off + ((((i >> 1) * 4 + g) ^ k_swz) << 4));
+#pragma unroll
+      for (int i = 0; i < NQK; ++i)
+        acc[i & 1][(i >> 1) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i], qf[i >> 1], acc[i & 1][(i >> 1) & 1], 0, 0, 0);
+      // schedule: PD fragment reads ahead, then one read per MFMA (sched_group_barrier: 0x100 = DS read, 0x008 = MFMA)
+      __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);
+#pragma unroll
+      for (int i = 0; i < NQK; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i + PD < NQK) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) sc[kb] = KS > 1 ? acc[kb][0] + acc[kb][1] : acc[kb][0];
     }
+    if constexpr (TIMED) asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
+    U2_STAMP(3)  // Q K^T
     // ---- online softmax: lane owns keys kt * 32 + 16 kb + 4 g + r of query row qrow
     float x[8];
     float mt = -INFINITY;
@@ -222,24 +258,49 @@ __global__ __launch_bounds__(256, 2) void tok_attn_kernel(const TokAttnArgs a) {
     pf.u[2] = pack2_bf16(x[4], x[5]);
     pf.u[3] = pack2_bf16(x[6], x[7]);
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // V(kt) has landed; every wave is done with K(kt)
-    if (kt + 1 < kt1) dma_k(kt + 1);
-    // ---- O^T += V^T P^T
+    if constexpr (TIMED) asm volatile("" : "+v"(pf.v));
+    U2_STAMP(4)  // softmax
+    if (kt + 1 < kt1) dma_v(kt + 1, stage ^ 1);
+    U2_STAMP(5)  // V DMA issue
+    // ---- O^T += V^T P^T (same software pipeline over the d blocks)
+    {
+      constexpr int PD = DB < 6 ? DB : 6;
+      bf16x8 vf[DB];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int db = 0; db < DB; ++db) {
-      const int cc = 2 * db + v_cc;
-      const int cp = (cc & ~(SEG - 1)) | (((cc & (SEG - 1)) + v_rot) & (SEG - 1));
-      const char* p = sV + v_base_off + cp * 16;
-      const ta_v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)p);
-      const ta_v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p + 16 * ROWB));
-      const bf16x8 vf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf.v, o[db], 0, 0, 0);
-      if constexpr (DB > 8) {
-        if ((db & 3) == 3) asm volatile("" ::: "memory");
+      for (int db = 0; db < DB; ++db) {
+        const int cc = 2 * db + v_cc;
+        const int cp = (cc & ~(SEG - 1)) | (((cc & (SEG - 1)) + v_rot) & (SEG - 1));
+        const char* p = tV + v_base_off + cp * 16;
+        const ta_v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)p);
+        const ta_v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p + 16 * ROWB));
+        vf[db] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
+#pragma unroll
+      for (int db = 0; db < DB; ++db) o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[db], pf.v, o[db], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * PD, 0);
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (db + PD < DB) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (TIMED) {
+#pragma unroll
+      for (int db = 0; db < DB; ++db) asm volatile("" : "+v"(o[db]));
+    }
+    U2_STAMP(6)  // P V
+  }
+  if constexpr (TIMED) {
+    if (lane == 0 && a.dbg) {
+      unsigned long long* dp = a.dbg + ((size_t)blockIdx.x * 4 + w) * 8;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) dp[i] += ts[i];
+      dp[7] += (unsigned long long)(kt1 - kt0);
     }
   }
+#undef U2_STAMP
 
   // ---- epilogue: lane holds O^T[d = 16 db + 4 g + r][q = qrow]
   float l_tot = l_run + __shfl_xor(l_run, 16, 64);
@@ -302,6 +363,12 @@ static int tok_attn_pick_splits(int nb, int H, int Sq, int Skv, int d, size_t ws
   return std::max(ns, 1);
 }
 
+static unsigned long long* g_tokattn_dbg = nullptr;  // diagnostics only, process-wide (like flash_set_debug_buffer)
+int tok_attention_set_debug_buffer(void* p) {
+  g_tokattn_dbg = reinterpret_cast<unsigned long long*>(p);
+  return U2_OK;
+}
+
 size_t tok_attention_workspace_bytes(int nb, int H, int Sq, int Skv, int d) {
   const int64_t base = (int64_t)nb * H * cdiv(Sq, 64);
   const int ntile = (int)cdiv(Skv, 32);
@@ -352,7 +419,13 @@ int tok_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out
   if (grid > 0x7fffffff) return U2_ERR_ARG;
   ProfScope ps(PROF_TOKATTN, 4.0 * nb * H * (double)Sq * Skv * d, stream,
                2.0 * nb * H * d * (2.0 * Sq + 2.0 * Skv));  // q, k, v read + o written, once
-#define U2_TA(D_) hipLaunchKernelGGL((tok_attn_kernel<D_>), dim3((unsigned)grid), dim3(256), 0, stream, a)
+  a.dbg = g_tokattn_dbg;
+#define U2_TA(D_)                                                                                                      \
+  do {                                                                                                                 \
+    constexpr size_t smem_ = 4 * 32 * (D_) * 2 + TOKATTN_BIAS_SLOTS * 4;                                               \
+    if (a.dbg) hipLaunchKernelGGL((tok_attn_kernel<D_, true>), dim3((unsigned)grid), dim3(256), smem_, stream, a);    \
+    else hipLaunchKernelGGL((tok_attn_kernel<D_, false>), dim3((unsigned)grid), dim3(256), smem_, stream, a);         \
+  } while (0)
   if (d == 512) U2_TA(512);
   else if (d == 256) U2_TA(256);
   else if (d == 128) U2_TA(128);
