@@ -58,6 +58,19 @@ def test_loading_into_a_packed_module_keeps_it_packed():
         assert torch.equal(a, b), k
 
 
+def test_dead_aggregator_parameters_can_live_on_the_host_losslessly():
+    """offload_dead_parameters on a host module: names / values / state dict unchanged, the four tensors stop requiring grad,
+    and the weight table no longer hands them to the library."""
+    m = _modules()
+    ref = {k: v.clone() for k, v in m.state_dict().items()}
+    tok = m.u2tokenizer
+    assert tok.offload_dead_parameters() == 0            # nothing on a GPU here
+    assert all(not p.requires_grad for p in tok.dead_parameters())
+    assert tok._weights()[-5:] == [None] * 5 and tok._weights()[-9] is tok.tta_module.layer_linagg.linear_aggregator.wq.weight
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, ref[k]), k
+
+
 def test_prefix_selection_like_the_reference_projector_load():
     m = _modules()
     whole = {"model." + k: v.clone() for k, v in m.state_dict().items()}
@@ -122,3 +135,14 @@ def test_reference_checkpoint_into_packed_gpu_model_forward_parity(tmp_path):
         assert out.keys() == ref.keys()
         for k in ref:
             assert torch.equal(out[k], ref[k]), k
+    # the reference's never-read aggregator projections (tta.py:47-48,62-65) leave HBM: same output bit for bit, same file
+    E = c.hidden_size
+    freed = m.u2tokenizer.offload_dead_parameters()
+    assert freed == (2 * E * E + 2 * E) * 2 and not any(p.is_cuda for p in m.u2tokenizer.dead_parameters())
+    with torch.no_grad():
+        again = m.u2tokenizer(v_token=f.view(1, 2, -1, E), t_token=t.to(D))
+    assert torch.equal(again, got)
+    out = CK.read_checkpoint(CK.save_checkpoint(m, str(tmp_path / "out_offloaded"), safe_serialization=True))
+    assert out.keys() == ref.keys() and all(torch.equal(out[k], ref[k]) for k in ref)
+    m.to(D)                                                     # sticky: moving the model parks them again
+    assert not any(p.is_cuda for p in m.u2tokenizer.dead_parameters())

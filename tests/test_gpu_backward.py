@@ -296,6 +296,10 @@ TOK_TRAIN_CASES = {
                         lively=True, seed=82),
     "hard_rope_1l": dict(E=512, layers=1, B=1, T=3, N=24, Lt=16, Q=16, top_k=32, ms=True, attn="rope", diffts=False,
                          dmtp=False, lively=False, seed=83),
+    # the nn.MultiheadAttention ("linvt") ablation, a shipped stage-1 recipe (script/amos_mm_stage1/amos_mm_linvt_stage1.sh:46):
+    # attention across batch entries -- B = 2 makes that visible
+    "linvt_2l_live": dict(E=512, layers=2, B=2, T=4, N=24, Lt=20, Q=16, top_k=32, ms=True, attn="linvt", diffts=True,
+                          dmtp=True, lively=True, seed=84),
 }
 
 
@@ -339,19 +343,20 @@ def test_tokenizer_gradients_vs_oracle(name):
     check_grads(got, ref32, ref16, what=name)
 
 
-def test_tokenizer_gradients_vs_reference_fixture():
-    """HIP backward against the REFERENCE modules' own backward (tests/golden/tokenizer_mu2_2l_grads.npz, float64, written by
+@pytest.mark.parametrize("case", ["mu2_2l", "linvt_b2_live"])
+def test_tokenizer_gradients_vs_reference_fixture(case):
+    """HIP backward against the REFERENCE modules' own backward (tests/golden/tokenizer_*_grads.npz, float64, written by
     make_golden.py grads): norm and name-seeded projection of every parameter gradient, column sample of the input
     gradients.  (tests/test_oracle_golden.py pins the oracle's autograd to the same fixtures to 1e-9; this closes the loop
-    without the oracle in between, on the shipped rma + DiffTS + DMTP flavour.)"""
+    without the oracle in between, on the shipped rma + DiffTS + DMTP flavour and on the nn.MultiheadAttention ablation.)"""
     from cases import TOKENIZER_CASES, tokenizer_inputs
     from helpers import load_golden
     from u2tokenizer_amd.tokenizer import u2Tokenizer
-    c = TOKENIZER_CASES["mu2_2l"]
-    g = load_golden("tokenizer_mu2_2l_grads")
+    c = TOKENIZER_CASES[case]
+    g = load_golden(f"tokenizer_{case}_grads")
     tok = u2Tokenizer(c["E"], c["heads"], c["layers"], c["top_k"], c["use_multi_scale"], c["Q"], c["E"], c["attn_type"],
                       c["enable_diffts"], c["enable_dmtp"])
-    sd32 = module_sd(tok, "u2tokenizer.", c["seed"])
+    sd32 = module_sd(tok, "u2tokenizer.", c["seed"], lively=c.get("lively", False))
     tok.load_state_dict({k[len("u2tokenizer."):]: v for k, v in sd32.items()})
     tok = tok.to(bf).to(D).train()
     v, t = tokenizer_inputs(c)
@@ -364,19 +369,26 @@ def test_tokenizer_gradients_vs_reference_fixture():
     assert set(got) == set(names), set(got) ^ set(names)
     top = float(g["norms"].max())
     bad = []
+    tol = 0.35 if c.get("lively") else 6e-2  # (selective attention amplifies bf16 rounding -- 0.29 measured on the two-layer
+    # gain-4 set; test_tokenizer_gradients_vs_oracle carries the bf16 reference's own distance as the yardstick)
     for k, n_ref, p_ref in zip(names, g["norms"], g["probes"]):
         n_ref, p_ref = float(n_ref), float(p_ref)
         probe = synth.synth_tensor(k + "/probe", tuple(got[k].shape), c["seed"]).double()
         scale = max(n_ref, 2e-3 * top)            # gradients that are tiny next to the largest: absolute floor
         e_norm = abs(got[k].norm().item() - n_ref) / scale
         e_probe = abs((got[k] * probe).sum().item() - p_ref) / (scale * probe.norm().item())
-        if e_norm > 6e-2 or e_probe > 6e-2:
+        if e_norm > tol or e_probe > tol:
             bad.append((k, round(e_norm, 4), round(e_probe, 4), n_ref / top))
     assert not bad, sorted(bad, key=lambda b: -max(b[1], b[2]))[:8]
     ref_v = g["d_v_token_s8"].double()
     got_v = vd.grad.double().cpu()[..., ::8]
     e_v = (got_v - ref_v).norm().item() / ref_v.norm().item()
-    assert e_v <= 0.15, e_v
+    assert e_v <= (0.3 if c.get("lively") else 0.15), e_v
+    if float(g["d_t_token_norm"]) > 1e-6 * top:   # the text really matters for this parameter set: compare its gradient too
+        ref_t = g["d_t_token_s8"].double()
+        e_t = (td.grad.double().cpu()[..., ::8] - ref_t).norm().item() / ref_t.norm().item()
+        assert e_t <= 0.3, e_t
+        return
     # In exact arithmetic the TEXT input of this parameter set has no influence on the output (the reference's float64
     # gradient is 1e-12 of the others).  Any bf16 run -- the reference's as well, see the bar of
     # test_tokenizer_gradients_vs_oracle -- breaks that cancellation with its rounding and leaves noise; it has to stay small
@@ -580,7 +592,12 @@ def test_dpo_duplicate_image_batch_is_deduplicated():
     assert torch.equal(res[True][0][0, 1:17], res[True][0][1, 1:17])
     assert rel(res[True][0].float(), res[False][0].float()) < 1e-3
     for k, g in res[False][1].items():
-        assert rel(res[True][1][k].float(), g.float(), 1e-3 * g.float().abs().max().item()) < 5e-2, k
+        # (a key bias shifts every logit of a row alike: its exact gradient is zero, what a bf16 run leaves there is rounding
+        # noise of the other gradients' size -- compared against that size, not against itself)
+        floor = 1e-3 * g.float().abs().max().item()
+        if k.endswith(".wk.bias"):
+            floor = res[False][1][k.replace(".wk.bias", ".wq.bias")].float().abs().max().item()
+        assert rel(res[True][1][k].float(), g.float(), floor) < 5e-2, k
 
 
 def test_config4_full_depth_full_width_gradients():
@@ -653,3 +670,36 @@ def test_config4_full_depth_full_width_gradients():
     assert e_out <= 1.5 * float(g["out_rel16"]) + 1e-3, (e_out, float(g["out_rel16"]))
     assert not bad, dict(list(bad.items())[:8])
     assert cos >= float(g["cos16"]) - 0.02, (cos, float(g["cos16"]))
+
+
+def test_backward_runs_on_the_context_of_its_forward():
+    """Function.backward runs on the autograd engine's thread, whose thread-local context stack is empty: every Function
+    remembers the context its forward ran on and re-enters it.  Visible through the profiling records: the two
+    backward GEMMs (dX, dW) of a linear layer used inside `with ops.Context()` must land on THAT context."""
+    import ctypes as C
+    from u2tokenizer_amd import _lib, autograd as AG, ops
+
+    def gemm_launches(ctx):
+        h = _lib.load_library()
+        prev = h.u2tok_ctx_get_current()
+        h.u2tok_ctx_set_current(ctx.handle)
+        try:
+            ms, fl, cnt = (C.c_double * 6)(), (C.c_double * 6)(), (C.c_int64 * 6)()
+            _lib.check(h.u2tok_profile_collect(ms, fl, cnt, 6), "u2tok_profile_collect")
+        finally:
+            h.u2tok_ctx_set_current(prev)
+        return cnt[0]
+
+    x, w = leaf(rnd(64, 256, seed=1), D), leaf(rnd(128, 256, seed=2), D)
+    c = ops.Context()
+    try:
+        c.set_option("profile", 1)
+        with c:
+            y = AG.linear(x, w)
+        assert gemm_launches(c) == 1
+        y.float().sum().backward()              # outside the with-block: the engine thread has no bound context of its own
+        torch.cuda.synchronize()
+        assert gemm_launches(c) == 2
+        assert x.grad is not None and w.grad is not None
+    finally:
+        c.close()

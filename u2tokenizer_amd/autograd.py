@@ -545,6 +545,25 @@ def _self_attention(m, x, attn_type: str, H: int):
     return linear(ctxv, m.dense.weight, m.dense.bias)
 
 
+def _mha_attention(m, x, H: int):
+    """nn.MultiheadAttention(embed, heads) called as m(x, x, x) with its default batch_first=False -- the "linvt" ablation
+    (svr.py:16-18,29,35; tta.py:83-84,94; script/amos_mm_stage1/amos_mm_linvt_stage1.sh:46 `--enable_rpe False`): dim 0
+    of x is read as the SEQUENCE and dim 1 as the batch, so the "spatial" call attends across (batch, chunk) pairs, the
+    "temporal" call across (batch, token) pairs and the TTA self-attention across batch entries.  The kernels are
+    batch-first: swap the two axes around the same packed-projection + attention-core + out-projection sequence."""
+    E = x.shape[-1]
+    xb = x.permute(1, 0, 2).contiguous()                       # (batch = dim 1, sequence = dim 0, E)
+    qkv = linear(xb, m.in_proj_weight, m.in_proj_bias)
+    ctxv = SelfAttnFn.apply(qkv, None, H, 1.0 / math.sqrt(E // H), 0, False)
+    return linear(ctxv, m.out_proj.weight, m.out_proj.bias).permute(1, 0, 2)
+
+
+def _self_attention_any(m, x, attn_type: str, H: int):
+    if attn_type in ("rma", "rope"):
+        return _self_attention(m, x, attn_type, H)
+    return _mha_attention(m, x, H).contiguous()
+
+
 def _cross_attention(m, query, value, H: int):
     """MultiHeadCrossAttention forward (tta.py:42-69), is_compress = False."""
     E = query.shape[-1]
@@ -556,8 +575,6 @@ def _cross_attention(m, query, value, H: int):
 
 def tokenizer_forward(tok, v_token: torch.Tensor, t_token: torch.Tensor) -> torch.Tensor:
     """u2Tokenizer.forward under autograd (u2Tokenizer.py:40-47 = svr.py:166-188 + tta.py:126-140)."""
-    if tok.attn_type not in ("rma", "rope"):
-        raise NotImplementedError("training the nn.MultiheadAttention ('linvt') ablation is not supported by the HIP path")
     B, T, N, E = v_token.shape
     H = tok.num_heads
     ensure_gemm_scratch(v_token.device)
@@ -565,9 +582,9 @@ def tokenizer_forward(tok, v_token: torch.Tensor, t_token: torch.Tensor) -> torc
     t_token = t_token.to(BF)
     # ---- SVR: x = attn(x), spatial then temporal, no residual / norm (svr.py:23-40)
     for layer in tok.svt_module.attention_network.layers:
-        xs = _self_attention(layer.spatial_attention, x.reshape(B * T, N, E), tok.attn_type, H)
+        xs = _self_attention_any(layer.spatial_attention, x.reshape(B * T, N, E), tok.attn_type, H)
         xt = xs.view(B, T, N, E).permute(0, 2, 1, 3).reshape(B * N, T, E)
-        xt = _self_attention(layer.temporal_attention, xt, tok.attn_type, H)
+        xt = _self_attention_any(layer.temporal_attention, xt, tok.attn_type, H)
         x = xt.view(B, N, T, E).permute(0, 2, 1, 3).contiguous()
     flat = x.reshape(B, T * N, E)
     sel_m = tok.svt_module.token_selection
@@ -587,7 +604,7 @@ def tokenizer_forward(tok, v_token: torch.Tensor, t_token: torch.Tensor) -> torc
     # ---- TTA (tta.py:93-107,126-140)
     q = tok.query_tokens.expand(B, -1, -1)
     for layer in tok.tta_module.layers_vt:
-        so = _self_attention(layer.self_attention, q, tok.attn_type, H)
+        so = _self_attention_any(layer.self_attention, q, tok.attn_type, H)
         q1 = layernorm(q.contiguous(), layer.norm_self.weight, layer.norm_self.bias, res=so)
         co = _cross_attention(layer.visual_cross_attention, q1, V, H)
         q2 = layernorm(q1, layer.norm_cross_v.weight, layer.norm_cross_v.bias, res=co)

@@ -65,11 +65,13 @@ def read_checkpoint(path: str) -> Dict[str, torch.Tensor]:
     return torch.load(path, map_location="cpu", weights_only=True)
 
 
-def load_checkpoint(model: torch.nn.Module, path_or_state_dict, strict: bool = True, prefix: Optional[str] = None):
+def load_checkpoint(model: torch.nn.Module, path_or_state_dict, strict: bool = True, prefix: Optional[str] = None,
+                    offload_dead: bool = False):
     """model.load_state_dict(..., strict) of a reference checkpoint (file, directory or dict).  `prefix` selects a
     sub-dict the way the reference's get_w does for the projector (u2_arch.py:75-77): keys containing `prefix + "."`
     are kept with everything up to and including it removed.  Parameters are copied INTO the existing storages, so a
-    tokenizer that is already packed on the GPU stays packed; it is (re)packed otherwise."""
+    tokenizer that is already packed on the GPU stays packed; it is (re)packed otherwise.  offload_dead: park the
+    aggregator's never-read wv / dense (tta.py:47-48,62-65) in host memory after loading (u2Tokenizer.offload_dead_parameters)."""
     sd = path_or_state_dict if isinstance(path_or_state_dict, dict) else read_checkpoint(path_or_state_dict)
     if prefix is not None:
         sd = {k.split(prefix + ".")[1]: v for k, v in sd.items() if prefix in k}
@@ -77,6 +79,8 @@ def load_checkpoint(model: torch.nn.Module, path_or_state_dict, strict: bool = T
     for m in model.modules():
         if hasattr(m, "pack_weights") and next(m.parameters()).is_cuda:
             m.pack_weights()
+            if offload_dead:  # the reference's never-read linear_aggregator.wv / dense leave HBM; saving stays lossless
+                m.offload_dead_parameters()
     return result
 
 

@@ -220,21 +220,30 @@ __global__ __launch_bounds__(256, DH >= 512 ? 1 : 2) void tok_attn_kernel(const 
     if constexpr (TIMED) asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
     U2_STAMP(3)  // Q K^T
     // ---- online softmax: lane owns keys kt * 32 + 16 kb + 4 g + r of query row qrow
+    // (one wave per SIMD issues a VALU instruction every 5-9 cycles: the instruction count of this block is its cost.
+    //  Without bias the scale is folded into the exponent's FMA and the row max is taken on the raw scores -- scale > 0
+    //  commutes with max; key masking only in a partial last tile.)
     float x[8];
-    float mt = -INFINITY;
+    if (has_bias) {
+      float bb[8];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int i = 0; i < 8; ++i) bb[i] = sbias[(kt * BK - kbeg) + (i >> 2) * 16 + 4 * g + (i & 3) + bias_q];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = kt * BK + kb * 16 + 4 * g + r;
-        float s = sc[kb][r] * c_scale;
-        if (has_bias) s += sbias[(j - kbeg) + bias_q];
-        if (j >= Skv) s = -INFINITY;
-        x[kb * 4 + r] = s;
-        mt = fmaxf(mt, s);
-      }
+      for (int i = 0; i < 8; ++i) x[i] = __builtin_fmaf(sc[i >> 2][i & 3], c_scale, bb[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = sc[i >> 2][i & 3];
+    }
+    if (kt == ntile_all - 1 && (Skv & (BK - 1))) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (kt * BK + (i >> 2) * 16 + 4 * g + (i & 3) >= Skv) x[i] = -INFINITY;
+    }
+    float mt = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7])));
     mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float xs = has_bias ? 1.0f : c_scale;  // what is left to multiply into x
+    mt *= xs;
     if (__any(mt > m_run + TOKATTN_RESCALE_THR)) {  // wave-uniform; always taken on the first tile
       const float m_new = fmaxf(m_run, mt);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -248,7 +257,7 @@ __global__ __launch_bounds__(256, DH >= 512 ? 1 : 2) void tok_attn_kernel(const 
     float ps = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      x[i] = __builtin_amdgcn_exp2f(x[i] - m_run);
+      x[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[i], xs, -m_run));
       ps += x[i];
     }
     l_run += ps;

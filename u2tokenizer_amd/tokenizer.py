@@ -193,7 +193,10 @@ def _pack_qkv_linear(m) -> None:
         bs[i].data = Bv[i * E:(i + 1) * E]
 
 
-def _att_ptrs(m):
+def _att_ptrs(m, value_side: bool = True):
+    """value_side = False: the value / output projections are not handed to the library (the un-projected aggregator)."""
+    if not value_side:
+        return [m.wq.weight, m.wq.bias, m.wk.weight, m.wk.bias, None, None, None, None, None]
     if isinstance(m, nn.MultiheadAttention):  # packed q | k | v rows of in_proj_weight; no relative bias
         E = m.embed_dim
         W, b = m.in_proj_weight, m.in_proj_bias
@@ -234,6 +237,7 @@ class u2Tokenizer(nn.Module):
         self.enable_diffts, self.enable_dmtp = bool(enable_diffts), bool(enable_dmtp)
         self._ws = ops._Workspace()
         self._packed_key = None
+        self._dead_offloaded = False
         self._register_state_dict_hook(_unshare_packed)
         self.last_topk_indices = None  # (B, top_k) int64 -- set by forward() when hard top-k selection is on
         self.capture_svr_tokens = False  # True: forward() also keeps the refined tokens in last_svr_tokens
@@ -254,7 +258,8 @@ class u2Tokenizer(nn.Module):
                 + _att_ptrs(layer.text_cross_attention)
             w += [layer.norm_self.weight, layer.norm_self.bias, layer.norm_cross_v.weight, layer.norm_cross_v.bias,
                   layer.norm_cross_t.weight, layer.norm_cross_t.bias]
-        w += _att_ptrs(self.tta_module.layer_linagg.linear_aggregator)
+        # LinearAggregation runs its cross attention with is_compress=True (tta.py:109-116): wv / dense are never read
+        w += _att_ptrs(self.tta_module.layer_linagg.linear_aggregator, value_side=False)
         return w
 
     def pack_weights(self) -> None:
@@ -281,7 +286,29 @@ class u2Tokenizer(nn.Module):
         self._packed_key = None
         if self.query_tokens.is_cuda:
             self.pack_weights()
+            if self._dead_offloaded:
+                self.offload_dead_parameters()
         return r
+
+    def dead_parameters(self):
+        """linear_aggregator.wv / dense: constructed, initialised and checkpointed by the reference, never read by its
+        forward (MultiHeadCrossAttention with is_compress=True skips both: tta.py:47-48,62-65,109-116)."""
+        la = self.tta_module.layer_linagg.linear_aggregator
+        return [la.wv.weight, la.wv.bias, la.dense.weight, la.dense.bias]
+
+    def offload_dead_parameters(self) -> int:
+        """Park the never-read aggregator projections in host memory (2 E^2 + 2 E elements -- 67 MB of HBM at
+        E = 4096).  They stay nn.Parameters under their reference names, so state_dict() / save_checkpoint() /
+        load_state_dict() are unchanged and lossless; they stop requiring gradients (they never receive any), so optimisers
+        skip them.  Sticky: a later .to(device) parks them again.  Returns the device bytes released."""
+        freed = 0
+        for p in self.dead_parameters():
+            if p.is_cuda:
+                freed += p.numel() * p.element_size()
+                p.data = p.data.to("cpu")
+            p.requires_grad_(False)
+        self._dead_offloaded = True
+        return freed
 
     # The envelope of the HIP path, checked here so that a violation names the limit instead of a bare U2TOK_ERR_ARG.
     def _check_envelope(self, B, T, N, E, Lt):
