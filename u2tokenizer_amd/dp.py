@@ -297,7 +297,9 @@ class Zero1AdamW:
         if self.max_grad_norm is not None:
             for b in self.buckets:
                 self._finish_reduce(b)
-            sq = torch.stack([(b.my_grad[:b.piece].float() / self.world).pow(2).sum() for b in self.buckets]).sum()
+            # (one reduction kernel per bucket straight from the bf16 piece: no fp32 temporaries)
+            sq = torch.stack([torch.linalg.vector_norm(b.my_grad[:b.piece], 2, dtype=torch.float32).pow(2)
+                              for b in self.buckets]).sum() / (self.world * self.world)
             if self.world > 1:
                 dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=self.group)
             total = sq.sqrt()
