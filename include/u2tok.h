@@ -287,6 +287,30 @@ int u2tok_tok_attention(const void* q, const void* k, const void* v, void* out, 
                         int64_t o_bs, float scale, const void* rel_bias, int32_t max_len, int32_t splits, void* workspace,
                         size_t workspace_bytes, u2tok_stream_t stream);
 
+/* ---- the consumer of the path's output ("next" row f3): prefill of the stock HF decoder on the spliced embeddings ---------
+ * (LlamaForCausalLM / Qwen3ForCausalLM.forward with inputs_embeds, src/model/language_model/u2llama.py:76-87,123-126).  The
+ * decoder keeps its HuggingFace module tree, parameters, KV cache and generate loop; u2tokenizer_amd/prefill.py runs each
+ * layer of the PREFILL as RMSNorm -> packed q|k|v GEMM -> head norm + rotary -> causal grouped-query attention -> out
+ * projection (+ residual) -> RMSNorm -> packed gate|up GEMM -> SiLU(gate) * up -> down projection (+ residual). */
+/* softmax(q k^T scale [causal: key j <= query i + Skv - Sq]) v with grouped-query heads: query head h (column h*d of q / out)
+ * reads key / value head h / (Hq / Hkv) (column of k / v); d in {64, 128, 256, 512}; layout conventions of
+ * u2tok_tok_attention. */
+int u2tok_attention_gqa(const void* q, const void* k, const void* v, void* out, int32_t nb, int32_t Sq, int32_t Skv, int32_t Hq,
+                        int32_t Hkv, int32_t d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs,
+                        int64_t v_bs, int64_t o_bs, float scale, int32_t causal, u2tok_stream_t stream);
+/* y[r] = bf16(x[r] * rsqrt(mean(x[r]^2) + eps)) * w   (LlamaRMSNorm / Qwen3RMSNorm); C % 8 == 0, C <= 8192 */
+int u2tok_rmsnorm_bf16(const void* x, const void* w, void* y, int64_t rows, int32_t C, int64_t ldx, int64_t ldy, float eps,
+                       u2tok_stream_t stream);
+/* In place on the q and k heads of a packed projection output qkv[rows][(Hq + 2 Hkv) D] (D = 64 / 128): per-head RMSNorm
+ * with weights wq / wk (Qwen3Attention.q_norm / k_norm; both NULL: none, Llama) and x cos + rotate_half(x) sin
+ * (apply_rotary_pos_emb) with cos / sin [rows][cs_ld >= D], fp32 (cos_sin_f32 != 0) or bf16. */
+int u2tok_qk_norm_rope(void* qkv, const void* wq, const void* wk, const void* cos, const void* sin, int32_t cos_sin_f32,
+                       int64_t rows, int32_t Hq, int32_t Hkv, int32_t D, int64_t ld, int64_t cs_ld, float eps,
+                       u2tok_stream_t stream);
+/* out[r][i] = bf16(silu(gate_up[r][i])) * gate_up[r][I + i]   (LlamaMLP / Qwen3MLP with gate | up packed); I % 8 == 0 */
+int u2tok_swiglu_bf16(const void* gate_up, void* out, int64_t rows, int32_t I, int64_t ld_in, int64_t ld_out,
+                      u2tok_stream_t stream);
+
 /* in-place rotate-half RoPE (rope.py:6-13,77-80): rows indexed (outer, s, inner), position = s; inverse != 0 rotates
  * the other way (the backward of the rotation) */
 int u2tok_rope_apply(void* x, int64_t n_outer, int32_t S, int32_t n_inner, int32_t H, int32_t d, int64_t ld,

@@ -1,0 +1,177 @@
+"""GPU: the decoder prefill on the spliced embeddings (u2llama.py:76-87,123-126) through the HIP kernels
+(u2tokenizer_amd/prefill.py) against the stock HuggingFace decoder -- building blocks against fp32 torch expressions, whole
+models (Qwen3 with its per-head q / k norms and Llama, grouped-query heads) against the same model in fp32 on the host with the
+stock bf16 GPU run as the yardstick, and `generate` through the patched layers (prefill fused, decode steps stock, one cache)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from u2tokenizer_amd import synth
+
+pytestmark = pytest.mark.gpu
+bf = torch.bfloat16
+D = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from u2tokenizer_amd import ops as _ops
+    _ops.device_check()
+    torch.set_grad_enabled(False)
+    return _ops
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed * 7919 + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(bf)
+
+
+def close_bf16(got, ref, rounds=2):
+    got, ref = got.float().cpu(), ref.float()
+    assert torch.isfinite(got).all()
+    tol = rounds * 2.0 ** -8 * ref.abs() + 2.0 ** -8 * ref.abs().max()
+    bad = (got - ref).abs() > tol
+    assert not bad.any(), f"{bad.sum().item()} elements off; worst {(got - ref).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("rows,C", [(1024, 4096), (77, 2048), (5, 512), (300, 8192)])
+def test_rmsnorm(ops, rows, C):
+    x, w = rnd(rows, C, seed=1), (1 + 0.1 * rnd(C, seed=2).float()).to(bf)
+    xf = x.float()
+    ref = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(bf).float() * w.float()   # HF's rounding points
+    close_bf16(ops.rmsnorm(x.to(D), w.to(D), 1e-6), ref)
+
+
+@pytest.mark.parametrize("rows,Hq,Hkv,d,norm,f32", [(1024, 32, 8, 128, True, False), (70, 8, 4, 64, False, True),
+                                                     (33, 4, 4, 128, True, True), (9, 32, 8, 64, False, False)])
+def test_qk_norm_rope(ops, rows, Hq, Hkv, d, norm, f32):
+    """Qwen3Attention: q_norm / k_norm over head_dim, then apply_rotary_pos_emb (rotate_half) -- V untouched."""
+    qkv = rnd(rows, (Hq + 2 * Hkv) * d, seed=3)
+    wq, wk = (1 + 0.1 * rnd(d, seed=4).float()).to(bf), (1 + 0.1 * rnd(d, seed=5).float()).to(bf)
+    pos = torch.arange(rows, dtype=torch.float32)
+    inv = 1.0 / (1e6 ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+    fr = torch.cat([pos[:, None] * inv[None]] * 2, -1)
+    cos, sin = fr.cos(), fr.sin()
+    if not f32:
+        cos, sin = cos.to(bf), sin.to(bf)
+    x = qkv.float().view(rows, Hq + 2 * Hkv, d)
+    ref = x.clone()
+    for lo, hi, w in ((0, Hq, wq), (Hq, Hq + Hkv, wk)):
+        h = x[:, lo:hi]
+        if norm:
+            h = ((h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + 1e-6)).to(bf).float() * w.float()).to(bf).float()
+        rot = torch.cat((-h[..., d // 2:], h[..., :d // 2]), -1)
+        ref[:, lo:hi] = h * cos.float()[:, None] + rot * sin.float()[:, None]
+    got = qkv.to(D)
+    ops.qk_norm_rope(got, wq.to(D) if norm else None, wk.to(D) if norm else None, cos.to(D), sin.to(D), Hq, Hkv, d, 1e-6)
+    close_bf16(got, ref.reshape(rows, -1))
+    assert torch.equal(got[:, (Hq + Hkv) * d:].cpu(), qkv[:, (Hq + Hkv) * d:])
+
+
+def test_swiglu(ops):
+    gu = rnd(300, 2 * 1536, scale=2.0, seed=6)
+    g, u = gu[:, :1536].float(), gu[:, 1536:].float()
+    close_bf16(ops.swiglu(gu.to(D)), F.silu(g).to(bf).float() * u)
+
+
+@pytest.mark.parametrize("nb,Sq,Skv,Hq,Hkv,d", [(1, 1024, 1024, 32, 8, 128), (2, 77, 77, 8, 4, 64), (1, 50, 50, 4, 4, 128),
+                                                (1, 200, 200, 32, 8, 64), (1, 40, 100, 8, 2, 128), (3, 1, 1, 2, 1, 64)])
+def test_attention_gqa_causal(ops, nb, Sq, Skv, Hq, Hkv, d):
+    """Grouped-query causal attention (the prefill's attention; Skv > Sq = a query block at the end of a longer key range)
+    against torch on the same bf16 inputs in fp32; q / k / v are column slices of one packed buffer, as prefill.py passes them."""
+    if Sq == Skv:
+        buf = rnd(nb, Sq, (Hq + 2 * Hkv) * d, seed=Sq + d)
+        q, k, v = buf[..., :Hq * d], buf[..., Hq * d:(Hq + Hkv) * d], buf[..., (Hq + Hkv) * d:]
+        dbuf = buf.to(D)
+        dq, dk, dv = dbuf[..., :Hq * d], dbuf[..., Hq * d:(Hq + Hkv) * d], dbuf[..., (Hq + Hkv) * d:]
+    else:
+        q, kv = rnd(nb, Sq, Hq * d, seed=1), rnd(nb, Skv, 2 * Hkv * d, seed=2)
+        k, v = kv[..., :Hkv * d], kv[..., Hkv * d:]
+        dq, dkv = q.to(D), kv.to(D)
+        dk, dv = dkv[..., :Hkv * d], dkv[..., Hkv * d:]
+    scale = 1.5 / math.sqrt(d)
+    got = [ops.attention_gqa(dq, dk, dv, Hq, Hkv, scale, causal=True) for _ in range(2)]
+    assert torch.equal(got[0], got[1])
+    qh = q.float().view(nb, Sq, Hq, d).transpose(1, 2)
+    kh = k.float().view(nb, Skv, Hkv, d).transpose(1, 2).repeat_interleave(Hq // Hkv, 1)
+    vh = v.float().view(nb, Skv, Hkv, d).transpose(1, 2).repeat_interleave(Hq // Hkv, 1)
+    s = qh @ kh.transpose(-1, -2) * scale
+    i, j = torch.arange(Sq)[:, None], torch.arange(Skv)[None, :]
+    s = s.masked_fill(j > i + (Skv - Sq), float("-inf"))
+    ref = (F.softmax(s, -1) @ vh).transpose(1, 2).reshape(nb, Sq, Hq * d)
+    close_bf16(got[0], ref)
+    # and without the mask (grouped heads only)
+    ref2 = (F.softmax(qh @ kh.transpose(-1, -2) * scale, -1) @ vh).transpose(1, 2).reshape(nb, Sq, Hq * d)
+    close_bf16(ops.attention_gqa(dq, dk, dv, Hq, Hkv, scale, causal=False), ref2)
+
+
+def _small(kind, layers=3):
+    from transformers import LlamaConfig, LlamaForCausalLM, Qwen3Config, Qwen3ForCausalLM
+    common = dict(vocab_size=1024, hidden_size=512, intermediate_size=1536, num_hidden_layers=layers, num_attention_heads=8,
+                  num_key_value_heads=4, head_dim=64, max_position_embeddings=512, tie_word_embeddings=False,
+                  pad_token_id=0, bos_token_id=1, eos_token_id=2)
+    if kind == "qwen3":
+        m = Qwen3ForCausalLM(Qwen3Config(**common))
+    else:
+        m = LlamaForCausalLM(LlamaConfig(**common, rope_theta=500000.0))
+    synth.fill_module_(m, seed=17, prefix="decoder.")
+    return m.eval()
+
+
+def _err(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+
+
+@pytest.mark.parametrize("kind", ["qwen3", "llama"])
+def test_fused_prefill_matches_the_stock_decoder(ops, kind):
+    """Logits and the KV cache of a prefill through the patched layers: no further from the fp32 model than 1.5 x the stock bf16
+    GPU run is; a padded batch must take the stock layers (bit-identical to the unpatched model)."""
+    from u2tokenizer_amd.prefill import disable_fused_prefill, enable_fused_prefill
+    m32 = _small(kind)
+    x = 0.5 * synth.synth_tensor("inputs_embeds", (2, 70, 512), 3)
+    ref = m32(inputs_embeds=x, use_cache=True)
+    mg = _small(kind).to(bf).to(D)
+    xd = x.to(bf).to(D)
+    stock = mg(inputs_embeds=xd, use_cache=True)
+    assert enable_fused_prefill(mg) == 3
+    fused = mg(inputs_embeds=xd, use_cache=True)
+    e_stock, e_fused = _err(stock.logits.float().cpu(), ref.logits), _err(fused.logits.float().cpu(), ref.logits)
+    assert e_fused <= 1.5 * e_stock + 1e-3, (e_fused, e_stock)
+    assert not torch.equal(fused.logits, stock.logits)          # (it really took another code path)
+    for li in (0, 2):
+        for name in ("keys", "values"):
+            r = getattr(ref.past_key_values.layers[li], name)
+            es = _err(getattr(stock.past_key_values.layers[li], name).float().cpu(), r)
+            ef = _err(getattr(fused.past_key_values.layers[li], name).float().cpu(), r)
+            assert ef <= 1.5 * es + 1e-3, (li, name, ef, es)
+    mask = torch.ones((2, 70), dtype=torch.int64, device=D)
+    mask[1, :5] = 0
+    padded = mg(inputs_embeds=xd, attention_mask=mask, use_cache=True)
+    disable_fused_prefill(mg)
+    assert torch.equal(padded.logits, mg(inputs_embeds=xd, attention_mask=mask, use_cache=True).logits)
+
+
+def test_generate_prefills_fused_and_decodes_on_the_same_cache(ops):
+    """HF generate over the patched model: the prefill goes through the HIP layers, every decode step through the stock ones on
+    the cache the prefill filled.  Greedy ids equal the unpatched model's unless the fp32 model's own top-2 margin at that step
+    is below the bf16 noise (a bf16 run may legitimately flip such an argmax)."""
+    from u2tokenizer_amd.prefill import enable_fused_prefill
+    m32 = _small("qwen3", layers=2)
+    x = 0.5 * synth.synth_tensor("inputs_embeds", (1, 48, 512), 5)
+    new = 6
+    g32 = m32.generate(inputs_embeds=x, max_new_tokens=new, do_sample=False, output_scores=True, return_dict_in_generate=True)
+    mg = _small("qwen3", layers=2).to(bf).to(D)
+    g_stock = mg.generate(inputs_embeds=x.to(bf).to(D), max_new_tokens=new, do_sample=False).cpu()
+    enable_fused_prefill(mg)
+    g_fused = mg.generate(inputs_embeds=x.to(bf).to(D), max_new_tokens=new, do_sample=False).cpu()
+    assert g_fused.shape == g_stock.shape == g32.sequences.shape
+    for t in range(new):
+        top2 = g32.scores[t][0].topk(2).values
+        if (top2[0] - top2[1]).item() > 0.05:
+            assert g_fused[0, t] == g32.sequences[0, t] == g_stock[0, t], (t, g_fused, g_stock, g32.sequences)
+        else:
+            break   # past an ambiguous step the continuations may differ legitimately

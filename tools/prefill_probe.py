@@ -37,3 +37,22 @@ ms = (time.perf_counter() - t0) / n * 1e3
 flop = 2.0 * (nparam - cfg.vocab_size * cfg.hidden_size) * 1024 + 4.0 * layers * 1024 * 1024 * 4096
 print(f"Qwen3-8B-shaped prefill, {layers} layers, S=1024, bf16, stock HF on PyTorch-ROCm: {ms:.2f} ms "
       f"({flop / ms / 1e9:.0f} TFLOP/s of {flop / 1e12:.1f} TFLOP); logits {tuple(out.logits.shape)}; {nparam / 1e9:.2f} B params")
+
+# the same prefill through the HIP layers (u2tokenizer_amd/prefill.py): fused q|k|v and gate|up GEMMs, causal grouped-query
+# flash attention, residuals in the GEMM epilogues
+from pathlib import Path  # noqa: E402
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from u2tokenizer_amd.prefill import enable_fused_prefill  # noqa: E402
+ref = out.logits[:, -1].float()
+enable_fused_prefill(m)
+for _ in range(2):
+    m(inputs_embeds=x, use_cache=True)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(n):
+    out = m(inputs_embeds=x, use_cache=True)
+torch.cuda.synchronize()
+ms2 = (time.perf_counter() - t0) / n * 1e3
+d = (out.logits[:, -1].float() - ref)
+print(f"same through u2tokenizer_amd.prefill (HIP layers): {ms2:.2f} ms ({flop / ms2 / 1e9:.0f} TFLOP/s), x{ms / ms2:.2f}; "
+      f"last-position logits vs stock: rel rms {(d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item():.3e}")

@@ -261,6 +261,26 @@ int u2tok_tok_attention(const void* q, const void* k, const void* v, void* out, 
                        BF(rel_bias), max_len, splits, workspace, workspace_bytes, ST(stream));
 }
 
+int u2tok_attention_gqa(const void* q, const void* k, const void* v, void* out, int32_t nb, int32_t Sq, int32_t Skv, int32_t Hq,
+                        int32_t Hkv, int32_t d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs,
+                        int64_t v_bs, int64_t o_bs, float scale, int32_t causal, u2tok_stream_t stream) {
+  return attention_ex(BF(q), BF(k), BF(v), BFW(out), nb, Sq, Skv, Hq, Hkv, d, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, scale,
+                      nullptr, 0, causal, 1, nullptr, 0, ST(stream));
+}
+int u2tok_rmsnorm_bf16(const void* x, const void* w, void* y, int64_t rows, int32_t C, int64_t ldx, int64_t ldy, float eps,
+                       u2tok_stream_t stream) {
+  return rmsnorm_bf16(BF(x), BF(w), BFW(y), rows, C, ldx, ldy, eps, ST(stream));
+}
+int u2tok_qk_norm_rope(void* qkv, const void* wq, const void* wk, const void* cos, const void* sin, int32_t cos_sin_f32,
+                       int64_t rows, int32_t Hq, int32_t Hkv, int32_t D, int64_t ld, int64_t cs_ld, float eps,
+                       u2tok_stream_t stream) {
+  return qk_norm_rope(BFW(qkv), BF(wq), BF(wk), cos, sin, cos_sin_f32, rows, Hq, Hkv, D, ld, cs_ld, eps, ST(stream));
+}
+int u2tok_swiglu_bf16(const void* gate_up, void* out, int64_t rows, int32_t I, int64_t ld_in, int64_t ld_out,
+                      u2tok_stream_t stream) {
+  return swiglu_bf16(BF(gate_up), BFW(out), rows, I, ld_in, ld_out, ST(stream));
+}
+
 int u2tok_rope_apply(void* x, int64_t n_outer, int32_t S, int32_t n_inner, int32_t H, int32_t d, int64_t ld,
                      int32_t max_len, int32_t inverse, u2tok_stream_t stream) {
   return rope_apply(BFW(x), n_outer, S, n_inner, H, d, ld, max_len, inverse, ST(stream));

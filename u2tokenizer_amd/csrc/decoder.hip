@@ -1,0 +1,168 @@
+// Row kernels of the decoder prefill that consumes the path's output (the step AFTER the path --
+// LlamaForCausalLM / Qwen3ForCausalLM.forward on the spliced inputs_embeds, src/model/language_model/u2llama.py:76-87,123-126).
+// The decoder stays the stock HuggingFace module tree (its parameters, its KV cache, its generate loop); for the PREFILL of
+// the S = 1024 spliced embeddings the host side (u2tokenizer_amd/prefill.py) runs each layer as
+//   RMSNorm -> packed q|k|v GEMM -> per-head RMSNorm (Qwen3) + rotary embedding -> causal grouped-query attention
+//   (tokattn.hip) -> out-projection GEMM (+ residual) -> RMSNorm -> packed gate|up GEMM -> SiLU(gate) * up -> down GEMM (+ residual)
+// and these are the HBM-bound pieces between the GEMMs.  All bf16 in / out, fp32 arithmetic, 16-byte accesses.
+#include "kernels.h"
+
+namespace u2 {
+
+// ------------------------------------------------------------------------------------------------ RMSNorm
+// y[r][:] = bf16(x[r][:] * rsqrt(mean(x[r][:]^2) + eps)) * w   (LlamaRMSNorm / Qwen3RMSNorm: the normalised value is rounded
+// to the input dtype before the product with w -- the same two rounding points here)
+template <int NC>  // 16-byte chunks per lane held in registers: C <= NC * 512
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                      bf16_t* __restrict__ y, int64_t rows, int C, int64_t ldx, int64_t ldy,
+                                                      float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xp = x + row * ldx;
+  bf16_t* yp = y + row * ldy;
+  const int nchunk = C >> 3;
+  uint4 v[NC];
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = i * 64 + lane;
+    v[i] = uint4{0, 0, 0, 0};
+    if (c < nchunk) {
+      v[i] = *reinterpret_cast<const uint4*>(xp + c * 8);
+      const float a0 = bf16lo(v[i].x), a1 = bf16hi(v[i].x), a2 = bf16lo(v[i].y), a3 = bf16hi(v[i].y);
+      const float a4 = bf16lo(v[i].z), a5 = bf16hi(v[i].z), a6 = bf16lo(v[i].w), a7 = bf16hi(v[i].w);
+      sq += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3 + a4 * a4 + a5 * a5 + a6 * a6 + a7 * a7;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = i * 64 + lane;
+    if (c < nchunk) {
+      const uint4 uw = *reinterpret_cast<const uint4*>(w + c * 8);
+      const uint4 n = uint4{pack2_bf16(bf16lo(v[i].x) * rstd, bf16hi(v[i].x) * rstd), pack2_bf16(bf16lo(v[i].y) * rstd, bf16hi(v[i].y) * rstd),
+                            pack2_bf16(bf16lo(v[i].z) * rstd, bf16hi(v[i].z) * rstd), pack2_bf16(bf16lo(v[i].w) * rstd, bf16hi(v[i].w) * rstd)};
+      *reinterpret_cast<uint4*>(yp + c * 8) =
+          uint4{pack2_bf16(bf16lo(n.x) * bf16lo(uw.x), bf16hi(n.x) * bf16hi(uw.x)), pack2_bf16(bf16lo(n.y) * bf16lo(uw.y), bf16hi(n.y) * bf16hi(uw.y)),
+                pack2_bf16(bf16lo(n.z) * bf16lo(uw.z), bf16hi(n.z) * bf16hi(uw.z)), pack2_bf16(bf16lo(n.w) * bf16lo(uw.w), bf16hi(n.w) * bf16hi(uw.w))};
+    }
+  }
+}
+
+int rmsnorm_bf16(const bf16_t* x, const bf16_t* w, bf16_t* y, int64_t rows, int C, int64_t ldx, int64_t ldy, float eps,
+                 hipStream_t stream) {
+  if (!x || !w || !y || rows <= 0 || C <= 0 || (C & 7) || C > 8192 || (ldx & 7) || (ldy & 7)) return U2_ERR_ARG;
+  if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) || cdiv(rows, 4) > 0x7fffffff) return U2_ERR_ARG;
+  ProfScope ps(PROF_ROWOP, 0, stream, (double)rows * C * 4.0);
+  dim3 grid((unsigned)cdiv(rows, 4));
+#define U2_RN(NC) hipLaunchKernelGGL((rmsnorm_kernel<NC>), grid, dim3(256), 0, stream, x, w, y, rows, C, ldx, ldy, eps)
+  if (C <= 1024) U2_RN(2);
+  else if (C <= 2048) U2_RN(4);
+  else if (C <= 4096) U2_RN(8);
+  else U2_RN(16);
+#undef U2_RN
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ q / k: head norm + rotary
+// In place on the q and k column blocks of the packed projection output qkv[rows][(Hq + 2 Hkv) D]: for every (row, head)
+//   x <- RMSNorm_D(x) * w_q|k          (Qwen3Attention.q_norm / k_norm; skipped when the weight pointer is null: Llama)
+//   x <- x * cos + rotate_half(x) * sin (apply_rotary_pos_emb; cos / sin: [rows][D] fp32 or bf16 as HF hands them out)
+// One wave per (row, head); lane l < D/2 holds the pair (x[l], x[l + D/2]) rotate_half couples.
+template <int D, typename CS>
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ qkv, const bf16_t* __restrict__ wq,
+                                                           const bf16_t* __restrict__ wk, const CS* __restrict__ cosp,
+                                                           const CS* __restrict__ sinp, int64_t rows, int Hq, int Hkv,
+                                                           int64_t ld, int64_t cs_ld, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nh = Hq + Hkv;
+  if (item >= rows * nh) return;
+  const int64_t row = item / nh;
+  const int hh = (int)(item - row * nh);
+  bf16_t* p = qkv + row * ld + (int64_t)hh * D;  // k heads follow the q heads in the packed row
+  const bf16_t* w = hh < Hq ? wq : wk;
+  constexpr int HALF = D / 2;
+  const bool on = lane < HALF;
+  float a = 0.f, b = 0.f;
+  if (on) {
+    a = bf16_to_f32(p[lane]);
+    b = bf16_to_f32(p[lane + HALF]);
+  }
+  if (w) {
+    const float rstd = rsqrtf(wave_sum(a * a + b * b) / (float)D + eps);
+    if (on) {
+      // (the reference rounds the normalised value to bf16 before the weight product: keep that rounding point)
+      a = bf16_to_f32(f32_to_bf16(a * rstd)) * bf16_to_f32(w[lane]);
+      b = bf16_to_f32(f32_to_bf16(b * rstd)) * bf16_to_f32(w[lane + HALF]);
+      a = bf16_to_f32(f32_to_bf16(a));
+      b = bf16_to_f32(f32_to_bf16(b));
+    }
+  }
+  if (on) {
+    const CS* cr = cosp + row * cs_ld;
+    const CS* sr = sinp + row * cs_ld;
+    const float c0 = (float)cr[lane], c1 = (float)cr[lane + HALF], s0 = (float)sr[lane], s1 = (float)sr[lane + HALF];
+    p[lane] = f32_to_bf16(a * c0 - b * s0);          // rotate_half(x) = (-x2, x1)
+    p[lane + HALF] = f32_to_bf16(b * c1 + a * s1);
+  }
+}
+
+struct Bf16Val {  // bf16 cos / sin tables
+  bf16_t v;
+  __device__ explicit operator float() const { return bf16_to_f32(v); }
+};
+
+int qk_norm_rope(bf16_t* qkv, const bf16_t* wq, const bf16_t* wk, const void* cosp, const void* sinp, int cs_is_f32,
+                 int64_t rows, int Hq, int Hkv, int D, int64_t ld, int64_t cs_ld, float eps, hipStream_t stream) {
+  if (!qkv || !cosp || !sinp || rows <= 0 || Hq <= 0 || Hkv <= 0 || (D != 64 && D != 128) || (!wq) != (!wk)) return U2_ERR_ARG;
+  const int64_t items = rows * (Hq + Hkv);
+  if (cdiv(items, 4) > 0x7fffffff) return U2_ERR_ARG;
+  ProfScope ps(PROF_ROWOP, 0, stream, (double)items * D * 4.0);
+  dim3 grid((unsigned)cdiv(items, 4));
+#define U2_QK(D_, T_)                                                                                                     \
+  hipLaunchKernelGGL((qk_norm_rope_kernel<D_, T_>), grid, dim3(256), 0, stream, qkv, wq, wk, reinterpret_cast<const T_*>(cosp), \
+                     reinterpret_cast<const T_*>(sinp), rows, Hq, Hkv, ld, cs_ld, eps)
+  if (D == 128 && cs_is_f32) U2_QK(128, float);
+  else if (D == 128) U2_QK(128, Bf16Val);
+  else if (cs_is_f32) U2_QK(64, float);
+  else U2_QK(64, Bf16Val);
+#undef U2_QK
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ SwiGLU
+// out[r][i] = silu(gu[r][i]) * gu[r][I + i]   (LlamaMLP / Qwen3MLP: down_proj(act_fn(gate_proj(x)) * up_proj(x)) with the
+// gate | up projections packed into one GEMM); the reference rounds silu(gate) to bf16 before the product: kept.
+__global__ __launch_bounds__(256) void swiglu_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ out, int64_t rows, int I,
+                                                     int64_t ld_in, int64_t ld_out) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int per = I >> 3;
+  if (idx >= rows * per) return;
+  const int64_t r = idx / per;
+  const int c = (int)(idx - r * per) * 8;
+  const uint4 g = *reinterpret_cast<const uint4*>(gu + r * ld_in + c);
+  const uint4 u = *reinterpret_cast<const uint4*>(gu + r * ld_in + I + c);
+  auto f = [](float gate, float up) {
+    const float s = gate / (1.0f + __expf(-gate));
+    return bf16_to_f32(f32_to_bf16(s)) * up;
+  };
+  *reinterpret_cast<uint4*>(out + r * ld_out + c) =
+      uint4{pack2_bf16(f(bf16lo(g.x), bf16lo(u.x)), f(bf16hi(g.x), bf16hi(u.x))),
+            pack2_bf16(f(bf16lo(g.y), bf16lo(u.y)), f(bf16hi(g.y), bf16hi(u.y))),
+            pack2_bf16(f(bf16lo(g.z), bf16lo(u.z)), f(bf16hi(g.z), bf16hi(u.z))),
+            pack2_bf16(f(bf16lo(g.w), bf16lo(u.w)), f(bf16hi(g.w), bf16hi(u.w)))};
+}
+
+int swiglu_bf16(const bf16_t* gu, bf16_t* out, int64_t rows, int I, int64_t ld_in, int64_t ld_out, hipStream_t stream) {
+  if (!gu || !out || rows <= 0 || I <= 0 || (I & 7) || (ld_in & 7) || (ld_out & 7) || (((uintptr_t)gu | (uintptr_t)out) & 15))
+    return U2_ERR_ARG;
+  const int64_t total = rows * (I >> 3);
+  if (cdiv(total, 256) > 0x7fffffff) return U2_ERR_ARG;
+  ProfScope ps(PROF_ROWOP, 0, stream, (double)rows * I * 6.0);
+  hipLaunchKernelGGL(swiglu_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, gu, out, rows, I, ld_in, ld_out);
+  return launch_status();
+}
+
+}  // namespace u2

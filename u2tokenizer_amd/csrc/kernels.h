@@ -193,7 +193,19 @@ int tok_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out
                   int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
                   float scale, const bf16_t* rel_bias, int max_len, int force_splits, void* ws, size_t ws_bytes,
                   hipStream_t stream);
-int tok_attention_set_debug_buffer(void* p);  // diagnostics: >= grid * 4 * 8 uint64, zeroed; null detaches (instrumented build)
+// The same kernel for the decoder prefill: grouped-query heads (query head h reads key / value head h / (H / Hkv)) and a causal
+// mask (key j visible to query i iff j <= i + Skv - Sq); no relative bias and no key splits with causal.
+int attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int nb, int Sq, int Skv, int H, int Hkv, int d,
+                 int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
+                 float scale, const bf16_t* rel_bias, int max_len, int causal, int force_splits, void* ws, size_t ws_bytes,
+                 hipStream_t stream);
+int tok_attention_set_debug_buffer(void* p);
+// ------------------------------------------------------------------ decoder prefill row kernels (decoder.hip)
+int rmsnorm_bf16(const bf16_t* x, const bf16_t* w, bf16_t* y, int64_t rows, int C, int64_t ldx, int64_t ldy, float eps,
+                 hipStream_t stream);
+int qk_norm_rope(bf16_t* qkv, const bf16_t* wq, const bf16_t* wk, const void* cosp, const void* sinp, int cs_is_f32,
+                 int64_t rows, int Hq, int Hkv, int D, int64_t ld, int64_t cs_ld, float eps, hipStream_t stream);
+int swiglu_bf16(const bf16_t* gu, bf16_t* out, int64_t rows, int I, int64_t ld_in, int64_t ld_out, hipStream_t stream);  // diagnostics: >= grid * 4 * 8 uint64, zeroed; null detaches (instrumented build)
 // Diagnostics only (process-wide, not for concurrent use): s_memtime phase sums per (workgroup, wave) of the double
 // pipeline kernel; while a buffer is attached the kernel runs its instrumented build.  See attn.hip.
 int flash_set_debug_buffer(void* p);

@@ -44,6 +44,8 @@ struct TokAttnArgs {
   int max_len;
   float* opart;  // ns > 1: [ns][nb][Sq][H * DH] fp32, un-normalised
   float* ml;     // ns > 1: [ns][nb * H][Sq][2] = (running max in log2 units, row sum)
+  int kv_group;  // grouped-query attention: query head h reads key / value head h / kv_group (1: plain multi-head)
+  int causal;    // 1: key j is visible to query i iff j <= i + (Skv - Sq)   (decoder prefill)
   unsigned long long* dbg;  // diagnostics (tok_attention_set_debug_buffer): s_memtime sums per (workgroup, wave), 8 slots
 };
 
@@ -100,11 +102,15 @@ __global__ __launch_bounds__(256, DH >= 512 ? 1 : 2) void tok_attn_kernel(const 
   const int q0 = qblk * 64;
   const int Sq = a.Sq, Skv = a.Skv;
   const int ntile_all = (Skv + BK - 1) / BK;
-  const int kt0 = sp * a.tps, kt1 = min(ntile_all, kt0 + a.tps);
+  const int c_off = Skv - Sq;  // causal: query i sees keys j <= i + c_off
+  int kt1_ = min(ntile_all, sp * a.tps + a.tps);
+  if (a.causal) kt1_ = min(kt1_, (q0 + 63 + c_off) / BK + 1);  // tiles past the block's last visible key are skipped
+  const int kt0 = sp * a.tps, kt1 = kt1_;
   const int kbeg = kt0 * BK;
 
-  const bf16_t* kb_ = a.k + (int64_t)b * a.k_bs + h * DH;
-  const bf16_t* vb_ = a.v + (int64_t)b * a.v_bs + h * DH;
+  const int hkv = h / a.kv_group;
+  const bf16_t* kb_ = a.k + (int64_t)b * a.k_bs + hkv * DH;
+  const bf16_t* vb_ = a.v + (int64_t)b * a.v_bs + hkv * DH;
 
   // ---- Q fragments (B operand): Q[q][32 ks + 8 g .. + 7]
   const int qrow = q0 + 16 * w + l15;
@@ -238,6 +244,11 @@ __global__ __launch_bounds__(256, DH >= 512 ? 1 : 2) void tok_attn_kernel(const 
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         if (kt * BK + (i >> 2) * 16 + 4 * g + (i & 3) >= Skv) x[i] = -INFINITY;
+    }
+    if (a.causal && kt * BK + BK - 1 > q0 + 16 * w + c_off) {  // (wave-uniform) the tile reaches past this wave's diagonal
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (kt * BK + (i >> 2) * 16 + 4 * g + (i & 3) > qrow + c_off) x[i] = -INFINITY;
     }
     float mt = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7])));
     mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
@@ -401,7 +412,16 @@ int tok_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out
                   int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
                   float scale, const bf16_t* rel_bias, int max_len, int force_splits, void* ws, size_t ws_bytes,
                   hipStream_t stream) {
-  if (!q || !k || !v || !out || nb <= 0 || Sq <= 0 || Skv <= 0 || H <= 0) return U2_ERR_ARG;
+  return attention_ex(q, k, v, out, nb, Sq, Skv, H, H, d, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, scale, rel_bias, max_len, 0,
+                      force_splits, ws, ws_bytes, stream);
+}
+
+int attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int nb, int Sq, int Skv, int H, int Hkv, int d,
+                 int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
+                 float scale, const bf16_t* rel_bias, int max_len, int causal, int force_splits, void* ws, size_t ws_bytes,
+                 hipStream_t stream) {
+  if (!q || !k || !v || !out || nb <= 0 || Sq <= 0 || Skv <= 0 || H <= 0 || Hkv <= 0 || H % Hkv) return U2_ERR_ARG;
+  if (causal && (Skv < Sq || rel_bias)) return U2_ERR_ARG;
   if (!tok_attention_supported(q, k, v, out, Sq, Skv, d, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, rel_bias, max_len))
     return U2_ERR_ARG;
   TokAttnArgs a;
@@ -411,7 +431,10 @@ int tok_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out
   a.scale_log2e = scale * 1.44269504088896340736f;
   a.rel_bias = rel_bias; a.max_len = max_len;
   const int ntile = (int)cdiv(Skv, 32);
+  a.kv_group = H / Hkv;
+  a.causal = causal ? 1 : 0;
   int ns = force_splits > 0 ? std::min(force_splits, ntile) : tok_attn_pick_splits(nb, H, Sq, Skv, d, ws ? ws_bytes : 0);
+  if (causal) ns = 1;  // (a causal unit's key range depends on its query block: no key splits; prefill has enough units)
   const size_t per = (size_t)nb * Sq * ((size_t)H * d * 4 + (size_t)H * 8);
   if (ns > 1 && (!ws || ws_bytes < (size_t)ns * per || ((uintptr_t)ws & 15))) {
     if (force_splits > 0) return U2_ERR_WORKSPACE;
@@ -426,8 +449,8 @@ int tok_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out
   }
   const int64_t grid = (int64_t)nb * H * a.nqb * a.ns;
   if (grid > 0x7fffffff) return U2_ERR_ARG;
-  ProfScope ps(PROF_TOKATTN, 4.0 * nb * H * (double)Sq * Skv * d, stream,
-               2.0 * nb * H * d * (2.0 * Sq + 2.0 * Skv));  // q, k, v read + o written, once
+  ProfScope ps(PROF_TOKATTN, (causal ? 2.0 : 4.0) * nb * H * (double)Sq * Skv * d, stream,
+               2.0 * nb * d * (2.0 * Sq * H + 2.0 * Skv * Hkv));  // q, k, v read + o written, once
   a.dbg = g_tokattn_dbg;
 #define U2_TA(D_)                                                                                                      \
   do {                                                                                                                 \

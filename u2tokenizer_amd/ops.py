@@ -463,6 +463,73 @@ def tok_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
     return out
 
 
+# ---------------------------------------------------------------------------------- decoder prefill blocks (prefill.py)
+@_guarded
+def attention_gqa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, kv_heads: int, scale: float,
+                  causal: bool = True) -> torch.Tensor:
+    """softmax(q k^T scale [+ causal mask]) v with grouped-query heads (u2tok_attention_gqa): q (nb, Sq, heads * d),
+    k / v (nb, Skv, kv_heads * d) -- views with a contiguous last dim -> (nb, Sq, heads * d)."""
+    h = _lib.load_library()
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _need(t, torch.bfloat16, n)
+        if t.dim() != 3 or t.stride(2) != 1:
+            raise RuntimeError(f"attention_gqa: {n} must be (nb, S, H * d) with a contiguous last dim")
+    nb, Sq, Eq = q.shape
+    Skv = k.shape[1]
+    d = Eq // heads
+    if Eq % heads or k.shape != (nb, Skv, kv_heads * d) or v.shape != k.shape or heads % kv_heads:
+        raise RuntimeError(f"attention_gqa: shapes {tuple(q.shape)}, {tuple(k.shape)}, {tuple(v.shape)}, heads {heads}/{kv_heads}")
+    out = torch.empty((nb, Sq, Eq), dtype=torch.bfloat16, device=q.device)
+    _lib.check(h.u2tok_attention_gqa(_ptr(q), _ptr(k), _ptr(v), _ptr(out), nb, Sq, Skv, heads, kv_heads, d, q.stride(1),
+                                     k.stride(1), v.stride(1), Eq, q.stride(0), k.stride(0), v.stride(0), Sq * Eq,
+                                     float(scale), int(bool(causal)), _stream()), "u2tok_attention_gqa")
+    return out
+
+
+@_guarded
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    """LlamaRMSNorm / Qwen3RMSNorm over the last dim of x (rows, C) bf16."""
+    h = _lib.load_library()
+    x = _need(x, torch.bfloat16, "x")
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise RuntimeError("rmsnorm: x must be (rows, C) with a contiguous last dim")
+    y = torch.empty((x.shape[0], x.shape[1]), dtype=torch.bfloat16, device=x.device)
+    _lib.check(h.u2tok_rmsnorm_bf16(_ptr(x), _ptr(_need(w, torch.bfloat16, "w")), _ptr(y), x.shape[0], x.shape[1], x.stride(0),
+                                    x.shape[1], float(eps), _stream()), "u2tok_rmsnorm_bf16")
+    return y
+
+
+@_guarded
+def qk_norm_rope(qkv: torch.Tensor, q_norm_w, k_norm_w, cos: torch.Tensor, sin: torch.Tensor, heads: int, kv_heads: int,
+                 head_dim: int, eps: float = 1e-6) -> torch.Tensor:
+    """In place on the q and k heads of qkv (rows, (heads + 2 kv_heads) * head_dim): per-head RMSNorm (weights may both be
+    None: Llama) then rotary embedding with cos / sin (rows, head_dim), fp32 or bf16 (u2tok_qk_norm_rope)."""
+    h = _lib.load_library()
+    _need(qkv, torch.bfloat16, "qkv")
+    rows = qkv.shape[0]
+    if qkv.dim() != 2 or qkv.stride(1) != 1 or qkv.shape[1] != (heads + 2 * kv_heads) * head_dim:
+        raise RuntimeError("qk_norm_rope: qkv must be (rows, (heads + 2 kv_heads) * head_dim)")
+    if cos.dtype != sin.dtype or cos.dtype not in (torch.float32, torch.bfloat16) or cos.shape != (rows, head_dim) \
+            or sin.shape != cos.shape or cos.stride(1) != 1 or sin.stride(1) != 1 or cos.stride(0) != sin.stride(0):
+        raise RuntimeError("qk_norm_rope: cos / sin must be (rows, head_dim) fp32 or bf16 with equal strides")
+    _lib.check(h.u2tok_qk_norm_rope(_ptr(qkv), _ptr(q_norm_w), _ptr(k_norm_w), _ptr(cos), _ptr(sin),
+                                    int(cos.dtype == torch.float32), rows, heads, kv_heads, head_dim, qkv.stride(0),
+                                    cos.stride(0), float(eps), _stream()), "u2tok_qk_norm_rope")
+    return qkv
+
+
+@_guarded
+def swiglu(gate_up: torch.Tensor) -> torch.Tensor:
+    """(rows, 2 I) packed gate | up -> silu(gate) * up (rows, I)  (u2tok_swiglu_bf16)."""
+    h = _lib.load_library()
+    _need(gate_up, torch.bfloat16, "gate_up")
+    rows, two_i = gate_up.shape
+    out = torch.empty((rows, two_i // 2), dtype=torch.bfloat16, device=gate_up.device)
+    _lib.check(h.u2tok_swiglu_bf16(_ptr(gate_up), _ptr(out), rows, two_i // 2, gate_up.stride(0), two_i // 2, _stream()),
+               "u2tok_swiglu_bf16")
+    return out
+
+
 @_guarded
 def rope_apply(x: torch.Tensor, n_outer, S, n_inner, H, d, max_len=512, inverse=False):
     h = _lib.load_library()

@@ -1,0 +1,139 @@
+"""Decoder prefill on the spliced embeddings through the HIP kernels (the step AFTER the path:
+`LlamaForCausalLM / Qwen3ForCausalLM.forward(inputs_embeds=...)`, /root/reference/src/model/language_model/u2llama.py:76-87,
+and the first forward of `generate`, u2llama.py:123-126).
+
+The decoder stays the stock HuggingFace module tree: its parameters (names, shapes, state dict), its KV cache and its
+`generate` loop are untouched.  `enable_fused_prefill(model)` replaces the `forward` of every decoder layer by one that,
+for the PREFILL call only (no grad, bf16 on the GPU, more than one position, empty cache for that layer, full attention, no
+padding), runs the layer as
+
+    RMSNorm -> ONE q|k|v GEMM -> per-head RMSNorm (Qwen3) + rotary embedding -> causal grouped-query attention
+    -> out-projection GEMM with the residual in its epilogue -> RMSNorm -> ONE gate|up GEMM -> SiLU(gate) * up
+    -> down-projection GEMM with the residual in its epilogue
+
+on the library's MFMA GEMMs (include/u2tok.h: u2tok_gemm_bf16), the fused attention kernel of tokattn.hip
+(u2tok_attention_gqa: grouped-query heads, causal mask, scores never in HBM) and the row kernels of decoder.hip.  Everything
+else -- decode steps, training, CPU tensors, sliding-window layers, padded batches -- takes the layer's original forward.
+q|k|v and gate|up are packed the way the tokenizer packs its projections: the nn.Parameters keep their names and shapes,
+their storage becomes a view of one buffer, so the stock modules keep working on them.
+"""
+from __future__ import annotations
+
+import types
+from typing import Optional
+
+import torch
+
+from . import ops
+
+
+def _pack(linears):
+    """Lay the weights (and biases, if any) of `linears` back to back in one buffer; returns (W, b | None)."""
+    ws = [lin.weight for lin in linears]
+    es = ws[0].element_size()
+    st0 = ws[0].untyped_storage()
+    adjacent = all(w.is_contiguous() and w.untyped_storage().data_ptr() == st0.data_ptr() for w in ws) and all(
+        ws[i + 1].data_ptr() == ws[i].data_ptr() + ws[i].numel() * es for i in range(len(ws) - 1))  # (one storage: neighbours
+    # in two allocations are not a packed buffer)
+    if not adjacent:
+        W = torch.cat([w.data for w in ws], 0).contiguous()
+        o = 0
+        for w in ws:
+            w.data = W[o:o + w.shape[0]]
+            o += w.shape[0]
+    W = ws[0].data.as_strided((sum(w.shape[0] for w in ws), ws[0].shape[1]), (ws[0].shape[1], 1))
+    b = None
+    if all(lin.bias is not None for lin in linears):
+        b = torch.cat([lin.bias.data for lin in linears], 0).contiguous()  # (biases are tiny: a copy, refreshed per call)
+    elif any(lin.bias is not None for lin in linears):
+        raise RuntimeError("mixed bias / no-bias projections cannot be packed")
+    return W, b
+
+
+def _layer_forward(self, hidden_states, *args, **kwargs):
+    st = self._u2_prefill
+    x = hidden_states
+    pe = kwargs.get("position_embeddings")
+    cache = kwargs.get("past_key_values")
+    att = self.self_attn
+    fused = (not args and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 3
+             and x.shape[1] > 1 and pe is not None and st["owner"]._u2_prefill_mask_ok
+             and getattr(att, "sliding_window", None) is None and att.head_dim in (64, 128)
+             and (cache is None or cache.get_seq_length(att.layer_idx) == 0))
+    if not fused:
+        return st["orig"](hidden_states, *args, **kwargs)
+    B, S, E = x.shape
+    rows = B * S
+    cfg = att.config
+    Hq, Hkv, d = cfg.num_attention_heads, cfg.num_key_value_heads, att.head_dim
+    with ops.on_device(x):
+        Wqkv, bqkv = _pack((att.q_proj, att.k_proj, att.v_proj))
+        Wgu, bgu = _pack((self.mlp.gate_proj, self.mlp.up_proj))
+        x2 = x.reshape(rows, E)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        cos, sin = pe
+        cos = cos.expand(B, S, d).reshape(rows, d)
+        sin = sin.expand(B, S, d).reshape(rows, d)
+        xn = ops.rmsnorm(x2, self.input_layernorm.weight, self.input_layernorm.variance_epsilon)
+        qkv = ops.gemm(xn, Wqkv, bias=bqkv)
+        qn, kn = getattr(att, "q_norm", None), getattr(att, "k_norm", None)
+        ops.qk_norm_rope(qkv, None if qn is None else qn.weight, None if kn is None else kn.weight, cos, sin, Hq, Hkv, d,
+                         qn.variance_epsilon if qn is not None else 1e-6)
+        q3 = qkv.view(B, S, -1)
+        k3, v3 = q3[..., Hq * d:(Hq + Hkv) * d], q3[..., (Hq + Hkv) * d:]
+        ctx = ops.attention_gqa(q3[..., :Hq * d], k3, v3, Hq, Hkv, float(att.scaling), causal=True)
+        h = ops.gemm(ctx.view(rows, Hq * d), att.o_proj.weight, bias=att.o_proj.bias, residual=x2)
+        hn = ops.rmsnorm(h, self.post_attention_layernorm.weight, self.post_attention_layernorm.variance_epsilon)
+        act = ops.swiglu(ops.gemm(hn, Wgu, bias=bgu))
+        out = ops.gemm(act, self.mlp.down_proj.weight, bias=self.mlp.down_proj.bias, residual=h)
+        if cache is not None:
+            # the cache keeps what it is handed: give it its own storage, in the (B, kv heads, S, d) layout HF uses
+            cache.update(k3.reshape(B, S, Hkv, d).transpose(1, 2).contiguous(),
+                         v3.reshape(B, S, Hkv, d).transpose(1, 2).contiguous(), att.layer_idx)
+    return out.view(B, S, E)
+
+
+def _mask_hook(module, args, kwargs):
+    """Forward pre-hook of the decoder stack: the fused layers assume no padding (the path's prompts are left-aligned and the
+    reference evaluates at batch 1, eval/mrg.py:74); a 2-D mask with zeros sends the whole call to the stock layers."""
+    m = kwargs.get("attention_mask")
+    ok = m is None or (torch.is_tensor(m) and m.dim() == 2 and bool(m.to(torch.bool).all()))
+    module._u2_prefill_mask_ok = ok
+    return None
+
+
+def enable_fused_prefill(model) -> int:
+    """Patch the decoder layers of an HF Llama / Qwen3 causal LM (u2LlamaForCausalLM / u2Qwen3ForCausalLM included) for the
+    fused prefill.  Idempotent; returns the number of layers patched.  `disable_fused_prefill` restores the stock forwards."""
+    base = model.get_model() if hasattr(model, "get_model") else getattr(model, "model", model)
+    layers = getattr(base, "layers", None)
+    if layers is None:
+        raise RuntimeError("enable_fused_prefill: no decoder layers found (expected an HF Llama / Qwen3 model)")
+    n = 0
+    for layer in layers:
+        if hasattr(layer, "_u2_prefill"):
+            continue
+        needed = all(hasattr(layer, a) for a in ("self_attn", "mlp", "input_layernorm", "post_attention_layernorm")) and \
+            all(hasattr(layer.self_attn, a) for a in ("q_proj", "k_proj", "v_proj", "o_proj", "head_dim", "scaling")) and \
+            all(hasattr(layer.mlp, a) for a in ("gate_proj", "up_proj", "down_proj"))
+        if not needed:
+            raise RuntimeError(f"enable_fused_prefill: unsupported decoder layer {type(layer).__name__}")
+        layer._u2_prefill = {"orig": layer.forward, "owner": base}
+        layer.forward = types.MethodType(_layer_forward, layer)
+        n += 1
+    if not hasattr(base, "_u2_prefill_hook"):
+        base._u2_prefill_mask_ok = True
+        base._u2_prefill_hook = base.register_forward_pre_hook(_mask_hook, with_kwargs=True)
+    return n
+
+
+def disable_fused_prefill(model) -> None:
+    base = model.get_model() if hasattr(model, "get_model") else getattr(model, "model", model)
+    for layer in base.layers:
+        st = layer.__dict__.pop("_u2_prefill", None)
+        if st is not None:
+            layer.forward = st["orig"]
+    hook = base.__dict__.pop("_u2_prefill_hook", None)
+    if hook is not None:
+        hook.remove()
