@@ -53,6 +53,12 @@ for _ in range(n):
     out = m(inputs_embeds=x, use_cache=True)
 torch.cuda.synchronize()
 ms2 = (time.perf_counter() - t0) / n * 1e3
+t0 = time.perf_counter()
+for _ in range(n):
+    m(inputs_embeds=x, use_cache=True, logits_to_keep=1)     # what generate() asks of its prefill: the last position's logits
+torch.cuda.synchronize()
+ms3 = (time.perf_counter() - t0) / n * 1e3
+print(f"HIP layers with logits_to_keep=1 (generate's prefill): {ms3:.2f} ms")
 d = (out.logits[:, -1].float() - ref)
 print(f"same through u2tokenizer_amd.prefill (HIP layers): {ms2:.2f} ms ({flop / ms2 / 1e9:.0f} TFLOP/s), x{ms / ms2:.2f}; "
       f"last-position logits vs stock: rel rms {(d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item():.3e}")

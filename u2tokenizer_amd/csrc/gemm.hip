@@ -549,13 +549,16 @@ int gemm_classic(GemmDesc d, hipStream_t stream) {
     const int64_t wgs = cdiv(d.M, tile) * cdiv(d.N, tile) * d.nz;
     const int nkt = (int)cdiv(d.K, 64);
     int s = o.gemm_splitk > 1 ? o.gemm_splitk : 0;
+    // (128 x 128 tiles: two workgroups per CU are resident -> aim at 512; the decoder prefill's M = 1024 out / down
+    //  projections are 256 tiles with K = 4096 / 12288: one K loop per CU with nothing to overlap it otherwise)
     if (s == 0 && d.nz == 1 && (wgs <= 320 || longk) && nkt >= 16)
-      s = (int)std::min<int64_t>(8, std::min<int64_t>(nkt / 4, cdiv(longk ? 640 : 1024, wgs)));
+      s = (int)std::min<int64_t>(8, std::min<int64_t>(nkt / 4, cdiv(longk ? 640 : (tile == 128 ? 512 : 1024), wgs)));
     if (s > 1) {
       const Scratch sc = ctx().scratch_of(stream);
       const size_t slice = (size_t)d.nz * d.M * d.N * sizeof(float);
       // partial sums cost HBM traffic: capped at 24 MB unless the K loop is long enough to dwarf it
-      if (o.gemm_splitk <= 1) s = (int)std::min<size_t>(s, (longk ? sc.bytes : std::min<size_t>(sc.bytes, 24u << 20)) / slice);
+      if (o.gemm_splitk <= 1)
+        s = (int)std::min<size_t>(s, (longk ? sc.bytes : std::min<size_t>(sc.bytes, (tile == 128 ? 40u : 24u) << 20)) / slice);
       const size_t need = (size_t)s * slice;
       if (s > 1 && sc.p && need <= sc.bytes && d.nz <= 65535) {
         d.ksplit = s;

@@ -69,7 +69,9 @@ __global__ __launch_bounds__(256, DH >= 512 ? 1 : 2) void tok_attn_kernel(const 
     ts[i_] += t_ - tprev;                                       \
     tprev = t_;                                                 \
   }
-  constexpr int BK = 32;              // keys per tile
+  constexpr int BK = DH <= 128 ? 64 : 32;  // keys per tile (narrow heads: twice the keys per barrier / DMA wait / softmax step)
+  constexpr int NKB = BK / 16;        // 16-key blocks of S^T per tile
+  constexpr int NPF = BK / 32;        // P fragments (32 keys = one MFMA k step of P V) per tile
   constexpr int CPR = DH / 8;         // 16-byte chunks per tile row
   constexpr int ROWB = DH * 2;        // bytes per tile row
   constexpr int TILE = BK * ROWB;     // bytes per K (or V) tile
@@ -95,7 +97,8 @@ __global__ __launch_bounds__(256, DH >= 512 ? 1 : 2) void tok_attn_kernel(const 
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
   }
-  const int qblk = bid % a.nqb;
+  // causal: the LAST query block of a head has the longest key range -- hand those out first
+  const int qblk = a.causal ? a.nqb - 1 - bid % a.nqb : bid % a.nqb;
   const int sp = (bid / a.nqb) % a.ns;
   const int bh = bid / (a.nqb * a.ns);
   const int b = bh / a.H, h = bh - b * a.H;
@@ -192,28 +195,26 @@ __global__ __launch_bounds__(256, DH >= 512 ? 1 : 2) void tok_attn_kernel(const 
     U2_STAMP(1)  // barrier
     if (kt + 1 < kt1) dma_k(kt + 1, stage ^ 1);
     U2_STAMP(2)  // K DMA issue
-    // ---- S^T = K Q^T, two 16-key blocks.  Four independent accumulator chains (2 key blocks x even / odd k steps): a
-    // dependent v_mfma_f32_16x16x32 chain issues at its ~8-pass latency, not at the pipe rate
-    f32x4 sc[2];
+    // ---- S^T = K Q^T, NKB 16-key blocks.  Independent accumulator chains (key blocks x even / odd k steps): a dependent
+    // v_mfma_f32_16x16x32 chain issues at its ~8-pass latency, not at the pipe rate
+    f32x4 sc[NKB];
     {
-      // software pipeline: the fragment of step i + PD is requested before the MFMA of step i is issued (the compiler
-      // barriers keep hipcc from clustering all reads in front of all MFMAs, which exposes the LDS latency once per phase
-      // AND from serialising read -> wait -> MFMA; the in-flight fragments live in the registers the one-wave-per-SIMD
-      // configuration has to spare)
-      constexpr int NQK = 2 * KS, PD = NQK < 8 ? NQK : 8;
-      f32x4 acc[2][2];
+      // software pipeline: PD fragment reads ahead, then one read per MFMA (sched_group_barrier below: hipcc otherwise
+      // either clusters all reads in front of all MFMAs or serialises read -> wait -> MFMA)
+      constexpr int NQK = NKB * KS, PD = NQK < 8 ? NQK : 8;
+      f32x4 acc[NKB][2];
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) acc[kb][0] = acc[kb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int kb = 0; kb < NKB; ++kb) acc[kb][0] = acc[kb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
       bf16x8 kf[NQK];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < NQK; ++i)  // step i = (ks = i >> 1, kb = i & 1)
-        kf[i] = *reinterpret_cast<const bf16x8*>(tK + (i & 1) * 16 * ROWB + k_row_off + ((((i >> 1) * 4 + g) ^ k_swz) << 4));
+      for (int i = 0; i < NQK; ++i)  // step i = (ks = i / NKB, kb = i % NKB)
+        kf[i] = *reinterpret_cast<const bf16x8*>(tK + (i % NKB) * 16 * ROWB + k_row_off + ((((i / NKB) * 4 + g) ^ k_swz) << 4));
 #pragma unroll
       for (int i = 0; i < NQK; ++i)
-        acc[i & 1][(i >> 1) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i], qf[i >> 1], acc[i & 1][(i >> 1) & 1], 0, 0, 0);
-      // schedule: PD fragment reads ahead, then one read per MFMA (sched_group_barrier: 0x100 = DS read, 0x008 = MFMA)
-      __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);
+        acc[i % NKB][(i / NKB) & 1] =
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i], qf[i / NKB], acc[i % NKB][(i / NKB) & 1], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);  // 0x100 = DS read, 0x008 = MFMA
 #pragma unroll
       for (int i = 0; i < NQK; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -221,36 +222,42 @@ __global__ __launch_bounds__(256, DH >= 512 ? 1 : 2) void tok_attn_kernel(const 
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) sc[kb] = KS > 1 ? acc[kb][0] + acc[kb][1] : acc[kb][0];
+      for (int kb = 0; kb < NKB; ++kb) sc[kb] = KS > 1 ? acc[kb][0] + acc[kb][1] : acc[kb][0];
     }
-    if constexpr (TIMED) asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
+    if constexpr (TIMED) {
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) asm volatile("" : "+v"(sc[kb]));
+    }
     U2_STAMP(3)  // Q K^T
     // ---- online softmax: lane owns keys kt * 32 + 16 kb + 4 g + r of query row qrow
     // (one wave per SIMD issues a VALU instruction every 5-9 cycles: the instruction count of this block is its cost.
     //  Without bias the scale is folded into the exponent's FMA and the row max is taken on the raw scores -- scale > 0
     //  commutes with max; key masking only in a partial last tile.)
-    float x[8];
+    constexpr int NX = 4 * NKB;  // scores per lane: x[i] = key kt * BK + 16 (i >> 2) + 4 g + (i & 3)
+    float x[NX];
     if (has_bias) {
-      float bb[8];
+      float bb[NX];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) bb[i] = sbias[(kt * BK - kbeg) + (i >> 2) * 16 + 4 * g + (i & 3) + bias_q];
+      for (int i = 0; i < NX; ++i) bb[i] = sbias[(kt * BK - kbeg) + (i >> 2) * 16 + 4 * g + (i & 3) + bias_q];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) x[i] = __builtin_fmaf(sc[i >> 2][i & 3], c_scale, bb[i]);
+      for (int i = 0; i < NX; ++i) x[i] = __builtin_fmaf(sc[i >> 2][i & 3], c_scale, bb[i]);
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) x[i] = sc[i >> 2][i & 3];
+      for (int i = 0; i < NX; ++i) x[i] = sc[i >> 2][i & 3];
     }
     if (kt == ntile_all - 1 && (Skv & (BK - 1))) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < NX; ++i)
         if (kt * BK + (i >> 2) * 16 + 4 * g + (i & 3) >= Skv) x[i] = -INFINITY;
     }
     if (a.causal && kt * BK + BK - 1 > q0 + 16 * w + c_off) {  // (wave-uniform) the tile reaches past this wave's diagonal
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < NX; ++i)
         if (kt * BK + (i >> 2) * 16 + 4 * g + (i & 3) > qrow + c_off) x[i] = -INFINITY;
     }
-    float mt = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7])));
+    float mt = x[0];
+#pragma unroll
+    for (int i = 1; i < NX; ++i) mt = fmaxf(mt, x[i]);
     mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float xs = has_bias ? 1.0f : c_scale;  // what is left to multiply into x
@@ -267,42 +274,50 @@ __global__ __launch_bounds__(256, DH >= 512 ? 1 : 2) void tok_attn_kernel(const 
     }
     float ps = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NX; ++i) {
       x[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[i], xs, -m_run));
       ps += x[i];
     }
     l_run += ps;
-    union { bf16x8 v; uint32_t u[4]; } pf;
-    pf.u[0] = pack2_bf16(x[0], x[1]);
-    pf.u[1] = pack2_bf16(x[2], x[3]);
-    pf.u[2] = pack2_bf16(x[4], x[5]);
-    pf.u[3] = pack2_bf16(x[6], x[7]);
+    // P fragment j = keys 32 j .. 32 j + 31 of the tile: k-slot (g, e) carries key 32 j + 16 (e >> 2) + 4 g + (e & 3)
+    union { bf16x8 v; uint32_t u[4]; } pf[NPF];
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+      pf[j].u[0] = pack2_bf16(x[8 * j + 0], x[8 * j + 1]);
+      pf[j].u[1] = pack2_bf16(x[8 * j + 2], x[8 * j + 3]);
+      pf[j].u[2] = pack2_bf16(x[8 * j + 4], x[8 * j + 5]);
+      pf[j].u[3] = pack2_bf16(x[8 * j + 6], x[8 * j + 7]);
+    }
 
-    if constexpr (TIMED) asm volatile("" : "+v"(pf.v));
+    if constexpr (TIMED) {
+#pragma unroll
+      for (int j = 0; j < NPF; ++j) asm volatile("" : "+v"(pf[j].v));
+    }
     U2_STAMP(4)  // softmax
     if (kt + 1 < kt1) dma_v(kt + 1, stage ^ 1);
     U2_STAMP(5)  // V DMA issue
     // ---- O^T += V^T P^T (same software pipeline over the d blocks)
     {
-      constexpr int PD = DB < 6 ? DB : 6;
-      bf16x8 vf[DB];
+      constexpr int NPV = NPF * DB, PD = NPV < 6 ? NPV : 6;  // step i = (P fragment j = i / DB, d block db = i % DB)
+      bf16x8 vf[NPV];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int db = 0; db < DB; ++db) {
-        const int cc = 2 * db + v_cc;
+      for (int i = 0; i < NPV; ++i) {
+        const int cc = 2 * (i % DB) + v_cc;
         const int cp = (cc & ~(SEG - 1)) | (((cc & (SEG - 1)) + v_rot) & (SEG - 1));
-        const char* p = tV + v_base_off + cp * 16;
+        const char* p = tV + (i / DB) * 32 * ROWB + v_base_off + cp * 16;
         const ta_v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)p);
         const ta_v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p + 16 * ROWB));
-        vf[db] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        vf[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
 #pragma unroll
-      for (int db = 0; db < DB; ++db) o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[db], pf.v, o[db], 0, 0, 0);
+      for (int i = 0; i < NPV; ++i)
+        o[i % DB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[i], pf[i / DB].v, o[i % DB], 0, 0, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * PD, 0);
 #pragma unroll
-      for (int db = 0; db < DB; ++db) {
+      for (int i = 0; i < NPV; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (db + PD < DB) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        if (i + PD < NPV) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -371,10 +386,12 @@ __global__ __launch_bounds__(256) void tok_attn_combine_kernel(const TokAttnArgs
       uint2{pack2_bf16(acc[0] * inv, acc[1] * inv), pack2_bf16(acc[2] * inv, acc[3] * inv)};
 }
 
+static inline int tok_attn_bk(int d) { return d <= 128 ? 64 : 32; }  // keys per tile (tok_attn_kernel: BK)
+
 // ns for a call: enough workgroups to cover the 256 CUs, at least two tiles per split, partial sums within the scratch.
 static int tok_attn_pick_splits(int nb, int H, int Sq, int Skv, int d, size_t ws_bytes) {
   const int64_t base = (int64_t)nb * H * cdiv(Sq, 64);
-  const int ntile = (int)cdiv(Skv, 32);
+  const int ntile = (int)cdiv(Skv, tok_attn_bk(d));
   if (base >= 192 || ntile < 4) return 1;
   int ns = (int)std::min<int64_t>(cdiv(256, base), ntile / 2);
   const size_t per = (size_t)nb * Sq * ((size_t)H * d * 4 + (size_t)H * 8);
@@ -391,7 +408,7 @@ int tok_attention_set_debug_buffer(void* p) {
 
 size_t tok_attention_workspace_bytes(int nb, int H, int Sq, int Skv, int d) {
   const int64_t base = (int64_t)nb * H * cdiv(Sq, 64);
-  const int ntile = (int)cdiv(Skv, 32);
+  const int ntile = (int)cdiv(Skv, tok_attn_bk(d));
   if (base >= 192 || ntile < 4) return 0;
   const int ns = (int)std::min<int64_t>(cdiv(256, base), ntile / 2);
   return (size_t)ns * nb * Sq * ((size_t)H * d * 4 + (size_t)H * 8);
@@ -404,7 +421,7 @@ bool tok_attention_supported(const bf16_t* q, const bf16_t* k, const bf16_t* v, 
   if ((ldq | ldk | ldv | q_bs | k_bs | v_bs) & 7) return false;
   if ((ldo | o_bs) & 3) return false;
   if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) || ((uintptr_t)out & 7)) return false;
-  if (rel_bias && (Sq > max_len || Skv > max_len || (int)cdiv(Skv, 32) * 32 + 63 > TOKATTN_BIAS_SLOTS)) return false;
+  if (rel_bias && (Sq > max_len || Skv > max_len || (int)cdiv(Skv, 64) * 64 + 63 > TOKATTN_BIAS_SLOTS)) return false;
   return true;
 }
 
@@ -430,7 +447,7 @@ int attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out,
   a.nb = nb; a.H = H; a.Sq = Sq; a.Skv = Skv; a.nqb = (int)cdiv(Sq, 64);
   a.scale_log2e = scale * 1.44269504088896340736f;
   a.rel_bias = rel_bias; a.max_len = max_len;
-  const int ntile = (int)cdiv(Skv, 32);
+  const int ntile = (int)cdiv(Skv, tok_attn_bk(d));
   a.kv_group = H / Hkv;
   a.causal = causal ? 1 : 0;
   int ns = force_splits > 0 ? std::min(force_splits, ntile) : tok_attn_pick_splits(nb, H, Sq, Skv, d, ws ? ws_bytes : 0);
@@ -454,7 +471,7 @@ int attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out,
   a.dbg = g_tokattn_dbg;
 #define U2_TA(D_)                                                                                                      \
   do {                                                                                                                 \
-    constexpr size_t smem_ = 4 * 32 * (D_) * 2 + TOKATTN_BIAS_SLOTS * 4;                                               \
+    constexpr size_t smem_ = 4 * ((D_) <= 128 ? 64 : 32) * (D_) * 2 + TOKATTN_BIAS_SLOTS * 4;                                               \
     if (a.dbg) hipLaunchKernelGGL((tok_attn_kernel<D_, true>), dim3((unsigned)grid), dim3(256), smem_, stream, a);    \
     else hipLaunchKernelGGL((tok_attn_kernel<D_, false>), dim3((unsigned)grid), dim3(256), smem_, stream, a);         \
   } while (0)

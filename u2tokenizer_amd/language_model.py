@@ -46,6 +46,18 @@ class _u2CausalLMMixin(u2MetaForCausalLM):
     def get_model(self):
         return self.model
 
+    def _maybe_fuse_prefill(self) -> None:
+        """The prefill of the spliced embeddings through the HIP decoder layers (u2tokenizer_amd/prefill.py)
+        unless `config.u2_fused_prefill` is False: patched once, when the decoder sits on the GPU in bf16.  Training,
+        decode steps, padded batches and CPU runs keep the stock HuggingFace layers."""
+        if getattr(self, "_u2_prefill_checked", False) or not getattr(self.config, "u2_fused_prefill", True):
+            return
+        p = next(self.model.layers[0].parameters(), None) if len(self.model.layers) else None
+        if p is not None and p.is_cuda and p.dtype == torch.bfloat16:
+            from .prefill import enable_fused_prefill
+            enable_fused_prefill(self)
+            self._u2_prefill_checked = True
+
     def forward(self, images: Optional[torch.FloatTensor] = None, input_ids: torch.LongTensor = None,
                 labels: Optional[torch.LongTensor] = None, attention_mask: Optional[torch.Tensor] = None,
                 question_ids: Optional[torch.LongTensor] = None, position_ids: Optional[torch.LongTensor] = None,
@@ -56,6 +68,8 @@ class _u2CausalLMMixin(u2MetaForCausalLM):
         # aliases used by the in-tree Qwen3 variant (u2qwen3.py:42-47)
         images = kwargs.pop("vision_input", images)
         question_ids = kwargs.pop("raw_question_ids", question_ids)
+        if not torch.is_grad_enabled():
+            self._maybe_fuse_prefill()
         if inputs_embeds is None:
             (input_ids, position_ids, attention_mask, past_key_values, inputs_embeds, labels) = \
                 self.prepare_inputs_for_multimodal(input_ids, position_ids, attention_mask, past_key_values, labels,

@@ -50,6 +50,20 @@ def _pack(linears):
     return W, b
 
 
+_scratch = {}
+
+
+def _ensure_gemm_scratch(device) -> None:
+    """Split-K scratch of the calling stream (the M = 1024 out / down projections are 256 tiles of 128 x 128: cut in two along
+    K they put two workgroups on every CU), registered on the active context like the training path's."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, id(ops.active_context(device)))
+    if key not in _scratch:
+        buf = torch.empty(40 << 20, dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            ops.set_gemm_scratch(buf)
+        _scratch[key] = buf
+
+
 def _layer_forward(self, hidden_states, *args, **kwargs):
     st = self._u2_prefill
     x = hidden_states
@@ -66,6 +80,7 @@ def _layer_forward(self, hidden_states, *args, **kwargs):
     rows = B * S
     cfg = att.config
     Hq, Hkv, d = cfg.num_attention_heads, cfg.num_key_value_heads, att.head_dim
+    _ensure_gemm_scratch(x.device)
     with ops.on_device(x):
         Wqkv, bqkv = _pack((att.q_proj, att.k_proj, att.v_proj))
         Wgu, bgu = _pack((self.mlp.gate_proj, self.mlp.up_proj))
@@ -88,9 +103,9 @@ def _layer_forward(self, hidden_states, *args, **kwargs):
         act = ops.swiglu(ops.gemm(hn, Wgu, bias=bgu))
         out = ops.gemm(act, self.mlp.down_proj.weight, bias=self.mlp.down_proj.bias, residual=h)
         if cache is not None:
-            # the cache keeps what it is handed: give it its own storage, in the (B, kv heads, S, d) layout HF uses
-            cache.update(k3.reshape(B, S, Hkv, d).transpose(1, 2).contiguous(),
-                         v3.reshape(B, S, Hkv, d).transpose(1, 2).contiguous(), att.layer_idx)
+            # (B, kv heads, S, d) VIEWS of the packed projection: every HF cache layer copies what it is handed into storage of
+            # its own (DynamicLayer: torch.cat with its empty tensors; static layers: index_copy_), so no copy is made here
+            cache.update(k3.unflatten(-1, (Hkv, d)).transpose(1, 2), v3.unflatten(-1, (Hkv, d)).transpose(1, 2), att.layer_idx)
     return out.view(B, S, E)
 
 
