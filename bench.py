@@ -203,9 +203,10 @@ def cpu_baseline(E, Lt, iters=3, sample_chunks=1):
 
 # ---------------------------------------------------------------------------------------------------- HBM traffic (PMC)
 PMC_CLASSES = [("gemm_bf16_nt_kernel", "gemm_bf16"), ("gemm_bt_kernel", "gemm_bf16"), ("gemm_splitk", "gemm_bf16"),
-               ("flash_", "flash_d64"), ("tok_attn", "tok_attention")]
+               ("gemm_rows16", "gemm_bf16"), ("flash_", "flash_d64"), ("tok_attn", "tok_attention")]
 # kernel name fragment -> class of the per-kernel table (order matters: first match)
 KERNEL_CLASSES = [("gemm_bf16_nt_kernel", "gemm_bf16"), ("gemm_bt_kernel", "gemm_bf16"), ("gemm_splitk", "gemm_bf16"),
+                  ("gemm_rows16", "gemm_bf16"),
                   ("flash_", "flash_d64"), ("tok_attn", "tok_attention"), ("temporal_attention", "temporal_attention"),
                   ("layernorm", "row_ops"), ("softmax", "row_ops"), ("rope", "row_ops"), ("score_gemv", "row_ops"),
                   ("topk", "row_ops"), ("multiscale_pool", "row_ops"), ("dmtp_gate", "row_ops"), ("avgpool3d", "row_ops"),
@@ -515,7 +516,7 @@ def main():
         ms, flops, byts, cnt = (C.c_double * 6)(), (C.c_double * 6)(), (C.c_double * 6)(), (C.c_int64 * 6)()
         _lib.check(h.u2tok_profile_collect2(ms, flops, byts, cnt, 6), "u2tok_profile_collect2")
         ops.set_option("profile", 0)
-        names = ["gemm_bf16 (gemm_bt_kernel + gemm_bf16_nt_kernel + gemm_splitk_reduce_kernel)",
+        names = ["gemm_bf16 (gemm_bt_kernel + gemm_bf16_nt_kernel + gemm_rows16_kernel + gemm_splitk_reduce_kernel)",
                  "flash_d64 (flash_dp_kernel)", "temporal_attention_kernel", "row_ops", "data_movement",
                  "tok_attention (tok_attn_kernel + tok_attn_combine_kernel)"]
         # per class: time, launches, algorithmic TFLOP/s and algorithmic GB/s (operands + results once) of its launches
@@ -570,8 +571,10 @@ def main():
                             for k, v in sorted(kt_ms.items(), key=lambda kv: -kv[1])},
                 "sum_ms_per_volume": round(total_ms, 4), "one_stream_wall_ms_per_volume": round(wall_ms, 4),
                 # kernels of one volume on one stream cannot add up to more than its wall time, except for what the tokenizer's
-                # side stream overlaps (TTA k|v projections) -- a sanity check on the bookkeeping, reported, not enforced
-                "sum_le_wall": bool(total_ms <= 1.03 * wall_ms)}
+                # side stream overlaps: the 9 k|v / key projections of the TTA (~1.0 ms of GEMM time per volume) run beside the
+                # query chain in the one-stream run -- the bookkeeping check allows for exactly that
+                "side_stream_overlap_ms_allowed": 1.2,
+                "sum_le_wall": bool(total_ms <= 1.03 * wall_ms + 1.2)}
 
         def roof(idx, key, kernel):
             ach_ev = flops[idx] / ms[idx] / 1e9
