@@ -126,3 +126,34 @@ def test_packed_weight_alias_is_a_view_and_routes_gradients():
         assert torch.equal(AG._cat_rows(parts).detach()[4:8], parts[1].detach())
     finally:
         torch.set_grad_enabled(prev)
+
+
+def test_fused_prefill_patch_is_inert_off_the_gpu_and_packs_losslessly():
+    """u2tokenizer_amd/prefill.py on the host: patched decoder layers take their stock forward (CPU tensors), packing q|k|v and
+    gate|up into one buffer keeps every parameter's value / name / shape (the stock modules keep working on the views), and
+    disable_fused_prefill restores the original methods."""
+    from transformers import Qwen3Config, Qwen3ForCausalLM
+    from u2tokenizer_amd import prefill as P
+    torch.manual_seed(0)
+    cfg = Qwen3Config(vocab_size=128, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                      num_key_value_heads=1, head_dim=64, max_position_embeddings=64)
+    m = Qwen3ForCausalLM(cfg).eval()
+    x = torch.randn(1, 9, 128)
+    with torch.no_grad():
+        ref = m(inputs_embeds=x).logits
+        assert P.enable_fused_prefill(m) == 2 and P.enable_fused_prefill(m) == 0      # idempotent
+        assert torch.equal(m(inputs_embeds=x).logits, ref)                            # CPU: the stock layers ran
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        att = m.model.layers[0].self_attn
+        W, b = P._pack((att.q_proj, att.k_proj, att.v_proj))
+        assert b is None and W.shape == (128 + 64 + 64, 128)
+        assert att.k_proj.weight.data_ptr() == att.q_proj.weight.data_ptr() + att.q_proj.weight.numel() * 4
+        assert torch.equal(W[:128], sd["model.layers.0.self_attn.q_proj.weight"])
+        assert torch.equal(W[192:], sd["model.layers.0.self_attn.v_proj.weight"])
+        W2, _ = P._pack((att.q_proj, att.k_proj, att.v_proj))                         # already packed: the same buffer
+        assert W2.data_ptr() == W.data_ptr()
+        for k, v in m.state_dict().items():
+            assert torch.equal(v, sd[k]), k
+        assert torch.equal(m(inputs_embeds=x).logits, ref)
+        P.disable_fused_prefill(m)
+        assert not hasattr(m.model.layers[0], "_u2_prefill") and torch.equal(m(inputs_embeds=x).logits, ref)
