@@ -231,7 +231,11 @@ int u2tok_preprocess_volume_aug(const float* vol, void* out, int32_t* info, int3
  * flags: 1 bias[n], 2 bias[m], 4 GELU(erf), 8 + R[m][n], 16 C is fp32 (else bf16), 64 B is K-tile-major [K/64][N][64],
  * 256 B is stored K-major, (K,N) with ldb >= N (C = A B: the input-gradient product dX = dY W without a transposed W),
  * 128 | 256 A is stored K-major too, (K,M) with lda >= M (C = A^T B: the weight-gradient product dW = dY^T X without
- * transposed activations); the K-major dimension (M resp. N) must be a multiple of 8. */
+ * transposed activations); the K-major dimension (M resp. N) must be a multiple of 8.
+ * 512: gate | up pair product of a gated MLP (LlamaMLP / Qwen3MLP: act_fn(gate_proj(x)) * up_proj(x)): B = the gate weight's
+ * I rows followed by the up weight's I rows (N = 2 I), C (M, I) bf16 = bf16(silu(bf16(x gate^T))) * bf16(x up^T) -- the values
+ * u2tok_gemm_bf16 + u2tok_swiglu_bf16 produce, bit for bit, without the (M, 2 I) intermediate; alone (no other flag, nz = 1),
+ * K % 64 == 0, I % 16 == 0, 16-byte aligned operands; U2TOK_ERR_ARG otherwise. */
 int u2tok_gemm_bf16(const void* A, const void* B, void* C, const void* bias, const void* R, int32_t M, int32_t N,
                     int32_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int32_t nz, int32_t nbh,
                     int64_t sAb, int64_t sAh, int64_t sBb, int64_t sBh, int64_t sCb, int64_t sCh, int64_t sRb,
@@ -307,6 +311,12 @@ int u2tok_rmsnorm_bf16(const void* x, const void* w, void* y, int64_t rows, int3
 int u2tok_qk_norm_rope(void* qkv, const void* wq, const void* wk, const void* cos, const void* sin, int32_t cos_sin_f32,
                        int64_t rows, int32_t Hq, int32_t Hkv, int32_t D, int64_t ld, int64_t cs_ld, float eps,
                        u2tok_stream_t stream);
+/* The same, and the finished k heads and the v heads also written in the KV cache's layout: k_cache / v_cache
+ * [rows / S][Hkv][S][D] dense bf16 (HF DynamicLayer: (batch, kv heads, seq, head_dim); row = batch * S + position), so the
+ * prefill hands the cache its tensors without a transposing copy (language_model/u2llama.py:123-126: generate()). */
+int u2tok_qk_norm_rope_kv(void* qkv, const void* wq, const void* wk, const void* cos, const void* sin, int32_t cos_sin_f32,
+                          int64_t rows, int32_t Hq, int32_t Hkv, int32_t D, int64_t ld, int64_t cs_ld, float eps,
+                          void* k_cache, void* v_cache, int32_t S, u2tok_stream_t stream);
 /* out[r][i] = bf16(silu(gate_up[r][i])) * gate_up[r][I + i]   (LlamaMLP / Qwen3MLP with gate | up packed); I % 8 == 0 */
 int u2tok_swiglu_bf16(const void* gate_up, void* out, int64_t rows, int32_t I, int64_t ld_in, int64_t ld_out,
                       u2tok_stream_t stream);

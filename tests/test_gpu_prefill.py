@@ -69,12 +69,38 @@ def test_qk_norm_rope(ops, rows, Hq, Hkv, d, norm, f32):
     ops.qk_norm_rope(got, wq.to(D) if norm else None, wk.to(D) if norm else None, cos.to(D), sin.to(D), Hq, Hkv, d, 1e-6)
     close_bf16(got, ref.reshape(rows, -1))
     assert torch.equal(got[:, (Hq + Hkv) * d:].cpu(), qkv[:, (Hq + Hkv) * d:])
+    # the KV-cache form: the same values in place, and keys / values once more as dense (batch, kv heads, S, d) tensors
+    for S in {rows, rows // 3 if rows % 3 == 0 else rows}:
+        got2 = qkv.to(D)
+        r = ops.qk_norm_rope(got2, wq.to(D) if norm else None, wk.to(D) if norm else None, cos.to(D), sin.to(D), Hq, Hkv, d,
+                             1e-6, kv_cache_seq=S)
+        assert torch.equal(r[0], got)
+        g4 = got.view(rows // S, S, Hq + 2 * Hkv, d)
+        assert r[1].is_contiguous() and r[1].shape == (rows // S, Hkv, S, d)
+        assert torch.equal(r[1], g4[:, :, Hq:Hq + Hkv].transpose(1, 2))
+        assert torch.equal(r[2], g4[:, :, Hq + Hkv:].transpose(1, 2))
 
 
 def test_swiglu(ops):
     gu = rnd(300, 2 * 1536, scale=2.0, seed=6)
     g, u = gu[:, :1536].float(), gu[:, 1536:].float()
     close_bf16(ops.swiglu(gu.to(D)), F.silu(g).to(bf).float() * u)
+
+
+@pytest.mark.parametrize("rows,K,I", [(1024, 4096, 12288), (300, 512, 1536), (257, 128, 1040), (7, 192, 16), (640, 1024, 96)])
+def test_gemm_swiglu_pair_equals_the_two_step_form(ops, rows, K, I):
+    """u2tok_gemm_bf16 flag 512: SiLU(gate) * up in the epilogue of the packed gate | up product -- bit for bit the values of the
+    GEMM followed by u2tok_swiglu_bf16 (same accumulation order, same rounding points), tiles that straddle M and I included."""
+    x = rnd(rows, K, seed=11).to(D)
+    w = rnd(2 * I, K, scale=2.0 / math.sqrt(K), seed=12).to(D)
+    assert ops.gemm_swiglu_supported(rows, K, I)
+    two = ops.swiglu(ops.gemm(x, w))
+    one = ops.gemm_swiglu(x, w)
+    assert one.shape == two.shape == (rows, I)
+    assert torch.equal(one, two), (one.float() - two.float()).abs().max()
+    g, u = (x.float() @ w[:I].float().T).to(bf).float(), (x.float() @ w[I:].float().T).to(bf).float()
+    close_bf16(one, (F.silu(g).to(bf).float() * u).cpu(), rounds=4)
+    assert not ops.gemm_swiglu_supported(rows, K + 8, I) and not ops.gemm_swiglu_supported(rows, K, I + 8)
 
 
 @pytest.mark.parametrize("nb,Sq,Skv,Hq,Hkv,d", [(1, 1024, 1024, 32, 8, 128), (2, 77, 77, 8, 4, 64), (1, 50, 50, 4, 4, 128),

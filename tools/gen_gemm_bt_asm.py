@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generates u2tokenizer_amd/csrc/gemm_bt_asm.inc: the K loop of the 256 x (64 NJ) x 64 "big tile" bf16 GEMM
-(gemm_bt.hip, gemm_bt_kernel<NJ>, NJ = 4 or 3) as ONE inline-asm block for gfx950.
+(gemm_bt.hip, gemm_bt_kernel<NJ, PAIR>, NJ = 4 or 3; NJ = 3 also in the SwiGLU-pair form) as ONE inline-asm block for gfx950.
 
 One workgroup = 4 waves (2 x 2), one wave per SIMD, each wave a 128 x (32 NJ) output tile = 4 x NJ accumulators of
 v_mfma_f32_32x32x16_bf16 in AccVGPRs (asm operands "+a": the compiler zeroes them before and runs the epilogue after).
@@ -120,7 +120,7 @@ def mfma_block(b, extra):
         extra(slot)
 
 
-def gen(nj):
+def gen(nj, pair=False):
     """All four waves run the same MFMA / read / barrier skeleton, but each has its own copy of the loop with its
     LDS-DMA pieces in different slots: issued in the same slot by all four (lock-step) waves, the pieces queue behind
     one another in the CU's single address path and every one of them blocks its wave for ~130 cycles with the
@@ -154,10 +154,17 @@ def gen(nj):
     e(f"v_mov_b32 {v(AA[0])}, %[aa0]")
     e(f"v_mov_b32 {v(AB[0])}, %[ab0]")
     e(f"s_mov_b32 {s(S_ROWA[0])}, 0")
-    e(f"s_mov_b32 {s(S_ROWB[0])}, 0")
     for q in (1, 2, 3):
         e(f"s_add_u32 {s(S_ROWA[q])}, {s(S_ROWA[q - 1])}, %[lda16]")
-        e(f"s_add_u32 {s(S_ROWB[q])}, {s(S_ROWB[q - 1])}, %[ldb16]")
+    if pair:
+        # SwiGLU-pair form (gemm_bt.hip): the wave's 16-row groups of the B tile alternate between gate rows and up rows of
+        # the weight -- their byte offsets (relative to the tile origin) are operands instead of q * 16 ldb
+        for q in range((npb + 1) // 2):
+            e(f"s_mov_b32 {s(S_ROWB[q])}, %[rowb{q}]")
+    else:
+        e(f"s_mov_b32 {s(S_ROWB[0])}, 0")
+        for q in (1, 2, 3):
+            e(f"s_add_u32 {s(S_ROWB[q])}, {s(S_ROWB[q - 1])}, %[ldb16]")
     e(f"s_mov_b32 {s(S_KT)}, 0")
     e(f"s_lshl_b32 {s(S_DA)}, %[wave], 13")                       # 64 rows x 128 B per wave
     e(f"s_mul_i32 {s(S_DB)}, %[wave], {2048 * NJ}")               # 16 NJ rows per wave
@@ -261,11 +268,11 @@ def gen(nj):
 
 print("// GENERATED by tools/gen_gemm_bt_asm.py -- do not edit")
 print("// clang-format off")
-for nj, abl in ((4, ""), (3, "")):
+for nj, abl in ((4, ""), (3, ""), (3, "pair")):
     ABL.clear()
-    if abl:
+    if abl and abl != "pair":
         ABL.add(abl)
-    gen(nj)
+    gen(nj, pair=abl == "pair")
     print(f"#define GEMM_BT_ASM_TEXT_NJ{nj}{('_' + abl.upper()) if abl else ''} \\")
     for i, line in enumerate(out):
         print(f'  "{line}\\n"' + (" \\" if i + 1 < len(out) else ""))

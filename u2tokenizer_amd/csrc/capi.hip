@@ -173,7 +173,8 @@ int u2tok_gemm_bf16(const void* A, const void* B, void* C, const void* bias, con
   g.nz = nz; g.nbh = nbh;
   g.sAb = sAb; g.sAh = sAh; g.sBb = sBb; g.sBh = sBh; g.sCb = sCb; g.sCh = sCh; g.sRb = sRb; g.sRh = sRh;
   g.alpha = alpha;
-  g.flags = flags & (GEMM_BIAS_N | GEMM_BIAS_M | GEMM_GELU | GEMM_RESIDUAL | GEMM_OUT_F32 | GEMM_A_KMAJOR | GEMM_B_KMAJOR);
+  g.flags = flags & (GEMM_BIAS_N | GEMM_BIAS_M | GEMM_GELU | GEMM_RESIDUAL | GEMM_OUT_F32 | GEMM_A_KMAJOR | GEMM_B_KMAJOR |
+                     GEMM_SWIGLU);
   if (flags & GEMM_B_KTILE) {
     if ((K & 63) || nz != 1) return U2_ERR_ARG;
     g.ldb = 64;
@@ -274,7 +275,15 @@ int u2tok_rmsnorm_bf16(const void* x, const void* w, void* y, int64_t rows, int3
 int u2tok_qk_norm_rope(void* qkv, const void* wq, const void* wk, const void* cos, const void* sin, int32_t cos_sin_f32,
                        int64_t rows, int32_t Hq, int32_t Hkv, int32_t D, int64_t ld, int64_t cs_ld, float eps,
                        u2tok_stream_t stream) {
-  return qk_norm_rope(BFW(qkv), BF(wq), BF(wk), cos, sin, cos_sin_f32, rows, Hq, Hkv, D, ld, cs_ld, eps, ST(stream));
+  return qk_norm_rope(BFW(qkv), BF(wq), BF(wk), cos, sin, cos_sin_f32, rows, Hq, Hkv, D, ld, cs_ld, eps, nullptr, nullptr, 0,
+                      ST(stream));
+}
+int u2tok_qk_norm_rope_kv(void* qkv, const void* wq, const void* wk, const void* cos, const void* sin, int32_t cos_sin_f32,
+                          int64_t rows, int32_t Hq, int32_t Hkv, int32_t D, int64_t ld, int64_t cs_ld, float eps,
+                          void* k_cache, void* v_cache, int32_t S, u2tok_stream_t stream) {
+  if (!k_cache || !v_cache) return U2_ERR_ARG;
+  return qk_norm_rope(BFW(qkv), BF(wq), BF(wk), cos, sin, cos_sin_f32, rows, Hq, Hkv, D, ld, cs_ld, eps, BFW(k_cache),
+                      BFW(v_cache), S, ST(stream));
 }
 int u2tok_swiglu_bf16(const void* gate_up, void* out, int64_t rows, int32_t I, int64_t ld_in, int64_t ld_out,
                       u2tok_stream_t stream) {

@@ -70,21 +70,37 @@ int rmsnorm_bf16(const bf16_t* x, const bf16_t* w, bf16_t* y, int64_t rows, int 
 //   x <- RMSNorm_D(x) * w_q|k          (Qwen3Attention.q_norm / k_norm; skipped when the weight pointer is null: Llama)
 //   x <- x * cos + rotate_half(x) * sin (apply_rotary_pos_emb; cos / sin: [rows][D] fp32 or bf16 as HF hands them out)
 // One wave per (row, head); lane l < D/2 holds the pair (x[l], x[l + D/2]) rotate_half couples.
+// kc / vc (optional): the KV cache's own layout, [batch][kv head][S][D] dense (HF DynamicLayer: (B, H_kv, S, D)); the finished
+// k heads are written there as well and the v heads copied, so the cache takes the tensors as they are (row = batch * S + s).
 template <int D, typename CS>
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ qkv, const bf16_t* __restrict__ wq,
                                                            const bf16_t* __restrict__ wk, const CS* __restrict__ cosp,
                                                            const CS* __restrict__ sinp, int64_t rows, int Hq, int Hkv,
-                                                           int64_t ld, int64_t cs_ld, float eps) {
+                                                           int64_t ld, int64_t cs_ld, float eps, bf16_t* __restrict__ kc,
+                                                           bf16_t* __restrict__ vc, int S) {
   const int lane = threadIdx.x & 63;
   const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int nh = Hq + Hkv;
+  const int nh = Hq + Hkv + (kc ? Hkv : 0);
   if (item >= rows * nh) return;
   const int64_t row = item / nh;
   const int hh = (int)(item - row * nh);
-  bf16_t* p = qkv + row * ld + (int64_t)hh * D;  // k heads follow the q heads in the packed row
-  const bf16_t* w = hh < Hq ? wq : wk;
+  bf16_t* p = qkv + row * ld + (int64_t)hh * D;  // k heads follow the q heads in the packed row, v heads the k heads
   constexpr int HALF = D / 2;
   const bool on = lane < HALF;
+  bf16_t* cdst = nullptr;
+  if (kc && hh >= Hq) {
+    const int64_t bi = row / S, si = row - bi * S;
+    const int hk = hh - Hq;
+    cdst = (hk < Hkv ? kc + ((bi * Hkv + hk) * S + si) * D : vc + ((bi * Hkv + (hk - Hkv)) * S + si) * D);
+    if (hk >= Hkv) {  // a v head: copy
+      if (on) {
+        cdst[lane] = p[lane];
+        cdst[lane + HALF] = p[lane + HALF];
+      }
+      return;
+    }
+  }
+  const bf16_t* w = hh < Hq ? wq : wk;
   float a = 0.f, b = 0.f;
   if (on) {
     a = bf16_to_f32(p[lane]);
@@ -104,8 +120,13 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
     const CS* cr = cosp + row * cs_ld;
     const CS* sr = sinp + row * cs_ld;
     const float c0 = (float)cr[lane], c1 = (float)cr[lane + HALF], s0 = (float)sr[lane], s1 = (float)sr[lane + HALF];
-    p[lane] = f32_to_bf16(a * c0 - b * s0);          // rotate_half(x) = (-x2, x1)
-    p[lane + HALF] = f32_to_bf16(b * c1 + a * s1);
+    const bf16_t r0 = f32_to_bf16(a * c0 - b * s0), r1 = f32_to_bf16(b * c1 + a * s1);  // rotate_half(x) = (-x2, x1)
+    p[lane] = r0;
+    p[lane + HALF] = r1;
+    if (cdst) {
+      cdst[lane] = r0;
+      cdst[lane + HALF] = r1;
+    }
   }
 }
 
@@ -115,15 +136,17 @@ struct Bf16Val {  // bf16 cos / sin tables
 };
 
 int qk_norm_rope(bf16_t* qkv, const bf16_t* wq, const bf16_t* wk, const void* cosp, const void* sinp, int cs_is_f32,
-                 int64_t rows, int Hq, int Hkv, int D, int64_t ld, int64_t cs_ld, float eps, hipStream_t stream) {
+                 int64_t rows, int Hq, int Hkv, int D, int64_t ld, int64_t cs_ld, float eps, bf16_t* kc, bf16_t* vc, int S,
+                 hipStream_t stream) {
   if (!qkv || !cosp || !sinp || rows <= 0 || Hq <= 0 || Hkv <= 0 || (D != 64 && D != 128) || (!wq) != (!wk)) return U2_ERR_ARG;
-  const int64_t items = rows * (Hq + Hkv);
+  if ((!kc) != (!vc) || (kc && (S <= 0 || rows % S))) return U2_ERR_ARG;
+  const int64_t items = rows * (Hq + Hkv + (kc ? Hkv : 0));
   if (cdiv(items, 4) > 0x7fffffff) return U2_ERR_ARG;
   ProfScope ps(PROF_ROWOP, 0, stream, (double)items * D * 4.0);
   dim3 grid((unsigned)cdiv(items, 4));
 #define U2_QK(D_, T_)                                                                                                     \
   hipLaunchKernelGGL((qk_norm_rope_kernel<D_, T_>), grid, dim3(256), 0, stream, qkv, wq, wk, reinterpret_cast<const T_*>(cosp), \
-                     reinterpret_cast<const T_*>(sinp), rows, Hq, Hkv, ld, cs_ld, eps)
+                     reinterpret_cast<const T_*>(sinp), rows, Hq, Hkv, ld, cs_ld, eps, kc, vc, S)
   if (D == 128 && cs_is_f32) U2_QK(128, float);
   else if (D == 128) U2_QK(128, Bf16Val);
   else if (cs_is_f32) U2_QK(64, float);

@@ -476,6 +476,15 @@ int gemm_bf16(GemmDesc d, hipStream_t stream) {
   if (trace) fprintf(stderr, "gemm M=%d N=%d K=%d nz=%d flags=0x%x lda=%d ldb=%d ldc=%d\n", d.M, d.N, d.K, d.nz, d.flags, (int)d.lda, (int)d.ldb, (int)d.ldc);
   // 16-byte chunked loads along the contiguous dimension of each operand (K, or M / N of a K-major one): that dimension,
   // leading dims and batch strides must keep every chunk aligned
+  if (d.flags & GEMM_SWIGLU) {  // gate | up pair product with SiLU(gate) * up in the epilogue: the 256 x 192-tile kernel only
+    const int64_t I = d.N >> 1;
+    if ((d.flags & ~GEMM_SWIGLU) || d.nz != 1 || d.ldbk || (d.N & 1) || (I & 15) || (d.K & 63) || d.ldc < I || (d.ldc & 7) ||
+        (d.lda & 7) || (d.ldb & 7) || (((uintptr_t)d.A | (uintptr_t)d.B | (uintptr_t)d.C) & 15))
+      return U2_ERR_ARG;
+    ProfScope ps(PROF_GEMM, 2.0 * d.M * d.N * d.K, stream, 2.0 * d.M * d.K + 2.0 * d.N * d.K + 2.0 * d.M * I);
+    const int big = gemm_big_try(d, stream);
+    return big > 0 ? U2_OK : (big < 0 ? big : U2_ERR_ARG);
+  }
   const bool ta = d.flags & GEMM_A_KMAJOR, tb = d.flags & GEMM_B_KMAJOR;
   if ((ta && !tb) || (tb && d.ldbk)) return U2_ERR_ARG;
   if ((ta ? d.M : d.K) & 7) return U2_ERR_ARG;

@@ -51,7 +51,7 @@ __device__ __forceinline__ void pp_tile(const GemmDesc& d, int round, int gd, in
 // quads between the half-waves so that every lane owns 8 CONSECUTIVE n of one row m: 16-byte bias / residual loads
 // and bf16 stores, two float4 stores for fp32 output.
 //   lane (l31, hi), pair t of fragment (mi, ni):  m = m_base + 32 mi,  n = n_tile + 32 ni + 16 t + 8 hi + [0, 8)
-template <class CFG, int G>
+template <class CFG, int G, bool PAIR = false>
 __device__ __forceinline__ void pp_epilogue(const GemmDesc& d, f32x16 (&acc)[2][CFG::NI], int z, int bm0, int bn0, int wm2,
                                             int wn2, int lane) {
   constexpr int NI = CFG::NI, BN = CFG::BN;
@@ -75,6 +75,34 @@ __device__ __forceinline__ void pp_epilogue(const GemmDesc& d, f32x16 (&acc)[2][
           acc[mi][ni][8 * t + e] = __uint_as_float(r[0]);
           acc[mi][ni][8 * t + 4 + e] = __uint_as_float(r[1]);
         }
+  if constexpr (PAIR) {
+    // SwiGLU-pair form (see the kernel): block ni of this wave holds gate columns (t = 0) and up columns (t = 1) of output
+    // columns (bn0 / 2) + 16 (NI wn2 + ni) + 8 hi + [0, 8).  Rounding points of HF's LlamaMLP on bf16 tensors, the ones
+    // swiglu_kernel (decoder.hip) keeps: gate, up and silu(gate) are bf16 values.
+    const int I = (int)(d.N >> 1);
+    bf16_t* C16 = reinterpret_cast<bf16_t*>(Cz);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int c0 = (bn0 >> 1) + 16 * (NI * wn2 + ni) + 8 * hi;
+      if (c0 >= I) continue;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int m = m_base + mi * 32;
+        if (m >= d.M) continue;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float g = bf16_to_f32(f32_to_bf16(acc[mi][ni][e] * d.alpha));
+          const float u = bf16_to_f32(f32_to_bf16(acc[mi][ni][8 + e] * d.alpha));
+          const float sg = g / (1.0f + __expf(-g));
+          o[e] = bf16_to_f32(f32_to_bf16(sg)) * u;
+        }
+        *reinterpret_cast<uint4*>(C16 + (int64_t)m * d.ldc + c0) =
+            uint4{pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]), pack2_bf16(o[4], o[5]), pack2_bf16(o[6], o[7])};
+      }
+    }
+    return;
+  }
   // FULL: the tile lies inside C (no row / column predicates); flags resolved at compile time.
   auto body = [&](auto FULL_, auto BIAS_, auto GELU_, auto RES_, auto F32_) {
     constexpr bool FULL = decltype(FULL_)::value;
@@ -159,8 +187,9 @@ __device__ __forceinline__ void pp_epilogue(const GemmDesc& d, f32x16 (&acc)[2][
 #include "gemm_bt_asm.inc"
 typedef int bt_i32x4 __attribute__((ext_vector_type(4)));
 
-template <int NJ>  // 32-column blocks per wave: tile = 256 x (64 NJ)
+template <int NJ, bool PAIR = false>  // 32-column blocks per wave: tile = 256 x (64 NJ)
 __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
+  static_assert(!PAIR || NJ == 3, "the pair form exists for 256 x 192 tiles");
   constexpr int BN = 64 * NJ;
   using CFG = BTCfg<BN>;
   __shared__ __attribute__((aligned(1024))) char lds[131072];  // [stage][A tile 32 KB | B tile <= 32 KB]
@@ -176,11 +205,24 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
   // piece; LDS position p of row r holds global chunk p ^ ((r >> 1) & 7): even / odd pieces differ by 4 in that term.
   // Lane offsets are relative to the tile origin; the origin (and the K tile) travel in the scalar offset.
   const int pr = lane >> 3, sw0 = (lane >> 4) & 3, pc = lane & 7;
-  const int ra = wave * 64 + pr, rb = wave * (16 * NJ) + pr;
+  const int ra = wave * 64 + pr;
   const int va0 = (ra * (int)d.lda + ((pc ^ sw0) << 3)) * 2;
   const int va1 = ((ra + 8) * (int)d.lda + ((pc ^ sw0 ^ 4) << 3)) * 2;
+  // PAIR (GEMM_SWIGLU: B = [gate rows | up rows], N = 2 I, C[m][j] = silu(gate_j) * up_j; NJ = 3): tile row
+  // R = 32 b + 16 half + i  <->  weight row half * I + (bn0 / 2) + 16 b + i, so every 32-column MFMA block holds 16 gate columns
+  // and THE SAME 16 up columns, which the epilogue finds in one lane (t = 0 / 1).  The lane offsets then address a row inside a
+  // 16-row group and the group's offset is a scalar per (wave, group) handed to the K loop.
+  const int rb = (PAIR ? 0 : wave * (16 * NJ)) + pr;
   const int vb0 = (rb * (int)d.ldb + ((pc ^ sw0) << 3)) * 2;
   const int vb1 = ((rb + 8) * (int)d.ldb + ((pc ^ sw0 ^ 4) << 3)) * 2;
+  [[maybe_unused]] int rowb[3] = {0, 0, 0};
+  if constexpr (PAIR) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int g = NJ * wave + q;  // 16-row group of the tile
+      rowb[q] = __builtin_amdgcn_readfirstlane(((g & 1) * (int)(d.N >> 1) + 16 * (g >> 1)) * (int)d.ldb * 2);
+    }
+  }
   const uint32_t lds_u32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&lds[0];  // 0: the only LDS object
   const uint32_t abk0 = (uint32_t)(l31 * 128 + ((hi ^ ((l31 >> 1) & 7)) << 4));
   const int lda16 = 16 * (int)d.lda * 2, ldb16 = 16 * (int)d.ldb * 2;
@@ -211,9 +253,9 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
     const uint32_t aa0 = (lds_u32 + wm * 16384 + abk0) ^ st0, ab0 = (lds_u32 + 32768 + wn * (NJ * 4096) + abk0) ^ st0;
     // (readfirstlane: the values are uniform, but hipcc keeps loop-carried tile coordinates in VGPRs)
     const int base_a = __builtin_amdgcn_readfirstlane(bm0 * (int)d.lda * 2);
-    const int base_b = __builtin_amdgcn_readfirstlane(bn0 * (int)d.ldb * 2);
+    const int base_b = __builtin_amdgcn_readfirstlane((PAIR ? bn0 >> 1 : bn0) * (int)d.ldb * 2);
     const int nbase_a = __builtin_amdgcn_readfirstlane((chain ? bm0n : bm0) * (int)d.lda * 2);
-    const int nbase_b = __builtin_amdgcn_readfirstlane((chain ? bn0n : bn0) * (int)d.ldb * 2);
+    const int nbase_b = __builtin_amdgcn_readfirstlane((PAIR ? (chain ? bn0n : bn0) >> 1 : (chain ? bn0n : bn0)) * (int)d.ldb * 2);
     const int st0_s = __builtin_amdgcn_readfirstlane((int)st0), first_s = __builtin_amdgcn_readfirstlane(first);
     f32x16 acc[2][2][NJ];  // [64-row half of the wave tile][32-row block][32-column block]
 #pragma unroll
@@ -227,37 +269,45 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
 #define BT_ACC3(h_, m_) [c##h_##m_##0] "+a"(acc[h_][m_][0]), [c##h_##m_##1] "+a"(acc[h_][m_][1]), [c##h_##m_##2] "+a"(acc[h_][m_][2])
 #define BT_IN                                                                                                         \
   [va0] "v"(va0), [va1] "v"(va1), [vb0] "v"(vb0), [vb1] "v"(vb1), [aa0] "v"(aa0), [ab0] "v"(ab0), [rsa] "s"(rsa),     \
-      [rsb] "s"(rsb), [lda16] "s"(lda16), [ldb16] "s"(ldb16), [nkt] "s"(nkt), [wave] "s"(wave), [st0] "s"(st0_s),     \
-      [first] "s"(first_s), [base_a] "s"(base_a), [base_b] "s"(base_b), [nbase_a] "s"(nbase_a), [nbase_b] "s"(nbase_b)
+      [rsb] "s"(rsb), [lda16] "s"(lda16), [nkt] "s"(nkt), [wave] "s"(wave), [st0] "s"(st0_s), [first] "s"(first_s),   \
+      [base_a] "s"(base_a), [base_b] "s"(base_b), [nbase_a] "s"(nbase_a), [nbase_b] "s"(nbase_b)
     if constexpr (NJ == 4) {
       asm volatile(GEMM_BT_ASM_TEXT_NJ4
                    : BT_ACC3(0, 0), [c003] "+a"(acc[0][0][3]), BT_ACC3(0, 1), [c013] "+a"(acc[0][1][3]), BT_ACC3(1, 0),
                      [c103] "+a"(acc[1][0][3]), BT_ACC3(1, 1), [c113] "+a"(acc[1][1][3])
-                   : BT_IN
+                   : BT_IN, [ldb16] "s"(ldb16)
+                   : GEMM_BT_ASM_CLOBBERS);
+    } else if constexpr (PAIR) {
+      asm volatile(GEMM_BT_ASM_TEXT_NJ3_PAIR
+                   : BT_ACC3(0, 0), BT_ACC3(0, 1), BT_ACC3(1, 0), BT_ACC3(1, 1)
+                   : BT_IN, [rowb0] "s"(rowb[0]), [rowb1] "s"(rowb[1]), [rowb2] "s"(rowb[2])
                    : GEMM_BT_ASM_CLOBBERS);
     } else {
-      asm volatile(GEMM_BT_ASM_TEXT_NJ3 : BT_ACC3(0, 0), BT_ACC3(0, 1), BT_ACC3(1, 0), BT_ACC3(1, 1) : BT_IN : GEMM_BT_ASM_CLOBBERS);
+      asm volatile(GEMM_BT_ASM_TEXT_NJ3
+                   : BT_ACC3(0, 0), BT_ACC3(0, 1), BT_ACC3(1, 0), BT_ACC3(1, 1)
+                   : BT_IN, [ldb16] "s"(ldb16)
+                   : GEMM_BT_ASM_CLOBBERS);
     }
 #undef BT_ACC3
 #undef BT_IN
     // pp_epilogue's row base is bm0 + 128 G + 64 wm2: G = 0 with the wave's 128-row offset folded into bm0 (its "tile
     // inside C" fast-path test then only errs towards the predicated path)
-    pp_epilogue<CFG, 0>(d, acc[0], z, bm0 + wm * 128, bn0, 0, wn, lane);
-    pp_epilogue<CFG, 0>(d, acc[1], z, bm0 + wm * 128, bn0, 1, wn, lane);
+    pp_epilogue<CFG, 0, PAIR>(d, acc[0], z, bm0 + wm * 128, bn0, 0, wn, lane);
+    pp_epilogue<CFG, 0, PAIR>(d, acc[1], z, bm0 + wm * 128, bn0, 1, wn, lane);
     st0 ^= (uint32_t)(nkt & 1) << 16;
     z = zn; bm0 = bm0n; bn0 = bn0n;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last K loop's prefetch into LDS
 }
 
-template <int NJ>
+template <int NJ, bool PAIR = false>
 static int bt_launch(GemmDesc d, hipStream_t stream) {
   d.tiles_m = (int)cdiv(d.M, 256);
   d.tiles_n = (int)cdiv(d.N, 64 * NJ);
   const int64_t total = (int64_t)d.tiles_m * d.tiles_n * d.nz;
   if (total > 0x3fffffff) return U2_ERR_ARG;
   const int grid = (int)std::min<int64_t>(total, opts().gemm_big_grid);
-  hipLaunchKernelGGL(gemm_bt_kernel<NJ>, dim3(grid), dim3(256), 0, stream, d);
+  hipLaunchKernelGGL((gemm_bt_kernel<NJ, PAIR>), dim3(grid), dim3(256), 0, stream, d);
   return launch_status();
 }
 
@@ -295,6 +345,11 @@ static int bt_pick(const GemmDesc& d) {
 // Returns 1 when the product was launched here, 0 when the caller should use gemm.hip's kernel, < 0 on error.
 // `d` has been validated by gemm_bf16 (alignment of A / B, GEMM_VEC_OK resolved).
 int gemm_big_try(const GemmDesc& d, hipStream_t stream) {
+  if (d.flags & GEMM_SWIGLU) {  // only this kernel has the pair form (256 x 192 tiles = 96 output columns); gemm_bf16 validated
+    if (!bt_legal(d)) return U2_ERR_ARG;
+    const int e = bt_launch<3, true>(d, stream);
+    return e == U2_OK ? 1 : e;
+  }
   const int mode = opts().gemm_big;
   if (mode < 0) return 0;
   if (!(d.flags & GEMM_VEC_OK) || (d.flags & (GEMM_BIAS_M | GEMM_A_KMAJOR | GEMM_B_KMAJOR)) || (d.N & 7)) return 0;

@@ -31,6 +31,8 @@ enum : int {
   GEMM_VEC_OK = 32,    // internal: vector epilogue legal (set by the launcher)
   GEMM_B_KTILE = 64,   // C-ABI only: B is K-tile-major [K/64][N][64] (pack_ktile_major); K % 64 == 0, nz == 1
   GEMM_A_KMAJOR = 128, // A is stored [K][M] (leading dim lda >= M, M % 8 == 0): C = A^T B^T-form products without a transpose
+  GEMM_SWIGLU = 512,   // B = [gate rows | up rows] (N = 2 I): C[m][j] = bf16(silu(gate_j)) * up_j, C is [M][I] bf16; no other epilogue
+                       // flag, K % 64 == 0, I % 16 == 0 (the 256 x 192-tile kernel stages gate / up rows pairwise, gemm_bt.hip)
   GEMM_B_KMAJOR = 256, // B is stored [K][N] (leading dim ldb >= N, N % 8 == 0); A K-major requires B K-major too
 };
 
@@ -204,7 +206,8 @@ int tok_attention_set_debug_buffer(void* p);
 int rmsnorm_bf16(const bf16_t* x, const bf16_t* w, bf16_t* y, int64_t rows, int C, int64_t ldx, int64_t ldy, float eps,
                  hipStream_t stream);
 int qk_norm_rope(bf16_t* qkv, const bf16_t* wq, const bf16_t* wk, const void* cosp, const void* sinp, int cs_is_f32,
-                 int64_t rows, int Hq, int Hkv, int D, int64_t ld, int64_t cs_ld, float eps, hipStream_t stream);
+                 int64_t rows, int Hq, int Hkv, int D, int64_t ld, int64_t cs_ld, float eps, bf16_t* kc, bf16_t* vc, int S,
+                 hipStream_t stream);
 int swiglu_bf16(const bf16_t* gu, bf16_t* out, int64_t rows, int I, int64_t ld_in, int64_t ld_out, hipStream_t stream);  // diagnostics: >= grid * 4 * 8 uint64, zeroed; null detaches (instrumented build)
 // Diagnostics only (process-wide, not for concurrent use): s_memtime phase sums per (workgroup, wave) of the double
 // pipeline kernel; while a buffer is attached the kernel runs its instrumented build.  See attn.hip.

@@ -195,6 +195,35 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, bias_m=F
     return out.reshape(*a.shape[:-1], N) if b.dim() == 2 else out
 
 
+GEMM_SWIGLU = 512
+
+
+def gemm_swiglu_supported(rows: int, K: int, I: int) -> bool:
+    """Shapes the gate | up pair form of u2tok_gemm_bf16 (flag 512) takes."""
+    return rows >= 1 and K % 64 == 0 and K >= 128 and I % 16 == 0 and rows * K < (1 << 30) and 2 * I * K < (1 << 30)
+
+
+@_guarded
+def gemm_swiglu(a: torch.Tensor, w_gate_up: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(rows, I) = bf16(silu(a @ gate^T)) * (a @ up^T) for w_gate_up (2 I, K) = gate rows then up rows: the values of
+    `swiglu(gemm(a, w_gate_up))` bit for bit, the (rows, 2 I) intermediate never written (LlamaMLP / Qwen3MLP)."""
+    h = _lib.load_library()
+    _need(a, torch.bfloat16, "A"), _need(w_gate_up, torch.bfloat16, "W")
+    a2 = a.reshape(-1, a.shape[-1]).contiguous()
+    w = w_gate_up.contiguous()
+    M, K = a2.shape
+    N = w.shape[0]
+    I = N // 2
+    if w.shape[1] != K or N % 2 or not gemm_swiglu_supported(M, K, I):
+        raise RuntimeError(f"gemm_swiglu: unsupported shape rows {M}, K {K}, 2I {N}")
+    if out is None:
+        out = torch.empty((M, I), dtype=torch.bfloat16, device=a.device)
+    st = h.u2tok_gemm_bf16(_ptr(a2), _ptr(w), _ptr(out), None, None, M, N, K, K, K, out.stride(0), 0, 1, 1,
+                           0, 0, 0, 0, 0, 0, 0, 0, 1.0, GEMM_SWIGLU, _stream())
+    _lib.check(st, "u2tok_gemm_bf16 (swiglu pair)")
+    return out.reshape(*a.shape[:-1], I)
+
+
 @_guarded
 def gemm_kmajor(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool, alpha=1.0, out_f32=False) -> torch.Tensor:
     """Products with K-major operands (no transposes in HBM; u2tok_gemm_bf16 flags 128 / 256):
@@ -501,9 +530,11 @@ def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float = 1e-6) -> torch.Tensor
 
 @_guarded
 def qk_norm_rope(qkv: torch.Tensor, q_norm_w, k_norm_w, cos: torch.Tensor, sin: torch.Tensor, heads: int, kv_heads: int,
-                 head_dim: int, eps: float = 1e-6) -> torch.Tensor:
+                 head_dim: int, eps: float = 1e-6, kv_cache_seq: int = 0):
     """In place on the q and k heads of qkv (rows, (heads + 2 kv_heads) * head_dim): per-head RMSNorm (weights may both be
-    None: Llama) then rotary embedding with cos / sin (rows, head_dim), fp32 or bf16 (u2tok_qk_norm_rope)."""
+    None: Llama) then rotary embedding with cos / sin (rows, head_dim), fp32 or bf16 (u2tok_qk_norm_rope).
+    kv_cache_seq = S > 0 (rows = batch * S): also returns the finished keys and the values as fresh dense
+    (batch, kv_heads, S, head_dim) tensors -- the KV cache's layout (u2tok_qk_norm_rope_kv): (qkv, k_cache, v_cache)."""
     h = _lib.load_library()
     _need(qkv, torch.bfloat16, "qkv")
     rows = qkv.shape[0]
@@ -512,6 +543,17 @@ def qk_norm_rope(qkv: torch.Tensor, q_norm_w, k_norm_w, cos: torch.Tensor, sin: 
     if cos.dtype != sin.dtype or cos.dtype not in (torch.float32, torch.bfloat16) or cos.shape != (rows, head_dim) \
             or sin.shape != cos.shape or cos.stride(1) != 1 or sin.stride(1) != 1 or cos.stride(0) != sin.stride(0):
         raise RuntimeError("qk_norm_rope: cos / sin must be (rows, head_dim) fp32 or bf16 with equal strides")
+    if kv_cache_seq:
+        S = int(kv_cache_seq)
+        if S <= 0 or rows % S:
+            raise RuntimeError("qk_norm_rope: rows must be batch * kv_cache_seq")
+        kc = torch.empty((rows // S, kv_heads, S, head_dim), dtype=torch.bfloat16, device=qkv.device)
+        vc = torch.empty_like(kc)
+        _lib.check(h.u2tok_qk_norm_rope_kv(_ptr(qkv), _ptr(q_norm_w), _ptr(k_norm_w), _ptr(cos), _ptr(sin),
+                                           int(cos.dtype == torch.float32), rows, heads, kv_heads, head_dim, qkv.stride(0),
+                                           cos.stride(0), float(eps), _ptr(kc), _ptr(vc), S, _stream()),
+                   "u2tok_qk_norm_rope_kv")
+        return qkv, kc, vc
     _lib.check(h.u2tok_qk_norm_rope(_ptr(qkv), _ptr(q_norm_w), _ptr(k_norm_w), _ptr(cos), _ptr(sin),
                                     int(cos.dtype == torch.float32), rows, heads, kv_heads, head_dim, qkv.stride(0),
                                     cos.stride(0), float(eps), _stream()), "u2tok_qk_norm_rope")

@@ -8,8 +8,8 @@ for the PREFILL call only (no grad, bf16 on the GPU, more than one position, emp
 padding), runs the layer as
 
     RMSNorm -> ONE q|k|v GEMM -> per-head RMSNorm (Qwen3) + rotary embedding -> causal grouped-query attention
-    -> out-projection GEMM with the residual in its epilogue -> RMSNorm -> ONE gate|up GEMM -> SiLU(gate) * up
-    -> down-projection GEMM with the residual in its epilogue
+    -> out-projection GEMM with the residual in its epilogue -> RMSNorm -> ONE gate|up GEMM with SiLU(gate) * up in its
+    epilogue -> down-projection GEMM with the residual in its epilogue
 
 on the library's MFMA GEMMs (include/u2tok.h: u2tok_gemm_bf16), the fused attention kernel of tokattn.hip
 (u2tok_attention_gqa: grouped-query heads, causal mask, scores never in HBM) and the row kernels of decoder.hip.  Everything
@@ -93,20 +93,49 @@ def _layer_forward(self, hidden_states, *args, **kwargs):
         xn = ops.rmsnorm(x2, self.input_layernorm.weight, self.input_layernorm.variance_epsilon)
         qkv = ops.gemm(xn, Wqkv, bias=bqkv)
         qn, kn = getattr(att, "q_norm", None), getattr(att, "k_norm", None)
-        ops.qk_norm_rope(qkv, None if qn is None else qn.weight, None if kn is None else kn.weight, cos, sin, Hq, Hkv, d,
-                         qn.variance_epsilon if qn is not None else 1e-6)
+        r = ops.qk_norm_rope(qkv, None if qn is None else qn.weight, None if kn is None else kn.weight, cos, sin, Hq, Hkv, d,
+                             qn.variance_epsilon if qn is not None else 1e-6, kv_cache_seq=S if cache is not None else 0)
+        kc, vc = (r[1], r[2]) if cache is not None else (None, None)  # keys / values in the cache's own (B, H_kv, S, d) layout
         q3 = qkv.view(B, S, -1)
         k3, v3 = q3[..., Hq * d:(Hq + Hkv) * d], q3[..., (Hq + Hkv) * d:]
         ctx = ops.attention_gqa(q3[..., :Hq * d], k3, v3, Hq, Hkv, float(att.scaling), causal=True)
         h = ops.gemm(ctx.view(rows, Hq * d), att.o_proj.weight, bias=att.o_proj.bias, residual=x2)
         hn = ops.rmsnorm(h, self.post_attention_layernorm.weight, self.post_attention_layernorm.variance_epsilon)
-        act = ops.swiglu(ops.gemm(hn, Wgu, bias=bgu))
+        if bgu is None and ops.gemm_swiglu_supported(rows, E, Wgu.shape[0] // 2):
+            act = ops.gemm_swiglu(hn, Wgu)  # SiLU(gate) * up in the epilogue of the pair product: no (rows, 2 I) tensor
+        else:
+            act = ops.swiglu(ops.gemm(hn, Wgu, bias=bgu))
         out = ops.gemm(act, self.mlp.down_proj.weight, bias=self.mlp.down_proj.bias, residual=h)
         if cache is not None:
-            # (B, kv heads, S, d) VIEWS of the packed projection: every HF cache layer copies what it is handed into storage of
-            # its own (DynamicLayer: torch.cat with its empty tensors; static layers: index_copy_), so no copy is made here
-            cache.update(k3.unflatten(-1, (Hkv, d)).transpose(1, 2), v3.unflatten(-1, (Hkv, d)).transpose(1, 2), att.layer_idx)
+            _cache_prefill(cache, kc, vc, att.layer_idx)
     return out.view(B, S, E)
+
+
+def _cache_prefill(cache, keys, values, layer_idx: int) -> None:
+    """Hand the prefill's keys / values (fresh dense (B, H_kv, S, d) tensors nobody else holds) to the KV cache.  An EMPTY
+    `DynamicLayer` of a plain `DynamicCache` would only `torch.cat` them onto its empty tensors (two more copies per layer: 72
+    launches per Qwen3-8B prefill) -- it takes them as they are; every other cache type goes through its `update`."""
+    try:
+        from transformers.cache_utils import DynamicCache, DynamicLayer
+    except ImportError:  # (older transformers: no per-layer cache objects)
+        DynamicCache = DynamicLayer = None
+    layers = getattr(cache, "layers", None)
+    if DynamicLayer is not None and type(cache) is DynamicCache and isinstance(layers, list) \
+            and not getattr(cache, "offloading", False):
+        repl = getattr(cache, "layer_class_to_replicate", None)
+        if repl is DynamicLayer:
+            while len(layers) <= layer_idx:
+                layers.append(repl())
+        lay = layers[layer_idx] if layer_idx < len(layers) else None
+        if type(lay) is DynamicLayer and lay.get_seq_length() == 0 and hasattr(lay, "lazy_initialization"):
+            try:
+                if not getattr(lay, "is_initialized", False):
+                    lay.lazy_initialization(keys, values)
+                lay.keys, lay.values = keys, values
+                return
+            except TypeError:  # (another transformers version's signature: let the cache do it its way)
+                pass
+    cache.update(keys, values, layer_idx)
 
 
 def _mask_hook(module, args, kwargs):
