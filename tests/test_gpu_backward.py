@@ -526,6 +526,39 @@ def test_training_step_through_the_hf_model():
     check_grads(got, ref, what="training step")
 
 
+@pytest.mark.parametrize("n,off", [(8 * 4096, 0), (8 * 4096 + 5, 0), (4099, 3), (7, 0), (2048 * 3 + 1, 8)])
+def test_adamw_step_kernel_matches_torch_adamw(n, off):
+    """u2tok_adamw_step (fused ZeRO-1 shard update) against torch.optim.AdamW on the same fp32 state: the 8-wide form, its
+    tail, an unaligned piece (offset slices of larger buffers) and two parameter groups with a device-side clip coefficient."""
+    from u2tokenizer_amd import ops
+    g = torch.Generator().manual_seed(n + off)
+    tot = n + off
+    master = torch.randn(tot, generator=g)
+    grads = [(torch.randn(tot, generator=g) * 0.1).to(bf) for _ in range(3)]
+    group = (torch.arange(tot) % 3 == 0).to(torch.uint8)            # group 1: no decay, its own lr
+    lrs, wds, coef = [1e-2, 3e-2], [0.1, 0.0], 0.37
+    pa = master[off:][group[off:] == 0].clone().requires_grad_(True)
+    pb = master[off:][group[off:] == 1].clone().requires_grad_(True)
+    ref = torch.optim.AdamW([{"params": [pa], "lr": lrs[0], "weight_decay": wds[0]},
+                             {"params": [pb], "lr": lrs[1], "weight_decay": wds[1]}], betas=(0.9, 0.95), eps=1e-8)
+    md, m1, m2 = master.to(D), torch.zeros(tot, device=D), torch.zeros(tot, device=D)
+    out = torch.zeros(tot, dtype=bf, device=D)
+    cf = torch.tensor([coef], device=D)
+    for step, gr in enumerate(grads, 1):
+        gf = gr.float()[off:] * coef * 0.5
+        pa.grad, pb.grad = gf[group[off:] == 0].clone(), gf[group[off:] == 1].clone()
+        ref.step()
+        ops.adamw_step(md[off:], m1[off:], m2[off:], gr.to(D)[off:], out[off:], step, lrs, wds, betas=(0.9, 0.95), eps=1e-8,
+                       grad_scale=0.5, grad_coef=cf, group=group.to(D)[off:])
+    want = torch.empty(n)
+    want[group[off:] == 0], want[group[off:] == 1] = pa.detach(), pb.detach()
+    got = md[off:].cpu()
+    assert torch.allclose(got, want, rtol=2e-5, atol=1e-6), (got - want).abs().max()
+    assert torch.equal(out[off:].cpu(), got.to(bf))
+    if off:
+        assert torch.equal(md[:off].cpu(), master[:off]) and not out[:off].any()
+
+
 def test_zero1_adamw_on_the_gpu_keeps_packed_weights_in_sync():
     """Two optimiser steps of dp.Zero1AdamW (one rank: no collective) on a GPU tokenizer trained through the HIP path: the
     parameters follow torch.optim.AdamW on an fp32 copy fed with the same gradients, the in-place updates land in the packed

@@ -452,22 +452,53 @@ int rowdot_bf16(const bf16_t* a, const bf16_t* b, float* out, int64_t rows, int 
 //   g = grad * gscale (* *gcoef: the clipping coefficient, computed on the device);  p *= 1 - lr wd;
 //   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= (lr / c1) m / (sqrt(v) / sqrt(c2) + eps)
 // group[i] (may be null: group 0) selects (lr, wd) from the per-group tables (param groups: biases / LayerNorm without decay).
+__device__ __forceinline__ void adamw_one(float& p, float& mi, float& vi, float g, float lr, float wd, const AdamWArgs& a) {
+  p *= 1.0f - lr * wd;
+  mi = a.b1 * mi + (1.0f - a.b1) * g;
+  vi = a.b2 * vi + (1.0f - a.b2) * g * g;
+  p -= (lr * a.inv_c1) * mi / (sqrtf(vi) * a.inv_sqrt_c2 + a.eps);
+}
+
+// VEC: every pointer 16-byte aligned (group: 8-byte) -- a lane owns 8 consecutive elements: 2 x 16-byte loads / stores per fp32
+// array, one 16-byte load of gradients, one 16-byte store of parameters (29 bytes per element each way at full-width accesses;
+// the scalar form of round 3's first version ran at 2.2 TB/s).  Tail elements (n % 8) and unaligned pieces: one element per lane.
+template <bool VEC>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, float* __restrict__ m, float* __restrict__ v,
                                                     const bf16_t* __restrict__ grad, const uint8_t* __restrict__ group,
-                                                    bf16_t* __restrict__ out, int64_t n, AdamWArgs a) {
+                                                    bf16_t* __restrict__ out, int64_t n, int64_t first, AdamWArgs a) {
   const float gs = a.gscale * (a.gcoef ? *a.gcoef : 1.0f);
-  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i0 >= n) return;
-  const int cnt = (int)min((int64_t)4, n - i0);
-  for (int r = 0; r < cnt; ++r) {
-    const int64_t i = i0 + r;
+  if constexpr (VEC) {
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i0 >= n) return;  // (n is a multiple of 8 here)
+    float4 p0 = *reinterpret_cast<const float4*>(master + i0), p1 = *reinterpret_cast<const float4*>(master + i0 + 4);
+    float4 m0 = *reinterpret_cast<const float4*>(m + i0), m1 = *reinterpret_cast<const float4*>(m + i0 + 4);
+    float4 v0 = *reinterpret_cast<const float4*>(v + i0), v1 = *reinterpret_cast<const float4*>(v + i0 + 4);
+    const uint4 g4 = *reinterpret_cast<const uint4*>(grad + i0);
+    uint2 gi2 = uint2{0u, 0u};
+    if (group) gi2 = *reinterpret_cast<const uint2*>(group + i0);
+    float pp[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+    float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+    float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    const float gg[8] = {bf16lo(g4.x), bf16hi(g4.x), bf16lo(g4.y), bf16hi(g4.y), bf16lo(g4.z), bf16hi(g4.z), bf16lo(g4.w), bf16hi(g4.w)};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int gi = (int)(((r < 4 ? gi2.x : gi2.y) >> (8 * (r & 3))) & 255u);
+      adamw_one(pp[r], mm[r], vv[r], gg[r] * gs, a.lr[gi], a.wd[gi], a);
+    }
+    *reinterpret_cast<float4*>(master + i0) = float4{pp[0], pp[1], pp[2], pp[3]};
+    *reinterpret_cast<float4*>(master + i0 + 4) = float4{pp[4], pp[5], pp[6], pp[7]};
+    *reinterpret_cast<float4*>(m + i0) = float4{mm[0], mm[1], mm[2], mm[3]};
+    *reinterpret_cast<float4*>(m + i0 + 4) = float4{mm[4], mm[5], mm[6], mm[7]};
+    *reinterpret_cast<float4*>(v + i0) = float4{vv[0], vv[1], vv[2], vv[3]};
+    *reinterpret_cast<float4*>(v + i0 + 4) = float4{vv[4], vv[5], vv[6], vv[7]};
+    *reinterpret_cast<uint4*>(out + i0) = uint4{pack2_bf16(pp[0], pp[1]), pack2_bf16(pp[2], pp[3]), pack2_bf16(pp[4], pp[5]),
+                                                pack2_bf16(pp[6], pp[7])};
+  } else {
+    const int64_t i = first + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
     const int gi = group ? group[i] : 0;
-    const float lr = a.lr[gi], wd = a.wd[gi];
-    const float g = bf16_to_f32(grad[i]) * gs;
-    float p = master[i] * (1.0f - lr * wd);
-    const float mi = a.b1 * m[i] + (1.0f - a.b1) * g;
-    const float vi = a.b2 * v[i] + (1.0f - a.b2) * g * g;
-    p -= (lr * a.inv_c1) * mi / (sqrtf(vi) * a.inv_sqrt_c2 + a.eps);
+    float p = master[i], mi = m[i], vi = v[i];
+    adamw_one(p, mi, vi, bf16_to_f32(grad[i]) * gs, a.lr[gi], a.wd[gi], a);
     m[i] = mi; v[i] = vi; master[i] = p;
     out[i] = f32_to_bf16(p);
   }
@@ -475,9 +506,17 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
 
 int adamw_step(float* master, float* m, float* v, const bf16_t* grad, const uint8_t* group, bf16_t* out, int64_t n,
                const AdamWArgs& a, hipStream_t st) {
-  if (!master || !m || !v || !grad || !out || n <= 0 || cdiv(n, 1024) > 0x7fffffff) return U2_ERR_ARG;
+  if (!master || !m || !v || !grad || !out || n <= 0 || cdiv(n, 256) > 0x7fffffff) return U2_ERR_ARG;
   ProfScope ps(PROF_ROWOP, 0, st, (double)n * 28.0);
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)cdiv(n, 1024)), dim3(256), 0, st, master, m, v, grad, group, out, n, a);
+  const bool aligned = !((((uintptr_t)master | (uintptr_t)m | (uintptr_t)v | (uintptr_t)grad | (uintptr_t)out) & 15) ||
+                         ((uintptr_t)group & 7));
+  const int64_t nv = aligned ? (n & ~(int64_t)7) : 0;
+  if (nv)
+    hipLaunchKernelGGL(adamw_kernel<true>, dim3((unsigned)cdiv(nv, 2048)), dim3(256), 0, st, master, m, v, grad, group, out, nv,
+                       (int64_t)0, a);
+  if (nv < n)
+    hipLaunchKernelGGL(adamw_kernel<false>, dim3((unsigned)cdiv(n - nv, 256)), dim3(256), 0, st, master, m, v, grad, group, out,
+                       n, nv, a);
   return launch_status();
 }
 

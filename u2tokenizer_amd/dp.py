@@ -315,8 +315,7 @@ class Zero1AdamW:
             stage = self._stage[i % len(self._stage)]
             if self.world == 1:
                 self._update_piece(b, st, stage[:b.numel], coef)
-                for p, o in zip(b.params, b.offsets):
-                    p.copy_(stage[o:o + p.numel()].view_as(p))
+                self._copy_out(b, stage)
             elif cuda:
                 cur = torch.cuda.current_stream(dev)
                 si = i % len(self._stage)
@@ -329,16 +328,14 @@ class Zero1AdamW:
                 with torch.cuda.stream(self._comm_stream):   # all-gather + copy-out of bucket i under the AdamW of i + 1
                     self._comm_stream.wait_event(updated)
                     dist.all_gather_into_tensor(stage[:b.numel], mine, group=self.group)
-                    for p, o in zip(b.params, b.offsets):
-                        p.copy_(stage[o:o + p.numel()].view_as(p))
+                    self._copy_out(b, stage)
                     stage_free[si] = torch.cuda.Event()
                     stage_free[si].record(self._comm_stream)
             else:
                 mine = stage[self.rank * b.piece:(self.rank + 1) * b.piece]
                 self._update_piece(b, st, mine, coef)
                 dist.all_gather_into_tensor(stage[:b.numel], mine.clone(), group=self.group)
-                for p, o in zip(b.params, b.offsets):
-                    p.copy_(stage[o:o + p.numel()].view_as(p))
+                self._copy_out(b, stage)
         if cuda and self.world > 1:
             torch.cuda.current_stream(dev).wait_stream(self._comm_stream)
         # the step owns the gradients: zero the buckets and re-arm
@@ -348,6 +345,18 @@ class Zero1AdamW:
             b.full = b.launched = False
         self._next_launch = 0
         self._install_grad_views()
+
+    @staticmethod
+    def _copy_out(b, stage) -> None:
+        """The gathered bf16 bucket -> the parameters it holds: one multi-tensor copy instead of a launch per parameter (the
+        u2Qwen3-8B-shaped model has ~700 of them)."""
+        srcs = [stage[o:o + p.numel()].view_as(p) for p, o in zip(b.params, b.offsets)]
+        dsts = [p.data for p in b.params]
+        if hasattr(torch, "_foreach_copy_"):
+            torch._foreach_copy_(dsts, srcs)
+        else:
+            for d, s_ in zip(dsts, srcs):
+                d.copy_(s_)
 
     def zero_grad(self, set_to_none: bool = False):
         """The buckets are zeroed by step(); this only matters for a step that is abandoned half-way."""
@@ -387,8 +396,7 @@ class Zero1AdamW:
                 mine.copy_(st["master"])
                 if self.world > 1:
                     dist.all_gather_into_tensor(stage[:b.numel], mine.clone(), group=self.group)
-                for p, o in zip(b.params, b.offsets):
-                    p.copy_(stage[o:o + p.numel()].view_as(p))
+                self._copy_out(b, stage)
 
     def state_bytes_per_rank(self) -> int:
         return sum(s["master"].numel() * 12 for s in self.state)
