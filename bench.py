@@ -303,6 +303,22 @@ def measure_traffic(E, timeout=240):
 
 
 # ---------------------------------------------------------------------------------------------------- training step
+def train_step_full(timeout=240):
+    """BASELINE configs[3] on this GPU: one whole stage-1 step (path + 36-layer Qwen3-8B-shaped decoder with gradient
+    checkpointing + Zero1AdamW.step() over 9.7 B parameters; tools/train_step_full.py) in a CHILD process -- it needs 163 GiB of
+    HBM of its own and must not be able to cost the inference line anything.  Not part of `value`."""
+    tool = Path(__file__).resolve().parent / "tools" / "train_step_full.py"
+    try:
+        torch.cuda.empty_cache()
+        r = subprocess.run([sys.executable, str(tool), "3"], env=_child_env(), capture_output=True, text=True, timeout=timeout)
+        for ln in reversed(r.stdout.splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return {"error": (r.stderr or "no output")[-300:]}
+    except (OSError, subprocess.SubprocessError, ValueError) as e:
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def train_step(path, ids, qids, vol, E, iters=3):
     """Forward under autograd + backward of the path (ViT, projector, tokenizer, embedding table) on the benchmark
     configuration with a dummy loss on the spliced embeddings (the decoder and the optimiser are not part
@@ -615,6 +631,8 @@ def main():
             line["train_step"] = train_step(path, ids, qids, vols[0], E)
         except Exception as e:  # never lose the inference line to the extra
             line["train_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if rank == 0 and world == 1 and not args.no_train_step and not args.stub_cpu and B == 1 and E == 4096:
+        line["train_step_full"] = train_step_full()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stub_cpu:
         line["cpu_baseline"] = cpu_baseline(E, Lt, iters=args.cpu_baseline_iters)
     if rank == 0:

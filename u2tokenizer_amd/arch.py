@@ -157,6 +157,9 @@ class u2MetaForCausalLM(ABC):
             embed_tokens_weight = weights["model.embed_tokens.weight"]
             input_embeddings = self.get_input_embeddings().weight.data
             if input_embeddings.shape == embed_tokens_weight.shape:
+                # NOTE: deliberate difference.  The reference REBINDS its local name here (`input_embeddings =
+                # embed_tokens_weight`, u2_arch.py:155), which leaves the model's embedding table untouched -- the checkpoint's
+                # table is silently dropped.  The evident intent (and the sibling branch below) is a copy into the table.
                 input_embeddings.copy_(embed_tokens_weight)
             elif embed_tokens_weight.shape[0] == num_new_tokens:
                 input_embeddings[-num_new_tokens:] = embed_tokens_weight
