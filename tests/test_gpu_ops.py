@@ -450,6 +450,32 @@ def test_gemm_big_tile_variants(ops, variant):
         ops.set_option("gemm_big", 0)
 
 
+@pytest.mark.parametrize("variant,slices", [(21, 2), (21, 8), (20, 5), (21, 3), (20, 2)])
+def test_gemm_big_tile_k_slices(ops, variant, slices):
+    """The big-tile kernel with its K range cut into slices (fp32 partial sums in the stream's scratch, epilogue applied by the
+    reduce kernel in a fixed order): uneven last slices, several tiles per workgroup with slices of different lengths chained in
+    one K loop, row / column tails, every epilogue; repeatable bit for bit."""
+    scratch = torch.empty(96 << 20, dtype=torch.uint8, device=D)
+    ops.set_gemm_scratch(scratch)
+    ops.set_option("gemm_big", variant)
+    ops.set_option("gemm_big_splitk", slices)
+    try:
+        for (M, N, K) in [(256, 4096, 4096), (200, 520, 1024), (1024, 1032, 2176), (2049, 384, 704), (129, 136, 640)]:
+            a, b, bias, res = rnd(M, K, seed=41), rnd(N, K, seed=42), rnd(N, seed=43), rnd(M, N, seed=44)
+            ad, bd, biasd, resd = a.to(D), b.to(D), bias.to(D), res.to(D)
+            base = a.float() @ b.float().t()
+            outs = [ops.gemm(ad, bd, bias=biasd, residual=resd).clone() for _ in range(3)]
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+            close_bf16(outs[0], base + bias.float() + res.float())
+            close_bf16(ops.gemm(ad, bd), base)
+            close_f32(ops.gemm(ad, bd, bias=biasd, out_f32=True, alpha=0.5), 0.5 * base + bias.float())
+    finally:
+        ops.set_option("gemm_big", 0)
+        ops.set_option("gemm_big_splitk", 0)
+        ops.set_gemm_scratch(None)
+        torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("M,N,K", [(8, 2304, 768), (8, 768, 3072), (1, 40, 64), (16, 4096, 4096), (5, 24, 96), (8, 768, 768)])
 def test_gemm_few_rows(ops, M, N, K):
     """M <= 16 (the ViT's 8 cls rows behind the big-tile launches): gemm_rows16_kernel -- waves split K, partial tiles are

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generates u2tokenizer_amd/csrc/gemm_bt_asm.inc: the K loop of the 256 x (64 NJ) x 64 "big tile" bf16 GEMM
-(gemm_bt.hip, gemm_bt_kernel<NJ, PAIR>, NJ = 4 or 3; NJ = 3 also in the SwiGLU-pair form) as ONE inline-asm block for gfx950.
+(gemm_bt.hip, gemm_bt_kernel<NJ, PAIR, SPLIT>, NJ = 4 or 3; NJ = 3 also in the SwiGLU-pair form) as ONE inline-asm block for gfx950.
 
 One workgroup = 4 waves (2 x 2), one wave per SIMD, each wave a 128 x (32 NJ) output tile = 4 x NJ accumulators of
 v_mfma_f32_32x32x16_bf16 in AccVGPRs (asm operands "+a": the compiler zeroes them before and runs the epilogue after).
@@ -268,7 +268,8 @@ def gen(nj, pair=False):
 
 print("// GENERATED by tools/gen_gemm_bt_asm.py -- do not edit")
 print("// clang-format off")
-for nj, abl in ((4, ""), (3, ""), (3, "pair")):
+for nj, abl in ((4, ""), (3, ""), (3, "pair")):   # (NJ = 2, 256 x 128 tiles, generates too: measured slower than both on
+    # every shape of this model, profiles/r03_bt_sweep.log -- its K loop is LDS-bound -- and left out of the product)
     ABL.clear()
     if abl and abl != "pair":
         ABL.add(abl)

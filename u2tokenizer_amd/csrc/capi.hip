@@ -53,6 +53,7 @@ int u2tok_set_option(const char* name, int value) {
   static const Opt table[] = {
       {"gemm_splitk", &Options::gemm_splitk, -1, 16},   {"gemm_big", &Options::gemm_big, -1, 21},
       {"gemm_big_grid", &Options::gemm_big_grid, 1, 4096}, {"gemm_big_gelu", &Options::gemm_big_gelu, 0, 1},
+      {"gemm_big_splitk", &Options::gemm_big_splitk, 0, 16}, {"gemm_big_skinny", &Options::gemm_big_skinny, 0, 1},
       {"kmajor_b", &Options::kmajor_b, 0, 1},
       {"flash_mode", &Options::flash_mode, 0, 5},
       {"vit_flash", &Options::vit_flash, 0, 1},         {"tta_overlap", &Options::tta_overlap, 0, 1},

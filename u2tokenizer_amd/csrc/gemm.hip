@@ -581,6 +581,10 @@ int gemm_classic(GemmDesc d, hipStream_t stream) {
   if (longk && d.ksplit == 1) tile = 64;  // no scratch for the slices: the tile that fills the CUs
   const int e = tile == 128 ? launch_tile<128, 128>(d, stream) : launch_tile<64, 64>(d, stream);
   if (e != U2_OK || d.ksplit == 1) return e;
+  return gemm_splitk_reduce(d, stream);
+}
+
+int gemm_splitk_reduce(const GemmDesc& d, hipStream_t stream) {
   const int64_t total = (int64_t)d.nz * d.M * ((d.N + 3) >> 2);
   hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, d);
   return launch_status();

@@ -187,9 +187,11 @@ __device__ __forceinline__ void pp_epilogue(const GemmDesc& d, f32x16 (&acc)[2][
 #include "gemm_bt_asm.inc"
 typedef int bt_i32x4 __attribute__((ext_vector_type(4)));
 
-template <int NJ, bool PAIR = false>  // 32-column blocks per wave: tile = 256 x (64 NJ)
+template <int NJ, bool PAIR = false, bool SPLIT = false>  // 32-column blocks per wave: tile = 256 x (64 NJ)
 __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
+  static_assert(!(PAIR && SPLIT), "the pair form is not sliced");
   static_assert(!PAIR || NJ == 3, "the pair form exists for 256 x 192 tiles");
+  static_assert(NJ == 3 || NJ == 4, "256 x 192 / 256 x 256 tiles");
   constexpr int BN = 64 * NJ;
   using CFG = BTCfg<BN>;
   __shared__ __attribute__((aligned(1024))) char lds[131072];  // [stage][A tile 32 KB | B tile <= 32 KB]
@@ -198,7 +200,10 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
   const int wm = wave >> 1, wn = wave & 1;
   const int hi = lane >> 5, l31 = lane & 31;
   const int tiles_mn = d.tiles_m * d.tiles_n;
-  const int total = tiles_mn * d.nz;
+  // split-K (nz == 1 then): the K slices take the place of the batch index -- "z" of a tile is its slice, which leaves raw
+  // fp32 sums in partial[slice][m][n] for gemm_splitk_reduce_kernel (gemm.hip), epilogue flags and all
+  constexpr bool split = SPLIT;
+  const int total = tiles_mn * (split ? d.ksplit : d.nz);
   const int gd = gridDim.x, bid = blockIdx.x;
   const int my_tiles = (total - bid + gd - 1) / gd;  // >= 1: grid <= total
   // DMA pieces of this wave: rows [64 w, 64 w + 64) of the A tile and [16 NJ w, ..) of the B tile, 8 rows x 128 B per
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
   const uint32_t lds_u32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&lds[0];  // 0: the only LDS object
   const uint32_t abk0 = (uint32_t)(l31 * 128 + ((hi ^ ((l31 >> 1) & 7)) << 4));
   const int lda16 = 16 * (int)d.lda * 2, ldb16 = 16 * (int)d.ldb * 2;
-  const int nkt = d.K >> 6;
+  const int nkt_all = d.K >> 6;
   const bool chain = d.nz == 1;  // one K loop runs on from tile to tile (same descriptors)
   uint32_t st0 = 0;              // LDS stage that holds K tile 0 of the current output tile
   int z, bm0, bn0;
@@ -234,9 +239,13 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
   for (int r = 0; r < my_tiles; ++r) {
     int zn = z, bm0n = bm0, bn0n = bn0;  // next output tile of this workgroup (itself after the last one: its K
     if (r + 1 < my_tiles) pp_tile<BN>(d, r + 1, gd, bid, total, tiles_mn, zn, bm0n, bn0n);  // loop prefetches in-bounds garbage)
-    const int zb = z / d.nbh, zh = z - zb * d.nbh;
+    const int zq = split ? 0 : z;
+    const int zb = zq / d.nbh, zh = zq - zb * d.nbh;
     const bf16_t* A = d.A + zb * d.sAb + zh * d.sAh;
     const bf16_t* B = d.B + zb * d.sBb + zh * d.sBh;
+    // K range of this tile (split-K: slice z, the last one may be shorter; >= 2 K tiles each, the launcher sees to it)
+    const int kt0 = split ? z * d.kt_per : 0, kt0n = split ? zn * d.kt_per : 0;
+    const int nkt = __builtin_amdgcn_readfirstlane(split ? min(d.kt_per, nkt_all - kt0) : nkt_all);
     // MUBUF descriptors: rows past M / N read as zero
     const uint64_t aaddr = (uint64_t)(uintptr_t)A, baddr = (uint64_t)(uintptr_t)B;
     bt_i32x4 rsa, rsb;
@@ -252,10 +261,11 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
     if (first) st0 = 0;
     const uint32_t aa0 = (lds_u32 + wm * 16384 + abk0) ^ st0, ab0 = (lds_u32 + 32768 + wn * (NJ * 4096) + abk0) ^ st0;
     // (readfirstlane: the values are uniform, but hipcc keeps loop-carried tile coordinates in VGPRs)
-    const int base_a = __builtin_amdgcn_readfirstlane(bm0 * (int)d.lda * 2);
-    const int base_b = __builtin_amdgcn_readfirstlane((PAIR ? bn0 >> 1 : bn0) * (int)d.ldb * 2);
-    const int nbase_a = __builtin_amdgcn_readfirstlane((chain ? bm0n : bm0) * (int)d.lda * 2);
-    const int nbase_b = __builtin_amdgcn_readfirstlane((PAIR ? (chain ? bn0n : bn0) >> 1 : (chain ? bn0n : bn0)) * (int)d.ldb * 2);
+    const int base_a = __builtin_amdgcn_readfirstlane((bm0 * (int)d.lda + kt0 * 64) * 2);
+    const int base_b = __builtin_amdgcn_readfirstlane(((PAIR ? bn0 >> 1 : bn0) * (int)d.ldb + kt0 * 64) * 2);
+    const int nbase_a = __builtin_amdgcn_readfirstlane(((chain ? bm0n : bm0) * (int)d.lda + (chain ? kt0n : kt0) * 64) * 2);
+    const int nbase_b = __builtin_amdgcn_readfirstlane(
+        ((PAIR ? (chain ? bn0n : bn0) >> 1 : (chain ? bn0n : bn0)) * (int)d.ldb + (chain ? kt0n : kt0) * 64) * 2);
     const int st0_s = __builtin_amdgcn_readfirstlane((int)st0), first_s = __builtin_amdgcn_readfirstlane(first);
     f32x16 acc[2][2][NJ];  // [64-row half of the wave tile][32-row block][32-column block]
 #pragma unroll
@@ -292,8 +302,18 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
 #undef BT_IN
     // pp_epilogue's row base is bm0 + 128 G + 64 wm2: G = 0 with the wave's 128-row offset folded into bm0 (its "tile
     // inside C" fast-path test then only errs towards the predicated path)
-    pp_epilogue<CFG, 0, PAIR>(d, acc[0], z, bm0 + wm * 128, bn0, 0, wn, lane);
-    pp_epilogue<CFG, 0, PAIR>(d, acc[1], z, bm0 + wm * 128, bn0, 1, wn, lane);
+    if constexpr (split) {
+      GemmDesc ds = d;  // this slice's raw sums: partial[z][m][n], dense fp32
+      ds.C = d.partial + (int64_t)z * d.M * d.N;
+      ds.ldc = d.N;
+      ds.alpha = 1.f;
+      ds.flags = GEMM_OUT_F32 | GEMM_VEC_OK;
+      pp_epilogue<CFG, 0, false>(ds, acc[0], 0, bm0 + wm * 128, bn0, 0, wn, lane);
+      pp_epilogue<CFG, 0, false>(ds, acc[1], 0, bm0 + wm * 128, bn0, 1, wn, lane);
+    } else {
+      pp_epilogue<CFG, 0, PAIR>(d, acc[0], z, bm0 + wm * 128, bn0, 0, wn, lane);
+      pp_epilogue<CFG, 0, PAIR>(d, acc[1], z, bm0 + wm * 128, bn0, 1, wn, lane);
+    }
     st0 ^= (uint32_t)(nkt & 1) << 16;
     z = zn; bm0 = bm0n; bn0 = bn0n;
   }
@@ -304,9 +324,16 @@ template <int NJ, bool PAIR = false>
 static int bt_launch(GemmDesc d, hipStream_t stream) {
   d.tiles_m = (int)cdiv(d.M, 256);
   d.tiles_n = (int)cdiv(d.N, 64 * NJ);
-  const int64_t total = (int64_t)d.tiles_m * d.tiles_n * d.nz;
+  if (d.ksplit > 1 && (d.nz != 1 || PAIR || !d.partial)) return U2_ERR_ARG;
+  const int64_t total = (int64_t)d.tiles_m * d.tiles_n * (d.ksplit > 1 ? d.ksplit : d.nz);
   if (total > 0x3fffffff) return U2_ERR_ARG;
   const int grid = (int)std::min<int64_t>(total, opts().gemm_big_grid);
+  if constexpr (!PAIR) {
+    if (d.ksplit > 1) {
+      hipLaunchKernelGGL((gemm_bt_kernel<NJ, false, true>), dim3(grid), dim3(256), 0, stream, d);
+      return gemm_splitk_reduce(d, stream);
+    }
+  }
   hipLaunchKernelGGL((gemm_bt_kernel<NJ, PAIR>), dim3(grid), dim3(256), 0, stream, d);
   return launch_status();
 }
@@ -316,8 +343,33 @@ static bool bt_legal(const GemmDesc& d) {
   return !(d.K & 63) && d.K >= 128 && (int64_t)d.M * d.lda < (1ll << 30) && (int64_t)d.N * d.ldb < (1ll << 30);
 }
 
+// K slices for a product of `tiles` output tiles: fill the 256 CUs, keep >= 4 K tiles per slice (and >= 2 in the last one:
+// the K loop's pipeline), within the stream's scratch.  0 / 1 = unsplit.
+static int bt_slices(GemmDesc& d, int64_t tiles, int want, hipStream_t stream) {
+  d.ksplit = 1;
+  const int nkt = d.K >> 6;
+  if (want <= 1 || d.nz != 1 || nkt < 8) return 1;
+  const Scratch sc = ctx().scratch_of(stream);
+  const size_t slice = (size_t)d.M * d.N * sizeof(float);
+  if (!sc.p || sc.bytes < 2 * slice) return 1;
+  int s = (int)std::min<int64_t>(std::min<int64_t>(want, nkt / 4), (int64_t)(sc.bytes / slice));
+  while (s > 1) {
+    const int per = (int)cdiv(nkt, s), used = (int)cdiv(nkt, per);
+    if (nkt - (used - 1) * per >= 2) {  // last slice long enough
+      d.ksplit = used;
+      d.kt_per = per;
+      d.partial = reinterpret_cast<float*>(sc.p);
+      return used > 1 ? used : (d.ksplit = 1);
+    }
+    --s;
+  }
+  (void)tiles;
+  return 1;
+}
+
+// variants: 20 = 256 x 256, 21 = 256 x 192 tiles
 static int bt_launch_variant(int v, const GemmDesc& d, hipStream_t stream) {
-  return v == 20 ? bt_launch<4>(d, stream) : bt_launch<3>(d, stream);  // 256x256 / 256x192 tiles
+  return v == 20 ? bt_launch<4>(d, stream) : bt_launch<3>(d, stream);
 }
 
 // Which tile (tools/gpu_check.py ppperf on MI355X, random operands; DESIGN.md section 3 has the tables): the kernel
@@ -340,6 +392,27 @@ static int bt_pick(const GemmDesc& d) {
   const double c4 = (double)r4, c3 = 0.9 * (double)r3;  // a 192-wide tile takes ~0.9 of the time of a 256-wide one
   if (c3 < c4) return fill3 >= 0.7 ? 21 : (fill4 >= 0.7 ? 20 : 0);
   return fill4 >= 0.7 ? 20 : (fill3 >= 0.7 ? 21 : 0);
+}
+
+// Products that leave the 256 CUs a partial round of big tiles, sliced along K so that (tiles x slices) fills them -- the
+// cases tools/bt_sweep.py measured ahead of the 128 x 128 kernel with its own split-K (profiles/r03_bt_sweep.log, cold weights,
+// us: 128^2 kernel -> here):
+//   (a) 129..256 rows against a wide weight (the TTA self-attention's packed q|k|v, 256 x 12288 x 4096): 71.5 -> 51.0
+//       (256 x 192 tiles, 4 slices); the 256 x 4096 x 4096 products of the same chain tie at 30 us and stay where they are
+//   (b) 512..1024 rows, K >= 8192 (decoder down-projection at prefill, 1024 x 4096 x 12288): 131.7 -> 111.0 (256 x 256, 4)
+//   (c) 512..1024 rows whose 192-wide tiles make exactly half a round (prefill q|k|v, 1024 x 6144 x 4096): 77.1 -> 71.6
+//       (256 x 192, 2)
+// Returns variant | slices << 8, or 0.  The caller falls back to the small-tile kernel when the scratch cannot hold the slices.
+static int bt_pick_sliced(const GemmDesc& d) {
+  if (!bt_legal(d) || d.nz != 1 || (d.flags & GEMM_GELU)) return 0;
+  const int64_t tm = cdiv(d.M, 256);
+  if (d.M > 128 && d.M <= 256 && d.N >= 8192 && d.K >= 2048) return 21 | (4 << 8);
+  if (d.M >= 512 && d.M <= 1024 && (d.M & 255) == 0) {
+    if (d.K >= 8192 && d.N >= 2048 && tm * cdiv(d.N, 256) <= 64) return 20 | (4 << 8);
+    const int64_t t3 = tm * (d.N / 192);
+    if (d.N % 192 == 0 && d.K >= 4096 && t3 >= 112 && t3 <= 128) return 21 | (2 << 8);
+  }
+  return 0;
 }
 
 // Returns 1 when the product was launched here, 0 when the caller should use gemm.hip's kernel, < 0 on error.
@@ -365,8 +438,20 @@ int gemm_big_try(const GemmDesc& d, hipStream_t stream) {
   if ((d.flags & GEMM_RESIDUAL) && (((uintptr_t)d.R & 15) || (d.ldr & 7) || (d.sRb & 7) || (d.sRh & 7))) return 0;
   if (mode > 0) {  // forced (tests, measurements)
     if (!bt_legal(d)) return 0;
-    const int e = bt_launch_variant(mode, d, stream);
+    GemmDesc ds = d;
+    bt_slices(ds, 0, opts().gemm_big_splitk, stream);
+    const int e = bt_launch_variant(mode, ds, stream);
     return e == U2_OK ? 1 : e;
+  }
+  if (opts().gemm_big_skinny) {
+    const int v = bt_pick_sliced(d);
+    if (v > 0) {
+      GemmDesc ds = d;
+      if (bt_slices(ds, 0, v >> 8, stream) == (v >> 8)) {  // (fewer slices than wanted: the small-tile kernel is the better one)
+        const int e = bt_launch_variant(v & 0xff, ds, stream);
+        return e == U2_OK ? 1 : e;
+      }
+    }
   }
   if (d.M < 512 || d.N < 256 || d.K < 128) return 0;
   // A few rows past a multiple of 256 (the ViT's 8 cls rows: M = 8 * 2049) would cost a whole extra round of

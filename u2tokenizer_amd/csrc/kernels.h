@@ -63,6 +63,7 @@ int gemm_bf16(GemmDesc d, hipStream_t stream);
 // internal: the kernels behind gemm_bf16 (descriptor already validated there)
 int gemm_classic(GemmDesc d, hipStream_t stream);        // gemm.hip: 128^2 / 64^2 tiles, 2+ workgroups per CU
 int gemm_big_try(const GemmDesc& d, hipStream_t stream);  // gemm_bt.hip: 1 launched, 0 not applicable, < 0 error
+int gemm_splitk_reduce(const GemmDesc& d, hipStream_t stream);  // gemm.hip: epilogue over d.partial[ksplit][nz][M][N]
 
 // ------------------------------------------------------------------ row ops (rowops.hip)
 // y[b][r][:] = LayerNorm(x[b][r][:] (+ res[b][r][:])) * w + bias   (bf16 in/out, fp32 math)

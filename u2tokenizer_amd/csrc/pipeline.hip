@@ -366,7 +366,9 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
   Arena ar(ws, ws_bytes, dry);
   // split-K scratch for the skinny linear layers of this forward (M = 256 queries against E x E weights); registered
   // for this stream only while the launches below are being enqueued
-  constexpr size_t kSplitK = 24u << 20;
+  // (24 MB covers the E x E products; the TTA self-attention's packed q|k|v product takes the big-tile kernel in 4 K slices:
+  //  4 x rows x 3E fp32)
+  const size_t kSplitK = std::max<size_t>(24u << 20, (size_t)16 * B * c.num_query * 3 * E);
   char* skw = ar.get<char>(kSplitK);
   U2_CHECK_WS(ar);
   Context& cx = ctx();

@@ -54,11 +54,12 @@ _scratch = {}
 
 
 def _ensure_gemm_scratch(device) -> None:
-    """Split-K scratch of the calling stream (the M = 1024 out / down projections are 256 tiles of 128 x 128: cut in two along
-    K they put two workgroups on every CU), registered on the active context like the training path's."""
+    """Split-K scratch of the calling stream (at S = 1024 the out projection is 256 tiles of 128 x 128: cut in two along K it puts
+    two workgroups on every CU; q|k|v and the down projection take the big-tile kernel in 2 / 4 K slices, gemm_bt.hip:
+    bt_pick_sliced), registered on the active context like the training path's."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream, id(ops.active_context(device)))
     if key not in _scratch:
-        buf = torch.empty(40 << 20, dtype=torch.uint8, device=device)
+        buf = torch.empty(72 << 20, dtype=torch.uint8, device=device)  # 4 slices of (1024, 4096) fp32 sums + slack
         with torch.cuda.device(device):
             ops.set_gemm_scratch(buf)
         _scratch[key] = buf
