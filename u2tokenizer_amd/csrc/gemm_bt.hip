@@ -46,6 +46,58 @@ __device__ __forceinline__ void pp_tile(const GemmDesc& d, int round, int gd, in
   bn0 = (in_g / gsz) * BN;
 }
 
+typedef unsigned int bt_u32x4 __attribute__((ext_vector_type(4)));
+
+// Fast form of the epilogue below for the cases the big products are (tile inside C, bf16 output, bias[n] and / or residual):
+// the bias vectors of the wave's columns were loaded BEFORE the K loop (`bpre`, NI x 2 x 16 bytes: their latency used to be
+// exposed once per column group), all residual loads of a 64-row half are issued before the first use (they were one
+// load -> wait -> store chain per 8 values: C and R may alias -- the ViT's residual products are in place --, so the compiler
+// kept that order).  (Non-temporal stores were tried and are wrong here: 32-byte row pieces that bypass the L2's write
+// combining -- the q|k|v product went 73 -> 106 us.)  profiles/r03_bt_epilogue_ablation.log has what the epilogue cost:
+// 26 of 76 us of the ViT's q|k|v product, 13.5 of 35 us of its out-projection.
+template <int NI, bool BIAS, bool RES>
+__device__ __forceinline__ void bt_epilogue_fast(const GemmDesc& d, f32x16 (&acc)[2][NI], bf16_t* Cz, const bf16_t* Rz, int m_base,
+                                                 int n_base, const bt_u32x4 (&bpre)[NI * 2]) {
+  // one 32-row block (mi) at a time: its NI x 2 residual vectors in flight together, then per 8-column group
+  // swap -> scale / bias / residual -> pack -> store straight from the accumulator registers (8 live values, no write-back)
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    bt_u32x4 rr[NI][2];
+    if constexpr (RES) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          rr[ni][t] = *reinterpret_cast<const bt_u32x4*>(Rz + (int64_t)(m_base + mi * 32) * d.ldr + n_base + ni * 32 + t * 16);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mi][ni][8 * t + e]),
+                                                          __float_as_uint(acc[mi][ni][8 * t + 4 + e]), false, false);
+          v[e] = __uint_as_float(r[0]) * d.alpha;
+          v[4 + e] = __uint_as_float(r[1]) * d.alpha;
+        }
+        if constexpr (BIAS) {
+          const bt_u32x4 b4 = bpre[ni * 2 + t];
+          v[0] += bf16lo(b4.x); v[1] += bf16hi(b4.x); v[2] += bf16lo(b4.y); v[3] += bf16hi(b4.y);
+          v[4] += bf16lo(b4.z); v[5] += bf16hi(b4.z); v[6] += bf16lo(b4.w); v[7] += bf16hi(b4.w);
+        }
+        if constexpr (RES) {
+          const bt_u32x4 r4 = rr[ni][t];
+          v[0] += bf16lo(r4.x); v[1] += bf16hi(r4.x); v[2] += bf16lo(r4.y); v[3] += bf16hi(r4.y);
+          v[4] += bf16lo(r4.z); v[5] += bf16hi(r4.z); v[6] += bf16lo(r4.w); v[7] += bf16hi(r4.w);
+        }
+        const bt_u32x4 pk = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])};
+        *reinterpret_cast<bt_u32x4*>(Cz + (int64_t)(m_base + mi * 32) * d.ldc + n_base + ni * 32 + t * 16) = pk;
+      }
+  }
+}
+
 // Epilogue of one 256 x BN tile for the calling wave.  The accumulator fragment of v_mfma_f32_32x32x16 leaves a lane
 // with 4 consecutive n (register quad q) and its partner lane (+32) with the next 4; v_permlane32_swap exchanges
 // quads between the half-waves so that every lane owns 8 CONSECUTIVE n of one row m: 16-byte bias / residual loads
@@ -53,7 +105,7 @@ __device__ __forceinline__ void pp_tile(const GemmDesc& d, int round, int gd, in
 //   lane (l31, hi), pair t of fragment (mi, ni):  m = m_base + 32 mi,  n = n_tile + 32 ni + 16 t + 8 hi + [0, 8)
 template <class CFG, int G, bool PAIR = false>
 __device__ __forceinline__ void pp_epilogue(const GemmDesc& d, f32x16 (&acc)[2][CFG::NI], int z, int bm0, int bn0, int wm2,
-                                            int wn2, int lane) {
+                                            int wn2, int lane, const bt_u32x4 (&bpre)[CFG::NI * 2], bool fast) {
   constexpr int NI = CFG::NI, BN = CFG::BN;
   const int hi = lane >> 5, l31 = lane & 31;
   const bool out_f32 = d.flags & GEMM_OUT_F32;
@@ -62,6 +114,18 @@ __device__ __forceinline__ void pp_epilogue(const GemmDesc& d, f32x16 (&acc)[2][
   const bf16_t* Rz = (d.flags & GEMM_RESIDUAL) ? d.R + zb * d.sRb + zh * d.sRh : nullptr;
   const int m_base = bm0 + G * 128 + wm2 * 64 + l31;
   const int n_base = bn0 + wn2 * (BN / 2) + 8 * hi;
+  if constexpr (!PAIR && NI == 3) {
+    if (fast) {  // (uniform: the caller checked tile-inside-C, bf16 output and the flag set)
+      bf16_t* C16 = reinterpret_cast<bf16_t*>(Cz);
+      switch (d.flags & (GEMM_BIAS_N | GEMM_RESIDUAL)) {
+        case GEMM_BIAS_N: bt_epilogue_fast<NI, true, false>(d, acc, C16, Rz, m_base, n_base, bpre); break;
+        case GEMM_BIAS_N | GEMM_RESIDUAL: bt_epilogue_fast<NI, true, true>(d, acc, C16, Rz, m_base, n_base, bpre); break;
+        case GEMM_RESIDUAL: bt_epilogue_fast<NI, false, true>(d, acc, C16, Rz, m_base, n_base, bpre); break;
+        default: bt_epilogue_fast<NI, false, false>(d, acc, C16, Rz, m_base, n_base, bpre); break;
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -267,6 +331,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
     const int nbase_b = __builtin_amdgcn_readfirstlane(
         ((PAIR ? (chain ? bn0n : bn0) >> 1 : (chain ? bn0n : bn0)) * (int)d.ldb + (chain ? kt0n : kt0) * 64) * 2);
     const int st0_s = __builtin_amdgcn_readfirstlane((int)st0), first_s = __builtin_amdgcn_readfirstlane(first);
+    // fast epilogue (bt_epilogue_fast): tile inside C, bf16 output, bias[n] / residual only; its bias vectors are fetched here,
+    // under the K loop
     f32x16 acc[2][2][NJ];  // [64-row half of the wave tile][32-row block][32-column block]
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -308,11 +374,25 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
       ds.ldc = d.N;
       ds.alpha = 1.f;
       ds.flags = GEMM_OUT_F32 | GEMM_VEC_OK;
-      pp_epilogue<CFG, 0, false>(ds, acc[0], 0, bm0 + wm * 128, bn0, 0, wn, lane);
-      pp_epilogue<CFG, 0, false>(ds, acc[1], 0, bm0 + wm * 128, bn0, 1, wn, lane);
+      const bt_u32x4 bnone[NJ * 2] = {};
+      pp_epilogue<CFG, 0, false>(ds, acc[0], 0, bm0 + wm * 128, bn0, 0, wn, lane, bnone, false);
+      pp_epilogue<CFG, 0, false>(ds, acc[1], 0, bm0 + wm * 128, bn0, 1, wn, lane, bnone, false);
     } else {
-      pp_epilogue<CFG, 0, PAIR>(d, acc[0], z, bm0 + wm * 128, bn0, 0, wn, lane);
-      pp_epilogue<CFG, 0, PAIR>(d, acc[1], z, bm0 + wm * 128, bn0, 1, wn, lane);
+      auto fast_tile = [&]() {  // (evaluated again after the K loop instead of living in an SGPR across it: none to spare)
+        // (256 x 192 tiles only: with 256 accumulator registers the 256-wide form has no room for the residual batch)
+        return NJ == 3 && !PAIR && !SPLIT && !(d.flags & (GEMM_OUT_F32 | GEMM_GELU)) && bm0 + 256 <= d.M && bn0 + BN <= d.N;
+      };
+      bt_u32x4 bpre[NJ * 2];
+#pragma unroll
+      for (int j = 0; j < NJ * 2; ++j) bpre[j] = bt_u32x4{0u, 0u, 0u, 0u};
+      if (fast_tile() && (d.flags & GEMM_BIAS_N)) {
+#pragma unroll
+        for (int j = 0; j < NJ * 2; ++j)
+          bpre[j] = *reinterpret_cast<const bt_u32x4*>(d.bias + bn0 + wn * (BN / 2) + 8 * hi + (j >> 1) * 32 + (j & 1) * 16);
+      }
+      const bool fast = fast_tile();
+      pp_epilogue<CFG, 0, PAIR>(d, acc[0], z, bm0 + wm * 128, bn0, 0, wn, lane, bpre, fast);
+      pp_epilogue<CFG, 0, PAIR>(d, acc[1], z, bm0 + wm * 128, bn0, 1, wn, lane, bpre, fast);
     }
     st0 ^= (uint32_t)(nkt & 1) << 16;
     z = zn; bm0 = bm0n; bn0 = bn0n;
