@@ -736,3 +736,64 @@ def test_backward_runs_on_the_context_of_its_forward():
         assert x.grad is not None and w.grad is not None
     finally:
         c.close()
+
+
+def test_dpo_duplicate_image_batch_at_benchmark_size():
+    """The same at BASELINE configs[2] size (E = 4096, one 256^3 volume duplicated as the DPO trainer does): the de-duplicated
+    run equals the plain one -- embeddings bit for bit on the duplicated rows, every gradient within the bf16 noise of summing
+    two halves instead of doubling one -- at about half the time (only the toy size was covered)."""
+    import sys
+    import time
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    import bench
+    torch.set_grad_enabled(True)
+    E, vocab = 4096, 32768
+    path, _ = bench.build_path(E, vocab, D)
+    for p in path.holder.parameters():
+        p.requires_grad_(True)
+    g = torch.Generator(device=D).manual_seed(5)
+    vol = torch.rand((1, 8, 32, 256, 256), device=D, generator=g).half()
+    ids = torch.randint(1, vocab, (2, 1024), device=D, generator=g)
+    qids = torch.zeros((1, 1024), dtype=torch.int64, device=D)
+    qids[:, :40] = torch.randint(1, vocab, (1, 40), device=D, generator=g)
+    vol2, qids2 = torch.cat([vol, vol]), torch.cat([qids, qids])
+    w = torch.randn(2, 1024, E, device=D, generator=g)
+    res, ms = {}, {}
+    for flag in (True, False, True, False):
+        path.config.u2_dedup_duplicate_images = flag
+        for p in path.holder.parameters():
+            p.grad = None
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        emb = path.prepare_inputs_for_multimodal(ids, None, None, None, None, vol2, qids2)[4]
+        (emb.float() * w).sum().backward()
+        torch.cuda.synchronize()
+        ms[flag] = (time.perf_counter() - t0) * 1e3
+        res[flag] = (emb.detach(), {k: p.grad.float() for k, p in path.holder.named_parameters() if p.grad is not None})
+    path.config.u2_dedup_duplicate_images = True
+
+    def drel(a, b, floor=0.0):  # on the device: 2.1 B gradient values
+        return ((a - b).double().pow(2).mean().sqrt() / (b.double().pow(2).mean().sqrt() + floor)).item()
+
+    assert torch.equal(res[True][0][0, 1:257], res[True][0][1, 1:257])   # the repeated result: the 256 spliced visual tokens
+    e_emb = drel(res[True][0].float(), res[False][0].float())    # (B = 1 and B = 2 launches slice K differently: not bit-equal)
+    assert e_emb < 1e-2, e_emb
+    assert len(res[True][1]) == len(res[False][1]) > 300
+    # the yardstick of check_grads: distances against a floor of 2e-3 x the largest per-parameter RMS gradient (parameters
+    # whose exact gradient is ~0 in this regime -- key biases, the first layers' bias tables and query weights -- are rounding
+    # noise in any bf16 run, and the two runs round differently: B = 1 and B = 2 launches cut K differently), and the
+    # direction of the whole gradient vector
+    top = max(gr.double().pow(2).mean().sqrt().item() for gr in res[False][1].values())
+    worst, dot, na, nb = 0.0, 0.0, 0.0, 0.0
+    for k, gr in res[False][1].items():
+        e = drel(res[True][1][k], gr, 2e-3 * top)
+        worst = max(worst, e)
+        assert e < 5e-2, (k, e)
+        x, y = res[True][1][k].double().flatten(), gr.double().flatten()
+        dot, na, nb = dot + (x @ y).item(), na + (x @ x).item(), nb + (y @ y).item()
+    cosine = dot / (na * nb) ** 0.5
+    assert cosine > 0.9995, cosine
+    assert ms[True] < 0.75 * ms[False], ms
+    print(f"DPO de-dup at E=4096: {ms[True]:.1f} ms against {ms[False]:.1f} ms; embeddings {e_emb:.2e}, worst gradient {worst:.2e}, cosine {cosine:.6f}")
+
