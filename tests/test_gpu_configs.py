@@ -453,3 +453,48 @@ def test_hard_topk_end_to_end_agreement(layers, qk_gain):
                                                "oracle_bf16_vs_fp32": {"set_overlap": os_, "same_position": oo},
                                                "k": k, "n": 2048, "chance_overlap": k / 2048, "qk_gain": qk_gain})
     assert hs >= os_ - 0.02, (hs, os_)
+
+
+def test_frozen_vision_tower_is_shared_between_policy_and_reference():
+    """DPO with a frozen vision tower runs the ViT on the same images for the policy and for the reference model
+    (dpo_u2trainer.py builds the image batch anew for each): after `share_frozen_vision_tower` the second pass returns the
+    first pass's features (byte-identical input, unchanged weights) -- same embeddings as an unshared run, the ViT launched
+    once; another image, or an updated tower, computes again."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    import bench
+    from u2tokenizer_amd import share_frozen_vision_tower
+    E, vocab = 2048, 4096
+    pol, _ = bench.build_path(E, vocab, D)
+    ref, _ = bench.build_path(E, vocab, D)         # (same seed: equal weights, separate modules)
+    g = torch.Generator(device=D).manual_seed(3)
+    vol = torch.rand((1, 8, 32, 256, 256), device=D, generator=g).half()
+    ids = torch.randint(1, vocab, (1, 1024), device=D, generator=g)
+    qids = torch.zeros((1, 1024), dtype=torch.int64, device=D)
+    qids[:, :30] = torch.randint(1, vocab, (1, 30), device=D, generator=g)
+    with torch.no_grad():
+        want = ref.prepare_inputs_for_multimodal(ids, None, None, None, None, vol, qids)[4].clone()
+        pol.holder.vision_tower.requires_grad_(True)
+        with pytest.raises(RuntimeError):
+            share_frozen_vision_tower(pol, ref)        # a trainable tower cannot be shared
+        pol.holder.vision_tower.requires_grad_(False)
+        ref.holder.vision_tower.requires_grad_(False)
+        share_frozen_vision_tower(pol, ref)
+        assert ref.holder.vision_tower is pol.holder.vision_tower
+        tower = pol.holder.vision_tower
+        calls = []
+        inner = tower.vision_tower.forward_features
+        tower.vision_tower.forward_features = lambda x, keep_cls: (calls.append(1), inner(x, keep_cls))[1]
+        a = pol.prepare_inputs_for_multimodal(ids, None, None, None, None, vol.clone(), qids)[4]
+        b = ref.prepare_inputs_for_multimodal(ids, None, None, None, None, vol.clone(), qids)[4]   # another tensor, same bytes
+        assert len(calls) == 1
+        assert torch.equal(a, want) and torch.equal(b, want)
+        vol2 = vol.clone()
+        vol2[0, 3, 5, 7, 9] += 0.25
+        c = ref.prepare_inputs_for_multimodal(ids, None, None, None, None, vol2, qids)[4]
+        assert len(calls) == 2 and not torch.equal(c, want)
+        tower.vision_tower.norm.weight.mul_(1.5)                                             # the tower changed: no stale features
+        d = pol.prepare_inputs_for_multimodal(ids, None, None, None, None, vol2.clone(), qids)[4]
+        assert len(calls) == 3 and not torch.equal(d, c)
+

@@ -157,3 +157,34 @@ def test_fused_prefill_patch_is_inert_off_the_gpu_and_packs_losslessly():
         assert torch.equal(m(inputs_embeds=x).logits, ref)
         P.disable_fused_prefill(m)
         assert not hasattr(m.model.layers[0], "_u2_prefill") and torch.equal(m(inputs_embeds=x).logits, ref)
+
+
+def test_frozen_tower_feature_sharing_logic():
+    """ViT3DTower's opt-in cache of the last features (the DPO step's second pass over the same images with a
+    frozen tower): host logic only -- the tower's compute is stubbed.  Byte-identical input + unchanged frozen weights -> the
+    cached features; a trainable tower, another image or an in-place weight update -> computed again."""
+    tower = U.build_vision_tower(_cfg())
+    calls = []
+
+    def fake(x, keep_cls):
+        calls.append(keep_cls)
+        return x.float().sum().reshape(1) + tower.vision_tower.norm.weight.sum()
+
+    tower.vision_tower.forward_features = fake
+    img = torch.rand(2, 1, 32, 64, 64)
+    tower.share_frozen_features = True
+    a, b = tower(img), tower(img.clone())
+    assert len(calls) == 2                                  # trainable tower: never cached
+    tower.requires_grad_(False)
+    a, b = tower(img), tower(img.clone())
+    assert len(calls) == 3 and b is a
+    c = tower(img + 1)
+    assert len(calls) == 4 and not torch.equal(c, a)
+    with torch.no_grad():
+        tower.vision_tower.norm.weight.add_(1.0)
+    d = tower(img + 1)
+    assert len(calls) == 5 and not torch.equal(d, c)
+    tower.share_frozen_features = False
+    tower(img + 1)
+    assert len(calls) == 6
+

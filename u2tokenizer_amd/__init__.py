@@ -9,7 +9,7 @@ or the device is not gfx950, the forwards raise.
 """
 from ._lib import lib_path, load_library, LibraryNotBuilt  # noqa: F401
 from .builder import build_vision_tower, build_mm_projector, build_u2tokenizer_tower  # noqa: F401
-from .vit import ViT3DTower  # noqa: F401
+from .vit import ViT3DTower, share_frozen_vision_tower  # noqa: F401
 from .projector import SpatialPoolingProjector  # noqa: F401
 from .tokenizer import u2Tokenizer  # noqa: F401
 from .arch import u2MetaModel, u2MetaForCausalLM  # noqa: F401

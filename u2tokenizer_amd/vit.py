@@ -169,15 +169,34 @@ class ViT3DTower(nn.Module):
         self.vision_tower = ViT(in_channels=self.config.image_channel, img_size=self.config.image_size,
                                 patch_size=self.config.patch_size, pos_embed="perceptron",
                                 spatial_dims=len(self.config.patch_size), classification=True)
+        # with a FROZEN tower (train_stage1.py:56 `freeze_vision_tower`, u2_arch.py:58) the DPO step runs the
+        # same ViT on the same images twice -- once for the policy, once for the reference model (dpo_u2trainer.py builds
+        # `cat([images, images])` anew for each).  Opt-in (`share_frozen_vision_tower`): the tower keeps its last input and
+        # output and returns the output again when the next input is byte-identical and no parameter has changed.
+        self.share_frozen_features = False
+        self._feat_cache = None
+
+    def _frozen_key(self):
+        ps = list(self.parameters())
+        if any(p.requires_grad for p in ps):
+            return None
+        return (self.select_feature, sum(p._version for p in ps), ps[0].data_ptr(), ps[0].device)
 
     def forward(self, images):
         if self.select_layer != -1:
             raise ValueError(f"Unexpected select layer: {self.select_layer}")
-        if self.select_feature == "patch":
-            return self.vision_tower.forward_features(images, keep_cls=False)
-        if self.select_feature == "cls_patch":
-            return self.vision_tower.forward_features(images, keep_cls=True)
-        raise ValueError(f"Unexpected select feature: {self.select_feature}")
+        if self.select_feature not in ("patch", "cls_patch"):
+            raise ValueError(f"Unexpected select feature: {self.select_feature}")
+        key = self._frozen_key() if self.share_frozen_features else None
+        if key is not None and self._feat_cache is not None:
+            k0, img0, out0 = self._feat_cache
+            if k0 == key and img0.shape == images.shape and img0.dtype == images.dtype and img0.device == images.device \
+                    and torch.equal(img0, images):
+                return out0
+        out = self.vision_tower.forward_features(images, keep_cls=self.select_feature == "cls_patch")
+        if key is not None:
+            self._feat_cache = (key, images.detach().clone(), out)
+        return out
 
     @property
     def dtype(self):
@@ -190,3 +209,18 @@ class ViT3DTower(nn.Module):
     @property
     def hidden_size(self):
         return self.vision_tower.hidden_size
+
+
+def share_frozen_vision_tower(policy, reference) -> None:
+    """DPO with a frozen vision tower: make `reference` (the frozen reference model) use `policy`'s tower
+    module and let that tower return its last features for a byte-identical input, so the second model's pass over the same
+    images costs one comparison instead of twelve ViT blocks.  Both towers must be frozen and hold equal weights (checked)."""
+    tp, tr = policy.get_model().get_vision_tower(), reference.get_model().get_vision_tower()
+    if any(p.requires_grad for p in tp.parameters()) or any(p.requires_grad for p in tr.parameters()):
+        raise RuntimeError("share_frozen_vision_tower: both vision towers must be frozen (requires_grad False)")
+    sp, sr = tp.state_dict(), tr.state_dict()
+    if sp.keys() != sr.keys() or any(not torch.equal(sp[k], sr[k].to(sp[k].device)) for k in sp):
+        raise RuntimeError("share_frozen_vision_tower: the two towers hold different weights")
+    reference.get_model().vision_tower = tp
+    tp.share_frozen_features = True
+
