@@ -54,14 +54,15 @@ def hf_param_groups(model: torch.nn.Module, weight_decay: float, lr: Optional[fl
 
 
 class _Bucket:
-    def __init__(self, params, offsets, groups, numel_padded, device, dtype, world, rank):
+    def __init__(self, params, offsets, groups, numel_padded, device, dtype, world, rank, multi=None):
         self.params, self.offsets = params, offsets          # offsets of the params inside the flat bucket
         self.numel = numel_padded                             # multiple of world
         self.piece = numel_padded // world
         self.flat_grad = torch.zeros(numel_padded, dtype=dtype, device=device)
         self.views = [self.flat_grad[o:o + p.numel()].view_as(p) for p, o in zip(params, offsets)]
         # this rank's piece of the reduced gradient; with one rank it is the bucket itself
-        self.my_grad = self.flat_grad if world == 1 else torch.empty(self.piece, dtype=dtype, device=device)
+        multi = world > 1 if multi is None else multi
+        self.my_grad = torch.empty(self.piece, dtype=dtype, device=device) if multi else self.flat_grad
         # parameter-group index of every element of this rank's piece (padding: group 0, gradient 0)
         gidx = torch.zeros(numel_padded, dtype=torch.uint8)
         for p, o, g in zip(params, offsets, groups):
@@ -91,10 +92,15 @@ class Zero1AdamW:
 
     def __init__(self, params: Iterable, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
                  process_group=None, reduce_bucket_size: int = int(2e8), allgather_bucket_size: int = int(2e8),
-                 overlap_comm: bool = True, max_grad_norm: Optional[float] = None, gradient_accumulation_steps: int = 1):
+                 overlap_comm: bool = True, max_grad_norm: Optional[float] = None, gradient_accumulation_steps: int = 1,
+                 force_collectives: bool = False):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        # `force_collectives`: run the reduce-scatter / all-reduce / all-gather sequence even in a world of ONE rank (they are
+        # copies then) -- the way to execute the RCCL code path, its streams and events on a single-GPU box
+        # (tests/test_gpu_backward.py); needs an initialised process group
+        self._multi = self.world > 1 or (bool(force_collectives) and dist.is_initialized())
         self.betas, self.eps = betas, eps
         # global gradient-norm clipping ("gradient_clipping": "auto" of config/ds_config.json:41 = the trainer's max_grad_norm;
         # torch.nn.utils.clip_grad_norm_ semantics on the MEAN gradient): every rank owns a piece of every bucket, so the
@@ -103,7 +109,7 @@ class Zero1AdamW:
         self._last_norm = None
         self.t = 0
         self.accum = max(1, int(gradient_accumulation_steps))
-        self.overlap = overlap_comm and self.world > 1
+        self.overlap = overlap_comm and self._multi
         plist = list(params)
         if plist and isinstance(plist[0], dict):
             self.param_groups = [{"lr": g.get("lr", lr), "weight_decay": g.get("weight_decay", weight_decay)} for g in plist]
@@ -126,7 +132,7 @@ class Zero1AdamW:
             nonlocal cur, offs, grp, n
             if cur:
                 pad = (-n) % self.world
-                self.buckets.append(_Bucket(cur, offs, grp, n + pad, cur[0].device, cur[0].dtype, self.world, self.rank))
+                self.buckets.append(_Bucket(cur, offs, grp, n + pad, cur[0].device, cur[0].dtype, self.world, self.rank, self._multi))
             cur, offs, grp, n = [], [], [], 0
 
         for p, gi in tagged:
@@ -149,7 +155,7 @@ class Zero1AdamW:
         # two staging buffers for the all-gathered bf16 parameters of a bucket (bucket i + 1 is updated while i is gathered)
         big = max(b.numel for b in self.buckets)
         b0 = self.buckets[0]
-        self._stage = [torch.empty(big, dtype=b0.flat_grad.dtype, device=b0.flat_grad.device) for _ in range(2 if self.world > 1 else 1)]
+        self._stage = [torch.empty(big, dtype=b0.flat_grad.dtype, device=b0.flat_grad.device) for _ in range(2 if self._multi else 1)]
         self._comm_stream = None
         self._use_rs = True          # dist.reduce_scatter_tensor; falls back to all_reduce + slice where unsupported (gloo)
         self._next_launch = 0        # buckets [0, _next_launch) have their reduce-scatter in flight / done for this step
@@ -189,7 +195,7 @@ class Zero1AdamW:
                 if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
                     view.add_(p.grad)
                 p.grad = view
-            if b.launched and self.world > 1:
+            if b.launched and self._multi:
                 raise RuntimeError("Zero1AdamW: a gradient arrived after its bucket was reduced -- the set of parameters that "
                                    "receive gradients changed between steps; construct with overlap_comm=False for such models")
             b.ready += 1
@@ -216,7 +222,7 @@ class Zero1AdamW:
             self._next_launch += 1
 
     def _launch_reduce(self, b: _Bucket):
-        if self.world == 1:
+        if not self._multi:
             return                                # my_grad IS flat_grad
         if b.work is not None:                    # (defensive: never leave a handle un-waited)
             self._finish_reduce(b)
@@ -300,20 +306,20 @@ class Zero1AdamW:
             # (one reduction kernel per bucket straight from the bf16 piece: no fp32 temporaries)
             sq = torch.stack([torch.linalg.vector_norm(b.my_grad[:b.piece], 2, dtype=torch.float32).pow(2)
                               for b in self.buckets]).sum() / (self.world * self.world)
-            if self.world > 1:
+            if self._multi:
                 dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=self.group)
             total = sq.sqrt()
             self._last_norm = total
             coef = torch.clamp(self.max_grad_norm / (total + 1e-6), max=1.0).reshape(1).float()
         cuda = self.buckets[0].flat_grad.is_cuda
         dev = self.buckets[0].flat_grad.device
-        if cuda and self.world > 1 and self._comm_stream is None:
+        if cuda and self._multi and self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(device=dev)
         stage_free = [None] * len(self._stage)
         for i, (b, st) in enumerate(zip(self.buckets, self.state)):
             self._finish_reduce(b)
             stage = self._stage[i % len(self._stage)]
-            if self.world == 1:
+            if not self._multi:
                 self._update_piece(b, st, stage[:b.numel], coef)
                 self._copy_out(b, stage)
             elif cuda:
@@ -336,7 +342,7 @@ class Zero1AdamW:
                 self._update_piece(b, st, mine, coef)
                 dist.all_gather_into_tensor(stage[:b.numel], mine.clone(), group=self.group)
                 self._copy_out(b, stage)
-        if cuda and self.world > 1:
+        if cuda and self._multi:
             torch.cuda.current_stream(dev).wait_stream(self._comm_stream)
         # the step owns the gradients: zero the buckets and re-arm
         for b in self.buckets:
@@ -394,7 +400,7 @@ class Zero1AdamW:
                 stage = self._stage[0]
                 mine = stage[self.rank * b.piece:(self.rank + 1) * b.piece]
                 mine.copy_(st["master"])
-                if self.world > 1:
+                if self._multi:
                     dist.all_gather_into_tensor(stage[:b.numel], mine.clone(), group=self.group)
                 self._copy_out(b, stage)
 
