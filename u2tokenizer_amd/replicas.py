@@ -14,8 +14,9 @@ def init_from_env(backend: Optional[str] = None, device: Optional[torch.device] 
     """Returns (dist module or None, rank, world). Reads RANK / WORLD_SIZE / MASTER_* set by torch.distributed.run."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world == 1:
-        return None, 0, 1
+    if world == 1 and os.environ.get("U2_REPLICAS_FORCE_DIST", "0") != "1":
+        return None, 0, 1   # (U2_REPLICAS_FORCE_DIST=1: a process group of one rank anyway -- runs the RCCL init / barrier /
+        #                      reductions of the N > 1 launch on a single-GPU box: tests/test_gpu_replicas.py)
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")
