@@ -23,5 +23,7 @@ run qkv_bt192 gemm 3 21
 run fc1_gelu128 gemmmlp 3 -1
 run skinny64 gemm256 16 0
 run flashbwd flashbwd 3
+run tokattn tokattn 5
+run prefillattn prefillattn 5
 run kmajor_dw kmajor 3
 cd $R && python tools/pmc_kernels.py $O > $R/gpurun_out/kernel_pmc.json && cat $R/gpurun_out/kernel_pmc.json | head -80

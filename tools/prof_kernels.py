@@ -1,5 +1,5 @@
 """Tiny driver for rocprofv3 counter passes:
-    python tools/prof_kernels.py flash|flashbwd|kmajor|gemm|gemm4k|gemm256|gemm8k|gemmmlp [iters] [gemm_big: -1 | 0 | 20 | 21] [flash_mode]
+    python tools/prof_kernels.py flash|flashbwd|kmajor|tokattn|prefillattn|gemm|gemm4k|gemm256|gemm8k|gemmmlp [iters] [gemm_big: -1 | 0 | 20 | 21] [flash_mode]
 gemm256 = the M = 256 query-side product of the TTA with 16 COLD weight matrices in rotation and split-K scratch, as the
 pipeline runs it (64 x 64 tiles, 4 K slices + reduce)."""
 import sys
@@ -26,6 +26,18 @@ elif what == "flashbwd":
     out = ops.flash_attention_d64(qkv, 12, 0.125, extra_last=True)
     for _ in range(iters):
         ops.flash_attention_d64_bwd(qkv, out, dout, 12, 0.125)
+elif what == "tokattn":
+    # the SVR's spatial attention core at E = 4096: 8 chunks, 8 heads of 512, 256 x 256, relative bias; packed q | k | v
+    E, H = 4096, 8
+    qkv = (torch.randn(8, 256, 3 * E, device="cuda") * 0.5).to(bf)
+    rb = (torch.randn(1023, H, device="cuda") * 0.1).to(bf)
+    for _ in range(iters):
+        ops.tok_attention(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], H, 512 ** -0.5, rel_bias=rb, max_len=512)
+elif what == "prefillattn":
+    # the decoder prefill's attention: 32 query / 8 key-value heads of 128, S = 1024, causal
+    qkv = (torch.randn(1, 1024, (32 + 16) * 128, device="cuda") * 0.5).to(bf)
+    for _ in range(iters):
+        ops.attention_gqa(qkv[..., :4096], qkv[..., 4096:5120], qkv[..., 5120:], 32, 8, 128 ** -0.5, causal=True)
 elif what == "kmajor":
     # the ViT's fc1 weight gradient: dW (3072, 768) = dY (16392, 3072)^T X (16392, 768), both operands K-major
     scratch = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
