@@ -302,6 +302,14 @@ int u2tok_tok_attention(const void* q, const void* k, const void* v, void* out, 
 int u2tok_attention_gqa(const void* q, const void* k, const void* v, void* out, int32_t nb, int32_t Sq, int32_t Skv, int32_t Hq,
                         int32_t Hkv, int32_t d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs,
                         int64_t v_bs, int64_t o_bs, float scale, int32_t causal, u2tok_stream_t stream);
+/* The same without the causal mask and WITH key splits (flash-decoding: partial results per key range in `workspace`, merged in a
+ * fixed order): the decode step's attention of a few query rows over a long KV cache -- nb = batch x kv heads entries of
+ * (Skv, d) keys, Hq = query heads per kv head, Hkv = 1 (Qwen3 / Llama decode, language_model/u2llama.py:123-126: generate()).
+ * workspace: u2tok_tok_attention_workspace_bytes(nb, Hq, Sq, Skv, d) bytes, 16-byte aligned; NULL = unsplit. */
+int u2tok_attention_gqa_split(const void* q, const void* k, const void* v, void* out, int32_t nb, int32_t Sq, int32_t Skv,
+                              int32_t Hq, int32_t Hkv, int32_t d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs,
+                              int64_t k_bs, int64_t v_bs, int64_t o_bs, float scale, void* workspace, size_t workspace_bytes,
+                              u2tok_stream_t stream);
 /* y[r] = bf16(x[r] * rsqrt(mean(x[r]^2) + eps)) * w   (LlamaRMSNorm / Qwen3RMSNorm); C % 8 == 0, C <= 8192 */
 int u2tok_rmsnorm_bf16(const void* x, const void* w, void* y, int64_t rows, int32_t C, int64_t ldx, int64_t ldy, float eps,
                        u2tok_stream_t stream);

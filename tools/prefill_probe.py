@@ -63,16 +63,19 @@ d = (out.logits[:, -1].float() - ref)
 print(f"same through u2tokenizer_amd.prefill (HIP layers): {ms2:.2f} ms ({flop / ms2 / 1e9:.0f} TFLOP/s), x{ms / ms2:.2f}; "
       f"last-position logits vs stock: rel rms {(d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item():.3e}")
 
-# what the NEXT row would be: the decode steps of generate() (eval/mrg.py asks for up to 768 new tokens) on the stock layers
+# the decode steps of generate() (eval/mrg.py asks for up to 768 new tokens): stock layers against the fused decode step
+from u2tokenizer_amd.prefill import disable_fused_prefill  # noqa: E402
 steps = 64
-for _ in range(1):
+for label, decode in (("stock HF layers", False), ("HIP layers (u2tokenizer_amd.prefill._decode_step)", True)):
+    disable_fused_prefill(m)
+    enable_fused_prefill(m, decode=decode)
     m.generate(inputs_embeds=x, max_new_tokens=4, do_sample=False)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-m.generate(inputs_embeds=x, max_new_tokens=steps + 1, min_new_tokens=steps + 1, do_sample=False)
-torch.cuda.synchronize()
-tg = (time.perf_counter() - t0) * 1e3
-print(f"generate(): prefill (HIP layers) + {steps} greedy decode steps on the stock HF layers: {tg:.0f} ms -> "
-      f"{(tg - ms3) / steps:.2f} ms per decode step (weights alone: {2 * nparam / 1e9:.1f} GB per step = "
-      f"{2 * nparam / 5e12 * 1e3:.1f} ms at 5 TB/s)")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m.generate(inputs_embeds=x, max_new_tokens=steps + 1, min_new_tokens=steps + 1, do_sample=False)
+    torch.cuda.synchronize()
+    tg = (time.perf_counter() - t0) * 1e3
+    print(f"generate(): prefill (HIP layers) + {steps} greedy decode steps on the {label}: {tg:.0f} ms -> "
+          f"{(tg - ms3) / steps:.2f} ms per decode step (weights alone: {2 * nparam / 1e9:.1f} GB per step = "
+          f"{2 * nparam / 5e12 * 1e3:.1f} ms at 5 TB/s)")
 

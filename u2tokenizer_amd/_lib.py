@@ -113,6 +113,8 @@ SIGNATURES = {
                                              _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp]),
     "u2tok_attention_gqa": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                    _i64, _f32, _i32, _vp]),
+    "u2tok_attention_gqa_split": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64,
+                                         _i64, _i64, _f32, _vp, _sz, _vp]),
     "u2tok_rmsnorm_bf16": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _f32, _vp]),
     "u2tok_qk_norm_rope": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i64, _i64, _f32, _vp]),
     "u2tok_qk_norm_rope_kv": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i64, _i64, _f32, _vp, _vp, _i32,

@@ -269,6 +269,13 @@ int u2tok_attention_gqa(const void* q, const void* k, const void* v, void* out, 
   return attention_ex(BF(q), BF(k), BF(v), BFW(out), nb, Sq, Skv, Hq, Hkv, d, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, scale,
                       nullptr, 0, causal, 1, nullptr, 0, ST(stream));
 }
+int u2tok_attention_gqa_split(const void* q, const void* k, const void* v, void* out, int32_t nb, int32_t Sq, int32_t Skv,
+                              int32_t Hq, int32_t Hkv, int32_t d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs,
+                              int64_t k_bs, int64_t v_bs, int64_t o_bs, float scale, void* workspace, size_t workspace_bytes,
+                              u2tok_stream_t stream) {
+  return attention_ex(BF(q), BF(k), BF(v), BFW(out), nb, Sq, Skv, Hq, Hkv, d, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, scale,
+                      nullptr, 0, 0, 0, workspace, workspace_bytes, ST(stream));
+}
 int u2tok_rmsnorm_bf16(const void* x, const void* w, void* y, int64_t rows, int32_t C, int64_t ldx, int64_t ldy, float eps,
                        u2tok_stream_t stream) {
   return rmsnorm_bf16(BF(x), BF(w), BFW(y), rows, C, ldx, ldy, eps, ST(stream));

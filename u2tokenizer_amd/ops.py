@@ -495,9 +495,11 @@ def tok_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
 # ---------------------------------------------------------------------------------- decoder prefill blocks (prefill.py)
 @_guarded
 def attention_gqa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, kv_heads: int, scale: float,
-                  causal: bool = True) -> torch.Tensor:
+                  causal: bool = True, split_keys: bool = False) -> torch.Tensor:
     """softmax(q k^T scale [+ causal mask]) v with grouped-query heads (u2tok_attention_gqa): q (nb, Sq, heads * d),
-    k / v (nb, Skv, kv_heads * d) -- views with a contiguous last dim -> (nb, Sq, heads * d)."""
+    k / v (nb, Skv, kv_heads * d) -- views with a contiguous last dim -> (nb, Sq, heads * d).
+    split_keys (not causal): key ranges on separate workgroups, merged in a fixed order (u2tok_attention_gqa_split) -- few
+    query rows over a long KV cache (decode steps)."""
     h = _lib.load_library()
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _need(t, torch.bfloat16, n)
@@ -509,6 +511,14 @@ def attention_gqa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
     if Eq % heads or k.shape != (nb, Skv, kv_heads * d) or v.shape != k.shape or heads % kv_heads:
         raise RuntimeError(f"attention_gqa: shapes {tuple(q.shape)}, {tuple(k.shape)}, {tuple(v.shape)}, heads {heads}/{kv_heads}")
     out = torch.empty((nb, Sq, Eq), dtype=torch.bfloat16, device=q.device)
+    if split_keys and not causal:
+        nbytes = h.u2tok_tok_attention_workspace_bytes(nb, heads, Sq, Skv, d)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=q.device)
+        _lib.check(h.u2tok_attention_gqa_split(_ptr(q), _ptr(k), _ptr(v), _ptr(out), nb, Sq, Skv, heads, kv_heads, d, q.stride(1),
+                                               k.stride(1), v.stride(1), Eq, q.stride(0), k.stride(0), v.stride(0), Sq * Eq,
+                                               float(scale), _ptr(ws) if nbytes else None, nbytes, _stream()),
+                   "u2tok_attention_gqa_split")
+        return out
     _lib.check(h.u2tok_attention_gqa(_ptr(q), _ptr(k), _ptr(v), _ptr(out), nb, Sq, Skv, heads, kv_heads, d, q.stride(1),
                                      k.stride(1), v.stride(1), Eq, q.stride(0), k.stride(0), v.stride(0), Sq * Eq,
                                      float(scale), int(bool(causal)), _stream()), "u2tok_attention_gqa")

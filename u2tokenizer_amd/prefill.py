@@ -71,10 +71,13 @@ def _layer_forward(self, hidden_states, *args, **kwargs):
     pe = kwargs.get("position_embeddings")
     cache = kwargs.get("past_key_values")
     att = self.self_attn
-    fused = (not args and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 3
-             and x.shape[1] > 1 and pe is not None and st["owner"]._u2_prefill_mask_ok
-             and getattr(att, "sliding_window", None) is None and att.head_dim in (64, 128)
-             and (cache is None or cache.get_seq_length(att.layer_idx) == 0))
+    common = (not args and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 3
+              and pe is not None and st["owner"]._u2_prefill_mask_ok
+              and getattr(att, "sliding_window", None) is None and att.head_dim in (64, 128))
+    if common and x.shape[1] == 1 and x.shape[0] <= 16 and st["owner"]._u2_fused_decode \
+            and _plain_dynamic_layer(cache, att.layer_idx) is not None:
+        return _decode_step(self, x, pe, cache)
+    fused = common and x.shape[1] > 1 and (cache is None or cache.get_seq_length(att.layer_idx) == 0)
     if not fused:
         return st["orig"](hidden_states, *args, **kwargs)
     B, S, E = x.shape
@@ -110,6 +113,62 @@ def _layer_forward(self, hidden_states, *args, **kwargs):
         if cache is not None:
             _cache_prefill(cache, kc, vc, att.layer_idx)
     return out.view(B, S, E)
+
+
+def _plain_dynamic_layer(cache, layer_idx: int):
+    """The cache layer if `cache` is a plain HF DynamicCache (no offloading) whose layer `layer_idx` is a non-empty DynamicLayer
+    -- the case the fused decode step handles (its `update` is a torch.cat: dense (B, H_kv, T, d) tensors come back)."""
+    try:
+        from transformers.cache_utils import DynamicCache, DynamicLayer
+    except ImportError:
+        return None
+    layers = getattr(cache, "layers", None)
+    if type(cache) is not DynamicCache or not isinstance(layers, list) or getattr(cache, "offloading", False) \
+            or layer_idx >= len(layers):
+        return None
+    lay = layers[layer_idx]
+    return lay if type(lay) is DynamicLayer and lay.get_seq_length() > 0 else None
+
+
+def _decode_step(self, x, pe, cache):
+    """One decode step of a layer (B <= 16 new tokens, one each, against the KV cache): the step `generate` repeats up to 768
+    times per report (eval/mrg.py:74-77).  Every product is weight streaming -- q|k|v, out, gate|up and down go through the
+    few-rows GEMM (gemm.hip: gemm_rows16_kernel, all loads of a wave in flight before its first MFMA) --, the attention is the
+    fused kernel with the KEYS split over workgroups (u2tok_attention_gqa_split: batch x kv-head entries of (T, d) keys, the
+    query heads of a group as its heads), 10 launches per layer instead of the stock layer's ~40."""
+    att = self.self_attn
+    B, _, E = x.shape
+    cfg = att.config
+    Hq, Hkv, d = cfg.num_attention_heads, cfg.num_key_value_heads, att.head_dim
+    g = Hq // Hkv
+    with ops.on_device(x):
+        Wqkv, bqkv = _pack((att.q_proj, att.k_proj, att.v_proj))
+        Wgu, bgu = _pack((self.mlp.gate_proj, self.mlp.up_proj))
+        x2 = x.reshape(B, E)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        cos, sin = pe
+        cos = cos.expand(B, 1, d).reshape(B, d)
+        sin = sin.expand(B, 1, d).reshape(B, d)
+        xn = ops.rmsnorm(x2, self.input_layernorm.weight, self.input_layernorm.variance_epsilon)
+        qkv = ops.gemm(xn, Wqkv, bias=bqkv)
+        qn, kn = getattr(att, "q_norm", None), getattr(att, "k_norm", None)
+        _, kc, vc = ops.qk_norm_rope(qkv, None if qn is None else qn.weight, None if kn is None else kn.weight, cos, sin, Hq, Hkv,
+                                     d, qn.variance_epsilon if qn is not None else 1e-6, kv_cache_seq=1)
+        K, V = cache.update(kc, vc, att.layer_idx)          # DynamicLayer: torch.cat -> dense (B, H_kv, T, d)
+        if not K.is_contiguous():
+            K = K.contiguous()
+        if not V.is_contiguous():
+            V = V.contiguous()
+        T = K.shape[2]
+        q = qkv[:, :Hq * d].reshape(B * Hkv, 1, g * d)       # query heads i g .. i g + g - 1 read kv head i (repeat_kv's order)
+        ctx = ops.attention_gqa(q, K.view(B * Hkv, T, d), V.view(B * Hkv, T, d), g, 1, float(att.scaling), causal=False,
+                                split_keys=True)
+        h = ops.gemm(ctx.view(B, Hq * d), att.o_proj.weight, bias=att.o_proj.bias, residual=x2)
+        hn = ops.rmsnorm(h, self.post_attention_layernorm.weight, self.post_attention_layernorm.variance_epsilon)
+        act = ops.swiglu(ops.gemm(hn, Wgu, bias=bgu))
+        out = ops.gemm(act, self.mlp.down_proj.weight, bias=self.mlp.down_proj.bias, residual=h)
+    return out.view(B, 1, E)
 
 
 def _cache_prefill(cache, keys, values, layer_idx: int) -> None:
@@ -148,9 +207,10 @@ def _mask_hook(module, args, kwargs):
     return None
 
 
-def enable_fused_prefill(model) -> int:
+def enable_fused_prefill(model, decode: bool = True) -> int:
     """Patch the decoder layers of an HF Llama / Qwen3 causal LM (u2LlamaForCausalLM / u2Qwen3ForCausalLM included) for the
-    fused prefill.  Idempotent; returns the number of layers patched.  `disable_fused_prefill` restores the stock forwards."""
+    fused prefill and (decode=True) the fused decode step.  Idempotent; returns the number of layers patched.
+    `disable_fused_prefill` restores the stock forwards."""
     base = model.get_model() if hasattr(model, "get_model") else getattr(model, "model", model)
     layers = getattr(base, "layers", None)
     if layers is None:
@@ -167,6 +227,7 @@ def enable_fused_prefill(model) -> int:
         layer._u2_prefill = {"orig": layer.forward, "owner": base}
         layer.forward = types.MethodType(_layer_forward, layer)
         n += 1
+    base._u2_fused_decode = bool(decode)
     if not hasattr(base, "_u2_prefill_hook"):
         base._u2_prefill_mask_ok = True
         base._u2_prefill_hook = base.register_forward_pre_hook(_mask_hook, with_kwargs=True)
