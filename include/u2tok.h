@@ -329,6 +329,28 @@ int u2tok_qk_norm_rope_kv(void* qkv, const void* wq, const void* wk, const void*
 int u2tok_swiglu_bf16(const void* gate_up, void* out, int64_t rows, int32_t I, int64_t ld_in, int64_t ld_out,
                       u2tok_stream_t stream);
 
+/* ---- one decode step of a decoder layer (the step HF generate() repeats per new token: language_model/u2llama.py:123-126,
+ * eval/mrg.py:74-77 asks for up to 768) in two calls -- between them the host appends the new k / v to its KV cache.
+ *   pre : input RMSNorm -> packed q|k|v projection (few-rows GEMM) -> per-head q / k RMSNorm (NULL weights: none) + rotary;
+ *         qkv (B, (Hq + 2 Hkv) D) keeps the finished queries, k_new / v_new (B, Hkv, 1, D) are the cache entries of the step
+ *   post: attention of the B query rows over the cache K / V (B, Hkv, T, D dense; keys split over workgroups, merged in a
+ *         fixed order) -> out projection + residual x -> RMSNorm -> packed gate|up -> SiLU(gate) * up -> down + residual
+ * B <= 16, D in {64, 128}, E % 32 == 0, I % 32 == 0; biases may be NULL; same rounding points as the HF modules in bf16.
+ * One workspace for both calls: u2tok_decoder_decode_workspace_bytes(cfg, T) bytes. */
+typedef struct u2tok_decode_config {
+  int32_t B, E, Hq, Hkv, D, I; /* new tokens (= batch), hidden size, query / key-value heads, head dim, MLP width */
+  float eps, qk_eps, scale;    /* RMSNorm eps, q / k norm eps, softmax scale */
+} u2tok_decode_config;
+size_t u2tok_decoder_decode_workspace_bytes(const u2tok_decode_config* cfg, int32_t T);
+int u2tok_decoder_decode_pre(const u2tok_decode_config* cfg, const void* x, const void* w_in_norm, const void* Wqkv,
+                             const void* bqkv, const void* wq_norm, const void* wk_norm, const void* cos, const void* sin,
+                             int32_t cos_sin_f32, int64_t cs_ld, void* qkv, void* k_new, void* v_new, void* workspace,
+                             size_t workspace_bytes, u2tok_stream_t stream);
+int u2tok_decoder_decode_post(const u2tok_decode_config* cfg, const void* x, const void* qkv, const void* K, const void* V,
+                              int32_t T, const void* Wo, const void* bo, const void* w_post_norm, const void* Wgu,
+                              const void* bgu, const void* Wdown, const void* bdown, void* out, void* workspace,
+                              size_t workspace_bytes, u2tok_stream_t stream);
+
 /* in-place rotate-half RoPE (rope.py:6-13,77-80): rows indexed (outer, s, inner), position = s; inverse != 0 rotates
  * the other way (the backward of the rotation) */
 int u2tok_rope_apply(void* x, int64_t n_outer, int32_t S, int32_t n_inner, int32_t H, int32_t d, int64_t ld,

@@ -52,6 +52,11 @@ class TokConfig(C.Structure):
                 ("ln_eps", C.c_float)]
 
 
+class DecodeConfig(C.Structure):   # u2tok_decode_config
+    _fields_ = [("B", C.c_int32), ("E", C.c_int32), ("Hq", C.c_int32), ("Hkv", C.c_int32), ("D", C.c_int32), ("I", C.c_int32),
+                ("eps", C.c_float), ("qk_eps", C.c_float), ("scale", C.c_float)]
+
+
 class TokTaps(C.Structure):
     _fields_ = [("svr_in", C.POINTER(C.c_void_p)), ("svr_out", C.POINTER(C.c_void_p)), ("visual_in", C.c_void_p),
                 ("visual_out", C.c_void_p), ("tta_in", C.POINTER(C.c_void_p)), ("tta_out", C.POINTER(C.c_void_p))]
@@ -120,6 +125,9 @@ SIGNATURES = {
     "u2tok_qk_norm_rope_kv": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i64, _i64, _f32, _vp, _vp, _i32,
                                      _vp]),
     "u2tok_swiglu_bf16": (_i32, [_vp, _vp, _i64, _i32, _i64, _i64, _vp]),
+    "u2tok_decoder_decode_workspace_bytes": (_sz, [_vp, _i32]),
+    "u2tok_decoder_decode_pre": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "u2tok_decoder_decode_post": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "u2tok_rope_apply": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i64, _i32, _i32, _vp]),
     "u2tok_gelu_fwd": (_i32, [_vp, _vp, _i64, _vp]),
     "u2tok_gelu_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp]),

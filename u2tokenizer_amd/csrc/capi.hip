@@ -293,6 +293,35 @@ int u2tok_qk_norm_rope_kv(void* qkv, const void* wq, const void* wk, const void*
   return qk_norm_rope(BFW(qkv), BF(wq), BF(wk), cos, sin, cos_sin_f32, rows, Hq, Hkv, D, ld, cs_ld, eps, BFW(k_cache),
                       BFW(v_cache), S, ST(stream));
 }
+static DecodeCfg dec_cfg(const u2tok_decode_config* c) {
+  DecodeCfg d;
+  d.B = c->B; d.E = c->E; d.Hq = c->Hq; d.Hkv = c->Hkv; d.D = c->D; d.I = c->I;
+  d.eps = c->eps; d.qk_eps = c->qk_eps; d.scale = c->scale;
+  return d;
+}
+static bool dec_ok(const u2tok_decode_config* c) {
+  return c && c->B > 0 && c->B <= 16 && c->E > 0 && !(c->E & 31) && c->Hq > 0 && c->Hkv > 0 && c->Hq % c->Hkv == 0 &&
+         (c->D == 64 || c->D == 128) && c->I > 0 && !(c->I & 31);
+}
+size_t u2tok_decoder_decode_workspace_bytes(const u2tok_decode_config* c, int32_t T) {
+  return dec_ok(c) && T > 0 ? decoder_decode_workspace_bytes(dec_cfg(c), T) : 0;
+}
+int u2tok_decoder_decode_pre(const u2tok_decode_config* c, const void* x, const void* w_in_norm, const void* Wqkv, const void* bqkv,
+                             const void* wq_norm, const void* wk_norm, const void* cos, const void* sin, int32_t cos_sin_f32,
+                             int64_t cs_ld, void* qkv, void* k_new, void* v_new, void* workspace, size_t workspace_bytes,
+                             u2tok_stream_t stream) {
+  if (!dec_ok(c)) return U2_ERR_ARG;
+  return decoder_decode_pre(dec_cfg(c), BF(x), BF(w_in_norm), BF(Wqkv), BF(bqkv), BF(wq_norm), BF(wk_norm), cos, sin, cos_sin_f32,
+                            cs_ld, BFW(qkv), BFW(k_new), BFW(v_new), workspace, workspace_bytes, ST(stream));
+}
+int u2tok_decoder_decode_post(const u2tok_decode_config* c, const void* x, const void* qkv, const void* K, const void* V, int32_t T,
+                              const void* Wo, const void* bo, const void* w_post_norm, const void* Wgu, const void* bgu,
+                              const void* Wdown, const void* bdown, void* out, void* workspace, size_t workspace_bytes,
+                              u2tok_stream_t stream) {
+  if (!dec_ok(c)) return U2_ERR_ARG;
+  return decoder_decode_post(dec_cfg(c), BF(x), BF(qkv), BF(K), BF(V), T, BF(Wo), BF(bo), BF(w_post_norm), BF(Wgu), BF(bgu),
+                             BF(Wdown), BF(bdown), BFW(out), workspace, workspace_bytes, ST(stream));
+}
 int u2tok_swiglu_bf16(const void* gate_up, void* out, int64_t rows, int32_t I, int64_t ld_in, int64_t ld_out,
                       u2tok_stream_t stream) {
   return swiglu_bf16(BF(gate_up), BFW(out), rows, I, ld_in, ld_out, ST(stream));

@@ -188,4 +188,78 @@ int swiglu_bf16(const bf16_t* gu, bf16_t* out, int64_t rows, int I, int64_t ld_i
   return launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------ one decode step of a layer
+// The two halves of a decoder layer's decode step (B <= 16 new tokens against the KV cache), each ONE call for the host: the
+// step `generate` repeats up to 768 times per report is bound by the host's launch rate when every kernel is its own Python
+// call (7.9 ms per step of a 36-layer decoder, ~4 ms of kernels).  Between the halves the host appends k / v to its cache
+// (HF DynamicCache: a torch.cat) and hands back the dense (B, H_kv, T, D) tensors.
+static int dec_linear(const bf16_t* x, int64_t ldx, const bf16_t* w, const bf16_t* b, bf16_t* y, int64_t ldy, int rows, int in,
+                      int out, const bf16_t* R, int64_t ldr, hipStream_t st) {
+  GemmDesc g;
+  g.A = x; g.B = w; g.C = y; g.bias = b; g.R = R;
+  g.M = rows; g.N = out; g.K = in;
+  g.lda = ldx; g.ldb = in; g.ldc = ldy; g.ldr = ldr;
+  g.flags = (b ? GEMM_BIAS_N : 0) | (R ? GEMM_RESIDUAL : 0);
+  return gemm_bf16(g, st);
+}
+
+size_t decoder_decode_workspace_bytes(const DecodeCfg& c, int T) {
+  const size_t rows = (size_t)c.B;
+  size_t n = rows * ((size_t)3 * c.E + (size_t)c.Hq * c.D + (size_t)3 * c.I) * sizeof(bf16_t);  // xn, h, hn | ctx | gu (2 I), act
+  n = (n + 255) & ~(size_t)255;
+  return n + tok_attention_workspace_bytes(c.Hkv, c.Hq / c.Hkv, 1, T, c.D) + 256;
+}
+
+// input RMSNorm -> q|k|v projection -> per-head RMSNorm + rotary; qkv (B, (Hq + 2 Hkv) D) keeps the finished queries, kc / vc
+// (B, Hkv, 1, D) receive the new cache entries
+int decoder_decode_pre(const DecodeCfg& c, const bf16_t* x, const bf16_t* w_in_norm, const bf16_t* Wqkv, const bf16_t* bqkv,
+                       const bf16_t* wq_norm, const bf16_t* wk_norm, const void* cosp, const void* sinp, int cs_is_f32,
+                       int64_t cs_ld, bf16_t* qkv, bf16_t* kc, bf16_t* vc, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (c.B <= 0 || c.B > 16 || c.Hkv <= 0 || c.Hq % c.Hkv || !x || !w_in_norm || !Wqkv || !qkv || !kc || !vc || !ws) return U2_ERR_ARG;
+  if (ws_bytes < (size_t)c.B * c.E * sizeof(bf16_t)) return U2_ERR_WORKSPACE;
+  bf16_t* xn = reinterpret_cast<bf16_t*>(ws);
+  const int nq = (c.Hq + 2 * c.Hkv) * c.D;
+  int e = rmsnorm_bf16(x, w_in_norm, xn, c.B, c.E, c.E, c.E, c.eps, st);
+  if (e != U2_OK) return e;
+  e = dec_linear(xn, c.E, Wqkv, bqkv, qkv, nq, c.B, c.E, nq, nullptr, 0, st);
+  if (e != U2_OK) return e;
+  return qk_norm_rope(qkv, wq_norm, wk_norm, cosp, sinp, cs_is_f32, c.B, c.Hq, c.Hkv, c.D, nq, cs_ld, c.qk_eps, kc, vc, 1, st);
+}
+
+// attention over the cache (keys split over workgroups) -> out projection + residual -> RMSNorm -> gate|up -> SwiGLU -> down
+// projection + residual.  K / V: (B, Hkv, T, D) dense; out (B, E).
+int decoder_decode_post(const DecodeCfg& c, const bf16_t* x, const bf16_t* qkv, const bf16_t* K, const bf16_t* V, int T,
+                        const bf16_t* Wo, const bf16_t* bo, const bf16_t* w_post_norm, const bf16_t* Wgu, const bf16_t* bgu,
+                        const bf16_t* Wdown, const bf16_t* bdown, bf16_t* out, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (c.B <= 0 || c.B > 16 || T <= 0 || !x || !qkv || !K || !V || !Wo || !w_post_norm || !Wgu || !Wdown || !out || !ws) return U2_ERR_ARG;
+  if (ws_bytes < decoder_decode_workspace_bytes(c, T)) return U2_ERR_WORKSPACE;
+  const int g = c.Hq / c.Hkv, nq = (c.Hq + 2 * c.Hkv) * c.D, qd = c.Hq * c.D;
+  bf16_t* p = reinterpret_cast<bf16_t*>(ws);
+  bf16_t* h = p + (size_t)c.B * c.E;          // (xn of the first half lives at p)
+  bf16_t* hn = h + (size_t)c.B * c.E;
+  bf16_t* ctx = hn + (size_t)c.B * c.E;
+  bf16_t* gu = ctx + (size_t)c.B * qd;
+  bf16_t* act = gu + (size_t)c.B * 2 * c.I;
+  size_t used = ((size_t)c.B * ((size_t)3 * c.E + qd + (size_t)3 * c.I) * sizeof(bf16_t) + 255) & ~(size_t)255;
+  char* aws = reinterpret_cast<char*>(ws) + used;
+  const size_t aws_bytes = ws_bytes - used;
+  const float scale = c.scale;
+  for (int b = 0; b < c.B; ++b) {  // entries of one batch element: its kv heads; the g query heads of a group are the "heads"
+    const int e = attention_ex(qkv + (size_t)b * nq, K + (size_t)b * c.Hkv * T * c.D, V + (size_t)b * c.Hkv * T * c.D,
+                               ctx + (size_t)b * qd, c.Hkv, 1, T, g, 1, c.D, /*ldq*/ (int64_t)g * c.D, /*ldk*/ c.D, /*ldv*/ c.D,
+                               /*ldo*/ (int64_t)g * c.D, /*q_bs*/ (int64_t)g * c.D, /*k_bs*/ (int64_t)T * c.D,
+                               /*v_bs*/ (int64_t)T * c.D, /*o_bs*/ (int64_t)g * c.D, scale, nullptr, 0, 0, 0, aws, aws_bytes, st);
+    if (e != U2_OK) return e;
+  }
+  int e = dec_linear(ctx, qd, Wo, bo, h, c.E, c.B, qd, c.E, x, c.E, st);
+  if (e != U2_OK) return e;
+  e = rmsnorm_bf16(h, w_post_norm, hn, c.B, c.E, c.E, c.E, c.eps, st);
+  if (e != U2_OK) return e;
+  e = dec_linear(hn, c.E, Wgu, bgu, gu, 2 * c.I, c.B, c.E, 2 * c.I, nullptr, 0, st);
+  if (e != U2_OK) return e;
+  e = swiglu_bf16(gu, act, c.B, c.I, 2 * c.I, c.I, st);
+  if (e != U2_OK) return e;
+  return dec_linear(act, c.I, Wdown, bdown, out, c.E, c.B, c.I, c.E, h, c.E, st);
+}
+
 }  // namespace u2

@@ -76,7 +76,9 @@ def _layer_forward(self, hidden_states, *args, **kwargs):
               and getattr(att, "sliding_window", None) is None and att.head_dim in (64, 128))
     if common and x.shape[1] == 1 and x.shape[0] <= 16 and st["owner"]._u2_fused_decode \
             and _plain_dynamic_layer(cache, att.layer_idx) is not None:
-        return _decode_step(self, x, pe, cache)
+        out = _decode_step(self, x, pe, cache)
+        if out is not None:
+            return out
     fused = common and x.shape[1] > 1 and (cache is None or cache.get_seq_length(att.layer_idx) == 0)
     if not fused:
         return st["orig"](hidden_states, *args, **kwargs)
@@ -130,45 +132,89 @@ def _plain_dynamic_layer(cache, layer_idx: int):
     return lay if type(lay) is DynamicLayer and lay.get_seq_length() > 0 else None
 
 
+def _decode_state(self, B: int, device):
+    """Per-layer constants of the decode step (weight pointers of the packed projections, the config struct), rebuilt when a
+    weight moved; per-model scratch (workspace, q|k|v row, new cache entries) shared by all layers."""
+    import ctypes as C
+    from . import _lib
+    st = self._u2_prefill
+    att, mlp = self.self_attn, self.mlp
+    key = (att.q_proj.weight.data_ptr(), mlp.gate_proj.weight.data_ptr(), att.o_proj.weight.data_ptr(),
+           mlp.down_proj.weight.data_ptr(), B)
+    d = st.get("dec")
+    if d is None or d["key"] != key:
+        cfg = att.config
+        Hq, Hkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, att.head_dim
+        Wqkv, bqkv = _pack((att.q_proj, att.k_proj, att.v_proj))
+        Wgu, bgu = _pack((mlp.gate_proj, mlp.up_proj))
+        qn, kn = getattr(att, "q_norm", None), getattr(att, "k_norm", None)
+        E, inter = Wqkv.shape[1], Wgu.shape[0] // 2
+        c = _lib.DecodeConfig(B=B, E=E, Hq=Hq, Hkv=Hkv, D=hd, I=inter, eps=float(self.input_layernorm.variance_epsilon),
+                              qk_eps=float(qn.variance_epsilon) if qn is not None else 1e-6, scale=float(att.scaling))
+        ok = (E % 32 == 0 and inter % 32 == 0 and att.o_proj.weight.is_contiguous() and mlp.down_proj.weight.is_contiguous()
+              and self.post_attention_layernorm.variance_epsilon == self.input_layernorm.variance_epsilon)
+        p = ops._ptr
+        d = {"key": key, "ok": ok, "cfg": c, "cfg_ref": C.byref(c), "keep": (Wqkv, bqkv, Wgu, bgu), "nq": (Hq + 2 * Hkv) * hd,
+             "Hkv": Hkv, "hd": hd, "E": E,
+             "pre": (p(self.input_layernorm.weight), p(Wqkv), p(bqkv), p(None if qn is None else qn.weight),
+                     p(None if kn is None else kn.weight)),
+             "post": (p(att.o_proj.weight), p(att.o_proj.bias), p(self.post_attention_layernorm.weight), p(Wgu), p(bgu),
+                      p(mlp.down_proj.weight), p(mlp.down_proj.bias))}
+        st["dec"] = d
+    owner = st["owner"]
+    sc = owner.__dict__.get("_u2_decode_scratch")
+    if sc is None or sc["B"] != B or sc["device"] != device:
+        sc = {"B": B, "device": device, "ws": None, "T": 0,
+              "qkv": torch.empty((B, d["nq"]), dtype=torch.bfloat16, device=device),
+              "kc": torch.empty((B, d["Hkv"], 1, d["hd"]), dtype=torch.bfloat16, device=device),
+              "vc": torch.empty((B, d["Hkv"], 1, d["hd"]), dtype=torch.bfloat16, device=device)}
+        owner.__dict__["_u2_decode_scratch"] = sc
+    return d, sc
+
+
 def _decode_step(self, x, pe, cache):
     """One decode step of a layer (B <= 16 new tokens, one each, against the KV cache): the step `generate` repeats up to 768
     times per report (eval/mrg.py:74-77).  Every product is weight streaming -- q|k|v, out, gate|up and down go through the
     few-rows GEMM (gemm.hip: gemm_rows16_kernel, all loads of a wave in flight before its first MFMA) --, the attention is the
-    fused kernel with the KEYS split over workgroups (u2tok_attention_gqa_split: batch x kv-head entries of (T, d) keys, the
-    query heads of a group as its heads), 10 launches per layer instead of the stock layer's ~40."""
+    fused kernel with the KEYS split over workgroups (batch x kv-head entries of (T, d) keys, the query heads of a group as its
+    heads).  TWO library calls per layer (u2tok_decoder_decode_pre / _post, 10 launches) around the cache's own `update`: with a
+    Python call per kernel the step was bound by the host (7.9 ms against ~4 ms of kernels)."""
+    from . import _lib
     att = self.self_attn
     B, _, E = x.shape
-    cfg = att.config
-    Hq, Hkv, d = cfg.num_attention_heads, cfg.num_key_value_heads, att.head_dim
-    g = Hq // Hkv
-    with ops.on_device(x):
-        Wqkv, bqkv = _pack((att.q_proj, att.k_proj, att.v_proj))
-        Wgu, bgu = _pack((self.mlp.gate_proj, self.mlp.up_proj))
+    d, sc = _decode_state(self, B, x.device)
+    if not d["ok"]:
+        return None                                   # (the caller takes the stock layer)
+    hd = d["hd"]
+    with ops.on_device(x) as (h, stream):
         x2 = x.reshape(B, E)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         cos, sin = pe
-        cos = cos.expand(B, 1, d).reshape(B, d)
-        sin = sin.expand(B, 1, d).reshape(B, d)
-        xn = ops.rmsnorm(x2, self.input_layernorm.weight, self.input_layernorm.variance_epsilon)
-        qkv = ops.gemm(xn, Wqkv, bias=bqkv)
-        qn, kn = getattr(att, "q_norm", None), getattr(att, "k_norm", None)
-        _, kc, vc = ops.qk_norm_rope(qkv, None if qn is None else qn.weight, None if kn is None else kn.weight, cos, sin, Hq, Hkv,
-                                     d, qn.variance_epsilon if qn is not None else 1e-6, kv_cache_seq=1)
-        K, V = cache.update(kc, vc, att.layer_idx)          # DynamicLayer: torch.cat -> dense (B, H_kv, T, d)
+        cos = cos.expand(B, 1, hd).reshape(B, hd)
+        sin = sin.expand(B, 1, hd).reshape(B, hd)
+        if cos.dtype != sin.dtype or cos.dtype not in (torch.float32, torch.bfloat16) or cos.stride(1) != 1 or sin.stride(1) != 1 \
+                or cos.stride(0) != sin.stride(0):
+            cos, sin = cos.float().contiguous(), sin.float().contiguous()
+        T1 = cache.get_seq_length(att.layer_idx) + 1
+        if sc["ws"] is None or sc["T"] < T1:
+            Tcap = max(2048, 2 * T1)                      # (grows geometrically: the workspace depends on T through the key splits)
+            d["cfg"].B = B
+            sc["ws"] = torch.empty(h.u2tok_decoder_decode_workspace_bytes(d["cfg_ref"], Tcap), dtype=torch.uint8, device=x.device)
+            sc["T"] = Tcap
+        ws, nws = sc["ws"].data_ptr(), sc["ws"].numel()
+        _lib.check(h.u2tok_decoder_decode_pre(d["cfg_ref"], x2.data_ptr(), *d["pre"], cos.data_ptr(), sin.data_ptr(),
+                                              int(cos.dtype == torch.float32), cos.stride(0), sc["qkv"].data_ptr(),
+                                              sc["kc"].data_ptr(), sc["vc"].data_ptr(), ws, nws, stream), "u2tok_decoder_decode_pre")
+        K, V = cache.update(sc["kc"], sc["vc"], att.layer_idx)   # DynamicLayer: torch.cat -> dense (B, H_kv, T, d)
         if not K.is_contiguous():
             K = K.contiguous()
         if not V.is_contiguous():
             V = V.contiguous()
-        T = K.shape[2]
-        q = qkv[:, :Hq * d].reshape(B * Hkv, 1, g * d)       # query heads i g .. i g + g - 1 read kv head i (repeat_kv's order)
-        ctx = ops.attention_gqa(q, K.view(B * Hkv, T, d), V.view(B * Hkv, T, d), g, 1, float(att.scaling), causal=False,
-                                split_keys=True)
-        h = ops.gemm(ctx.view(B, Hq * d), att.o_proj.weight, bias=att.o_proj.bias, residual=x2)
-        hn = ops.rmsnorm(h, self.post_attention_layernorm.weight, self.post_attention_layernorm.variance_epsilon)
-        act = ops.swiglu(ops.gemm(hn, Wgu, bias=bgu))
-        out = ops.gemm(act, self.mlp.down_proj.weight, bias=self.mlp.down_proj.bias, residual=h)
-    return out.view(B, 1, E)
+        out = torch.empty((B, 1, E), dtype=torch.bfloat16, device=x.device)
+        _lib.check(h.u2tok_decoder_decode_post(d["cfg_ref"], x2.data_ptr(), sc["qkv"].data_ptr(), K.data_ptr(), V.data_ptr(),
+                                               K.shape[2], *d["post"], out.data_ptr(), ws, nws, stream), "u2tok_decoder_decode_post")
+    return out
 
 
 def _cache_prefill(cache, keys, values, layer_idx: int) -> None:
