@@ -320,11 +320,13 @@ int u2tok_qk_norm_rope(void* qkv, const void* wq, const void* wk, const void* co
                        int64_t rows, int32_t Hq, int32_t Hkv, int32_t D, int64_t ld, int64_t cs_ld, float eps,
                        u2tok_stream_t stream);
 /* The same, and the finished k heads and the v heads also written in the KV cache's layout: k_cache / v_cache
- * [rows / S][Hkv][S][D] dense bf16 (HF DynamicLayer: (batch, kv heads, seq, head_dim); row = batch * S + position), so the
- * prefill hands the cache its tensors without a transposing copy (language_model/u2llama.py:123-126: generate()). */
+ * [rows / S][Hkv][capacity][D] bf16 (HF DynamicLayer: (batch, kv heads, seq, head_dim); row = batch * S + position) at positions
+ * s_off .. s_off + S - 1, kv_stride = capacity * D elements between (batch, kv head) entries (0: dense, capacity = S) -- the
+ * prefill hands the cache its tensors without a transposing copy, a decode step appends in place
+ * (language_model/u2llama.py:123-126: generate()). */
 int u2tok_qk_norm_rope_kv(void* qkv, const void* wq, const void* wk, const void* cos, const void* sin, int32_t cos_sin_f32,
                           int64_t rows, int32_t Hq, int32_t Hkv, int32_t D, int64_t ld, int64_t cs_ld, float eps,
-                          void* k_cache, void* v_cache, int32_t S, u2tok_stream_t stream);
+                          void* k_cache, void* v_cache, int32_t S, int64_t kv_stride, int32_t s_off, u2tok_stream_t stream);
 /* out[r][i] = bf16(silu(gate_up[r][i])) * gate_up[r][I + i]   (LlamaMLP / Qwen3MLP with gate | up packed); I % 8 == 0 */
 int u2tok_swiglu_bf16(const void* gate_up, void* out, int64_t rows, int32_t I, int64_t ld_in, int64_t ld_out,
                       u2tok_stream_t stream);
@@ -332,9 +334,10 @@ int u2tok_swiglu_bf16(const void* gate_up, void* out, int64_t rows, int32_t I, i
 /* ---- one decode step of a decoder layer (the step HF generate() repeats per new token: language_model/u2llama.py:123-126,
  * eval/mrg.py:74-77 asks for up to 768) in two calls -- between them the host appends the new k / v to its KV cache.
  *   pre : input RMSNorm -> packed q|k|v projection (few-rows GEMM) -> per-head q / k RMSNorm (NULL weights: none) + rotary;
- *         qkv (B, (Hq + 2 Hkv) D) keeps the finished queries, k_new / v_new (B, Hkv, 1, D) are the cache entries of the step
- *   post: attention of the B query rows over the cache K / V (B, Hkv, T, D dense; keys split over workgroups, merged in a
- *         fixed order) -> out projection + residual x -> RMSNorm -> packed gate|up -> SiLU(gate) * up -> down + residual
+ *         qkv (B, (Hq + 2 Hkv) D) keeps the finished queries; the step's keys / values go to position s_off of k_cache / v_cache
+ *         (B, Hkv, capacity, D; kv_stride = capacity * D, 0: a dense (B, Hkv, 1, D) pair with s_off = 0)
+ *   post: attention of the B query rows over the first T positions of K / V (same layout; keys split over workgroups, merged
+ *         in a fixed order) -> out projection + residual x -> RMSNorm -> packed gate|up -> SiLU(gate) * up -> down + residual
  * B <= 16, D in {64, 128}, E % 32 == 0, I % 32 == 0; biases may be NULL; same rounding points as the HF modules in bf16.
  * One workspace for both calls: u2tok_decoder_decode_workspace_bytes(cfg, T) bytes. */
 typedef struct u2tok_decode_config {
@@ -344,10 +347,10 @@ typedef struct u2tok_decode_config {
 size_t u2tok_decoder_decode_workspace_bytes(const u2tok_decode_config* cfg, int32_t T);
 int u2tok_decoder_decode_pre(const u2tok_decode_config* cfg, const void* x, const void* w_in_norm, const void* Wqkv,
                              const void* bqkv, const void* wq_norm, const void* wk_norm, const void* cos, const void* sin,
-                             int32_t cos_sin_f32, int64_t cs_ld, void* qkv, void* k_new, void* v_new, void* workspace,
-                             size_t workspace_bytes, u2tok_stream_t stream);
+                             int32_t cos_sin_f32, int64_t cs_ld, void* qkv, void* k_cache, void* v_cache, int64_t kv_stride,
+                             int32_t s_off, void* workspace, size_t workspace_bytes, u2tok_stream_t stream);
 int u2tok_decoder_decode_post(const u2tok_decode_config* cfg, const void* x, const void* qkv, const void* K, const void* V,
-                              int32_t T, const void* Wo, const void* bo, const void* w_post_norm, const void* Wgu,
+                              int32_t T, int64_t kv_stride, const void* Wo, const void* bo, const void* w_post_norm, const void* Wgu,
                               const void* bgu, const void* Wdown, const void* bdown, void* out, void* workspace,
                               size_t workspace_bytes, u2tok_stream_t stream);
 

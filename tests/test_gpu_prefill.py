@@ -79,6 +79,15 @@ def test_qk_norm_rope(ops, rows, Hq, Hkv, d, norm, f32):
         assert r[1].is_contiguous() and r[1].shape == (rows // S, Hkv, S, d)
         assert torch.equal(r[1], g4[:, :, Hq:Hq + Hkv].transpose(1, 2))
         assert torch.equal(r[2], g4[:, :, Hq + Hkv:].transpose(1, 2))
+        # ... and into the middle of larger (batch, kv heads, capacity, d) buffers: an append-in-place cache
+        cap, pos = S + 7, 3
+        kb = torch.full((rows // S, Hkv, cap, d), 7.0, dtype=bf, device=D)
+        vb = torch.full((rows // S, Hkv, cap, d), 7.0, dtype=bf, device=D)
+        got3 = qkv.to(D)
+        ops.qk_norm_rope(got3, wq.to(D) if norm else None, wk.to(D) if norm else None, cos.to(D), sin.to(D), Hq, Hkv, d, 1e-6,
+                         kv_cache_seq=S, kv_out=(kb, vb), kv_pos=pos)
+        assert torch.equal(kb[:, :, pos:pos + S], r[1]) and torch.equal(vb[:, :, pos:pos + S], r[2])
+        assert (kb[:, :, :pos] == 7).all() and (kb[:, :, pos + S:] == 7).all() and (vb[:, :, pos + S:] == 7).all()
 
 
 def test_swiglu(ops):

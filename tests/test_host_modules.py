@@ -188,3 +188,28 @@ def test_frozen_tower_feature_sharing_logic():
     tower(img + 1)
     assert len(calls) == 6
 
+
+def test_append_in_place_cache_layer_behaves_like_dynamic_layer():
+    """prefill._append_layer_class(): the KV-cache layer the fused prefill installs in a plain DynamicCache -- appends in place into
+    doubling buffers; every observable (returned keys / values, lengths, crop, batch selection followed by further updates) equals
+    HF's DynamicLayer, whose `update` is a torch.cat."""
+    from transformers.cache_utils import DynamicLayer
+    from u2tokenizer_amd.prefill import _append_layer_class
+    a, d = _append_layer_class()(), DynamicLayer()
+    g = torch.Generator().manual_seed(0)
+
+    def step(B, n):
+        k, v = torch.randn(B, 3, n, 8, generator=g), torch.randn(B, 3, n, 8, generator=g)
+        (ka, va), (kd, vd) = a.update(k, v), d.update(k, v)
+        assert torch.equal(ka, kd) and torch.equal(va, vd) and a.get_seq_length() == d.get_seq_length()
+
+    for n in (5, 1, 1, 300, 1, 1):
+        step(2, n)
+    assert a._kb.shape[2] >= 309 and a.keys.data_ptr() == a._kb.data_ptr()      # in place: a view of the buffer
+    a.crop(-2), d.crop(-2)
+    step(2, 1)
+    a.batch_select_indices(torch.tensor([1])), d.batch_select_indices(torch.tensor([1]))
+    step(1, 2)
+    a.batch_repeat_interleave(3), d.batch_repeat_interleave(3)
+    step(3, 1)
+

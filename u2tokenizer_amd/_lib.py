@@ -123,11 +123,13 @@ SIGNATURES = {
     "u2tok_rmsnorm_bf16": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _f32, _vp]),
     "u2tok_qk_norm_rope": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i64, _i64, _f32, _vp]),
     "u2tok_qk_norm_rope_kv": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i64, _i64, _f32, _vp, _vp, _i32,
-                                     _vp]),
+                                     _i64, _i32, _vp]),
     "u2tok_swiglu_bf16": (_i32, [_vp, _vp, _i64, _i32, _i64, _i64, _vp]),
     "u2tok_decoder_decode_workspace_bytes": (_sz, [_vp, _i32]),
-    "u2tok_decoder_decode_pre": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "u2tok_decoder_decode_post": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "u2tok_decoder_decode_pre": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i64, _i32, _vp,
+                                        _sz, _vp]),
+    "u2tok_decoder_decode_post": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                                         _vp]),
     "u2tok_rope_apply": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i64, _i32, _i32, _vp]),
     "u2tok_gelu_fwd": (_i32, [_vp, _vp, _i64, _vp]),
     "u2tok_gelu_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp]),

@@ -283,15 +283,15 @@ int u2tok_rmsnorm_bf16(const void* x, const void* w, void* y, int64_t rows, int3
 int u2tok_qk_norm_rope(void* qkv, const void* wq, const void* wk, const void* cos, const void* sin, int32_t cos_sin_f32,
                        int64_t rows, int32_t Hq, int32_t Hkv, int32_t D, int64_t ld, int64_t cs_ld, float eps,
                        u2tok_stream_t stream) {
-  return qk_norm_rope(BFW(qkv), BF(wq), BF(wk), cos, sin, cos_sin_f32, rows, Hq, Hkv, D, ld, cs_ld, eps, nullptr, nullptr, 0,
+  return qk_norm_rope(BFW(qkv), BF(wq), BF(wk), cos, sin, cos_sin_f32, rows, Hq, Hkv, D, ld, cs_ld, eps, nullptr, nullptr, 0, 0, 0,
                       ST(stream));
 }
 int u2tok_qk_norm_rope_kv(void* qkv, const void* wq, const void* wk, const void* cos, const void* sin, int32_t cos_sin_f32,
                           int64_t rows, int32_t Hq, int32_t Hkv, int32_t D, int64_t ld, int64_t cs_ld, float eps,
-                          void* k_cache, void* v_cache, int32_t S, u2tok_stream_t stream) {
+                          void* k_cache, void* v_cache, int32_t S, int64_t kv_stride, int32_t s_off, u2tok_stream_t stream) {
   if (!k_cache || !v_cache) return U2_ERR_ARG;
   return qk_norm_rope(BFW(qkv), BF(wq), BF(wk), cos, sin, cos_sin_f32, rows, Hq, Hkv, D, ld, cs_ld, eps, BFW(k_cache),
-                      BFW(v_cache), S, ST(stream));
+                      BFW(v_cache), S, kv_stride, s_off, ST(stream));
 }
 static DecodeCfg dec_cfg(const u2tok_decode_config* c) {
   DecodeCfg d;
@@ -308,18 +308,18 @@ size_t u2tok_decoder_decode_workspace_bytes(const u2tok_decode_config* c, int32_
 }
 int u2tok_decoder_decode_pre(const u2tok_decode_config* c, const void* x, const void* w_in_norm, const void* Wqkv, const void* bqkv,
                              const void* wq_norm, const void* wk_norm, const void* cos, const void* sin, int32_t cos_sin_f32,
-                             int64_t cs_ld, void* qkv, void* k_new, void* v_new, void* workspace, size_t workspace_bytes,
-                             u2tok_stream_t stream) {
+                             int64_t cs_ld, void* qkv, void* k_cache, void* v_cache, int64_t kv_stride, int32_t s_off,
+                             void* workspace, size_t workspace_bytes, u2tok_stream_t stream) {
   if (!dec_ok(c)) return U2_ERR_ARG;
   return decoder_decode_pre(dec_cfg(c), BF(x), BF(w_in_norm), BF(Wqkv), BF(bqkv), BF(wq_norm), BF(wk_norm), cos, sin, cos_sin_f32,
-                            cs_ld, BFW(qkv), BFW(k_new), BFW(v_new), workspace, workspace_bytes, ST(stream));
+                            cs_ld, BFW(qkv), BFW(k_cache), BFW(v_cache), kv_stride, s_off, workspace, workspace_bytes, ST(stream));
 }
 int u2tok_decoder_decode_post(const u2tok_decode_config* c, const void* x, const void* qkv, const void* K, const void* V, int32_t T,
-                              const void* Wo, const void* bo, const void* w_post_norm, const void* Wgu, const void* bgu,
+                              int64_t kv_stride, const void* Wo, const void* bo, const void* w_post_norm, const void* Wgu, const void* bgu,
                               const void* Wdown, const void* bdown, void* out, void* workspace, size_t workspace_bytes,
                               u2tok_stream_t stream) {
   if (!dec_ok(c)) return U2_ERR_ARG;
-  return decoder_decode_post(dec_cfg(c), BF(x), BF(qkv), BF(K), BF(V), T, BF(Wo), BF(bo), BF(w_post_norm), BF(Wgu), BF(bgu),
+  return decoder_decode_post(dec_cfg(c), BF(x), BF(qkv), BF(K), BF(V), T, kv_stride, BF(Wo), BF(bo), BF(w_post_norm), BF(Wgu), BF(bgu),
                              BF(Wdown), BF(bdown), BFW(out), workspace, workspace_bytes, ST(stream));
 }
 int u2tok_swiglu_bf16(const void* gate_up, void* out, int64_t rows, int32_t I, int64_t ld_in, int64_t ld_out,

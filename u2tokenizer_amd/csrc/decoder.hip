@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
                                                            const bf16_t* __restrict__ wk, const CS* __restrict__ cosp,
                                                            const CS* __restrict__ sinp, int64_t rows, int Hq, int Hkv,
                                                            int64_t ld, int64_t cs_ld, float eps, bf16_t* __restrict__ kc,
-                                                           bf16_t* __restrict__ vc, int S) {
+                                                           bf16_t* __restrict__ vc, int S, int64_t kvs, int s_off) {
   const int lane = threadIdx.x & 63;
   const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nh = Hq + Hkv + (kc ? Hkv : 0);
@@ -91,7 +91,9 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
   if (kc && hh >= Hq) {
     const int64_t bi = row / S, si = row - bi * S;
     const int hk = hh - Hq;
-    cdst = (hk < Hkv ? kc + ((bi * Hkv + hk) * S + si) * D : vc + ((bi * Hkv + (hk - Hkv)) * S + si) * D);
+    // (kvs: elements between consecutive (batch, kv head) entries -- S * D dense, or the capacity of an append-in-place cache,
+    //  whose next free position is s_off)
+    cdst = (hk < Hkv ? kc + (bi * Hkv + hk) * kvs + (int64_t)(s_off + si) * D : vc + (bi * Hkv + (hk - Hkv)) * kvs + (int64_t)(s_off + si) * D);
     if (hk >= Hkv) {  // a v head: copy
       if (on) {
         cdst[lane] = p[lane];
@@ -137,16 +139,18 @@ struct Bf16Val {  // bf16 cos / sin tables
 
 int qk_norm_rope(bf16_t* qkv, const bf16_t* wq, const bf16_t* wk, const void* cosp, const void* sinp, int cs_is_f32,
                  int64_t rows, int Hq, int Hkv, int D, int64_t ld, int64_t cs_ld, float eps, bf16_t* kc, bf16_t* vc, int S,
-                 hipStream_t stream) {
+                 int64_t kv_stride, int s_off, hipStream_t stream) {
   if (!qkv || !cosp || !sinp || rows <= 0 || Hq <= 0 || Hkv <= 0 || (D != 64 && D != 128) || (!wq) != (!wk)) return U2_ERR_ARG;
   if ((!kc) != (!vc) || (kc && (S <= 0 || rows % S))) return U2_ERR_ARG;
+  if (kv_stride == 0) kv_stride = (int64_t)S * D;
+  if (kc && (s_off < 0 || kv_stride < (int64_t)(s_off + S) * D)) return U2_ERR_ARG;
   const int64_t items = rows * (Hq + Hkv + (kc ? Hkv : 0));
   if (cdiv(items, 4) > 0x7fffffff) return U2_ERR_ARG;
   ProfScope ps(PROF_ROWOP, 0, stream, (double)items * D * 4.0);
   dim3 grid((unsigned)cdiv(items, 4));
 #define U2_QK(D_, T_)                                                                                                     \
   hipLaunchKernelGGL((qk_norm_rope_kernel<D_, T_>), grid, dim3(256), 0, stream, qkv, wq, wk, reinterpret_cast<const T_*>(cosp), \
-                     reinterpret_cast<const T_*>(sinp), rows, Hq, Hkv, ld, cs_ld, eps, kc, vc, S)
+                     reinterpret_cast<const T_*>(sinp), rows, Hq, Hkv, ld, cs_ld, eps, kc, vc, S, kv_stride, s_off)
   if (D == 128 && cs_is_f32) U2_QK(128, float);
   else if (D == 128) U2_QK(128, Bf16Val);
   else if (cs_is_f32) U2_QK(64, float);
@@ -214,7 +218,8 @@ size_t decoder_decode_workspace_bytes(const DecodeCfg& c, int T) {
 // (B, Hkv, 1, D) receive the new cache entries
 int decoder_decode_pre(const DecodeCfg& c, const bf16_t* x, const bf16_t* w_in_norm, const bf16_t* Wqkv, const bf16_t* bqkv,
                        const bf16_t* wq_norm, const bf16_t* wk_norm, const void* cosp, const void* sinp, int cs_is_f32,
-                       int64_t cs_ld, bf16_t* qkv, bf16_t* kc, bf16_t* vc, void* ws, size_t ws_bytes, hipStream_t st) {
+                       int64_t cs_ld, bf16_t* qkv, bf16_t* kc, bf16_t* vc, int64_t kv_stride, int s_off, void* ws, size_t ws_bytes,
+                       hipStream_t st) {
   if (c.B <= 0 || c.B > 16 || c.Hkv <= 0 || c.Hq % c.Hkv || !x || !w_in_norm || !Wqkv || !qkv || !kc || !vc || !ws) return U2_ERR_ARG;
   if (ws_bytes < (size_t)c.B * c.E * sizeof(bf16_t)) return U2_ERR_WORKSPACE;
   bf16_t* xn = reinterpret_cast<bf16_t*>(ws);
@@ -223,13 +228,14 @@ int decoder_decode_pre(const DecodeCfg& c, const bf16_t* x, const bf16_t* w_in_n
   if (e != U2_OK) return e;
   e = dec_linear(xn, c.E, Wqkv, bqkv, qkv, nq, c.B, c.E, nq, nullptr, 0, st);
   if (e != U2_OK) return e;
-  return qk_norm_rope(qkv, wq_norm, wk_norm, cosp, sinp, cs_is_f32, c.B, c.Hq, c.Hkv, c.D, nq, cs_ld, c.qk_eps, kc, vc, 1, st);
+  return qk_norm_rope(qkv, wq_norm, wk_norm, cosp, sinp, cs_is_f32, c.B, c.Hq, c.Hkv, c.D, nq, cs_ld, c.qk_eps, kc, vc, 1, kv_stride,
+                      s_off, st);
 }
 
 // attention over the cache (keys split over workgroups) -> out projection + residual -> RMSNorm -> gate|up -> SwiGLU -> down
-// projection + residual.  K / V: (B, Hkv, T, D) dense; out (B, E).
+// projection + residual.  K / V: (B, Hkv, T, D) with kv_stride elements between (batch, kv head) entries (0: dense); out (B, E).
 int decoder_decode_post(const DecodeCfg& c, const bf16_t* x, const bf16_t* qkv, const bf16_t* K, const bf16_t* V, int T,
-                        const bf16_t* Wo, const bf16_t* bo, const bf16_t* w_post_norm, const bf16_t* Wgu, const bf16_t* bgu,
+                        int64_t kv_stride, const bf16_t* Wo, const bf16_t* bo, const bf16_t* w_post_norm, const bf16_t* Wgu, const bf16_t* bgu,
                         const bf16_t* Wdown, const bf16_t* bdown, bf16_t* out, void* ws, size_t ws_bytes, hipStream_t st) {
   if (c.B <= 0 || c.B > 16 || T <= 0 || !x || !qkv || !K || !V || !Wo || !w_post_norm || !Wgu || !Wdown || !out || !ws) return U2_ERR_ARG;
   if (ws_bytes < decoder_decode_workspace_bytes(c, T)) return U2_ERR_WORKSPACE;
@@ -244,11 +250,13 @@ int decoder_decode_post(const DecodeCfg& c, const bf16_t* x, const bf16_t* qkv, 
   char* aws = reinterpret_cast<char*>(ws) + used;
   const size_t aws_bytes = ws_bytes - used;
   const float scale = c.scale;
+  if (kv_stride == 0) kv_stride = (int64_t)T * c.D;
+  if (kv_stride < (int64_t)T * c.D || (kv_stride & 7)) return U2_ERR_ARG;
   for (int b = 0; b < c.B; ++b) {  // entries of one batch element: its kv heads; the g query heads of a group are the "heads"
-    const int e = attention_ex(qkv + (size_t)b * nq, K + (size_t)b * c.Hkv * T * c.D, V + (size_t)b * c.Hkv * T * c.D,
+    const int e = attention_ex(qkv + (size_t)b * nq, K + (size_t)b * c.Hkv * kv_stride, V + (size_t)b * c.Hkv * kv_stride,
                                ctx + (size_t)b * qd, c.Hkv, 1, T, g, 1, c.D, /*ldq*/ (int64_t)g * c.D, /*ldk*/ c.D, /*ldv*/ c.D,
-                               /*ldo*/ (int64_t)g * c.D, /*q_bs*/ (int64_t)g * c.D, /*k_bs*/ (int64_t)T * c.D,
-                               /*v_bs*/ (int64_t)T * c.D, /*o_bs*/ (int64_t)g * c.D, scale, nullptr, 0, 0, 0, aws, aws_bytes, st);
+                               /*ldo*/ (int64_t)g * c.D, /*q_bs*/ (int64_t)g * c.D, /*k_bs*/ kv_stride, /*v_bs*/ kv_stride,
+                               /*o_bs*/ (int64_t)g * c.D, scale, nullptr, 0, 0, 0, aws, aws_bytes, st);
     if (e != U2_OK) return e;
   }
   int e = dec_linear(ctx, qd, Wo, bo, h, c.E, c.B, qd, c.E, x, c.E, st);

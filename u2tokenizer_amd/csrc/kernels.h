@@ -208,7 +208,7 @@ int rmsnorm_bf16(const bf16_t* x, const bf16_t* w, bf16_t* y, int64_t rows, int 
                  hipStream_t stream);
 int qk_norm_rope(bf16_t* qkv, const bf16_t* wq, const bf16_t* wk, const void* cosp, const void* sinp, int cs_is_f32,
                  int64_t rows, int Hq, int Hkv, int D, int64_t ld, int64_t cs_ld, float eps, bf16_t* kc, bf16_t* vc, int S,
-                 hipStream_t stream);
+                 int64_t kv_stride, int s_off, hipStream_t stream);
 int swiglu_bf16(const bf16_t* gu, bf16_t* out, int64_t rows, int I, int64_t ld_in, int64_t ld_out, hipStream_t stream);
 struct DecodeCfg {  // one decode step of a decoder layer (decoder.hip)
   int B, E, Hq, Hkv, D, I;
@@ -217,9 +217,10 @@ struct DecodeCfg {  // one decode step of a decoder layer (decoder.hip)
 size_t decoder_decode_workspace_bytes(const DecodeCfg& c, int T);
 int decoder_decode_pre(const DecodeCfg& c, const bf16_t* x, const bf16_t* w_in_norm, const bf16_t* Wqkv, const bf16_t* bqkv,
                        const bf16_t* wq_norm, const bf16_t* wk_norm, const void* cosp, const void* sinp, int cs_is_f32,
-                       int64_t cs_ld, bf16_t* qkv, bf16_t* kc, bf16_t* vc, void* ws, size_t ws_bytes, hipStream_t st);
+                       int64_t cs_ld, bf16_t* qkv, bf16_t* kc, bf16_t* vc, int64_t kv_stride, int s_off, void* ws, size_t ws_bytes,
+                       hipStream_t st);
 int decoder_decode_post(const DecodeCfg& c, const bf16_t* x, const bf16_t* qkv, const bf16_t* K, const bf16_t* V, int T,
-                        const bf16_t* Wo, const bf16_t* bo, const bf16_t* w_post_norm, const bf16_t* Wgu, const bf16_t* bgu,
+                        int64_t kv_stride, const bf16_t* Wo, const bf16_t* bo, const bf16_t* w_post_norm, const bf16_t* Wgu, const bf16_t* bgu,
                         const bf16_t* Wdown, const bf16_t* bdown, bf16_t* out, void* ws, size_t ws_bytes, hipStream_t st);  // diagnostics: >= grid * 4 * 8 uint64, zeroed; null detaches (instrumented build)
 // Diagnostics only (process-wide, not for concurrent use): s_memtime phase sums per (workgroup, wave) of the double
 // pipeline kernel; while a buffer is attached the kernel runs its instrumented build.  See attn.hip.

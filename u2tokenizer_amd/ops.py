@@ -540,11 +540,13 @@ def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float = 1e-6) -> torch.Tensor
 
 @_guarded
 def qk_norm_rope(qkv: torch.Tensor, q_norm_w, k_norm_w, cos: torch.Tensor, sin: torch.Tensor, heads: int, kv_heads: int,
-                 head_dim: int, eps: float = 1e-6, kv_cache_seq: int = 0):
+                 head_dim: int, eps: float = 1e-6, kv_cache_seq: int = 0, kv_out=None, kv_pos: int = 0):
     """In place on the q and k heads of qkv (rows, (heads + 2 kv_heads) * head_dim): per-head RMSNorm (weights may both be
     None: Llama) then rotary embedding with cos / sin (rows, head_dim), fp32 or bf16 (u2tok_qk_norm_rope).
     kv_cache_seq = S > 0 (rows = batch * S): also returns the finished keys and the values as fresh dense
-    (batch, kv_heads, S, head_dim) tensors -- the KV cache's layout (u2tok_qk_norm_rope_kv): (qkv, k_cache, v_cache)."""
+    (batch, kv_heads, S, head_dim) tensors -- the KV cache's layout (u2tok_qk_norm_rope_kv): (qkv, k_cache, v_cache).
+    kv_out = (k_buf, v_buf): write them instead at positions kv_pos .. kv_pos + S - 1 of (batch, kv_heads, capacity, head_dim)
+    buffers (an append-in-place cache)."""
     h = _lib.load_library()
     _need(qkv, torch.bfloat16, "qkv")
     rows = qkv.shape[0]
@@ -557,11 +559,23 @@ def qk_norm_rope(qkv: torch.Tensor, q_norm_w, k_norm_w, cos: torch.Tensor, sin: 
         S = int(kv_cache_seq)
         if S <= 0 or rows % S:
             raise RuntimeError("qk_norm_rope: rows must be batch * kv_cache_seq")
-        kc = torch.empty((rows // S, kv_heads, S, head_dim), dtype=torch.bfloat16, device=qkv.device)
-        vc = torch.empty_like(kc)
+        kvs, pos = 0, 0
+        if kv_out is not None:
+            kc, vc = kv_out
+            for t in (kc, vc):
+                _need(t, torch.bfloat16, "kv_out")
+                if t.dim() != 4 or t.shape[0] != rows // S or t.shape[1] != kv_heads or t.shape[3] != head_dim or t.stride(3) != 1 \
+                        or t.stride(2) != head_dim or t.stride(0) != kv_heads * t.stride(1) or kv_pos + S > t.shape[2]:
+                    raise RuntimeError("qk_norm_rope: kv_out must be (batch, kv_heads, capacity, head_dim) buffers with room")
+            if kc.stride(1) != vc.stride(1):
+                raise RuntimeError("qk_norm_rope: the two kv_out buffers must have the same capacity")
+            kvs, pos = kc.stride(1), int(kv_pos)
+        else:
+            kc = torch.empty((rows // S, kv_heads, S, head_dim), dtype=torch.bfloat16, device=qkv.device)
+            vc = torch.empty_like(kc)
         _lib.check(h.u2tok_qk_norm_rope_kv(_ptr(qkv), _ptr(q_norm_w), _ptr(k_norm_w), _ptr(cos), _ptr(sin),
                                            int(cos.dtype == torch.float32), rows, heads, kv_heads, head_dim, qkv.stride(0),
-                                           cos.stride(0), float(eps), _ptr(kc), _ptr(vc), S, _stream()),
+                                           cos.stride(0), float(eps), _ptr(kc), _ptr(vc), S, kvs, pos, _stream()),
                    "u2tok_qk_norm_rope_kv")
         return qkv, kc, vc
     _lib.check(h.u2tok_qk_norm_rope(_ptr(qkv), _ptr(q_norm_w), _ptr(k_norm_w), _ptr(cos), _ptr(sin),

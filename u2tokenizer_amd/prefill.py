@@ -99,9 +99,13 @@ def _layer_forward(self, hidden_states, *args, **kwargs):
         xn = ops.rmsnorm(x2, self.input_layernorm.weight, self.input_layernorm.variance_epsilon)
         qkv = ops.gemm(xn, Wqkv, bias=bqkv)
         qn, kn = getattr(att, "q_norm", None), getattr(att, "k_norm", None)
+        # keys / values in the cache's own (B, H_kv, S, d) layout: straight into an append-in-place layer of a plain DynamicCache
+        # (room for the decode steps behind them), else as dense tensors for the cache's own `update`
+        lay = _prefill_append_layer(cache, att.layer_idx, B, Hkv, S, d, x) if cache is not None else None
         r = ops.qk_norm_rope(qkv, None if qn is None else qn.weight, None if kn is None else kn.weight, cos, sin, Hq, Hkv, d,
-                             qn.variance_epsilon if qn is not None else 1e-6, kv_cache_seq=S if cache is not None else 0)
-        kc, vc = (r[1], r[2]) if cache is not None else (None, None)  # keys / values in the cache's own (B, H_kv, S, d) layout
+                             qn.variance_epsilon if qn is not None else 1e-6, kv_cache_seq=S if cache is not None else 0,
+                             kv_out=None if lay is None else (lay._kb, lay._vb))
+        kc, vc = (r[1], r[2]) if cache is not None and lay is None else (None, None)
         q3 = qkv.view(B, S, -1)
         k3, v3 = q3[..., Hq * d:(Hq + Hkv) * d], q3[..., (Hq + Hkv) * d:]
         ctx = ops.attention_gqa(q3[..., :Hq * d], k3, v3, Hq, Hkv, float(att.scaling), causal=True)
@@ -112,9 +116,61 @@ def _layer_forward(self, hidden_states, *args, **kwargs):
         else:
             act = ops.swiglu(ops.gemm(hn, Wgu, bias=bgu))
         out = ops.gemm(act, self.mlp.down_proj.weight, bias=self.mlp.down_proj.bias, residual=h)
-        if cache is not None:
-            _cache_prefill(cache, kc, vc, att.layer_idx)
+        if lay is not None:
+            lay._commit(S)
+        elif cache is not None:
+            cache.update(kc, vc, att.layer_idx)
     return out.view(B, S, E)
+
+
+_APPEND_LAYER = None
+
+
+def _append_layer_class():
+    """A DynamicLayer that APPENDS IN PLACE: keys / values are views [:, :, :T] of buffers with room to grow (doubling), so a decode
+    step writes one row instead of re-copying the whole cache (DynamicLayer.update is a torch.cat: two launches and 2 x T rows per
+    layer and step).  Everything else -- crop, batch selection, beam reordering, the stock attention reading `.keys` -- is
+    DynamicLayer's: those reassign `.keys` / `.values`, after which the next update re-homes them."""
+    global _APPEND_LAYER
+    if _APPEND_LAYER is None:
+        from transformers.cache_utils import DynamicLayer
+
+        class AppendLayer(DynamicLayer):
+            _kb = _vb = None
+
+            def _room(self, n: int, like: torch.Tensor) -> int:
+                """Make sure `n` more positions fit behind the current ones; returns the current length."""
+                T0 = self.keys.shape[-2] if self.is_initialized and self.keys.numel() else 0
+                kb = self._kb
+                homed = kb is not None and (T0 == 0 or (self.keys.data_ptr() == kb.data_ptr() and self.values.data_ptr() == self._vb.data_ptr()
+                                                        and self.keys.shape[:2] == kb.shape[:2]))
+                if not homed or T0 + n > kb.shape[-2] or kb.shape[:2] != like.shape[:2]:
+                    cap = max(256, 2 * (T0 + n))
+                    shape = (like.shape[0], like.shape[1], cap, like.shape[3])
+                    nk = torch.empty(shape, dtype=like.dtype, device=like.device)
+                    nv = torch.empty(shape, dtype=like.dtype, device=like.device)
+                    if T0:
+                        nk[:, :, :T0].copy_(self.keys)
+                        nv[:, :, :T0].copy_(self.values)
+                    self._kb, self._vb = nk, nv
+                    self.keys, self.values = nk[:, :, :T0], nv[:, :, :T0]
+                return T0
+
+            def _commit(self, T: int) -> None:
+                self.keys, self.values = self._kb[:, :, :T], self._vb[:, :, :T]
+
+            def update(self, key_states, value_states, *args, **kwargs):
+                if not self.is_initialized:
+                    self.lazy_initialization(key_states, value_states)
+                n = key_states.shape[-2]
+                T0 = self._room(n, key_states)
+                self._kb[:, :, T0:T0 + n].copy_(key_states)
+                self._vb[:, :, T0:T0 + n].copy_(value_states)
+                self._commit(T0 + n)
+                return self.keys, self.values
+
+        _APPEND_LAYER = AppendLayer
+    return _APPEND_LAYER
 
 
 def _plain_dynamic_layer(cache, layer_idx: int):
@@ -129,7 +185,7 @@ def _plain_dynamic_layer(cache, layer_idx: int):
             or layer_idx >= len(layers):
         return None
     lay = layers[layer_idx]
-    return lay if type(lay) is DynamicLayer and lay.get_seq_length() > 0 else None
+    return lay if type(lay) in (DynamicLayer, _APPEND_LAYER) and lay.get_seq_length() > 0 else None
 
 
 def _decode_state(self, B: int, device):
@@ -203,45 +259,61 @@ def _decode_step(self, x, pe, cache):
             sc["ws"] = torch.empty(h.u2tok_decoder_decode_workspace_bytes(d["cfg_ref"], Tcap), dtype=torch.uint8, device=x.device)
             sc["T"] = Tcap
         ws, nws = sc["ws"].data_ptr(), sc["ws"].numel()
+        lay = cache.layers[att.layer_idx]
+        out = torch.empty((B, 1, E), dtype=torch.bfloat16, device=x.device)
+        if type(lay) is _APPEND_LAYER and lay._kb is not None and lay._kb.shape[0] == B:
+            # append in place: the rotary kernel writes the step's keys / values at position T0 of the layer's buffers
+            T0 = lay._room(1, sc["kc"])
+            kb, vb = lay._kb, lay._vb
+            _lib.check(h.u2tok_decoder_decode_pre(d["cfg_ref"], x2.data_ptr(), *d["pre"], cos.data_ptr(), sin.data_ptr(),
+                                                  int(cos.dtype == torch.float32), cos.stride(0), sc["qkv"].data_ptr(),
+                                                  kb.data_ptr(), vb.data_ptr(), kb.stride(1), T0, ws, nws, stream),
+                       "u2tok_decoder_decode_pre")
+            lay._commit(T0 + 1)
+            _lib.check(h.u2tok_decoder_decode_post(d["cfg_ref"], x2.data_ptr(), sc["qkv"].data_ptr(), kb.data_ptr(), vb.data_ptr(),
+                                                   T0 + 1, kb.stride(1), *d["post"], out.data_ptr(), ws, nws, stream),
+                       "u2tok_decoder_decode_post")
+            return out
         _lib.check(h.u2tok_decoder_decode_pre(d["cfg_ref"], x2.data_ptr(), *d["pre"], cos.data_ptr(), sin.data_ptr(),
                                               int(cos.dtype == torch.float32), cos.stride(0), sc["qkv"].data_ptr(),
-                                              sc["kc"].data_ptr(), sc["vc"].data_ptr(), ws, nws, stream), "u2tok_decoder_decode_pre")
+                                              sc["kc"].data_ptr(), sc["vc"].data_ptr(), 0, 0, ws, nws, stream),
+                   "u2tok_decoder_decode_pre")
         K, V = cache.update(sc["kc"], sc["vc"], att.layer_idx)   # DynamicLayer: torch.cat -> dense (B, H_kv, T, d)
         if not K.is_contiguous():
             K = K.contiguous()
         if not V.is_contiguous():
             V = V.contiguous()
-        out = torch.empty((B, 1, E), dtype=torch.bfloat16, device=x.device)
         _lib.check(h.u2tok_decoder_decode_post(d["cfg_ref"], x2.data_ptr(), sc["qkv"].data_ptr(), K.data_ptr(), V.data_ptr(),
-                                               K.shape[2], *d["post"], out.data_ptr(), ws, nws, stream), "u2tok_decoder_decode_post")
+                                               K.shape[2], 0, *d["post"], out.data_ptr(), ws, nws, stream),
+                   "u2tok_decoder_decode_post")
     return out
 
 
-def _cache_prefill(cache, keys, values, layer_idx: int) -> None:
-    """Hand the prefill's keys / values (fresh dense (B, H_kv, S, d) tensors nobody else holds) to the KV cache.  An EMPTY
-    `DynamicLayer` of a plain `DynamicCache` would only `torch.cat` them onto its empty tensors (two more copies per layer: 72
-    launches per Qwen3-8B prefill) -- it takes them as they are; every other cache type goes through its `update`."""
+def _prefill_append_layer(cache, layer_idx: int, B: int, Hkv: int, S: int, d: int, like: torch.Tensor):
+    """For a plain HF DynamicCache whose layer `layer_idx` is still empty: put an append-in-place layer there with room for S
+    positions (and as many again for the decode steps) and return it; None for every other cache (its `update` is used)."""
     try:
         from transformers.cache_utils import DynamicCache, DynamicLayer
     except ImportError:  # (older transformers: no per-layer cache objects)
-        DynamicCache = DynamicLayer = None
+        return None
     layers = getattr(cache, "layers", None)
-    if DynamicLayer is not None and type(cache) is DynamicCache and isinstance(layers, list) \
-            and not getattr(cache, "offloading", False):
-        repl = getattr(cache, "layer_class_to_replicate", None)
-        if repl is DynamicLayer:
-            while len(layers) <= layer_idx:
-                layers.append(repl())
-        lay = layers[layer_idx] if layer_idx < len(layers) else None
-        if type(lay) is DynamicLayer and lay.get_seq_length() == 0 and hasattr(lay, "lazy_initialization"):
-            try:
-                if not getattr(lay, "is_initialized", False):
-                    lay.lazy_initialization(keys, values)
-                lay.keys, lay.values = keys, values
-                return
-            except TypeError:  # (another transformers version's signature: let the cache do it its way)
-                pass
-    cache.update(keys, values, layer_idx)
+    if type(cache) is not DynamicCache or not isinstance(layers, list) or getattr(cache, "offloading", False):
+        return None
+    cls = _append_layer_class()
+    if getattr(cache, "layer_class_to_replicate", None) is DynamicLayer:
+        while len(layers) <= layer_idx:
+            layers.append(DynamicLayer())
+    if layer_idx >= len(layers) or type(layers[layer_idx]) not in (DynamicLayer, cls) or layers[layer_idx].get_seq_length() != 0:
+        return None
+    try:
+        lay = cls()
+        proto = torch.empty((B, Hkv, 0, d), dtype=like.dtype, device=like.device)
+        lay.lazy_initialization(proto, proto)
+        lay._room(S, torch.empty((B, Hkv, 1, d), dtype=like.dtype, device=like.device))
+    except (TypeError, AttributeError):  # (another transformers version's layer protocol)
+        return None
+    layers[layer_idx] = lay
+    return lay
 
 
 def _mask_hook(module, args, kwargs):
