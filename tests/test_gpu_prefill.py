@@ -143,11 +143,13 @@ def test_attention_gqa_causal(ops, nb, Sq, Skv, Hq, Hkv, d):
     close_bf16(ops.attention_gqa(dq, dk, dv, Hq, Hkv, scale, causal=False), ref2)
 
 
-def _small(kind, layers=3):
+def _small(kind, layers=3, wide=False):
     from transformers import LlamaConfig, LlamaForCausalLM, Qwen3Config, Qwen3ForCausalLM
     common = dict(vocab_size=1024, hidden_size=512, intermediate_size=1536, num_hidden_layers=layers, num_attention_heads=8,
                   num_key_value_heads=4, head_dim=64, max_position_embeddings=512, tie_word_embeddings=False,
                   pad_token_id=0, bos_token_id=1, eos_token_id=2)
+    if wide:  # one layer at the Qwen3-8B width: the kernel variants the real decoder takes (E = 4096, I = 12288, 32 / 8 heads of 128)
+        common.update(hidden_size=4096, intermediate_size=12288, num_attention_heads=32, num_key_value_heads=8, head_dim=128)
     if kind == "qwen3":
         m = Qwen3ForCausalLM(Qwen3Config(**common))
     else:
@@ -203,29 +205,31 @@ def test_attention_gqa_split_keys_single_query_row(ops, nb, T, g, d):
     close_bf16(outs[0], ref, rounds=3)
 
 
-@pytest.mark.parametrize("kind,B", [("qwen3", 1), ("llama", 2)])
-def test_fused_decode_step_matches_the_stock_decoder(ops, kind, B):
+@pytest.mark.parametrize("kind,B,wide", [("qwen3", 1, False), ("llama", 2, False), ("qwen3", 2, True)])
+def test_fused_decode_step_matches_the_stock_decoder(ops, kind, B, wide):
     """One decode step after a prefill (both through the patched layers, then the same two calls through the stock layers):
     logits and the new cache entries no further from the fp32 model than 1.5 x the stock bf16 GPU run is; with decode=False the
     step takes the stock layers (bit-identical to an unpatched model on the same cache)."""
     from u2tokenizer_amd.prefill import disable_fused_prefill, enable_fused_prefill
-    m32 = _small(kind)
-    x = 0.5 * synth.synth_tensor("inputs_embeds", (B, 40, 512), 7)
-    x1 = 0.5 * synth.synth_tensor("inputs_embeds", (B, 1, 512), 8)
+    nl, E = (1, 4096) if wide else (3, 512)
+    m32 = _small(kind, nl, wide)
+    x = 0.5 * synth.synth_tensor("inputs_embeds", (B, 40, E), 7)
+    x1 = 0.5 * synth.synth_tensor("inputs_embeds", (B, 1, E), 8)
     p32 = m32(inputs_embeds=x, use_cache=True)
     ref = m32(inputs_embeds=x1, past_key_values=p32.past_key_values, use_cache=True)
-    mg = _small(kind).to(bf).to(D)
+    mg = _small(kind, nl, wide).to(bf).to(D)
     xd, x1d = x.to(bf).to(D), x1.to(bf).to(D)
     ps = mg(inputs_embeds=xd, use_cache=True)
     stock = mg(inputs_embeds=x1d, past_key_values=ps.past_key_values, use_cache=True)
     enable_fused_prefill(mg)
     pf = mg(inputs_embeds=xd, use_cache=True)
     fused = mg(inputs_embeds=x1d, past_key_values=pf.past_key_values, use_cache=True)
+    assert type(pf.past_key_values.layers[0]).__name__ == "AppendLayer"          # the in-place cache layer took the prompt
     assert fused.logits.shape == stock.logits.shape == (B, 1, ref.logits.shape[-1])
     e_stock, e_fused = _err(stock.logits.float().cpu(), ref.logits), _err(fused.logits.float().cpu(), ref.logits)
     assert e_fused <= 1.5 * e_stock + 1e-3, (e_fused, e_stock)
     assert not torch.equal(fused.logits, stock.logits)
-    for li in (0, 2):
+    for li in (0, nl - 1):
         for name in ("keys", "values"):
             r = getattr(ref.past_key_values.layers[li], name)
             gk = getattr(fused.past_key_values.layers[li], name)
