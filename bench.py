@@ -319,6 +319,22 @@ def train_step_full(timeout=240):
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
+def decoder_after_path(timeout=240):
+    """The consumer of the path (SURVEY 8f rank 3 and the decode steps behind it): tools/prefill_probe.py in a CHILD process --
+    Qwen3-8B-shaped decoder, prefill of the 1024 spliced embeddings and 64 greedy decode steps, stock HF layers against the
+    HIP layers of u2tokenizer_amd.prefill.  Not part of `value`."""
+    tool = Path(__file__).resolve().parent / "tools" / "prefill_probe.py"
+    try:
+        torch.cuda.empty_cache()
+        r = subprocess.run([sys.executable, str(tool)], env=_child_env(), capture_output=True, text=True, timeout=timeout)
+        for ln in reversed(r.stdout.splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return {"error": (r.stderr or "no output")[-300:]}
+    except (OSError, subprocess.SubprocessError, ValueError) as e:
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def train_step(path, ids, qids, vol, E, iters=3):
     """Forward under autograd + backward of the path (ViT, projector, tokenizer, embedding table) on the benchmark
     configuration with a dummy loss on the spliced embeddings (the decoder and the optimiser are not part
@@ -633,6 +649,7 @@ def main():
             line["train_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0 and world == 1 and not args.no_train_step and not args.stub_cpu and B == 1 and E == 4096:
         line["train_step_full"] = train_step_full()
+        line["decoder_after_path"] = decoder_after_path()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stub_cpu:
         line["cpu_baseline"] = cpu_baseline(E, Lt, iters=args.cpu_baseline_iters)
     if rank == 0:

@@ -66,6 +66,7 @@ print(f"same through u2tokenizer_amd.prefill (HIP layers): {ms2:.2f} ms ({flop /
 # the decode steps of generate() (eval/mrg.py asks for up to 768 new tokens): stock layers against the fused decode step
 from u2tokenizer_amd.prefill import disable_fused_prefill  # noqa: E402
 steps = 64
+per_step = {}
 for label, decode in (("stock HF layers", False), ("HIP layers (u2tokenizer_amd.prefill._decode_step)", True)):
     disable_fused_prefill(m)
     enable_fused_prefill(m, decode=decode)
@@ -75,7 +76,15 @@ for label, decode in (("stock HF layers", False), ("HIP layers (u2tokenizer_amd.
     m.generate(inputs_embeds=x, max_new_tokens=steps + 1, min_new_tokens=steps + 1, do_sample=False)
     torch.cuda.synchronize()
     tg = (time.perf_counter() - t0) * 1e3
+    per_step[decode] = (tg - ms3) / steps
     print(f"generate(): prefill (HIP layers) + {steps} greedy decode steps on the {label}: {tg:.0f} ms -> "
           f"{(tg - ms3) / steps:.2f} ms per decode step (weights alone: {2 * nparam / 1e9:.1f} GB per step = "
           f"{2 * nparam / 5e12 * 1e3:.1f} ms at 5 TB/s)")
+import json  # noqa: E402
+print(json.dumps({"what": "Qwen3-8B-shaped decoder (36 layers, random bf16 weights) after the path: prefill of the 1024 spliced "
+                          "embeddings and greedy decode steps of generate(), stock HF layers on PyTorch-ROCm against "
+                          "u2tokenizer_amd.prefill (HIP layers); not part of `value`",
+                  "prefill_ms_stock": round(ms, 2), "prefill_ms": round(ms2, 2), "prefill_ms_last_logits_only": round(ms3, 2),
+                  "decode_ms_per_step_stock": round(per_step[False], 2), "decode_ms_per_step": round(per_step[True], 2),
+                  "decode_steps_timed": steps}))
 
