@@ -218,13 +218,18 @@ def _decode_state(self, B: int, device):
                       p(mlp.down_proj.weight), p(mlp.down_proj.bias))}
         st["dec"] = d
     owner = st["owner"]
-    sc = owner.__dict__.get("_u2_decode_scratch")
-    if sc is None or sc["B"] != B or sc["device"] != device:
+    # (per model, batch size AND stream: two generate() calls in flight on different streams must not share the step's scratch)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    pool = owner.__dict__.setdefault("_u2_decode_scratch", {})
+    sc = pool.get((B, device, stream))
+    if sc is None:
+        if len(pool) >= 8:
+            pool.clear()
         sc = {"B": B, "device": device, "ws": None, "T": 0,
               "qkv": torch.empty((B, d["nq"]), dtype=torch.bfloat16, device=device),
               "kc": torch.empty((B, d["Hkv"], 1, d["hd"]), dtype=torch.bfloat16, device=device),
               "vc": torch.empty((B, d["Hkv"], 1, d["hd"]), dtype=torch.bfloat16, device=device)}
-        owner.__dict__["_u2_decode_scratch"] = sc
+        pool[(B, device, stream)] = sc
     return d, sc
 
 
@@ -361,3 +366,4 @@ def disable_fused_prefill(model) -> None:
     hook = base.__dict__.pop("_u2_prefill_hook", None)
     if hook is not None:
         hook.remove()
+    base.__dict__.pop("_u2_decode_scratch", None)
