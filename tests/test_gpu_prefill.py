@@ -96,7 +96,8 @@ def test_swiglu(ops):
     close_bf16(ops.swiglu(gu.to(D)), F.silu(g).to(bf).float() * u)
 
 
-@pytest.mark.parametrize("rows,K,I", [(1024, 4096, 12288), (300, 512, 1536), (257, 128, 1040), (7, 192, 16), (640, 1024, 96)])
+@pytest.mark.parametrize("rows,K,I", [(1024, 4096, 12288), (300, 512, 1536), (257, 128, 1040), (7, 192, 16), (640, 1024, 96),
+                                      (1, 4096, 12288), (16, 512, 1536), (3, 2048, 48)])   # <= 16 rows: the few-rows kernel
 def test_gemm_swiglu_pair_equals_the_two_step_form(ops, rows, K, I):
     """u2tok_gemm_bf16 flag 512: SiLU(gate) * up in the epilogue of the packed gate | up product -- bit for bit the values of the
     GEMM followed by u2tok_swiglu_bf16 (same accumulation order, same rounding points), tiles that straddle M and I included."""

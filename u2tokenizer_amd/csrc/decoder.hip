@@ -263,10 +263,20 @@ int decoder_decode_post(const DecodeCfg& c, const bf16_t* x, const bf16_t* qkv, 
   if (e != U2_OK) return e;
   e = rmsnorm_bf16(h, w_post_norm, hn, c.B, c.E, c.E, c.E, c.eps, st);
   if (e != U2_OK) return e;
-  e = dec_linear(hn, c.E, Wgu, bgu, gu, 2 * c.I, c.B, c.E, 2 * c.I, nullptr, 0, st);
-  if (e != U2_OK) return e;
-  e = swiglu_bf16(gu, act, c.B, c.I, 2 * c.I, c.I, st);
-  if (e != U2_OK) return e;
+  if (!bgu && !(c.E & 63) && !(c.I & 15)) {  // SiLU(gate) * up in the epilogue of the pair product (gemm_rows16_kernel<., true>)
+    GemmDesc g;
+    g.A = hn; g.B = Wgu; g.C = act;
+    g.M = c.B; g.N = 2 * c.I; g.K = c.E;
+    g.lda = c.E; g.ldb = c.E; g.ldc = c.I;
+    g.flags = GEMM_SWIGLU;
+    e = gemm_bf16(g, st);
+    if (e != U2_OK) return e;
+  } else {
+    e = dec_linear(hn, c.E, Wgu, bgu, gu, 2 * c.I, c.B, c.E, 2 * c.I, nullptr, 0, st);
+    if (e != U2_OK) return e;
+    e = swiglu_bf16(gu, act, c.B, c.I, 2 * c.I, c.I, st);
+    if (e != U2_OK) return e;
+  }
   return dec_linear(act, c.I, Wdown, bdown, out, c.E, c.B, c.I, c.E, h, c.E, st);
 }
 

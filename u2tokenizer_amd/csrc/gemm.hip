@@ -394,7 +394,10 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmDesc d) {
 // from memory -- all loads of a wave are issued before its first MFMA, so the whole product costs about one memory latency
 // -- and the waves' partial tiles are added through LDS in a fixed order (bit-repeatable).  v_mfma_f32_16x16x32_bf16 with
 // the weights as A: a lane ends up with 4 consecutive output columns of one row, as in the tile kernels.
-template <int NW>
+// PAIR (GEMM_SWIGLU: B = [gate rows | up rows], N = 2 I, C (M, I) = bf16(silu(gate)) * up -- the form the big-tile kernel has for
+// the prefill): the workgroup's 16 weight rows are 8 gate rows and the SAME 8 up rows, so the lanes of column groups 0 / 1 hold
+// the gates and those of groups 2 / 3 (32 lanes further) the matching ups; the decode step's SwiGLU launch goes away.
+template <int NW, bool PAIR = false>
 __global__ __launch_bounds__(NW * 64) void gemm_rows16_kernel(GemmDesc d) {
   __shared__ float red[NW][64][4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -402,7 +405,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows16_kernel(GemmDesc d) {
   const int n0 = blockIdx.x * 16;
   const int nsteps = d.K >> 5;  // K % 32 == 0 (launcher)
   const int per = (nsteps + NW - 1) / NW, s0 = wv * per, s1 = min(nsteps, s0 + per);
-  const int nrow = min(n0 + l15, d.N - 1), mrow = min(l15, d.M - 1);
+  const int I2 = d.N >> 1;
+  const int nrow = PAIR ? min((l15 < 8 ? 0 : I2) + (int)blockIdx.x * 8 + (l15 & 7), d.N - 1) : min(n0 + l15, d.N - 1);
+  const int mrow = min(l15, d.M - 1);
   const bf16_t* wp = d.B + (int64_t)nrow * d.ldb + g * 8;
   const bf16_t* xp = d.A + (int64_t)mrow * d.lda + g * 8;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows16_kernel(GemmDesc d) {
   // lane holds C[m = l15][n = n0 + 4 g + r]
   red[wv][lane][0] = acc[0]; red[wv][lane][1] = acc[1]; red[wv][lane][2] = acc[2]; red[wv][lane][3] = acc[3];
   __syncthreads();
-  if (wv != 0 || l15 >= d.M) return;
+  if (wv != 0 || (!PAIR && l15 >= d.M)) return;
   float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int w = 0; w < NW; ++w)
@@ -430,6 +435,19 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows16_kernel(GemmDesc d) {
     for (int r = 0; r < 4; ++r) v[r] += red[w][lane][r];
   const bool out_f32 = d.flags & GEMM_OUT_F32;
   const int m = l15;
+  if constexpr (PAIR) {  // (wave 0, all 64 lanes: lanes of rows >= M carry copies of row M - 1 and write nothing)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float gate = bf16_to_f32(f32_to_bf16(v[r] * d.alpha));
+      const float up = bf16_to_f32(f32_to_bf16(__shfl_xor(v[r], 32, 64) * d.alpha));  // column group g + 2 of the same row
+      const int n = (int)blockIdx.x * 8 + 4 * g + r;
+      if (g < 2 && l15 < d.M && n < I2) {
+        const float sg = gate / (1.0f + __expf(-gate));
+        reinterpret_cast<bf16_t*>(d.C)[(int64_t)m * d.ldc + n] = f32_to_bf16(bf16_to_f32(f32_to_bf16(sg)) * up);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int n = n0 + 4 * g + r;
@@ -449,6 +467,12 @@ static int gemm_rows16_try(const GemmDesc& d, hipStream_t stream) {
   if (d.M > 16 || d.nz != 1 || (d.K & 31) || d.ldbk || (d.flags & (GEMM_A_KMAJOR | GEMM_B_KMAJOR))) return 0;
   const int nsteps = d.K >> 5;
   dim3 grid((unsigned)cdiv(d.N, 16));
+  if (d.flags & GEMM_SWIGLU) {  // (validated by gemm_bf16: alone, N = 2 I)
+    if (nsteps >= 64) hipLaunchKernelGGL((gemm_rows16_kernel<16, true>), grid, dim3(1024), 0, stream, d);
+    else if (nsteps >= 16) hipLaunchKernelGGL((gemm_rows16_kernel<8, true>), grid, dim3(512), 0, stream, d);
+    else hipLaunchKernelGGL((gemm_rows16_kernel<4, true>), grid, dim3(256), 0, stream, d);
+    return launch_status() == U2_OK ? 1 : U2_ERR_LAUNCH;
+  }
   if (nsteps >= 64) hipLaunchKernelGGL((gemm_rows16_kernel<16>), grid, dim3(1024), 0, stream, d);
   else if (nsteps >= 16) hipLaunchKernelGGL((gemm_rows16_kernel<8>), grid, dim3(512), 0, stream, d);
   else hipLaunchKernelGGL((gemm_rows16_kernel<4>), grid, dim3(256), 0, stream, d);
@@ -482,6 +506,10 @@ int gemm_bf16(GemmDesc d, hipStream_t stream) {
         (d.lda & 7) || (d.ldb & 7) || (((uintptr_t)d.A | (uintptr_t)d.B | (uintptr_t)d.C) & 15))
       return U2_ERR_ARG;
     ProfScope ps(PROF_GEMM, 2.0 * d.M * d.N * d.K, stream, 2.0 * d.M * d.K + 2.0 * d.N * d.K + 2.0 * d.M * I);
+    if (d.M <= 16 && opts().gemm_tile == 0) {  // a few rows (decode steps): the few-rows kernel has the pair form too
+      const int r = gemm_rows16_try(d, stream);
+      if (r != 0) return r > 0 ? U2_OK : r;
+    }
     const int big = gemm_big_try(d, stream);
     return big > 0 ? U2_OK : (big < 0 ? big : U2_ERR_ARG);
   }
