@@ -4,23 +4,24 @@ and the first forward of `generate`, u2llama.py:123-126).
 
 The decoder stays the stock HuggingFace module tree: its parameters (names, shapes, state dict), its KV cache and its
 `generate` loop are untouched.  `enable_fused_prefill(model)` replaces the `forward` of every decoder layer by one that,
-for the PREFILL call only (no grad, bf16 on the GPU, more than one position, empty cache for that layer, full attention, no
-padding), runs the layer as
+for the PREFILL call (no grad, bf16 on the GPU, more than one position, empty cache for that layer, full attention, no
+padding) runs the layer as
 
     RMSNorm -> ONE q|k|v GEMM -> per-head RMSNorm (Qwen3) + rotary embedding -> causal grouped-query attention
     -> out-projection GEMM with the residual in its epilogue -> RMSNorm -> ONE gate|up GEMM with SiLU(gate) * up in its
     epilogue -> down-projection GEMM with the residual in its epilogue
 
 on the library's MFMA GEMMs (include/u2tok.h: u2tok_gemm_bf16), the fused attention kernel of tokattn.hip
-(u2tok_attention_gqa: grouped-query heads, causal mask, scores never in HBM) and the row kernels of decoder.hip.  Everything
-else -- decode steps, training, CPU tensors, sliding-window layers, padded batches -- takes the layer's original forward.
+(u2tok_attention_gqa: grouped-query heads, causal mask, scores never in HBM) and the row kernels of decoder.hip, and for a
+DECODE step (one new position per sequence, batch <= 16, a plain HF DynamicCache) as two library calls around the cache update
+(`_decode_step`: weight-streaming few-rows products, attention with the keys split over workgroups).  Everything else --
+training, CPU tensors, sliding-window layers, padded batches, other cache types -- takes the layer's original forward.
 q|k|v and gate|up are packed the way the tokenizer packs its projections: the nn.Parameters keep their names and shapes,
 their storage becomes a view of one buffer, so the stock modules keep working on them.
 """
 from __future__ import annotations
 
 import types
-from typing import Optional
 
 import torch
 
