@@ -100,6 +100,11 @@ def test_gemm_bt_fragment_reads_hit_the_rows_the_dma_wrote():
                     assert len(set(slots[16 * q:16 * q + 16])) == 16  # conflict-free ds_read_b128
 
 
+def test_flash_dp2_asm_is_generated():
+    want = "".join(_run("tools/gen_flash_dp2_asm.py", *f) for f in ((), ("--timed",), ("--exact",), ("--exact", "--timed")))
+    assert want == (CSRC / "flash_dp2_asm.inc").read_text()
+
+
 def test_flash_dp_fragment_reads_hit_the_rows_the_dma_wrote():
     """Same executable spec for the flash KV loop: a 64-key ring slot = K tile [64 keys][64 d] at +0 and V^T tile
     [64 d][64 keys] at +8192, both 128-byte rows with the kt_off swizzle; DMA pieces per attn.hip (flash_dp_kernel), reads

@@ -215,10 +215,10 @@ def _sdpa_ref(qkv, nb, S, H):
 
 @pytest.mark.parametrize("nb,S,H,scale", [(1, 64, 1, 1.0), (2, 129, 3, 1.0), (1, 513, 12, 1.0), (1, 2049, 2, 1.0),
                                           (3, 100, 12, 1.0), (1, 300, 2, 3.0), (1, 1, 1, 1.0)])
-@pytest.mark.parametrize("mode", [1, 5])
+@pytest.mark.parametrize("mode", [1, 5, 7])
 def test_flash_attention(ops, nb, S, H, scale, mode):
     """scale 3.0 makes the logits spiky so the online-softmax rescale branch does real work.  mode 1 = plain 128-row
-    units, mode 5 = the double pipeline (256-row units, generated asm KV loop)."""
+    units, mode 5 / 7 = the double pipeline (256-row units, generated asm KV loop of round 1 / round 4)."""
     qkv = rnd(nb, S, 3 * H * 64, scale=scale, seed=S)
     ops.set_option("flash_mode", mode)
     try:
@@ -232,7 +232,9 @@ def test_flash_attention(ops, nb, S, H, scale, mode):
                                                (1, 2049, 3, 1.0, 0), (1, 2049, 3, 1.0, 1),
                                                (3, 101, 12, 3.0, 0), (1, 2, 1, 1.0, 0),
                                                (1, 2049, 3, 1.0, 5), (2, 321, 3, 3.0, 5), (1, 66, 2, 1.0, 5), (1, 2, 1, 1.0, 5),
-                                               (2, 577, 3, 1.0, 5), (1, 34, 1, 3.0, 5), (1, 97, 2, 3.0, 5)])
+                                               (2, 577, 3, 1.0, 5), (1, 34, 1, 3.0, 5), (1, 97, 2, 3.0, 5),
+                                               (1, 2049, 3, 1.0, 7), (2, 321, 3, 3.0, 7), (1, 66, 2, 1.0, 7), (1, 2, 1, 1.0, 7),
+                                               (2, 577, 3, 1.0, 7), (1, 34, 1, 3.0, 7), (1, 97, 2, 3.0, 7), (1, 1025, 2, 1.0, 7)])
 def test_flash_attention_extra_row(ops, nb, S, H, scale, mode):
     """The ViT path: S - 1 tiled main rows + one "extra" row per batch (the cls token) as key AND query.  The result
     must equal plain attention over all S rows."""
@@ -265,6 +267,84 @@ def test_flash_attention_forced_rescale(ops):
     x = qkv.float().view(nb, S, 3, H, 64).permute(2, 0, 3, 1, 4)
     p = F.softmax(x[0] @ x[1].transpose(-1, -2) * 0.125, dim=-1)
     close_bf16(got, (p @ x[2]).permute(0, 2, 1, 3).reshape(nb, S, 64))
+
+
+@pytest.mark.parametrize("nb,S,H", [(1, 513, 12), (1, 2049, 2), (2, 640, 3)])
+def test_flash_attention_mode8_prescaled_fragments(ops, nb, S, H):
+    """mode 8 = the fast loop of mode 7 (no per-score multiply) with the kernel scaling its own Q fragments in bf16: what
+    the ViT pipeline runs, except that there the q|k|v product scales q from its fp32 accumulator.  One more bf16
+    rounding of q, so only checked at ordinary logit sizes."""
+    qkv = rnd(nb, S, 3 * H * 64, seed=S)
+    ops.set_option("flash_mode", 8)
+    try:
+        got = ops.flash_attention_d64(qkv.to(D), H, 0.125, extra_last=True)
+    finally:
+        ops.set_option("flash_mode", 0)
+    close_bf16(got, _sdpa_ref(qkv, nb, S, H), rounds=2)
+
+
+def _sdpa_ref64(qkv, nb, S, H):
+    x = qkv.double().view(nb, S, 3, H, 64).permute(2, 0, 3, 1, 4)
+    p = F.softmax(x[0] @ x[1].transpose(-1, -2) * 0.125, dim=-1)
+    return (p @ x[2]).permute(0, 2, 1, 3).reshape(nb, S, H * 64).float()
+
+
+@pytest.mark.parametrize("S,extra", [(1536, False), (1537, True), (1100, False)])
+@pytest.mark.parametrize("gain", [4.0, 12.0, 30.0])
+def test_flash_mode7_out_of_line_rescale(ops, S, extra, gain):
+    """Mode 7 keeps its running max only within 2^64 of the true one and tests a row-sum piece instead of taking row
+    maxima; the exact max, the rescale of O / l / the C tuple and the redone exponentials live out of line.  Inputs that
+    force that path at chosen places: key j = gain x (a query row), so that row's score jumps by ~8 gain natural units
+    (gain 12: 2^138 over the first keys' max -- above the 2^64 test; gain 30: 2^346, v_exp_f32 returns +inf first),
+    at keys in the first / second half tile, in both 32-row blocks of a wave, in late tiles and in the last, partial one,
+    twice in a row with growing size; gain 4 stays under the test (stale max, no rescale).  Checked against float64."""
+    nb, H = 1, 2
+    qkv = rnd(nb, S, 3 * H * 64, seed=S + int(gain))
+    n = S - 1 if extra else S
+    spikes = [(70, 5), (100, 40), (700, 300), (n - 3, 77), (n - 40, 250), (333, 250), (900, 3)]  # (key row, query row)
+    for h in range(H):
+        for i, (kj, qi) in enumerate(spikes):
+            q = qkv[0, qi, 64 * h:64 * (h + 1)].float()
+            qkv[0, kj, 64 * H + 64 * h: 64 * H + 64 * (h + 1)] = (q * gain * (1 + 0.5 * (i % 3))).to(bf)
+    ops.set_option("flash_mode", 7)
+    try:
+        got = ops.flash_attention_d64(qkv.to(D), H, 0.125, extra_last=extra)
+    finally:
+        ops.set_option("flash_mode", 0)
+    assert torch.isfinite(got.float()).all()
+    close_bf16(got, _sdpa_ref64(qkv, nb, S, H))
+
+
+def test_flash_mode7_first_keys_dominate(ops):
+    """The other direction: the first 32 keys hold a row's maximum by a wide margin, every later p underflows to 0."""
+    nb, S, H = 1, 1024, 1
+    qkv = rnd(nb, S, 192, seed=5)
+    for qi in (3, 40, 200, 777):
+        qkv[0, qi % 32, 64:128] = (qkv[0, qi, :64].float() * 25).to(bf)
+    ops.set_option("flash_mode", 7)
+    try:
+        got = ops.flash_attention_d64(qkv.to(D), H, 0.125)
+    finally:
+        ops.set_option("flash_mode", 0)
+    close_bf16(got, _sdpa_ref64(qkv, nb, S, H))
+
+
+def test_flash_mode7_matches_mode5_and_lse(ops):
+    """Same inputs through both generated loops: outputs agree to bf16 rounding, log-sum-exp rows to fp32 rounding."""
+    nb, S, H = 2, 1281, 3
+    qkv = rnd(nb, S, 3 * H * 64, seed=11).to(D)
+    res = {}
+    for mode in (5, 7):
+        ops.set_option("flash_mode", mode)
+        try:
+            res[mode] = ops.flash_attention_d64(qkv, H, 0.125, extra_last=True, return_lse=True)
+        finally:
+            ops.set_option("flash_mode", 0)
+    close_bf16(res[7][0], res[5][0].float().cpu())
+    assert (res[7][1][:, :S] - res[5][1][:, :S]).abs().max().item() < 2e-2   # q * c rounded to bf16 once more: ~1e-3 relative on s
+    ref = torch.logsumexp((lambda x: x[0] @ x[1].transpose(-1, -2) * 0.125)(
+        qkv.float().cpu().view(nb, S, 3, H, 64).permute(2, 0, 3, 1, 4)), dim=-1) * 1.4426950408889634
+    assert (res[7][1].cpu()[:, :S] - ref.reshape(nb * H, S)).abs().max().item() < 3e-2
 
 
 def _tok_attn_ref(q, k, v, H, scale, tbl=None, L=512):

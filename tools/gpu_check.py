@@ -420,7 +420,7 @@ def sec_flashperf():
     for (nb, S, H, extra) in [(8, 2049, 12, True), (8, 2049, 12, False), (8, 2048, 12, False), (16, 513, 12, True)]:
         qkv = rnd(nb, S, 3 * H * 64, seed=3).to(dev)
         fl = 4 * nb * H * S * S * 64
-        for mode in (5,):
+        for mode in (5, 7, 8):
             ops.set_option("flash_mode", mode)
             ms = timeit(lambda: ops.flash_attention_d64(qkv, H, 0.125, extra_last=extra), iters=10)
             # the transpose alone
@@ -443,6 +443,32 @@ def _flash_ref(qkv, H):
     return (p @ x[2]).permute(0, 2, 1, 3).reshape(nb, S, H * 64)
 
 
+def flash_timeline(buf):
+    """mode 7, TIMED build: wall-clock (100 MHz) stamps per wave: entry, before / after the KV loop, exit; HW_ID"""
+    t = buf[65536:65536 + 1024 * 4 * 8].view(-1, 8).cpu().double()
+    t = t[t[:, 0] > 0]
+    t0 = t[:, 0].min()
+    main = t[t[:, 1] > 0]
+    extra = t[t[:, 1] == 0]
+    us = lambda x: (x - t0) / 100.0
+    print(f"  timeline (us from the first workgroup's entry; {len(main)} main waves, {len(extra)} extra-row waves)")
+    ent, pre, post, ex = us(main[:, 0]), us(main[:, 1]), us(main[:, 2]), us(main[:, 3])
+    first = ent < 5.0
+    for name, sel in (("round 1 (entry < 5 us)", first), ("later entries", ~first)):
+        if sel.sum() == 0:
+            continue
+        e_, p_, q_, x_ = ent[sel], pre[sel], post[sel], ex[sel]
+        print(f"    {name}: {int(sel.sum())} waves | entry {e_.min():6.1f}..{e_.max():6.1f} | prologue {(p_ - e_).mean():5.2f} (max {(p_ - e_).max():5.2f}) | "
+              f"KV loop {(q_ - p_).mean():6.2f} (min {(q_ - p_).min():6.2f} max {(q_ - p_).max():6.2f}) | epilogue {(x_ - q_).mean():5.2f} (max {(x_ - q_).max():5.2f}) | "
+              f"exit {x_.min():6.1f}..{x_.max():6.1f}")
+    if len(extra):
+        e_, x_ = us(extra[:, 0]), us(extra[:, 3])
+        print(f"    extra-row workgroups: entry {e_.min():6.1f}..{e_.max():6.1f}, duration {(x_ - e_).mean():5.2f} (max {(x_ - e_).max():5.2f}), last exit {x_.max():6.1f}")
+    # how many main workgroups per CU at once: HW_ID bits: wave 3:0, simd 5:4, cu 11:8, sh 12, se 15:13 ... ; XCC in [5]
+    allw = torch.cat([main, extra])
+    print(f"    kernel span by these stamps: {us(allw[:, 3]).max():6.1f} us")
+
+
 def sec_flashtime():
     """s_memtime phase breakdown of the flash attention kernel (cycles per KV tile per wave)"""
     from u2tokenizer_amd import _lib
@@ -450,7 +476,7 @@ def sec_flashtime():
     nb, S, H = 8, 2049, 12
     qkv = rnd(nb, S, 3 * H * 64, seed=3).to(dev)
     names = ["gload", "QK^T", "softmax", "PV", "wait+lstore", "-", "barrier"]
-    for mode in (5,):
+    for mode in (5, 7, 8):
         ops.set_option("flash_mode", mode)
         ms0 = timeit(lambda: ops.flash_attention_d64(qkv, H, 0.125, extra_last=True), iters=5)
         buf = torch.zeros(4096 * 4 * 8, dtype=torch.int64, device=dev)
@@ -461,7 +487,9 @@ def sec_flashtime():
         r = buf.view(-1, 8).double()
         r = r[r[:, 7] > 0]
         per = r[:, :7].sum(0) / r[:, 7].sum()
-        if mode % 10 == 5:
+        if mode in (7, 8):
+            flash_timeline(buf)
+        if mode % 10 in (5, 7, 8):
             print(f"  mode {mode}: {ms0 * 1e3:7.1f} us untimed | per 64-key tile per wave (2 blocks): phases u=2t {per[0]:6.0f}  dma wait {per[1]:6.0f}  "
                   f"barrier {per[2]:6.0f}  dma issue {per[3]:6.0f}  phases u=2t+1 {per[4]:6.0f}  total {per[:5].sum():6.0f}", flush=True)
             continue

@@ -181,6 +181,7 @@ struct FlashArgs {
   const bf16_t *qx, *kx, *vx;
   bf16_t* outx;
   int S, H, nb, S_pad, n_extra, mode, n_main;
+  int q_prescaled;  // q and qx already carry scale * log2 e (mode 7 only)
   int64_t ld_qk, q_bs, ld_out, out_bs, x_bs, ox_bs;
   float scale_log2e;
   float* lse;      // optional: lse[(b * H + h) * lse_ld + row] = log2 sum_k exp2(s_k scale log2e) per query row (the extra
@@ -469,7 +470,7 @@ __device__ __forceinline__ void flash_extra_row(const FlashArgs& a, char* lds_ra
   float* red = reinterpret_cast<float*>(lds_raw) + a.S_pad;   // [2 * NW] block reductions
   const int S = a.S, S_pad = a.S_pad;
   const int lane = tid & 63, wv = tid >> 6;
-  const float c = a.scale_log2e;
+  const float c = a.q_prescaled ? 1.0f : a.scale_log2e;
   uint4 qv[8];
   {
     const bf16_t* qp = a.qx + (int64_t)b * a.x_bs + h * 64;
@@ -593,8 +594,8 @@ struct FdpBlock {       // final state of one 32-row query block of a wave
 
 // the extra key (one per batch) and the output of one block
 __device__ __forceinline__ void fdp_finish(const FlashArgs& a, FdpBlock& x, const bf16x8 (&qfx)[4], const int b, const int h,
-                                           const int qrow, const int hi) {
-  const float scale_log2e = a.scale_log2e;
+                                           const int qrow, const int hi, const bool q_prescaled = false) {
+  const float scale_log2e = q_prescaled ? 1.0f : a.scale_log2e;  // mode 7 carries scale * log2 e in its Q fragments
   if (a.n_extra) {
     const bf16_t* kxp = a.kx + (int64_t)b * a.x_bs + h * 64 + hi * 8;
     const bf16_t* vxp = a.vx + (int64_t)b * a.x_bs + h * 64 + 4 * hi;
@@ -745,6 +746,144 @@ __global__ __launch_bounds__(256, 2) void flash_dp_kernel(const FlashArgs a) {
   fdp_finish(a, x1, qf[1], b, h, wrow0 + 32 + l31, hi);
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Double-pipeline form, round 4 (mode 7): same units, ring and DMA as mode 5; the KV loop is
+// flash_dp2_asm.inc (tools/gen_flash_dp2_asm.py, where the schedule and the reasons are written down).  In short,
+// the loop of mode 5 was VALU-issue bound at 59 SIMD cycles per MFMA slot; this one takes the scale FMAs, the row
+// max, the address adds and the trans-use nops out of the slot: Q fragments carry scale * log2 e (one bf16
+// rounding of q * c instead of q: the same relative error, a different rounding point than the reference's), the
+// running max is subtracted by the matrix pipe (C operand of the first Q K^T MFMA = a tuple holding -m), m is only
+// kept within 2^64 of the true running max (an out-of-line path restores that when a row-sum piece says so), and
+// the tile loop is unrolled over the ring so fragment reads are lane base + immediate.
+#include "flash_dp2_asm.inc"
+
+__device__ __forceinline__ bf16x8 fdp2_prescale(const bf16x8 q, const float c) {
+  union { bf16x8 v; uint32_t u[4]; } in, o;
+  in.v = q;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o.u[j] = pack2_bf16(bf16lo(in.u[j]) * c, bf16hi(in.u[j]) * c);
+  return o.v;
+}
+
+// QMODE: 0 = q as the reference has it, every score multiplied by scale * log2 e in fp32 (flash_dp2_asm.inc, "_X" text);
+//        1 = the caller's q / qx already carry scale * log2 e (the ViT's q|k|v product scales its q columns in the
+//            epilogue, from the fp32 accumulator: one rounding, as for the unscaled q);
+//        2 = the kernel multiplies its Q fragments itself (a second bf16 rounding of q: diagnostic / timing only).
+template <bool TIMED, int QMODE>
+__global__ __launch_bounds__(256, 2) void flash_dp2_kernel(const FlashArgs a) {
+  __shared__ __attribute__((aligned(1024))) char lds[FDP_SLOTS][16384];  // [slot][K tile 8 KB | V^T tile 8 KB]
+  const int tid = threadIdx.x;
+  // TIMED: wall-clock stamps (s_memrealtime, 100 MHz) of the workgroup's sections in a second region of the debug buffer
+  unsigned long long* tl = nullptr;
+  if constexpr (TIMED) {
+    tl = g_flash_dbg + 65536 + ((size_t)blockIdx.x * 4 + (tid >> 6)) * 8;
+    if ((tid & 63) == 0) {
+      tl[0] = __builtin_amdgcn_s_memrealtime();
+      tl[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+      tl[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); // XCC_ID
+    }
+  }
+  if ((int)blockIdx.x >= a.n_main) {
+    const int e = blockIdx.x - a.n_main;
+    flash_extra_row(a, &lds[0][0], e / a.H, e % a.H, tid);
+    if constexpr (TIMED) if ((tid & 63) == 0) tl[3] = __builtin_amdgcn_s_memrealtime();
+    return;
+  }
+  int bid;
+  {
+    const int nwg = a.n_main, qn = nwg >> 3, rn = nwg & 7;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+  }
+  const int nqt = (a.S + 255) >> 8;
+  const int hh = bid / nqt, b = hh / a.H, h = hh % a.H, row0 = (bid % nqt) * 256;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int S = a.S, S_pad = a.S_pad;
+  const int64_t ld_qk = a.ld_qk;
+  const bf16_t* qb_ = a.q + (int64_t)b * a.q_bs + h * 64;
+  const bf16_t* kb_ = a.k + (int64_t)b * a.q_bs + h * 64;
+  const bf16_t* vb_ = a.vt + ((int64_t)b * a.H + h) * 64 * S_pad;
+  const int wrow0 = row0 + wv * 64;
+  const int ntile = (S + 63) >> 6;
+
+  bf16x8 qf[2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const bf16_t* qp = qb_ + (int64_t)min(wrow0 + qb * 32 + l31, S - 1) * ld_qk + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[qb][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+      if constexpr (QMODE == 2) qf[qb][ks] = fdp2_prescale(qf[qb][ks], a.scale_log2e);
+    }
+  }
+  // DMA pieces of this wave: MUBUF descriptors built by hand -- K rows past S read as zero
+  const int prow = wv * 16 + (lane >> 3);
+  const int pch0 = (lane & 7) ^ ((prow >> 1) & 7), pch1 = pch0 ^ 4;
+  const int ko0 = (prow * (int)ld_qk + pch0 * 8) * 2, ko1 = ((prow + 8) * (int)ld_qk + pch1 * 8) * 2;
+  const int vo0 = (prow * S_pad + pch0 * 8) * 2, vo1 = ((prow + 8) * S_pad + pch1 * 8) * 2;
+  const int k_tile_bytes = 64 * (int)ld_qk * 2;
+  const uint64_t kaddr = (uint64_t)(uintptr_t)kb_, vaddr = (uint64_t)(uintptr_t)vb_;
+  i32x4_t rsk, rsv;
+  rsk[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)kaddr);
+  rsk[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(kaddr >> 32));
+  rsk[2] = (int)((((int64_t)S - 1) * ld_qk + 64) * 2);
+  rsk[3] = 0x00020000;
+  rsv[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)vaddr);
+  rsv[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(vaddr >> 32));
+  rsv[2] = 64 * S_pad * 2;
+  rsv[3] = 0x00020000;
+  const uint32_t lds_u32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&lds[0][0];
+  const uint32_t dma_base = lds_u32 + wv * 2048;
+  const uint32_t ab0 = kt_off(l31, hi);
+  const uint32_t dump = lds_u32 + wv * 16384 + lane * 16;
+  const int hi4 = 4 * hi;
+  float mr0, lr0, mr1, lr1;
+  int lane2;  // the lane id as the block returns it: keeps the epilogue's per-lane values from living across the block
+  unsigned long long* dbg = g_flash_dbg + ((size_t)blockIdx.x * 4 + wv) * 8;  // TIMED: 5 section times, [7] = tiles
+#define FDP2_OPERANDS                                                                                                  \
+               : [mr0] "=&v"(mr0), [lr0] "=&v"(lr0), [mr1] "=&v"(mr1), [lr1] "=&v"(lr1), [lid] "=&v"(lane2)             \
+               : [qf00] "v"(qf[0][0]), [qf01] "v"(qf[0][1]), [qf02] "v"(qf[0][2]), [qf03] "v"(qf[0][3]),                \
+                 [qf10] "v"(qf[1][0]), [qf11] "v"(qf[1][1]), [qf12] "v"(qf[1][2]), [qf13] "v"(qf[1][3]),                \
+                 [ab0] "v"(ab0), [ko0] "v"(ko0), [ko1] "v"(ko1), [vo0] "v"(vo0), [vo1] "v"(vo1), [hi4] "v"(hi4),        \
+                 [dump] "v"(dump), [rsk] "s"(rsk), [rsv] "s"(rsv), [lds] "s"(lds_u32), [dma_base] "s"(dma_base),        \
+                 [ktile] "s"(k_tile_bytes), [seq] "s"(S), [ntile] "s"(ntile), [dbg] "v"(dbg),                           \
+                 [scale] "s"(scale_log2e), [rscale] "s"(rscale)
+  const float scale_log2e = a.scale_log2e, rscale = 1.0f / a.scale_log2e;
+  if constexpr (TIMED) {
+    if (lane == 0) tl[1] = __builtin_amdgcn_s_memrealtime();
+    if constexpr (QMODE == 0) asm volatile(FLASH_DP2_ASM_TEXT_X_TIMED FDP2_OPERANDS : FLASH_DP2_ASM_CLOBBERS_X_TIMED);
+    else asm volatile(FLASH_DP2_ASM_TEXT_TIMED FDP2_OPERANDS : FLASH_DP2_ASM_CLOBBERS_TIMED);
+    if (lane2 == 0) { dbg[7] = (unsigned long long)ntile; tl[2] = __builtin_amdgcn_s_memrealtime(); }
+  } else {
+    if constexpr (QMODE == 0) asm volatile(FLASH_DP2_ASM_TEXT_X FDP2_OPERANDS : FLASH_DP2_ASM_CLOBBERS_X);
+    else asm volatile(FLASH_DP2_ASM_TEXT FDP2_OPERANDS : FLASH_DP2_ASM_CLOBBERS);
+  }
+#undef FDP2_OPERANDS
+  // the block left O^T in LDS: tuple T = 2 * block + nb, 16-byte quarter j at [wave][T * 4 + j][lane]
+  const int hi2 = lane2 >> 5, l31b = lane2 & 31;
+  const char* dp = &lds[0][0] + wv * 16384 + lane2 * 16;
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {  // one block at a time: 32 accumulator values live, not 64
+    FdpBlock x;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 u = *reinterpret_cast<const float4*>(dp + ((2 * blk + nb) * 4 + j) * 1024);
+        x.oacc[nb][4 * j] = u.x; x.oacc[nb][4 * j + 1] = u.y; x.oacc[nb][4 * j + 2] = u.z; x.oacc[nb][4 * j + 3] = u.w;
+      }
+    x.m_run = blk ? mr1 : mr0;
+    x.l_run = blk ? lr1 : lr0;
+    fdp_finish(a, x, qf[blk], b, h, wrow0 + 32 * blk + l31b, hi2, QMODE != 0);
+  }
+  if constexpr (TIMED) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane2 == 0) tl[3] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+
 static bool g_flash_timed = false;
 int flash_set_debug_buffer(void* p) {  // >= grid * 4 * 8 uint64, zeroed by the caller; null detaches
   unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
@@ -755,7 +894,7 @@ int flash_set_debug_buffer(void* p) {  // >= grid * 4 * 8 uint64, zeroed by the 
 int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int nb, int S, int H,
                         int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs, int S_pad, float scale,
                         const bf16_t* qx, const bf16_t* kx, const bf16_t* vx, bf16_t* outx, int64_t x_bs, int64_t ox_bs,
-                        int n_extra, float* lse, int64_t lse_ld, hipStream_t stream) {
+                        int n_extra, float* lse, int64_t lse_ld, hipStream_t stream, int q_prescaled) {
   if (!q || !k || !vt || !out || nb <= 0 || S <= 0 || H <= 0 || n_extra < 0 || n_extra > 1) return U2_ERR_ARG;
   if (lse && lse_ld < S + n_extra) return U2_ERR_ARG;
   if ((S_pad & 63) || S_pad < ((S + 63) & ~63)) return U2_ERR_ARG;
@@ -773,15 +912,29 @@ int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16
   a.lse = lse; a.lse_ld = lse_ld;
   const int64_t nbh = (int64_t)nb * H;
   int mode = opts().flash_mode;
-  if (mode != 1 && mode != 5) mode = S >= 512 ? 5 : 1;  // measured: the double pipeline wins from S = 513 up
-  const int64_t blocks = mode == 5 ? nbh * ((S + 255) / 256) : nbh * ((S + 127) / 128);
+  if (mode != 1 && mode != 5 && mode != 7 && mode != 8) mode = S >= 512 ? 7 : 1;  // measured: the double pipeline wins from S = 513 up
+  if (q_prescaled) mode = 7;  // the only form that takes pre-scaled queries (the ViT launches it at S = 2048)
+  a.q_prescaled = q_prescaled;
+  const int64_t blocks = mode != 1 ? nbh * ((S + 255) / 256) : nbh * ((S + 127) / 128);
   a.mode = mode;
   a.n_main = (int)blocks;
   const int64_t grid = blocks + (n_extra ? nbh : 0);
   if (grid > 0x7fffffff) return U2_ERR_ARG;
   ProfScope ps(PROF_FLASH, 4.0 * nbh * (double)(S + n_extra) * (S + n_extra) * 64, stream,
                4.0 * nbh * (double)(S + n_extra) * 64 * 2.0);  // q, k, v^T read + o written, once
-  if (mode == 5) {
+  if (mode == 7 || mode == 8) {
+    const dim3 g((unsigned)grid), t(256);
+    if (q_prescaled) {
+      if (g_flash_timed) hipLaunchKernelGGL((flash_dp2_kernel<true, 1>), g, t, 0, stream, a);
+      else hipLaunchKernelGGL((flash_dp2_kernel<false, 1>), g, t, 0, stream, a);
+    } else if (mode == 8) {
+      if (g_flash_timed) hipLaunchKernelGGL((flash_dp2_kernel<true, 2>), g, t, 0, stream, a);
+      else hipLaunchKernelGGL((flash_dp2_kernel<false, 2>), g, t, 0, stream, a);
+    } else {
+      if (g_flash_timed) hipLaunchKernelGGL((flash_dp2_kernel<true, 0>), g, t, 0, stream, a);
+      else hipLaunchKernelGGL((flash_dp2_kernel<false, 0>), g, t, 0, stream, a);
+    }
+  } else if (mode == 5) {
     if (g_flash_timed) hipLaunchKernelGGL((flash_dp_kernel<true>), dim3((unsigned)grid), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((flash_dp_kernel<false>), dim3((unsigned)grid), dim3(256), 0, stream, a);
   } else {
