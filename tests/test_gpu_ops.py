@@ -283,6 +283,43 @@ def test_flash_attention_mode8_prescaled_fragments(ops, nb, S, H):
     close_bf16(got, _sdpa_ref(qkv, nb, S, H), rounds=2)
 
 
+@pytest.mark.parametrize("nb,S,H,extra,mode", [(1, 2049, 3, True, 7), (1, 2048, 3, False, 7), (3, 513, 2, True, 7),
+                                               (1, 2049, 3, True, 8), (2, 1024, 3, False, 7)])
+def test_flash_split_form(ops, nb, S, H, extra, mode):
+    """Shapes whose unit count divides by 3 and whose key tiles divide by 8 run 2/3 of the units as workgroups, each
+    walking 1.5 units' worth of key tiles; half a unit's state crosses between two workgroups through the workspace.
+    Against the reference, against the unsplit form, and bit-repeatable (fixed merge order)."""
+    qkv = rnd(nb, S, 3 * H * 64, seed=S + mode).to(D)
+    from u2tokenizer_amd import _lib
+    assert _lib.load_library().u2tok_flash_attention_d64_workspace_bytes(nb, S - 1 if extra else S, H) > 0
+    ops.set_option("flash_mode", mode)
+    try:
+        a1 = ops.flash_attention_d64(qkv, H, 0.125, extra_last=extra, return_lse=True)
+        a2 = ops.flash_attention_d64(qkv, H, 0.125, extra_last=extra, return_lse=True)
+        ops.set_option("flash_split", 0)
+        b1 = ops.flash_attention_d64(qkv, H, 0.125, extra_last=extra, return_lse=True)
+    finally:
+        ops.set_option("flash_mode", 0)
+        ops.set_option("flash_split", 1)
+    assert torch.equal(a1[0], a2[0]) and torch.equal(a1[1][:, :S], a2[1][:, :S])
+    close_bf16(a1[0], _sdpa_ref(qkv.cpu(), nb, S, H))
+    close_bf16(a1[0], b1[0].float().cpu(), rounds=1)
+    assert (a1[1][:, :S] - b1[1][:, :S]).abs().max().item() < 1e-3
+
+
+def test_flash_split_form_halves_far_apart(ops):
+    """The two halves of a split unit meet with running maxima 2^100 apart in either direction, and rows whose first half
+    ran the out-of-line rescale."""
+    nb, S, H = 1, 2048, 3
+    qkv = rnd(nb, S, 3 * H * 64, seed=8)
+    for h in range(H):
+        for (kj, qi, g) in [(1500, 300, 12.0), (200, 310, 12.0), (1900, 330, 30.0), (90, 260, 9.0), (1100, 500, 14.0), (40, 700, 11.0)]:
+            q = qkv[0, qi, 64 * h:64 * (h + 1)].float()
+            qkv[0, kj, 64 * H + 64 * h: 64 * H + 64 * (h + 1)] = (q * g).to(bf)
+    got = ops.flash_attention_d64(qkv.to(D), H, 0.125)
+    close_bf16(got, _sdpa_ref64(qkv, nb, S, H))
+
+
 def _sdpa_ref64(qkv, nb, S, H):
     x = qkv.double().view(nb, S, 3, H, 64).permute(2, 0, 3, 1, 4)
     p = F.softmax(x[0] @ x[1].transpose(-1, -2) * 0.125, dim=-1)

@@ -420,16 +420,18 @@ def sec_flashperf():
     for (nb, S, H, extra) in [(8, 2049, 12, True), (8, 2049, 12, False), (8, 2048, 12, False), (16, 513, 12, True)]:
         qkv = rnd(nb, S, 3 * H * 64, seed=3).to(dev)
         fl = 4 * nb * H * S * S * 64
-        for mode in (5, 7, 8):
+        for mode, split in ((5, 0), (7, 0), (7, 1), (8, 0), (8, 1)):
             ops.set_option("flash_mode", mode)
+            ops.set_option("flash_split", split)
             ms = timeit(lambda: ops.flash_attention_d64(qkv, H, 0.125, extra_last=extra), iters=10)
             # the transpose alone
             ref = _flash_ref(qkv[:1, :, :], H)
             got = ops.flash_attention_d64(qkv[:1].contiguous(), H, 0.125, extra_last=extra)
             err = (got.float() - ref).abs().max().item()
-            print(f"  nb={nb} S={S} extra={int(extra)} mode={mode}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF/s  "
+            print(f"  nb={nb} S={S} extra={int(extra)} mode={mode} split={split}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF/s  "
                   f"util={fl / ms / 1e9 / 2500:.3f}  max_err={err:.2e}", flush=True)
     ops.set_option("flash_mode", 0)
+    ops.set_option("flash_split", 1)
     qkv = rnd(8, 2049, 3 * 768, seed=3).to(dev)
     vt = torch.empty((8, 768, 2048), dtype=bf, device=dev)
     ms = timeit(lambda: ops.transpose(qkv[:, :2048, 1536:].contiguous(), ld_out=2048, perm16=True), iters=10)
@@ -443,30 +445,42 @@ def _flash_ref(qkv, H):
     return (p @ x[2]).permute(0, 2, 1, 3).reshape(nb, S, H * 64)
 
 
-def flash_timeline(buf):
-    """mode 7, TIMED build: wall-clock (100 MHz) stamps per wave: entry, before / after the KV loop, exit; HW_ID"""
-    t = buf[65536:65536 + 1024 * 4 * 8].view(-1, 8).cpu().double()
-    t = t[t[:, 0] > 0]
+def flash_timeline(buf, split):
+    """modes 7 / 8, TIMED build: wall-clock (100 MHz) stamps per wave: [0] entry, [1] before the KV loop, [2] after it,
+    [3] exit; the first region of the buffer has the number of key tiles the wave walked in [7]"""
+    n = 2048 * 4
+    t = buf[65536:65536 + n * 8].view(-1, 8).cpu().double()
+    tiles = buf[:n * 8].view(-1, 8).cpu().double()[:, 7]
+    ok = t[:, 0] > 0
+    t, tiles = t[ok], tiles[ok]
     t0 = t[:, 0].min()
-    main = t[t[:, 1] > 0]
-    extra = t[t[:, 1] == 0]
     us = lambda x: (x - t0) / 100.0
-    print(f"  timeline (us from the first workgroup's entry; {len(main)} main waves, {len(extra)} extra-row waves)")
-    ent, pre, post, ex = us(main[:, 0]), us(main[:, 1]), us(main[:, 2]), us(main[:, 3])
-    first = ent < 5.0
-    for name, sel in (("round 1 (entry < 5 us)", first), ("later entries", ~first)):
+    ent, pre, post, ex = us(t[:, 0]), us(t[:, 1]), us(t[:, 2]), us(t[:, 3])
+    main = t[:, 1] > 0
+    print(f"  timeline (us from the first workgroup's entry; {int(main.sum())} main waves, {int((~main).sum())} extra-row waves)")
+    tmax = tiles[main].max()
+    groups = [("whole units, entry < 5 us", main & (tiles == tmax) & (ent < 5.0)), ("whole units, later", main & (tiles == tmax) & (ent >= 5.0)),
+              ("half units", main & (tiles < tmax))]
+    for name, sel in groups:
         if sel.sum() == 0:
             continue
         e_, p_, q_, x_ = ent[sel], pre[sel], post[sel], ex[sel]
         print(f"    {name}: {int(sel.sum())} waves | entry {e_.min():6.1f}..{e_.max():6.1f} | prologue {(p_ - e_).mean():5.2f} (max {(p_ - e_).max():5.2f}) | "
               f"KV loop {(q_ - p_).mean():6.2f} (min {(q_ - p_).min():6.2f} max {(q_ - p_).max():6.2f}) | epilogue {(x_ - q_).mean():5.2f} (max {(x_ - q_).max():5.2f}) | "
               f"exit {x_.min():6.1f}..{x_.max():6.1f}")
-    if len(extra):
-        e_, x_ = us(extra[:, 0]), us(extra[:, 3])
+    # first-round whole units by XCD (workgroup w runs on XCD w % 8): is the spread of the loop times systematic?
+    widx = torch.arange(n)[ok] // 4
+    sel = groups[0][1]
+    if sel.sum():
+        loop = (post - pre)
+        per_xcd = [loop[sel & ((widx & 7) == x)].mean().item() for x in range(8)]
+        print("    first round, KV loop by XCD: " + "  ".join(f"{v:5.1f}" for v in per_xcd) +
+              f" | spread inside a workgroup (max - min of its 4 waves), mean: "
+              f"{(loop[sel].view(-1, 4).max(1).values - loop[sel].view(-1, 4).min(1).values).mean().item():4.2f}")
+    if (~main).sum():
+        e_, x_ = ent[~main], ex[~main]
         print(f"    extra-row workgroups: entry {e_.min():6.1f}..{e_.max():6.1f}, duration {(x_ - e_).mean():5.2f} (max {(x_ - e_).max():5.2f}), last exit {x_.max():6.1f}")
-    # how many main workgroups per CU at once: HW_ID bits: wave 3:0, simd 5:4, cu 11:8, sh 12, se 15:13 ... ; XCC in [5]
-    allw = torch.cat([main, extra])
-    print(f"    kernel span by these stamps: {us(allw[:, 3]).max():6.1f} us")
+    print(f"    kernel span by these stamps: {ex.max():6.1f} us")
 
 
 def sec_flashtime():
@@ -476,10 +490,11 @@ def sec_flashtime():
     nb, S, H = 8, 2049, 12
     qkv = rnd(nb, S, 3 * H * 64, seed=3).to(dev)
     names = ["gload", "QK^T", "softmax", "PV", "wait+lstore", "-", "barrier"]
-    for mode in (5, 7, 8):
+    for mode, split in ((5, 0), (7, 0), (8, 0), (8, 1)):
         ops.set_option("flash_mode", mode)
+        ops.set_option("flash_split", split)
         ms0 = timeit(lambda: ops.flash_attention_d64(qkv, H, 0.125, extra_last=True), iters=5)
-        buf = torch.zeros(4096 * 4 * 8, dtype=torch.int64, device=dev)
+        buf = torch.zeros(65536 + 2048 * 4 * 8, dtype=torch.int64, device=dev)
         _lib.check(h.u2tok_flash_debug_buffer(buf.data_ptr()), "flash_debug_buffer")
         ops.flash_attention_d64(qkv, H, 0.125, extra_last=True)
         torch.cuda.synchronize()
@@ -488,9 +503,9 @@ def sec_flashtime():
         r = r[r[:, 7] > 0]
         per = r[:, :7].sum(0) / r[:, 7].sum()
         if mode in (7, 8):
-            flash_timeline(buf)
+            flash_timeline(buf, split)
         if mode % 10 in (5, 7, 8):
-            print(f"  mode {mode}: {ms0 * 1e3:7.1f} us untimed | per 64-key tile per wave (2 blocks): phases u=2t {per[0]:6.0f}  dma wait {per[1]:6.0f}  "
+            print(f"  mode {mode} split {split}: {ms0 * 1e3:7.1f} us untimed | per 64-key tile per wave (2 blocks): phases u=2t {per[0]:6.0f}  dma wait {per[1]:6.0f}  "
                   f"barrier {per[2]:6.0f}  dma issue {per[3]:6.0f}  phases u=2t+1 {per[4]:6.0f}  total {per[:5].sum():6.0f}", flush=True)
             continue
         if mode % 10 == 4:

@@ -182,6 +182,11 @@ struct FlashArgs {
   bf16_t* outx;
   int S, H, nb, S_pad, n_extra, mode, n_main;
   int q_prescaled;  // q and qx already carry scale * log2 e (mode 7 only)
+  int wide_out;     // out rows are 16-byte aligned: the double-pipeline forms store 16 bytes per lane
+  int n_xwg, n_tail;   // flash_dp2_kernel: grid = n_main whole units | n_xwg extra-row workgroups | 2 n_tail half units
+  float* part;         //   split units: O^T of the half that arrived first,
+  float* part_stat;    //   its (m, l) per lane,
+  unsigned* part_flag; //   one ticket word per split unit (zero before the launch)
   int64_t ld_qk, q_bs, ld_out, out_bs, x_bs, ox_bs;
   float scale_log2e;
   float* lse;      // optional: lse[(b * H + h) * lse_ld + row] = log2 sum_k exp2(s_k scale log2e) per query row (the extra
@@ -639,8 +644,25 @@ __device__ __forceinline__ void fdp_finish(const FlashArgs& a, FdpBlock& x, cons
   const float l_tot = x.l_run + __shfl_xor(x.l_run, 32, 64);
   const float inv = 1.f / l_tot;
   if (a.lse && hi == 0 && qrow < a.S) a.lse[((int64_t)b * a.H + h) * a.lse_ld + qrow] = x.m_run + __builtin_log2f(l_tot);
-  if (qrow < a.S) {
-    bf16_t* op = a.out + (int64_t)b * a.out_bs + (int64_t)qrow * a.ld_out + h * 64;
+  bf16_t* op = a.out + (int64_t)b * a.out_bs + (int64_t)qrow * a.ld_out + h * 64;
+  if (a.wide_out) {
+    // 16-byte stores (guide T21): the lane owns d = 8 g + 4 hi + [0, 4) of its row, its partner lane (+32) the other half
+    // of the same 8; v_permlane32_swap on the packed words of two neighbouring groups leaves 8 consecutive d per lane.
+    // All 64 lanes take part in the swaps; rows past S are only not stored.
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        const int g0 = 2 * gp, g1 = 2 * gp + 1;
+        const uint32_t a0 = pack2_bf16(x.oacc[nb][4 * g0] * inv, x.oacc[nb][4 * g0 + 1] * inv);
+        const uint32_t a1 = pack2_bf16(x.oacc[nb][4 * g0 + 2] * inv, x.oacc[nb][4 * g0 + 3] * inv);
+        const uint32_t b0 = pack2_bf16(x.oacc[nb][4 * g1] * inv, x.oacc[nb][4 * g1 + 1] * inv);
+        const uint32_t b1 = pack2_bf16(x.oacc[nb][4 * g1 + 2] * inv, x.oacc[nb][4 * g1 + 3] * inv);
+        const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        if (qrow < a.S) *reinterpret_cast<uint4*>(op + nb * 32 + 8 * (g0 + hi)) = uint4{r0[0], r1[0], r0[1], r1[1]};
+      }
+  } else if (qrow < a.S) {
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -765,10 +787,127 @@ __device__ __forceinline__ bf16x8 fdp2_prescale(const bf16x8 q, const float c) {
   return o.v;
 }
 
+// Extra query row of head (b, h) for the double pipeline of round 4 (NT threads).  The first form (flash_extra_row above)
+// took ~40 us per row -- 64 dependent 16-byte loads per thread -- and sat on the kernel's tail.  Scores: 8 lanes per key
+// (16-byte K chunks, fully coalesced rows), 16 keys per thread in flight; softmax through LDS; P V: 16 lanes per V^T
+// row, 16 independent 16-byte loads per thread in flight.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ float dot2_bf16(const uint32_t a, const uint32_t b, const float c) {  // v_dot2c_f32_bf16
+  return __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const bf16x2_t*>(&a), *reinterpret_cast<const bf16x2_t*>(&b), c, false);
+}
+template <int NT>
+__device__ __forceinline__ void flash_extra_row2(const FlashArgs& a, float* sbuf, const int b, const int h, const int tid) {
+  constexpr int NW = NT / 64;
+  float* red = sbuf + a.S_pad;                                    // [2 NW] block reductions
+  bf16_t* pb = reinterpret_cast<bf16_t*>(sbuf + a.S_pad + 64);    // [S_pad] probabilities, bf16, in V^T's key order
+  const int lane = tid & 63, wv = tid >> 6;
+  const int S = a.S, S_pad = a.S_pad;
+  const float c = a.q_prescaled ? 1.0f : a.scale_log2e;
+  const int kk = lane >> 3, ch = lane & 7;
+  // the products run on v_dot2c_f32_bf16 (two bf16 x bf16 terms per instruction, fp32 sum, no unpacking): in the shadow of
+  // the main waves, which are VALU-issue bound, this routine is paid for in issue slots, not in bytes
+  const uint4 qw = *reinterpret_cast<const uint4*>(a.qx + (int64_t)b * a.x_bs + h * 64 + ch * 8);
+  auto dot8 = [&](const uint4 u) {
+    float acc = dot2_bf16(qw.x, u.x, 0.f);
+    acc = dot2_bf16(qw.y, u.y, acc); acc = dot2_bf16(qw.z, u.z, acc); acc = dot2_bf16(qw.w, u.w, acc);
+    acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+    return acc * c;
+  };
+  const bf16_t* kb_ = a.k + (int64_t)b * a.q_bs + h * 64 + ch * 8;
+  const float sx = dot8(*reinterpret_cast<const uint4*>(a.kx + (int64_t)b * a.x_bs + h * 64 + ch * 8));  // the extra key
+  float m = sx;
+  constexpr int KU = 8;  // keys per thread in flight
+  for (int j0 = wv * 8 + kk; j0 < S_pad; j0 += KU * 8 * NW) {
+    uint4 u[KU];
+#pragma unroll
+    for (int i = 0; i < KU; ++i) u[i] = *reinterpret_cast<const uint4*>(kb_ + (int64_t)min(j0 + 8 * NW * i, S - 1) * a.ld_qk);
+#pragma unroll
+    for (int i = 0; i < KU; ++i) {
+      const int j = j0 + 8 * NW * i;
+      float sc = dot8(u[i]);
+      if (j >= S) sc = -INFINITY;  // padding columns of V^T are zero: probability 0 there
+      if (j < S_pad) {
+        if (ch == 0) sbuf[j] = sc;
+        m = fmaxf(m, sc);
+      }
+    }
+  }
+  m = wave_max(m);
+  if (lane == 0) red[wv] = m;
+  __syncthreads();
+  m = red[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w]);
+  float sum = 0.f;
+  for (int j = tid; j < S_pad; j += NT) {
+    const float p = __builtin_amdgcn_exp2f(sbuf[j] - m);
+    // inside a group of 16 keys V^T stores [0-3, 8-11, 4-7, 12-15]: the same permutation for P
+    const int r = j & 15;
+    pb[(j & ~15) + ((r & 3) | ((r & 4) << 1) | ((r & 8) >> 1))] = f32_to_bf16(p);
+    sum += p;
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[NW + wv] = sum;
+  __syncthreads();
+  const float px = __builtin_amdgcn_exp2f(sx - m);
+  float l_tot = px;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) l_tot += red[NW + w];
+  if (a.lse && tid == 0) a.lse[((int64_t)b * a.H + h) * a.lse_ld + S] = m + __builtin_log2f(l_tot);
+  // O[d] = sum_j p_j V[j][d]: 16 lanes per row d of V^T, 16-byte pieces against the 16 bytes of P at the same offset
+  const int part = tid & 15;
+  const int npc = S_pad >> 3;
+  for (int d = tid >> 4; d < 64; d += NT / 16) {
+    const bf16_t* vrow = a.vt + (((int64_t)b * a.H + h) * 64 + d) * S_pad;
+    float o0 = 0.f, o1 = 0.f;
+    for (int p0 = part; p0 < npc; p0 += 128) {
+      uint4 vv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int pc = p0 + 16 * i;
+        vv[i] = pc < npc ? *reinterpret_cast<const uint4*>(vrow + pc * 8) : uint4{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint4 pw = *reinterpret_cast<const uint4*>(pb + min(p0 + 16 * i, npc - 1) * 8);
+        o0 = dot2_bf16(pw.x, vv[i].x, o0); o1 = dot2_bf16(pw.y, vv[i].y, o1);
+        o0 = dot2_bf16(pw.z, vv[i].z, o0); o1 = dot2_bf16(pw.w, vv[i].w, o1);
+      }
+    }
+    float o = o0 + o1;
+    o += __shfl_xor(o, 1, 64); o += __shfl_xor(o, 2, 64); o += __shfl_xor(o, 4, 64); o += __shfl_xor(o, 8, 64);
+    if (part == 0) {
+      o = __builtin_fmaf(px, bf16_to_f32(a.vx[(int64_t)b * a.x_bs + h * 64 + d]), o);
+      a.outx[(int64_t)b * a.ox_bs + h * 64 + d] = f32_to_bf16(o / l_tot);
+    }
+  }
+}
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+// write-through stores / L1-bypassing loads for the hand-off of a split unit's partial state between two workgroups
+// (MI355X guide, "valid forms": 16-byte sc1 stores AND sc1 loads need no fences; the ticket is a relaxed agent atomic
+// behind the publisher's own vmcnt(0))
+__device__ __forceinline__ void st_sc1(float* p, const f32x4v v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4v ld_sc1(const float* p) {
+  f32x4v v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
 // QMODE: 0 = q as the reference has it, every score multiplied by scale * log2 e in fp32 (flash_dp2_asm.inc, "_X" text);
 //        1 = the caller's q / qx already carry scale * log2 e (the ViT's q|k|v product scales its q columns in the
 //            epilogue, from the fp32 accumulator: one rounding, as for the unscaled q);
 //        2 = the kernel multiplies its Q fragments itself (a second bf16 rounding of q: diagnostic / timing only).
+// Grid = [n_full whole units | n_xwg extra-row workgroups | 2 n_tail half units].  768 units on 512 workgroup slots are
+// 1.5 rounds, and the half-empty second round ran ONE wave per SIMD at 2/3 of a pair's throughput (timeline in
+// profiles/r04_flash_mode7_first.log).  With a scratch slab from the caller the units past the last full round are cut
+// in two key ranges, so the second round also runs two workgroups per CU; the workgroup of a pair that finishes first
+// leaves its state (O^T unnormalised, m, l) in the slab and exits, the other one merges -- always as (first key half) +
+// (second key half), whoever merges: bit-repeatable -- and finishes the rows.  A publisher never waits, so the scheme
+// cannot deadlock at any residency.  (A persistent form, every workgroup 1.5 units in lock step, measured no gain: with
+// all workgroups at their seams together nothing overlaps the epilogues.)
 template <bool TIMED, int QMODE>
 __global__ __launch_bounds__(256, 2) void flash_dp2_kernel(const FlashArgs a) {
   __shared__ __attribute__((aligned(1024))) char lds[FDP_SLOTS][16384];  // [slot][K tile 8 KB | V^T tile 8 KB]
@@ -777,26 +916,36 @@ __global__ __launch_bounds__(256, 2) void flash_dp2_kernel(const FlashArgs a) {
   unsigned long long* tl = nullptr;
   if constexpr (TIMED) {
     tl = g_flash_dbg + 65536 + ((size_t)blockIdx.x * 4 + (tid >> 6)) * 8;
-    if ((tid & 63) == 0) {
-      tl[0] = __builtin_amdgcn_s_memrealtime();
-      tl[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
-      tl[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); // XCC_ID
+    if ((tid & 63) == 0) tl[0] = __builtin_amdgcn_s_memrealtime();
+  }
+  // XCD-aware order inside each region of the grid: workgroup w runs on XCD w % 8 (observed dispatch rule); every XCD
+  // gets a contiguous range of logical ids so that the units of one (batch, head) share that XCD's L2 copy of K and V^T
+  auto xcd_order = [](const int w, const int nwg) {
+    const int qn = nwg >> 3, rn = nwg & 7, xcd = w & 7, idx = w >> 3;
+    return (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+  };
+  const int ntile = (a.S + 63) >> 6;
+  int unit, t0 = 0, t1 = ntile, half = -1;  // half: -1 = whole unit, 0 / 1 = first / second half of the key tiles
+  {
+    int w = blockIdx.x;
+    if (w < a.n_main) unit = xcd_order(w, a.n_main);
+    else if ((w -= a.n_main) < a.n_xwg) {
+      // these four waves share their SIMDs with main waves that are VALU-issue bound, and as the younger waves they would
+      // get the leftover issue slots (30 us for ~10 us of work): static priority, their demand is small
+      __builtin_amdgcn_s_setprio(3);
+      if (w < a.nb * a.H) flash_extra_row2<256>(a, reinterpret_cast<float*>(&lds[0][0]), w / a.H, w % a.H, tid);
+      if constexpr (TIMED) if ((tid & 63) == 0) tl[3] = __builtin_amdgcn_s_memrealtime();
+      return;
+    } else {
+      const int id = xcd_order(w - a.n_xwg, 2 * a.n_tail);
+      unit = a.n_main + (id >> 1);
+      half = id & 1;
+      t0 = half ? ntile >> 1 : 0;
+      t1 = half ? ntile : ntile >> 1;
     }
   }
-  if ((int)blockIdx.x >= a.n_main) {
-    const int e = blockIdx.x - a.n_main;
-    flash_extra_row(a, &lds[0][0], e / a.H, e % a.H, tid);
-    if constexpr (TIMED) if ((tid & 63) == 0) tl[3] = __builtin_amdgcn_s_memrealtime();
-    return;
-  }
-  int bid;
-  {
-    const int nwg = a.n_main, qn = nwg >> 3, rn = nwg & 7;
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
-  }
   const int nqt = (a.S + 255) >> 8;
-  const int hh = bid / nqt, b = hh / a.H, h = hh % a.H, row0 = (bid % nqt) * 256;
+  const int hh = unit / nqt, b = hh / a.H, h = hh % a.H, row0 = (unit % nqt) * 256;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
@@ -806,7 +955,6 @@ __global__ __launch_bounds__(256, 2) void flash_dp2_kernel(const FlashArgs a) {
   const bf16_t* kb_ = a.k + (int64_t)b * a.q_bs + h * 64;
   const bf16_t* vb_ = a.vt + ((int64_t)b * a.H + h) * 64 * S_pad;
   const int wrow0 = row0 + wv * 64;
-  const int ntile = (S + 63) >> 6;
 
   bf16x8 qf[2][4];
 #pragma unroll
@@ -839,6 +987,7 @@ __global__ __launch_bounds__(256, 2) void flash_dp2_kernel(const FlashArgs a) {
   const uint32_t ab0 = kt_off(l31, hi);
   const uint32_t dump = lds_u32 + wv * 16384 + lane * 16;
   const int hi4 = 4 * hi;
+  const float scale_log2e = a.scale_log2e, rscale = 1.0f / a.scale_log2e;
   float mr0, lr0, mr1, lr1;
   int lane2;  // the lane id as the block returns it: keeps the epilogue's per-lane values from living across the block
   unsigned long long* dbg = g_flash_dbg + ((size_t)blockIdx.x * 4 + wv) * 8;  // TIMED: 5 section times, [7] = tiles
@@ -848,14 +997,13 @@ __global__ __launch_bounds__(256, 2) void flash_dp2_kernel(const FlashArgs a) {
                  [qf10] "v"(qf[1][0]), [qf11] "v"(qf[1][1]), [qf12] "v"(qf[1][2]), [qf13] "v"(qf[1][3]),                \
                  [ab0] "v"(ab0), [ko0] "v"(ko0), [ko1] "v"(ko1), [vo0] "v"(vo0), [vo1] "v"(vo1), [hi4] "v"(hi4),        \
                  [dump] "v"(dump), [rsk] "s"(rsk), [rsv] "s"(rsv), [lds] "s"(lds_u32), [dma_base] "s"(dma_base),        \
-                 [ktile] "s"(k_tile_bytes), [seq] "s"(S), [ntile] "s"(ntile), [dbg] "v"(dbg),                           \
+                 [ktile] "s"(k_tile_bytes), [seq] "s"(S), [t0] "s"(t0), [t1] "s"(t1), [dbg] "v"(dbg),                   \
                  [scale] "s"(scale_log2e), [rscale] "s"(rscale)
-  const float scale_log2e = a.scale_log2e, rscale = 1.0f / a.scale_log2e;
   if constexpr (TIMED) {
     if (lane == 0) tl[1] = __builtin_amdgcn_s_memrealtime();
     if constexpr (QMODE == 0) asm volatile(FLASH_DP2_ASM_TEXT_X_TIMED FDP2_OPERANDS : FLASH_DP2_ASM_CLOBBERS_X_TIMED);
     else asm volatile(FLASH_DP2_ASM_TEXT_TIMED FDP2_OPERANDS : FLASH_DP2_ASM_CLOBBERS_TIMED);
-    if (lane2 == 0) { dbg[7] = (unsigned long long)ntile; tl[2] = __builtin_amdgcn_s_memrealtime(); }
+    if (lane2 == 0) { dbg[7] = (unsigned long long)(t1 - t0); tl[2] = __builtin_amdgcn_s_memrealtime(); }
   } else {
     if constexpr (QMODE == 0) asm volatile(FLASH_DP2_ASM_TEXT_X FDP2_OPERANDS : FLASH_DP2_ASM_CLOBBERS_X);
     else asm volatile(FLASH_DP2_ASM_TEXT FDP2_OPERANDS : FLASH_DP2_ASM_CLOBBERS);
@@ -864,6 +1012,27 @@ __global__ __launch_bounds__(256, 2) void flash_dp2_kernel(const FlashArgs a) {
   // the block left O^T in LDS: tuple T = 2 * block + nb, 16-byte quarter j at [wave][T * 4 + j][lane]
   const int hi2 = lane2 >> 5, l31b = lane2 & 31;
   const char* dp = &lds[0][0] + wv * 16384 + lane2 * 16;
+  // a split unit: which half arrived first?  ticket word: +1 on arrival, +2 more once the first arriver has published
+  float* slab = nullptr;
+  float* stat = nullptr;
+  bool publish = false;
+  if (half >= 0) {
+    const int su = unit - a.n_main;
+    slab = a.part + (size_t)su * (4 * 2 * 8 * 64 * 4) + (size_t)wv * (2 * 8 * 64 * 4) + lane2 * 4;
+    stat = a.part_stat + (size_t)su * (4 * 2 * 64 * 2) + (size_t)wv * (2 * 64 * 2) + lane2 * 2;
+    unsigned* tick = a.part_flag + su;
+    __shared__ int bc_s;  // the four dumps fill the ring's 64 KB
+    int* bc = &bc_s;
+    if (tid == 0) {
+      const unsigned t = __hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t != 0u) {  // second arriver: the first one publishes without waiting for anybody
+        while (__hip_atomic_load(tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 4u) __builtin_amdgcn_s_sleep(8);
+      }
+      *bc = t == 0u ? 1 : 0;
+    }
+    __syncthreads();
+    publish = *bc != 0;
+  }
 #pragma unroll
   for (int blk = 0; blk < 2; ++blk) {  // one block at a time: 32 accumulator values live, not 64
     FdpBlock x;
@@ -876,7 +1045,58 @@ __global__ __launch_bounds__(256, 2) void flash_dp2_kernel(const FlashArgs a) {
       }
     x.m_run = blk ? mr1 : mr0;
     x.l_run = blk ? lr1 : lr0;
-    fdp_finish(a, x, qf[blk], b, h, wrow0 + 32 * blk + l31b, hi2, QMODE != 0);
+    if (half >= 0) {
+      if (publish) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            st_sc1(slab + (size_t)(blk * 8 + nb * 4 + j) * 256,
+                   f32x4v{x.oacc[nb][4 * j], x.oacc[nb][4 * j + 1], x.oacc[nb][4 * j + 2], x.oacc[nb][4 * j + 3]});
+        __hip_atomic_store(stat + blk * 128, x.m_run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(stat + blk * 128 + 1, x.l_run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        continue;
+      }
+      f32x4v pv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) pv[q] = ld_sc1(slab + (size_t)(blk * 8 + q) * 256);
+      const float mp = __hip_atomic_load(stat + blk * 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float lp = __hip_atomic_load(stat + blk * 128 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]),
+                   "+v"(pv[6]), "+v"(pv[7])::"memory");
+      // always (first key half) f0 + (second key half) f1, whichever of the two this workgroup computed
+      const float mn = fmaxf(x.m_run, mp);
+      const float fo = __builtin_amdgcn_exp2f(x.m_run - mn), fp = __builtin_amdgcn_exp2f(mp - mn);
+      const float f0 = half == 0 ? fo : fp, f1 = half == 0 ? fp : fo;
+      const float l0 = half == 0 ? x.l_run : lp, l1 = half == 0 ? lp : x.l_run;
+      x.m_run = mn;
+      x.l_run = l0 * f0 + l1 * f1;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float mine = x.oacc[nb][4 * j + e], theirs = pv[nb * 4 + j][e];
+            x.oacc[nb][4 * j + e] = (half == 0 ? mine : theirs) * f0 + (half == 0 ? theirs : mine) * f1;
+          }
+    }
+    // the Q fragments again for the extra key's scores (cheap; kept live they were spilled around the block)
+    bf16x8 qfx[4];
+    if (a.n_extra) {
+      const bf16_t* qp = qb_ + (int64_t)min(wrow0 + blk * 32 + l31b, S - 1) * ld_qk + hi2 * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        qfx[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+        if constexpr (QMODE == 2) qfx[ks] = fdp2_prescale(qfx[ks], a.scale_log2e);
+      }
+    }
+    fdp_finish(a, x, qfx, b, h, wrow0 + 32 * blk + l31b, hi2, QMODE != 0);
+  }
+  if (half >= 0 && publish) {  // all four waves' stores acknowledged, then the ticket moves on
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(a.part_flag + (unit - a.n_main), 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if constexpr (TIMED) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -891,10 +1111,40 @@ int flash_set_debug_buffer(void* p) {  // >= grid * 4 * 8 uint64, zeroed by the 
   return hipMemcpyToSymbol(HIP_SYMBOL(g_flash_dbg), &q, sizeof(q)) == hipSuccess ? U2_OK : U2_ERR_LAUNCH;
 }
 
+// split form of the round-4 double pipeline: the units past the last full round of 2 workgroups per CU are cut in two key
+// ranges when they fill at most half a round (768 units on 512 slots: 256 of them); per split unit a 64 KB slab + 4 KB of
+// (m, l) + a ticket word
+static int flash_wg_slots() {
+  static int slots = 0;
+  if (!slots) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    slots = 2 * cus;
+  }
+  return slots;
+}
+static inline int64_t flash_split_units(int64_t nbh, int S) {
+  const int64_t units = nbh * ((S + 255) / 256);
+  const int ntile = (S + 63) / 64;
+  const int64_t cap = flash_wg_slots(), rem = units % cap;
+  return (ntile % 8 == 0 && rem > 0 && 2 * rem <= cap) ? rem : 0;
+}
+size_t flash_attention_d64_workspace_bytes(int nb, int S, int H) {
+  const int64_t ns = flash_split_units((int64_t)nb * H, S);
+  return ns ? (size_t)ns * (65536 + 4096) + (((size_t)ns * 4 + 255) & ~(size_t)255) : 0;
+}
+
+__global__ void flash_clear_flags_kernel(unsigned* f, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) f[i] = 0u;
+}
+
 int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int nb, int S, int H,
                         int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs, int S_pad, float scale,
                         const bf16_t* qx, const bf16_t* kx, const bf16_t* vx, bf16_t* outx, int64_t x_bs, int64_t ox_bs,
-                        int n_extra, float* lse, int64_t lse_ld, hipStream_t stream, int q_prescaled) {
+                        int n_extra, float* lse, int64_t lse_ld, hipStream_t stream, int q_prescaled, void* workspace,
+                        size_t workspace_bytes) {
   if (!q || !k || !vt || !out || nb <= 0 || S <= 0 || H <= 0 || n_extra < 0 || n_extra > 1) return U2_ERR_ARG;
   if (lse && lse_ld < S + n_extra) return U2_ERR_ARG;
   if ((S_pad & 63) || S_pad < ((S + 63) & ~63)) return U2_ERR_ARG;
@@ -910,6 +1160,8 @@ int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16
   a.ld_qk = ld_qk; a.q_bs = q_bs; a.ld_out = ld_out; a.out_bs = out_bs; a.x_bs = x_bs; a.ox_bs = ox_bs;
   a.scale_log2e = scale * 1.44269504088896340736f;
   a.lse = lse; a.lse_ld = lse_ld;
+  a.part = nullptr; a.part_stat = nullptr; a.part_flag = nullptr; a.n_xwg = 0; a.n_tail = 0;
+  a.wide_out = !((uintptr_t)out & 15) && !(ld_out & 7) && !(out_bs & 7);
   const int64_t nbh = (int64_t)nb * H;
   int mode = opts().flash_mode;
   if (mode != 1 && mode != 5 && mode != 7 && mode != 8) mode = S >= 512 ? 7 : 1;  // measured: the double pipeline wins from S = 513 up
@@ -918,22 +1170,37 @@ int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16
   const int64_t blocks = mode != 1 ? nbh * ((S + 255) / 256) : nbh * ((S + 127) / 128);
   a.mode = mode;
   a.n_main = (int)blocks;
-  const int64_t grid = blocks + (n_extra ? nbh : 0);
+  const int64_t grid = blocks + (n_extra ? nbh : 0);  // modes 1 / 5 (modes 7 / 8 lay their grid out below)
   if (grid > 0x7fffffff) return U2_ERR_ARG;
   ProfScope ps(PROF_FLASH, 4.0 * nbh * (double)(S + n_extra) * (S + n_extra) * 64, stream,
                4.0 * nbh * (double)(S + n_extra) * 64 * 2.0);  // q, k, v^T read + o written, once
   if (mode == 7 || mode == 8) {
-    const dim3 g((unsigned)grid), t(256);
-    if (q_prescaled) {
-      if (g_flash_timed) hipLaunchKernelGGL((flash_dp2_kernel<true, 1>), g, t, 0, stream, a);
-      else hipLaunchKernelGGL((flash_dp2_kernel<false, 1>), g, t, 0, stream, a);
-    } else if (mode == 8) {
-      if (g_flash_timed) hipLaunchKernelGGL((flash_dp2_kernel<true, 2>), g, t, 0, stream, a);
-      else hipLaunchKernelGGL((flash_dp2_kernel<false, 2>), g, t, 0, stream, a);
-    } else {
-      if (g_flash_timed) hipLaunchKernelGGL((flash_dp2_kernel<true, 0>), g, t, 0, stream, a);
-      else hipLaunchKernelGGL((flash_dp2_kernel<false, 0>), g, t, 0, stream, a);
+    // split form: the units past the last full round as two half units each (flash_dp2_kernel)
+    const int64_t ns = opts().flash_split ? flash_split_units(nbh, S) : 0;
+    const bool split = ns > 0 && workspace && workspace_bytes >= flash_attention_d64_workspace_bytes(nb, S, H) &&
+                       !((uintptr_t)workspace & 15);
+    a.n_tail = 0;
+    a.n_xwg = n_extra ? (int)((nbh + 7) & ~(int64_t)7) : 0;  // the tail region starts on a multiple of 8 (XCD order)
+    if (split) {
+      a.part = reinterpret_cast<float*>(workspace);
+      a.part_stat = a.part + (size_t)ns * 16384;
+      a.part_flag = reinterpret_cast<unsigned*>(a.part_stat + (size_t)ns * 1024);
+      a.n_tail = (int)ns;
+      a.n_main = (int)(blocks - ns);
+      hipLaunchKernelGGL(flash_clear_flags_kernel, dim3((unsigned)cdiv(ns, 256)), dim3(256), 0, stream, a.part_flag, (int)ns);
     }
+    const int64_t g2 = (int64_t)a.n_main + a.n_xwg + 2 * (int64_t)a.n_tail;
+    if (g2 > 0x7fffffff) return U2_ERR_ARG;
+    const dim3 g((unsigned)g2), t(256);
+    const int qm = q_prescaled ? 1 : mode == 8 ? 2 : 0;
+#define U2_FDP2_Q(T_)                                                                                            \
+  do {                                                                                                           \
+    if (qm == 0) hipLaunchKernelGGL((flash_dp2_kernel<T_, 0>), g, t, 0, stream, a);                             \
+    else if (qm == 1) hipLaunchKernelGGL((flash_dp2_kernel<T_, 1>), g, t, 0, stream, a);                        \
+    else hipLaunchKernelGGL((flash_dp2_kernel<T_, 2>), g, t, 0, stream, a);                                     \
+  } while (0)
+    if (g_flash_timed) U2_FDP2_Q(true); else U2_FDP2_Q(false);
+#undef U2_FDP2_Q
   } else if (mode == 5) {
     if (g_flash_timed) hipLaunchKernelGGL((flash_dp_kernel<true>), dim3((unsigned)grid), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((flash_dp_kernel<false>), dim3((unsigned)grid), dim3(256), 0, stream, a);

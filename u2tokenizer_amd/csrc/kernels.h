@@ -175,7 +175,9 @@ int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16
                         int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs, int S_pad, float scale,
                         const bf16_t* qx, const bf16_t* kx, const bf16_t* vx, bf16_t* outx, int64_t x_bs, int64_t ox_bs,
                         int n_extra, float* lse, int64_t lse_ld, hipStream_t stream,  // lse: optional row statistics out
-                        int q_prescaled = 0);  // 1: q and qx already carry scale * log2 e (double pipeline of round 4 only)
+                        int q_prescaled = 0,  // 1: q and qx already carry scale * log2 e (double pipeline of round 4 only)
+                        void* workspace = nullptr, size_t workspace_bytes = 0);  // enables the split form (balanced 1.5 units per workgroup)
+size_t flash_attention_d64_workspace_bytes(int nb, int S, int H);  // 0: the split form does not apply to this shape
 // Backward of the same attention (attn_bwd.hip): dq / dk / dv of out = softmax(q k^T scale) v for head dim 64, all S rows
 // of a batch in ONE row-major view (q, k, v: row r of batch b at + b*bs_qkv + r*ld_qkv, head h at column h*64; o / dout with
 // ld_o / bs_o; dq / dk / dv with ld_d / bs_d).  lse: optional row statistics of the forward kernel.  Workspace: the row statistics (lse, D).
