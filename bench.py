@@ -428,7 +428,7 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the two live rocprofv3 PMC passes behind roofline.traffic")
     ap.add_argument("--cpu-baseline-iters", type=int, default=3)
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
-                    help="library tuning switch for A/B measurements (u2tok_set_option), e.g. --option flash_mode=5")
+                    help="library tuning switch for A/B measurements (u2tok_set_option), e.g. --option flash_mode=8")
     ap.add_argument("--stub-cpu", action="store_true",
                     help="TEST PLUMBING ONLY (tests/test_bench_launcher.py): replace the step by a host no-op and use the "
                          "gloo backend, so that the launcher / barrier / MAX-over-ranks / JSON path can run on a box "
@@ -549,7 +549,7 @@ def main():
         _lib.check(h.u2tok_profile_collect2(ms, flops, byts, cnt, 6), "u2tok_profile_collect2")
         ops.set_option("profile", 0)
         names = ["gemm_bf16 (gemm_bt_kernel + gemm_bf16_nt_kernel + gemm_rows16_kernel + gemm_splitk_reduce_kernel)",
-                 "flash_d64 (flash_dp_kernel)", "temporal_attention_kernel", "row_ops", "data_movement",
+                 "flash_d64 (flash_dp2_kernel)", "temporal_attention_kernel", "row_ops", "data_movement",
                  "tok_attention (tok_attn_kernel + tok_attn_combine_kernel)"]
         # per class: time, launches, algorithmic TFLOP/s and algorithmic GB/s (operands + results once) of its launches
         classes = {n: {"ms_per_step": round(ms[i] / nprof, 4), "launches_per_step": cnt[i] // nprof,
@@ -635,7 +635,7 @@ def main():
                                                 "tiles, gemm_bf16_nt_kernel 128^2 / 64^2 tiles, split-K reduce)")
         line["roofline"]["classes"] = classes
         if ms[1] > 0:
-            line["roofline_attention"] = roof(1, "flash_d64", "flash_dp_kernel: ViT attention, 8 chunks x 12 heads x 2049 "
+            line["roofline_attention"] = roof(1, "flash_d64", "flash_dp2_kernel: ViT attention, 8 chunks x 12 heads x 2049 "
                                                                "tokens x head dim 64 (MONAI SABlock, vit.py:100-105)")
         if ms[5] > 0:
             line["roofline_tokenizer_attention"] = roof(5, "tok_attention",

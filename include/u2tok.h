@@ -278,17 +278,6 @@ int u2tok_flash_attention_d64_lse(const void* q, const void* k, const void* vt, 
                               float scale, const void* qx, const void* kx, const void* vx, void* outx, int64_t x_bs,
                               int64_t ox_bs, int32_t n_extra, float* lse, int64_t lse_ld,
                                   u2tok_stream_t stream);
-/* Same with a caller-owned scratch: when the shape allows it (units = nb * H * ceil(S / 256) divisible by 3, ceil(S / 64)
- * divisible by 8 -- the ViT-B/16 tower at 256^3: 768 units of 32 key tiles) the kernel runs its balanced split form, 2/3 of
- * the units as workgroups that each walk 1.5 units' worth of key tiles and hand half a unit's state through `workspace`
- * (u2tok_flash_attention_d64_workspace_bytes, 0 = the shape does not split; 16-byte aligned; contents undefined on entry
- * and exit).  lse may be NULL.  Results do not depend on the form beyond fp32 rounding of the merge. */
-size_t u2tok_flash_attention_d64_workspace_bytes(int32_t nb, int32_t S, int32_t H);
-int u2tok_flash_attention_d64_ws(const void* q, const void* k, const void* vt, void* out, int32_t nb, int32_t S,
-                                 int32_t H, int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs, int32_t S_pad,
-                                 float scale, const void* qx, const void* kx, const void* vx, void* outx, int64_t x_bs,
-                                 int64_t ox_bs, int32_t n_extra, float* lse, int64_t lse_ld, void* workspace,
-                                 size_t workspace_bytes, u2tok_stream_t stream);
 /* Fused attention core of the tokenizer's attention modules -- RelativeMultiheadAttention (rma.py:60-75: + relative_bias
  * [j - i + max_len - 1][h], bf16 (2 max_len - 1, H)), RotaryMultiheadAttention (rope.py:82-86), MultiHeadCrossAttention /
  * LinearAggregation (tta.py:55-61; rel_bias NULL):  out = softmax(q k^T scale + bias) v  per (batch, head), scores and

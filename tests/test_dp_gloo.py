@@ -68,7 +68,9 @@ def _worker(rank, world, port, q, overlap, bucket, clip=None, accum=1, variant="
                 m.zero_grad(set_to_none=True)
             else:
                 opt.zero_grad()
-        q.put((rank, [p.detach().clone() for p in m.parameters()], len(opt.buckets), opt.state_bytes_per_rank(), norms,
+        # numpy arrays travel through the queue BY VALUE; torch tensors would travel as shared-memory file descriptors that
+        # the parent has to fetch from this process while it is still alive (ConnectionResetError on a loaded host)
+        q.put((rank, [p.detach().clone().numpy() for p in m.parameters()], len(opt.buckets), opt.state_bytes_per_rank(), norms,
                launched_early))
     except Exception:  # a failure of the exchange under test must surface as itself, not as a start-up hiccup
         q.put((rank, "error", traceback.format_exc()))
@@ -121,6 +123,7 @@ def _run_once(overlap, bucket, clip=None, accum=1, variant="plain"):
         p.join(timeout=60)
     for r in res:
         assert r[1] != "error", r[2]
+    res = [(r[0], [torch.from_numpy(a) for a in r[1]], *r[2:]) for r in res]
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     return res
 

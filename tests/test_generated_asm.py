@@ -16,11 +16,6 @@ def test_gemm_bt_asm_is_generated():
     assert _run("tools/gen_gemm_bt_asm.py") == (CSRC / "gemm_bt_asm.inc").read_text()
 
 
-def test_flash_dp_asm_is_generated():
-    want = _run("tools/gen_flash_dp_asm.py") + _run("tools/gen_flash_dp_asm.py", "--timed")
-    assert want == (CSRC / "flash_dp_asm.inc").read_text()
-
-
 def test_gemm_bt_schedule_issues_every_piece_once():
     """per wave and K tile: 8 A pieces + 2 NJ B pieces, 16 NJ MFMAs, 4 (4 + NJ) fragment reads inside the loop"""
     import re
@@ -107,29 +102,32 @@ def test_flash_dp2_asm_is_generated():
 
 def test_flash_dp_fragment_reads_hit_the_rows_the_dma_wrote():
     """Same executable spec for the flash KV loop: a 64-key ring slot = K tile [64 keys][64 d] at +0 and V^T tile
-    [64 d][64 keys] at +8192, both 128-byte rows with the kt_off swizzle; DMA pieces per attn.hip (flash_dp_kernel), reads
-    from the generated asm (v_add_u32 ADR, S_AK | S_AV, ab[k] ; ds_read_b128 .., ADR offset:..)."""
+    [64 d][64 keys] at +8192, both 128-byte rows with the kt_off swizzle; DMA pieces per attn.hip (flash_dp2_kernel), reads
+    from the generated asm (lane base register AB[k] = lds + (ab0 ^ 32 k), ds_read_b128 .., AB[k] offset:slot * 16384 + ..)."""
     import re
-    text = (CSRC / "flash_dp_asm.inc").read_text()
-    body = re.search(r"#define FLASH_DP_ASM_TEXT \\\n(.*?)\n#define", text, re.S).group(1)
+    text = (CSRC / "flash_dp2_asm.inc").read_text()
+    body = re.search(r"#define FLASH_DP2_ASM_TEXT \\\n(.*?)\n#define", text, re.S).group(1)
     lines = re.findall(r'"(.*)\\n"', body)
-    abreg = {"%[ab0]": 0}
+    abreg = {}
     for l in lines:
-        m = re.match(r"v_xor_b32 v(\d+), (\d+), %\[ab0\]", l)
+        m = re.match(r"v_add_u32 v(\d+), %\[lds\], %\[ab0\]", l)
+        if m:
+            abreg["v" + m.group(1)] = 0
+            base = m.group(1)
+    for l in lines:
+        m = re.match(rf"v_xor_b32 v(\d+), (\d+), v{base}$", l)
         if m:
             abreg["v" + m.group(1)] = int(m.group(2)) >> 5
     assert sorted(abreg.values()) == [0, 1, 2, 3]
     reads = set()
-    for a, b in zip(lines, lines[1:]):
-        m = re.match(r"v_add_u32 v(\d+), s(\d+), (%\[ab0\]|v\d+)", a)
-        n = re.match(r"ds_read_b128 v\[\d+:\d+\], v(\d+) offset:(\d+)", b)
-        if m and n and m.group(1) == n.group(1):
-            reads.add((int(m.group(2)), abreg[m.group(3)], int(n.group(2))))
-    sregs = sorted({r[0] for r in reads})
-    assert len(sregs) == 2
-    s_ak, s_av = sregs                                   # S_AK < S_AV in the generator's register plan
-    assert {(k, off) for (sr, k, off) in reads if sr == s_ak} == {(k, 0) for k in range(4)}
-    assert {(k, off) for (sr, k, off) in reads if sr == s_av} == {(k, off) for k in range(4) for off in (0, 4096)}
+    for l in lines:
+        n = re.match(r"ds_read_b128 v\[\d+:\d+\], (v\d+) offset:(\d+)", l)
+        if n and n.group(1) in abreg:
+            reads.add((abreg[n.group(1)], int(n.group(2))))
+    # every ring slot: K rows of both 32-row halves through all four k slices; V^T rows of both 32-row blocks through all
+    # four (key half, k slice pair) lane bases
+    assert {(k, off) for (k, off) in reads if off % 16384 < 8192} == {(k, sl * 16384 + 4096 * hf) for k in range(4) for sl in range(4) for hf in range(2)}
+    assert {(k, off) for (k, off) in reads if off % 16384 >= 8192} == {(k, sl * 16384 + 8192 + 4096 * nb) for k in range(4) for sl in range(4) for nb in range(2)}
     # what the DMA pieces of the four waves put where (tile-relative byte address -> (row, 16-byte chunk))
     tile = {}
     for wv in range(4):
@@ -168,12 +166,12 @@ def test_generated_asm_passes_the_hazard_lint():
     sys.path.insert(0, str(ROOT / "tools"))
     import asm_lint
     seen = 0
-    for inc in ("flash_dp_asm.inc", "gemm_bt_asm.inc"):
+    for inc in ("flash_dp2_asm.inc", "gemm_bt_asm.inc"):
         for name, lines in asm_lint.blocks(str(CSRC / inc)):
             seen += 1
             assert len(lines) > 200
             assert asm_lint.lint(name, lines) == []
-    assert seen == 5  # flash KV loop (2 builds), GEMM K loop NJ = 4, NJ = 3 and NJ = 3 in the SwiGLU-pair form
+    assert seen == 7  # flash KV loop (exact / pre-scaled x plain / timed), GEMM K loop NJ = 4, NJ = 3 and NJ = 3 SwiGLU-pair
     # the linter itself: each rule fires on a minimal violation
     bad = {
         "R1": ["v_exp_f32 v1, v1", "v_add_f32 v2, v1, v1"],

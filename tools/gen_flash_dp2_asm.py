@@ -2,7 +2,7 @@
 """Generates u2tokenizer_amd/csrc/flash_dp2_asm.inc: the KV loop of the round-4 double-pipeline flash attention kernel
 (attn.hip, flash_dp2_kernel, "mode 7") as ONE inline-asm block for gfx950.
 
-Same work split as gen_flash_dp_asm.py (mode 5): one wave owns two 32-row query blocks and alternates phases over
+Same work split as the round-1 loop (mode 5, tools/gen_flash_dp_asm.py, removed in round 4; history da95d2b): one wave owns two 32-row query blocks and alternates phases over
 32-key half tiles in which the 8 MFMAs of block x are interleaved, slot by slot, with the softmax VALU of block y.
 The round-1..3 loop ran 59 SIMD cycles per MFMA slot and was VALU-ISSUE bound (per slot: 2 v_fma 7.3 + 2 v_exp 14.9 +
 2 v_add 4.2 + v_cvt_pk 4.2 + address add 2 + a share of the row max / rescale test 6 + ~12 beside the MFMA).  What
@@ -113,7 +113,7 @@ def call(label):
 
 def issue(slot, label):
     """DMA of tile S_ISSUE (if < ntile) into ring slot `slot`: 2 K pieces + 2 V^T pieces of 1 KB per wave."""
-    e(f"s_cmp_ge_u32 {s(S_ISSUE)}, %[t1]")
+    e(f"s_cmp_ge_u32 {s(S_ISSUE)}, %[ntile]")
     e(f"s_cbranch_scc1 .Lfd2_noissue_{label}_%=")
     e(f"s_mul_i32 {s(S_KOFF)}, {s(S_ISSUE)}, %[ktile]")
     e(f"s_lshl_b32 {s(S_VOFF)}, {s(S_ISSUE)}, 7")
@@ -315,16 +315,14 @@ def gen():
             e(f"v_mov_b32 {v(O[key] + r)}, 0")
     for b in range(2):
         e(f"v_mov_b32 {l_run(b)}, 0")
-    # the block walks the key tiles [t0, t1) of its unit (t0 a multiple of the ring size: tile t lives in slot t & 3)
-    e(f"s_mov_b32 {s(S_T)}, %[t0]")
-    e(f"s_mov_b32 {s(S_ISSUE)}, %[t0]")
+    e(f"s_mov_b32 {s(S_T)}, 0")
+    e(f"s_mov_b32 {s(S_ISSUE)}, 0")
     # ---- prologue DMA, wait for tile 0
     for i in range(AHEAD):
         issue(i, f"pro{i}")
-    e(f"s_sub_u32 {s(S_A)}, %[t1], %[t0]")
-    e(f"s_cmp_ge_u32 {s(S_A)}, 3")
+    e("s_cmp_ge_u32 %[ntile], 3")
     e("s_cbranch_scc1 .Lfd2_w3_%=")
-    e(f"s_cmp_eq_u32 {s(S_A)}, 2")
+    e("s_cmp_eq_u32 %[ntile], 2")
     e("s_cbranch_scc1 .Lfd2_w2_%=")
     e("s_waitcnt vmcnt(0)")
     e("s_branch .Lfd2_w_%=")
@@ -336,8 +334,7 @@ def gen():
     e(".Lfd2_w_%=:")
     e("s_barrier")
     # ---- prologue phases on half 0 (tile 0, slot 0)
-    e(f"s_lshl_b32 {s(S_A)}, %[t0], 6")
-    e(f"s_sub_i32 {s(S_NV)}, %[seq], {s(S_A)}")
+    e(f"s_mov_b32 {s(S_NV)}, %[seq]")
     phase(0, True, False, False, 0, 0, 0, first=True)
     mask_call(0)
     init_max(0)
@@ -364,12 +361,12 @@ def gen():
         mask_call(1)
         stamp(0)
         e(f"s_add_u32 {s(S_A)}, {s(S_T)}, 1")
-        e(f"s_cmp_eq_u32 {s(S_A)}, %[t1]")
+        e(f"s_cmp_eq_u32 {s(S_A)}, %[ntile]")
         e(f"s_mov_b32 {s(S_AV)}, {base + 8192}")
         e("s_cbranch_scc1 .Lfd2_epi_%=")
         # tile t+1 must have landed; behind the barrier tile t-1 is dead and its slot takes tile t+AHEAD
         e(f"s_add_u32 {s(S_A)}, {s(S_T)}, 2")
-        e(f"s_cmp_lt_u32 {s(S_A)}, %[t1]")
+        e(f"s_cmp_lt_u32 {s(S_A)}, %[ntile]")
         e(f"s_cbranch_scc1 .Lfd2_lw4_{j}_%=")
         e("s_waitcnt vmcnt(0)")
         e(f"s_branch .Lfd2_lw_{j}_%=")

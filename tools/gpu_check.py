@@ -420,9 +420,8 @@ def sec_flashperf():
     for (nb, S, H, extra) in [(8, 2049, 12, True), (8, 2049, 12, False), (8, 2048, 12, False), (16, 513, 12, True)]:
         qkv = rnd(nb, S, 3 * H * 64, seed=3).to(dev)
         fl = 4 * nb * H * S * S * 64
-        for mode, split in ((5, 0), (7, 0), (7, 1), (8, 0), (8, 1)):
+        for mode, split in ((7, 0), (8, 0)):
             ops.set_option("flash_mode", mode)
-            ops.set_option("flash_split", split)
             ms = timeit(lambda: ops.flash_attention_d64(qkv, H, 0.125, extra_last=extra), iters=10)
             # the transpose alone
             ref = _flash_ref(qkv[:1, :, :], H)
@@ -431,7 +430,6 @@ def sec_flashperf():
             print(f"  nb={nb} S={S} extra={int(extra)} mode={mode} split={split}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF/s  "
                   f"util={fl / ms / 1e9 / 2500:.3f}  max_err={err:.2e}", flush=True)
     ops.set_option("flash_mode", 0)
-    ops.set_option("flash_split", 1)
     qkv = rnd(8, 2049, 3 * 768, seed=3).to(dev)
     vt = torch.empty((8, 768, 2048), dtype=bf, device=dev)
     ms = timeit(lambda: ops.transpose(qkv[:, :2048, 1536:].contiguous(), ld_out=2048, perm16=True), iters=10)
@@ -490,9 +488,8 @@ def sec_flashtime():
     nb, S, H = 8, 2049, 12
     qkv = rnd(nb, S, 3 * H * 64, seed=3).to(dev)
     names = ["gload", "QK^T", "softmax", "PV", "wait+lstore", "-", "barrier"]
-    for mode, split in ((5, 0), (7, 0), (8, 0), (8, 1)):
+    for mode, split in ((7, 0), (8, 0)):
         ops.set_option("flash_mode", mode)
-        ops.set_option("flash_split", split)
         ms0 = timeit(lambda: ops.flash_attention_d64(qkv, H, 0.125, extra_last=True), iters=5)
         buf = torch.zeros(65536 + 2048 * 4 * 8, dtype=torch.int64, device=dev)
         _lib.check(h.u2tok_flash_debug_buffer(buf.data_ptr()), "flash_debug_buffer")

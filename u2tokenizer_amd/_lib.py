@@ -116,9 +116,6 @@ SIGNATURES = {
                                          _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "u2tok_flash_attention_d64_lse": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _f32,
                                              _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp]),
-    "u2tok_flash_attention_d64_workspace_bytes": (_sz, [_i32, _i32, _i32]),
-    "u2tok_flash_attention_d64_ws": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _f32,
-                                            _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _sz, _vp]),
     "u2tok_attention_gqa": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                    _i64, _f32, _i32, _vp]),
     "u2tok_attention_gqa_split": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64,

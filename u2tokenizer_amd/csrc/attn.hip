@@ -166,7 +166,7 @@ int temporal_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t
 //   running max grows by more than 2^8 (wave-uniform branch); the softmax scale is folded into one FMA per score;
 //   key masking only in a partial last tile; the extra key is one VALU step after the tile loop.
 // This plain pass (QB = 1, "mode 1") serves short sequences; S >= 512 takes the double pipeline further down
-// ("mode 5").  The QB = 2 / mixed-unit / 8-wave ping-pong forms measured in round 1 (profiles/r01_flash_study.log) were
+// ("mode 7").  The QB = 2 / mixed-unit / 8-wave ping-pong forms measured in round 1 (profiles/r01_flash_study.log) were
 // removed from the product in round 2 (history: fc1ca7f).
 // Extra query rows (one per head) are handled by small VALU workgroups at the end of the grid.
 // LDS tiles ([64][64] bf16, 128 B rows): 16-byte chunks XOR-swizzled with (row>>1)&7 -> conflict-free
@@ -183,10 +183,6 @@ struct FlashArgs {
   int S, H, nb, S_pad, n_extra, mode, n_main;
   int q_prescaled;  // q and qx already carry scale * log2 e (mode 7 only)
   int wide_out;     // out rows are 16-byte aligned: the double-pipeline forms store 16 bytes per lane
-  int n_xwg, n_tail;   // flash_dp2_kernel: grid = n_main whole units | n_xwg extra-row workgroups | 2 n_tail half units
-  float* part;         //   split units: O^T of the half that arrived first,
-  float* part_stat;    //   its (m, l) per lane,
-  unsigned* part_flag; //   one ticket word per split unit (zero before the launch)
   int64_t ld_qk, q_bs, ld_out, out_bs, x_bs, ox_bs;
   float scale_log2e;
   float* lse;      // optional: lse[(b * H + h) * lse_ld + row] = log2 sum_k exp2(s_k scale log2e) per query row (the extra
@@ -572,24 +568,23 @@ __global__ __launch_bounds__(256, 3) void flash_d64_kernel(const FlashArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// Double-pipeline form (mode 5).  The measurements behind it (profiles/r01_flash_study.log, tools/ubench/
-// valu_rate.hip): at head dim 64 a 32 x 64 score block costs a SIMD 16 MFMAs (512 matrix-pipe cycles) and ~550 cycles
-// of softmax VALU issue (v_exp_f32 7.5, 3-operand VALU ~4, 2-operand ~2 cycles per wave64 instruction); the forms
-// above run them one after the other and rely on a second, unrelated wave of the SIMD to fill the gaps, which it
-// does only by chance (matrix pipe busy 28 %).  Here ONE wave owns two 32-row query blocks and alternates phases
-// over 32-key half tiles in which the MFMAs of one block are interleaved, slot by slot, with the softmax VALU of the
-// other:
+// Double-pipeline form (modes 7 / 8; the round-1 loop, "mode 5", was removed in round 4: history da95d2b).  The
+// measurements behind it (profiles/r01_flash_study.log, tools/ubench/valu_rate.hip): at head dim 64 a 32 x 64 score block
+// costs a SIMD 16 MFMAs (512 matrix-pipe cycles) against hundreds of cycles of softmax VALU issue (v_exp_f32 7.5,
+// 3-operand VALU ~4, 2-operand ~2 cycles per wave64 instruction); the plain form above runs them one after the other and
+// relies on a second, unrelated wave of the SIMD to fill the gaps, which it does only by chance (matrix pipe busy 28 %).
+// Here ONE wave owns two 32-row query blocks and alternates phases over 32-key half tiles in which the MFMAs of one block
+// are interleaved, slot by slot, with the softmax VALU of the other:
 //     B(u):   S0(u+1) = K(u+1) Q0^T ; O0 += V(u) P0(u)      ||   P1(u)   = softmax step on S1(u)
 //     A(u+1): S1(u+1) = K(u+1) Q1^T ; O1 += V(u) P1(u)      ||   P0(u+1) = softmax step on S0(u+1)
 // (an in-order wave keeps issuing independent VALU while its own MFMA occupies the matrix pipe; the second wave of
-// the SIMD runs the same mix).  The row max of the block that just got its scores, and the rare rescale branch,
-// close each phase.  K / V^T tiles (64 keys) arrive by LDS-DMA (buffer_load ... lds) into a ring of 4 slots, 3 tiles
-// ahead, one s_barrier per tile.  4 waves x 64 rows = 256-row units, two workgroups per CU.
-// The whole KV loop is ONE generated asm block (flash_dp_asm.inc, written by tools/gen_flash_dp_asm.py; register map
-// and schedule are documented there): hipcc could not be made to keep the slot order AND the six 16-register
-// accumulators in place at 256 VGPRs -- through asm operands it reordered the slots, rotated the accumulators
-// through extra tuples, copied them around pinned registers, or spilled (~290 VGPRs, one wave per SIMD, slower than
-// mode 2).  With every loop register fixed by hand the kernel runs two waves per SIMD.
+// the SIMD runs the same mix).  K / V^T tiles (64 keys) arrive by LDS-DMA (buffer_load ... lds) into a ring of 4 slots,
+// 3 tiles ahead, one s_barrier per tile.  4 waves x 64 rows = 256-row units, two workgroups per CU.
+// The whole KV loop is ONE generated asm block (flash_dp2_asm.inc, written by tools/gen_flash_dp2_asm.py; register map
+// and schedule are documented there): hipcc could not be made to keep the slot order AND the accumulators in place at
+// 256 VGPRs -- through asm operands it reordered the slots, rotated the accumulators through extra tuples, copied them
+// around pinned registers, or spilled (~290 VGPRs, one wave per SIMD).  With every loop register fixed by hand the
+// kernel runs two waves per SIMD.
 constexpr int FDP_SLOTS = 4;
 
 struct FdpBlock {       // final state of one 32-row query block of a wave
@@ -675,103 +670,12 @@ __device__ __forceinline__ void fdp_finish(const FlashArgs& a, FdpBlock& x, cons
   }
 }
 
-#include "flash_dp_asm.inc"
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 
-template <bool TIMED>
-__global__ __launch_bounds__(256, 2) void flash_dp_kernel(const FlashArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[FDP_SLOTS][16384];  // [slot][K tile 8 KB | V^T tile 8 KB]
-  const int tid = threadIdx.x;
-  if ((int)blockIdx.x >= a.n_main) {
-    const int e = blockIdx.x - a.n_main;
-    flash_extra_row(a, &lds[0][0], e / a.H, e % a.H, tid);
-    return;
-  }
-  int bid;
-  {
-    const int nwg = a.n_main, qn = nwg >> 3, rn = nwg & 7;
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
-  }
-  const int nqt = (a.S + 255) >> 8;
-  const int hh = bid / nqt, b = hh / a.H, h = hh % a.H, row0 = (bid % nqt) * 256;
-  const int lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5, l31 = lane & 31;
-  const int S = a.S, S_pad = a.S_pad;
-  const int64_t ld_qk = a.ld_qk;
-  const bf16_t* qb_ = a.q + (int64_t)b * a.q_bs + h * 64;
-  const bf16_t* kb_ = a.k + (int64_t)b * a.q_bs + h * 64;
-  const bf16_t* vb_ = a.vt + ((int64_t)b * a.H + h) * 64 * S_pad;
-  const int wrow0 = row0 + wv * 64;
-  const int ntile = (S + 63) >> 6;
-
-  bf16x8 qf[2][4];
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const bf16_t* qp = qb_ + (int64_t)min(wrow0 + qb * 32 + l31, S - 1) * ld_qk + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
-  }
-  // DMA pieces of this wave (as in flash_dp_kernel): MUBUF descriptors built by hand -- K rows past S read as zero
-  const int prow = wv * 16 + (lane >> 3);
-  const int pch0 = (lane & 7) ^ ((prow >> 1) & 7), pch1 = pch0 ^ 4;
-  const int ko0 = (prow * (int)ld_qk + pch0 * 8) * 2, ko1 = ((prow + 8) * (int)ld_qk + pch1 * 8) * 2;
-  const int vo0 = (prow * S_pad + pch0 * 8) * 2, vo1 = ((prow + 8) * S_pad + pch1 * 8) * 2;
-  const int k_tile_bytes = 64 * (int)ld_qk * 2;
-  const uint64_t kaddr = (uint64_t)(uintptr_t)kb_, vaddr = (uint64_t)(uintptr_t)vb_;
-  i32x4_t rsk, rsv;
-  rsk[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)kaddr);
-  rsk[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(kaddr >> 32));
-  rsk[2] = (int)((((int64_t)S - 1) * ld_qk + 64) * 2);
-  rsk[3] = 0x00020000;
-  rsv[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)vaddr);
-  rsv[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(vaddr >> 32));
-  rsv[2] = 64 * S_pad * 2;
-  rsv[3] = 0x00020000;
-  const uint32_t lds_u32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&lds[0][0];
-  const uint32_t dma_base = lds_u32 + wv * 2048;
-  const uint32_t ab0 = kt_off(l31, hi);
-  const uint32_t dump = lds_u32 + wv * 16384 + lane * 16;
-  const int hi4 = 4 * hi;
-  const float scale_log2e = a.scale_log2e;
-  float mr0, lr0, mr1, lr1;
-  unsigned long long* dbg = g_flash_dbg + ((size_t)blockIdx.x * 4 + wv) * 8;  // TIMED: 5 section times, [7] = tiles
-#define FDP_OPERANDS                                                                                                   \
-               : [mr0] "=&v"(mr0), [lr0] "=&v"(lr0), [mr1] "=&v"(mr1), [lr1] "=&v"(lr1)                                 \
-               : [qf00] "v"(qf[0][0]), [qf01] "v"(qf[0][1]), [qf02] "v"(qf[0][2]), [qf03] "v"(qf[0][3]),                \
-                 [qf10] "v"(qf[1][0]), [qf11] "v"(qf[1][1]), [qf12] "v"(qf[1][2]), [qf13] "v"(qf[1][3]),                \
-                 [ab0] "v"(ab0), [ko0] "v"(ko0), [ko1] "v"(ko1), [vo0] "v"(vo0), [vo1] "v"(vo1), [hi4] "v"(hi4),        \
-                 [dump] "v"(dump), [rsk] "s"(rsk), [rsv] "s"(rsv), [lds] "s"(lds_u32), [dma_base] "s"(dma_base),        \
-                 [ktile] "s"(k_tile_bytes), [seq] "s"(S), [ntile] "s"(ntile), [scale] "s"(scale_log2e), [dbg] "v"(dbg)
-  if constexpr (TIMED) {
-    asm volatile(FLASH_DP_ASM_TEXT_TIMED FDP_OPERANDS : FLASH_DP_ASM_CLOBBERS_TIMED);
-    if (lane == 0) dbg[7] = (unsigned long long)ntile;
-  } else {
-    asm volatile(FLASH_DP_ASM_TEXT FDP_OPERANDS : FLASH_DP_ASM_CLOBBERS);
-  }
-#undef FDP_OPERANDS
-  // the block left O^T in LDS: tuple T = 2 * block + nb, 16-byte quarter j at [wave][T * 4 + j][lane]
-  FdpBlock x0, x1;
-  const char* dp = &lds[0][0] + wv * 16384 + lane * 16;
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float4 u0 = *reinterpret_cast<const float4*>(dp + ((0 + nb) * 4 + j) * 1024);
-      const float4 u1 = *reinterpret_cast<const float4*>(dp + ((2 + nb) * 4 + j) * 1024);
-      x0.oacc[nb][4 * j] = u0.x; x0.oacc[nb][4 * j + 1] = u0.y; x0.oacc[nb][4 * j + 2] = u0.z; x0.oacc[nb][4 * j + 3] = u0.w;
-      x1.oacc[nb][4 * j] = u1.x; x1.oacc[nb][4 * j + 1] = u1.y; x1.oacc[nb][4 * j + 2] = u1.z; x1.oacc[nb][4 * j + 3] = u1.w;
-    }
-  x0.m_run = mr0; x0.l_run = lr0; x1.m_run = mr1; x1.l_run = lr1;
-  fdp_finish(a, x0, qf[0], b, h, wrow0 + l31, hi);
-  fdp_finish(a, x1, qf[1], b, h, wrow0 + 32 + l31, hi);
-}
-
 // ----------------------------------------------------------------------------------------------------------------
-// Double-pipeline form, round 4 (mode 7): same units, ring and DMA as mode 5; the KV loop is
-// flash_dp2_asm.inc (tools/gen_flash_dp2_asm.py, where the schedule and the reasons are written down).  In short,
-// the loop of mode 5 was VALU-issue bound at 59 SIMD cycles per MFMA slot; this one takes the scale FMAs, the row
+// Round 4 (mode 7): same units, ring and DMA as the round-1 loop; the KV loop is flash_dp2_asm.inc
+// (tools/gen_flash_dp2_asm.py, where the schedule and the reasons are written down).  In short, the round-1 loop
+// was VALU-issue bound at 59 SIMD cycles per MFMA slot; this one takes the scale FMAs, the row
 // max, the address adds and the trans-use nops out of the slot: Q fragments carry scale * log2 e (one bf16
 // rounding of q * c instead of q: the same relative error, a different rounding point than the reference's), the
 // running max is subtracted by the matrix pipe (C operand of the first Q K^T MFMA = a tuple holding -m), m is only
@@ -883,31 +787,16 @@ __device__ __forceinline__ void flash_extra_row2(const FlashArgs& a, float* sbuf
   }
 }
 
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-// write-through stores / L1-bypassing loads for the hand-off of a split unit's partial state between two workgroups
-// (MI355X guide, "valid forms": 16-byte sc1 stores AND sc1 loads need no fences; the ticket is a relaxed agent atomic
-// behind the publisher's own vmcnt(0))
-__device__ __forceinline__ void st_sc1(float* p, const f32x4v v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ f32x4v ld_sc1(const float* p) {
-  f32x4v v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-
 // QMODE: 0 = q as the reference has it, every score multiplied by scale * log2 e in fp32 (flash_dp2_asm.inc, "_X" text);
 //        1 = the caller's q / qx already carry scale * log2 e (the ViT's q|k|v product scales its q columns in the
 //            epilogue, from the fp32 accumulator: one rounding, as for the unscaled q);
 //        2 = the kernel multiplies its Q fragments itself (a second bf16 rounding of q: diagnostic / timing only).
-// Grid = [n_full whole units | n_xwg extra-row workgroups | 2 n_tail half units].  768 units on 512 workgroup slots are
-// 1.5 rounds, and the half-empty second round ran ONE wave per SIMD at 2/3 of a pair's throughput (timeline in
-// profiles/r04_flash_mode7_first.log).  With a scratch slab from the caller the units past the last full round are cut
-// in two key ranges, so the second round also runs two workgroups per CU; the workgroup of a pair that finishes first
-// leaves its state (O^T unnormalised, m, l) in the slab and exits, the other one merges -- always as (first key half) +
-// (second key half), whoever merges: bit-repeatable -- and finishes the rows.  A publisher never waits, so the scheme
-// cannot deadlock at any residency.  (A persistent form, every workgroup 1.5 units in lock step, measured no gain: with
-// all workgroups at their seams together nothing overlaps the epilogues.)
+// Grid = [n_main units of 256 query rows | one extra-row workgroup per (batch, head)].  768 units on 512 workgroup slots
+// are 1.5 rounds; two ways of cutting the last half round in two key ranges (a persistent form, every workgroup 1.5 units
+// in lock step; a tail form, the last 256 units as 512 half units with a ticket and an fp32 slab per pair) were built and
+// measured in round 4 and removed again: the extra-row workgroups need ~30 us of a slot whatever they execute and only
+// the half-empty second round has slots to spare, and the first round's exits are spread over 16 us, which the plain
+// form absorbs for free (profiles/r04_flash_tail_split_trial.log; the commit before this form).
 template <bool TIMED, int QMODE>
 __global__ __launch_bounds__(256, 2) void flash_dp2_kernel(const FlashArgs a) {
   __shared__ __attribute__((aligned(1024))) char lds[FDP_SLOTS][16384];  // [slot][K tile 8 KB | V^T tile 8 KB]
@@ -925,23 +814,18 @@ __global__ __launch_bounds__(256, 2) void flash_dp2_kernel(const FlashArgs a) {
     return (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
   };
   const int ntile = (a.S + 63) >> 6;
-  int unit, t0 = 0, t1 = ntile, half = -1;  // half: -1 = whole unit, 0 / 1 = first / second half of the key tiles
+  int unit;
   {
-    int w = blockIdx.x;
+    const int w = blockIdx.x;
     if (w < a.n_main) unit = xcd_order(w, a.n_main);
-    else if ((w -= a.n_main) < a.n_xwg) {
+    else {
       // these four waves share their SIMDs with main waves that are VALU-issue bound, and as the younger waves they would
       // get the leftover issue slots (30 us for ~10 us of work): static priority, their demand is small
       __builtin_amdgcn_s_setprio(3);
-      if (w < a.nb * a.H) flash_extra_row2<256>(a, reinterpret_cast<float*>(&lds[0][0]), w / a.H, w % a.H, tid);
+      const int e = w - a.n_main;
+      flash_extra_row2<256>(a, reinterpret_cast<float*>(&lds[0][0]), e / a.H, e % a.H, tid);
       if constexpr (TIMED) if ((tid & 63) == 0) tl[3] = __builtin_amdgcn_s_memrealtime();
       return;
-    } else {
-      const int id = xcd_order(w - a.n_xwg, 2 * a.n_tail);
-      unit = a.n_main + (id >> 1);
-      half = id & 1;
-      t0 = half ? ntile >> 1 : 0;
-      t1 = half ? ntile : ntile >> 1;
     }
   }
   const int nqt = (a.S + 255) >> 8;
@@ -997,13 +881,13 @@ __global__ __launch_bounds__(256, 2) void flash_dp2_kernel(const FlashArgs a) {
                  [qf10] "v"(qf[1][0]), [qf11] "v"(qf[1][1]), [qf12] "v"(qf[1][2]), [qf13] "v"(qf[1][3]),                \
                  [ab0] "v"(ab0), [ko0] "v"(ko0), [ko1] "v"(ko1), [vo0] "v"(vo0), [vo1] "v"(vo1), [hi4] "v"(hi4),        \
                  [dump] "v"(dump), [rsk] "s"(rsk), [rsv] "s"(rsv), [lds] "s"(lds_u32), [dma_base] "s"(dma_base),        \
-                 [ktile] "s"(k_tile_bytes), [seq] "s"(S), [t0] "s"(t0), [t1] "s"(t1), [dbg] "v"(dbg),                   \
+                 [ktile] "s"(k_tile_bytes), [seq] "s"(S), [ntile] "s"(ntile), [dbg] "v"(dbg),                           \
                  [scale] "s"(scale_log2e), [rscale] "s"(rscale)
   if constexpr (TIMED) {
     if (lane == 0) tl[1] = __builtin_amdgcn_s_memrealtime();
     if constexpr (QMODE == 0) asm volatile(FLASH_DP2_ASM_TEXT_X_TIMED FDP2_OPERANDS : FLASH_DP2_ASM_CLOBBERS_X_TIMED);
     else asm volatile(FLASH_DP2_ASM_TEXT_TIMED FDP2_OPERANDS : FLASH_DP2_ASM_CLOBBERS_TIMED);
-    if (lane2 == 0) { dbg[7] = (unsigned long long)(t1 - t0); tl[2] = __builtin_amdgcn_s_memrealtime(); }
+    if (lane2 == 0) { dbg[7] = (unsigned long long)ntile; tl[2] = __builtin_amdgcn_s_memrealtime(); }
   } else {
     if constexpr (QMODE == 0) asm volatile(FLASH_DP2_ASM_TEXT_X FDP2_OPERANDS : FLASH_DP2_ASM_CLOBBERS_X);
     else asm volatile(FLASH_DP2_ASM_TEXT FDP2_OPERANDS : FLASH_DP2_ASM_CLOBBERS);
@@ -1012,27 +896,6 @@ __global__ __launch_bounds__(256, 2) void flash_dp2_kernel(const FlashArgs a) {
   // the block left O^T in LDS: tuple T = 2 * block + nb, 16-byte quarter j at [wave][T * 4 + j][lane]
   const int hi2 = lane2 >> 5, l31b = lane2 & 31;
   const char* dp = &lds[0][0] + wv * 16384 + lane2 * 16;
-  // a split unit: which half arrived first?  ticket word: +1 on arrival, +2 more once the first arriver has published
-  float* slab = nullptr;
-  float* stat = nullptr;
-  bool publish = false;
-  if (half >= 0) {
-    const int su = unit - a.n_main;
-    slab = a.part + (size_t)su * (4 * 2 * 8 * 64 * 4) + (size_t)wv * (2 * 8 * 64 * 4) + lane2 * 4;
-    stat = a.part_stat + (size_t)su * (4 * 2 * 64 * 2) + (size_t)wv * (2 * 64 * 2) + lane2 * 2;
-    unsigned* tick = a.part_flag + su;
-    __shared__ int bc_s;  // the four dumps fill the ring's 64 KB
-    int* bc = &bc_s;
-    if (tid == 0) {
-      const unsigned t = __hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t != 0u) {  // second arriver: the first one publishes without waiting for anybody
-        while (__hip_atomic_load(tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 4u) __builtin_amdgcn_s_sleep(8);
-      }
-      *bc = t == 0u ? 1 : 0;
-    }
-    __syncthreads();
-    publish = *bc != 0;
-  }
 #pragma unroll
   for (int blk = 0; blk < 2; ++blk) {  // one block at a time: 32 accumulator values live, not 64
     FdpBlock x;
@@ -1045,42 +908,6 @@ __global__ __launch_bounds__(256, 2) void flash_dp2_kernel(const FlashArgs a) {
       }
     x.m_run = blk ? mr1 : mr0;
     x.l_run = blk ? lr1 : lr0;
-    if (half >= 0) {
-      if (publish) {
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            st_sc1(slab + (size_t)(blk * 8 + nb * 4 + j) * 256,
-                   f32x4v{x.oacc[nb][4 * j], x.oacc[nb][4 * j + 1], x.oacc[nb][4 * j + 2], x.oacc[nb][4 * j + 3]});
-        __hip_atomic_store(stat + blk * 128, x.m_run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(stat + blk * 128 + 1, x.l_run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        continue;
-      }
-      f32x4v pv[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) pv[q] = ld_sc1(slab + (size_t)(blk * 8 + q) * 256);
-      const float mp = __hip_atomic_load(stat + blk * 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const float lp = __hip_atomic_load(stat + blk * 128 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]),
-                   "+v"(pv[6]), "+v"(pv[7])::"memory");
-      // always (first key half) f0 + (second key half) f1, whichever of the two this workgroup computed
-      const float mn = fmaxf(x.m_run, mp);
-      const float fo = __builtin_amdgcn_exp2f(x.m_run - mn), fp = __builtin_amdgcn_exp2f(mp - mn);
-      const float f0 = half == 0 ? fo : fp, f1 = half == 0 ? fp : fo;
-      const float l0 = half == 0 ? x.l_run : lp, l1 = half == 0 ? lp : x.l_run;
-      x.m_run = mn;
-      x.l_run = l0 * f0 + l1 * f1;
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float mine = x.oacc[nb][4 * j + e], theirs = pv[nb * 4 + j][e];
-            x.oacc[nb][4 * j + e] = (half == 0 ? mine : theirs) * f0 + (half == 0 ? theirs : mine) * f1;
-          }
-    }
     // the Q fragments again for the extra key's scores (cheap; kept live they were spilled around the block)
     bf16x8 qfx[4];
     if (a.n_extra) {
@@ -1092,11 +919,6 @@ __global__ __launch_bounds__(256, 2) void flash_dp2_kernel(const FlashArgs a) {
       }
     }
     fdp_finish(a, x, qfx, b, h, wrow0 + 32 * blk + l31b, hi2, QMODE != 0);
-  }
-  if (half >= 0 && publish) {  // all four waves' stores acknowledged, then the ticket moves on
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(a.part_flag + (unit - a.n_main), 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if constexpr (TIMED) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1111,40 +933,10 @@ int flash_set_debug_buffer(void* p) {  // >= grid * 4 * 8 uint64, zeroed by the 
   return hipMemcpyToSymbol(HIP_SYMBOL(g_flash_dbg), &q, sizeof(q)) == hipSuccess ? U2_OK : U2_ERR_LAUNCH;
 }
 
-// split form of the round-4 double pipeline: the units past the last full round of 2 workgroups per CU are cut in two key
-// ranges when they fill at most half a round (768 units on 512 slots: 256 of them); per split unit a 64 KB slab + 4 KB of
-// (m, l) + a ticket word
-static int flash_wg_slots() {
-  static int slots = 0;
-  if (!slots) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    slots = 2 * cus;
-  }
-  return slots;
-}
-static inline int64_t flash_split_units(int64_t nbh, int S) {
-  const int64_t units = nbh * ((S + 255) / 256);
-  const int ntile = (S + 63) / 64;
-  const int64_t cap = flash_wg_slots(), rem = units % cap;
-  return (ntile % 8 == 0 && rem > 0 && 2 * rem <= cap) ? rem : 0;
-}
-size_t flash_attention_d64_workspace_bytes(int nb, int S, int H) {
-  const int64_t ns = flash_split_units((int64_t)nb * H, S);
-  return ns ? (size_t)ns * (65536 + 4096) + (((size_t)ns * 4 + 255) & ~(size_t)255) : 0;
-}
-
-__global__ void flash_clear_flags_kernel(unsigned* f, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) f[i] = 0u;
-}
-
 int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int nb, int S, int H,
                         int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs, int S_pad, float scale,
                         const bf16_t* qx, const bf16_t* kx, const bf16_t* vx, bf16_t* outx, int64_t x_bs, int64_t ox_bs,
-                        int n_extra, float* lse, int64_t lse_ld, hipStream_t stream, int q_prescaled, void* workspace,
-                        size_t workspace_bytes) {
+                        int n_extra, float* lse, int64_t lse_ld, hipStream_t stream, int q_prescaled) {
   if (!q || !k || !vt || !out || nb <= 0 || S <= 0 || H <= 0 || n_extra < 0 || n_extra > 1) return U2_ERR_ARG;
   if (lse && lse_ld < S + n_extra) return U2_ERR_ARG;
   if ((S_pad & 63) || S_pad < ((S + 63) & ~63)) return U2_ERR_ARG;
@@ -1160,38 +952,21 @@ int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16
   a.ld_qk = ld_qk; a.q_bs = q_bs; a.ld_out = ld_out; a.out_bs = out_bs; a.x_bs = x_bs; a.ox_bs = ox_bs;
   a.scale_log2e = scale * 1.44269504088896340736f;
   a.lse = lse; a.lse_ld = lse_ld;
-  a.part = nullptr; a.part_stat = nullptr; a.part_flag = nullptr; a.n_xwg = 0; a.n_tail = 0;
   a.wide_out = !((uintptr_t)out & 15) && !(ld_out & 7) && !(out_bs & 7);
   const int64_t nbh = (int64_t)nb * H;
   int mode = opts().flash_mode;
-  if (mode != 1 && mode != 5 && mode != 7 && mode != 8) mode = S >= 512 ? 7 : 1;  // measured: the double pipeline wins from S = 513 up
+  if (mode != 1 && mode != 7 && mode != 8) mode = S >= 512 ? 7 : 1;  // measured: the double pipeline wins from S = 513 up
   if (q_prescaled) mode = 7;  // the only form that takes pre-scaled queries (the ViT launches it at S = 2048)
   a.q_prescaled = q_prescaled;
   const int64_t blocks = mode != 1 ? nbh * ((S + 255) / 256) : nbh * ((S + 127) / 128);
   a.mode = mode;
   a.n_main = (int)blocks;
-  const int64_t grid = blocks + (n_extra ? nbh : 0);  // modes 1 / 5 (modes 7 / 8 lay their grid out below)
+  const int64_t grid = blocks + (n_extra ? nbh : 0);
   if (grid > 0x7fffffff) return U2_ERR_ARG;
   ProfScope ps(PROF_FLASH, 4.0 * nbh * (double)(S + n_extra) * (S + n_extra) * 64, stream,
                4.0 * nbh * (double)(S + n_extra) * 64 * 2.0);  // q, k, v^T read + o written, once
   if (mode == 7 || mode == 8) {
-    // split form: the units past the last full round as two half units each (flash_dp2_kernel)
-    const int64_t ns = opts().flash_split ? flash_split_units(nbh, S) : 0;
-    const bool split = ns > 0 && workspace && workspace_bytes >= flash_attention_d64_workspace_bytes(nb, S, H) &&
-                       !((uintptr_t)workspace & 15);
-    a.n_tail = 0;
-    a.n_xwg = n_extra ? (int)((nbh + 7) & ~(int64_t)7) : 0;  // the tail region starts on a multiple of 8 (XCD order)
-    if (split) {
-      a.part = reinterpret_cast<float*>(workspace);
-      a.part_stat = a.part + (size_t)ns * 16384;
-      a.part_flag = reinterpret_cast<unsigned*>(a.part_stat + (size_t)ns * 1024);
-      a.n_tail = (int)ns;
-      a.n_main = (int)(blocks - ns);
-      hipLaunchKernelGGL(flash_clear_flags_kernel, dim3((unsigned)cdiv(ns, 256)), dim3(256), 0, stream, a.part_flag, (int)ns);
-    }
-    const int64_t g2 = (int64_t)a.n_main + a.n_xwg + 2 * (int64_t)a.n_tail;
-    if (g2 > 0x7fffffff) return U2_ERR_ARG;
-    const dim3 g((unsigned)g2), t(256);
+    const dim3 g((unsigned)grid), t(256);
     const int qm = q_prescaled ? 1 : mode == 8 ? 2 : 0;
 #define U2_FDP2_Q(T_)                                                                                            \
   do {                                                                                                           \
@@ -1201,9 +976,6 @@ int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16
   } while (0)
     if (g_flash_timed) U2_FDP2_Q(true); else U2_FDP2_Q(false);
 #undef U2_FDP2_Q
-  } else if (mode == 5) {
-    if (g_flash_timed) hipLaunchKernelGGL((flash_dp_kernel<true>), dim3((unsigned)grid), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((flash_dp_kernel<false>), dim3((unsigned)grid), dim3(256), 0, stream, a);
   } else {
     hipLaunchKernelGGL(flash_d64_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
   }

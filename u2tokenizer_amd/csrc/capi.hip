@@ -56,7 +56,6 @@ int u2tok_set_option(const char* name, int value) {
       {"gemm_big_splitk", &Options::gemm_big_splitk, 0, 16}, {"gemm_big_skinny", &Options::gemm_big_skinny, 0, 1},
       {"kmajor_b", &Options::kmajor_b, 0, 1},
       {"flash_mode", &Options::flash_mode, 0, 8},
-      {"flash_split", &Options::flash_split, 0, 1},
       {"vit_flash", &Options::vit_flash, 0, 1},         {"tta_overlap", &Options::tta_overlap, 0, 1},
       {"tok_flash", &Options::tok_flash, 0, 1},
   };
@@ -70,7 +69,7 @@ int u2tok_set_option(const char* name, int value) {
     if (!strcmp(name, t.name)) {
       if (value < t.lo || value > t.hi) return U2_ERR_ARG;
       if (t.field == &Options::gemm_big && value > 0 && value != 20 && value != 21) return U2_ERR_ARG;
-      if (t.field == &Options::flash_mode && value != 0 && value != 1 && value != 5 && value != 7 && value != 8) return U2_ERR_ARG;
+      if (t.field == &Options::flash_mode && value != 0 && value != 1 && value != 7 && value != 8) return U2_ERR_ARG;
       o.*(t.field) = value;
       return U2_OK;
     }
@@ -251,19 +250,6 @@ int u2tok_flash_attention_d64_lse(const void* q, const void* k, const void* vt, 
   if (!lse) return U2_ERR_ARG;
   return flash_attention_d64(BF(q), BF(k), BF(vt), BFW(out), nb, S, H, ld_qk, q_bs, ld_out, out_bs, S_pad, scale,
                              BF(qx), BF(kx), BF(vx), BFW(outx), x_bs, ox_bs, n_extra, lse, lse_ld, ST(stream));
-}
-
-size_t u2tok_flash_attention_d64_workspace_bytes(int32_t nb, int32_t S, int32_t H) {
-  return flash_attention_d64_workspace_bytes(nb, S, H);
-}
-int u2tok_flash_attention_d64_ws(const void* q, const void* k, const void* vt, void* out, int32_t nb, int32_t S,
-                                 int32_t H, int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs, int32_t S_pad,
-                                 float scale, const void* qx, const void* kx, const void* vx, void* outx, int64_t x_bs,
-                                 int64_t ox_bs, int32_t n_extra, float* lse, int64_t lse_ld, void* workspace,
-                                 size_t workspace_bytes, u2tok_stream_t stream) {
-  return flash_attention_d64(BF(q), BF(k), BF(vt), BFW(out), nb, S, H, ld_qk, q_bs, ld_out, out_bs, S_pad, scale,
-                             BF(qx), BF(kx), BF(vx), BFW(outx), x_bs, ox_bs, n_extra, lse, lse_ld, ST(stream), 0, workspace,
-                             workspace_bytes);
 }
 
 size_t u2tok_tok_attention_workspace_bytes(int32_t nb, int32_t H, int32_t Sq, int32_t Skv, int32_t d) {

@@ -292,8 +292,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int n0 = n_base + ni * 16;
-        float v0 = acc[mi][ni][0] * d.alpha, v1 = acc[mi][ni][1] * d.alpha, v2 = acc[mi][ni][2] * d.alpha,
-              v3 = acc[mi][ni][3] * d.alpha;
+        const float al = n0 < d.nsplit ? d.alpha_lo : d.alpha;
+        float v0 = acc[mi][ni][0] * al, v1 = acc[mi][ni][1] * al, v2 = acc[mi][ni][2] * al, v3 = acc[mi][ni][3] * al;
         if constexpr (decltype(BN_)::value) { v0 += bn[ni].x; v1 += bn[ni].y; v2 += bn[ni].z; v3 += bn[ni].w; }
         if constexpr (decltype(GELU_)::value) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
         if constexpr (decltype(RES_)::value) {
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
       for (int r = 0; r < 4; ++r) {
         const int n = n_base + ni * 16 + r;
         if (n >= d.N) break;
-        float x = acc[mi][ni][r] * d.alpha + bm_v;
+        float x = acc[mi][ni][r] * (n < d.nsplit ? d.alpha_lo : d.alpha) + bm_v;
         if (d.flags & GEMM_BIAS_N) x += bf16_to_f32(d.bias[n]);
         if (d.flags & GEMM_GELU) x = gelu_erf(x);
         if (Rz) x += bf16_to_f32(Rz[(int64_t)m * d.ldr + n]);
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmDesc d) {
   for (int r = 0; r < 4; ++r) {
     const int n = n0 + r;
     if (n >= d.N) break;
-    float x = v[r] * d.alpha + bm_v;
+    float x = v[r] * (n < d.nsplit ? d.alpha_lo : d.alpha) + bm_v;
     if (d.flags & GEMM_BIAS_N) x += bf16_to_f32(d.bias[n]);
     if (d.flags & GEMM_GELU) x = gelu_erf(x);
     if (Rz) x += bf16_to_f32(Rz[n]);
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows16_kernel(GemmDesc d) {
   for (int r = 0; r < 4; ++r) {
     const int n = n0 + 4 * g + r;
     if (n >= d.N) break;
-    float x = v[r] * d.alpha;
+    float x = v[r] * (n < d.nsplit ? d.alpha_lo : d.alpha);
     if (d.flags & GEMM_BIAS_M) x += bf16_to_f32(d.bias[m]);
     if (d.flags & GEMM_BIAS_N) x += bf16_to_f32(d.bias[n]);
     if (d.flags & GEMM_GELU) x = gelu_fast(x);
@@ -495,6 +495,7 @@ static int launch_tile(GemmDesc d, hipStream_t stream) {
 int gemm_bf16(GemmDesc d, hipStream_t stream) {
   if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.nz <= 0 || d.nz > 65535) return U2_ERR_ARG;
   if (!d.A || !d.B || !d.C) return U2_ERR_ARG;
+  if (d.nsplit < 0 || (d.nsplit & 15) || (d.nsplit && (d.flags & GEMM_SWIGLU))) return U2_ERR_ARG;
   if (d.nbh <= 0) d.nbh = 1;
   static const bool trace = getenv("U2TOK_GEMM_TRACE") != nullptr;  // diagnostics: one line per product on stderr
   if (trace) fprintf(stderr, "gemm M=%d N=%d K=%d nz=%d flags=0x%x lda=%d ldb=%d ldc=%d\n", d.M, d.N, d.K, d.nz, d.flags, (int)d.lda, (int)d.ldb, (int)d.ldc);

@@ -75,12 +75,13 @@ __device__ __forceinline__ void bt_epilogue_fast(const GemmDesc& d, f32x16 (&acc
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         float v[8];
+        const float al = n_base + ni * 32 + t * 16 < d.nsplit ? d.alpha_lo : d.alpha;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mi][ni][8 * t + e]),
                                                           __float_as_uint(acc[mi][ni][8 * t + 4 + e]), false, false);
-          v[e] = __uint_as_float(r[0]) * d.alpha;
-          v[4 + e] = __uint_as_float(r[1]) * d.alpha;
+          v[e] = __uint_as_float(r[0]) * al;
+          v[4 + e] = __uint_as_float(r[1]) * al;
         }
         if constexpr (BIAS) {
           const bt_u32x4 b4 = bpre[ni * 2 + t];
@@ -188,7 +189,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmDesc& d, f32x16 (&acc)[2][
           if (!FULL && m >= d.M) continue;
           float v[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = acc[mi][ni][8 * t + e] * d.alpha;
+          for (int e = 0; e < 8; ++e) v[e] = acc[mi][ni][8 * t + e] * (n0 < d.nsplit ? d.alpha_lo : d.alpha);
           if constexpr (decltype(BIAS_)::value) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += bv[e];

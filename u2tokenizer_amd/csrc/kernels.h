@@ -49,6 +49,10 @@ struct GemmDesc {
   int nz = 1, nbh = 1;
   int64_t sAb = 0, sAh = 0, sBb = 0, sBh = 0, sCb = 0, sCh = 0, sRb = 0, sRh = 0;
   float alpha = 1.f;
+  // columns n < nsplit (a multiple of 16) take alpha_lo instead of alpha: the ViT's q|k|v product leaves its q columns
+  // multiplied by softmax scale * log2 e, from the fp32 accumulator (what flash_attention_d64(..., q_prescaled = 1) reads)
+  int nsplit = 0;
+  float alpha_lo = 1.f;
   int flags = 0;
   int tiles_m = 0, tiles_n = 0;  // filled by the launcher
   // split-K (filled by the launcher): K tiles [s * kt_per, (s + 1) * kt_per) go to grid.z slice s, which leaves raw
@@ -175,9 +179,7 @@ int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16
                         int64_t ld_qk, int64_t q_bs, int64_t ld_out, int64_t out_bs, int S_pad, float scale,
                         const bf16_t* qx, const bf16_t* kx, const bf16_t* vx, bf16_t* outx, int64_t x_bs, int64_t ox_bs,
                         int n_extra, float* lse, int64_t lse_ld, hipStream_t stream,  // lse: optional row statistics out
-                        int q_prescaled = 0,  // 1: q and qx already carry scale * log2 e (double pipeline of round 4 only)
-                        void* workspace = nullptr, size_t workspace_bytes = 0);  // enables the split form (balanced 1.5 units per workgroup)
-size_t flash_attention_d64_workspace_bytes(int nb, int S, int H);  // 0: the split form does not apply to this shape
+                        int q_prescaled = 0);  // 1: q and qx already carry scale * log2 e (S >= 512: the double pipeline)
 // Backward of the same attention (attn_bwd.hip): dq / dk / dv of out = softmax(q k^T scale) v for head dim 64, all S rows
 // of a batch in ONE row-major view (q, k, v: row r of batch b at + b*bs_qkv + r*ld_qkv, head h at column h*64; o / dout with
 // ld_o / bs_o; dq / dk / dv with ld_d / bs_d).  lse: optional row statistics of the forward kernel.  Workspace: the row statistics (lse, D).

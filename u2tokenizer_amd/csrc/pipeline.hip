@@ -59,12 +59,14 @@ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 // y[rows][ldy] = x[rows][ldx] @ W[out][in]^T + b  (+GELU) (+R)
 int linear(const bf16_t* x, int64_t ldx, const bf16_t* w, const bf16_t* b, bf16_t* y, int64_t ldy, int64_t rows,
-           int in, int out, int extra_flags, const bf16_t* R, int64_t ldr, hipStream_t st) {
+           int in, int out, int extra_flags, const bf16_t* R, int64_t ldr, hipStream_t st, int nsplit = 0,
+           float alpha_lo = 1.f) {
   GemmDesc g;
   g.A = x; g.B = w; g.C = y; g.bias = b; g.R = R;
   g.M = (int)rows; g.N = out; g.K = in;
   g.lda = ldx; g.ldb = in; g.ldc = ldy; g.ldr = ldr;
   g.flags = (b ? GEMM_BIAS_N : 0) | extra_flags | (R ? GEMM_RESIDUAL : 0);
+  g.nsplit = nsplit; g.alpha_lo = alpha_lo;  // columns [0, nsplit) scaled by alpha_lo (before the bias)
   return gemm_bf16(g, st);
 }
 
@@ -221,13 +223,17 @@ int vit_forward(const VitConfig& c, const void* const* W, const void* volume, bf
     const int b0 = 4 + 11 * l;
     // x = x + out_proj(attn(qkv(norm1(x))))   (MONAI TransformerBlock / SABlock)
     U2_RUN(layernorm_bf16(x, nullptr, w(b0 + 0), w(b0 + 1), xn, 1, (int)rows, Hd, 0, Hd, 0, 0, 0, Hd, c.ln_eps, st));
-    U2_RUN(linear(xn, Hd, w(b0 + 2), nullptr, qkv, 3 * Hd, rows, Hd, 3 * Hd, 0, nullptr, 0, st));
+    // the double pipeline reads q already multiplied by softmax scale * log2 e: the product scales its q columns from the
+    // fp32 accumulator (one rounding, as for the unscaled q of vit.py:100-105; the SABlock qkv projection has no bias)
+    const bool q_pre = opts().vit_flash && ntok >= 512 && (opts().flash_mode == 0 || opts().flash_mode == 7);
+    U2_RUN(linear(xn, Hd, w(b0 + 2), nullptr, qkv, 3 * Hd, rows, Hd, 3 * Hd, 0, nullptr, 0, st, q_pre ? Hd : 0,
+                  scale * 1.44269504088896340736f));
     if (opts().vit_flash) {
       U2_RUN(transpose_bf16(qkv + 2 * Hd, vt, nc, ntok, Hd, 3 * Hd, S_pad, (int64_t)ntok * 3 * Hd, (int64_t)Hd * S_pad, 1, st));
       const bf16_t* xq = qkv + prow * 3 * Hd;  // q | k | v of the cls rows
       U2_RUN(flash_attention_d64(qkv, qkv + Hd, vt, att, nc, ntok, c.heads, 3 * Hd, (int64_t)ntok * 3 * Hd, Hd,
                                  (int64_t)ntok * Hd, S_pad, scale, xq, xq + Hd, xq + 2 * Hd, att + prow * Hd, 3 * Hd, Hd,
-                                 1, nullptr, 0, st));
+                                 1, nullptr, 0, st, q_pre ? 1 : 0));
     } else {
       // unfused reference path (debug option "vit_flash" = 0): gather [cls | patches] per chunk, two GEMMs + softmax
       const size_t mark = ar.off;

@@ -424,20 +424,13 @@ def flash_attention_d64(qkv: torch.Tensor, heads: int, scale: float, extra_last:
             S_pad, float(scale), x0 if extra_last else None, x0 + Hd * es if extra_last else None,
             x0 + 2 * Hd * es if extra_last else None, out.data_ptr() + (S - 1) * Hd * es if extra_last else None,
             S * 3 * Hd, S * Hd, 1 if extra_last else 0)
-    lse, lse_ld = None, 0
     if return_lse:
         lse_ld = (S + 63) // 64 * 64
         lse = torch.empty((nb * heads, lse_ld), dtype=torch.float32, device=qkv.device)
-    nbytes = h.u2tok_flash_attention_d64_workspace_bytes(nb, Sm, heads)
-    if nbytes:  # the shape splits 1.5 units per workgroup (the ViT-B/16 tower at 256^3): hand the scratch over
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=qkv.device)
-        _lib.check(h.u2tok_flash_attention_d64_ws(*args, _ptr(lse), lse_ld, _ptr(ws), nbytes, _stream()),
-                   "u2tok_flash_attention_d64_ws")
-    elif return_lse:
         _lib.check(h.u2tok_flash_attention_d64_lse(*args, _ptr(lse), lse_ld, _stream()), "u2tok_flash_attention_d64_lse")
-    else:
-        _lib.check(h.u2tok_flash_attention_d64(*args, _stream()), "u2tok_flash_attention_d64")
-    return (out, lse) if return_lse else out
+        return out, lse
+    _lib.check(h.u2tok_flash_attention_d64(*args, _stream()), "u2tok_flash_attention_d64")
+    return out
 
 
 @_guarded
