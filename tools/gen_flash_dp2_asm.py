@@ -20,31 +20,46 @@ changed, all of it to take VALU instructions out of the slot:
   * the v_exp results are consumed one slot later (no trans-use s_nop).
   * LDS fragment addresses are lane base + IMMEDIATE: the tile loop is unrolled over the 4 ring slots, so the five
     v_add_u32 per phase are gone.
-Per slot: v_exp, v_exp, s_waitcnt, v_mfma, ds_read_b128, v_add, v_add, v_cvt_pk = 8 issues (was 12-13).
+  * the two query blocks of a wave read each K / V^T fragment from LDS ONCE: the phase of block 0 reads its 8 fragments
+    into 8 tuples, the phase of block 1 finds them there (no ds_read, no lgkmcnt wait: 6 issues per slot).
+  * the next tile's four LDS-DMA pieces go out from MFMA slots 1 / 3 / 5 / 7 of the phase behind the barrier instead of
+    from a stretch of their own between barrier and phase (260 of 2950 cycles per tile and wave); past the last tile
+    the pieces are aimed outside both buffers (zeros, no memory traffic), so every wait is a fixed count.
+Per slot: v_exp, v_exp, s_waitcnt, v_mfma, ds_read_b128, v_add, v_add, v_cvt_pk = 8 issues (was 12-13), 6 in the phases
+that reuse fragments.  Measured (profiles/r04_flash_loop_variants.log): 2950 -> 2734 cycles per 64-key tile and wave,
+118.4 -> 109.7 us per ViT launch; --no-share / --no-dmaphase rebuild the loops without them.
 
     python tools/gen_flash_dp2_asm.py > u2tokenizer_amd/csrc/flash_dp2_asm.inc
 """
 import sys
 
 EXACT = "--exact" in sys.argv   # Q fragments as given; every score is multiplied by scale * log2 e in fp32 (2 more VALU per slot)
+SHARE = "--no-share" not in sys.argv     # the two query blocks of a wave read each K / V^T fragment from LDS once (8 live tuples)
+DMAPH = "--no-dmaphase" not in sys.argv  # next tile's LDS-DMA pieces issued from MFMA slots of the phase behind the barrier
 TIMED = "--timed" in sys.argv   # diagnostics build: s_memtime deltas of the loop sections -> 5 x uint64 at %[dbg]
 PF = 3          # fragment reads in flight
 NSLOT = 4       # LDS ring slots (16 KB each: K tile 8 KB | V^T tile 8 KB)
 AHEAD = 3       # tiles in flight
 THR_BITS = 0x5f800000   # 2^64: a phase's row-sum piece above this sends the wave to the slow path
 
-# ---- fixed VGPRs: v[85:255]; tuples start on even registers (gfx90a+ rule) ----------------------------------------
-ADR = 85                                                     # address temporary of the epilogue's reads
-AB = [86, 87, 88, 89]               # lane base addresses of the fragment reads (LDS base folded in)
-O = {(0, 0): 90, (0, 1): 106, (1, 0): 122, (1, 1): 138}    # O^T accumulators [block][nb], 16 regs each
-SC = {0: 154, 1: 170}                                        # scores - m of a 32-key half, 16 regs each
-MNEG = {0: 186, 1: 202}                                      # -m of the lane's row, replicated: C operand of Q K^T
-PFR = {0: 218, 1: 226}                                       # packed P: 2 tuples of 4 per block
-FR = 234                                                     # fragment ring: 4 tuples of 4
-TT = [[250, 251], [252, 253]]                                # exp results, alternating by slot parity
-PSA, PSB = 254, 255
-MX, TM, TN, TA = FR, FR + 1, FR + 2, FR + 3                  # out-of-line pieces and prologue only: the ring is idle there
-VLO, VHI = 85, 255
+# ---- fixed VGPRs: v[VLO:255]; tuples start on even registers (gfx90a+ rule) ---------------------------------------
+NFR = 8 if SHARE else 4                                      # fragment tuples
+VLO = 69 if SHARE else 85
+ADR = VLO                                                    # address temporary of the epilogue's reads
+AB = [VLO + 1 + i for i in range(4)]    # lane base addresses of the fragment reads (LDS base folded in)
+_o = VLO + 5
+O = {(0, 0): _o, (0, 1): _o + 16, (1, 0): _o + 32, (1, 1): _o + 48}   # O^T accumulators [block][nb], 16 regs each
+SC = {0: _o + 64, 1: _o + 80}                                # scores - m of a 32-key half, 16 regs each
+MNEG = {0: _o + 96, 1: _o + 112}                             # -m of the lane's row, replicated: C operand of Q K^T
+PFR = {0: _o + 128, 1: _o + 136}                             # packed P: 2 tuples of 4 per block
+FR = _o + 144                                                # fragment tuples of 4
+TT = [[FR + 4 * NFR, FR + 4 * NFR + 1], [FR + 4 * NFR + 2, FR + 4 * NFR + 3]]   # exp results, alternating by slot parity
+PSA, PSB = FR + 4 * NFR + 4, FR + 4 * NFR + 5
+assert PSB == 255 and _o % 2 == 0
+# out-of-line pieces and prologue only (called at a phase end: the exp results, PSB and ADR are dead there; the fragment
+# tuples are NOT when the blocks share them)
+MX, TM, TN, TA = TT[1][0], TT[1][1], PSB, ADR
+VHI = 255
 
 # ---- fixed SGPRs -------------------------------------------------------------------------------------------------
 S_T, S_ISSUE, S_NV, S_A, S_B, S_KOFF, S_VOFF, S_AV = range(36, 44)
@@ -112,24 +127,33 @@ def call(label):
 
 
 def issue(slot, label):
-    """DMA of tile S_ISSUE (if < ntile) into ring slot `slot`: 2 K pieces + 2 V^T pieces of 1 KB per wave."""
-    e(f"s_cmp_ge_u32 {s(S_ISSUE)}, %[ntile]")
-    e(f"s_cbranch_scc1 .Lfd2_noissue_{label}_%=")
+    """DMA of tile S_ISSUE (if < ntile) into ring slot `slot`: 2 K pieces + 2 V^T pieces of 1 KB per wave.
+    DMAPH: always four pieces (past the last tile they read outside both buffers: zeros, no memory traffic)."""
+    if not DMAPH:
+        e(f"s_cmp_ge_u32 {s(S_ISSUE)}, %[ntile]")
+        e(f"s_cbranch_scc1 .Lfd2_noissue_{label}_%=")
     e(f"s_mul_i32 {s(S_KOFF)}, {s(S_ISSUE)}, %[ktile]")
     e(f"s_lshl_b32 {s(S_VOFF)}, {s(S_ISSUE)}, 7")
+    if DMAPH:
+        e(f"s_cmp_ge_u32 {s(S_ISSUE)}, %[ntile]")
+        e(f"s_cselect_b32 {s(S_KOFF)}, 0x7ff00000, {s(S_KOFF)}")
+        e(f"s_cselect_b32 {s(S_VOFF)}, 0x7ff00000, {s(S_VOFF)}")
     for (off, vo, rs, so) in [(0, "%[ko0]", "%[rsk]", S_KOFF), (1024, "%[ko1]", "%[rsk]", S_KOFF),
                               (8192, "%[vo0]", "%[rsv]", S_VOFF), (9216, "%[vo1]", "%[rsv]", S_VOFF)]:
         e(f"s_add_u32 m0, %[dma_base], {slot * 16384 + off}")
         e("s_nop 0")
         e(f"buffer_load_dwordx4 {vo}, {rs}, {s(so)} offen lds")
     e(f"s_add_u32 {s(S_ISSUE)}, {s(S_ISSUE)}, 1")
-    e(f".Lfd2_noissue_{label}_%=:")
+    if not DMAPH:
+        e(f".Lfd2_noissue_{label}_%=:")
 
 
-def phase(x, do_q, do_p, do_s, koff, voff, vh, first=False, dyn_v=False):
+def phase(x, do_q, do_p, do_s, koff, voff, vh, first=False, dyn_v=False, reuse=False, dma=None):
     """MFMAs of block x interleaved with the softmax of block y = 1 - x.
     koff / voff: immediate LDS offsets of the K half tile (32 rows) and of the V^T tile; vh: key half of the V^T tile.
-    first: the Q K^T chain starts from 0 (prologue: no running max yet).  dyn_v: V^T tile address = S_AV (epilogue)."""
+    first: the Q K^T chain starts from 0 (prologue: no running max yet).  dyn_v: V^T tile address = S_AV (epilogue).
+    reuse: the fragments are in their tuples already (SHARE: the other block's phase read them).  dma: ring slot whose
+    4 LDS-DMA pieces (tile S_ISSUE, made harmless past the last tile) go out from slots 1 / 3 / 5 / 7."""
     y = 1 - x
     nm = (4 if do_q else 0) + (4 if do_p else 0)
 
@@ -141,7 +165,9 @@ def phase(x, do_q, do_p, do_s, koff, voff, vh, first=False, dyn_v=False):
 
     def read(i):
         k = idx(i)
-        fr = vr(FR + 4 * (i % 4), 4)
+        fr = vr(FR + 4 * (i % NFR), 4)
+        if reuse:
+            return
         if is_q(i):
             e(f"ds_read_b128 {fr}, {v(AB[k])} offset:{koff}")
         else:
@@ -169,29 +195,52 @@ def phase(x, do_q, do_p, do_s, koff, voff, vh, first=False, dyn_v=False):
             e(f"v_mul_f32 {v(SC[y] + 2 * i)}, %[scale], {v(SC[y] + 2 * i)}")
             e(f"v_mul_f32 {v(SC[y] + 2 * i + 1)}, %[scale], {v(SC[y] + 2 * i + 1)}")
 
+    pieces = []
+    if dma is not None:
+        # tile S_ISSUE -> ring slot `dma`; past the last tile the source offsets point outside both buffers (the loads
+        # return zeros into a dead slot without touching memory): the same four pieces per tile, so the vmcnt waits are
+        # the same counts up to the last tile
+        e(f"s_mul_i32 {s(S_KOFF)}, {s(S_ISSUE)}, %[ktile]")
+        e(f"s_lshl_b32 {s(S_VOFF)}, {s(S_ISSUE)}, 7")
+        e(f"s_cmp_ge_u32 {s(S_ISSUE)}, %[ntile]")
+        e(f"s_cselect_b32 {s(S_KOFF)}, 0x7ff00000, {s(S_KOFF)}")
+        e(f"s_cselect_b32 {s(S_VOFF)}, 0x7ff00000, {s(S_VOFF)}")
+        e(f"s_add_u32 {s(S_ISSUE)}, {s(S_ISSUE)}, 1")
+        pieces = [(0, "%[ko0]", "%[rsk]", S_KOFF), (1024, "%[ko1]", "%[rsk]", S_KOFF),
+                  (8192, "%[vo0]", "%[rsv]", S_VOFF), (9216, "%[vo1]", "%[rsv]", S_VOFF)]
     for i in range(min(PF, nm)):
         read(i)
     if do_s:
         scale_pair(0)
+    def mfma(i):
+        k = idx(i)
+        fa = vr(FR + 4 * (i % NFR), 4)
+        if is_q(i):
+            acc = vr(SC[x], 16)
+            c = acc if k else ("0" if first else vr(MNEG[x], 16))
+            e(f"v_mfma_f32_32x32x16_bf16 {acc}, {fa}, {qf(x, k)}, {c}")
+        else:
+            acc = vr(O[(x, k & 1)], 16)
+            e(f"v_mfma_f32_32x32x16_bf16 {acc}, {fa}, {vr(PFR[x] + 4 * (k >> 1), 4)}, {acc}")
+
     for i in range(8):
+        piece = pieces[i // 2] if (pieces and i % 2 == 1) else None
+        if piece:
+            e(f"s_add_u32 m0, %[dma_base], {dma * 16384 + piece[0]}")
+        if reuse and i < nm:
+            mfma(i)   # nothing to wait for: the MFMA leads the slot (and keeps the other block's fresh scores 18 states away)
         if do_s:
             t0, t1 = TT[i & 1]
             e(f"v_exp_f32 {v(t0)}, {v(SC[y] + 2 * i)}")
             e(f"v_exp_f32 {v(t1)}, {v(SC[y] + 2 * i + 1)}")
-        if i < nm:
+        if i < nm and not reuse:
             outstanding = min(PF - 1, nm - 1 - i)
             e(f"s_waitcnt lgkmcnt({outstanding})")
-            k = idx(i)
-            fa = vr(FR + 4 * (i % 4), 4)
-            if is_q(i):
-                acc = vr(SC[x], 16)
-                c = acc if k else ("0" if first else vr(MNEG[x], 16))
-                e(f"v_mfma_f32_32x32x16_bf16 {acc}, {fa}, {qf(x, k)}, {c}")
-            else:
-                acc = vr(O[(x, k & 1)], 16)
-                e(f"v_mfma_f32_32x32x16_bf16 {acc}, {fa}, {vr(PFR[x] + 4 * (k >> 1), 4)}, {acc}")
+            mfma(i)
             if i + PF < nm:
                 read(i + PF)
+        if piece:
+            e(f"buffer_load_dwordx4 {piece[1]}, {piece[2]}, {s(piece[3])} offen lds")
         if do_s and i < 7:
             scale_pair(i + 1)
         if do_s and i > 0:
@@ -320,25 +369,28 @@ def gen():
     # ---- prologue DMA, wait for tile 0
     for i in range(AHEAD):
         issue(i, f"pro{i}")
-    e("s_cmp_ge_u32 %[ntile], 3")
-    e("s_cbranch_scc1 .Lfd2_w3_%=")
-    e("s_cmp_eq_u32 %[ntile], 2")
-    e("s_cbranch_scc1 .Lfd2_w2_%=")
-    e("s_waitcnt vmcnt(0)")
-    e("s_branch .Lfd2_w_%=")
-    e(".Lfd2_w2_%=:")
-    e("s_waitcnt vmcnt(4)")
-    e("s_branch .Lfd2_w_%=")
-    e(".Lfd2_w3_%=:")
-    e("s_waitcnt vmcnt(8)")
-    e(".Lfd2_w_%=:")
+    if DMAPH:
+        e("s_waitcnt vmcnt(8)")
+    else:
+        e("s_cmp_ge_u32 %[ntile], 3")
+        e("s_cbranch_scc1 .Lfd2_w3_%=")
+        e("s_cmp_eq_u32 %[ntile], 2")
+        e("s_cbranch_scc1 .Lfd2_w2_%=")
+        e("s_waitcnt vmcnt(0)")
+        e("s_branch .Lfd2_w_%=")
+        e(".Lfd2_w2_%=:")
+        e("s_waitcnt vmcnt(4)")
+        e("s_branch .Lfd2_w_%=")
+        e(".Lfd2_w3_%=:")
+        e("s_waitcnt vmcnt(8)")
+        e(".Lfd2_w_%=:")
     e("s_barrier")
     # ---- prologue phases on half 0 (tile 0, slot 0)
     e(f"s_mov_b32 {s(S_NV)}, %[seq]")
     phase(0, True, False, False, 0, 0, 0, first=True)
     mask_call(0)
     init_max(0)
-    phase(1, True, False, True, 0, 0, 0, first=True)
+    phase(1, True, False, True, 0, 0, 0, first=True, reuse=SHARE)
     mask_call(1)
     init_max(1)
     # ---- tile loop, unrolled over the ring slots
@@ -357,7 +409,7 @@ def gen():
         e(f"s_sub_i32 {s(S_NV)}, {s(S_NV)}, 32")
         phase(0, True, True, True, base + 4096, base + 8192, 0)
         mask_call(0)
-        phase(1, True, True, True, base + 4096, base + 8192, 0)
+        phase(1, True, True, True, base + 4096, base + 8192, 0, reuse=SHARE)
         mask_call(1)
         stamp(0)
         e(f"s_add_u32 {s(S_A)}, {s(S_T)}, 1")
@@ -365,24 +417,28 @@ def gen():
         e(f"s_mov_b32 {s(S_AV)}, {base + 8192}")
         e("s_cbranch_scc1 .Lfd2_epi_%=")
         # tile t+1 must have landed; behind the barrier tile t-1 is dead and its slot takes tile t+AHEAD
-        e(f"s_add_u32 {s(S_A)}, {s(S_T)}, 2")
-        e(f"s_cmp_lt_u32 {s(S_A)}, %[ntile]")
-        e(f"s_cbranch_scc1 .Lfd2_lw4_{j}_%=")
-        e("s_waitcnt vmcnt(0)")
-        e(f"s_branch .Lfd2_lw_{j}_%=")
-        e(f".Lfd2_lw4_{j}_%=:")
-        e("s_waitcnt vmcnt(4)")
-        e(f".Lfd2_lw_{j}_%=:")
+        if DMAPH:
+            e("s_waitcnt vmcnt(4)")                            # two tiles of four pieces are always in flight here
+        else:
+            e(f"s_add_u32 {s(S_A)}, {s(S_T)}, 2")
+            e(f"s_cmp_lt_u32 {s(S_A)}, %[ntile]")
+            e(f"s_cbranch_scc1 .Lfd2_lw4_{j}_%=")
+            e("s_waitcnt vmcnt(0)")
+            e(f"s_branch .Lfd2_lw_{j}_%=")
+            e(f".Lfd2_lw4_{j}_%=:")
+            e("s_waitcnt vmcnt(4)")
+            e(f".Lfd2_lw_{j}_%=:")
         stamp(1)
         e("s_barrier")
         stamp(2)
-        issue((j + AHEAD) % NSLOT, f"loop{j}")
+        if not DMAPH:
+            issue((j + AHEAD) % NSLOT, f"loop{j}")
         stamp(3)
         e(f"s_sub_i32 {s(S_NV)}, {s(S_NV)}, 32")              # half 2t+2
         # K rows 0..31 of tile t+1 (next slot); V^T tile t, keys 32..63 (vh = 1)
-        phase(0, True, True, True, nxt, base + 8192, 1)
+        phase(0, True, True, True, nxt, base + 8192, 1, dma=(j + AHEAD) % NSLOT if DMAPH else None)
         mask_call(0)
-        phase(1, True, True, True, nxt, base + 8192, 1)
+        phase(1, True, True, True, nxt, base + 8192, 1, reuse=SHARE)
         mask_call(1)
         stamp(4)
         e(f"s_add_u32 {s(S_T)}, {s(S_T)}, 1")
@@ -390,9 +446,9 @@ def gen():
     # ---- epilogue: the last half (tile ntile-1, keys 32..63): its V^T tile is at LDS offset S_AV
     e(".Lfd2_epi_%=:")
     phase(0, False, True, True, 0, 0, 1, dyn_v=True)
-    phase(1, False, True, False, 0, 0, 1, dyn_v=True)
-    # ---- leave O^T in LDS: all waves are done with the ring first
-    e("s_waitcnt lgkmcnt(0)")
+    phase(1, False, True, False, 0, 0, 1, dyn_v=True, reuse=SHARE)
+    # ---- leave O^T in LDS: all waves are done with the ring first (and no LDS-DMA piece is still on its way)
+    e("s_waitcnt vmcnt(0) lgkmcnt(0)")
     e("s_barrier")
     q = 0
     for key in [(0, 0), (0, 1), (1, 0), (1, 1)]:
@@ -408,7 +464,7 @@ def gen():
             e(f"global_store_dwordx2 %[dbg], {vr(TT[0][0], 2)}, off offset:{8 * i}")
         e("s_waitcnt vmcnt(0)")
     # the lane id again, as an OUTPUT: what the C++ epilogue derives from it cannot be hoisted above the block and
-    # kept alive across it (the compiler has v0..v84 there)
+    # kept alive across it (the compiler only has the registers below VLO there)
     e("v_mbcnt_lo_u32_b32 %[lid], -1, 0")
     e("v_mbcnt_hi_u32_b32 %[lid], -1, %[lid]")
     e("s_branch .Lfd2_end_%=")
@@ -421,7 +477,7 @@ def gen():
 
 
 gen()
-sfx = ("_X" if EXACT else "") + ("_TIMED" if TIMED else "")
+sfx = ("_X" if EXACT else "") + ("" if SHARE else "_NS") + ("" if DMAPH else "_ND") + ("_TIMED" if TIMED else "")
 print("// clang-format off")
 print(f"#define FLASH_DP2_ASM_TEXT{sfx} \\")
 body = [l for l in out if not l.startswith("//")]

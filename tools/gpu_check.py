@@ -427,7 +427,7 @@ def sec_flashperf():
             ref = _flash_ref(qkv[:1, :, :], H)
             got = ops.flash_attention_d64(qkv[:1].contiguous(), H, 0.125, extra_last=extra)
             err = (got.float() - ref).abs().max().item()
-            print(f"  nb={nb} S={S} extra={int(extra)} mode={mode} split={split}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF/s  "
+            print(f"  nb={nb} S={S} extra={int(extra)} mode={mode}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF/s  "
                   f"util={fl / ms / 1e9 / 2500:.3f}  max_err={err:.2e}", flush=True)
     ops.set_option("flash_mode", 0)
     qkv = rnd(8, 2049, 3 * 768, seed=3).to(dev)
@@ -502,7 +502,7 @@ def sec_flashtime():
         if mode in (7, 8):
             flash_timeline(buf, split)
         if mode % 10 in (5, 7, 8):
-            print(f"  mode {mode} split {split}: {ms0 * 1e3:7.1f} us untimed | per 64-key tile per wave (2 blocks): phases u=2t {per[0]:6.0f}  dma wait {per[1]:6.0f}  "
+            print(f"  mode {mode}: {ms0 * 1e3:7.1f} us untimed | per 64-key tile per wave (2 blocks): phases u=2t {per[0]:6.0f}  dma wait {per[1]:6.0f}  "
                   f"barrier {per[2]:6.0f}  dma issue {per[3]:6.0f}  phases u=2t+1 {per[4]:6.0f}  total {per[:5].sum():6.0f}", flush=True)
             continue
         if mode % 10 == 4:

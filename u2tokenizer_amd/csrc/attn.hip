@@ -883,15 +883,15 @@ __global__ __launch_bounds__(256, 2) void flash_dp2_kernel(const FlashArgs a) {
                  [dump] "v"(dump), [rsk] "s"(rsk), [rsv] "s"(rsv), [lds] "s"(lds_u32), [dma_base] "s"(dma_base),        \
                  [ktile] "s"(k_tile_bytes), [seq] "s"(S), [ntile] "s"(ntile), [dbg] "v"(dbg),                           \
                  [scale] "s"(scale_log2e), [rscale] "s"(rscale)
+#define FDP2_RUN(SFX_) asm volatile(FLASH_DP2_ASM_TEXT##SFX_ FDP2_OPERANDS : FLASH_DP2_ASM_CLOBBERS##SFX_)
   if constexpr (TIMED) {
     if (lane == 0) tl[1] = __builtin_amdgcn_s_memrealtime();
-    if constexpr (QMODE == 0) asm volatile(FLASH_DP2_ASM_TEXT_X_TIMED FDP2_OPERANDS : FLASH_DP2_ASM_CLOBBERS_X_TIMED);
-    else asm volatile(FLASH_DP2_ASM_TEXT_TIMED FDP2_OPERANDS : FLASH_DP2_ASM_CLOBBERS_TIMED);
+    if constexpr (QMODE == 0) FDP2_RUN(_X_TIMED); else FDP2_RUN(_TIMED);
     if (lane2 == 0) { dbg[7] = (unsigned long long)ntile; tl[2] = __builtin_amdgcn_s_memrealtime(); }
   } else {
-    if constexpr (QMODE == 0) asm volatile(FLASH_DP2_ASM_TEXT_X FDP2_OPERANDS : FLASH_DP2_ASM_CLOBBERS_X);
-    else asm volatile(FLASH_DP2_ASM_TEXT FDP2_OPERANDS : FLASH_DP2_ASM_CLOBBERS);
+    if constexpr (QMODE == 0) FDP2_RUN(_X); else FDP2_RUN();
   }
+#undef FDP2_RUN
 #undef FDP2_OPERANDS
   // the block left O^T in LDS: tuple T = 2 * block + nb, 16-byte quarter j at [wave][T * 4 + j][lane]
   const int hi2 = lane2 >> 5, l31b = lane2 & 31;
