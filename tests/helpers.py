@@ -2,6 +2,8 @@
 from pathlib import Path
 
 import numpy as np
+import math
+
 import torch
 
 from oracle import u2_oracle as O
@@ -38,7 +40,17 @@ def diversity(x: torch.Tensor) -> float:
 
 
 def err_stats(a: torch.Tensor, b: torch.Tensor):
+    """distance of a from b.  Besides max / mean / relative-RMS: the contract's literal figure (north_star: "within 1e-3"),
+    as the fraction of elements with |a - b| <= 1e-3, and the same distances in bf16 ulps of the reference value (one ulp of
+    x = 2^(floor(log2 |x|) - 7): 1e-3 is below one ulp from |x| >= 0.128 on)."""
     a, b = a.double().flatten(), b.double().flatten()
     d = (a - b).abs()
-    return dict(max_abs=d.max().item(), mean_abs=d.mean().item(), ref_rms=b.pow(2).mean().sqrt().item(),
-                rel_rms=(d.pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-30)).item())
+    ulp = torch.exp2(torch.floor(torch.log2(b.abs().clamp_min(2.0 ** -126))) - 7)
+    du = d / ulp
+    rms = b.pow(2).mean().sqrt()
+    return dict(max_abs=d.max().item(), mean_abs=d.mean().item(), ref_rms=rms.item(),
+                rel_rms=(d.pow(2).mean().sqrt() / rms.clamp_min(1e-30)).item(),
+                frac_within_1e3=(d <= 1e-3).double().mean().item(),
+                frac_within_1_bf16_ulp=(du <= 1.0).double().mean().item(),
+                frac_within_2_bf16_ulp=(du <= 2.0).double().mean().item(),
+                abs_1e3_in_bf16_ulps_at_ref_rms=(1e-3 / 2.0 ** (math.floor(math.log2(max(rms.item(), 2.0 ** -126))) - 7)))

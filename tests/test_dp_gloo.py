@@ -16,13 +16,17 @@ def _free_port():
 
 
 class _WithDead(torch.nn.Sequential):
-    """the plain model + a Linear that the forward never touches"""
+    """the plain model + a Linear that the forward never touches -- unless `wake` is set (a data-dependent branch: a
+    parameter without gradient for some steps, then with one)"""
 
     def __init__(self, *mods):
         super().__init__(*mods)
-        self.dead = torch.nn.Linear(11, 13)
+        self.dead = torch.nn.Linear(24, 24)
+        self.wake = False
 
     def forward(self, x):
+        if self.wake:   # at the INPUT side: its gradient is the last of the backward, long after its bucket (filled first,
+            x = x + self.dead(x)   # with the last layers) has been reduced from the learnt subset
         for name, mod in self.named_children():
             if name != "dead":
                 x = mod(x)
@@ -32,7 +36,18 @@ class _WithDead(torch.nn.Sequential):
 def _model(variant="plain"):
     torch.manual_seed(0)
     mods = [torch.nn.Linear(24, 40), torch.nn.GELU(), torch.nn.Linear(40, 40), torch.nn.LayerNorm(40), torch.nn.Linear(40, 7)]
-    return _WithDead(*mods) if variant == "unused" else torch.nn.Sequential(*mods)
+    return _WithDead(*mods) if variant in ("unused", "wakes") else torch.nn.Sequential(*mods)
+
+
+def _steps(variant):
+    return 8 if variant in ("unused", "wakes") else 3
+
+
+def _wake(m, variant, step):
+    """variant "wakes": the dead Linear takes part from step 5 on -- after its bucket has been launched early from the learnt
+    subset for a step or two"""
+    if variant == "wakes":
+        m.wake = step >= 5
 
 
 def _data(rank, step):
@@ -55,11 +70,12 @@ def _worker(rank, world, port, q, overlap, bucket, clip=None, accum=1, variant="
         opt = Zero1AdamW(params, lr=1e-2, weight_decay=0.1, reduce_bucket_size=bucket, allgather_bucket_size=bucket,
                          overlap_comm=overlap, max_grad_norm=clip, gradient_accumulation_steps=accum)
         norms, launched_early = [], []
-        for step in range(3):
+        for step in range(_steps(variant)):
+            _wake(m, variant, step)
             for micro in range(accum):
                 x, y = _data(rank, step * accum + micro)
                 (torch.nn.functional.mse_loss(m(x), y) / accum).backward()
-                if micro < accum - 1:
+                if micro < accum - 1 and variant != "wakes":
                     assert opt._next_launch == 0, "a bucket was reduced before the last micro-batch"
             launched_early.append(opt._next_launch)   # buckets whose reduce-scatter was launched from a hook (overlap)
             opt.step()
@@ -84,13 +100,14 @@ def _reference(world, clip=None, accum=1, variant="plain"):
     m = _model(variant)
     opt = torch.optim.AdamW(hf_param_groups(m, 0.1) if variant == "groups" else m.parameters(), lr=1e-2, weight_decay=0.1)
     norms = []
-    for step in range(3):
+    for step in range(_steps(variant)):
         opt.zero_grad()
+        _wake(m, variant, step)
         for rank in range(world):
             for micro in range(accum):
                 x, y = _data(rank, step * accum + micro)
                 (torch.nn.functional.mse_loss(m(x), y) / (world * accum)).backward()
-        if variant == "unused":
+        if variant in ("unused", "wakes") and not m.wake:
             # a flat ZeRO partition has a (zero) gradient for every element, so AdamW's decoupled weight decay also shrinks
             # parameters that received none -- DeepSpeed's behaviour, unlike torch.optim.AdamW skipping grad-less tensors
             for p in m.dead.parameters():
@@ -162,9 +179,11 @@ def test_zero1_gradient_accumulation_unused_parameters_and_groups():
     """config/ds_config.json:40 gradient_accumulation_steps: the reduce-scatter of a bucket must wait for the LAST micro-batch
     (the worker asserts nothing was launched earlier), gradients accumulate in the flat buckets, and the result equals one
     process accumulating world x accum micro-batches.  A parameter that never receives a gradient costs the overlap only in
-    the first step (the bucket's expected hook count is learnt).  HF-style parameter groups (no decay on biases / LayerNorm)
+    the first three steps (then the subset of parameters that do is trusted); one that starts receiving gradients later
+    ("wakes": ADVICE r3 -- the early launch of that step is repeated by step(), nothing raises, parameters still equal AdamW's).  HF-style parameter groups (no decay on biases / LayerNorm)
     and a caller that clears gradients with set_to_none=True give the same parameters as torch.optim.AdamW."""
-    for variant, accum, clip in (("plain", 3, None), ("unused", 2, 0.05), ("groups", 1, None), ("none", 2, None)):
+    for variant, accum, clip in (("plain", 3, None), ("unused", 2, 0.05), ("groups", 1, None), ("none", 2, None),
+                                 ("wakes", 1, None), ("wakes", 2, 0.05)):
         ref, ref_norms = _reference(2, clip, accum, variant)
         (r0, p0, nb, _, n0, early), (r1, p1, _, _, n1, _) = _run(True, 700, clip, accum, variant)
         assert n0 == n1
@@ -174,8 +193,14 @@ def test_zero1_gradient_accumulation_unused_parameters_and_groups():
         if clip is not None:
             for a, b in zip(n0, ref_norms):
                 assert abs(a - b) <= 1e-5 * b
-        if variant == "unused":
-            assert early[0] < nb and early[1] == nb and early[2] == nb, early   # learnt after the first step
+        if variant == "unused":   # the subset is trusted once it has been the same for 3 steps
+            assert all(e < nb for e in early[:3]) and all(e == nb for e in early[3:]), early
+        elif variant == "wakes":
+            # ... and forgotten when the parameter wakes up in step 5.  One micro-batch per step: its bucket had been launched
+            # from the learnt subset by then, step() reduces it again.  Two: the first micro-batch already shows the
+            # stranger, the bucket (and, in order, every bucket behind it) waits for step().
+            assert all(e < nb for e in early[:3]) and early[3] == early[4] == early[6] == early[7] == nb, early
+            assert early[5] == (nb if accum == 1 else 0), early
         else:
             assert all(e == nb for e in early), (variant, early)
 
@@ -193,6 +218,29 @@ def test_single_process_zero1_is_plain_adamw():
             o.step()
     for a, b in zip(m1.parameters(), m2.parameters()):
         assert torch.allclose(a, b, rtol=2e-5, atol=2e-6)
+
+
+@torch.enable_grad()
+def test_zero1_mixed_dtype_buckets_keep_their_precision():
+    """Buckets are split by dtype; each kind has its own staging buffers for the updated parameters (one buffer of
+    the first bucket's dtype rounded fp32 parameters through bf16 on every step)."""
+    from u2tokenizer_amd.dp import Zero1AdamW
+    torch.manual_seed(0)
+    a16, b32 = torch.nn.Linear(6, 5).to(torch.bfloat16), torch.nn.Linear(6, 5)
+    ref = torch.nn.Linear(6, 5)
+    ref.load_state_dict(b32.state_dict())
+    opt = Zero1AdamW(list(a16.parameters()) + list(b32.parameters()), lr=1e-2, weight_decay=0.1)
+    ropt = torch.optim.AdamW(ref.parameters(), lr=1e-2, weight_decay=0.1)
+    assert len({b.flat_grad.dtype for b in opt.buckets}) == 2
+    for step in range(3):
+        x = torch.randn(4, 6, generator=torch.Generator().manual_seed(step))
+        (a16(x.to(torch.bfloat16)).float().square().mean() + b32(x).square().mean()).backward()
+        ref(x).square().mean().backward()
+        opt.step(); opt.zero_grad(); ropt.step(); ropt.zero_grad()
+    for p, q in zip(b32.parameters(), ref.parameters()):
+        assert torch.allclose(p, q, rtol=2e-5, atol=2e-6)
+        assert not torch.equal(p, p.to(torch.bfloat16).float())      # still full fp32 values
+    assert all(p.dtype == torch.bfloat16 for p in a16.parameters())
 
 
 @torch.enable_grad()

@@ -3,7 +3,7 @@ host (same name-seeded "lively" parameters, same inputs), stage by stage.
 
 For every stage the three distances SURVEY.md section 8(d) asks for are computed -- |hip - oracle_fp32|,
 |hip - oracle_bf16|, |oracle_bf16 - oracle_fp32| -- gated with the bar of tests/test_gpu_path.py (the HIP path may be no
-further from the fp32 reference than 1.5x the bf16 reference run is) and written to gpurun_out/r03_parity.json, from
+further from the fp32 reference than 1.5x the bf16 reference run is) and written to gpurun_out/r04_parity.json, from
 where the round's copy under profiles/ is taken.
 """
 import json
@@ -35,11 +35,11 @@ def _gpu():
 
 
 def record(key, value):
-    """Merge {key: value} into gpurun_out/r03_parity.json (best effort: the numbers are also asserted)."""
+    """Merge {key: value} into gpurun_out/r04_parity.json (best effort: the numbers are also asserted)."""
     out = ROOT / "gpurun_out"
     try:
         out.mkdir(exist_ok=True)
-        p = out / "r03_parity.json"
+        p = out / "r04_parity.json"
         data = json.loads(p.read_text()) if p.exists() else {}
         data[key] = value
         p.write_text(json.dumps(data, indent=1, sort_keys=True))
@@ -53,9 +53,17 @@ def three_way(hip, o32, o16):
 
 
 def gate(d, what):
+    """The HIP path may be no further from the fp32 reference than the reference's own bf16 run is, with a margin for the
+    different (equally legitimate) rounding points: 1.2 x its relative RMS distance + 2e-4 (round 3 gated 1.5 x + 1e-3;
+    measured ratios over every stage and configuration: 0.45 .. 1.07, profiles/r03_parity.json, r04_parity.json), and
+    1.6 x its largest absolute deviation + four bf16 ulps of the reference RMS.  north_star's literal "within 1e-3 of the
+    bf16 reference" is reported beside it (err_stats: fraction of elements within 1e-3, distances in bf16 ulps): at these
+    magnitudes 1e-3 is a fraction of ONE bf16 ulp, which two correct bf16 computations cannot promise each other."""
     e_hip, e_orc = d["hip_vs_o32"], d["o16_vs_o32"]
-    assert e_hip["rel_rms"] <= 1.5 * e_orc["rel_rms"] + 1e-3, (what, e_hip, e_orc)
-    assert e_hip["max_abs"] <= 2.0 * e_orc["max_abs"] + 2.0 ** -8 * e_hip["ref_rms"] * 4, (what, e_hip, e_orc)
+    assert e_hip["rel_rms"] <= 1.2 * e_orc["rel_rms"] + 2e-4, (what, e_hip, e_orc)
+    assert e_hip["max_abs"] <= 1.6 * e_orc["max_abs"] + 2.0 ** -8 * e_hip["ref_rms"] * 4, (what, e_hip, e_orc)
+    # and against the bf16 reference itself: as close to it as it is to fp32 (the two differ by rounding, not by a bug)
+    assert d["hip_vs_o16"]["rel_rms"] <= 1.5 * e_orc["rel_rms"] + 2e-4, (what, d["hip_vs_o16"], e_orc)
 
 
 def mm_config(E, image_size, **kw):
@@ -201,6 +209,61 @@ def test_config3_full_path_vs_oracle():
     1024 (u2_arch.py:96-117)."""
     c = mm_config(4096, [32, 256, 256])
     run_full_config("config3_E4096_256cube", c, B=1, C=8, S=1024, Lt=1024, seed=71)
+
+
+def test_config3_end_to_end_first_step_logits_and_greedy_ids():
+    """SURVEY 8(d) at the benchmark's configuration, end to end (u2llama.py:76-87,123-126): one 256^3 volume through the HIP
+    ViT / SPP / 4-layer tokenizer, spliced into 1024 embeddings, then a Qwen3-8B-WIDTH decoder (hidden 4096, 32 / 8 heads of
+    128, MLP 12288; 4 layers, random init) through the fused HIP prefill -- first-step logits and 4 greedy ids against the
+    oracle path + the same HF decoder in fp32 on the host, with the reference's own bf16 run as the yardstick."""
+    from transformers import Qwen3ForCausalLM
+    from u2tokenizer_amd.language_model import u2Qwen3Config, u2Qwen3ForCausalLM
+    E, vocab, S, Lt, seed = 4096, 4096, 1024, 1024, 75
+    c = mm_config(E, [32, 256, 256])
+    cfg = u2Qwen3Config(vocab_size=vocab, hidden_size=E, intermediate_size=12288, num_hidden_layers=4,
+                        num_attention_heads=32, num_key_value_heads=8, head_dim=128, max_position_embeddings=2048,
+                        tie_word_embeddings=False, pad_token_id=0, bos_token_id=1, eos_token_id=2)
+    for k, v in c.items():
+        if k != "hidden_size":
+            setattr(cfg, k, v)
+    m = u2Qwen3ForCausalLM(cfg).eval()
+    synth.fill_module_(m, seed=seed, lively=True)
+    sd32 = {k: v.clone() for k, v in m.state_dict().items() if v.is_floating_point()}
+    sd16 = {k: v.to(bf) for k, v in sd32.items()}
+    vol = synth.synth_volume(1, 8, c["image_size"], seed=seed, dtype=torch.float16)
+    ids = synth.synth_ids(1, S, S - 24, vocab, seed=seed, name="input_ids")
+    qids = synth.synth_ids(1, Lt, 40, vocab, seed=seed, name="question_ids")
+    oc = oracle_cfg(c)
+    e32, _ = O.prepare_inputs_for_multimodal(sd32, sd32["model.embed_tokens.weight"], ids, vol.float(), qids, oc)
+    logits32 = m(inputs_embeds=e32).logits[:, -1]
+    new = 4
+    gen32 = Qwen3ForCausalLM.generate(m, inputs_embeds=e32, max_new_tokens=new, do_sample=False, output_scores=True,
+                                      return_dict_in_generate=True)
+    m16 = m.to(bf)
+    e16, _ = O.prepare_inputs_for_multimodal(sd16, sd16["model.embed_tokens.weight"], ids, vol.to(bf), qids, oc)
+    logits16 = m16(inputs_embeds=e16).logits[:, -1]
+    mg = m16.to(D)
+    out = mg(images=vol.to(D), input_ids=ids.to(D), question_ids=qids.to(D))
+    assert hasattr(mg.model.layers[0], "_u2_prefill")                      # the decoder ran through the fused HIP layers
+    emb = mg.prepare_inputs_for_multimodal(ids.to(D), None, None, None, None, vol.to(D), qids.to(D))[4]
+    gen = mg.generate(vol.to(D), ids.to(D), question_ids=qids.to(D), max_new_tokens=new, do_sample=False).cpu()
+    rep = {"decoder": "Qwen3-8B width (4096 / 12288, 32 q / 8 kv heads of 128), 4 layers, random init; fused HIP prefill + decode",
+           "inputs_embeds": three_way(emb, e32, e16), "logits_last": three_way(out.logits[:, -1], logits32, logits16),
+           "greedy_ids_hip": gen.tolist(), "greedy_ids_fp32": gen32.sequences.tolist()}
+    margins = []
+    for t in range(new):
+        top2 = gen32.scores[t][0].topk(2).values
+        margins.append(float(top2[0] - top2[1]))
+    rep["fp32_top2_margins"] = margins
+    record("config3_E4096_256cube_end_to_end", rep)
+    gate(rep["inputs_embeds"], "config3 e2e inputs_embeds")
+    gate(rep["logits_last"], "config3 e2e logits")
+    assert gen.shape == gen32.sequences.shape
+    for t in range(new):    # ids must agree while the fp32 model's own margin is above what a bf16 run can flip
+        if margins[t] > 4 * rep["logits_last"]["o16_vs_o32"]["max_abs"]:
+            assert gen[0, t] == gen32.sequences[0, t], (t, gen, gen32.sequences, margins)
+        else:
+            break
 
 
 def test_config2_full_path_vs_oracle():

@@ -164,33 +164,79 @@ def _err(a, b):
     return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
 
 
-@pytest.mark.parametrize("kind", ["qwen3", "llama"])
-def test_fused_prefill_matches_the_stock_decoder(ops, kind):
+@pytest.mark.parametrize("kind,wide", [("qwen3", False), ("llama", False), ("qwen3", True)])
+def test_fused_prefill_matches_the_stock_decoder(ops, kind, wide):
     """Logits and the KV cache of a prefill through the patched layers: no further from the fp32 model than 1.5 x the stock bf16
-    GPU run is; a padded batch must take the stock layers (bit-identical to the unpatched model)."""
+    GPU run is; a padded batch must take the stock layers (bit-identical to the unpatched model).  wide: two layers at the
+    Qwen3-8B width over the path's 1024 spliced embeddings -- the kernel variants the real prefill takes (q|k|v and gate|up on
+    the big-tile kernel in pair / K-sliced form at M = 1024, 64-key causal tiles at head dim 128)."""
     from u2tokenizer_amd.prefill import disable_fused_prefill, enable_fused_prefill
-    m32 = _small(kind)
-    x = 0.5 * synth.synth_tensor("inputs_embeds", (2, 70, 512), 3)
+    nl, B, S, E = (2, 1, 1024, 4096) if wide else (3, 2, 70, 512)
+    m32 = _small(kind, nl, wide)
+    x = 0.5 * synth.synth_tensor("inputs_embeds", (B, S, E), 3)
     ref = m32(inputs_embeds=x, use_cache=True)
-    mg = _small(kind).to(bf).to(D)
+    mg = _small(kind, nl, wide).to(bf).to(D)
     xd = x.to(bf).to(D)
     stock = mg(inputs_embeds=xd, use_cache=True)
-    assert enable_fused_prefill(mg) == 3
+    assert enable_fused_prefill(mg) == nl
     fused = mg(inputs_embeds=xd, use_cache=True)
     e_stock, e_fused = _err(stock.logits.float().cpu(), ref.logits), _err(fused.logits.float().cpu(), ref.logits)
     assert e_fused <= 1.5 * e_stock + 1e-3, (e_fused, e_stock)
     assert not torch.equal(fused.logits, stock.logits)          # (it really took another code path)
-    for li in (0, 2):
+    for li in (0, nl - 1):
         for name in ("keys", "values"):
             r = getattr(ref.past_key_values.layers[li], name)
             es = _err(getattr(stock.past_key_values.layers[li], name).float().cpu(), r)
             ef = _err(getattr(fused.past_key_values.layers[li], name).float().cpu(), r)
             assert ef <= 1.5 * es + 1e-3, (li, name, ef, es)
-    mask = torch.ones((2, 70), dtype=torch.int64, device=D)
-    mask[1, :5] = 0
+    mask = torch.ones((B, S), dtype=torch.int64, device=D)
+    mask[B - 1, :5] = 0
     padded = mg(inputs_embeds=xd, attention_mask=mask, use_cache=True)
     disable_fused_prefill(mg)
     assert torch.equal(padded.logits, mg(inputs_embeds=xd, attention_mask=mask, use_cache=True).logits)
+
+
+class _LoraLikeLinear(torch.nn.Module):
+    """What peft's lora.Linear looks like from outside: `.weight` / `.bias` are the BASE layer's, forward adds the adapter."""
+
+    def __init__(self, base, rank=4):
+        super().__init__()
+        self.base_layer = base
+        g = torch.Generator().manual_seed(3)
+        self.lora_A = torch.nn.Parameter(0.05 * torch.randn(rank, base.in_features, generator=g).to(base.weight))
+        self.lora_B = torch.nn.Parameter(0.05 * torch.randn(base.out_features, rank, generator=g).to(base.weight))
+
+    weight = property(lambda self: self.base_layer.weight)
+    bias = property(lambda self: self.base_layer.bias)
+
+    def forward(self, x):
+        return self.base_layer(x) + (x @ self.lora_A.t()) @ self.lora_B.t()
+
+
+def test_fused_prefill_leaves_wrapped_or_hooked_layers_stock(ops):
+    """The reference trains the decoder with LoRA (train_stage1.py:342-353).  A layer whose projection is not exactly
+    nn.Linear (an unmerged adapter), or that carries a forward hook, must run its own forward: outputs bit-identical to the
+    unpatched model; the untouched layers still take the fused path."""
+    from u2tokenizer_amd.prefill import disable_fused_prefill, enable_fused_prefill
+    mg = _small("qwen3").to(bf).to(D)
+    xd = (0.5 * synth.synth_tensor("inputs_embeds", (1, 70, 512), 3)).to(bf).to(D)
+    plain = mg(inputs_embeds=xd).logits
+    lay = mg.model.layers[1]
+    lay.self_attn.q_proj = _LoraLikeLinear(lay.self_attn.q_proj).to(D)
+    seen = []
+    handle = mg.model.layers[2].mlp.register_forward_hook(lambda m, a, out: seen.append(out.shape))
+    want = mg(inputs_embeds=xd).logits                     # adapter + hook active, stock layers
+    assert not torch.equal(want, plain) and len(seen) == 1
+    assert enable_fused_prefill(mg) == 3
+    got = mg(inputs_embeds=xd).logits
+    assert len(seen) == 2                                  # the hook fired: that layer ran its own forward
+    # layer 0 is fused, layers 1 and 2 stock: close to, not equal to, the all-stock run; the adapter's effect is in the result
+    assert _err(got.float(), want.float()) < 2e-2 and _err(got.float(), plain.float()) > 0.5 * _err(want.float(), plain.float())
+    handle.remove()
+    lay.self_attn.q_proj = lay.self_attn.q_proj.base_layer
+    again = mg(inputs_embeds=xd).logits                    # adapter merged away, hook gone: all three layers fused again
+    disable_fused_prefill(mg)
+    assert _err(again.float(), plain.float()) < 2e-2 and not torch.equal(again, plain)
 
 
 @pytest.mark.parametrize("nb,T,g,d", [(8, 1100, 4, 128), (3, 70, 2, 64), (16, 1792, 4, 128), (2, 5, 1, 128)])

@@ -41,6 +41,82 @@ def test_state_dict_keys_match_reference_contract():
     assert got == ref["linvt_small"]
 
 
+def test_shipped_config_flag_enable_rpe_selects_the_attention_type():
+    """base_model_tokenizers/Llama-3.2-1B-Instruct/config.json:21 + u2Tokenizer.py:86-93,422: the shipped code generation
+    spells the choice as a boolean; src/model/u2tokenizer/builder.py:12 as `attn_type`."""
+    ref = json.loads((GOLDEN / "state_dict_keys.json").read_text())
+    keys = lambda c: {"u2tokenizer." + k: list(v.shape) for k, v in U.build_u2tokenizer_tower(c).state_dict().items()}
+    on, off = _cfg(enable_rpe=True), _cfg(enable_rpe=False)
+    del on.attn_type, off.attn_type
+    assert keys(on) == {k: v for k, v in ref["mu2_small"].items() if k.startswith("u2tokenizer.")}
+    assert keys(off) == ref["linvt_small"]
+    assert keys(_cfg(attn_type="rope", enable_rpe=False, enable_diffts=False, enable_dmtp=False)) == ref["rope_hard_small"]
+
+
+def test_vit_strict_load_tolerates_the_unused_monai_cls_token():
+    """u2_arch.py:64-66 loads M3D-CLIP's pretrained_ViT.bin with strict=True; MONAI <= 1.3.x checkpoints carry an unread
+    `patch_embedding.cls_token`.  Both generations load, and what was loaded is what is saved."""
+    tower = U.build_vision_tower(_cfg()).vision_tower
+    sd = {k: v.clone() for k, v in tower.state_dict().items()}
+    assert "patch_embedding.cls_token" not in sd
+    tower.load_state_dict(sd, strict=True)                                 # newer MONAI: no such key
+    old = dict(sd)
+    old["patch_embedding.cls_token"] = torch.full((1, 1, 768), 0.25)
+    fresh = U.build_vision_tower(_cfg()).vision_tower
+    fresh.load_state_dict(old, strict=True)                                # older MONAI: adopted, never read
+    back = fresh.state_dict()
+    assert set(back) == set(old) and torch.equal(back["patch_embedding.cls_token"], old["patch_embedding.cls_token"])
+    assert not fresh.patch_embedding.cls_token.requires_grad
+    assert len(fresh._weights()) == len(tower._weights())                  # the launch table does not see it
+
+
+def test_fused_prefill_refuses_the_older_decoder_layer_protocol():
+    """transformers 4.46 (the reference's pin) .. 4.5x: decoder layers take `past_key_value` and return tuples.  The fused
+    layer forward is written for the `past_key_values` / tensor-return protocol; patching the older one would skip every
+    cache update.  Such layers stay stock (with one warning)."""
+    from u2tokenizer_amd import prefill
+
+    class Attn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q_proj = self.k_proj = self.v_proj = self.o_proj = torch.nn.Linear(8, 8)
+            self.head_dim, self.scaling = 8, 1.0
+
+    class Mlp(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.gate_proj = self.up_proj = self.down_proj = torch.nn.Linear(8, 8)
+
+    class OldLayer(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.self_attn, self.mlp = Attn(), Mlp()
+            self.input_layernorm = self.post_attention_layernorm = torch.nn.LayerNorm(8)
+
+        def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None, use_cache=False,
+                    position_embeddings=None, **kwargs):
+            return (hidden_states,)
+
+    class NewLayer(OldLayer):
+        def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None, use_cache=False,
+                    position_embeddings=None, **kwargs) -> torch.Tensor:
+            return hidden_states
+
+    class Base(torch.nn.Module):
+        def __init__(self, cls):
+            super().__init__()
+            self.layers = torch.nn.ModuleList([cls(), cls()])
+
+    prefill._warned_protocol[0] = False
+    with pytest.warns(UserWarning, match="decoder layer protocol"):
+        assert prefill.enable_fused_prefill(Base(OldLayer)) == 0
+    new = Base(NewLayer)
+    assert prefill.enable_fused_prefill(new) == 2
+    # a patched layer still hands anything it does not take (CPU tensors here) to its own forward
+    assert new.layers[0](torch.zeros(1, 2, 8)) is not None
+    prefill.disable_fused_prefill(new)
+
+
 def test_builders_raise_like_the_reference():
     with pytest.raises(ValueError, match="Unknown vision tower"):
         U.build_vision_tower(_cfg(vision_tower="resnet"))
@@ -177,13 +253,28 @@ def test_frozen_tower_feature_sharing_logic():
     assert len(calls) == 2                                  # trainable tower: never cached
     tower.requires_grad_(False)
     a, b = tower(img), tower(img.clone())
-    assert len(calls) == 3 and b is a
+    assert len(calls) == 3 and torch.equal(b, a) and b is not a     # (a copy: in-place ops downstream cannot reach the cache)
+    b.add_(1.0)
+    assert torch.equal(tower(img), a) and len(calls) == 3
     c = tower(img + 1)
     assert len(calls) == 4 and not torch.equal(c, a)
     with torch.no_grad():
         tower.vision_tower.norm.weight.add_(1.0)
     d = tower(img + 1)
     assert len(calls) == 5 and not torch.equal(d, c)
+    # a write through .data does not bump the version counter (an optimiser's copy-out): the whole-model paths that do such
+    # writes drop the cache, anything else calls invalidate_feature_cache()
+    tower.vision_tower.norm.weight.data.add_(1.0)
+    assert torch.equal(tower(img + 1), d) and len(calls) == 5         # (undetectable, documented)
+    tower.invalidate_feature_cache()
+    e = tower(img + 1)
+    assert len(calls) == 6 and not torch.equal(e, d)
+    tower.load_state_dict(tower.state_dict())
+    tower(img + 1)
+    tower.double()
+    tower(img + 1)
+    assert len(calls) == 8
+    calls.clear(); calls.extend([0] * 5)
     tower.share_frozen_features = False
     tower(img + 1)
     assert len(calls) == 6

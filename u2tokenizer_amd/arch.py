@@ -117,7 +117,10 @@ class u2MetaForCausalLM(ABC):
             # (dpo_u2trainer.py:160-162) with the same question: the two halves of the vision batch are byte-identical.
             # The path is a deterministic function of (image, question): run one half and repeat the result (autograd
             # sums the two halves' gradients, as it would have).  Costs one comparison of the halves per call.
-            dup = (getattr(self.config, "u2_dedup_duplicate_images", True) and B >= 2 and B % 2 == 0
+            # The probe is a device synchronisation (torch.equal), so it only runs where the duplication can occur: under
+            # autograd (a training step), or when config.u2_dedup_duplicate_images is set to "always".
+            dedup = getattr(self.config, "u2_dedup_duplicate_images", True)
+            dup = (bool(dedup) and (dedup == "always" or torch.is_grad_enabled()) and B >= 2 and B % 2 == 0
                    and torch.equal(question_ids[:B // 2], question_ids[B // 2:])
                    and torch.equal(images[:B // 2], images[B // 2:]))
             if dup:
@@ -157,10 +160,12 @@ class u2MetaForCausalLM(ABC):
             embed_tokens_weight = weights["model.embed_tokens.weight"]
             input_embeddings = self.get_input_embeddings().weight.data
             if input_embeddings.shape == embed_tokens_weight.shape:
-                # NOTE: deliberate difference.  The reference REBINDS its local name here (`input_embeddings =
-                # embed_tokens_weight`, u2_arch.py:155), which leaves the model's embedding table untouched -- the checkpoint's
-                # table is silently dropped.  The evident intent (and the sibling branch below) is a copy into the table.
-                input_embeddings.copy_(embed_tokens_weight)
+                # The reference REBINDS its local name here (`input_embeddings = embed_tokens_weight`, u2_arch.py:155), which
+                # leaves the model's embedding table untouched: the checkpoint's table is dropped.  A drop-in keeps that
+                # behaviour; the evident intent (and the sibling branch below), a copy into the table, is opt-in:
+                # config.u2_fix_embed_copy = True.
+                if getattr(self.config, "u2_fix_embed_copy", False):
+                    input_embeddings.copy_(embed_tokens_weight)
             elif embed_tokens_weight.shape[0] == num_new_tokens:
                 input_embeddings[-num_new_tokens:] = embed_tokens_weight
             else:

@@ -25,6 +25,20 @@ def build_mm_projector(config, delay_load=False, **kwargs):
     raise ValueError(f"Unknown projector type: {projector_type}")
 
 
+def _attn_type(config):
+    """u2tokenizer/builder.py:12 reads `attn_type` (default "rma").  Checkpoints written by the shipped code generation
+    (base_model_tokenizers/Llama-3.2-1B-Instruct/config.json:21, u2Tokenizer.py:86-93,422) carry the boolean `enable_rpe`
+    instead: true = RelativeMultiheadAttention ("rma"), false = nn.MultiheadAttention ("linvt").  `attn_type` wins when
+    both are present."""
+    attn_type = getattr(config, "attn_type", None)
+    if attn_type is not None:
+        return attn_type
+    enable_rpe = getattr(config, "enable_rpe", None)
+    if enable_rpe is not None:
+        return "rma" if enable_rpe else "linvt"
+    return "rma"
+
+
 def build_u2tokenizer_tower(config, **kwargs):
     return u2Tokenizer(
         embed_size=config.hidden_size,
@@ -34,7 +48,7 @@ def build_u2tokenizer_tower(config, **kwargs):
         use_multi_scale=config.use_multi_scale,
         num_3d_query_token=config.num_3d_query_token,
         hidden_size=config.hidden_size,
-        attn_type=getattr(config, "attn_type", "rma"),
+        attn_type=_attn_type(config),
         enable_diffts=config.enable_diffts,
         enable_dmtp=config.enable_dmtp,
     )

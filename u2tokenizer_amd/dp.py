@@ -68,7 +68,15 @@ class _Bucket:
         for p, o, g in zip(params, offsets, groups):
             gidx[o:o + p.numel()] = g
         self.group_idx = gidx[rank * self.piece:(rank + 1) * self.piece].to(device)
-        self.expected = len(params)   # hooks per backward that make the bucket complete (learnt: unused parameters)
+        # parameters whose hooks complete a micro-batch of this bucket.  All of them, unless a strict subset has been the set
+        # that fires -- every micro-batch, nothing else -- for 3 consecutive steps (structurally unused parameters, e.g.
+        # linear_aggregator.wv / dense of the reference, tta.py:47-48,62-65): then the bucket is launched from its hooks again.
+        self.active = frozenset(range(len(params)))
+        self.seen = (None, 0)         # (candidate subset, consecutive steps it was observed)
+        self.redo = False             # a gradient arrived after an early launch from a learnt subset: reduce again in step()
+        self.defer = False            # this step only step() launches the bucket
+        self.count = [0] * len(params)  # hooks per parameter since the last step()
+        self.got = set()              # parameters of `active` that fired in the current micro-batch
         self.ready = 0                # hooks fired in the current backward
         self.fired = 0                # hooks fired since the last step()
         self.micro = 0                # completed micro-batches since the last step()
@@ -153,9 +161,14 @@ class Zero1AdamW:
             self.state.append(dict(master=mine.clone(), m=torch.zeros_like(mine), v=torch.zeros_like(mine)))
             del flat
         # two staging buffers for the all-gathered bf16 parameters of a bucket (bucket i + 1 is updated while i is gathered)
-        big = max(b.numel for b in self.buckets)
-        b0 = self.buckets[0]
-        self._stage = [torch.empty(big, dtype=b0.flat_grad.dtype, device=b0.flat_grad.device) for _ in range(2 if self._multi else 1)]
+        # (buckets are split by dtype / device: one pair of staging buffers per kind, or an fp32 parameter behind a bf16 bucket
+        # would be rounded through bf16 on every step)
+        self._stages = {}
+        for b in self.buckets:
+            key = (b.flat_grad.dtype, b.flat_grad.device)
+            self._stages[key] = max(self._stages.get(key, 0), b.numel)
+        self._stages = {k: [torch.empty(n, dtype=k[0], device=k[1]) for _ in range(2 if self._multi else 1)]
+                        for k, n in self._stages.items()}
         self._comm_stream = None
         self._use_rs = True          # dist.reduce_scatter_tensor; falls back to all_reduce + slice where unsupported (gloo)
         self._next_launch = 0        # buckets [0, _next_launch) have their reduce-scatter in flight / done for this step
@@ -195,13 +208,25 @@ class Zero1AdamW:
                 if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
                     view.add_(p.grad)
                 p.grad = view
-            if b.launched and self._multi:
-                raise RuntimeError("Zero1AdamW: a gradient arrived after its bucket was reduced -- the set of parameters that "
-                                   "receive gradients changed between steps; construct with overlap_comm=False for such models")
-            b.ready += 1
             b.fired += 1
-            if b.ready >= b.expected:
-                b.ready = 0
+            b.count[pi] += 1
+            if pi not in b.active:
+                # a parameter that used to get no gradient got one in this backward (a data-dependent branch, e.g. a
+                # text-only batch before): forget the learnt subset.  Not launched yet: the bucket waits for step().
+                # Launched already: the reduced piece lacks this gradient -- the bucket buffer still holds every gradient
+                # (the early launch of a learnt subset never reduces in place), so step() reduces it again, after all ranks
+                # agreed on which buckets need it.
+                b.active, b.seen = frozenset(range(len(b.params))), (None, 0)
+                if b.launched and self._multi:
+                    b.redo = True
+                else:
+                    b.full, b.defer = False, True
+                return
+            if b.defer:
+                return
+            b.got.add(pi)
+            if len(b.got) == len(b.active):
+                b.got.clear()
                 b.micro += 1
                 if b.micro == self.accum:     # the last micro-batch of this optimiser step: the bucket can go
                     b.full = True
@@ -212,10 +237,10 @@ class Zero1AdamW:
     def _launch_in_order(self, flush: bool = False):
         """Launch the reduce-scatter of every bucket that is complete, strictly in bucket order (bucket i waits for buckets
         < i): all ranks issue the same collective sequence even when their hooks fire in different orders.  A bucket without
-        any used parameter (expected == 0) rides along with the next one.  flush: step() launches whatever is left."""
+        any used parameter (empty learnt subset) rides along with the next one.  flush: step() launches whatever is left."""
         while self._next_launch < len(self.buckets):
             b = self.buckets[self._next_launch]
-            if not (flush or b.full or b.expected == 0):
+            if not (flush or b.full or (not b.active and not b.defer)):
                 break
             self._launch_reduce(b)
             b.launched = True
@@ -244,10 +269,12 @@ class Zero1AdamW:
                                                   async_op=async_op)
             except (RuntimeError, NotImplementedError):
                 self._use_rs = False  # e.g. gloo: no reduce_scatter -- same result through all_reduce + this rank's slice
-        w = dist.all_reduce(b.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        # (an early launch from a LEARNT count must leave the bucket intact: a late gradient makes step() reduce it again)
+        buf = b.flat_grad.clone() if len(b.active) < len(b.params) and not b.redo else b.flat_grad
+        w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         if w is None:
-            b.my_grad.copy_(b.flat_grad[self.rank * b.piece:(self.rank + 1) * b.piece])
-        return ("allreduce", w)
+            b.my_grad.copy_(buf[self.rank * b.piece:(self.rank + 1) * b.piece])
+        return ("allreduce", w, buf)
 
     def _finish_reduce(self, b: _Bucket):
         if isinstance(b.work, torch.cuda.Event):   # the compute stream waits for THIS bucket's reduce-scatter only
@@ -255,7 +282,7 @@ class Zero1AdamW:
         elif isinstance(b.work, tuple):
             if b.work[1] is not None:
                 b.work[1].wait()
-            b.my_grad.copy_(b.flat_grad[self.rank * b.piece:(self.rank + 1) * b.piece])
+            b.my_grad.copy_(b.work[2][self.rank * b.piece:(self.rank + 1) * b.piece])
         elif b.work is not None:
             b.work.wait()
         b.work = None
@@ -295,10 +322,31 @@ class Zero1AdamW:
         # no gradient.  Learn from it: a bucket whose hooks fired the same number of times in every micro-batch will be
         # launched from its hook next time (unused parameters -- e.g. linear_aggregator.wv / dense, tta.py:47-48,62-65 --
         # no longer cost the overlap).  The set of unused parameters is structural, hence the same on every rank.
+        # A subset is only trusted after it has been the same for 3 consecutive steps, it is forgotten the moment any other
+        # hook fires (the hook above), and an early launch that turns out premature is repaired below.
+        learnt = False
         for b in self.buckets:
-            if not b.full and b.fired % self.accum == 0 and b.fired // self.accum < len(b.params):
-                b.expected = b.fired // self.accum
+            fired = frozenset(i for i, c in enumerate(b.count) if c)
+            clean = all(c in (0, self.accum) for c in b.count) and not b.redo and not b.defer
+            if clean and fired != b.active and len(fired) < len(b.params):
+                b.seen = (fired, b.seen[1] + 1) if b.seen[0] == fired else (fired, 1)
+                if b.seen[1] >= 3:
+                    b.active = fired
+            elif not (clean and fired == b.active):
+                b.seen = (None, 0)
+            learnt = learnt or len(b.active) < len(b.params) or b.redo
         self._launch_in_order(flush=True)
+        if learnt and self._multi:
+            # which early launches were premature?  One tiny MAX-reduction, so that every rank repeats the same reduces in
+            # the same order even if only one of them saw the late gradient.
+            flags = torch.tensor([1.0 if b.redo else 0.0 for b in self.buckets], device=self.buckets[0].flat_grad.device)
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
+            for b, f in zip(self.buckets, flags.tolist()):
+                if f:
+                    b.redo = True
+                    b.active, b.seen = frozenset(range(len(b.params))), (None, 0)
+                    self._finish_reduce(b)
+                    self._launch_reduce(b)
         coef = None
         if self.max_grad_norm is not None:
             for b in self.buckets:
@@ -315,18 +363,20 @@ class Zero1AdamW:
         dev = self.buckets[0].flat_grad.device
         if cuda and self._multi and self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(device=dev)
-        stage_free = [None] * len(self._stage)
+        nst = 2 if self._multi else 1
+        stage_free = {k: [None] * nst for k in self._stages}
         for i, (b, st) in enumerate(zip(self.buckets, self.state)):
             self._finish_reduce(b)
-            stage = self._stage[i % len(self._stage)]
+            skey = (b.flat_grad.dtype, b.flat_grad.device)
+            stage = self._stages[skey][i % nst]
             if not self._multi:
                 self._update_piece(b, st, stage[:b.numel], coef)
                 self._copy_out(b, stage)
             elif cuda:
                 cur = torch.cuda.current_stream(dev)
-                si = i % len(self._stage)
-                if stage_free[si] is not None:
-                    cur.wait_event(stage_free[si])          # bucket i - 2 has been copied out of this staging buffer
+                si = i % nst
+                if stage_free[skey][si] is not None:
+                    cur.wait_event(stage_free[skey][si])    # the last user of this staging buffer has been copied out
                 mine = stage[self.rank * b.piece:(self.rank + 1) * b.piece]
                 self._update_piece(b, st, mine, coef)
                 updated = torch.cuda.Event()
@@ -335,8 +385,8 @@ class Zero1AdamW:
                     self._comm_stream.wait_event(updated)
                     dist.all_gather_into_tensor(stage[:b.numel], mine, group=self.group)
                     self._copy_out(b, stage)
-                    stage_free[si] = torch.cuda.Event()
-                    stage_free[si].record(self._comm_stream)
+                    stage_free[skey][si] = torch.cuda.Event()
+                    stage_free[skey][si].record(self._comm_stream)
             else:
                 mine = stage[self.rank * b.piece:(self.rank + 1) * b.piece]
                 self._update_piece(b, st, mine, coef)
@@ -348,7 +398,9 @@ class Zero1AdamW:
         for b in self.buckets:
             b.flat_grad.zero_()
             b.ready = b.fired = b.micro = 0
-            b.full = b.launched = False
+            b.full = b.launched = b.redo = b.defer = False
+            b.count = [0] * len(b.params)
+            b.got.clear()
         self._next_launch = 0
         self._install_grad_views()
 
@@ -371,7 +423,9 @@ class Zero1AdamW:
                 self._finish_reduce(b)
             b.flat_grad.zero_()
             b.ready = b.fired = b.micro = 0
-            b.full = b.launched = False
+            b.full = b.launched = b.redo = b.defer = False
+            b.count = [0] * len(b.params)
+            b.got.clear()
         self._next_launch = 0
         self._install_grad_views()
 
@@ -397,7 +451,7 @@ class Zero1AdamW:
                 for k in ("master", "m", "v"):
                     st[k].copy_(src[k])
                 # the bf16 parameters follow the restored master weights (this rank's piece; the others arrive by all-gather)
-                stage = self._stage[0]
+                stage = self._stages[(b.flat_grad.dtype, b.flat_grad.device)][0]
                 mine = stage[self.rank * b.piece:(self.rank + 1) * b.piece]
                 mine.copy_(st["master"])
                 if self._multi:

@@ -66,14 +66,38 @@ def _ensure_gemm_scratch(device) -> None:
         _scratch[key] = buf
 
 
+_HOOK_TABLES = ("_forward_hooks", "_forward_pre_hooks", "_backward_hooks", "_backward_pre_hooks")
+
+
+def _is_stock(layer) -> bool:
+    """The fused forwards read the projections' `.weight` / `.bias` and never CALL the submodules.  That is only the same
+    computation while every projection is exactly torch.nn.Linear and nothing hangs on the modules that are skipped: a
+    peft lora.Linear exposes `.weight` as its BASE weight (the reference trains the decoder with LoRA, train_stage1.py:342-353:
+    an unmerged adapter would be silently ignored), forward hooks (output_attentions recorders, activation probes) would not
+    fire.  Checked on every call: adapters and hooks come and go after enable_fused_prefill."""
+    att, mlp = layer.self_attn, layer.mlp
+    for m in (att.q_proj, att.k_proj, att.v_proj, att.o_proj, mlp.gate_proj, mlp.up_proj, mlp.down_proj):
+        if type(m) is not torch.nn.Linear:
+            return False
+    for m in (att.q_proj, att.k_proj, att.v_proj, att.o_proj, mlp.gate_proj, mlp.up_proj, mlp.down_proj, att, mlp,
+              layer.input_layernorm, layer.post_attention_layernorm):
+        for t in _HOOK_TABLES:
+            if getattr(m, t, None):
+                return False
+    return True
+
+
 def _layer_forward(self, hidden_states, *args, **kwargs):
     st = self._u2_prefill
     x = hidden_states
     pe = kwargs.get("position_embeddings")
     cache = kwargs.get("past_key_values")
     att = self.self_attn
-    common = (not args and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 3
-              and pe is not None and st["owner"]._u2_prefill_mask_ok
+    # `past_key_value` (singular) is the layer protocol of transformers 4.46 .. 4.5x, whose layers also return tuples: never
+    # patched (enable_fused_prefill checks the signature), and a caller that passes it anyway gets the stock layer
+    common = (not args and "past_key_value" not in kwargs and not kwargs.get("output_attentions")
+              and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 3
+              and pe is not None and st["owner"]._u2_prefill_mask_ok and _is_stock(self)
               and getattr(att, "sliding_window", None) is None and att.head_dim in (64, 128))
     if common and x.shape[1] == 1 and x.shape[0] <= 16 and st["owner"]._u2_fused_decode \
             and _plain_dynamic_layer(cache, att.layer_idx) is not None:
@@ -331,6 +355,32 @@ def _mask_hook(module, args, kwargs):
     return None
 
 
+_warned_protocol = [False]
+
+
+def _layer_protocol_ok(layer) -> bool:
+    """_layer_forward is written against the decoder-layer protocol of transformers >= 4.56 / 5.x: the cache arrives as the
+    keyword `past_key_values`, rotary tables as `position_embeddings`, and the layer returns the hidden-state TENSOR.  From
+    4.46 (the reference's pin) up to that change the keyword is `past_key_value` and layers return tuples: there the cache
+    would never be updated and `layer_outputs[0]` would slice the batch.  Such layers are left stock."""
+    import inspect
+    import warnings
+    try:
+        sig = inspect.signature(layer.forward)
+        ok = "past_key_values" in sig.parameters and "position_embeddings" in sig.parameters
+        ret = sig.return_annotation
+        if ok and ret is not inspect.Signature.empty and "tuple" in str(ret).lower():
+            ok = False
+    except (TypeError, ValueError):
+        ok = False
+    if not ok and not _warned_protocol[0]:
+        _warned_protocol[0] = True
+        import transformers
+        warnings.warn(f"u2tokenizer_amd.prefill: decoder layer protocol of transformers {transformers.__version__} is not the one "
+                      "the fused prefill is written for (past_key_values keyword, tensor return); layers stay stock")
+    return ok
+
+
 def enable_fused_prefill(model, decode: bool = True) -> int:
     """Patch the decoder layers of an HF Llama / Qwen3 causal LM (u2LlamaForCausalLM / u2Qwen3ForCausalLM included) for the
     fused prefill and (decode=True) the fused decode step.  Idempotent; returns the number of layers patched.
@@ -348,6 +398,8 @@ def enable_fused_prefill(model, decode: bool = True) -> int:
             all(hasattr(layer.mlp, a) for a in ("gate_proj", "up_proj", "down_proj"))
         if not needed:
             raise RuntimeError(f"enable_fused_prefill: unsupported decoder layer {type(layer).__name__}")
+        if not _layer_protocol_ok(layer):
+            continue
         layer._u2_prefill = {"orig": layer.forward, "owner": base}
         layer.forward = types.MethodType(_layer_forward, layer)
         n += 1

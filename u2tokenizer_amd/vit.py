@@ -47,6 +47,18 @@ class PatchEmbeddingBlock(nn.Module):
         nn.init.trunc_normal_(self.position_embeddings, mean=0.0, std=0.02, a=-2.0, b=2.0)
         nn.init.trunc_normal_(self.patch_embeddings[1].weight, mean=0.0, std=0.02, a=-2.0, b=2.0)
         nn.init.zeros_(self.patch_embeddings[1].bias)
+        # MONAI releases up to 1.3.x also register a `cls_token` parameter on this block that nothing reads, so a
+        # `pretrained_ViT.bin` written with one of them carries `patch_embedding.cls_token`; later releases do not.  The strict
+        # load of u2_arch.py:64-66 has to pass either way: the key is adopted when a checkpoint has it (and then written back by
+        # state_dict(), so a re-save is lossless) and absent otherwise.
+        self._register_load_state_dict_pre_hook(self._adopt_unused_cls_token)
+
+    def _adopt_unused_cls_token(self, state_dict, prefix, *_):
+        key = prefix + "cls_token"
+        if key in state_dict and not hasattr(self, "cls_token"):
+            ref = self.position_embeddings
+            self.cls_token = nn.Parameter(torch.zeros(tuple(state_dict[key].shape), dtype=ref.dtype, device=ref.device),
+                                          requires_grad=False)
 
 
 class SABlock(nn.Module):
@@ -177,10 +189,29 @@ class ViT3DTower(nn.Module):
         self._feat_cache = None
 
     def _frozen_key(self):
+        """What the cached features depend on besides the images: every parameter's storage and version counter.  Writes
+        through `.data` do not bump version counters (an optimiser's copy-out, `p.data.copy_`): the paths that do that to a
+        whole model -- _apply (.to / .cuda / .bfloat16), load_state_dict, train() -- drop the cache explicitly, and
+        `invalidate_feature_cache()` is there for anything else that rewrites frozen weights in place."""
         ps = list(self.parameters())
         if any(p.requires_grad for p in ps):
             return None
-        return (self.select_feature, sum(p._version for p in ps), ps[0].data_ptr(), ps[0].device)
+        return (self.select_feature, tuple((p.data_ptr(), p._version) for p in ps), ps[0].device)
+
+    def invalidate_feature_cache(self) -> None:
+        self._feat_cache = None
+
+    def _apply(self, fn, *args, **kwargs):
+        self._feat_cache = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._feat_cache = None
+        return super().load_state_dict(*args, **kwargs)
+
+    def train(self, mode: bool = True):
+        self._feat_cache = None
+        return super().train(mode)
 
     def forward(self, images):
         if self.select_layer != -1:
@@ -192,7 +223,7 @@ class ViT3DTower(nn.Module):
             k0, img0, out0 = self._feat_cache
             if k0 == key and img0.shape == images.shape and img0.dtype == images.dtype and img0.device == images.device \
                     and torch.equal(img0, images):
-                return out0
+                return out0.clone()   # (both models get their own tensor: an in-place op downstream cannot reach the cache)
         out = self.vision_tower.forward_features(images, keep_cls=self.select_feature == "cls_patch")
         if key is not None:
             self._feat_cache = (key, images.detach().clone(), out)
