@@ -578,8 +578,18 @@ def main():
                                     "calls per volume; rocprofv3 --pmc, separate passes of this command; fabric-side "
                                     "requests (Infinity Cache hits included)")
 
-        # per-kernel table from the profiler's clock (one rocprofv3 --kernel-trace --stats child of this command)
-        ktab = measure_kernels(E, args.option) if (B == 1 and world == 1 and not args.no_traffic) else None
+        # per-kernel table from the profiler's clock (one rocprofv3 --kernel-trace --stats child of this command), and the wall
+        # time it has to fit into.  Both with the tokenizer's side stream OFF: one volume, one stream, every kernel behind
+        # the previous one -- the sum of kernel times then cannot exceed the wall, with no allowance for overlap.
+        serial_opts = [o for o in args.option if not o.startswith("tta_overlap=")] + ["tta_overlap=0"]
+        ktab = measure_kernels(E, serial_opts) if (B == 1 and world == 1 and not args.no_traffic) else None
+        wall_serial = None
+        if ktab:
+            ops.set_option("profile", 0)
+            ops.set_option("tta_overlap", 0)
+            t2, _ = timed_repeats(lambda i: step(i, multi=False), args.steps, args.warmup, 2, sync, rmax)
+            ops.set_option("tta_overlap", 1)
+            wall_serial = statistics.median(t2)
         cls_key = ["gemm_bf16", "flash_d64", "temporal_attention", "row_ops", "data_movement", "tok_attention"]
         kt_ms = {}
         if ktab:
@@ -591,9 +601,10 @@ def main():
                               "launches_per_volume": round(calls, 2), "avg_us": round(us, 2),
                               "ms_per_volume": round(calls * us / 1e3, 4)})
             total_ms = sum(kt_ms.values())
-            wall_ms = 1e3 * (single if single else elapsed) / args.steps
+            wall_ms = 1e3 * wall_serial / args.steps
             line["kernel_table"] = {
-                "source": "rocprofv3 --kernel-trace --stats child of this command: 7 volumes, one stream, no counters",
+                "source": "rocprofv3 --kernel-trace --stats child of this command: 7 volumes, one stream, tokenizer side stream "
+                          "off (tta_overlap=0), no counters",
                 "kernels": table[:24],
                 "classes": {k: {"ms_per_volume": round(v, 4),
                                 "tflops": (round(flops[cls_key.index(k)] / nprof / v / 1e9, 1)
@@ -601,12 +612,10 @@ def main():
                                 "frac_of_bf16_mfma_peak": (round(flops[cls_key.index(k)] / nprof / v / 1e9 / PEAK_BF16_TFLOPS, 4)
                                                            if k in cls_key and flops[cls_key.index(k)] > 0 and v > 0 else None)}
                             for k, v in sorted(kt_ms.items(), key=lambda kv: -kv[1])},
-                "sum_ms_per_volume": round(total_ms, 4), "one_stream_wall_ms_per_volume": round(wall_ms, 4),
-                # kernels of one volume on one stream cannot add up to more than its wall time, except for what the tokenizer's
-                # side stream overlaps: the 9 k|v / key projections of the TTA (~1.0 ms of GEMM time per volume) run beside the
-                # query chain in the one-stream run -- the bookkeeping check allows for exactly that
-                "side_stream_overlap_ms_allowed": 1.2,
-                "sum_le_wall": bool(total_ms <= 1.03 * wall_ms + 1.2)}
+                "sum_ms_per_volume": round(total_ms, 4), "one_stream_serial_wall_ms_per_volume": round(wall_ms, 4),
+                # kernels of one volume issued one behind the other on one stream cannot add up to more than its wall time
+                # (3 %: the profiled child is another process on a clock of its own)
+                "sum_le_wall": bool(total_ms <= 1.03 * wall_ms)}
 
         def roof(idx, key, kernel):
             ach_ev = flops[idx] / ms[idx] / 1e9

@@ -168,6 +168,23 @@ def test_hf_surface_and_early_outs():
                                                num_hidden_layers=1, num_attention_heads=4, num_key_value_heads=2,
                                                head_dim=16))
     assert q.get_vision_tower() is None
+    # the third surface of the reference (language_model/u2phi3.py:25-140, train_stage1.py:290-296)
+    pc = LM.u2Phi3Config(vocab_size=64, hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=4,
+                         num_key_value_heads=2, pad_token_id=0, bos_token_id=1, eos_token_id=2)
+    for k, v in c["mm"].items():
+        if k != "hidden_size":
+            setattr(pc, k, v)
+    ph = LM.u2Phi3ForCausalLM(pc).eval()
+    assert isinstance(AutoConfig.for_model("u2phi3"), LM.u2Phi3Config) and ph.get_model() is ph.model
+    with torch.no_grad():
+        assert ph(input_ids=ids % 64).logits.shape == (1, 12, 64)
+    r = ph.prepare_inputs_for_multimodal(ids, None, None, None, None, None, None)
+    assert r[0] is ids and r[4] is None
+    # its decoder layers have another layout (qkv_proj / gate_up_proj): the fused prefill declines them instead of raising
+    from u2tokenizer_amd.prefill import enable_fused_prefill
+    assert enable_fused_prefill(ph, strict=False) == 0
+    with pytest.raises(RuntimeError, match="unsupported decoder layer"):
+        enable_fused_prefill(ph)
 
 
 def test_packed_weight_alias_is_a_view_and_routes_gradients():

@@ -69,6 +69,24 @@ SLO, SHI = 36, 59 if TIMED else 45
 
 out = []
 uid = [0]
+inflight = []   # fragment tuples whose ds_read has been issued and not yet waited for, oldest first (LDS returns in order)
+
+
+def lds_read(text, tup):
+    e(text)
+    inflight.append(tup)
+
+
+def lds_wait_for(tup):
+    """s_waitcnt lgkmcnt(N) with the largest N that still guarantees the read into tuple `tup` has landed"""
+    if tup in inflight:
+        n = len(inflight) - 1 - max(i for i, t in enumerate(inflight) if t == tup)
+        e(f"s_waitcnt lgkmcnt({n})")
+        del inflight[:len(inflight) - n]
+
+
+def lds_drained():
+    del inflight[:]
 
 
 def e(s):
@@ -105,6 +123,7 @@ def stamp(i):
         return
     e(f"s_memtime s[{S_NOW}:{S_NOW + 1}]")
     e("s_waitcnt lgkmcnt(0)")
+    lds_drained()
     if i is not None:
         a = S_ACC + 2 * i
         e(f"s_sub_u32 {s(S_A)}, {s(S_NOW)}, {s(S_PREV)}")
@@ -148,12 +167,15 @@ def issue(slot, label):
         e(f".Lfd2_noissue_{label}_%=:")
 
 
-def phase(x, do_q, do_p, do_s, koff, voff, vh, first=False, dyn_v=False, reuse=False, dma=None):
+def phase(x, do_q, do_p, do_s, koff, voff, vh, first=False, dyn_v=False, reuse=False, dma=None, prefetch=None,
+          pre_done=False):
     """MFMAs of block x interleaved with the softmax of block y = 1 - x.
     koff / voff: immediate LDS offsets of the K half tile (32 rows) and of the V^T tile; vh: key half of the V^T tile.
     first: the Q K^T chain starts from 0 (prologue: no running max yet).  dyn_v: V^T tile address = S_AV (epilogue).
     reuse: the fragments are in their tuples already (SHARE: the other block's phase read them).  dma: ring slot whose
-    4 LDS-DMA pieces (tile S_ISSUE, made harmless past the last tile) go out from slots 1 / 3 / 5 / 7."""
+    4 LDS-DMA pieces (tile S_ISSUE, made harmless past the last tile) go out from slots 1 / 3 / 5 / 7.
+    prefetch = (koff, voff, vh) of the NEXT reading phase: its first PF fragment reads go out from slots 5 / 6 / 7 of this
+    (reusing) phase, whose tuples 0 .. PF-1 are free by then; that phase is then generated with pre_done."""
     y = 1 - x
     nm = (4 if do_q else 0) + (4 if do_p else 0)
 
@@ -165,18 +187,19 @@ def phase(x, do_q, do_p, do_s, koff, voff, vh, first=False, dyn_v=False, reuse=F
 
     def read(i):
         k = idx(i)
-        fr = vr(FR + 4 * (i % NFR), 4)
+        tup = i % NFR
+        fr = vr(FR + 4 * tup, 4)
         if reuse:
             return
         if is_q(i):
-            e(f"ds_read_b128 {fr}, {v(AB[k])} offset:{koff}")
+            lds_read(f"ds_read_b128 {fr}, {v(AB[k])} offset:{koff}", tup)
         else:
             base = AB[vh * 2 + (k >> 1)]
             if dyn_v:
                 e(f"v_add_u32 {v(ADR)}, {s(S_AV)}, {v(base)}")
-                e(f"ds_read_b128 {fr}, {v(ADR)} offset:{4096 * (k & 1)}")
+                lds_read(f"ds_read_b128 {fr}, {v(ADR)} offset:{4096 * (k & 1)}", tup)
             else:
-                e(f"ds_read_b128 {fr}, {v(base)} offset:{voff + 4096 * (k & 1)}")
+                lds_read(f"ds_read_b128 {fr}, {v(base)} offset:{voff + 4096 * (k & 1)}", tup)
 
     def finish_pair(i):
         """row-sum adds and the pack of score pair i (its exponentials were issued one slot earlier)"""
@@ -208,8 +231,9 @@ def phase(x, do_q, do_p, do_s, koff, voff, vh, first=False, dyn_v=False, reuse=F
         e(f"s_add_u32 {s(S_ISSUE)}, {s(S_ISSUE)}, 1")
         pieces = [(0, "%[ko0]", "%[rsk]", S_KOFF), (1024, "%[ko1]", "%[rsk]", S_KOFF),
                   (8192, "%[vo0]", "%[rsv]", S_VOFF), (9216, "%[vo1]", "%[rsv]", S_VOFF)]
-    for i in range(min(PF, nm)):
-        read(i)
+    if not pre_done:
+        for i in range(min(PF, nm)):
+            read(i)
     if do_s:
         scale_pair(0)
     def mfma(i):
@@ -234,13 +258,20 @@ def phase(x, do_q, do_p, do_s, koff, voff, vh, first=False, dyn_v=False, reuse=F
             e(f"v_exp_f32 {v(t0)}, {v(SC[y] + 2 * i)}")
             e(f"v_exp_f32 {v(t1)}, {v(SC[y] + 2 * i + 1)}")
         if i < nm and not reuse:
-            outstanding = min(PF - 1, nm - 1 - i)
-            e(f"s_waitcnt lgkmcnt({outstanding})")
+            lds_wait_for(i % NFR)
             mfma(i)
             if i + PF < nm:
                 read(i + PF)
         if piece:
             e(f"buffer_load_dwordx4 {piece[1]}, {piece[2]}, {s(piece[3])} offen lds")
+        if prefetch is not None and i >= 8 - PF:
+            j = i - (8 - PF)                    # read j of a full phase: even = K fragment j / 2, odd = V^T fragment j / 2
+            fr = vr(FR + 4 * (j % NFR), 4)
+            if j % 2 == 0:
+                lds_read(f"ds_read_b128 {fr}, {v(AB[j // 2])} offset:{prefetch[0]}", j % NFR)
+            else:
+                kk = j // 2
+                lds_read(f"ds_read_b128 {fr}, {v(AB[prefetch[2] * 2 + (kk >> 1)])} offset:{prefetch[1] + 4096 * (kk & 1)}", j % NFR)
         if do_s and i < 7:
             scale_pair(i + 1)
         if do_s and i > 0:
@@ -289,13 +320,57 @@ def row_max(sc):
     e(f"v_max_f32 {v(MX)}, {v(MX)}, {v(TM)}")
 
 
+VX = MNEG[1]   # prologue only: v^T of the extra key as 16 packed bf16 pairs, parked in block 1's C tuple until that is filled
+KX = SC[1]     # prologue only: the lane's 4 x 16 bytes of the extra key (dead before block 1's first Q K^T)
+SX = [PFR[1], PFR[1] + 1]   # prologue only: the extra key's score for the lane's row of block 0 / 1 (block 1's P comes later)
+
+
+def extra_scores():
+    """score of the extra key against the lane's two query rows, on the matrix pipe: a "K tile" whose 32 rows are all the
+    extra key (every lane holds the same 4 x 16 bytes of it, its half-wave's share of the head dim) times Q^T leaves the
+    score of query l31 in EVERY accumulator register of both half-waves: 4 MFMAs per block, no cross-lane step.
+    -inf when the call has no extra key (%[xflag] = 0)."""
+    e(f"v_mov_b32 {v(SX[0])}, 0xff800000")
+    e(f"v_mov_b32 {v(SX[1])}, 0xff800000")
+    e("s_cmp_eq_u32 %[xflag], 0")
+    e("s_cbranch_scc1 .Lfd2_nox_%=")
+    e("s_waitcnt vmcnt(12)")             # the 8 + 4 loads of the extra key are older than the 12 LDS-DMA pieces
+    for b in range(2):
+        acc = vr(SC[0], 16)
+        for ks in range(4):
+            e(f"v_mfma_f32_32x32x16_bf16 {acc}, {vr(KX + 4 * ks, 4)}, {qf(b, ks)}, {acc if ks else '0'}")
+        e("s_nop 15")
+        e("s_nop 3")
+        e(f"v_mov_b32 {v(SX[b])}, {v(SC[0])}")
+    e(".Lfd2_nox_%=:")
+
+
 def init_max(x):
-    """prologue: running max of block x := true row max of its first 32 keys; scores and C tuple follow"""
+    """prologue: running max of block x := the larger of the true row max of its first 32 keys and the EXTRA key's score
+    (%[sx]: -inf when the call has no extra key; raw units in the EXACT loop).  The extra key also opens the running sums:
+    l = p / 2 (both half-waves carry it), O^T = p v -- what the C++ epilogue did after the loop, behind three rounds of
+    global loads on the unit's critical path; here the loads fly while the first tiles arrive.  Scores and C tuple follow."""
     row_max(SC[x])
+    e(f"v_max_f32 {v(MX)}, {v(MX)}, {v(SX[x])}")
     if EXACT:
         e(f"v_mul_f32 {m_run(x)}, %[scale], {v(MX)}")     # m_run in exp2 units, MNEG and the fresh scores raw
     else:
         e(f"v_mov_b32 {m_run(x)}, {v(MX)}")
+    e(f"v_sub_f32 {v(TN)}, {v(SX[x])}, {v(MX)}")
+    if EXACT:
+        e(f"v_mul_f32 {v(TN)}, %[scale], {v(TN)}")
+    e(f"v_exp_f32 {v(TN)}, {v(TN)}")                       # p of the extra key (0 without one)
+    e("s_nop 0")
+    e(f"v_mul_f32 {l_run(x)}, 0.5, {v(TN)}")
+    for nb in range(2):
+        for g in range(4):
+            for w in range(2):
+                src = VX + nb * 8 + g * 2 + w               # d = 32 nb + 8 g + 4 hi + 2 w + {0, 1}
+                r = 4 * g + 2 * w
+                e(f"v_lshlrev_b32 {v(TM)}, 16, {v(src)}")
+                e(f"v_mul_f32 {v(O[(x, nb)] + r)}, {v(TN)}, {v(TM)}")
+                e(f"v_and_b32 {v(TM)}, 0xffff0000, {v(src)}")
+                e(f"v_mul_f32 {v(O[(x, nb)] + r + 1)}, {v(TN)}, {v(TM)}")
     for r in range(16):
         e(f"v_sub_f32 {v(MNEG[x] + r)}, 0, {v(MX)}")
     for r in range(16):
@@ -359,16 +434,19 @@ def gen():
     e(f"v_add_u32 {v(AB[0])}, %[lds], %[ab0]")
     for k in (1, 2, 3):
         e(f"v_xor_b32 {v(AB[k])}, {32 * k}, {v(AB[0])}")  # kt_off: chunk ^= 2k (the LDS base is 128-byte aligned)
-    for key in O:
-        for r in range(16):
-            e(f"v_mov_b32 {v(O[key] + r)}, 0")
-    for b in range(2):
-        e(f"v_mov_b32 {l_run(b)}, 0")
+    # v of the extra key for this lane's 32 output columns (the prologue's first vmcnt wait covers these 8 loads: they are
+    # older than every LDS-DMA piece); O^T and l are opened by init_max
+    for nb in range(2):
+        for g in range(4):
+            e(f"global_load_dwordx2 {vr(VX + nb * 8 + g * 2, 2)}, %[vxa], off offset:{nb * 64 + g * 16}")
+    for ks in range(4):
+        e(f"global_load_dwordx4 {vr(KX + 4 * ks, 4)}, %[kxa], off offset:{ks * 32}")
     e(f"s_mov_b32 {s(S_T)}, 0")
     e(f"s_mov_b32 {s(S_ISSUE)}, 0")
     # ---- prologue DMA, wait for tile 0
     for i in range(AHEAD):
         issue(i, f"pro{i}")
+    extra_scores()
     if DMAPH:
         e("s_waitcnt vmcnt(8)")
     else:
@@ -390,7 +468,8 @@ def gen():
     phase(0, True, False, False, 0, 0, 0, first=True)
     mask_call(0)
     init_max(0)
-    phase(1, True, False, True, 0, 0, 0, first=True, reuse=SHARE)
+    PRE = SHARE and "--no-prefetch" not in sys.argv
+    phase(1, True, False, True, 0, 0, 0, first=True, reuse=SHARE, prefetch=(4096, 8192, 0) if PRE else None)
     mask_call(1)
     init_max(1)
     # ---- tile loop, unrolled over the ring slots
@@ -407,7 +486,7 @@ def gen():
         e(f"s_lshl_b32 {s(S_A)}, {s(S_T)}, 6")
         e(f"s_sub_i32 {s(S_NV)}, %[seq], {s(S_A)}")
         e(f"s_sub_i32 {s(S_NV)}, {s(S_NV)}, 32")
-        phase(0, True, True, True, base + 4096, base + 8192, 0)
+        phase(0, True, True, True, base + 4096, base + 8192, 0, pre_done=PRE)
         mask_call(0)
         phase(1, True, True, True, base + 4096, base + 8192, 0, reuse=SHARE)
         mask_call(1)
@@ -438,17 +517,20 @@ def gen():
         # K rows 0..31 of tile t+1 (next slot); V^T tile t, keys 32..63 (vh = 1)
         phase(0, True, True, True, nxt, base + 8192, 1, dma=(j + AHEAD) % NSLOT if DMAPH else None)
         mask_call(0)
-        phase(1, True, True, True, nxt, base + 8192, 1, reuse=SHARE)
+        # (its spare slots carry the first fragment reads of the next tile's first phase: no barrier in between)
+        phase(1, True, True, True, nxt, base + 8192, 1, reuse=SHARE, prefetch=(nxt + 4096, nxt + 8192, 0) if PRE else None)
         mask_call(1)
         stamp(4)
         e(f"s_add_u32 {s(S_T)}, {s(S_T)}, 1")
     e("s_branch .Lfd2_loop_%=")
     # ---- epilogue: the last half (tile ntile-1, keys 32..63): its V^T tile is at LDS offset S_AV
     e(".Lfd2_epi_%=:")
+    lds_drained()   # (entered from behind a reusing phase: nothing in flight, whatever the last generated body left)
     phase(0, False, True, True, 0, 0, 1, dyn_v=True)
     phase(1, False, True, False, 0, 0, 1, dyn_v=True, reuse=SHARE)
     # ---- leave O^T in LDS: all waves are done with the ring first (and no LDS-DMA piece is still on its way)
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    lds_drained()
     e("s_barrier")
     q = 0
     for key in [(0, 0), (0, 1), (1, 0), (1, 1)]:

@@ -594,9 +594,10 @@ struct FdpBlock {       // final state of one 32-row query block of a wave
 
 // the extra key (one per batch) and the output of one block
 __device__ __forceinline__ void fdp_finish(const FlashArgs& a, FdpBlock& x, const bf16x8 (&qfx)[4], const int b, const int h,
-                                           const int qrow, const int hi, const bool q_prescaled = false) {
+                                           const int qrow, const int hi, const bool q_prescaled = false,
+                                           const bool extra_done = false) {
   const float scale_log2e = q_prescaled ? 1.0f : a.scale_log2e;  // mode 7 carries scale * log2 e in its Q fragments
-  if (a.n_extra) {
+  if (a.n_extra && !extra_done) {  // (the round-4 loop opens its running sums with the extra key: extra_done)
     const bf16_t* kxp = a.kx + (int64_t)b * a.x_bs + h * 64 + hi * 8;
     const bf16_t* vxp = a.vx + (int64_t)b * a.x_bs + h * 64 + 4 * hi;
     float part = 0.f;
@@ -872,6 +873,11 @@ __global__ __launch_bounds__(256, 2) void flash_dp2_kernel(const FlashArgs a) {
   const uint32_t dump = lds_u32 + wv * 16384 + lane * 16;
   const int hi4 = 4 * hi;
   const float scale_log2e = a.scale_log2e, rscale = 1.0f / a.scale_log2e;
+  // the extra key (one per batch): the block loads the lane's share of it (k: 4 x 16 bytes at 32-byte steps from kxa, v: 8 x 8
+  // bytes at 16-byte steps from vxa) and opens its running sums with it; without one the pointers only have to be readable
+  const bf16_t* kxa = a.n_extra ? a.kx + (int64_t)b * a.x_bs + h * 64 + hi * 8 : a.q;
+  const bf16_t* vxa = a.n_extra ? a.vx + (int64_t)b * a.x_bs + h * 64 + 4 * hi : a.q;
+  const int xflag = a.n_extra;
   float mr0, lr0, mr1, lr1;
   int lane2;  // the lane id as the block returns it: keeps the epilogue's per-lane values from living across the block
   unsigned long long* dbg = g_flash_dbg + ((size_t)blockIdx.x * 4 + wv) * 8;  // TIMED: 5 section times, [7] = tiles
@@ -882,7 +888,7 @@ __global__ __launch_bounds__(256, 2) void flash_dp2_kernel(const FlashArgs a) {
                  [ab0] "v"(ab0), [ko0] "v"(ko0), [ko1] "v"(ko1), [vo0] "v"(vo0), [vo1] "v"(vo1), [hi4] "v"(hi4),        \
                  [dump] "v"(dump), [rsk] "s"(rsk), [rsv] "s"(rsv), [lds] "s"(lds_u32), [dma_base] "s"(dma_base),        \
                  [ktile] "s"(k_tile_bytes), [seq] "s"(S), [ntile] "s"(ntile), [dbg] "v"(dbg),                           \
-                 [scale] "s"(scale_log2e), [rscale] "s"(rscale)
+                 [scale] "s"(scale_log2e), [rscale] "s"(rscale), [kxa] "v"(kxa), [vxa] "v"(vxa), [xflag] "s"(xflag)
 #define FDP2_RUN(SFX_) asm volatile(FLASH_DP2_ASM_TEXT##SFX_ FDP2_OPERANDS : FLASH_DP2_ASM_CLOBBERS##SFX_)
   if constexpr (TIMED) {
     if (lane == 0) tl[1] = __builtin_amdgcn_s_memrealtime();
@@ -908,17 +914,7 @@ __global__ __launch_bounds__(256, 2) void flash_dp2_kernel(const FlashArgs a) {
       }
     x.m_run = blk ? mr1 : mr0;
     x.l_run = blk ? lr1 : lr0;
-    // the Q fragments again for the extra key's scores (cheap; kept live they were spilled around the block)
-    bf16x8 qfx[4];
-    if (a.n_extra) {
-      const bf16_t* qp = qb_ + (int64_t)min(wrow0 + blk * 32 + l31b, S - 1) * ld_qk + hi2 * 8;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        qfx[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
-        if constexpr (QMODE == 2) qfx[ks] = fdp2_prescale(qfx[ks], a.scale_log2e);
-      }
-    }
-    fdp_finish(a, x, qfx, b, h, wrow0 + 32 * blk + l31b, hi2, QMODE != 0);
+    fdp_finish(a, x, qf[blk], b, h, wrow0 + 32 * blk + l31b, hi2, QMODE != 0, true);
   }
   if constexpr (TIMED) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -1,4 +1,4 @@
-"""HuggingFace surface (drop-in for /root/reference/src/model/language_model/{u2llama,u2qwen3}.py).
+"""HuggingFace surface (drop-in for /root/reference/src/model/language_model/{u2llama,u2qwen3,u2phi3}.py).
 
 `forward(images, input_ids, labels, attention_mask, question_ids, ...)` and
 `generate(images, inputs, question_ids=..., **kwargs)` keep the reference's call shapes
@@ -11,8 +11,8 @@ from typing import Any, List, Optional, Tuple, Union
 
 import torch
 import torch.nn as nn
-from transformers import (AutoConfig, AutoModelForCausalLM, LlamaConfig, LlamaForCausalLM, LlamaModel, Qwen3Config,
-                          Qwen3ForCausalLM, Qwen3Model)
+from transformers import (AutoConfig, AutoModelForCausalLM, LlamaConfig, LlamaForCausalLM, LlamaModel, Phi3Config,
+                          Phi3ForCausalLM, Phi3Model, Qwen3Config, Qwen3ForCausalLM, Qwen3Model)
 from transformers.modeling_outputs import CausalLMOutputWithPast
 
 from .arch import u2MetaForCausalLM, u2MetaModel
@@ -24,6 +24,10 @@ class u2Config(LlamaConfig):
 
 class u2Qwen3Config(Qwen3Config):
     model_type = "u2Qwen3"
+
+
+class u2Phi3Config(Phi3Config):
+    model_type = "u2phi3"
 
 
 class u2LlamaModel(u2MetaModel, LlamaModel):
@@ -40,8 +44,15 @@ class u2Qwen3Model(u2MetaModel, Qwen3Model):
         super(u2Qwen3Model, self).__init__(config)
 
 
+class u2Phi3Model(u2MetaModel, Phi3Model):
+    config_class = u2Phi3Config
+
+    def __init__(self, config: Phi3Config):
+        super(u2Phi3Model, self).__init__(config)
+
+
 class _u2CausalLMMixin(u2MetaForCausalLM):
-    """forward / generate / prepare_inputs_for_generation shared by the Llama and Qwen3 builds."""
+    """forward / generate / prepare_inputs_for_generation shared by the Llama, Qwen3 and Phi3 builds."""
 
     def get_model(self):
         return self.model
@@ -55,7 +66,7 @@ class _u2CausalLMMixin(u2MetaForCausalLM):
         p = next(self.model.layers[0].parameters(), None) if len(self.model.layers) else None
         if p is not None and p.is_cuda and p.dtype == torch.bfloat16:
             from .prefill import enable_fused_prefill
-            enable_fused_prefill(self)
+            enable_fused_prefill(self, strict=False)   # (layers of another layout -- Phi3 -- stay stock)
             self._u2_prefill_checked = True
 
     def forward(self, images: Optional[torch.FloatTensor] = None, input_ids: torch.LongTensor = None,
@@ -128,9 +139,23 @@ class u2Qwen3ForCausalLM(_u2CausalLMMixin, Qwen3ForCausalLM):
         self.post_init()
 
 
+class u2Phi3ForCausalLM(_u2CausalLMMixin, Phi3ForCausalLM):
+    """language_model/u2phi3.py:25-140 (train_stage1.py:290-296, model_type "phi3").  The path in front of the decoder is the
+    same HIP path; the Phi3 decoder (fused qkv_proj / gate_up_proj modules) stays the stock HuggingFace one: the fused
+    prefill of prefill.py knows the Llama / Qwen3 layer layout only and leaves these layers alone."""
+    config_class = u2Phi3Config
+
+    def __init__(self, config):
+        super(Phi3ForCausalLM, self).__init__(config)
+        self.model = u2Phi3Model(config)
+        self.vocab_size = config.vocab_size
+        self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+        self.post_init()
+
+
 def register_auto_classes() -> None:
-    """AutoConfig/AutoModelForCausalLM registration (u2llama.py:141-142, u2qwen3.py:144-145); idempotent."""
-    for cfg, cls in ((u2Config, u2LlamaForCausalLM), (u2Qwen3Config, u2Qwen3ForCausalLM)):
+    """AutoConfig/AutoModelForCausalLM registration (u2llama.py:141-142, u2qwen3.py:144-145, u2phi3.py:139-140); idempotent."""
+    for cfg, cls in ((u2Config, u2LlamaForCausalLM), (u2Qwen3Config, u2Qwen3ForCausalLM), (u2Phi3Config, u2Phi3ForCausalLM)):
         try:
             AutoConfig.register(cfg.model_type, cfg)
             AutoModelForCausalLM.register(cfg, cls)

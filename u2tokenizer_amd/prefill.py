@@ -381,9 +381,10 @@ def _layer_protocol_ok(layer) -> bool:
     return ok
 
 
-def enable_fused_prefill(model, decode: bool = True) -> int:
+def enable_fused_prefill(model, decode: bool = True, strict: bool = True) -> int:
     """Patch the decoder layers of an HF Llama / Qwen3 causal LM (u2LlamaForCausalLM / u2Qwen3ForCausalLM included) for the
-    fused prefill and (decode=True) the fused decode step.  Idempotent; returns the number of layers patched.
+    fused prefill and (decode=True) the fused decode step.  Idempotent; returns the number of layers patched.  strict=False: a
+    decoder layer of another layout is skipped instead of refused.
     `disable_fused_prefill` restores the stock forwards."""
     base = model.get_model() if hasattr(model, "get_model") else getattr(model, "model", model)
     layers = getattr(base, "layers", None)
@@ -397,7 +398,9 @@ def enable_fused_prefill(model, decode: bool = True) -> int:
             all(hasattr(layer.self_attn, a) for a in ("q_proj", "k_proj", "v_proj", "o_proj", "head_dim", "scaling")) and \
             all(hasattr(layer.mlp, a) for a in ("gate_proj", "up_proj", "down_proj"))
         if not needed:
-            raise RuntimeError(f"enable_fused_prefill: unsupported decoder layer {type(layer).__name__}")
+            if strict:
+                raise RuntimeError(f"enable_fused_prefill: unsupported decoder layer {type(layer).__name__}")
+            continue   # (another layer layout, e.g. Phi3's fused qkv_proj / gate_up_proj: stays stock)
         if not _layer_protocol_ok(layer):
             continue
         layer._u2_prefill = {"orig": layer.forward, "owner": base}
