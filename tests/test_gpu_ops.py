@@ -267,18 +267,42 @@ def test_flash_attention_forced_rescale(ops):
     close_bf16(got, (p @ x[2]).permute(0, 2, 1, 3).reshape(nb, S, 64))
 
 
-@pytest.mark.parametrize("nb,S,H", [(1, 513, 12), (1, 2049, 2), (2, 640, 3)])
-def test_flash_attention_mode8_prescaled_fragments(ops, nb, S, H):
-    """mode 8 = the fast loop of mode 7 (no per-score multiply) with the kernel scaling its own Q fragments in bf16: what
-    the ViT pipeline runs, except that there the q|k|v product scales q from its fp32 accumulator.  One more bf16
-    rounding of q, so only checked at ordinary logit sizes."""
+C_LOG2E = 0.125 * 1.4426950408889634
+
+
+def _prescale_q(qkv, H):
+    """what the ViT's q|k|v product leaves in the q columns: q * scale * log2 e, rounded to bf16 once"""
+    out = qkv.clone()
+    out[..., :64 * H] = (qkv[..., :64 * H].float() * C_LOG2E).to(bf)
+    return out
+
+
+def _sdpa_ref_prescaled(qkv, nb, S, H):
+    x = qkv.double().view(nb, S, 3, H, 64).permute(2, 0, 3, 1, 4)
+    p = F.softmax(x[0] @ x[1].transpose(-1, -2) * math.log(2.0), dim=-1)      # the kernel computes exp2(q' . k)
+    return (p @ x[2]).permute(0, 2, 1, 3).reshape(nb, S, H * 64).float()
+
+
+@pytest.mark.parametrize("nb,S,H,extra,gain", [(1, 513, 12, True, 0.0), (1, 2049, 2, True, 0.0), (2, 640, 3, False, 0.0),
+                                                (1, 66, 2, True, 0.0), (1, 1100, 2, False, 12.0), (1, 1537, 2, True, 30.0)])
+def test_flash_attention_prescaled_queries(ops, nb, S, H, extra, gain):
+    """Option flash_q_prescaled: the q handed over already carries scale * log2 e (the ViT pipeline's q|k|v product scales
+    its q columns from the fp32 accumulator) and the loop drops its per-score multiply.  Exact against a float64 reference
+    on the SAME pre-scaled inputs -- plain, ragged, short, and with keys that force the out-of-line rescale."""
     qkv = rnd(nb, S, 3 * H * 64, seed=S)
-    ops.set_option("flash_mode", 8)
+    if gain:
+        n = S - 1 if extra else S
+        for h in range(H):
+            for i, (kj, qi) in enumerate([(70, 5), (100, 40), (700, 300), (n - 3, 77), (n - 40, 250), (333, 250), (900, 3)]):
+                q = qkv[0, qi, 64 * h:64 * (h + 1)].float()
+                qkv[0, kj, 64 * H + 64 * h: 64 * H + 64 * (h + 1)] = (q * gain * (1 + 0.5 * (i % 3))).to(bf)
+    qp = _prescale_q(qkv, H)
+    ops.set_option("flash_q_prescaled", 1)
     try:
-        got = ops.flash_attention_d64(qkv.to(D), H, 0.125, extra_last=True)
+        got = ops.flash_attention_d64(qp.to(D), H, 0.125, extra_last=extra)
     finally:
-        ops.set_option("flash_mode", 0)
-    close_bf16(got, _sdpa_ref(qkv, nb, S, H), rounds=2)
+        ops.set_option("flash_q_prescaled", 0)
+    close_bf16(got, _sdpa_ref_prescaled(qp, nb, S, H))
 
 
 def _sdpa_ref64(qkv, nb, S, H):
@@ -328,22 +352,13 @@ def test_flash_mode7_first_keys_dominate(ops):
 
 
 def test_flash_mode7_log_sum_exp(ops):
-    """The row statistics the fused backward takes: the pre-scaled-fragment loop (mode 8) against the exact one to the
-    rounding of q * c in bf16, the exact one against float math."""
+    """The row statistics the fused backward takes: log2 sum_k exp2(s_k scale log2 e), against float math."""
     nb, S, H = 2, 1281, 3
     qkv = rnd(nb, S, 3 * H * 64, seed=11).to(D)
-    res = {}
-    for mode in (7, 8):
-        ops.set_option("flash_mode", mode)
-        try:
-            res[mode] = ops.flash_attention_d64(qkv, H, 0.125, extra_last=True, return_lse=True)
-        finally:
-            ops.set_option("flash_mode", 0)
-    close_bf16(res[8][0], res[7][0].float().cpu())
-    assert (res[8][1][:, :S] - res[7][1][:, :S]).abs().max().item() < 2e-2
+    out, lse = ops.flash_attention_d64(qkv, H, 0.125, extra_last=True, return_lse=True)
     ref = torch.logsumexp((lambda x: x[0] @ x[1].transpose(-1, -2) * 0.125)(
         qkv.float().cpu().view(nb, S, 3, H, 64).permute(2, 0, 3, 1, 4)), dim=-1) * 1.4426950408889634
-    assert (res[7][1].cpu()[:, :S] - ref.reshape(nb * H, S)).abs().max().item() < 2e-3
+    assert (lse.cpu()[:, :S] - ref.reshape(nb * H, S)).abs().max().item() < 2e-3
 
 
 def test_flash_wide_and_narrow_stores_agree(ops):

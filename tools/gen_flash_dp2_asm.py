@@ -44,10 +44,12 @@ THR_BITS = 0x5f800000   # 2^64: a phase's row-sum piece above this sends the wav
 
 # ---- fixed VGPRs: v[VLO:255]; tuples start on even registers (gfx90a+ rule) ---------------------------------------
 NFR = 8 if SHARE else 4                                      # fragment tuples
-VLO = 69 if SHARE else 85
-ADR = VLO                                                    # address temporary of the epilogue's reads
-AB = [VLO + 1 + i for i in range(4)]    # lane base addresses of the fragment reads (LDS base folded in)
-_o = VLO + 5
+VLO_REST = 69 if SHARE else 85
+VLO = VLO_REST - 33                                          # (even: the Q tuples start there; v[VLO_REST - 1] stays unused)
+QF = {(b, k): VLO + 16 * b + 4 * k for b in range(2) for k in range(4)}   # Q fragments [block][k slice], loaded by the block
+ADR = VLO_REST                                               # address temporary of the epilogue's reads
+AB = [VLO_REST + 1 + i for i in range(4)]    # lane base addresses of the fragment reads (LDS base folded in)
+_o = VLO_REST + 5
 O = {(0, 0): _o, (0, 1): _o + 16, (1, 0): _o + 32, (1, 1): _o + 48}   # O^T accumulators [block][nb], 16 regs each
 SC = {0: _o + 64, 1: _o + 80}                                # scores - m of a 32-key half, 16 regs each
 MNEG = {0: _o + 96, 1: _o + 112}                             # -m of the lane's row, replicated: C operand of Q K^T
@@ -106,7 +108,7 @@ def s(n):
 
 
 def qf(b, k):
-    return f"%[qf{b}{k}]"
+    return vr(QF[(b, k)], 4)
 
 
 def m_run(b):
@@ -334,7 +336,7 @@ def extra_scores():
     e(f"v_mov_b32 {v(SX[1])}, 0xff800000")
     e("s_cmp_eq_u32 %[xflag], 0")
     e("s_cbranch_scc1 .Lfd2_nox_%=")
-    e("s_waitcnt vmcnt(12)")             # the 8 + 4 loads of the extra key are older than the 12 LDS-DMA pieces
+    e("s_waitcnt vmcnt(12)")             # Q, the extra key and its v are older than the 12 LDS-DMA pieces
     for b in range(2):
         acc = vr(SC[0], 16)
         for ks in range(4):
@@ -434,8 +436,12 @@ def gen():
     e(f"v_add_u32 {v(AB[0])}, %[lds], %[ab0]")
     for k in (1, 2, 3):
         e(f"v_xor_b32 {v(AB[k])}, {32 * k}, {v(AB[0])}")  # kt_off: chunk ^= 2k (the LDS base is 128-byte aligned)
-    # v of the extra key for this lane's 32 output columns (the prologue's first vmcnt wait covers these 8 loads: they are
-    # older than every LDS-DMA piece); O^T and l are opened by init_max
+    # Q fragments of the lane's two query rows (B operands of every Q K^T MFMA), the extra key and its v: all issued here, in
+    # front of the first tiles' LDS-DMA, so that the unit pays ONE memory latency before its first MFMA.  Every wait of the
+    # prologue is a count of the 12 LDS-DMA pieces issued behind these 20 loads.  O^T and l are opened by init_max.
+    for b in range(2):
+        for k in range(4):
+            e(f"global_load_dwordx4 {qf(b, k)}, %[qa{b}], off offset:{32 * k}")
     for nb in range(2):
         for g in range(4):
             e(f"global_load_dwordx2 {vr(VX + nb * 8 + g * 2, 2)}, %[vxa], off offset:{nb * 64 + g * 16}")
@@ -517,7 +523,8 @@ def gen():
         # K rows 0..31 of tile t+1 (next slot); V^T tile t, keys 32..63 (vh = 1)
         phase(0, True, True, True, nxt, base + 8192, 1, dma=(j + AHEAD) % NSLOT if DMAPH else None)
         mask_call(0)
-        # (its spare slots carry the first fragment reads of the next tile's first phase: no barrier in between)
+        # (its spare slots carry the first fragment reads of the next tile's first phase: no barrier in between.  The LDS-DMA
+        # pieces stay in the reading phase above: moved here they measured 2677 -> 2714 cycles per tile)
         phase(1, True, True, True, nxt, base + 8192, 1, reuse=SHARE, prefetch=(nxt + 4096, nxt + 8192, 0) if PRE else None)
         mask_call(1)
         stamp(4)

@@ -420,16 +420,19 @@ def sec_flashperf():
     for (nb, S, H, extra) in [(8, 2049, 12, True), (8, 2049, 12, False), (8, 2048, 12, False), (16, 513, 12, True)]:
         qkv = rnd(nb, S, 3 * H * 64, seed=3).to(dev)
         fl = 4 * nb * H * S * S * 64
-        for mode, split in ((7, 0), (8, 0)):
+        for mode, split in ((7, 0), (7, 1)):   # (mode, flash_q_prescaled: the loop without its per-score multiply)
             ops.set_option("flash_mode", mode)
+            ops.set_option("flash_q_prescaled", split)
             ms = timeit(lambda: ops.flash_attention_d64(qkv, H, 0.125, extra_last=extra), iters=10)
             # the transpose alone
+            ops.set_option("flash_q_prescaled", 0)
             ref = _flash_ref(qkv[:1, :, :], H)
             got = ops.flash_attention_d64(qkv[:1].contiguous(), H, 0.125, extra_last=extra)
             err = (got.float() - ref).abs().max().item()
-            print(f"  nb={nb} S={S} extra={int(extra)} mode={mode}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF/s  "
+            print(f"  nb={nb} S={S} extra={int(extra)} mode={mode} q_prescaled={split}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF/s  "
                   f"util={fl / ms / 1e9 / 2500:.3f}  max_err={err:.2e}", flush=True)
     ops.set_option("flash_mode", 0)
+    ops.set_option("flash_q_prescaled", 0)
     qkv = rnd(8, 2049, 3 * 768, seed=3).to(dev)
     vt = torch.empty((8, 768, 2048), dtype=bf, device=dev)
     ms = timeit(lambda: ops.transpose(qkv[:, :2048, 1536:].contiguous(), ld_out=2048, perm16=True), iters=10)
@@ -488,8 +491,9 @@ def sec_flashtime():
     nb, S, H = 8, 2049, 12
     qkv = rnd(nb, S, 3 * H * 64, seed=3).to(dev)
     names = ["gload", "QK^T", "softmax", "PV", "wait+lstore", "-", "barrier"]
-    for mode, split in ((7, 0), (8, 0)):
+    for mode, split in ((7, 0), (7, 1)):
         ops.set_option("flash_mode", mode)
+        ops.set_option("flash_q_prescaled", split)
         ms0 = timeit(lambda: ops.flash_attention_d64(qkv, H, 0.125, extra_last=True), iters=5)
         buf = torch.zeros(65536 + 2048 * 4 * 8, dtype=torch.int64, device=dev)
         _lib.check(h.u2tok_flash_debug_buffer(buf.data_ptr()), "flash_debug_buffer")
@@ -499,19 +503,20 @@ def sec_flashtime():
         r = buf.view(-1, 8).double()
         r = r[r[:, 7] > 0]
         per = r[:, :7].sum(0) / r[:, 7].sum()
-        if mode in (7, 8):
+        if mode == 7:
             flash_timeline(buf, split)
-        if mode % 10 in (5, 7, 8):
-            print(f"  mode {mode}: {ms0 * 1e3:7.1f} us untimed | per 64-key tile per wave (2 blocks): phases u=2t {per[0]:6.0f}  dma wait {per[1]:6.0f}  "
+        if mode % 10 in (5, 7):
+            print(f"  mode {mode} q_prescaled {split}: {ms0 * 1e3:7.1f} us untimed | per 64-key tile per wave (2 blocks): phases u=2t {per[0]:6.0f}  dma wait {per[1]:6.0f}  "
                   f"barrier {per[2]:6.0f}  dma issue {per[3]:6.0f}  phases u=2t+1 {per[4]:6.0f}  total {per[:5].sum():6.0f}", flush=True)
             continue
         if mode % 10 == 4:
-            print(f"  mode {mode}: {ms0 * 1e3:7.1f} us untimed | per KV tile per wave: V {per[0]:6.0f}  wait {per[1]:6.0f}  M {per[2]:6.0f}  "
+            print(f"  mode {mode} q_prescaled {split}: {ms0 * 1e3:7.1f} us untimed | per KV tile per wave: V {per[0]:6.0f}  wait {per[1]:6.0f}  M {per[2]:6.0f}  "
                   f"wait {per[3]:6.0f}  total {per[:4].sum():6.0f}", flush=True)
             continue
-        print(f"  mode {mode}: {ms0 * 1e3:7.1f} us untimed | per KV tile per wave: " +
+        print(f"  mode {mode} q_prescaled {split}: {ms0 * 1e3:7.1f} us untimed | per KV tile per wave: " +
               "  ".join(f"{n} {v:6.0f}" for n, v in zip(names, per.tolist()) if n != "-") + f"  total {per.sum():6.0f}", flush=True)
     ops.set_option("flash_mode", 0)
+    ops.set_option("flash_q_prescaled", 0)
 
 
 def sec_preperf():

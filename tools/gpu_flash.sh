@@ -7,7 +7,7 @@ timeout 300 python tools/gpu_check.py flashperf 2>&1 | grep -v Warn > $O/flashpe
 timeout 300 python tools/gpu_check.py flashtime 2>&1 | grep -v Warn > $O/flashtime.log
 cd /tmp; export TMPDIR=/tmp
 SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"
-for m in ${MODES:-7_0 8_0}; do
+for m in ${MODES:-7_0 7_1}; do
   timeout 90 rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $O/pmc/flash${m}_p1 -o p -- python $R/tools/prof_kernels.py flash 3 0 ${m%_*} ${m#*_} > $O/pmc_flash$m.log 2>&1
   echo "pmc flash$m exit $?" >> $O/pmc.log
 done

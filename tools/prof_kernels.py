@@ -17,6 +17,7 @@ bf = torch.bfloat16
 torch.manual_seed(0)
 if what == "flash":
     ops.set_option("flash_mode", int(sys.argv[4]) if len(sys.argv) > 4 else 0)
+    ops.set_option("flash_q_prescaled", int(sys.argv[5]) if len(sys.argv) > 5 else 0)
     qkv = torch.randn(8, 2049, 2304, device="cuda").to(bf)
     for _ in range(iters):
         ops.flash_attention_d64(qkv, 12, 0.125, extra_last=True)

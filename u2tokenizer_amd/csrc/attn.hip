@@ -684,13 +684,6 @@ typedef int i32x4_t __attribute__((ext_vector_type(4)));
 // the tile loop is unrolled over the ring so fragment reads are lane base + immediate.
 #include "flash_dp2_asm.inc"
 
-__device__ __forceinline__ bf16x8 fdp2_prescale(const bf16x8 q, const float c) {
-  union { bf16x8 v; uint32_t u[4]; } in, o;
-  in.v = q;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) o.u[j] = pack2_bf16(bf16lo(in.u[j]) * c, bf16hi(in.u[j]) * c);
-  return o.v;
-}
 
 // Extra query row of head (b, h) for the double pipeline of round 4 (NT threads).  The first form (flash_extra_row above)
 // took ~40 us per row -- 64 dependent 16-byte loads per thread -- and sat on the kernel's tail.  Scores: 8 lanes per key
@@ -790,8 +783,7 @@ __device__ __forceinline__ void flash_extra_row2(const FlashArgs& a, float* sbuf
 
 // QMODE: 0 = q as the reference has it, every score multiplied by scale * log2 e in fp32 (flash_dp2_asm.inc, "_X" text);
 //        1 = the caller's q / qx already carry scale * log2 e (the ViT's q|k|v product scales its q columns in the
-//            epilogue, from the fp32 accumulator: one rounding, as for the unscaled q);
-//        2 = the kernel multiplies its Q fragments itself (a second bf16 rounding of q: diagnostic / timing only).
+//            epilogue, from the fp32 accumulator: one rounding, as for the unscaled q): two VALU per slot less.
 // Grid = [n_main units of 256 query rows | one extra-row workgroup per (batch, head)].  768 units on 512 workgroup slots
 // are 1.5 rounds; two ways of cutting the last half round in two key ranges (a persistent form, every workgroup 1.5 units
 // in lock step; a tail form, the last 256 units as 512 half units with a ticket and an fp32 slab per pair) were built and
@@ -841,16 +833,10 @@ __global__ __launch_bounds__(256, 2) void flash_dp2_kernel(const FlashArgs a) {
   const bf16_t* vb_ = a.vt + ((int64_t)b * a.H + h) * 64 * S_pad;
   const int wrow0 = row0 + wv * 64;
 
-  bf16x8 qf[2][4];
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const bf16_t* qp = qb_ + (int64_t)min(wrow0 + qb * 32 + l31, S - 1) * ld_qk + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      qf[qb][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
-      if constexpr (QMODE == 2) qf[qb][ks] = fdp2_prescale(qf[qb][ks], a.scale_log2e);
-    }
-  }
+  // the lane's two query rows (rows past S: the last one; their results are not stored): the block loads the fragments itself,
+  // 4 x 16 bytes at 32-byte steps from qa0 / qa1
+  const bf16_t* qa0 = qb_ + (int64_t)min(wrow0 + l31, S - 1) * ld_qk + hi * 8;
+  const bf16_t* qa1 = qb_ + (int64_t)min(wrow0 + 32 + l31, S - 1) * ld_qk + hi * 8;
   // DMA pieces of this wave: MUBUF descriptors built by hand -- K rows past S read as zero
   const int prow = wv * 16 + (lane >> 3);
   const int pch0 = (lane & 7) ^ ((prow >> 1) & 7), pch1 = pch0 ^ 4;
@@ -883,8 +869,7 @@ __global__ __launch_bounds__(256, 2) void flash_dp2_kernel(const FlashArgs a) {
   unsigned long long* dbg = g_flash_dbg + ((size_t)blockIdx.x * 4 + wv) * 8;  // TIMED: 5 section times, [7] = tiles
 #define FDP2_OPERANDS                                                                                                  \
                : [mr0] "=&v"(mr0), [lr0] "=&v"(lr0), [mr1] "=&v"(mr1), [lr1] "=&v"(lr1), [lid] "=&v"(lane2)             \
-               : [qf00] "v"(qf[0][0]), [qf01] "v"(qf[0][1]), [qf02] "v"(qf[0][2]), [qf03] "v"(qf[0][3]),                \
-                 [qf10] "v"(qf[1][0]), [qf11] "v"(qf[1][1]), [qf12] "v"(qf[1][2]), [qf13] "v"(qf[1][3]),                \
+               : [qa0] "v"(qa0), [qa1] "v"(qa1),                                                                        \
                  [ab0] "v"(ab0), [ko0] "v"(ko0), [ko1] "v"(ko1), [vo0] "v"(vo0), [vo1] "v"(vo1), [hi4] "v"(hi4),        \
                  [dump] "v"(dump), [rsk] "s"(rsk), [rsv] "s"(rsv), [lds] "s"(lds_u32), [dma_base] "s"(dma_base),        \
                  [ktile] "s"(k_tile_bytes), [seq] "s"(S), [ntile] "s"(ntile), [dbg] "v"(dbg),                           \
@@ -902,7 +887,7 @@ __global__ __launch_bounds__(256, 2) void flash_dp2_kernel(const FlashArgs a) {
   // the block left O^T in LDS: tuple T = 2 * block + nb, 16-byte quarter j at [wave][T * 4 + j][lane]
   const int hi2 = lane2 >> 5, l31b = lane2 & 31;
   const char* dp = &lds[0][0] + wv * 16384 + lane2 * 16;
-#pragma unroll
+#pragma unroll 1
   for (int blk = 0; blk < 2; ++blk) {  // one block at a time: 32 accumulator values live, not 64
     FdpBlock x;
 #pragma unroll
@@ -914,7 +899,8 @@ __global__ __launch_bounds__(256, 2) void flash_dp2_kernel(const FlashArgs a) {
       }
     x.m_run = blk ? mr1 : mr0;
     x.l_run = blk ? lr1 : lr0;
-    fdp_finish(a, x, qf[blk], b, h, wrow0 + 32 * blk + l31b, hi2, QMODE != 0, true);
+    const bf16x8 no_q[4] = {};   // (the extra key was folded in by the block)
+    fdp_finish(a, x, no_q, b, h, wrow0 + 32 * blk + l31b, hi2, QMODE != 0, true);
   }
   if constexpr (TIMED) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -951,7 +937,8 @@ int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16
   a.wide_out = !((uintptr_t)out & 15) && !(ld_out & 7) && !(out_bs & 7);
   const int64_t nbh = (int64_t)nb * H;
   int mode = opts().flash_mode;
-  if (mode != 1 && mode != 7 && mode != 8) mode = S >= 512 ? 7 : 1;  // measured: the double pipeline wins from S = 513 up
+  if (mode != 1 && mode != 7) mode = S >= 512 ? 7 : 1;  // measured: the double pipeline wins from S = 513 up
+  q_prescaled = q_prescaled || opts().flash_q_prescaled;
   if (q_prescaled) mode = 7;  // the only form that takes pre-scaled queries (the ViT launches it at S = 2048)
   a.q_prescaled = q_prescaled;
   const int64_t blocks = mode != 1 ? nbh * ((S + 255) / 256) : nbh * ((S + 127) / 128);
@@ -961,14 +948,12 @@ int flash_attention_d64(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16
   if (grid > 0x7fffffff) return U2_ERR_ARG;
   ProfScope ps(PROF_FLASH, 4.0 * nbh * (double)(S + n_extra) * (S + n_extra) * 64, stream,
                4.0 * nbh * (double)(S + n_extra) * 64 * 2.0);  // q, k, v^T read + o written, once
-  if (mode == 7 || mode == 8) {
+  if (mode == 7) {
     const dim3 g((unsigned)grid), t(256);
-    const int qm = q_prescaled ? 1 : mode == 8 ? 2 : 0;
 #define U2_FDP2_Q(T_)                                                                                            \
   do {                                                                                                           \
-    if (qm == 0) hipLaunchKernelGGL((flash_dp2_kernel<T_, 0>), g, t, 0, stream, a);                             \
-    else if (qm == 1) hipLaunchKernelGGL((flash_dp2_kernel<T_, 1>), g, t, 0, stream, a);                        \
-    else hipLaunchKernelGGL((flash_dp2_kernel<T_, 2>), g, t, 0, stream, a);                                     \
+    if (q_prescaled) hipLaunchKernelGGL((flash_dp2_kernel<T_, 1>), g, t, 0, stream, a);                         \
+    else hipLaunchKernelGGL((flash_dp2_kernel<T_, 0>), g, t, 0, stream, a);                                     \
   } while (0)
     if (g_flash_timed) U2_FDP2_Q(true); else U2_FDP2_Q(false);
 #undef U2_FDP2_Q

@@ -22,7 +22,8 @@ struct Options {
   int gemm_big_splitk = 0;  // K slices of a FORCED big-tile launch (gemm_big = 20 / 21): measurements, tests
   int gemm_big_skinny = 1;  // 1: partial-round products may take the big-tile kernel with K slices (bt_pick_sliced); 0: never
   int kmajor_b = 1;         // 1: P V / DiffTS aggregation read V / X in place as K-major B operands; 0: transposed copies
-  int flash_mode = 0;       // 0 pick, 1 plain 128-row units, 7 double pipeline (generated asm KV loop), 8 = 7 with in-kernel bf16 pre-scaling of q (diagnostic)
+  int flash_mode = 0;       // 0 pick, 1 plain 128-row units, 7 double pipeline (generated asm KV loop)
+  int flash_q_prescaled = 0;  // the q handed to u2tok_flash_attention_d64 already carries scale * log2 e (what the ViT's q|k|v product leaves)
   int vit_flash = 1;        // 0: unfused ViT attention (debug)
   int tok_flash = 1;        // 1: fused attention kernel for the tokenizer's attention cores (tokattn.hip); 0: GEMM chain
   int tta_overlap = 1;      // k | v projections of the TTA cross attentions on a side stream
