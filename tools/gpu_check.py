@@ -481,6 +481,10 @@ def flash_timeline(buf, split):
     if (~main).sum():
         e_, x_ = ent[~main], ex[~main]
         print(f"    extra-row workgroups: entry {e_.min():6.1f}..{e_.max():6.1f}, duration {(x_ - e_).mean():5.2f} (max {(x_ - e_).max():5.2f}), last exit {x_.max():6.1f}")
+        tx = t[~main]
+        if (tx[:, 4] > 0).all():
+            sc, sm, pv = (tx[:, 4] - tx[:, 0]) / 100, (tx[:, 5] - tx[:, 4]) / 100, (tx[:, 3] - tx[:, 5]) / 100
+            print(f"      of which scores {sc.mean():5.2f}  softmax {sm.mean():5.2f}  P V + store {pv.mean():5.2f} us")
     print(f"    kernel span by these stamps: {ex.max():6.1f} us")
 
 

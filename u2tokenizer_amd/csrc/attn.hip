@@ -694,7 +694,8 @@ __device__ __forceinline__ float dot2_bf16(const uint32_t a, const uint32_t b, c
   return __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const bf16x2_t*>(&a), *reinterpret_cast<const bf16x2_t*>(&b), c, false);
 }
 template <int NT>
-__device__ __forceinline__ void flash_extra_row2(const FlashArgs& a, float* sbuf, const int b, const int h, const int tid) {
+__device__ __forceinline__ void flash_extra_row2(const FlashArgs& a, float* sbuf, const int b, const int h, const int tid,
+                                                 unsigned long long* tl = nullptr) {
   constexpr int NW = NT / 64;
   float* red = sbuf + a.S_pad;                                    // [2 NW] block reductions
   bf16_t* pb = reinterpret_cast<bf16_t*>(sbuf + a.S_pad + 64);    // [S_pad] probabilities, bf16, in V^T's key order
@@ -714,7 +715,10 @@ __device__ __forceinline__ void flash_extra_row2(const FlashArgs& a, float* sbuf
   const bf16_t* kb_ = a.k + (int64_t)b * a.q_bs + h * 64 + ch * 8;
   const float sx = dot8(*reinterpret_cast<const uint4*>(a.kx + (int64_t)b * a.x_bs + h * 64 + ch * 8));  // the extra key
   float m = sx;
-  constexpr int KU = 8;  // keys per thread in flight
+  // keys per thread in flight (8, 16 and 32 measure the same ~30 us beside the main waves: scores 18.6 + softmax 2 + P V 11.4 us
+  // by s_memrealtime; moved into the V^T launch in front of the flash launch the rows took 24 us there against 12 us for the
+  // transpose alone and bought the flash launch 2 us: removed again, profiles/r04_flash_tail_split_trial.log)
+  constexpr int KU = 8;
   for (int j0 = wv * 8 + kk; j0 < S_pad; j0 += KU * 8 * NW) {
     uint4 u[KU];
 #pragma unroll
@@ -731,6 +735,7 @@ __device__ __forceinline__ void flash_extra_row2(const FlashArgs& a, float* sbuf
     }
   }
   m = wave_max(m);
+  if (tl && lane == 0) tl[4] = __builtin_amdgcn_s_memrealtime();
   if (lane == 0) red[wv] = m;
   __syncthreads();
   m = red[0];
@@ -747,6 +752,7 @@ __device__ __forceinline__ void flash_extra_row2(const FlashArgs& a, float* sbuf
   sum = wave_sum(sum);
   if (lane == 0) red[NW + wv] = sum;
   __syncthreads();
+  if (tl && lane == 0) tl[5] = __builtin_amdgcn_s_memrealtime();
   const float px = __builtin_amdgcn_exp2f(sx - m);
   float l_tot = px;
 #pragma unroll
@@ -758,15 +764,16 @@ __device__ __forceinline__ void flash_extra_row2(const FlashArgs& a, float* sbuf
   for (int d = tid >> 4; d < 64; d += NT / 16) {
     const bf16_t* vrow = a.vt + (((int64_t)b * a.H + h) * 64 + d) * S_pad;
     float o0 = 0.f, o1 = 0.f;
-    for (int p0 = part; p0 < npc; p0 += 128) {
-      uint4 vv[8];
+    constexpr int PU = 8;   // V^T pieces per thread in flight
+    for (int p0 = part; p0 < npc; p0 += 16 * PU) {
+      uint4 vv[PU];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < PU; ++i) {
         const int pc = p0 + 16 * i;
         vv[i] = pc < npc ? *reinterpret_cast<const uint4*>(vrow + pc * 8) : uint4{0, 0, 0, 0};
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < PU; ++i) {
         const uint4 pw = *reinterpret_cast<const uint4*>(pb + min(p0 + 16 * i, npc - 1) * 8);
         o0 = dot2_bf16(pw.x, vv[i].x, o0); o1 = dot2_bf16(pw.y, vv[i].y, o1);
         o0 = dot2_bf16(pw.z, vv[i].z, o0); o1 = dot2_bf16(pw.w, vv[i].w, o1);
@@ -816,7 +823,7 @@ __global__ __launch_bounds__(256, 2) void flash_dp2_kernel(const FlashArgs a) {
       // get the leftover issue slots (30 us for ~10 us of work): static priority, their demand is small
       __builtin_amdgcn_s_setprio(3);
       const int e = w - a.n_main;
-      flash_extra_row2<256>(a, reinterpret_cast<float*>(&lds[0][0]), e / a.H, e % a.H, tid);
+      flash_extra_row2<256>(a, reinterpret_cast<float*>(&lds[0][0]), e / a.H, e % a.H, tid, TIMED ? tl : nullptr);
       if constexpr (TIMED) if ((tid & 63) == 0) tl[3] = __builtin_amdgcn_s_memrealtime();
       return;
     }
