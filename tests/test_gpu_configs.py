@@ -266,6 +266,56 @@ def test_config3_end_to_end_first_step_logits_and_greedy_ids():
             break
 
 
+def test_float16_model_under_autocast():
+    """evalscipt/ourmodel_amos.py:33,70: the whole model in float16, generate under torch.autocast.  The path modules run their
+    bf16 copies (ops.Fp16Twin), the decoder is stock HF in fp16.  Against the oracle + HF decoder in fp32 on the SAME
+    (fp16-representable) weights: the spliced embeddings within the bf16 reference's distance (the path's arithmetic IS
+    bf16; the fp16 oracle's distance is recorded beside it), greedy ids as in the bf16 test."""
+    from transformers import Qwen3ForCausalLM
+    from u2tokenizer_amd.language_model import u2Qwen3Config, u2Qwen3ForCausalLM
+    E, vocab, S, Lt, seed = 2048, 4096, 320, 1024, 73
+    c = mm_config(E, [32, 64, 64], u2t_num_layers=1, u2t_top_k=16, use_multi_scale=False, enable_diffts=False,
+                  enable_dmtp=False)
+    cfg = u2Qwen3Config(vocab_size=vocab, hidden_size=E, intermediate_size=6144, num_hidden_layers=2,
+                        num_attention_heads=16, num_key_value_heads=8, head_dim=128, max_position_embeddings=2048,
+                        tie_word_embeddings=False, pad_token_id=0, bos_token_id=1, eos_token_id=2)
+    for k, v in c.items():
+        if k != "hidden_size":
+            setattr(cfg, k, v)
+    m = u2Qwen3ForCausalLM(cfg).eval()
+    synth.fill_module_(m, seed=seed, lively=True)
+    m = m.half().float()                                   # weights that fp16 holds exactly
+    sd32 = {k: v.clone() for k, v in m.state_dict().items() if v.is_floating_point()}
+    vol = synth.synth_volume(1, 2, c["image_size"], seed=seed, dtype=torch.float16)
+    ids = synth.synth_ids(1, S, S - 8, vocab, seed=seed, name="input_ids")
+    qids = synth.synth_ids(1, Lt, 40, vocab, seed=seed, name="question_ids")
+    oc = oracle_cfg(c)
+    e32, _ = O.prepare_inputs_for_multimodal(sd32, sd32["model.embed_tokens.weight"], ids, vol.float(), qids, oc)
+    gen32 = Qwen3ForCausalLM.generate(m, inputs_embeds=e32, max_new_tokens=4, do_sample=False, output_scores=True,
+                                      return_dict_in_generate=True)
+    logits32 = m(inputs_embeds=e32).logits[:, -1]
+    sd16 = {k: v.to(bf) for k, v in sd32.items()}
+    e16, _ = O.prepare_inputs_for_multimodal(sd16, sd16["model.embed_tokens.weight"], ids, vol.to(bf), qids, oc)
+    sdh = {k: v.half() for k, v in sd32.items()}
+    eh, _ = O.prepare_inputs_for_multimodal(sdh, sdh["model.embed_tokens.weight"], ids, vol.half(), qids, oc)
+    mg = m.half().to(D)
+    assert next(mg.get_model().get_u2tokenizer().parameters()).dtype == torch.float16
+    with torch.autocast("cuda", dtype=torch.float16):
+        emb = mg.prepare_inputs_for_multimodal(ids.to(D), None, None, None, None, vol.to(D), qids.to(D))[4]
+        out = mg(images=vol.to(D), input_ids=ids.to(D), question_ids=qids.to(D))
+        gen = mg.generate(vol.to(D), ids.to(D), question_ids=qids.to(D), max_new_tokens=4, do_sample=False).cpu()
+    assert emb.dtype == torch.float16 and out.logits.dtype in (torch.float16, torch.float32)
+    rep = {"inputs_embeds": three_way(emb, e32, e16), "fp16_oracle_vs_o32": err_stats(eh.float(), e32),
+           "logits_last_hip_vs_o32": err_stats(out.logits[:, -1].float().cpu(), logits32),
+           "greedy_ids_hip": gen.tolist(), "greedy_ids_fp32": gen32.sequences.tolist()}
+    record("float16_model_config1", rep)
+    gate(rep["inputs_embeds"], "float16 model inputs_embeds")
+    top2 = gen32.scores[0][0].topk(2).values
+    if float(top2[0] - top2[1]) > 0.5:
+        assert gen[0, 0] == gen32.sequences[0, 0], (gen, gen32.sequences)
+    assert gen.shape == gen32.sequences.shape
+
+
 def test_config2_full_path_vs_oracle():
     """BASELINE configs[1]: E = 2048, 128^3 volumes = 4 chunks of (32,128,128), batch 4, full tokenizer."""
     c = mm_config(2048, [32, 128, 128])

@@ -117,6 +117,34 @@ def test_fused_prefill_refuses_the_older_decoder_layer_protocol():
     prefill.disable_fused_prefill(new)
 
 
+def test_float16_parameters_run_a_bf16_twin():
+    """evalscipt/ourmodel_amos.py:33 loads the model in float16.  The path modules then compute through a bf16 copy of
+    themselves (ops.Fp16Twin): built lazily, rebuilt when a weight changes, invisible to state_dict(), inference only."""
+    tok = U.build_u2tokenizer_tower(_cfg()).half().eval()
+    keys = set(tok.state_dict())
+    twin = tok._fp16_twin()
+    assert twin is not None and all(p.dtype == torch.bfloat16 and not p.requires_grad for p in twin.parameters())
+    assert all(p.dtype == torch.float16 for p in tok.parameters()) and set(tok.state_dict()) == keys
+    assert tok._fp16_twin() is twin                                    # cached
+    w = tok.query_tokens
+    assert torch.equal(twin.query_tokens.float(), w.detach().to(torch.bfloat16).float())
+    with torch.no_grad():
+        w.add_(1.0)
+    twin2 = tok._fp16_twin()
+    assert twin2 is not twin and torch.equal(twin2.query_tokens.float(), w.detach().to(torch.bfloat16).float())
+    tok.train()
+    with torch.enable_grad(), pytest.raises(RuntimeError, match="inference only"):
+        tok._fp16_twin()
+    tok.eval()
+    assert U.build_u2tokenizer_tower(_cfg()).bfloat16()._fp16_twin() is None
+    # the three path modules carry the mixin; a forward without a GPU still refuses loudly (no CPU fallback through the twin)
+    tok.requires_grad_(False)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="GPU tensor"):
+        tok(v_token=torch.zeros(1, 2, 16, 512, dtype=torch.float16), t_token=torch.zeros(1, 8, 512, dtype=torch.float16))
+    for m in (U.build_vision_tower(_cfg()), U.build_mm_projector(_cfg())):
+        assert m.half().eval()._fp16_twin() is not None
+
+
 def test_builders_raise_like_the_reference():
     with pytest.raises(ValueError, match="Unknown vision tower"):
         U.build_vision_tower(_cfg(vision_tower="resnet"))

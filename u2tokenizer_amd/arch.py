@@ -106,9 +106,12 @@ class u2MetaForCausalLM(ABC):
         # u2_arch.py:131-135): lookup and splice go through autograd (nn.Embedding + cat, as in the reference) so the
         # table receives its gradient; otherwise the fused HIP gather / splice kernel.
         track = torch.is_grad_enabled() and embed_w.requires_grad
+        # a float16 model (evalscipt/ourmodel_amos.py:33): the path modules run their bf16 copies (ops.Fp16Twin); the decoder's
+        # own embedding table stays what it is, so lookup and splice are the reference's torch ops on the GPU
+        plain = embed_w.dtype != torch.bfloat16
 
         def lookup(ids):
-            return embed(ids) if track else ops.embed_splice(embed_w, ids)
+            return embed(ids) if (track or plain) else ops.embed_splice(embed_w, ids)
 
         if self.config.enable_u2tokenizer:
             B, C, D, H, W = images.shape
@@ -134,7 +137,7 @@ class u2MetaForCausalLM(ABC):
                 image_features = image_features.repeat(2, 1, 1)
         else:
             image_features = self.encode_images(images.to(dev))
-        if track or (torch.is_grad_enabled() and image_features.requires_grad):
+        if track or plain or (torch.is_grad_enabled() and image_features.requires_grad):
             emb = embed(input_ids.to(dev))
             inputs_embeds = torch.cat((emb[:, :1, :], image_features.to(emb.dtype),
                                        emb[:, image_features.shape[1] + 1:, :]), dim=1)  # u2_arch.py:113-116

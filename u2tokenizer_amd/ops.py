@@ -114,6 +114,39 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+class Fp16Twin:
+    """Mixin of the three path modules (ViT3DTower, SpatialPoolingProjector, u2Tokenizer) for float16 PARAMETERS --
+    evalscipt/ourmodel_amos.py:33 loads the whole model with torch_dtype=float16 and generates under autocast.  The HIP
+    kernels compute in bf16 (fp32 accumulation): a module whose parameters are fp16 keeps a bf16 copy of itself (rebuilt
+    when a parameter's storage or version changes; inference only), runs that on bf16-rounded inputs and hands the result
+    back as fp16.  The interface of the fp16 entry point, the arithmetic of the bf16 one: three mantissa bits fewer than a
+    true fp16 run (documented in DESIGN.md section 5); bf16 parameters under `torch.autocast` (green_refactored/lu2_model.py:
+    30,62) take the normal path, the kernels are not autocast-aware."""
+
+    def _fp16_twin(self):
+        ps = list(self.parameters())
+        if not ps or ps[0].dtype != torch.float16:
+            return None
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in ps):
+            raise RuntimeError(f"{type(self).__name__}: float16 parameters are supported for inference only (train in bf16, "
+                               "as train_stage1.py / config/ds_config.json do)")
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if self.__dict__.get("_twin_key") != key:
+            import copy
+            self.__dict__.pop("_twin_mod", None)
+            self.__dict__.pop("_twin_key", None)
+            with torch.no_grad():
+                twin = copy.deepcopy(self).to(torch.bfloat16)
+            for q in twin.parameters():
+                q.requires_grad_(False)
+            self.__dict__["_twin_mod"], self.__dict__["_twin_key"] = twin, key   # (not a registered submodule: not in state_dict)
+        return self.__dict__["_twin_mod"]
+
+    @staticmethod
+    def _to_bf16(t):
+        return t.to(torch.bfloat16) if torch.is_tensor(t) and t.is_floating_point() and t.dtype != torch.bfloat16 else t
+
+
 def _need(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
     if not t.is_cuda:
         raise RuntimeError(f"{name}: expected a GPU tensor (the u2tok HIP path has no CPU fallback)")

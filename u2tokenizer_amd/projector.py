@@ -10,7 +10,7 @@ import torch.nn as nn
 from . import _lib, ops
 
 
-class SpatialPoolingProjector(nn.Module):
+class SpatialPoolingProjector(ops.Fp16Twin, nn.Module):
     def __init__(self, image_size, patch_size, in_dim, out_dim, layer_type, layer_num, pooling_type="spatial",
                  pooling_size=2):
         super().__init__()
@@ -42,6 +42,9 @@ class SpatialPoolingProjector(nn.Module):
         self._ws = ops._Workspace()
 
     def forward(self, x):
+        twin = self._fp16_twin()
+        if twin is not None:
+            return twin(self._to_bf16(x)).to(torch.float16)
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             from . import autograd as AG  # training: the same kernels behind torch.autograd.Function
             ops._need(x, torch.bfloat16, "image_features")

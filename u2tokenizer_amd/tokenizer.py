@@ -216,7 +216,7 @@ def _unshare_packed(module, state_dict, prefix, local_metadata):
     return state_dict
 
 
-class u2Tokenizer(nn.Module):
+class u2Tokenizer(ops.Fp16Twin, nn.Module):
     """Same constructor and forward as the reference (u2Tokenizer.py:6-47)."""
 
     def __init__(self, embed_size, num_heads, num_layers, top_k, use_multi_scale, num_3d_query_token, hidden_size,
@@ -382,6 +382,11 @@ class u2Tokenizer(nn.Module):
                               ln_eps=1e-5)
 
     def forward(self, v_token, t_token):
+        twin = self._fp16_twin()
+        if twin is not None:
+            out = twin(self._to_bf16(v_token), self._to_bf16(t_token)).to(torch.float16)
+            self.last_topk_indices = getattr(twin, "last_topk_indices", None)
+            return out
         if torch.is_grad_enabled() and (v_token.requires_grad or t_token.requires_grad
                                         or any(p.requires_grad for p in self.parameters())):
             # training: the same kernels sequenced op by op behind torch.autograd.Function (autograd.py)

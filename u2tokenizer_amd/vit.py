@@ -170,7 +170,7 @@ class ViT(nn.Module):
         return self.forward_features(x, keep_cls=True), []
 
 
-class ViT3DTower(nn.Module):
+class ViT3DTower(ops.Fp16Twin, nn.Module):
     """Drop-in for ViT3DTower (vit.py:132-176)."""
 
     def __init__(self, config):
@@ -218,6 +218,9 @@ class ViT3DTower(nn.Module):
             raise ValueError(f"Unexpected select layer: {self.select_layer}")
         if self.select_feature not in ("patch", "cls_patch"):
             raise ValueError(f"Unexpected select feature: {self.select_feature}")
+        twin = self._fp16_twin()
+        if twin is not None:
+            return twin(images).to(torch.float16)
         key = self._frozen_key() if self.share_frozen_features else None
         if key is not None and self._feat_cache is not None:
             k0, img0, out0 = self._feat_cache
