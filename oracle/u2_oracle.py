@@ -153,8 +153,8 @@ def spp_forward(sd: SD, p: str, x: torch.Tensor, cfg: PathConfig) -> torch.Tenso
     if cfg.proj_pooling_type == "spatial":
         g = cfg.grid
         x = x.reshape(B, g[0], g[1], g[2], dim).permute(0, 4, 1, 2, 3)
-        if x.dtype == torch.bfloat16:  # CPU torch has no bf16 avg_pool3d kernel: fp32 accumulate, one rounding
-            x = F.avg_pool3d(x.float(), kernel_size=ps, stride=ps).to(torch.bfloat16)
+        if x.dtype in (torch.bfloat16, torch.float16):  # CPU torch has no 16-bit avg_pool3d kernel: fp32 accumulate, one rounding
+            x = F.avg_pool3d(x.float(), kernel_size=ps, stride=ps).to(x.dtype)
         else:
             x = F.avg_pool3d(x, kernel_size=ps, stride=ps)
         x = x.permute(0, 2, 3, 4, 1).reshape(B, -1, dim)

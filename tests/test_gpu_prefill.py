@@ -101,6 +101,9 @@ def test_swiglu(ops):
 def test_gemm_swiglu_pair_equals_the_two_step_form(ops, rows, K, I):
     """u2tok_gemm_bf16 flag 512: SiLU(gate) * up in the epilogue of the packed gate | up product -- bit for bit the values of the
     GEMM followed by u2tok_swiglu_bf16 (same accumulation order, same rounding points), tiles that straddle M and I included."""
+    from u2tokenizer_amd import prefill
+    prefill._scratch.clear()            # (an ambient split-K scratch left by a fused prefill would slice the plain product's K
+    ops.set_gemm_scratch(None)          #  loop: fp32 partial sums in another order -- equal to rounding, not bit for bit)
     x = rnd(rows, K, seed=11).to(D)
     w = rnd(2 * I, K, scale=2.0 / math.sqrt(K), seed=12).to(D)
     assert ops.gemm_swiglu_supported(rows, K, I)
