@@ -95,6 +95,90 @@ def test_gemm_bt_fragment_reads_hit_the_rows_the_dma_wrote():
                     assert len(set(slots[16 * q:16 * q + 16])) == 16  # conflict-free ds_read_b128
 
 
+def _ring_lines():
+    import re
+    text = (CSRC / "gemm_bt_asm.inc").read_text()
+    body = re.search(r"#define GEMM_BT_ASM_TEXT_NJ2_RING \\\n(.*?)\n#define", text, re.S).group(1)
+    return re.findall(r'"(.*)\\n"', body)
+
+
+def test_gemm_bt_ring_schedule_and_counted_waits():
+    """Ring form (256 x 128 tiles, three LDS stages): every body of every wave issues the 12 pieces of ONE K tile into the stage
+    two ahead of the one it computes on, 32 MFMAs, 24 fragment reads (18 from its own stage, 6 from the next one behind the
+    barrier), and its one counted wait names exactly the pieces issued in front of it -- so that everything older (the whole
+    of the K tile the next iteration computes on) has landed."""
+    import re
+    lines = _ring_lines()
+    for w in range(4):
+        for st in range(3):
+            i0 = lines.index(f".Lbr_b{w}_{st}_%=:")
+            i1 = next(k for k in range(i0, len(lines)) if lines[k].startswith("s_cmp_lt_u32"))
+            body = lines[i0:i1]
+            assert sum(l.startswith("v_mfma") for l in body) == 32
+            assert sum(l.startswith("s_barrier") for l in body) == 1
+            bar = body.index("s_barrier")
+            wait = re.match(r"s_waitcnt vmcnt\((\d+)\)", body[bar - 1])
+            assert wait and int(wait.group(1)) == sum("buffer_load_dwordx4" in l for l in body[:bar])
+            assert sum("buffer_load_dwordx4" in l for l in body) == 12
+            # DMA targets: m0 = wave base register + stage * 49152 + 1024 * piece, stage = (st + 2) % 3
+            m0 = [int(re.match(r"s_add_u32 m0, s(\d+), (\d+)", l).group(2)) for l in body if l.startswith("s_add_u32 m0")]
+            assert sorted(x - 49152 * ((st + 2) % 3) for x in m0) == sorted([1024 * p for p in range(8)] + [1024 * p for p in range(4)])
+            # fragment reads: address registers of stage st in front of the barrier, of stage st + 1 behind it
+            regs = [int(re.match(r"ds_read_b128 v\[\d+:\d+\], v(\d+)", l).group(1)) for l in body if l.startswith("ds_read")]
+            nb = sum(l.startswith("ds_read") for l in body[:bar])
+            assert len(regs) == 24 and nb == 18
+            assert all(56 + 4 * st <= r < 60 + 4 * st or 68 + 4 * st <= r < 72 + 4 * st for r in regs[:nb])
+            nx = (st + 1) % 3
+            assert all(r in (56 + 4 * nx, 68 + 4 * nx) for r in regs[nb:])
+
+
+def test_gemm_bt_ring_fragment_reads_hit_the_rows_the_dma_wrote():
+    """Executable spec of the ring form's LDS layout: stage s = [A tile 32 KB | B tile 16 KB] at 49152 s; the address registers the
+    asm derives for stage s (v_add_u32 of 49152 s to the xor-ed stage-0 address) read, for every wave and k16 step, the
+    (row, K chunk) the MFMA operand wants out of bytes a DMA piece of that stage wrote; quarter waves are conflict-free."""
+    import re
+    lines = _ring_lines()
+    nj = 2
+    areg = {}
+    for l in lines:
+        m = re.match(r"v_xor_b32 v(\d+), (\d+), %\[(aa0|ab0)\]", l)
+        if m:
+            areg[int(m.group(1))] = (m.group(3)[1], int(m.group(2)), 0)
+        m = re.match(r"v_mov_b32 v(\d+), %\[(aa0|ab0)\]", l)
+        if m:
+            areg[int(m.group(1))] = (m.group(2)[1], 0, 0)
+    for l in lines:
+        m = re.match(r"v_add_u32 v(\d+), (\d+), v(\d+)", l)
+        if m:
+            mat, kx, _ = areg[int(m.group(3))]
+            areg[int(m.group(1))] = (mat, kx, int(m.group(2)))
+    assert len(areg) == 24 and sorted({x for _, _, x in areg.values()}) == [0, 49152, 98304]
+    reads = set()
+    for l in lines:
+        m = re.match(r"ds_read_b128 v\[(\d+):\d+\], v(\d+) offset:(\d+)", l)
+        if m:
+            mat, kx, stage = areg[int(m.group(2))]
+            reads.add((mat, kx >> 5, stage, int(m.group(3))))
+    assert reads == {("a", kk, 49152 * st, 4096 * i) for kk in range(4) for st in range(3) for i in range(4)} | \
+                    {("b", kk, 49152 * st, 4096 * j) for kk in range(4) for st in range(3) for j in range(nj)}
+    lds0 = _bt_layout(nj)          # one stage as the DMA pieces write it (same piece -> row / chunk formulas as the two-stage form)
+    assert max(lds0) < 49152
+    for wave in range(4):
+        wm, wn = wave >> 1, wave & 1
+        for (mat, kk, stage, off) in reads:
+            slots = []
+            for lane in range(64):
+                hi, l31 = lane >> 5, lane & 31
+                abk0 = l31 * 128 + ((hi ^ ((l31 >> 1) & 7)) << 4)
+                base = wm * 16384 if mat == "a" else 32768 + wn * (nj * 4096)
+                addr = ((base + abk0) ^ (kk << 5)) + stage + off
+                want_row = (wm * 128 if mat == "a" else wn * 32 * nj) + (off // 4096) * 32 + l31
+                assert lds0[addr - stage] == (mat, want_row, kk * 2 + hi), (wave, mat, kk, stage, off, lane)
+                slots.append((addr // 16) % 16)
+            for q in range(4):
+                assert len(set(slots[16 * q:16 * q + 16])) == 16
+
+
 def test_flash_dp2_asm_is_generated():
     want = "".join(_run("tools/gen_flash_dp2_asm.py", *f) for f in ((), ("--timed",), ("--exact",), ("--exact", "--timed")))
     assert want == (CSRC / "flash_dp2_asm.inc").read_text()
@@ -171,7 +255,7 @@ def test_generated_asm_passes_the_hazard_lint():
             seen += 1
             assert len(lines) > 200
             assert asm_lint.lint(name, lines) == []
-    assert seen == 7  # flash KV loop (exact / pre-scaled x plain / timed), GEMM K loop NJ = 4, NJ = 3 and NJ = 3 SwiGLU-pair
+    assert seen == 8  # flash KV loop (exact / pre-scaled x plain / timed), GEMM K loop NJ = 4, NJ = 3, NJ = 3 SwiGLU-pair, NJ = 2 ring
     # the linter itself: each rule fires on a minimal violation
     bad = {
         "R1": ["v_exp_f32 v1, v1", "v_add_f32 v2, v1, v1"],

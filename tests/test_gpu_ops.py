@@ -534,16 +534,17 @@ def test_gemm_ktile_major_weights(ops):
         torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("variant", [20, 21])
+@pytest.mark.parametrize("variant", [20, 21, 22])
 def test_gemm_big_tile_variants(ops, variant):
-    """gemm_bt.hip (persistent 256 x 256 / 256 x 192 big-tile kernel, asm K loop) forced on shapes with row / column
-    tails, several tiles per workgroup, every fused epilogue, batches; each product is launched 3 times and must
-    repeat bit for bit (a race between the LDS-DMA ring and the fragment reads would not).  Shapes the kernel cannot
-    take (K % 64 != 0, K < 128) fall through to the small-tile kernel."""
+    """gemm_bt.hip (persistent 256 x 256 / 256 x 192 big-tile kernel, asm K loop; 22 = the 256 x 128 three-stage ring form)
+    forced on shapes with row / column tails, several tiles per workgroup (K loops of 4 and 5 K tiles chained from tile to
+    tile: the ring form then enters at each of its three stages), every fused epilogue, batches; each product is launched 3
+    times and must repeat bit for bit (a race between the LDS-DMA ring and the fragment reads would not).  Shapes the
+    kernel cannot take (K % 64 != 0, K < 128) fall through to the small-tile kernel."""
     ops.set_option("gemm_big", variant)
     try:
         for (M, N, K) in [(256, 256, 128), (300, 200, 136), (77, 520, 192), (1000, 768, 1024), (2049, 768, 768),
-                          (5000, 1536, 256)]:
+                          (5000, 1536, 256), (9000, 2304, 256), (4100, 3000, 320), (9000, 1100, 128)]:
             a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
             ad, bd = a.to(D), b.to(D)
             outs = [ops.gemm(ad, bd).clone() for _ in range(3)]

@@ -3,20 +3,24 @@
 the 256 MB Infinity Cache holds -- what the pipeline sees at batch 1): default heuristic vs the big-tile kernel with 256 / 192-wide tiles
 and K slices.
 
-    python tools/bt_sweep.py [shape ...]          shape = MxNxK
+    python tools/bt_sweep.py [--root DIR] [--only NAME,NAME] [shape ...]          shape = MxNxK
 """
 import sys
 from pathlib import Path
 
 import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+ROOT = Path(sys.argv[sys.argv.index("--root") + 1]).resolve() if "--root" in sys.argv else Path(__file__).resolve().parents[1]
+if "--root" in sys.argv:                      # A/B of two builds on one box: import the package of another checkout
+    del sys.argv[sys.argv.index("--root"):sys.argv.index("--root") + 2]
+sys.path.insert(0, str(ROOT))
 from u2tokenizer_amd import ops  # noqa: E402
 
 SHAPES = [(256, 4096, 4096), (256, 12288, 4096), (2048, 4096, 4096), (1024, 8192, 4096), (1024, 6144, 4096), (1024, 4096, 4096),
           (1024, 4096, 12288), (1792, 8192, 4096), (2048, 12288, 4096)]
 CONFIGS = [("default", {}), ("classic", {"gemm_big": -1, "gemm_big_skinny": 0}),
-           # (round 3 also measured a 256 x 128-tile build of the kernel here, option value 22: profiles/r03_bt_sweep.log)
+           # (round 3 measured a TWO-stage 256 x 128-tile build of the kernel under the same option value: profiles/r03_bt_sweep.log)
+           ("256x128 ring", {"gemm_big": 22}),
            ("256x192", {"gemm_big": 21}), ("256x192 s2", {"gemm_big": 21, "gemm_big_splitk": 2}),
            ("256x192 s4", {"gemm_big": 21, "gemm_big_splitk": 4}),
            ("256x256", {"gemm_big": 20}), ("256x256 s2", {"gemm_big": 20, "gemm_big_splitk": 2}),
@@ -25,6 +29,13 @@ RESET = {"gemm_big": 0, "gemm_big_splitk": 0, "gemm_big_skinny": 1}
 
 
 def main():
+    global CONFIGS
+    if "--only" in sys.argv:
+        i = sys.argv.index("--only")
+        keep = sys.argv[i + 1].split(",")
+        del sys.argv[i:i + 2]
+        CONFIGS = [c for c in CONFIGS if c[0] in keep]
+    print(f"[{ROOT.name}]", flush=True)
     shapes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]] or SHAPES
     dev = torch.device("cuda", 0)
     ops.device_check()

@@ -111,12 +111,36 @@ def dma(mat, p, s_stage, s_k):
     e(f"buffer_load_dwordx4 {vo}, %[rs{mat}], {s(S_TMP)} offen lds")
 
 
-def mfma_block(b, extra):
-    """the 4 NJ MFMAs of one k16 step out of buffer b; extra(slot) emits the slot's companion instruction(s)"""
-    e("s_waitcnt lgkmcnt(0)")
+COUNTED = "--drain-waits" not in sys.argv   # fragment waits counted per slot (below); --drain-waits: one lgkmcnt(0) per k16 step
+
+
+def frag_waits():
+    """slot -> N of the `s_waitcnt lgkmcnt(N)` in front of that slot's MFMA.  The 4 + NJ fragments of a k16 step were read in
+    the order A0 B0 .. B(NJ-1) A1 A2 A3, one per slot, during the first 4 + NJ slots of the PREVIOUS step (LDS returns in
+    order); this step's slots issue the next step's reads the same way.  Slot (i, j) needs A_i and B_j: it may leave
+    outstanding the older reads behind the ones it needs plus the newer reads issued so far -- the last fragment (A3, read
+    in slot 3 + NJ) is waited for 3 NJ slots into the step instead of at its start, where one lgkmcnt(0) used to stall
+    the matrix pipe for the LDS latency of a read issued 4 (NJ = 2: 2) slots earlier."""
+    nread = 4 + NJ
+    waits, have = {}, -1
     for slot in range(4 * NJ):
         i, j = slot // NJ, slot % NJ
-        e(f"v_mfma_f32_32x32x16_bf16 {acc(i, j)}, {bfrag(b, j)}, {afrag(b, i)}, {acc(i, j)}")
+        need = max(0 if i == 0 else NJ + i, 1 + j)
+        if need > have:
+            have = need
+            waits[slot] = (nread - 1 - need) + min(slot, nread)
+    return waits
+
+
+def mfma_block(b, extra, a=None, bb=None):
+    """the 4 NJ MFMAs of one k16 step out of buffer b; extra(slot) emits the slot's companion instruction(s)"""
+    a, bb = a or afrag, bb or bfrag
+    waits = frag_waits() if COUNTED else {0: 0}
+    for slot in range(4 * NJ):
+        i, j = slot // NJ, slot % NJ
+        if slot in waits:
+            e(f"s_waitcnt lgkmcnt({waits[slot]})")
+        e(f"v_mfma_f32_32x32x16_bf16 {acc(i, j)}, {bb(b, j)}, {a(b, i)}, {acc(i, j)}")
         extra(slot)
 
 
@@ -266,6 +290,161 @@ def gen(nj, pair=False):
     e("s_nop 7")
 
 
+# ---- ring form: 256 x 128 tiles (NJ = 2), THREE LDS stages -------------------------------------------------------------
+# A 256 x 128 x 64 stage is 48 KB (A 32 KB | B 16 KB), so three fit (144 KB) and a K tile can be two iterations ahead of
+# its use: the pieces of K tile t+2 are issued over ALL FOUR k16 blocks of iteration t (into the stage tile t-1 left one
+# barrier ago) and have to land by the barrier of iteration t+1 -- between 3 and 7 blocks later; the two-stage form gives
+# a piece 1 .. 3 blocks (of 8 MFMAs at this tile width: its K loop measured 2500 cycles per K tile for 1024 cycles of
+# MFMA, profiles/r03_bt_sweep.log "256x128").  The wait in front of the barrier is COUNTED: s_waitcnt vmcnt(n), n = the
+# pieces of tile t+2 this wave has issued so far in the iteration; everything older -- all of tile t+1 -- has landed
+# (vector memory returns in order).  The loop is unrolled over the three stages (every LDS address is a register picked at
+# generation time or an immediate), entered at the stage that holds K tile 0 (operand st0 = 0 / 1 / 2) and left after
+# any body; as in the two-stage form it runs on into the next output tile of the workgroup: on exit K tile 0 of the next
+# tile has landed and ALL of its K tile 1 is in flight.
+RSTAGE = 49152
+RAA = [[56 + 4 * st + k for k in range(4)] for st in range(3)]        # v56..v67: A fragment addresses [stage][kk]
+RAB = [[68 + 4 * st + k for k in range(4)] for st in range(3)]        # v68..v79: B fragment addresses
+RBUF = 80                                                             # fragment double buffer: buf b at RBUF + 32 b
+RVLO, RVHI = 56, 143
+
+
+def gen_ring(nj=2):
+    global NJ
+    NJ = nj
+    del out[:]
+    nslot, nread, npb = 4 * NJ, 4 + NJ, 2 * NJ
+    npw = 8 + npb
+    window = 4 * nslot
+    sched = {w: {} for w in range(4)}
+    for n in range(npw):
+        for w in range(4):
+            g = (n * 4 + w) * window // (4 * npw)
+            sched[w].setdefault(g, []).append(n)
+
+    def rafrag(b, i):
+        return vr(RBUF + 32 * b + 4 * i, 4)
+
+    def rbfrag(b, j):
+        return vr(RBUF + 32 * b + 16 + 4 * j, 4)
+
+    def rread(b, st, kk, n):
+        order = [("a", 0)] + [("b", j) for j in range(NJ)] + [("a", 1), ("a", 2), ("a", 3)]
+        m, idx = order[n]
+        if m == "a":
+            e(f"ds_read_b128 {rafrag(b, idx)}, {v(RAA[st][kk])} offset:{4096 * idx}")
+        else:
+            e(f"ds_read_b128 {rbfrag(b, idx)}, {v(RAB[st][kk])} offset:{4096 * idx}")
+
+    def rpiece(n, st, s_k):
+        """piece n of this wave (A pieces 0..7, then B) of a K tile into stage st; s_k = (A, B) offset registers of the K tile"""
+        mat, p = ("a", n) if n < 8 else ("b", n - 8)
+        e(f"s_add_u32 m0, {s(S_DA if mat == 'a' else S_DB)}, {RSTAGE * st + 1024 * p}")
+        row = (S_ROWA if mat == "a" else S_ROWB)[p >> 1]
+        e(f"s_add_u32 {s(S_TMP)}, {s(s_k[0] if mat == 'a' else s_k[1])}, {s(row)}")
+        e(f"buffer_load_dwordx4 %[v{mat}{p & 1}], %[rs{mat}], {s(S_TMP)} offen lds")
+
+    def rblock(b, extra):
+        mfma_block(b, extra, rafrag, rbfrag)
+
+    K0, K1, K2 = (S_K0A, S_K0B), (S_K1A, S_K1B), (S_K2A, S_K2B)
+    # ---- setup (common)
+    for k in range(4):
+        if k:
+            e(f"v_xor_b32 {v(RAA[0][k])}, {32 * k}, %[aa0]")
+            e(f"v_xor_b32 {v(RAB[0][k])}, {32 * k}, %[ab0]")
+        else:
+            e(f"v_mov_b32 {v(RAA[0][0])}, %[aa0]")
+            e(f"v_mov_b32 {v(RAB[0][0])}, %[ab0]")
+    for st in (1, 2):
+        for k in range(4):
+            e(f"v_add_u32 {v(RAA[st][k])}, {RSTAGE * st}, {v(RAA[0][k])}")
+            e(f"v_add_u32 {v(RAB[st][k])}, {RSTAGE * st}, {v(RAB[0][k])}")
+    e(f"s_mov_b32 {s(S_ROWA[0])}, 0")
+    for q in (1, 2, 3):
+        e(f"s_add_u32 {s(S_ROWA[q])}, {s(S_ROWA[q - 1])}, %[lda16]")
+    e(f"s_mov_b32 {s(S_ROWB[0])}, 0")
+    for q in (1, 2, 3):
+        e(f"s_add_u32 {s(S_ROWB[q])}, {s(S_ROWB[q - 1])}, %[ldb16]")
+    e(f"s_mov_b32 {s(S_KT)}, 0")
+    e(f"s_lshl_b32 {s(S_DA)}, %[wave], 13")
+    e(f"s_mul_i32 {s(S_DB)}, %[wave], {2048 * NJ}")
+    e(f"s_add_u32 {s(S_DB)}, {s(S_DB)}, 0x8000")
+    e(f"s_mov_b32 {s(S_K0A)}, %[base_a]")
+    e(f"s_mov_b32 {s(S_K0B)}, %[base_b]")
+    e(f"s_add_u32 {s(S_K1A)}, %[base_a], 128")
+    e(f"s_add_u32 {s(S_K1B)}, %[base_b], 128")
+    e(f"s_add_u32 {s(S_K2A)}, %[base_a], 256")
+    e(f"s_add_u32 {s(S_K2B)}, %[base_b], 256")
+    e("s_cmp_eq_u32 %[nkt], 2")
+    e(f"s_cselect_b32 {s(S_K2A)}, %[nbase_a], {s(S_K2A)}")
+    e(f"s_cselect_b32 {s(S_K2B)}, %[nbase_b], {s(S_K2B)}")
+    for w in (1, 2, 3):
+        e(f"s_cmp_eq_u32 %[wave], {w}")
+        e(f"s_cbranch_scc1 .Lbr_w{w}_%=")
+    for w in range(4):
+        if w:
+            e(f".Lbr_w{w}_%=:")
+        # first tile of the workgroup (st0 = 0 then): K tiles 0 and 1 at once; tile 0 has landed when only tile 1's pieces
+        # are outstanding
+        e("s_cmp_eq_u32 %[first], 0")
+        e(f"s_cbranch_scc1 .Lbr_cont{w}_%=")
+        for n in range(npw):
+            rpiece(n, 0, K0)
+        for n in range(npw):
+            rpiece(n, 1, K1)
+        e(f"s_waitcnt vmcnt({npw})")
+        e("s_barrier")
+        e(f".Lbr_cont{w}_%=:")
+        for st in (1, 2):
+            e(f"s_cmp_eq_u32 %[st0], {st}")
+            e(f"s_cbranch_scc1 .Lbr_e{w}_{st}_%=")
+        for st in range(3):                      # entry st: fragments of k16 step 0 of K tile 0, then body st
+            if st:
+                e(f".Lbr_e{w}_{st}_%=:")
+            for n in range(nread):
+                rread(0, st, 0, n)
+            e(f"s_branch .Lbr_b{w}_{st}_%=")
+        IN_LOOP[0] = True
+        for st in range(3):
+            e(f".Lbr_b{w}_{st}_%=:")
+            tgt, nxt = (st + 2) % 3, (st + 1) % 3
+
+            def xk(blk, rb, rst, rkk):
+                def f(slot):
+                    if slot < nread:
+                        rread(rb, rst, rkk, slot)
+                    for n in sched[w].get(blk * nslot + slot, []):
+                        rpiece(n, tgt, K2)
+                return f
+
+            rblock(0, xk(0, 1, st, 1))
+            rblock(1, xk(1, 0, st, 2))
+            rblock(0, xk(2, 1, st, 3))
+            issued = sum(len(sched[w].get(g, [])) for g in range(3 * nslot))
+            e(f"s_waitcnt vmcnt({issued})")
+            e("s_barrier")
+            rblock(1, xk(3, 0, nxt, 0))
+            e(f"s_add_u32 {s(S_KT)}, {s(S_KT)}, 1")
+            e(f"s_add_u32 {s(S_K2A)}, {s(S_K2A)}, 128")
+            e(f"s_add_u32 {s(S_K2B)}, {s(S_K2B)}, 128")
+            e(f"s_add_u32 {s(S_TMP)}, {s(S_KT)}, 2")
+            e(f"s_cmp_eq_u32 {s(S_TMP)}, %[nkt]")
+            e(f"s_cselect_b32 {s(S_K2A)}, %[nbase_a], {s(S_K2A)}")
+            e(f"s_cselect_b32 {s(S_K2B)}, %[nbase_b], {s(S_K2B)}")
+            e(f"s_cmp_lt_u32 {s(S_KT)}, %[nkt]")
+            if st < 2:
+                e(f"s_cbranch_scc0 .Lbr_done_%=")
+            else:
+                e(f"s_cbranch_scc1 .Lbr_b{w}_0_%=")
+        IN_LOOP[0] = False
+        if w < 3:
+            e("s_branch .Lbr_done_%=")
+    e(".Lbr_done_%=:")
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_nop 15")
+    e("s_nop 7")
+
+
 print("// GENERATED by tools/gen_gemm_bt_asm.py -- do not edit")
 print("// clang-format off")
 for nj, abl in ((4, ""), (3, ""), (3, "pair")):   # (NJ = 2, 256 x 128 tiles, generates too: measured slower than both on
@@ -277,9 +456,15 @@ for nj, abl in ((4, ""), (3, ""), (3, "pair")):   # (NJ = 2, 256 x 128 tiles, ge
     print(f"#define GEMM_BT_ASM_TEXT_NJ{nj}{('_' + abl.upper()) if abl else ''} \\")
     for i, line in enumerate(out):
         print(f'  "{line}\\n"' + (" \\" if i + 1 < len(out) else ""))
-clob = [f'"v{i}"' for i in range(VLO, VHI + 1)] + [f'"s{i}"' for i in range(SLO, SHI + 1)] + ['"scc"', '"memory"']
-print("#define GEMM_BT_ASM_CLOBBERS \\")
-for i in range(0, len(clob), 12):
-    tail = ", \\" if i + 12 < len(clob) else ""
-    print("  " + ", ".join(clob[i:i + 12]) + tail)
+ABL.clear()
+gen_ring(2)
+print("#define GEMM_BT_ASM_TEXT_NJ2_RING \\")
+for i, line in enumerate(out):
+    print(f'  "{line}\\n"' + (" \\" if i + 1 < len(out) else ""))
+for name, lo, hi in (("GEMM_BT_ASM_CLOBBERS", VLO, VHI), ("GEMM_BT_ASM_CLOBBERS_RING", RVLO, RVHI)):
+    clob = [f'"v{i}"' for i in range(lo, hi + 1)] + [f'"s{i}"' for i in range(SLO, SHI + 1)] + ['"scc"', '"memory"']
+    print(f"#define {name} \\")
+    for i in range(0, len(clob), 12):
+        tail = ", \\" if i + 12 < len(clob) else ""
+        print("  " + ", ".join(clob[i:i + 12]) + tail)
 print("// clang-format on")

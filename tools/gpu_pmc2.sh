@@ -18,7 +18,8 @@ PASSES=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MF
 # collect them one per pass as tools/gpu_round.sh does; with SQ_INSTS_VALU added to the LDS set the profiled process
 # never exited and every pass ran into its timeout (the counters were still written).  Keep the per-pass timeout short.
 PASSES+=("FETCH_SIZE" "WRITE_SIZE")
-run flash5 flash 3 0 5
+run flash7 flash 3 0 7 0
+run flash7pre flash 3 0 7 1
 run qkv_bt192 gemm 3 21
 run fc1_gelu128 gemmmlp 3 -1
 run skinny64 gemm256 16 0

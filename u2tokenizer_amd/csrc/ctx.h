@@ -16,7 +16,7 @@ namespace u2 {
 struct Options {
   int gemm_tile = 0;        // 0 heuristic, 64 / 128 force the small-tile kernel's tile
   int gemm_splitk = 0;      // -1 never, 0 heuristic, 2..16 force that many K slices where scratch allows
-  int gemm_big = 0;         // -1 never, 0 heuristic, 20 / 21 force the 256x256 / 256x192 big-tile kernel
+  int gemm_big = 0;         // -1 never, 0 heuristic, 20 / 21 / 22 force the 256x256 / 256x192 / 256x128 (ring) big-tile kernel
   int gemm_big_grid = 256;  // persistent workgroups of the big-tile kernel
   int gemm_big_gelu = 0;    // 1: GELU products may take the big-tile kernel too
   int gemm_big_splitk = 0;  // K slices of a FORCED big-tile launch (gemm_big = 20 / 21): measurements, tests

@@ -252,14 +252,20 @@ __device__ __forceinline__ void pp_epilogue(const GemmDesc& d, f32x16 (&acc)[2][
 #include "gemm_bt_asm.inc"
 typedef int bt_i32x4 __attribute__((ext_vector_type(4)));
 
+// NJ = 2 is the RING form (256 x 128 tiles, variant 22): three LDS stages of 48 KB, K tile t + 2 issued during iteration t and
+// waited for with a counted vmcnt one iteration later (tools/gen_gemm_bt_asm.py, gen_ring) -- the tile for products whose
+// 256-wide tiles would leave half of the CUs without work (M = 2048 / 1024 against E x E and E x 2E weights: 256 tiles).
 template <int NJ, bool PAIR = false, bool SPLIT = false>  // 32-column blocks per wave: tile = 256 x (64 NJ)
 __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
   static_assert(!(PAIR && SPLIT), "the pair form is not sliced");
   static_assert(!PAIR || NJ == 3, "the pair form exists for 256 x 192 tiles");
-  static_assert(NJ == 3 || NJ == 4, "256 x 192 / 256 x 256 tiles");
+  static_assert(NJ == 2 || NJ == 3 || NJ == 4, "256 x 128 (ring) / 256 x 192 / 256 x 256 tiles");
+  static_assert(NJ != 2 || (!PAIR && !SPLIT), "the ring form is plain");
   constexpr int BN = 64 * NJ;
+  constexpr bool RING = NJ == 2;
   using CFG = BTCfg<BN>;
-  __shared__ __attribute__((aligned(1024))) char lds[131072];  // [stage][A tile 32 KB | B tile <= 32 KB]
+  // two stages: [stage][A tile 32 KB | B tile <= 32 KB];  ring: three stages of [A tile 32 KB | B tile 16 KB]
+  __shared__ __attribute__((aligned(1024))) char lds[RING ? 147456 : 131072];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
   const int lda16 = 16 * (int)d.lda * 2, ldb16 = 16 * (int)d.ldb * 2;
   const int nkt_all = d.K >> 6;
   const bool chain = d.nz == 1;  // one K loop runs on from tile to tile (same descriptors)
-  uint32_t st0 = 0;              // LDS stage that holds K tile 0 of the current output tile
+  uint32_t st0 = 0;              // LDS stage that holds K tile 0 of the current output tile (byte offset 0 / 0x10000; ring: index 0..2)
   int z, bm0, bn0;
   pp_tile<BN>(d, 0, gd, bid, total, tiles_mn, z, bm0, bn0);
   for (int r = 0; r < my_tiles; ++r) {
@@ -324,7 +330,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
     rsb[3] = 0x00020000;
     const int first = (r == 0 || !chain) ? 1 : 0;
     if (first) st0 = 0;
-    const uint32_t aa0 = (lds_u32 + wm * 16384 + abk0) ^ st0, ab0 = (lds_u32 + 32768 + wn * (NJ * 4096) + abk0) ^ st0;
+    const uint32_t aa0 = (lds_u32 + wm * 16384 + abk0) ^ (RING ? 0u : st0);  // (ring: stage 0's addresses, the asm adds the stage)
+    const uint32_t ab0 = (lds_u32 + 32768 + wn * (NJ * 4096) + abk0) ^ (RING ? 0u : st0);
     // (readfirstlane: the values are uniform, but hipcc keeps loop-carried tile coordinates in VGPRs)
     const int base_a = __builtin_amdgcn_readfirstlane((bm0 * (int)d.lda + kt0 * 64) * 2);
     const int base_b = __builtin_amdgcn_readfirstlane(((PAIR ? bn0 >> 1 : bn0) * (int)d.ldb + kt0 * 64) * 2);
@@ -348,7 +355,13 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
   [va0] "v"(va0), [va1] "v"(va1), [vb0] "v"(vb0), [vb1] "v"(vb1), [aa0] "v"(aa0), [ab0] "v"(ab0), [rsa] "s"(rsa),     \
       [rsb] "s"(rsb), [lda16] "s"(lda16), [nkt] "s"(nkt), [wave] "s"(wave), [st0] "s"(st0_s), [first] "s"(first_s),   \
       [base_a] "s"(base_a), [base_b] "s"(base_b), [nbase_a] "s"(nbase_a), [nbase_b] "s"(nbase_b)
-    if constexpr (NJ == 4) {
+    if constexpr (NJ == 2) {
+      asm volatile(GEMM_BT_ASM_TEXT_NJ2_RING
+                   : [c000] "+a"(acc[0][0][0]), [c001] "+a"(acc[0][0][1]), [c010] "+a"(acc[0][1][0]), [c011] "+a"(acc[0][1][1]),
+                     [c100] "+a"(acc[1][0][0]), [c101] "+a"(acc[1][0][1]), [c110] "+a"(acc[1][1][0]), [c111] "+a"(acc[1][1][1])
+                   : BT_IN, [ldb16] "s"(ldb16)
+                   : GEMM_BT_ASM_CLOBBERS_RING);
+    } else if constexpr (NJ == 4) {
       asm volatile(GEMM_BT_ASM_TEXT_NJ4
                    : BT_ACC3(0, 0), [c003] "+a"(acc[0][0][3]), BT_ACC3(0, 1), [c013] "+a"(acc[0][1][3]), BT_ACC3(1, 0),
                      [c103] "+a"(acc[1][0][3]), BT_ACC3(1, 1), [c113] "+a"(acc[1][1][3])
@@ -395,7 +408,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
       pp_epilogue<CFG, 0, PAIR>(d, acc[0], z, bm0 + wm * 128, bn0, 0, wn, lane, bpre, fast);
       pp_epilogue<CFG, 0, PAIR>(d, acc[1], z, bm0 + wm * 128, bn0, 1, wn, lane, bpre, fast);
     }
-    st0 ^= (uint32_t)(nkt & 1) << 16;
+    if constexpr (RING) st0 = (st0 + (uint32_t)nkt) % 3u;
+    else st0 ^= (uint32_t)(nkt & 1) << 16;
     z = zn; bm0 = bm0n; bn0 = bn0n;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last K loop's prefetch into LDS
@@ -409,7 +423,9 @@ static int bt_launch(GemmDesc d, hipStream_t stream) {
   const int64_t total = (int64_t)d.tiles_m * d.tiles_n * (d.ksplit > 1 ? d.ksplit : d.nz);
   if (total > 0x3fffffff) return U2_ERR_ARG;
   const int grid = (int)std::min<int64_t>(total, opts().gemm_big_grid);
-  if constexpr (!PAIR) {
+  if constexpr (NJ == 2) {
+    if (d.ksplit > 1) return U2_ERR_ARG;
+  } else if constexpr (!PAIR) {
     if (d.ksplit > 1) {
       hipLaunchKernelGGL((gemm_bt_kernel<NJ, false, true>), dim3(grid), dim3(256), 0, stream, d);
       return gemm_splitk_reduce(d, stream);
@@ -448,9 +464,9 @@ static int bt_slices(GemmDesc& d, int64_t tiles, int want, hipStream_t stream) {
   return 1;
 }
 
-// variants: 20 = 256 x 256, 21 = 256 x 192 tiles
+// variants: 20 = 256 x 256, 21 = 256 x 192, 22 = 256 x 128 tiles (ring form)
 static int bt_launch_variant(int v, const GemmDesc& d, hipStream_t stream) {
-  return v == 20 ? bt_launch<4>(d, stream) : bt_launch<3>(d, stream);
+  return v == 20 ? bt_launch<4>(d, stream) : v == 22 ? bt_launch<2>(d, stream) : bt_launch<3>(d, stream);
 }
 
 // Which tile (tools/gpu_check.py ppperf on MI355X, random operands; DESIGN.md section 3 has the tables): the kernel
@@ -473,6 +489,19 @@ static int bt_pick(const GemmDesc& d) {
   const double c4 = (double)r4, c3 = 0.9 * (double)r3;  // a 192-wide tile takes ~0.9 of the time of a 256-wide one
   if (c3 < c4) return fill3 >= 0.7 ? 21 : (fill4 >= 0.7 ? 20 : 0);
   return fill4 >= 0.7 ? 20 : (fill3 >= 0.7 ? 21 : 0);
+}
+
+// The ring form (256 x 128 tiles, variant 22) for products whose 256- and 192-wide tiles leave the CUs a partial round
+// (bt_pick: fill < 70 %) while the 128-wide ones make ONE round that is at least three-quarters full: M = 2048 rows against an
+// E x E weight (the SVR's output projections), 1024 against 2E x E (the TTA's text k | v), 2048 x 4096 x 6144 (projector) --
+// 256 tiles each.  tools/bt_sweep.py, cold weights, us (128^2 kernel -> here; vendor library beside it): 89.7 -> 69.4 (65.9),
+// 82.0 -> 64.4 (62.9), 115.1 -> 95.5 (profiles/r04_bt_ring_sweep.log).  With 128 tiles (1024 x 4096 x 4096) it ties the 128^2 kernel.
+static int bt_pick_ring(const GemmDesc& d) {
+  if (!bt_legal(d) || d.K < 512) return 0;
+  if ((d.flags & GEMM_GELU) && !opts().gemm_big_gelu) return 0;
+  const int gmax = opts().gemm_big_grid;
+  const int64_t t2 = cdiv(d.M, 256) * cdiv(d.N, 128) * d.nz;
+  return (t2 * 4 > (int64_t)gmax * 3 && t2 <= gmax) ? 22 : 0;
 }
 
 // Products that leave the 256 CUs a partial round of big tiles, sliced along K so that (tiles x slices) fills them -- the
@@ -520,7 +549,7 @@ int gemm_big_try(const GemmDesc& d, hipStream_t stream) {
   if (mode > 0) {  // forced (tests, measurements)
     if (!bt_legal(d)) return 0;
     GemmDesc ds = d;
-    bt_slices(ds, 0, opts().gemm_big_splitk, stream);
+    if (mode != 22) bt_slices(ds, 0, opts().gemm_big_splitk, stream);
     const int e = bt_launch_variant(mode, ds, stream);
     return e == U2_OK ? 1 : e;
   }
@@ -552,7 +581,8 @@ int gemm_big_try(const GemmDesc& d, hipStream_t stream) {
     e = gemm_classic(tail, stream);
     return e == U2_OK ? 1 : e;
   }
-  const int v = bt_pick(d);
+  int v = bt_pick(d);
+  if (v == 0) v = bt_pick_ring(d);
   if (v == 0) return 0;
   const int e = bt_launch_variant(v, d, stream);
   return e == U2_OK ? 1 : e;
