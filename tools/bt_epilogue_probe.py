@@ -13,6 +13,9 @@ from u2tokenizer_amd import ops  # noqa: E402
 dev = torch.device("cuda", 0)
 ops.device_check()
 tag = root.name
+if "--big" in sys.argv:                      # force a big-tile variant (gemm_big option)
+    ops.set_option("gemm_big", int(sys.argv[sys.argv.index("--big") + 1]))
+    tag += " big=" + sys.argv[sys.argv.index("--big") + 1]
 for (M, N, K, res) in [(16384, 2304, 768, False), (16384, 768, 768, True), (16384, 768, 3072, True), (16384, 3072, 768, False),
                        (2048, 12288, 4096, False)]:
     a = torch.randn(M, K, device=dev).to(torch.bfloat16)
