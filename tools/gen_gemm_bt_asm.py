@@ -40,7 +40,22 @@ S_ROWA = [43, 44, 45, 46]
 S_ROWB = [47, 48, 49, 50]
 S_DA, S_DB = 51, 52          # LDS byte offsets of this wave's DMA rows in the A / B tile of stage 0
 S_K1B, S_K2B, S_K0A, S_K0B = 53, 54, 55, 56   # scalar byte offsets of K tiles kt+1 / kt+2 (and 0) per matrix
-SLO, SHI = 36, 56
+S_PFA, S_PFB = 57, 58        # scalar byte offsets of the K tile the L2 prefetch touches (kt + PF_D), per matrix
+SLO, SHI = 36, 58
+
+
+def _flag(name, default):
+    return sys.argv[sys.argv.index(name) + 1] if name in sys.argv else default
+
+
+# L2 prefetch (four-wave forms): the K loop is bound by its LDS-DMA stream, and that stream by latency -- 2048 x 12288 x 4096 with
+# cold weights: the DMA alone 160 us, the MFMAs alone 110, together 197 (profiles/r04_bt_kloop_ablations.log); at most one K
+# tile (two in the ring form) is in flight per CU against ~1.5 us from HBM.  Every iteration each wave touches, PF_D K tiles
+# ahead, one dword of each 128-byte row segment of its share of the A and B tiles (buffer_load_dword ... lds into a scratch
+# corner of the LDS: no registers, nothing to wait for) so that the DMA pieces of that tile find their lines in the L2.
+# Issued last in front of the barrier's wait, which becomes vmcnt(number of prefetch loads): everything older has landed.
+PF_D = int(_flag("--pf", "0"))           # 0 = off
+PF_OPS = _flag("--pf-ops", "ab")
 
 out = []
 ABL = set()   # measurement-only builds (wrong results): "nodma" / "noread" / "nobar" / "nomfma" inside the K loop
@@ -132,6 +147,47 @@ def frag_waits():
     return waits
 
 
+def prefetch(dummy):
+    """the iteration's L2 prefetch loads (see PF_D); returns how many were issued"""
+    if not PF_D:
+        return 0
+    e(f"s_mov_b32 m0, {dummy}")
+    e("s_nop 0")
+    n = 0
+    for mat, reg in (("a", S_PFA), ("b", S_PFB)):
+        if mat in PF_OPS:
+            e(f"buffer_load_dword %[pf{mat}], %[rs{mat}], {s(reg)} offen lds")
+            n += 1
+    return n
+
+
+def prefetch_setup():
+    """S_PF? = offset of K tile PF_D: base + 128 PF_D, or the next output tile's (nbase + 128 (PF_D - nkt)) when this tile is shorter"""
+    if not PF_D:
+        return
+    e(f"s_sub_u32 {s(S_TMP)}, {PF_D}, %[nkt]")
+    e(f"s_lshl_b32 {s(S_TMP)}, {s(S_TMP)}, 7")
+    e(f"s_add_u32 {s(S_PFA)}, %[nbase_a], {s(S_TMP)}")
+    e(f"s_add_u32 {s(S_PFB)}, %[nbase_b], {s(S_TMP)}")
+    e(f"s_add_u32 {s(S_SA)}, %[base_a], {128 * PF_D}")
+    e(f"s_add_u32 {s(S_SB)}, %[base_b], {128 * PF_D}")
+    e(f"s_cmp_lt_u32 {PF_D}, %[nkt]")
+    e(f"s_cselect_b32 {s(S_PFA)}, {s(S_SA)}, {s(S_PFA)}")
+    e(f"s_cselect_b32 {s(S_PFB)}, {s(S_SB)}, {s(S_PFB)}")
+
+
+def prefetch_advance():
+    """after kt += 1: the prefetch offsets follow; K tile kt + PF_D = nkt is K tile 0 of the next output tile"""
+    if not PF_D:
+        return
+    e(f"s_add_u32 {s(S_PFA)}, {s(S_PFA)}, 128")
+    e(f"s_add_u32 {s(S_PFB)}, {s(S_PFB)}, 128")
+    e(f"s_add_u32 {s(S_TMP)}, {s(S_KT)}, {PF_D}")
+    e(f"s_cmp_eq_u32 {s(S_TMP)}, %[nkt]")
+    e(f"s_cselect_b32 {s(S_PFA)}, %[nbase_a], {s(S_PFA)}")
+    e(f"s_cselect_b32 {s(S_PFB)}, %[nbase_b], {s(S_PFB)}")
+
+
 def mfma_block(b, extra, a=None, bb=None):
     """the 4 NJ MFMAs of one k16 step out of buffer b; extra(slot) emits the slot's companion instruction(s)"""
     a, bb = a or afrag, bb or bfrag
@@ -205,6 +261,8 @@ def gen(nj, pair=False):
     e("s_cmp_eq_u32 %[nkt], 2")
     e(f"s_cselect_b32 {s(S_K2A)}, %[nbase_a], {s(S_K2A)}")
     e(f"s_cselect_b32 {s(S_K2B)}, %[nbase_b], {s(S_K2B)}")
+    if not pair:
+        prefetch_setup()
     for w in (1, 2, 3):
         e(f"s_cmp_eq_u32 %[wave], {w}")
         e(f"s_cbranch_scc1 .Lbt_w{w}_%=")
@@ -250,7 +308,8 @@ def gen(nj, pair=False):
         mfma_block(0, xk(1, 1, 1))
         mfma_block(1, xk(2, 0, 2))
         mfma_block(0, lambda slot: read(1, 3, slot) if slot < nread else None)
-        e("s_waitcnt vmcnt(0)")
+        npf = 0 if pair else prefetch(131072)
+        e(f"s_waitcnt vmcnt({npf})")
         e("s_barrier")
         for k in range(4):                                   # fragment addresses -> the other stage
             e(f"v_xor_b32 {v(AA[k])}, 0x10000, {v(AA[k])}")
@@ -277,6 +336,8 @@ def gen(nj, pair=False):
         e(f"s_cmp_eq_u32 {s(S_TMP)}, %[nkt]")
         e(f"s_cselect_b32 {s(S_K2A)}, %[nbase_a], {s(S_K2A)}")
         e(f"s_cselect_b32 {s(S_K2B)}, %[nbase_b], {s(S_K2B)}")
+        if not pair:
+            prefetch_advance()
         e(f"s_cmp_lt_u32 {s(S_KT)}, %[nkt]")
         e(f"s_cbranch_scc1 .Lbt_loop{w}_%=")
         IN_LOOP[0] = False
@@ -378,6 +439,7 @@ def gen_ring(nj=2):
     e("s_cmp_eq_u32 %[nkt], 2")
     e(f"s_cselect_b32 {s(S_K2A)}, %[nbase_a], {s(S_K2A)}")
     e(f"s_cselect_b32 {s(S_K2B)}, %[nbase_b], {s(S_K2B)}")
+    prefetch_setup()
     for w in (1, 2, 3):
         e(f"s_cmp_eq_u32 %[wave], {w}")
         e(f"s_cbranch_scc1 .Lbr_w{w}_%=")
@@ -421,6 +483,7 @@ def gen_ring(nj=2):
             rblock(1, xk(1, 0, st, 2))
             rblock(0, xk(2, 1, st, 3))
             issued = sum(len(sched[w].get(g, [])) for g in range(3 * nslot))
+            issued += prefetch(147456)
             e(f"s_waitcnt vmcnt({issued})")
             e("s_barrier")
             rblock(1, xk(3, 0, nxt, 0))
@@ -431,6 +494,7 @@ def gen_ring(nj=2):
             e(f"s_cmp_eq_u32 {s(S_TMP)}, %[nkt]")
             e(f"s_cselect_b32 {s(S_K2A)}, %[nbase_a], {s(S_K2A)}")
             e(f"s_cselect_b32 {s(S_K2B)}, %[nbase_b], {s(S_K2B)}")
+            prefetch_advance()
             e(f"s_cmp_lt_u32 {s(S_KT)}, %[nkt]")
             if st < 2:
                 e(f"s_cbranch_scc0 .Lbr_done_%=")

@@ -266,7 +266,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
   constexpr bool RING = NJ == 2;
   using CFG = BTCfg<BN>;
   // two stages: [stage][A tile 32 KB | B tile <= 32 KB];  ring: three stages of [A tile 32 KB | B tile 16 KB]
-  __shared__ __attribute__((aligned(1024))) char lds[RING ? 147456 : 131072];
+  // (+ 256 bytes behind the stages: where the K loop's L2-prefetch loads put their dwords, never read)
+  __shared__ __attribute__((aligned(1024))) char lds[(RING ? 147456 : 131072) + 256];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -292,6 +293,9 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
   const int rb = (PAIR ? 0 : wave * (16 * NJ)) + pr;
   const int vb0 = (rb * (int)d.ldb + ((pc ^ sw0) << 3)) * 2;
   const int vb1 = ((rb + 8) * (int)d.ldb + ((pc ^ sw0 ^ 4) << 3)) * 2;
+  // L2 prefetch of the K loop (gen_gemm_bt_asm.py, PF_D): lane l touches one dword of row l of the wave's 64 A rows / 16 NJ B rows
+  const int pfa = (wave * 64 + lane) * (int)d.lda * 2;
+  const int pfb = (wave * (16 * NJ) + lane % (16 * NJ)) * (int)d.ldb * 2;
   [[maybe_unused]] int rowb[3] = {0, 0, 0};
   if constexpr (PAIR) {
 #pragma unroll
@@ -355,7 +359,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
 #define BT_IN                                                                                                         \
   [va0] "v"(va0), [va1] "v"(va1), [vb0] "v"(vb0), [vb1] "v"(vb1), [aa0] "v"(aa0), [ab0] "v"(ab0), [rsa] "s"(rsa),     \
       [rsb] "s"(rsb), [lda16] "s"(lda16), [nkt] "s"(nkt), [wave] "s"(wave), [st0] "s"(st0_s), [first] "s"(first_s),   \
-      [base_a] "s"(base_a), [base_b] "s"(base_b), [nbase_a] "s"(nbase_a), [nbase_b] "s"(nbase_b)
+      [base_a] "s"(base_a), [base_b] "s"(base_b), [nbase_a] "s"(nbase_a), [nbase_b] "s"(nbase_b), [pfa] "v"(pfa),     \
+      [pfb] "v"(pfb)
     if constexpr (NJ == 2) {
       asm volatile(GEMM_BT_ASM_TEXT_NJ2_RING
                    : [c000] "+a"(acc[0][0][0]), [c001] "+a"(acc[0][0][1]), [c010] "+a"(acc[0][1][0]), [c011] "+a"(acc[0][1][1]),
