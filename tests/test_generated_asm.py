@@ -179,110 +179,6 @@ def test_gemm_bt_ring_fragment_reads_hit_the_rows_the_dma_wrote():
                 assert len(set(slots[16 * q:16 * q + 16])) == 16
 
 
-W8 = {256: dict(ai=4, bj=2, wn=4, stages=2), 192: dict(ai=2, bj=3, wn=2, stages=2), 128: dict(ai=2, bj=2, wn=2, stages=3)}
-
-
-def _w8_lines(bn):
-    import re
-    text = (CSRC / "gemm_bt_asm.inc").read_text()
-    body = re.search(rf"#define GEMM_BT8_ASM_TEXT_{bn} \\\n(.*?)\n#define", text, re.S).group(1)
-    return re.findall(r'"(.*)\\n"', body)
-
-
-def _w8_layout(bn):
-    """One LDS stage of gemm_bt8_kernel<BN> as its eight waves' DMA pieces write it (lane offsets va0 / va1 / vb0 / vb1 and the
-    scalar row-group offsets of gemm_bt.hip): byte address -> (matrix, tile row, 16-byte K chunk)."""
-    lds = {}
-    for wave in range(8):
-        for lane in range(64):
-            pr, sw0, pc = lane >> 3, (lane >> 4) & 3, lane & 7
-            for mat, rows, base in (("a", 32, 0), ("b", bn // 8, 32768)):
-                wsw = 4 if (mat == "b" and bn == 192 and wave & 1) else 0
-                for p in range(rows // 8):
-                    row = wave * rows + (p >> 1) * 16 + (8 if p & 1 else 0) + pr     # v?0 / v?1 (+ 8 rows) + S_ROW?[p >> 1]
-                    chunk = pc ^ sw0 ^ (4 if p & 1 else 0) ^ wsw
-                    addr = base + wave * rows * 128 + p * 1024 + lane * 16
-                    assert addr not in lds
-                    lds[addr] = (mat, row, chunk)
-    return lds
-
-
-def test_gemm_bt8_schedule_and_layout():
-    """Eight-wave forms: per wave and body 4 + BN / 64 DMA pieces of one K tile, 4 AI BJ MFMAs, 4 (AI + BJ) fragment reads, one
-    barrier behind a wait that leaves exactly the pieces of the tile in flight (ring) or none (two stages); every fragment
-    read returns the (row, K chunk) its MFMA operand wants from bytes a DMA piece of that stage wrote -- the row's chunk p
-    sits at position p ^ ((row >> 1) & 7), odd waves of the 192-wide form included -- and is conflict-free."""
-    import re
-    for bn, c in W8.items():
-        AI, BJ, WN, NST = c["ai"], c["bj"], c["wn"], c["stages"]
-        STG = 32768 + bn * 128
-        lines = _w8_lines(bn)
-        lds0 = _w8_layout(bn)
-        assert len(lds0) == (256 + bn) * 8 and max(lds0) < STG
-        for (mat, row, chunk), addr in ((v, k) for k, v in lds0.items()):
-            assert (addr % 128) // 16 == chunk ^ ((row >> 1) & 7)
-        npw = 4 + bn // 64
-        vb = 128 - (NST * 8 + 2 * (AI + BJ) * 4)
-        areg = {}
-        for l in lines:
-            m = re.match(r"v_xor_b32 v(\d+), (\d+), %\[(aa0|ab0)\]", l)
-            if m:
-                areg[int(m.group(1))] = (m.group(3)[1], int(m.group(2)), 0)
-            m = re.match(r"v_mov_b32 v(\d+), %\[(aa0|ab0)\]", l)
-            if m:
-                areg[int(m.group(1))] = (m.group(2)[1], 0, 0)
-        for l in lines:
-            m = re.match(r"v_add_u32 v(\d+), (\d+), v(\d+)", l)
-            if m:
-                mat, kx, _ = areg[int(m.group(3))]
-                areg[int(m.group(1))] = (mat, kx, int(m.group(2)))
-        assert len(areg) == 8 * NST and min(areg) == vb
-        for w in range(8):
-            for st in range(NST):
-                i0 = lines.index(f".Lb8_b{w}_{st}_%=:")
-                i1 = next(k for k in range(i0, len(lines)) if lines[k].startswith("s_cmp_lt_u32"))
-                body = lines[i0:i1]
-                assert sum(l.startswith("v_mfma") for l in body) == 4 * AI * BJ
-                assert sum(l.startswith("s_barrier") for l in body) == 1
-                assert sum("buffer_load_dwordx4" in l for l in body) == npw
-                bar = body.index("s_barrier")
-                cnt = int(re.match(r"s_waitcnt vmcnt\((\d+)\)", body[bar - 1]).group(1))
-                before = sum("buffer_load_dwordx4" in l for l in body[:bar])
-                assert cnt == (before if NST == 3 else 0)
-                m0 = [int(re.match(r"s_add_u32 m0, s(\d+), (\d+)", l).group(2)) for l in body if l.startswith("s_add_u32 m0")]
-                if NST == 3:
-                    assert {x // STG for x in m0} == {(st + 2) % 3}
-                else:   # in front of the barrier: the rest of tile t+1 -> the other stage; behind it: tile t+2 -> this stage
-                    nb = sum(l.startswith("s_add_u32 m0") for l in body[:bar])
-                    assert all(x // STG == 1 - st for x in m0[:nb]) and all(x // STG == st for x in m0[nb:])
-                regs = [int(re.match(r"ds_read_b128 v\[\d+:\d+\], v(\d+)", l).group(1)) for l in body if l.startswith("ds_read")]
-                nbr = sum(l.startswith("ds_read") for l in body[:bar])
-                assert len(regs) == 4 * (AI + BJ) and nbr == 3 * (AI + BJ)
-                assert all(areg[r][2] == STG * st for r in regs[:nbr]) and all(areg[r][2] == STG * ((st + 1) % NST) for r in regs[nbr:])
-        reads = set()
-        for l in lines:
-            m = re.match(r"ds_read_b128 v\[(\d+):\d+\], v(\d+) offset:(\d+)", l)
-            if m:
-                mat, kx, stage = areg[int(m.group(2))]
-                reads.add((mat, kx >> 5, stage, int(m.group(3))))
-        assert reads == {("a", kk, STG * st, 4096 * i) for kk in range(4) for st in range(NST) for i in range(AI)} | \
-                        {("b", kk, STG * st, 4096 * j) for kk in range(4) for st in range(NST) for j in range(BJ)}
-        for wave in range(8):
-            wm, wn = wave // WN, wave % WN
-            for (mat, kk, stage, off) in reads:
-                slots = []
-                for lane in range(64):
-                    hi, l31 = lane >> 5, lane & 31
-                    abk0 = l31 * 128 + ((hi ^ ((l31 >> 1) & 7)) << 4)
-                    base = wm * (AI * 4096) if mat == "a" else 32768 + wn * (BJ * 4096)
-                    addr = ((base + abk0) ^ (kk << 5)) + off
-                    want_row = (wm * 32 * AI if mat == "a" else wn * 32 * BJ) + (off // 4096) * 32 + l31
-                    assert lds0[addr] == (mat, want_row, kk * 2 + hi), (bn, wave, mat, kk, off, lane)
-                    slots.append((addr // 16) % 16)
-                for q in range(4):
-                    assert len(set(slots[16 * q:16 * q + 16])) == 16
-
-
 def test_flash_dp2_asm_is_generated():
     want = "".join(_run("tools/gen_flash_dp2_asm.py", *f) for f in ((), ("--timed",), ("--exact",), ("--exact", "--timed")))
     assert want == (CSRC / "flash_dp2_asm.inc").read_text()
@@ -359,7 +255,7 @@ def test_generated_asm_passes_the_hazard_lint():
             seen += 1
             assert len(lines) > 200
             assert asm_lint.lint(name, lines) == []
-    assert seen == 11  # flash KV loop (exact / pre-scaled x plain / timed), GEMM K loop NJ = 4, NJ = 3, NJ = 3 SwiGLU-pair, NJ = 2 ring, three eight-wave forms
+    assert seen == 8  # flash KV loop (exact / pre-scaled x plain / timed), GEMM K loop NJ = 4, NJ = 3, NJ = 3 SwiGLU-pair, NJ = 2 ring
     # the linter itself: each rule fires on a minimal violation
     bad = {
         "R1": ["v_exp_f32 v1, v1", "v_add_f32 v2, v1, v1"],

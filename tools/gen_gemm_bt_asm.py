@@ -40,22 +40,7 @@ S_ROWA = [43, 44, 45, 46]
 S_ROWB = [47, 48, 49, 50]
 S_DA, S_DB = 51, 52          # LDS byte offsets of this wave's DMA rows in the A / B tile of stage 0
 S_K1B, S_K2B, S_K0A, S_K0B = 53, 54, 55, 56   # scalar byte offsets of K tiles kt+1 / kt+2 (and 0) per matrix
-S_PFA, S_PFB = 57, 58        # scalar byte offsets of the K tile the L2 prefetch touches (kt + PF_D), per matrix
-SLO, SHI = 36, 58
-
-
-def _flag(name, default):
-    return sys.argv[sys.argv.index(name) + 1] if name in sys.argv else default
-
-
-# L2 prefetch (four-wave forms): the K loop is bound by its LDS-DMA stream, and that stream by latency -- 2048 x 12288 x 4096 with
-# cold weights: the DMA alone 160 us, the MFMAs alone 110, together 197 (profiles/r04_bt_kloop_ablations.log); at most one K
-# tile (two in the ring form) is in flight per CU against ~1.5 us from HBM.  Every iteration each wave touches, PF_D K tiles
-# ahead, one dword of each 128-byte row segment of its share of the A and B tiles (buffer_load_dword ... lds into a scratch
-# corner of the LDS: no registers, nothing to wait for) so that the DMA pieces of that tile find their lines in the L2.
-# Issued last in front of the barrier's wait, which becomes vmcnt(number of prefetch loads): everything older has landed.
-PF_D = int(_flag("--pf", "0"))           # 0 = off
-PF_OPS = _flag("--pf-ops", "ab")
+SLO, SHI = 36, 56
 
 out = []
 ABL = set()   # measurement-only builds (wrong results): "nodma" / "noread" / "nobar" / "nomfma" inside the K loop
@@ -147,47 +132,6 @@ def frag_waits():
     return waits
 
 
-def prefetch(dummy):
-    """the iteration's L2 prefetch loads (see PF_D); returns how many were issued"""
-    if not PF_D:
-        return 0
-    e(f"s_mov_b32 m0, {dummy}")
-    e("s_nop 0")
-    n = 0
-    for mat, reg in (("a", S_PFA), ("b", S_PFB)):
-        if mat in PF_OPS:
-            e(f"buffer_load_dword %[pf{mat}], %[rs{mat}], {s(reg)} offen lds")
-            n += 1
-    return n
-
-
-def prefetch_setup():
-    """S_PF? = offset of K tile PF_D: base + 128 PF_D, or the next output tile's (nbase + 128 (PF_D - nkt)) when this tile is shorter"""
-    if not PF_D:
-        return
-    e(f"s_sub_u32 {s(S_TMP)}, {PF_D}, %[nkt]")
-    e(f"s_lshl_b32 {s(S_TMP)}, {s(S_TMP)}, 7")
-    e(f"s_add_u32 {s(S_PFA)}, %[nbase_a], {s(S_TMP)}")
-    e(f"s_add_u32 {s(S_PFB)}, %[nbase_b], {s(S_TMP)}")
-    e(f"s_add_u32 {s(S_SA)}, %[base_a], {128 * PF_D}")
-    e(f"s_add_u32 {s(S_SB)}, %[base_b], {128 * PF_D}")
-    e(f"s_cmp_lt_u32 {PF_D}, %[nkt]")
-    e(f"s_cselect_b32 {s(S_PFA)}, {s(S_SA)}, {s(S_PFA)}")
-    e(f"s_cselect_b32 {s(S_PFB)}, {s(S_SB)}, {s(S_PFB)}")
-
-
-def prefetch_advance():
-    """after kt += 1: the prefetch offsets follow; K tile kt + PF_D = nkt is K tile 0 of the next output tile"""
-    if not PF_D:
-        return
-    e(f"s_add_u32 {s(S_PFA)}, {s(S_PFA)}, 128")
-    e(f"s_add_u32 {s(S_PFB)}, {s(S_PFB)}, 128")
-    e(f"s_add_u32 {s(S_TMP)}, {s(S_KT)}, {PF_D}")
-    e(f"s_cmp_eq_u32 {s(S_TMP)}, %[nkt]")
-    e(f"s_cselect_b32 {s(S_PFA)}, %[nbase_a], {s(S_PFA)}")
-    e(f"s_cselect_b32 {s(S_PFB)}, %[nbase_b], {s(S_PFB)}")
-
-
 def mfma_block(b, extra, a=None, bb=None):
     """the 4 NJ MFMAs of one k16 step out of buffer b; extra(slot) emits the slot's companion instruction(s)"""
     a, bb = a or afrag, bb or bfrag
@@ -261,8 +205,6 @@ def gen(nj, pair=False):
     e("s_cmp_eq_u32 %[nkt], 2")
     e(f"s_cselect_b32 {s(S_K2A)}, %[nbase_a], {s(S_K2A)}")
     e(f"s_cselect_b32 {s(S_K2B)}, %[nbase_b], {s(S_K2B)}")
-    if not pair:
-        prefetch_setup()
     for w in (1, 2, 3):
         e(f"s_cmp_eq_u32 %[wave], {w}")
         e(f"s_cbranch_scc1 .Lbt_w{w}_%=")
@@ -308,8 +250,7 @@ def gen(nj, pair=False):
         mfma_block(0, xk(1, 1, 1))
         mfma_block(1, xk(2, 0, 2))
         mfma_block(0, lambda slot: read(1, 3, slot) if slot < nread else None)
-        npf = 0 if pair else prefetch(131072)
-        e(f"s_waitcnt vmcnt({npf})")
+        e("s_waitcnt vmcnt(0)")
         e("s_barrier")
         for k in range(4):                                   # fragment addresses -> the other stage
             e(f"v_xor_b32 {v(AA[k])}, 0x10000, {v(AA[k])}")
@@ -336,8 +277,6 @@ def gen(nj, pair=False):
         e(f"s_cmp_eq_u32 {s(S_TMP)}, %[nkt]")
         e(f"s_cselect_b32 {s(S_K2A)}, %[nbase_a], {s(S_K2A)}")
         e(f"s_cselect_b32 {s(S_K2B)}, %[nbase_b], {s(S_K2B)}")
-        if not pair:
-            prefetch_advance()
         e(f"s_cmp_lt_u32 {s(S_KT)}, %[nkt]")
         e(f"s_cbranch_scc1 .Lbt_loop{w}_%=")
         IN_LOOP[0] = False
@@ -439,7 +378,6 @@ def gen_ring(nj=2):
     e("s_cmp_eq_u32 %[nkt], 2")
     e(f"s_cselect_b32 {s(S_K2A)}, %[nbase_a], {s(S_K2A)}")
     e(f"s_cselect_b32 {s(S_K2B)}, %[nbase_b], {s(S_K2B)}")
-    prefetch_setup()
     for w in (1, 2, 3):
         e(f"s_cmp_eq_u32 %[wave], {w}")
         e(f"s_cbranch_scc1 .Lbr_w{w}_%=")
@@ -483,7 +421,6 @@ def gen_ring(nj=2):
             rblock(1, xk(1, 0, st, 2))
             rblock(0, xk(2, 1, st, 3))
             issued = sum(len(sched[w].get(g, [])) for g in range(3 * nslot))
-            issued += prefetch(147456)
             e(f"s_waitcnt vmcnt({issued})")
             e("s_barrier")
             rblock(1, xk(3, 0, nxt, 0))
@@ -494,7 +431,6 @@ def gen_ring(nj=2):
             e(f"s_cmp_eq_u32 {s(S_TMP)}, %[nkt]")
             e(f"s_cselect_b32 {s(S_K2A)}, %[nbase_a], {s(S_K2A)}")
             e(f"s_cselect_b32 {s(S_K2B)}, %[nbase_b], {s(S_K2B)}")
-            prefetch_advance()
             e(f"s_cmp_lt_u32 {s(S_KT)}, %[nkt]")
             if st < 2:
                 e(f"s_cbranch_scc0 .Lbr_done_%=")
@@ -509,193 +445,14 @@ def gen_ring(nj=2):
     e("s_nop 7")
 
 
-# ---- eight-wave forms: two waves per SIMD ------------------------------------------------------------------------------
-# What the four-wave loops above are bound by (round 4, profiles/r04_bt_ring_sweep.log): a K tile costs its MFMA cycles PLUS
-# ~90 cycles per LDS-DMA piece of the issuing wave -- 256 x 256: 2048 + 16 x 60..90 = ~3000 cycles, 256 x 192: 1536 + 14 x 90
-# = ~2800, 256 x 128 ring: 1024 + 12 x 90 = ~2100, the measured K-tile times -- because a buffer_load ... lds sits in the
-# wave's in-order issue until the CU's one address path takes it (~20 cycles per 1 KB piece, four waves queueing), and the
-# matrix pipe of that SIMD has nobody else to feed it.  Here a workgroup is EIGHT waves, two per SIMD, each with half the
-# output tile (64 x 64 / 64 x 96 / 128 x 64 accumulators: <= 128 AccVGPRs, so two waves fit the register file): while one
-# wave waits in front of a DMA piece, a fragment wait or the barrier, the other one issues MFMAs.  Same LDS layout, swizzle,
-# DMA descriptors and tile chaining as the forms above; the loop is unrolled over the LDS stages like the ring form
-# (two stages of 64 / 56 KB for 256 / 192-wide tiles, the 2-stage issue window: K tile t+1 over [k16 step 3 of iteration
-# t-1, steps 0 and 1 of iteration t], vmcnt(0) at the barrier;  three stages of 48 KB for 128-wide tiles, the ring window).
-W8 = {256: dict(ai=4, bj=2, wn=4, stages=2), 192: dict(ai=2, bj=3, wn=2, stages=2), 128: dict(ai=2, bj=2, wn=2, stages=3)}
-
-
-def gen_w8(bn):
-    cfg = W8[bn]
-    AI, BJ, NST = cfg["ai"], cfg["bj"], cfg["stages"]
-    STG = 32768 + bn * 128
-    nslot, nread = AI * BJ, AI + BJ
-    npb = bn // 64                      # B pieces per wave (BN / 8 rows)
-    npw = 4 + npb                       # A: 32 rows per wave
-    nfix = NST * 8 + 2 * nread * 4
-    VB = 128 - nfix                     # fixed registers at the top of the 128 arch VGPRs a 512-thread workgroup has
-    XAA = [[VB + 4 * st + k for k in range(4)] for st in range(NST)]
-    XAB = [[VB + 4 * NST + 4 * st + k for k in range(4)] for st in range(NST)]
-    XBUF = VB + 8 * NST
-    del out[:]
-
-    def xa(b, i):
-        return vr(XBUF + 4 * nread * b + 4 * i, 4)
-
-    def xb(b, j):
-        return vr(XBUF + 4 * nread * b + 4 * AI + 4 * j, 4)
-
-    def xread(b, st, kk, n):
-        order = [("a", 0)] + [("b", j) for j in range(BJ)] + [("a", i) for i in range(1, AI)]
-        m, idx = order[n]
-        if m == "a":
-            e(f"ds_read_b128 {xa(b, idx)}, {v(XAA[st][kk])} offset:{4096 * idx}")
-        else:
-            e(f"ds_read_b128 {xb(b, idx)}, {v(XAB[st][kk])} offset:{4096 * idx}")
-
-    def xpiece(n, st, s_k):
-        mat, p = ("a", n) if n < 4 else ("b", n - 4)
-        e(f"s_add_u32 m0, {s(S_DA if mat == 'a' else S_DB)}, {STG * st + 1024 * p}")
-        row = (S_ROWA if mat == "a" else S_ROWB)[p >> 1]
-        e(f"s_add_u32 {s(S_TMP)}, {s(s_k[0] if mat == 'a' else s_k[1])}, {s(row)}")
-        e(f"buffer_load_dwordx4 %[v{mat}{p & 1}], %[rs{mat}], {s(S_TMP)} offen lds")
-
-    waits, have = {}, -1
-    for slot in range(nslot):
-        i, j = slot // BJ, slot % BJ
-        need = max(0 if i == 0 else BJ + i, 1 + j)
-        if need > have:
-            have = need
-            waits[slot] = (nread - 1 - need) + min(slot, nread)
-
-    def xblock(b, extra):
-        for slot in range(nslot):
-            i, j = slot // BJ, slot % BJ
-            if slot in waits:
-                e(f"s_waitcnt lgkmcnt({waits[slot]})")
-            e(f"v_mfma_f32_32x32x16_bf16 %[c{i}{j}], {xb(b, j)}, {xa(b, i)}, %[c{i}{j}]")
-            extra(slot)
-
-    nwin = 3 if NST == 2 else 4          # k16 steps in the issue window of one K tile
-    window = nwin * nslot
-    sched = {w: {} for w in range(8)}
-    for n in range(npw):
-        for w in range(8):
-            g = (n * 8 + w) * window // (8 * npw)
-            sched[w].setdefault(g, []).append(n)
-    K0, K1, K2 = (S_K0A, S_K0B), (S_K1A, S_K1B), (S_K2A, S_K2B)
-    # ---- setup (common)
-    for k in range(4):
-        if k:
-            e(f"v_xor_b32 {v(XAA[0][k])}, {32 * k}, %[aa0]")
-            e(f"v_xor_b32 {v(XAB[0][k])}, {32 * k}, %[ab0]")
-        else:
-            e(f"v_mov_b32 {v(XAA[0][0])}, %[aa0]")
-            e(f"v_mov_b32 {v(XAB[0][0])}, %[ab0]")
-    for st in range(1, NST):
-        for k in range(4):
-            e(f"v_add_u32 {v(XAA[st][k])}, {STG * st}, {v(XAA[0][k])}")
-            e(f"v_add_u32 {v(XAB[st][k])}, {STG * st}, {v(XAB[0][k])}")
-    e(f"s_mov_b32 {s(S_ROWA[0])}, 0")
-    e(f"s_mov_b32 {s(S_ROWA[1])}, %[lda16]")
-    e(f"s_mov_b32 {s(S_ROWB[0])}, 0")
-    e(f"s_mov_b32 {s(S_ROWB[1])}, %[ldb16]")
-    e(f"s_mov_b32 {s(S_KT)}, 0")
-    e(f"s_lshl_b32 {s(S_DA)}, %[wave], 12")                       # 32 rows x 128 B per wave
-    e(f"s_mul_i32 {s(S_DB)}, %[wave], {bn * 16}")                 # BN / 8 rows per wave
-    e(f"s_add_u32 {s(S_DB)}, {s(S_DB)}, 0x8000")
-    e(f"s_mov_b32 {s(S_K0A)}, %[base_a]")
-    e(f"s_mov_b32 {s(S_K0B)}, %[base_b]")
-    e(f"s_add_u32 {s(S_K1A)}, %[base_a], 128")
-    e(f"s_add_u32 {s(S_K1B)}, %[base_b], 128")
-    e(f"s_add_u32 {s(S_K2A)}, %[base_a], 256")
-    e(f"s_add_u32 {s(S_K2B)}, %[base_b], 256")
-    e("s_cmp_eq_u32 %[nkt], 2")
-    e(f"s_cselect_b32 {s(S_K2A)}, %[nbase_a], {s(S_K2A)}")
-    e(f"s_cselect_b32 {s(S_K2B)}, %[nbase_b], {s(S_K2B)}")
-    for w in range(1, 8):
-        e(f"s_cmp_eq_u32 %[wave], {w}")
-        e(f"s_cbranch_scc1 .Lb8_w{w}_%=")
-    for w in range(8):
-        if w:
-            e(f".Lb8_w{w}_%=:")
-        e("s_cmp_eq_u32 %[first], 0")
-        e(f"s_cbranch_scc1 .Lb8_cont{w}_%=")
-        # first tile of the workgroup (st0 = 0): K tile 0 at once, and what the steady state has issued of the following
-        # tile(s) by the time an iteration starts
-        for n in range(npw):
-            xpiece(n, 0, K0)
-        if NST == 2:
-            early = [n for g in range(nslot) for n in sched[w].get(g, [])]
-            for n in early:
-                xpiece(n, 1, K1)
-            e(f"s_waitcnt vmcnt({len(early)})")
-        else:
-            for n in range(npw):
-                xpiece(n, 1, K1)
-            e(f"s_waitcnt vmcnt({npw})")
-        e("s_barrier")
-        e(f".Lb8_cont{w}_%=:")
-        for st in range(1, NST):
-            e(f"s_cmp_eq_u32 %[st0], {st}")
-            e(f"s_cbranch_scc1 .Lb8_e{w}_{st}_%=")
-        for st in range(NST):
-            if st:
-                e(f".Lb8_e{w}_{st}_%=:")
-            for n in range(nread):
-                xread(0, st, 0, n)
-            e(f"s_branch .Lb8_b{w}_{st}_%=")
-        for st in range(NST):
-            e(f".Lb8_b{w}_{st}_%=:")
-            nxt = (st + 1) % NST
-
-            def xk(pos, tgt, s_k, rb, rst, rkk):
-                """companions of the slots of one k16 step: fragment reads (buffer rb, stage rst, step rkk) and the DMA pieces
-                at window position pos * nslot + slot (pos None: none) into stage tgt"""
-                def f(slot):
-                    if slot < nread:
-                        xread(rb, rst, rkk, slot)
-                    if pos is not None:
-                        for n in sched[w].get(pos * nslot + slot, []):
-                            xpiece(n, tgt, s_k)
-                return f
-
-            if NST == 2:
-                xblock(0, xk(1, nxt, K1, 1, st, 1))
-                xblock(1, xk(2, nxt, K1, 0, st, 2))
-                xblock(0, xk(None, 0, K1, 1, st, 3))
-                e("s_waitcnt vmcnt(0)")
-                e("s_barrier")
-                xblock(1, xk(0, st, K2, 0, nxt, 0))
-            else:
-                tgt = (st + 2) % NST
-                xblock(0, xk(0, tgt, K2, 1, st, 1))
-                xblock(1, xk(1, tgt, K2, 0, st, 2))
-                xblock(0, xk(2, tgt, K2, 1, st, 3))
-                issued = sum(len(sched[w].get(g, [])) for g in range(3 * nslot))
-                e(f"s_waitcnt vmcnt({issued})")
-                e("s_barrier")
-                xblock(1, xk(3, tgt, K2, 0, nxt, 0))
-            e(f"s_add_u32 {s(S_KT)}, {s(S_KT)}, 1")
-            if NST == 2:
-                e(f"s_mov_b32 {s(S_K1A)}, {s(S_K2A)}")
-                e(f"s_mov_b32 {s(S_K1B)}, {s(S_K2B)}")
-            e(f"s_add_u32 {s(S_K2A)}, {s(S_K2A)}, 128")
-            e(f"s_add_u32 {s(S_K2B)}, {s(S_K2B)}, 128")
-            e(f"s_add_u32 {s(S_TMP)}, {s(S_KT)}, 2")
-            e(f"s_cmp_eq_u32 {s(S_TMP)}, %[nkt]")
-            e(f"s_cselect_b32 {s(S_K2A)}, %[nbase_a], {s(S_K2A)}")
-            e(f"s_cselect_b32 {s(S_K2B)}, %[nbase_b], {s(S_K2B)}")
-            e(f"s_cmp_lt_u32 {s(S_KT)}, %[nkt]")
-            if st < NST - 1:
-                e(f"s_cbranch_scc0 .Lb8_done_%=")
-            else:
-                e(f"s_cbranch_scc1 .Lb8_b{w}_0_%=")
-        if w < 7:
-            e("s_branch .Lb8_done_%=")
-    e(".Lb8_done_%=:")
-    e("s_waitcnt lgkmcnt(0)")
-    e("s_nop 15")
-    e("s_nop 7")
-    return VB
+# ---- measured and removed in round 4 (history: commits "eight-wave forms ...", "L2-prefetch trial ...") ----------------------------
+#  * eight-wave forms of all three tile widths (two waves per SIMD, 128 x 64 / 64 x 96 / 64 x 64 accumulators per wave): tie the
+#    four-wave loops on every shape (profiles/r04_bt8_vit.log, r04_bt8_tok.log) -- the K loop is not bound by one wave's in-order issue.
+#  * --ablate builds (profiles/r04_bt_kloop_ablations.log), 2048 x 12288 x 4096 cold: DMA stream alone 160 us, MFMAs alone 110, both
+#    197: the stream is latency-bound (one 56 KB K tile in flight per CU = 45 GB/s per CU against ~1.25 us), which is what
+#    the ring form's third stage buys back for 256 x 128 tiles; 256 x 192 / 256 x 256 stages do not fit three times.
+#  * L2 prefetch (a dword per 128-byte row segment, 2 / 4 / 8 K tiles ahead, through buffer_load_dword ... lds): the scattered
+#    touches cost the address path more than the latency they hide (r04_bt_l2_prefetch_*.log): ViT q|k|v 71 -> 80 us.
 
 
 print("// GENERATED by tools/gen_gemm_bt_asm.py -- do not edit")
@@ -714,15 +471,7 @@ gen_ring(2)
 print("#define GEMM_BT_ASM_TEXT_NJ2_RING \\")
 for i, line in enumerate(out):
     print(f'  "{line}\\n"' + (" \\" if i + 1 < len(out) else ""))
-w8_lo = {}
-for bn in (256, 192, 128):
-    w8_lo[bn] = gen_w8(bn)
-    print(f"#define GEMM_BT8_ASM_TEXT_{bn} \\")
-    for i, line in enumerate(out):
-        print(f'  "{line}\\n"' + (" \\" if i + 1 < len(out) else ""))
-for name, lo, hi in (("GEMM_BT_ASM_CLOBBERS", VLO, VHI), ("GEMM_BT_ASM_CLOBBERS_RING", RVLO, RVHI),
-                     ("GEMM_BT8_ASM_CLOBBERS_256", w8_lo[256], 127), ("GEMM_BT8_ASM_CLOBBERS_192", w8_lo[192], 127),
-                     ("GEMM_BT8_ASM_CLOBBERS_128", w8_lo[128], 127)):
+for name, lo, hi in (("GEMM_BT_ASM_CLOBBERS", VLO, VHI), ("GEMM_BT_ASM_CLOBBERS_RING", RVLO, RVHI)):
     clob = [f'"v{i}"' for i in range(lo, hi + 1)] + [f'"s{i}"' for i in range(SLO, SHI + 1)] + ['"scc"', '"memory"']
     print(f"#define {name} \\")
     for i in range(0, len(clob), 12):

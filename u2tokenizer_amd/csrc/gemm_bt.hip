@@ -106,8 +106,7 @@ __device__ __forceinline__ void bt_epilogue_fast(const GemmDesc& d, f32x16 (&acc
 //   lane (l31, hi), pair t of fragment (mi, ni):  m = m_base + 32 mi,  n = n_tile + 32 ni + 16 t + 8 hi + [0, 8)
 template <class CFG, int G, bool PAIR = false>
 __device__ __forceinline__ void pp_epilogue(const GemmDesc& d, f32x16 (&acc)[2][CFG::NI], int z, int bm0, int bn0, int wm2,
-                                            int wn2, int lane, const bt_u32x4 (&bpre)[CFG::NI * 2], bool fast,
-                                            int full_h = 256, int full_w = CFG::BN) {
+                                            int wn2, int lane, const bt_u32x4 (&bpre)[CFG::NI * 2], bool fast) {
   constexpr int NI = CFG::NI, BN = CFG::BN;
   const int hi = lane >> 5, l31 = lane & 31;
   const bool out_f32 = d.flags & GEMM_OUT_F32;
@@ -218,7 +217,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmDesc& d, f32x16 (&acc)[2][
   using T_ = std::true_type;
   using F_ = std::false_type;
   const int ef = d.flags & (GEMM_BIAS_N | GEMM_GELU | GEMM_RESIDUAL | GEMM_OUT_F32);
-  if (bm0 + full_h <= d.M && bn0 + full_w <= d.N) {
+  if (bm0 + 256 <= d.M && bn0 + BN <= d.N) {
     switch (ef) {
       case 0: body(T_{}, F_{}, F_{}, F_{}, F_{}); break;
       case GEMM_OUT_F32: body(T_{}, F_{}, F_{}, F_{}, T_{}); break;
@@ -266,8 +265,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
   constexpr bool RING = NJ == 2;
   using CFG = BTCfg<BN>;
   // two stages: [stage][A tile 32 KB | B tile <= 32 KB];  ring: three stages of [A tile 32 KB | B tile 16 KB]
-  // (+ 256 bytes behind the stages: where the K loop's L2-prefetch loads put their dwords, never read)
-  __shared__ __attribute__((aligned(1024))) char lds[(RING ? 147456 : 131072) + 256];
+  __shared__ __attribute__((aligned(1024))) char lds[RING ? 147456 : 131072];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -293,9 +291,6 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
   const int rb = (PAIR ? 0 : wave * (16 * NJ)) + pr;
   const int vb0 = (rb * (int)d.ldb + ((pc ^ sw0) << 3)) * 2;
   const int vb1 = ((rb + 8) * (int)d.ldb + ((pc ^ sw0 ^ 4) << 3)) * 2;
-  // L2 prefetch of the K loop (gen_gemm_bt_asm.py, PF_D): lane l touches one dword of row l of the wave's 64 A rows / 16 NJ B rows
-  const int pfa = (wave * 64 + lane) * (int)d.lda * 2;
-  const int pfb = (wave * (16 * NJ) + lane % (16 * NJ)) * (int)d.ldb * 2;
   [[maybe_unused]] int rowb[3] = {0, 0, 0};
   if constexpr (PAIR) {
 #pragma unroll
@@ -359,8 +354,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
 #define BT_IN                                                                                                         \
   [va0] "v"(va0), [va1] "v"(va1), [vb0] "v"(vb0), [vb1] "v"(vb1), [aa0] "v"(aa0), [ab0] "v"(ab0), [rsa] "s"(rsa),     \
       [rsb] "s"(rsb), [lda16] "s"(lda16), [nkt] "s"(nkt), [wave] "s"(wave), [st0] "s"(st0_s), [first] "s"(first_s),   \
-      [base_a] "s"(base_a), [base_b] "s"(base_b), [nbase_a] "s"(nbase_a), [nbase_b] "s"(nbase_b), [pfa] "v"(pfa),     \
-      [pfb] "v"(pfb)
+      [base_a] "s"(base_a), [base_b] "s"(base_b), [nbase_a] "s"(nbase_a), [nbase_b] "s"(nbase_b)
     if constexpr (NJ == 2) {
       asm volatile(GEMM_BT_ASM_TEXT_NJ2_RING
                    : [c000] "+a"(acc[0][0][0]), [c001] "+a"(acc[0][0][1]), [c010] "+a"(acc[0][1][0]), [c011] "+a"(acc[0][1][1]),
@@ -421,130 +415,6 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last K loop's prefetch into LDS
 }
 
-// Eight-wave forms (variants 30 / 31 / 32: 256 x 256, 256 x 192, 256 x 128 tiles): TWO waves per SIMD, each with a 128 x 64 /
-// 64 x 96 / 64 x 64 piece of the tile (<= 128 AccVGPRs), K loop = GEMM_BT8_ASM_TEXT_<BN> (tools/gen_gemm_bt_asm.py, gen_w8, which
-// says what the four-wave loops are bound by and why a second wave per SIMD lifts it).  Same persistent tile walk, LDS
-// layout, DMA descriptors and tile-to-tile chaining as gemm_bt_kernel; plain epilogues only (no SwiGLU pair, no K slices).
-template <int BN>
-__global__ __launch_bounds__(512, 1) void gemm_bt8_kernel(GemmDesc d) {
-  static_assert(BN == 256 || BN == 192 || BN == 128, "tile widths");
-  constexpr int AI = BN == 256 ? 4 : 2, BJ = BN == 192 ? 3 : 2, WN = BN == 256 ? 4 : 2;
-  constexpr int NST = BN == 128 ? 3 : 2, STG = 32768 + BN * 128;
-  __shared__ __attribute__((aligned(1024))) char lds[NST * STG];  // [stage][A tile 32 KB | B tile BN x 128 B]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int hi = lane >> 5, l31 = lane & 31;
-  const int tiles_mn = d.tiles_m * d.tiles_n;
-  const int total = tiles_mn * d.nz;
-  const int gd = gridDim.x, bid = blockIdx.x;
-  const int my_tiles = (total - bid + gd - 1) / gd;
-  // DMA pieces of this wave: rows [32 w, 32 w + 32) of the A tile and [(BN / 8) w, ..) of the B tile (8 rows x 128 B per piece;
-  // LDS position p of row r holds global chunk p ^ ((r >> 1) & 7): a 24-row share starts on an odd multiple of 8 for odd w)
-  const int pr = lane >> 3, sw0 = (lane >> 4) & 3, pc = lane & 7;
-  const int ra = wave * 32 + pr;
-  const int va0 = (ra * (int)d.lda + ((pc ^ sw0) << 3)) * 2;
-  const int va1 = ((ra + 8) * (int)d.lda + ((pc ^ sw0 ^ 4) << 3)) * 2;
-  const int rb = wave * (BN / 8) + pr;
-  const int wsw = (BN == 192 && (wave & 1)) ? 4 : 0;
-  const int vb0 = (rb * (int)d.ldb + ((pc ^ sw0 ^ wsw) << 3)) * 2;
-  const int vb1 = ((rb + 8) * (int)d.ldb + ((pc ^ sw0 ^ 4 ^ wsw) << 3)) * 2;
-  const uint32_t lds_u32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&lds[0];
-  const uint32_t abk0 = (uint32_t)(l31 * 128 + ((hi ^ ((l31 >> 1) & 7)) << 4));
-  const uint32_t aa0 = lds_u32 + wm * (AI * 4096) + abk0, ab0 = lds_u32 + 32768 + wn * (BJ * 4096) + abk0;
-  const int lda16 = 16 * (int)d.lda * 2, ldb16 = 16 * (int)d.ldb * 2;
-  const int nkt = __builtin_amdgcn_readfirstlane((int)(d.K >> 6));
-  const bool chain = d.nz == 1;
-  uint32_t st0 = 0;  // index of the LDS stage that holds K tile 0 of the current output tile
-  int z, bm0, bn0;
-  pp_tile<BN>(d, 0, gd, bid, total, tiles_mn, z, bm0, bn0);
-  for (int r = 0; r < my_tiles; ++r) {
-    int zn = z, bm0n = bm0, bn0n = bn0;
-    if (r + 1 < my_tiles) pp_tile<BN>(d, r + 1, gd, bid, total, tiles_mn, zn, bm0n, bn0n);
-    const int zb = z / d.nbh, zh = z - zb * d.nbh;
-    const bf16_t* A = d.A + zb * d.sAb + zh * d.sAh;
-    const bf16_t* B = d.B + zb * d.sBb + zh * d.sBh;
-    const uint64_t aaddr = (uint64_t)(uintptr_t)A, baddr = (uint64_t)(uintptr_t)B;
-    bt_i32x4 rsa, rsb;
-    rsa[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)aaddr);
-    rsa[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(aaddr >> 32));
-    rsa[2] = (int)((((int64_t)d.M - 1) * d.lda + d.K) * 2);
-    rsa[3] = 0x00020000;
-    rsb[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)baddr);
-    rsb[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(baddr >> 32));
-    rsb[2] = (int)((((int64_t)d.N - 1) * d.ldb + d.K) * 2);
-    rsb[3] = 0x00020000;
-    const int first = (r == 0 || !chain) ? 1 : 0;
-    if (first) st0 = 0;
-    const int base_a = __builtin_amdgcn_readfirstlane(bm0 * (int)d.lda * 2);
-    const int base_b = __builtin_amdgcn_readfirstlane(bn0 * (int)d.ldb * 2);
-    const int nbase_a = __builtin_amdgcn_readfirstlane((chain ? bm0n : bm0) * (int)d.lda * 2);
-    const int nbase_b = __builtin_amdgcn_readfirstlane((chain ? bn0n : bn0) * (int)d.ldb * 2);
-    const int st0_s = __builtin_amdgcn_readfirstlane((int)st0), first_s = __builtin_amdgcn_readfirstlane(first);
-    f32x16 acc[AI][BJ];
-#pragma unroll
-    for (int i = 0; i < AI; ++i)
-#pragma unroll
-      for (int j = 0; j < BJ; ++j)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-#define BT8_IN                                                                                                        \
-  [va0] "v"(va0), [va1] "v"(va1), [vb0] "v"(vb0), [vb1] "v"(vb1), [aa0] "v"(aa0), [ab0] "v"(ab0), [rsa] "s"(rsa),     \
-      [rsb] "s"(rsb), [lda16] "s"(lda16), [ldb16] "s"(ldb16), [nkt] "s"(nkt), [wave] "s"(wave), [st0] "s"(st0_s),     \
-      [first] "s"(first_s), [base_a] "s"(base_a), [base_b] "s"(base_b), [nbase_a] "s"(nbase_a), [nbase_b] "s"(nbase_b)
-#define BT8_ROW2(i_) [c##i_##0] "+a"(acc[i_][0]), [c##i_##1] "+a"(acc[i_][1])
-    if constexpr (BN == 256) {
-      asm volatile(GEMM_BT8_ASM_TEXT_256 : BT8_ROW2(0), BT8_ROW2(1), BT8_ROW2(2), BT8_ROW2(3) : BT8_IN : GEMM_BT8_ASM_CLOBBERS_256);
-    } else if constexpr (BN == 192) {
-      asm volatile(GEMM_BT8_ASM_TEXT_192
-                   : BT8_ROW2(0), [c02] "+a"(acc[0][2]), BT8_ROW2(1), [c12] "+a"(acc[1][2])
-                   : BT8_IN
-                   : GEMM_BT8_ASM_CLOBBERS_192);
-    } else {
-      asm volatile(GEMM_BT8_ASM_TEXT_128 : BT8_ROW2(0), BT8_ROW2(1) : BT8_IN : GEMM_BT8_ASM_CLOBBERS_128);
-    }
-#undef BT8_ROW2
-#undef BT8_IN
-    // this wave's 64-row halves through pp_epilogue: G = 0, wm2 = wn2 = 0 with the wave's offsets folded into bm0 / bn0, and the
-    // extents of the "inside C" test those of the half
-    {
-      using CFG = BTCfg<64 * BJ>;
-      bt_u32x4 bpre[BJ * 2];
-#pragma unroll
-      for (int j = 0; j < BJ * 2; ++j) bpre[j] = bt_u32x4{0u, 0u, 0u, 0u};
-      const int bme = bm0 + wm * (AI * 32), bne = bn0 + wn * (BJ * 32);
-      bool fast = false;
-      if constexpr (BJ == 3) {  // bt_epilogue_fast (bias vectors fetched ahead, residual loads batched) exists for three column blocks
-        fast = !(d.flags & (GEMM_OUT_F32 | GEMM_GELU)) && bm0 + 256 <= d.M && bn0 + BN <= d.N;
-        if (fast && (d.flags & GEMM_BIAS_N)) {
-#pragma unroll
-          for (int j = 0; j < BJ * 2; ++j)
-            bpre[j] = *reinterpret_cast<const bt_u32x4*>(d.bias + bne + 8 * hi + (j >> 1) * 32 + (j & 1) * 16);
-        }
-      }
-#pragma unroll
-      for (int h = 0; h < AI / 2; ++h)
-        pp_epilogue<CFG, 0, false>(d, reinterpret_cast<f32x16(&)[2][BJ]>(acc[2 * h]), z, bme + 64 * h, bne, 0, 0, lane, bpre, fast, 64,
-                                   32 * BJ);
-    }
-    st0 = (st0 + (uint32_t)nkt) % (uint32_t)NST;
-    z = zn; bm0 = bm0n; bn0 = bn0n;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-template <int BN>
-static int bt8_launch(GemmDesc d, hipStream_t stream) {
-  if (d.ksplit > 1) return U2_ERR_ARG;
-  d.tiles_m = (int)cdiv(d.M, 256);
-  d.tiles_n = (int)cdiv(d.N, BN);
-  const int64_t total = (int64_t)d.tiles_m * d.tiles_n * d.nz;
-  if (total > 0x3fffffff) return U2_ERR_ARG;
-  const int grid = (int)std::min<int64_t>(total, opts().gemm_big_grid);
-  hipLaunchKernelGGL((gemm_bt8_kernel<BN>), dim3(grid), dim3(512), 0, stream, d);
-  return launch_status();
-}
-
 template <int NJ, bool PAIR = false>
 static int bt_launch(GemmDesc d, hipStream_t stream) {
   d.tiles_m = (int)cdiv(d.M, 256);
@@ -594,16 +464,9 @@ static int bt_slices(GemmDesc& d, int64_t tiles, int want, hipStream_t stream) {
   return 1;
 }
 
-// variants: 20 = 256 x 256, 21 = 256 x 192, 22 = 256 x 128 tiles (ring form); 30 / 31 / 32 = the eight-wave forms of the same widths
+// variants: 20 = 256 x 256, 21 = 256 x 192, 22 = 256 x 128 tiles (ring form)
 static int bt_launch_variant(int v, const GemmDesc& d, hipStream_t stream) {
-  switch (v) {
-    case 20: return bt_launch<4>(d, stream);
-    case 22: return bt_launch<2>(d, stream);
-    case 30: return bt8_launch<256>(d, stream);
-    case 31: return bt8_launch<192>(d, stream);
-    case 32: return bt8_launch<128>(d, stream);
-    default: return bt_launch<3>(d, stream);
-  }
+  return v == 20 ? bt_launch<4>(d, stream) : v == 22 ? bt_launch<2>(d, stream) : bt_launch<3>(d, stream);
 }
 
 // Which tile (tools/gpu_check.py ppperf on MI355X, random operands; DESIGN.md section 3 has the tables): the kernel
@@ -632,13 +495,14 @@ static int bt_pick(const GemmDesc& d) {
 // (bt_pick: fill < 70 %) while the 128-wide ones make ONE round that is at least three-quarters full: M = 2048 rows against an
 // E x E weight (the SVR's output projections), 1024 against 2E x E (the TTA's text k | v), 2048 x 4096 x 6144 (projector) --
 // 256 tiles each.  tools/bt_sweep.py, cold weights, us (128^2 kernel -> here; vendor library beside it): 89.7 -> 69.4 (65.9),
-// 82.0 -> 64.4 (62.9), 115.1 -> 95.5 (profiles/r04_bt_ring_sweep.log).  With 128 tiles (1024 x 4096 x 4096) it ties the 128^2 kernel.
+// 82.0 -> 64.4 (62.9), 115.1 -> 95.5 (profiles/r04_bt_ring_sweep.log); 192 tiles (prefill q|k|v, 1024 x 6144 x 4096): 71.2 with two K
+// slices of 256 x 192 tiles -> 57.5 (r04_bt_counted_waits_ab.log).  With 128 tiles (1024 x 4096 x 4096) it ties the 128^2 kernel.
 static int bt_pick_ring(const GemmDesc& d) {
   if (!bt_legal(d) || d.K < 512) return 0;
   if ((d.flags & GEMM_GELU) && !opts().gemm_big_gelu) return 0;
   const int gmax = opts().gemm_big_grid;
   const int64_t t2 = cdiv(d.M, 256) * cdiv(d.N, 128) * d.nz;
-  return (t2 * 4 > (int64_t)gmax * 3 && t2 <= gmax) ? 22 : 0;
+  return (t2 * 4 >= (int64_t)gmax * 3 && t2 <= gmax) ? 22 : 0;
 }
 
 // Products that leave the 256 CUs a partial round of big tiles, sliced along K so that (tiles x slices) fills them -- the
@@ -686,8 +550,12 @@ int gemm_big_try(const GemmDesc& d, hipStream_t stream) {
   if (mode > 0) {  // forced (tests, measurements)
     if (!bt_legal(d)) return 0;
     GemmDesc ds = d;
-    if (mode < 22) bt_slices(ds, 0, opts().gemm_big_splitk, stream);
+    if (mode != 22) bt_slices(ds, 0, opts().gemm_big_splitk, stream);
     const int e = bt_launch_variant(mode, ds, stream);
+    return e == U2_OK ? 1 : e;
+  }
+  if (opts().gemm_big_ring && d.M >= 512 && bt_pick(d) == 0 && bt_pick_ring(d) == 22) {  // (ahead of the sliced forms: 192 ring tiles beat 2 x 128 sliced ones)
+    const int e = bt_launch_variant(22, d, stream);
     return e == U2_OK ? 1 : e;
   }
   if (opts().gemm_big_skinny) {
@@ -718,8 +586,7 @@ int gemm_big_try(const GemmDesc& d, hipStream_t stream) {
     e = gemm_classic(tail, stream);
     return e == U2_OK ? 1 : e;
   }
-  int v = bt_pick(d);
-  if (v == 0) v = bt_pick_ring(d);
+  const int v = bt_pick(d);
   if (v == 0) return 0;
   const int e = bt_launch_variant(v, d, stream);
   return e == U2_OK ? 1 : e;
