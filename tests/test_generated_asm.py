@@ -179,6 +179,89 @@ def test_gemm_bt_ring_fragment_reads_hit_the_rows_the_dma_wrote():
                 assert len(set(slots[16 * q:16 * q + 16])) == 16
 
 
+def test_gemm_bt_deep_forms_schedule_and_layout():
+    """Deep forms (three LDS stages for the streaming operand, two for the other; 256 x 192 and 256 x 256 tiles): per wave and
+    body the pieces of one K tile of each operand, issued shallow-first / deep-last so that the one counted wait (= the deep
+    operand's pieces per wave) covers everything older; targets: shallow tile t+1 -> its other stage in front of the barrier,
+    its tile t+2 -> the stage just left behind it, deep tile t+2 -> stage (t + 2) mod 3; fragment reads from the (t mod 3,
+    t mod 2) stage pair, behind the barrier from the next pair; the fragment reads return what the DMA pieces wrote."""
+    import re
+    text = (CSRC / "gemm_bt_asm.inc").read_text()
+    for nj in (3, 4):
+        for deep in "ab":
+            body = re.search(rf"#define GEMM_BT_ASM_TEXT_NJ{nj}_D{deep.upper()} \\\n(.*?)\n#define", text, re.S).group(1)
+            lines = re.findall(r'"(.*)\\n"', body)
+            SA, SB = (3, 2) if deep == "a" else (2, 3)
+            offb, bstg = 32768 * SA, nj * 8192
+            npc = {"a": 8, "b": 2 * nj}
+            nd, ns = npc[deep], npc["b" if deep == "a" else "a"]
+            # address registers -> (matrix, kk * 32, stage offset)
+            areg = {}
+            for l in lines:
+                m = re.match(r"v_xor_b32 v(\d+), (\d+), %\[(aa0|ab0)\]", l)
+                if m:
+                    areg[int(m.group(1))] = (m.group(3)[1], int(m.group(2)), 0)
+                m = re.match(r"v_mov_b32 v(\d+), %\[(aa0|ab0)\]", l)
+                if m:
+                    areg[int(m.group(1))] = (m.group(2)[1], 0, 0)
+            for l in lines:
+                m = re.match(r"v_add_u32 v(\d+), (\d+), v(\d+)", l)
+                if m:
+                    mat, kx, _ = areg[int(m.group(3))]
+                    areg[int(m.group(1))] = (mat, kx, int(m.group(2)))
+            assert len(areg) == 20
+            sda = int(re.search(r"s_lshl_b32 s(\d+), %\[wave\], 13", "\n".join(lines)).group(1))
+            for w in range(4):
+                for u in range(6):
+                    i0 = lines.index(f".Lbd_b{w}_{u}_%=:")
+                    i1 = next(k for k in range(i0, len(lines)) if lines[k].startswith("s_cmp_lt_u32"))
+                    bl = lines[i0:i1]
+                    assert sum(l.startswith("v_mfma") for l in bl) == 16 * nj
+                    assert sum(l.startswith("s_barrier") for l in bl) == 1
+                    bar = bl.index("s_barrier")
+                    assert bl[bar - 1] == f"s_waitcnt vmcnt({nd})"
+                    tg = [(("a" if int(m.group(1)) == sda else "b"), int(m.group(2)))
+                          for m in (re.match(r"s_add_u32 m0, s(\d+), (\d+)", l) for l in bl) if m]
+                    pos = [k for k, l in enumerate(bl) if l.startswith("s_add_u32 m0")]
+                    assert len(tg) == nd + ns
+                    stage = lambda mat, x: x // (32768 if mat == "a" else bstg)
+                    sh = "b" if deep == "a" else "a"
+                    front = [(m, x) for (m, x), k in zip(tg, pos) if k < bar]
+                    back = [(m, x) for (m, x), k in zip(tg, pos) if k > bar]
+                    # in front of the barrier: shallow pieces first, then ALL deep pieces
+                    kinds = [m for m, _ in front]
+                    assert kinds == sorted(kinds, key=lambda m: m == deep) and kinds.count(deep) == nd
+                    assert all(stage(m, x) == ((u + 2) % 3 if m == deep else (u + 1) % 2) for m, x in front)
+                    assert all(m == sh and stage(m, x) == u % 2 for m, x in back)
+                    assert len(back) + kinds.count(sh) == ns
+                    regs = [int(re.match(r"ds_read_b128 v\[\d+:\d+\], v(\d+)", l).group(1)) for l in bl if l.startswith("ds_read")]
+                    nbr = sum(l.startswith("ds_read") for l in bl[:bar])
+                    assert len(regs) == 4 * (4 + nj) and nbr == 3 * (4 + nj)
+                    want = lambda uu: {"a": 32768 * (uu % SA), "b": bstg * (uu % SB)}
+                    assert all(areg[r][2] == want(u)[areg[r][0]] for r in regs[:nbr])
+                    assert all(areg[r][2] == want(u + 1)[areg[r][0]] and areg[r][1] == 0 for r in regs[nbr:])
+            # layout: stage 0 of each operand as the DMA writes it (B tile behind the A stages)
+            lds0 = {}
+            for addr, (mat, row, chunk) in _bt_layout(nj).items():
+                lds0[addr if mat == "a" else addr - 32768 + offb] = (mat, row, chunk)
+            reads = set()
+            for l in lines:
+                m = re.match(r"ds_read_b128 v\[(\d+):\d+\], v(\d+) offset:(\d+)", l)
+                if m:
+                    mat, kx, st = areg[int(m.group(2))]
+                    reads.add((mat, kx >> 5, st, int(m.group(3))))
+            for wave in range(4):
+                wm, wn = wave >> 1, wave & 1
+                for (mat, kk, st, off) in reads:
+                    for lane in range(64):
+                        hi, l31 = lane >> 5, lane & 31
+                        abk0 = l31 * 128 + ((hi ^ ((l31 >> 1) & 7)) << 4)
+                        base = wm * 16384 if mat == "a" else offb + wn * (nj * 4096)
+                        addr = ((base + abk0) ^ (kk << 5)) + off          # (+ st: the same bytes of another stage)
+                        want_row = (wm * 128 if mat == "a" else wn * 32 * nj) + (off // 4096) * 32 + l31
+                        assert lds0[addr] == (mat, want_row, kk * 2 + hi)
+
+
 def test_flash_dp2_asm_is_generated():
     want = "".join(_run("tools/gen_flash_dp2_asm.py", *f) for f in ((), ("--timed",), ("--exact",), ("--exact", "--timed")))
     assert want == (CSRC / "flash_dp2_asm.inc").read_text()
@@ -255,7 +338,7 @@ def test_generated_asm_passes_the_hazard_lint():
             seen += 1
             assert len(lines) > 200
             assert asm_lint.lint(name, lines) == []
-    assert seen == 8  # flash KV loop (exact / pre-scaled x plain / timed), GEMM K loop NJ = 4, NJ = 3, NJ = 3 SwiGLU-pair, NJ = 2 ring
+    assert seen == 12  # flash KV loop (exact / pre-scaled x plain / timed), GEMM K loop NJ = 4, NJ = 3, NJ = 3 SwiGLU-pair, NJ = 2 ring, four deep forms
     # the linter itself: each rule fires on a minimal violation
     bad = {
         "R1": ["v_exp_f32 v1, v1", "v_add_f32 v2, v1, v1"],

@@ -445,6 +445,181 @@ def gen_ring(nj=2):
     e("s_nop 7")
 
 
+# ---- deep forms: THREE stages for the operand that streams, two for the other ----------------------------------------------
+# 256 x 192 (and 256 x 256) stages do not fit the LDS three times, but the two operands need not be treated alike: in the ViT the
+# activations stream (25-100 MB per product) against weights that stay in the L2; in the tokenizer 100 MB of cold weights stream
+# against 17 MB of activations.  The streaming ("deep") operand gets a third stage and the ring form's schedule -- its K tile
+# t+2 is issued during iteration t and has until the barrier of iteration t+1 --, the other one keeps two stages and the
+# two-stage deadline (K tile t+1 lands by the barrier of iteration t).  Vector memory returns in order, so inside an iteration
+# the shallow operand's pieces go FIRST (k16 step 3 of the previous iteration, behind its barrier, and step 0) and the deep
+# one's LAST (steps 1 and 2): the wait in front of the barrier, vmcnt(pieces of the deep operand per wave), then covers
+# everything older -- the shallow tile t+1 and the deep tile t+1 issued an iteration ago.  LDS: [A stages][B stages]; the loop is
+# unrolled over lcm(3, 2) = 6 stage pairs and entered at (K tiles this workgroup has consumed) mod 6 (operand st0).
+
+def gen_deep(nj, deep):
+    global NJ
+    NJ = nj
+    del out[:]
+    SA, SB = (3, 2) if deep == "a" else (2, 3)
+    L = 6
+    nslot, nread, npb = 4 * NJ, 4 + NJ, 2 * NJ
+    BSTG = NJ * 8192
+    OFFB = 32768 * SA
+    VB = 56
+    XAA = [[VB + 4 * st + k for k in range(4)] for st in range(SA)]
+    XAB = [[VB + 4 * SA + 4 * st + k for k in range(4)] for st in range(SB)]
+    XBUF = VB + 4 * (SA + SB)
+    vhi = XBUF + 2 * nread * 4 - 1
+
+    def xa(b, i):
+        return vr(XBUF + 4 * nread * b + 4 * i, 4)
+
+    def xb(b, j):
+        return vr(XBUF + 4 * nread * b + 16 + 4 * j, 4)
+
+    def xread(b, sa, sb, kk, n):
+        order = [("a", 0)] + [("b", j) for j in range(NJ)] + [("a", 1), ("a", 2), ("a", 3)]
+        m, idx = order[n]
+        if m == "a":
+            e(f"ds_read_b128 {xa(b, idx)}, {v(XAA[sa][kk])} offset:{4096 * idx}")
+        else:
+            e(f"ds_read_b128 {xb(b, idx)}, {v(XAB[sb][kk])} offset:{4096 * idx}")
+
+    def xpiece(mat, p, st, s_k):
+        if mat == "a":
+            e(f"s_add_u32 m0, {s(S_DA)}, {32768 * st + 1024 * p}")
+        else:
+            e(f"s_add_u32 m0, {s(S_DB)}, {BSTG * st + 1024 * p}")
+        row = (S_ROWA if mat == "a" else S_ROWB)[p >> 1]
+        e(f"s_add_u32 {s(S_TMP)}, {s(s_k[0] if mat == 'a' else s_k[1])}, {s(row)}")
+        e(f"buffer_load_dwordx4 %[v{mat}{p & 1}], %[rs{mat}], {s(S_TMP)} offen lds")
+
+    dmat, smat = ("a", "b") if deep == "a" else ("b", "a")
+    npc = {"a": 8, "b": npb}
+    window = 2 * nslot
+    # piece i of wave w of a matrix -> position in its two-step window
+    sched = {m: {w: {} for w in range(4)} for m in "ab"}
+    for m in "ab":
+        for i in range(npc[m]):
+            for w in range(4):
+                g = (i * 4 + w) * window // (4 * npc[m])
+                sched[m][w].setdefault(g, []).append(i)
+    K0, K1, K2 = (S_K0A, S_K0B), (S_K1A, S_K1B), (S_K2A, S_K2B)
+    # ---- setup (common)
+    for k in range(4):
+        if k:
+            e(f"v_xor_b32 {v(XAA[0][k])}, {32 * k}, %[aa0]")
+            e(f"v_xor_b32 {v(XAB[0][k])}, {32 * k}, %[ab0]")
+        else:
+            e(f"v_mov_b32 {v(XAA[0][0])}, %[aa0]")
+            e(f"v_mov_b32 {v(XAB[0][0])}, %[ab0]")
+    for st in range(1, SA):
+        for k in range(4):
+            e(f"v_add_u32 {v(XAA[st][k])}, {32768 * st}, {v(XAA[0][k])}")
+    for st in range(1, SB):
+        for k in range(4):
+            e(f"v_add_u32 {v(XAB[st][k])}, {BSTG * st}, {v(XAB[0][k])}")
+    e(f"s_mov_b32 {s(S_ROWA[0])}, 0")
+    for q in (1, 2, 3):
+        e(f"s_add_u32 {s(S_ROWA[q])}, {s(S_ROWA[q - 1])}, %[lda16]")
+    e(f"s_mov_b32 {s(S_ROWB[0])}, 0")
+    for q in (1, 2, 3):
+        e(f"s_add_u32 {s(S_ROWB[q])}, {s(S_ROWB[q - 1])}, %[ldb16]")
+    e(f"s_mov_b32 {s(S_KT)}, 0")
+    e(f"s_lshl_b32 {s(S_DA)}, %[wave], 13")
+    e(f"s_mul_i32 {s(S_DB)}, %[wave], {2048 * NJ}")
+    e(f"s_add_u32 {s(S_DB)}, {s(S_DB)}, {OFFB}")
+    e(f"s_mov_b32 {s(S_K0A)}, %[base_a]")
+    e(f"s_mov_b32 {s(S_K0B)}, %[base_b]")
+    e(f"s_add_u32 {s(S_K1A)}, %[base_a], 128")
+    e(f"s_add_u32 {s(S_K1B)}, %[base_b], 128")
+    e(f"s_add_u32 {s(S_K2A)}, %[base_a], 256")
+    e(f"s_add_u32 {s(S_K2B)}, %[base_b], 256")
+    e("s_cmp_eq_u32 %[nkt], 2")
+    e(f"s_cselect_b32 {s(S_K2A)}, %[nbase_a], {s(S_K2A)}")
+    e(f"s_cselect_b32 {s(S_K2B)}, %[nbase_b], {s(S_K2B)}")
+    for w in (1, 2, 3):
+        e(f"s_cmp_eq_u32 %[wave], {w}")
+        e(f"s_cbranch_scc1 .Lbd_w{w}_%=")
+    for w in range(4):
+        if w:
+            e(f".Lbd_w{w}_%=:")
+        e("s_cmp_eq_u32 %[first], 0")
+        e(f"s_cbranch_scc1 .Lbd_cont{w}_%=")
+        # first tile of the workgroup (st0 = 0): K tile 0 of both operands, then what the steady state has in flight when an
+        # iteration starts: all of the deep operand's K tile 1 and the part of the shallow one's that k16 step 3 issues
+        for i in range(8):
+            xpiece("a", i, 0, K0)
+        for i in range(npb):
+            xpiece("b", i, 0, K0)
+        early = [i for g in range(nslot) for i in sched[smat][w].get(g, [])]
+        for i in range(npc[dmat]):
+            xpiece(dmat, i, 1, K1)
+        for i in early:
+            xpiece(smat, i, 1, K1)
+        e(f"s_waitcnt vmcnt({npc[dmat] + len(early)})")
+        e("s_barrier")
+        e(f".Lbd_cont{w}_%=:")
+        for u in range(1, L):
+            e(f"s_cmp_eq_u32 %[st0], {u}")
+            e(f"s_cbranch_scc1 .Lbd_e{w}_{u}_%=")
+        for u in range(L):
+            if u:
+                e(f".Lbd_e{w}_{u}_%=:")
+            for n in range(nread):
+                xread(0, u % SA, u % SB, 0, n)
+            e(f"s_branch .Lbd_b{w}_{u}_%=")
+        for u in range(L):
+            e(f".Lbd_b{w}_{u}_%=:")
+            sa, sb = u % SA, u % SB
+            na, nb = (u + 1) % SA, (u + 1) % SB
+            st_of = {"a": sa, "b": sb}
+            nstages = {"a": SA, "b": SB}
+            shallow_next = (st_of[smat] + 1) % 2          # shallow tile t+1 -> its other stage
+            deep_tgt = (st_of[dmat] + 2) % 3              # deep tile t+2 -> the stage tile t-1 left
+
+            def xk(items, rb, rsa, rsb, rkk):
+                """companions of a k16 step's slots: fragment reads + the DMA pieces in items: slot -> [(matrix, piece, stage, K)]"""
+                def f(slot):
+                    if slot < nread:
+                        xread(rb, rsa, rsb, rkk, slot)
+                    for (m, i, st, s_k) in items.get(slot, []):
+                        xpiece(m, i, st, s_k)
+                return f
+
+            def win(m, half, st, s_k):
+                return {slot: [(m, i, st, s_k) for i in sched[m][w].get(half * nslot + slot, [])] for slot in range(nslot)}
+
+            mfma_block(0, xk(win(smat, 1, shallow_next, K1), 1, sa, sb, 1), xa, xb)
+            mfma_block(1, xk(win(dmat, 0, deep_tgt, K2), 0, sa, sb, 2), xa, xb)
+            mfma_block(0, xk(win(dmat, 1, deep_tgt, K2), 1, sa, sb, 3), xa, xb)
+            e(f"s_waitcnt vmcnt({npc[dmat]})")
+            e("s_barrier")
+            # behind the barrier: the shallow operand's stage of tile t is free -> first half of its tile t+2
+            mfma_block(1, xk(win(smat, 0, st_of[smat], K2), 0, na, nb, 0), xa, xb)
+            e(f"s_add_u32 {s(S_KT)}, {s(S_KT)}, 1")
+            e(f"s_mov_b32 {s(S_K1A)}, {s(S_K2A)}")
+            e(f"s_mov_b32 {s(S_K1B)}, {s(S_K2B)}")
+            e(f"s_add_u32 {s(S_K2A)}, {s(S_K2A)}, 128")
+            e(f"s_add_u32 {s(S_K2B)}, {s(S_K2B)}, 128")
+            e(f"s_add_u32 {s(S_TMP)}, {s(S_KT)}, 2")
+            e(f"s_cmp_eq_u32 {s(S_TMP)}, %[nkt]")
+            e(f"s_cselect_b32 {s(S_K2A)}, %[nbase_a], {s(S_K2A)}")
+            e(f"s_cselect_b32 {s(S_K2B)}, %[nbase_b], {s(S_K2B)}")
+            e(f"s_cmp_lt_u32 {s(S_KT)}, %[nkt]")
+            if u < L - 1:
+                e(f"s_cbranch_scc0 .Lbd_done_%=")
+            else:
+                e(f"s_cbranch_scc1 .Lbd_b{w}_0_%=")
+        if w < 3:
+            e("s_branch .Lbd_done_%=")
+    e(".Lbd_done_%=:")
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_nop 15")
+    e("s_nop 7")
+    return vhi
+
+
 # ---- measured and removed in round 4 (history: commits "eight-wave forms ...", "L2-prefetch trial ...") ----------------------------
 #  * eight-wave forms of all three tile widths (two waves per SIMD, 128 x 64 / 64 x 96 / 64 x 64 accumulators per wave): tie the
 #    four-wave loops on every shape (profiles/r04_bt8_vit.log, r04_bt8_tok.log) -- the K loop is not bound by one wave's in-order issue.
@@ -471,7 +646,15 @@ gen_ring(2)
 print("#define GEMM_BT_ASM_TEXT_NJ2_RING \\")
 for i, line in enumerate(out):
     print(f'  "{line}\\n"' + (" \\" if i + 1 < len(out) else ""))
-for name, lo, hi in (("GEMM_BT_ASM_CLOBBERS", VLO, VHI), ("GEMM_BT_ASM_CLOBBERS_RING", RVLO, RVHI)):
+deep_hi = {}
+for nj, deep in ((3, "a"), (3, "b"), (4, "a"), (4, "b")):
+    ABL.clear()
+    deep_hi[(nj, deep)] = gen_deep(nj, deep)
+    print(f"#define GEMM_BT_ASM_TEXT_NJ{nj}_D{deep.upper()} \\")
+    for i, line in enumerate(out):
+        print(f'  "{line}\\n"' + (" \\" if i + 1 < len(out) else ""))
+for name, lo, hi in (("GEMM_BT_ASM_CLOBBERS", VLO, VHI), ("GEMM_BT_ASM_CLOBBERS_RING", RVLO, RVHI),
+                     ("GEMM_BT_ASM_CLOBBERS_NJ3_DEEP", 56, deep_hi[(3, "a")]), ("GEMM_BT_ASM_CLOBBERS_NJ4_DEEP", 56, deep_hi[(4, "a")])):
     clob = [f'"v{i}"' for i in range(lo, hi + 1)] + [f'"s{i}"' for i in range(SLO, SHI + 1)] + ['"scc"', '"memory"']
     print(f"#define {name} \\")
     for i in range(0, len(clob), 12):

@@ -255,8 +255,11 @@ typedef int bt_i32x4 __attribute__((ext_vector_type(4)));
 // NJ = 2 is the RING form (256 x 128 tiles, variant 22): three LDS stages of 48 KB, K tile t + 2 issued during iteration t and
 // waited for with a counted vmcnt one iteration later (tools/gen_gemm_bt_asm.py, gen_ring) -- the tile for products whose
 // 256-wide tiles would leave half of the CUs without work (M = 2048 / 1024 against E x E and E x 2E weights: 256 tiles).
-template <int NJ, bool PAIR = false, bool SPLIT = false>  // 32-column blocks per wave: tile = 256 x (64 NJ)
+// DEEP = 1 / 2 (variants 23 / 24 at 256 x 192, 25 / 26 at 256 x 256): the A / the B operand streams -- it gets THREE LDS stages and
+// the ring's schedule, the other operand keeps two (gen_deep of the generator has the schedule and the in-order argument).
+template <int NJ, bool PAIR = false, bool SPLIT = false, int DEEP = 0>  // 32-column blocks per wave: tile = 256 x (64 NJ)
 __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
+  static_assert(DEEP == 0 || (NJ >= 3 && !PAIR && !SPLIT), "the deep forms are plain 256 x 192 / 256 x 256 kernels");
   static_assert(!(PAIR && SPLIT), "the pair form is not sliced");
   static_assert(!PAIR || NJ == 3, "the pair form exists for 256 x 192 tiles");
   static_assert(NJ == 2 || NJ == 3 || NJ == 4, "256 x 128 (ring) / 256 x 192 / 256 x 256 tiles");
@@ -265,7 +268,10 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
   constexpr bool RING = NJ == 2;
   using CFG = BTCfg<BN>;
   // two stages: [stage][A tile 32 KB | B tile <= 32 KB];  ring: three stages of [A tile 32 KB | B tile 16 KB]
-  __shared__ __attribute__((aligned(1024))) char lds[RING ? 147456 : 131072];
+  // deep forms: [A stages of 32 KB][B stages of 8 NJ KB], three of the deep operand and two of the other
+  constexpr int OFFB = DEEP == 1 ? 3 * 32768 : DEEP == 2 ? 2 * 32768 : 32768;
+  constexpr int LDS_BYTES = DEEP == 1 ? 3 * 32768 + 2 * NJ * 8192 : DEEP == 2 ? 2 * 32768 + 3 * NJ * 8192 : RING ? 147456 : 131072;
+  __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -304,7 +310,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
   const int lda16 = 16 * (int)d.lda * 2, ldb16 = 16 * (int)d.ldb * 2;
   const int nkt_all = d.K >> 6;
   const bool chain = d.nz == 1;  // one K loop runs on from tile to tile (same descriptors)
-  uint32_t st0 = 0;              // LDS stage that holds K tile 0 of the current output tile (byte offset 0 / 0x10000; ring: index 0..2)
+  uint32_t st0 = 0;              // LDS stage that holds K tile 0 of the current output tile (byte offset 0 / 0x10000; ring: index 0..2;
+                                 // deep forms: K tiles consumed so far mod 6 = the (A stage, B stage) pair)
   int z, bm0, bn0;
   pp_tile<BN>(d, 0, gd, bid, total, tiles_mn, z, bm0, bn0);
   for (int r = 0; r < my_tiles; ++r) {
@@ -330,8 +337,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
     rsb[3] = 0x00020000;
     const int first = (r == 0 || !chain) ? 1 : 0;
     if (first) st0 = 0;
-    const uint32_t aa0 = (lds_u32 + wm * 16384 + abk0) ^ (RING ? 0u : st0);  // (ring: stage 0's addresses, the asm adds the stage)
-    const uint32_t ab0 = (lds_u32 + 32768 + wn * (NJ * 4096) + abk0) ^ (RING ? 0u : st0);
+    const uint32_t aa0 = (lds_u32 + wm * 16384 + abk0) ^ ((RING || DEEP) ? 0u : st0);  // (ring / deep: stage 0's addresses, the asm adds the stage)
+    const uint32_t ab0 = (lds_u32 + OFFB + wn * (NJ * 4096) + abk0) ^ ((RING || DEEP) ? 0u : st0);
     // (readfirstlane: the values are uniform, but hipcc keeps loop-carried tile coordinates in VGPRs)
     const int base_a = __builtin_amdgcn_readfirstlane((bm0 * (int)d.lda + kt0 * 64) * 2);
     const int base_b = __builtin_amdgcn_readfirstlane(((PAIR ? bn0 >> 1 : bn0) * (int)d.ldb + kt0 * 64) * 2);
@@ -355,7 +362,31 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
   [va0] "v"(va0), [va1] "v"(va1), [vb0] "v"(vb0), [vb1] "v"(vb1), [aa0] "v"(aa0), [ab0] "v"(ab0), [rsa] "s"(rsa),     \
       [rsb] "s"(rsb), [lda16] "s"(lda16), [nkt] "s"(nkt), [wave] "s"(wave), [st0] "s"(st0_s), [first] "s"(first_s),   \
       [base_a] "s"(base_a), [base_b] "s"(base_b), [nbase_a] "s"(nbase_a), [nbase_b] "s"(nbase_b)
-    if constexpr (NJ == 2) {
+    if constexpr (DEEP != 0 && NJ == 3) {
+      if constexpr (DEEP == 1)
+        asm volatile(GEMM_BT_ASM_TEXT_NJ3_DA
+                     : BT_ACC3(0, 0), BT_ACC3(0, 1), BT_ACC3(1, 0), BT_ACC3(1, 1)
+                     : BT_IN, [ldb16] "s"(ldb16)
+                     : GEMM_BT_ASM_CLOBBERS_NJ3_DEEP);
+      else
+        asm volatile(GEMM_BT_ASM_TEXT_NJ3_DB
+                     : BT_ACC3(0, 0), BT_ACC3(0, 1), BT_ACC3(1, 0), BT_ACC3(1, 1)
+                     : BT_IN, [ldb16] "s"(ldb16)
+                     : GEMM_BT_ASM_CLOBBERS_NJ3_DEEP);
+    } else if constexpr (DEEP != 0) {
+      if constexpr (DEEP == 1)
+        asm volatile(GEMM_BT_ASM_TEXT_NJ4_DA
+                     : BT_ACC3(0, 0), [c003] "+a"(acc[0][0][3]), BT_ACC3(0, 1), [c013] "+a"(acc[0][1][3]), BT_ACC3(1, 0),
+                       [c103] "+a"(acc[1][0][3]), BT_ACC3(1, 1), [c113] "+a"(acc[1][1][3])
+                     : BT_IN, [ldb16] "s"(ldb16)
+                     : GEMM_BT_ASM_CLOBBERS_NJ4_DEEP);
+      else
+        asm volatile(GEMM_BT_ASM_TEXT_NJ4_DB
+                     : BT_ACC3(0, 0), [c003] "+a"(acc[0][0][3]), BT_ACC3(0, 1), [c013] "+a"(acc[0][1][3]), BT_ACC3(1, 0),
+                       [c103] "+a"(acc[1][0][3]), BT_ACC3(1, 1), [c113] "+a"(acc[1][1][3])
+                     : BT_IN, [ldb16] "s"(ldb16)
+                     : GEMM_BT_ASM_CLOBBERS_NJ4_DEEP);
+    } else if constexpr (NJ == 2) {
       asm volatile(GEMM_BT_ASM_TEXT_NJ2_RING
                    : [c000] "+a"(acc[0][0][0]), [c001] "+a"(acc[0][0][1]), [c010] "+a"(acc[0][1][0]), [c011] "+a"(acc[0][1][1]),
                      [c100] "+a"(acc[1][0][0]), [c101] "+a"(acc[1][0][1]), [c110] "+a"(acc[1][1][0]), [c111] "+a"(acc[1][1][1])
@@ -408,11 +439,24 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
       pp_epilogue<CFG, 0, PAIR>(d, acc[0], z, bm0 + wm * 128, bn0, 0, wn, lane, bpre, fast);
       pp_epilogue<CFG, 0, PAIR>(d, acc[1], z, bm0 + wm * 128, bn0, 1, wn, lane, bpre, fast);
     }
-    if constexpr (RING) st0 = (st0 + (uint32_t)nkt) % 3u;
+    if constexpr (DEEP != 0) st0 = (st0 + (uint32_t)nkt) % 6u;
+    else if constexpr (RING) st0 = (st0 + (uint32_t)nkt) % 3u;
     else st0 ^= (uint32_t)(nkt & 1) << 16;
     z = zn; bm0 = bm0n; bn0 = bn0n;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last K loop's prefetch into LDS
+}
+
+template <int NJ, int DEEP>
+static int bt_launch_deep(GemmDesc d, hipStream_t stream) {
+  if (d.ksplit > 1) return U2_ERR_ARG;
+  d.tiles_m = (int)cdiv(d.M, 256);
+  d.tiles_n = (int)cdiv(d.N, 64 * NJ);
+  const int64_t total = (int64_t)d.tiles_m * d.tiles_n * d.nz;
+  if (total > 0x3fffffff) return U2_ERR_ARG;
+  const int grid = (int)std::min<int64_t>(total, opts().gemm_big_grid);
+  hipLaunchKernelGGL((gemm_bt_kernel<NJ, false, false, DEEP>), dim3(grid), dim3(256), 0, stream, d);
+  return launch_status();
 }
 
 template <int NJ, bool PAIR = false>
@@ -464,10 +508,24 @@ static int bt_slices(GemmDesc& d, int64_t tiles, int want, hipStream_t stream) {
   return 1;
 }
 
-// variants: 20 = 256 x 256, 21 = 256 x 192, 22 = 256 x 128 tiles (ring form)
+// variants: 20 = 256 x 256, 21 = 256 x 192, 22 = 256 x 128 tiles (ring form); 23 / 24 = 256 x 192 with A / B deep, 25 / 26 = 256 x 256
 static int bt_launch_variant(int v, const GemmDesc& d, hipStream_t stream) {
-  return v == 20 ? bt_launch<4>(d, stream) : v == 22 ? bt_launch<2>(d, stream) : bt_launch<3>(d, stream);
+  switch (v) {
+    case 20: return bt_launch<4>(d, stream);
+    case 22: return bt_launch<2>(d, stream);
+    case 23: return bt_launch_deep<3, 1>(d, stream);
+    case 24: return bt_launch_deep<3, 2>(d, stream);
+    case 25: return bt_launch_deep<4, 1>(d, stream);
+    case 26: return bt_launch_deep<4, 2>(d, stream);
+    default: return bt_launch<3>(d, stream);
+  }
 }
+
+// The heuristic's choice (20 / 21) as launched: the deep form of the same tile width with B as the three-stage operand (26 / 24) --
+// tools/bt_sweep.py / bt_epilogue_probe.py, cold operands, us two-stage -> deep B (deep A beside it), profiles/r04_bt_deep_*.log:
+//   ViT q|k|v 67.6 -> 64.2 (65.6), out-projection 32.1 -> 30.6 (31.0), fc2 72.2 -> 67.4 (67.3); 2048 x 12288 x 4096 191.4 -> 163.0 (166.3);
+//   1792 x 8192 x 4096 114.9 -> 102.6 (102.9); 4096^3 117.8 -> 110.6 (110.4); 8192^3 890 -> 816 (831) = 1.35 PF/s.
+static int bt_deep_of(int v) { return !opts().gemm_big_deep ? v : v == 20 ? 26 : v == 21 ? 24 : v; }
 
 // Which tile (tools/gpu_check.py ppperf on MI355X, random operands; DESIGN.md section 3 has the tables): the kernel
 // runs its K loop at ~50 % of the MFMA peak (8192^3: 1.23-1.29 PF/s; gemm.hip's 128 x 128 tiles: 0.9) but nothing
@@ -550,7 +608,7 @@ int gemm_big_try(const GemmDesc& d, hipStream_t stream) {
   if (mode > 0) {  // forced (tests, measurements)
     if (!bt_legal(d)) return 0;
     GemmDesc ds = d;
-    if (mode != 22) bt_slices(ds, 0, opts().gemm_big_splitk, stream);
+    if (mode < 22) bt_slices(ds, 0, opts().gemm_big_splitk, stream);
     const int e = bt_launch_variant(mode, ds, stream);
     return e == U2_OK ? 1 : e;
   }
@@ -581,14 +639,14 @@ int gemm_big_try(const GemmDesc& d, hipStream_t stream) {
     tail.A = d.A + (int64_t)main.M * d.lda;
     tail.C = reinterpret_cast<char*>(d.C) + (int64_t)main.M * d.ldc * (f32 ? 4 : 2);
     if (d.flags & GEMM_RESIDUAL) tail.R = d.R + (int64_t)main.M * d.ldr;
-    int e = bt_launch_variant(v, main, stream);
+    int e = bt_launch_variant(bt_deep_of(v), main, stream);
     if (e != U2_OK) return e;
     e = gemm_classic(tail, stream);
     return e == U2_OK ? 1 : e;
   }
   const int v = bt_pick(d);
   if (v == 0) return 0;
-  const int e = bt_launch_variant(v, d, stream);
+  const int e = bt_launch_variant(bt_deep_of(v), d, stream);
   return e == U2_OK ? 1 : e;
 }
 
