@@ -52,11 +52,16 @@ u2tok_ctx_t u2tok_ctx_get_current(void);     /* NULL when the thread uses the de
 
 /* Tuning / diagnostics switches of the calling thread's current context; U2TOK_ERR_ARG if unknown / out of range:
     "gemm_tile" {0 heuristic, 64, 128: tile of the small-tile kernel}, "gemm_splitk" {-1 never, 0 heuristic, 2..16 force
-    that many K slices where scratch allows}, "gemm_big" {-1 never, 0 heuristic, 20 / 21 force the 256x256 / 256x192
-    big-tile kernel}, "gemm_big_grid" {persistent workgroups}, "gemm_big_gelu" {0, 1: GELU products may take the
-    big-tile kernel}, "kmajor_b" {1: P V and the DiffTS aggregation read V / X in place as K-major operands, 0: through
-    transposed copies},
-    "flash_mode" {0 pick, 1 plain 128-row units, 5 double pipeline (asm KV loop)}, "vit_flash" {0 unfused attention, 1}, "tta_overlap" {0, 1: side stream for the TTA k|v projections},
+    that many K slices where scratch allows}, "gemm_big" {-1 never, 0 heuristic; force a form of the big-tile kernel: 20 / 21 =
+    256x256 / 256x192 tiles with two LDS stages, 22 = 256x128 ring (three stages), 23 / 24 = 256x192 with three stages for A /
+    for B, 25 / 26 = the same at 256x256}, "gemm_big_grid" {persistent workgroups}, "gemm_big_gelu" {1: GELU products may take
+    the big-tile kernel, 0: never}, "gemm_big_ring" / "gemm_big_deep" {1: the heuristic may pick the ring / launches the deep
+    forms, 0: two-stage forms only}, "gemm_big_splitk" {K slices of a FORCED big-tile launch}, "gemm_big_skinny" {1: partial-round
+    products may take the big-tile kernel with K slices}, "kmajor_b" {1: P V and the DiffTS aggregation read V / X in place as
+    K-major operands, 0: through transposed copies},
+    "flash_mode" {0 pick, 1 plain 128-row units, 7 double pipeline (generated asm KV loop)}, "flash_q_prescaled" {1: the q handed to
+    u2tok_flash_attention_d64 already carries scale * log2 e}, "vit_flash" {0 unfused attention, 1}, "tta_overlap" {0, 1: side
+    stream for the TTA k|v projections},
     "tok_flash" {1: the tokenizer's attention cores run the fused kernel of u2tok_tok_attention, 0: GEMM -> softmax -> GEMM},
     "profile" {0, 1} */
 int u2tok_set_option(const char* name, int value);

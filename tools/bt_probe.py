@@ -43,4 +43,4 @@ for (M, N, K, gelu) in shapes:
     print(row)
 if OPT:
     ops.set_option(OPT, 0)
-ops.set_option("gemm_big_gelu", 0)
+ops.set_option("gemm_big_gelu", 1)

@@ -412,7 +412,7 @@ def sec_geluperf():
         print(f"  fc1 {M}x{N}x{K} {name:34s}: gelu {ms * 1e3:7.1f} us ({2 * M * N * K / ms / 1e9:5.0f} TF/s)   bias only "
               f"{ms2 * 1e3:7.1f} us", flush=True)
     ops.set_option("gemm_big", 0)
-    ops.set_option("gemm_big_gelu", 0)
+    ops.set_option("gemm_big_gelu", 1)
 
 
 def sec_flashperf():

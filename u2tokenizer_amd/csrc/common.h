@@ -75,6 +75,28 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return 0.5f * x * (1.0f + e);
 }
 
+// Two values per instruction (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: the same IEEE operations per half, so the results are
+// those of gelu_fast bit for bit): 21 instructions per PAIR instead of 19 per value in the GEMM epilogues.
+typedef float gelu_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_fast2(float& x0, float& x1) {
+  const gelu_f32x2 x = {x0, x1};
+  const gelu_f32x2 z = x * 0.70710678118654752440f;
+  const gelu_f32x2 a = {fabsf(z.x), fabsf(z.y)};
+  gelu_f32x2 p = {0.0000430638f, 0.0000430638f};
+  p = __builtin_elementwise_fma(p, a, (gelu_f32x2){0.0002765672f, 0.0002765672f});
+  p = __builtin_elementwise_fma(p, a, (gelu_f32x2){0.0001520143f, 0.0001520143f});
+  p = __builtin_elementwise_fma(p, a, (gelu_f32x2){0.0092705272f, 0.0092705272f});
+  p = __builtin_elementwise_fma(p, a, (gelu_f32x2){0.0422820123f, 0.0422820123f});
+  p = __builtin_elementwise_fma(p, a, (gelu_f32x2){0.0705230784f, 0.0705230784f});
+  p = __builtin_elementwise_fma(p, a, (gelu_f32x2){1.0f, 1.0f});
+  p = p * p; p = p * p; p = p * p; p = p * p;
+  const gelu_f32x2 e = {__builtin_copysignf(1.0f - __builtin_amdgcn_rcpf(p.x), z.x),
+                        __builtin_copysignf(1.0f - __builtin_amdgcn_rcpf(p.y), z.y)};
+  const gelu_f32x2 r = 0.5f * x * (1.0f + e);
+  x0 = r.x;
+  x1 = r.y;
+}
+
 static inline int launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? U2_OK : U2_ERR_LAUNCH;

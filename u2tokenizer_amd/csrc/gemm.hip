@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
         const float al = n0 < d.nsplit ? d.alpha_lo : d.alpha;
         float v0 = acc[mi][ni][0] * al, v1 = acc[mi][ni][1] * al, v2 = acc[mi][ni][2] * al, v3 = acc[mi][ni][3] * al;
         if constexpr (decltype(BN_)::value) { v0 += bn[ni].x; v1 += bn[ni].y; v2 += bn[ni].z; v3 += bn[ni].w; }
-        if constexpr (decltype(GELU_)::value) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
+        if constexpr (decltype(GELU_)::value) { gelu_fast2(v0, v1); gelu_fast2(v2, v3); }
         if constexpr (decltype(RES_)::value) {
           const uint2 r2 = *reinterpret_cast<const uint2*>(Rz + (int64_t)m * d.ldr + n0);
           v0 += bf16lo(r2.x); v1 += bf16hi(r2.x); v2 += bf16lo(r2.y); v3 += bf16hi(r2.y);

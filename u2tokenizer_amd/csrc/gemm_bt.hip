@@ -196,7 +196,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmDesc& d, f32x16 (&acc)[2][
           }
           if constexpr (decltype(GELU_)::value) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+            for (int e = 0; e < 8; e += 2) gelu_fast2(v[e], v[e + 1]);
           }
           if constexpr (decltype(RES_)::value) {
             const uint4 r4 = *reinterpret_cast<const uint4*>(Rz + (int64_t)m * d.ldr + n0);
@@ -525,7 +525,10 @@ static int bt_launch_variant(int v, const GemmDesc& d, hipStream_t stream) {
 // tools/bt_sweep.py / bt_epilogue_probe.py, cold operands, us two-stage -> deep B (deep A beside it), profiles/r04_bt_deep_*.log:
 //   ViT q|k|v 67.6 -> 64.2 (65.6), out-projection 32.1 -> 30.6 (31.0), fc2 72.2 -> 67.4 (67.3); 2048 x 12288 x 4096 191.4 -> 163.0 (166.3);
 //   1792 x 8192 x 4096 114.9 -> 102.6 (102.9); 4096^3 117.8 -> 110.6 (110.4); 8192^3 890 -> 816 (831) = 1.35 PF/s.
-static int bt_deep_of(int v) { return !opts().gemm_big_deep ? v : v == 20 ? 26 : v == 21 ? 24 : v; }
+//   (GELU products keep two stages: fc1 + bias + GELU 112.7 us against 123.6 deep, profiles/r04_bt_gelu_forms.log)
+static int bt_deep_of(int v, int flags) {
+  return (!opts().gemm_big_deep || (flags & GEMM_GELU)) ? v : v == 20 ? 26 : v == 21 ? 24 : v;
+}
 
 // Which tile (tools/gpu_check.py ppperf on MI355X, random operands; DESIGN.md section 3 has the tables): the kernel
 // runs its K loop at ~50 % of the MFMA peak (8192^3: 1.23-1.29 PF/s; gemm.hip's 128 x 128 tiles: 0.9) but nothing
@@ -536,7 +539,9 @@ static int bt_deep_of(int v) { return !opts().gemm_big_deep ? v : v == 20 ? 26 :
 static int bt_pick(const GemmDesc& d) {
   if (!bt_legal(d) || d.K < 256) return 0;
   // the GELU epilogue is 256 values per lane of VALU work that the 128 x 128 kernel hides under its second workgroup
-  // per CU (fc1 of the ViT: 112 us there, 120 us here in round 1); option "gemm_big_gelu" = 1 sends it here anyway
+  // per CU (fc1 of the ViT: 112 us there, 120 us here in round 1).  Round 4 (packed-math GELU, gelu_fast2): 128 -> 113 us with cold
+  // operands (profiles/r04_bt_gelu_forms.log), pipeline 8.98 -> 8.93 ms per volume (r04_ab_gelu_pipeline.log): default on;
+  // option "gemm_big_gelu" = 0 keeps GELU products on the 128 x 128 kernel
   if ((d.flags & GEMM_GELU) && !opts().gemm_big_gelu) return 0;
   const int gmax = opts().gemm_big_grid;
   const int64_t tm = cdiv(d.M, 256) * d.nz;
@@ -639,14 +644,14 @@ int gemm_big_try(const GemmDesc& d, hipStream_t stream) {
     tail.A = d.A + (int64_t)main.M * d.lda;
     tail.C = reinterpret_cast<char*>(d.C) + (int64_t)main.M * d.ldc * (f32 ? 4 : 2);
     if (d.flags & GEMM_RESIDUAL) tail.R = d.R + (int64_t)main.M * d.ldr;
-    int e = bt_launch_variant(bt_deep_of(v), main, stream);
+    int e = bt_launch_variant(bt_deep_of(v, d.flags), main, stream);
     if (e != U2_OK) return e;
     e = gemm_classic(tail, stream);
     return e == U2_OK ? 1 : e;
   }
   const int v = bt_pick(d);
   if (v == 0) return 0;
-  const int e = bt_launch_variant(bt_deep_of(v), d, stream);
+  const int e = bt_launch_variant(bt_deep_of(v, d.flags), d, stream);
   return e == U2_OK ? 1 : e;
 }
 
