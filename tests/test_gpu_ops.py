@@ -567,7 +567,7 @@ def test_gemm_big_tile_variants(ops, variant):
         ops.set_option("gemm_big", 0)
 
 
-@pytest.mark.parametrize("variant,slices", [(21, 2), (21, 8), (20, 5), (21, 3), (20, 2)])
+@pytest.mark.parametrize("variant,slices", [(21, 2), (21, 8), (20, 5), (21, 3), (20, 2), (22, 8), (22, 3)])
 def test_gemm_big_tile_k_slices(ops, variant, slices):
     """The big-tile kernel with its K range cut into slices (fp32 partial sums in the stream's scratch, epilogue applied by the
     reduce kernel in a fixed order): uneven last slices, several tiles per workgroup with slices of different lengths chained in

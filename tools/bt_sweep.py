@@ -20,7 +20,8 @@ SHAPES = [(256, 4096, 4096), (256, 12288, 4096), (2048, 4096, 4096), (1024, 8192
           (1024, 4096, 12288), (1792, 8192, 4096), (2048, 12288, 4096)]
 CONFIGS = [("default", {}), ("classic", {"gemm_big": -1, "gemm_big_skinny": 0}),
            # (round 3 measured a TWO-stage 256 x 128-tile build of the kernel under the same option value: profiles/r03_bt_sweep.log)
-           ("256x128 ring", {"gemm_big": 22}), ("192 deepA", {"gemm_big": 23}), ("192 deepB", {"gemm_big": 24}),
+           ("256x128 ring", {"gemm_big": 22}), ("ring s4", {"gemm_big": 22, "gemm_big_splitk": 4}),
+           ("ring s8", {"gemm_big": 22, "gemm_big_splitk": 8}), ("ring s16", {"gemm_big": 22, "gemm_big_splitk": 16}), ("192 deepA", {"gemm_big": 23}), ("192 deepB", {"gemm_big": 24}),
            ("256 deepA", {"gemm_big": 25}), ("256 deepB", {"gemm_big": 26}),
            ("256x192", {"gemm_big": 21}), ("256x192 s2", {"gemm_big": 21, "gemm_big_splitk": 2}),
            ("256x192 s4", {"gemm_big": 21, "gemm_big_splitk": 4}),

@@ -1,5 +1,6 @@
 #!/bin/bash
-# K-loop ablations of the four-wave big-tile GEMM (measurement-only builds under ab_abl/, WRONG results): what is left of a
+# K-loop ablations of the four-wave big-tile GEMM (measurement-only builds under ab_abl/ made by tools/mk_ab_build.sh ab_abl/NAME
+# --ablate nodma,...; WRONG results): what is left of a
 # product's time without the LDS-DMA / the fragment reads / the barrier / the MFMAs
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; cd $R
 (timeout 100 python tools/bt_epilogue_probe.py 2>&1 | grep -v amdgpu.ids

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
   static_assert(!(PAIR && SPLIT), "the pair form is not sliced");
   static_assert(!PAIR || NJ == 3, "the pair form exists for 256 x 192 tiles");
   static_assert(NJ == 2 || NJ == 3 || NJ == 4, "256 x 128 (ring) / 256 x 192 / 256 x 256 tiles");
-  static_assert(NJ != 2 || (!PAIR && !SPLIT), "the ring form is plain");
+  static_assert(NJ != 2 || !PAIR, "no SwiGLU-pair ring form");
   constexpr int BN = 64 * NJ;
   constexpr bool RING = NJ == 2;
   using CFG = BTCfg<BN>;
@@ -467,9 +467,7 @@ static int bt_launch(GemmDesc d, hipStream_t stream) {
   const int64_t total = (int64_t)d.tiles_m * d.tiles_n * (d.ksplit > 1 ? d.ksplit : d.nz);
   if (total > 0x3fffffff) return U2_ERR_ARG;
   const int grid = (int)std::min<int64_t>(total, opts().gemm_big_grid);
-  if constexpr (NJ == 2) {
-    if (d.ksplit > 1) return U2_ERR_ARG;
-  } else if constexpr (!PAIR) {
+  if constexpr (!PAIR) {
     if (d.ksplit > 1) {
       hipLaunchKernelGGL((gemm_bt_kernel<NJ, false, true>), dim3(grid), dim3(256), 0, stream, d);
       return gemm_splitk_reduce(d, stream);
@@ -613,7 +611,7 @@ int gemm_big_try(const GemmDesc& d, hipStream_t stream) {
   if (mode > 0) {  // forced (tests, measurements)
     if (!bt_legal(d)) return 0;
     GemmDesc ds = d;
-    if (mode < 22) bt_slices(ds, 0, opts().gemm_big_splitk, stream);
+    if (mode <= 22) bt_slices(ds, 0, opts().gemm_big_splitk, stream);
     const int e = bt_launch_variant(mode, ds, stream);
     return e == U2_OK ? 1 : e;
   }
