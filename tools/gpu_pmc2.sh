@@ -1,6 +1,7 @@
 #!/bin/bash
 # rocprofv3 counter passes (counters + kernel trace only) for the hot kernels (-> profiles/rNN_kernel_pmc.json): flash
-#   attention (double pipeline), big-tile GEMM on the ViT qkv shape (256x192 tiles), the 128^2 kernel on the fc1 shape, and
+#   attention (double pipeline), big-tile GEMM on the ViT qkv shape and the SVR's packed q|k|v (256x192 tiles, two-stage and
+#   deep forms), the ring form on the SVR output projection, the 128^2 kernel on the fc1 shape, and
 #   the 64^2 split-K kernel on the M = 256 query-side product of the TTA with cold weights.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/pmc2; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 run() {  # name, driver args..., then counter sets come from PASSES
@@ -18,13 +19,13 @@ PASSES=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MF
 # collect them one per pass as tools/gpu_round.sh does; with SQ_INSTS_VALU added to the LDS set the profiled process
 # never exited and every pass ran into its timeout (the counters were still written).  Keep the per-pass timeout short.
 PASSES+=("FETCH_SIZE" "WRITE_SIZE")
-run flash7 flash 3 0 7 0
 run flash7pre flash 3 0 7 1
-run qkv_bt192 gemm 3 21
+run qkv_bt192_deep gemm 3 24
+run svr_qkv_bt192_two_stage gemmsvr 8 21
+run svr_qkv_bt192_deep gemmsvr 8 24
+run svr_out_ring gemm4k 8 22
 run fc1_gelu128 gemmmlp 3 -1
 run skinny64 gemm256 16 0
-run flashbwd flashbwd 3
 run tokattn tokattn 5
-run prefillattn prefillattn 5
-run kmajor_dw kmajor 3
+# (unchanged kernels keep their round-3 rows in profiles/r03_kernel_pmc.json: flashbwd, prefillattn, kmajor_dw -- add them back here to refresh)
 cd $R && python tools/pmc_kernels.py $O > $R/gpurun_out/kernel_pmc.json && cat $R/gpurun_out/kernel_pmc.json | head -80

@@ -1,5 +1,5 @@
 """Tiny driver for rocprofv3 counter passes:
-    python tools/prof_kernels.py flash|flashbwd|kmajor|tokattn|prefillattn|gemm|gemm4k|gemm256|gemm8k|gemmmlp [iters] [gemm_big: -1 | 0 | 20 | 21] [flash_mode]
+    python tools/prof_kernels.py flash|flashbwd|kmajor|tokattn|prefillattn|gemm|gemm4k|gemmsvr|gemm256|gemm8k|gemmmlp [iters] [gemm_big: -1 | 0 | 20 .. 26] [flash_mode]
 gemm256 = the M = 256 query-side product of the TTA with 16 COLD weight matrices in rotation and split-K scratch, as the
 pipeline runs it (64 x 64 tiles, 4 K slices + reduce)."""
 import sys
@@ -49,10 +49,10 @@ elif what == "kmajor":
         ops.gemm_kmajor(dy, x, a_kmajor=True)
 elif what.startswith("gemm"):
     ops.set_option("gemm_big", variant)
-    M, N, K = {"gemm": (16384, 2304, 768), "gemm4k": (2048, 4096, 4096), "gemm256": (256, 4096, 4096),
+    M, N, K = {"gemm": (16384, 2304, 768), "gemm4k": (2048, 4096, 4096), "gemmsvr": (2048, 12288, 4096), "gemm256": (256, 4096, 4096),
                "gemm8k": (8192, 8192, 8192), "gemmmlp": (16384, 3072, 768)}[what]
     a = torch.randn(M, K, device="cuda").to(bf)
-    nw = 16 if what == "gemm256" else 1
+    nw = 16 if what == "gemm256" else 8 if what in ("gemm4k", "gemmsvr") else 1      # (cold weights in rotation)
     ws = [torch.randn(N, K, device="cuda").to(bf) for _ in range(nw)]
     bias = torch.randn(N, device="cuda").to(bf)
     out = torch.empty((1, M, N), dtype=bf, device="cuda")
