@@ -229,6 +229,7 @@ def gen(nj, pair=False):
         e(f"s_waitcnt vmcnt({len(early)})")
         e("s_barrier")
         e(f".Lbt_cont{w}_%=:")
+        e("s_waitcnt lgkmcnt(0)")     # (a scalar load the compiler left in flight would return out of order and spoil the counted fragment waits)
         for n in range(nread):
             read(0, 0, n)
         # ---- K loop of wave w
@@ -395,6 +396,7 @@ def gen_ring(nj=2):
         e(f"s_waitcnt vmcnt({npw})")
         e("s_barrier")
         e(f".Lbr_cont{w}_%=:")
+        e("s_waitcnt lgkmcnt(0)")     # (a scalar load the compiler left in flight would return out of order and spoil the counted fragment waits)
         for st in (1, 2):
             e(f"s_cmp_eq_u32 %[st0], {st}")
             e(f"s_cbranch_scc1 .Lbr_e{w}_{st}_%=")
@@ -560,6 +562,7 @@ def gen_deep(nj, deep):
         e(f"s_waitcnt vmcnt({npc[dmat] + len(early)})")
         e("s_barrier")
         e(f".Lbd_cont{w}_%=:")
+        e("s_waitcnt lgkmcnt(0)")     # (a scalar load the compiler left in flight would return out of order and spoil the counted fragment waits)
         for u in range(1, L):
             e(f"s_cmp_eq_u32 %[st0], {u}")
             e(f"s_cbranch_scc1 .Lbd_e{w}_{u}_%=")

@@ -615,11 +615,27 @@ int gemm_big_try(const GemmDesc& d, hipStream_t stream) {
     const int e = bt_launch_variant(mode, ds, stream);
     return e == U2_OK ? 1 : e;
   }
-  if (opts().gemm_big_ring && d.M >= 512 && bt_pick(d) == 0 && bt_pick_ring(d) == 22) {  // (ahead of the sliced forms: 192 ring tiles beat 2 x 128 sliced ones)
-    const int e = bt_launch_variant(22, d, stream);
-    return e == U2_OK ? 1 : e;
+  // A few rows past a multiple of 256 (the ViT's cls rows: M = 2049 per chunk, 8 * 2049 per volume) would cost a whole extra
+  // row of tiles: they go through the few-rows / small-tile kernel -- for EVERY form, so that a chunk's rows are computed
+  // by the same arithmetic whatever the number of chunks in the call (tests/test_gpu_path.py::test_vit_full_size_properties).
+  const int rem = d.M & 255;
+  const bool split_tail = d.nz == 1 && rem != 0 && rem <= 64 && d.M > 256;
+  GemmDesc main = d, tail = d;
+  if (split_tail) {
+    main.M = d.M - rem;
+    tail.M = rem;
+    tail.A = d.A + (int64_t)main.M * d.lda;
+    tail.C = reinterpret_cast<char*>(d.C) + (int64_t)main.M * d.ldc * (f32 ? 4 : 2);
+    if (d.flags & GEMM_RESIDUAL) tail.R = d.R + (int64_t)main.M * d.ldr;
   }
-  if (opts().gemm_big_skinny) {
+  auto launch = [&](int v) {
+    int e = bt_launch_variant(v, main, stream);
+    if (e == U2_OK && split_tail) e = gemm_classic(tail, stream);
+    return e == U2_OK ? 1 : e;
+  };
+  // (ahead of the sliced forms: 192 ring tiles beat 2 x 128 sliced ones)
+  if (opts().gemm_big_ring && main.M >= 512 && bt_pick(main) == 0 && bt_pick_ring(main) == 22) return launch(22);
+  if (opts().gemm_big_skinny && !split_tail) {
     const int v = bt_pick_sliced(d);
     if (v > 0) {
       GemmDesc ds = d;
@@ -630,27 +646,9 @@ int gemm_big_try(const GemmDesc& d, hipStream_t stream) {
     }
   }
   if (d.M < 512 || d.N < 256 || d.K < 128) return 0;
-  // A few rows past a multiple of 256 (the ViT's 8 cls rows: M = 8 * 2049) would cost a whole extra round of
-  // 256-row tiles: run them through the small-tile kernel instead.
-  const int rem = d.M & 255;
-  if (d.nz == 1 && rem != 0 && rem <= 64) {
-    GemmDesc main = d, tail = d;
-    main.M = d.M - rem;
-    const int v = bt_pick(main);
-    if (v == 0) return 0;
-    tail.M = rem;
-    tail.A = d.A + (int64_t)main.M * d.lda;
-    tail.C = reinterpret_cast<char*>(d.C) + (int64_t)main.M * d.ldc * (f32 ? 4 : 2);
-    if (d.flags & GEMM_RESIDUAL) tail.R = d.R + (int64_t)main.M * d.ldr;
-    int e = bt_launch_variant(bt_deep_of(v, d.flags), main, stream);
-    if (e != U2_OK) return e;
-    e = gemm_classic(tail, stream);
-    return e == U2_OK ? 1 : e;
-  }
-  const int v = bt_pick(d);
+  const int v = bt_pick(main);
   if (v == 0) return 0;
-  const int e = bt_launch_variant(bt_deep_of(v, d.flags), d, stream);
-  return e == U2_OK ? 1 : e;
+  return launch(bt_deep_of(v, d.flags));
 }
 
 }  // namespace u2
