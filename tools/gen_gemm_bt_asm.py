@@ -25,7 +25,14 @@ row-block advance in the scalar offset.  The K loop of one output tile runs on i
 (persistent) workgroup: K tile nkt of this tile IS K tile 0 of the next one (origin nbase), so a tile switch costs no
 DMA burst and no exposed latency (operand `first` = 1 only for a workgroup's first tile).
 
+Round 4 added, on the same skeleton (gen_ring, gen_deep below, each with its own schedule notes): the RING form (256 x 128 tiles, three
+LDS stages, K tile t+2 in flight behind a counted vmcnt) and the DEEP forms of the 192- and 256-wide tiles (three stages for one
+operand, two for the other) -- what the ablation builds (--ablate) showed the two-stage loop to be bound by is the latency of
+its own operand stream, not the matrix pipe.  Fragment waits are counted per slot (frag_waits); --drain-waits restores the one
+lgkmcnt(0) per k16 step.
+
     python tools/gen_gemm_bt_asm.py > u2tokenizer_amd/csrc/gemm_bt_asm.inc
+    python tools/gen_gemm_bt_asm.py --ablate nodma,noread   (measurement-only build, see tools/mk_ab_build.sh)
 """
 import sys
 

@@ -12,6 +12,9 @@
 //  * XCD-aware tile order (workgroup b runs on XCD b % 8): every XCD gets a compact band of tiles per round.
 //  * persistent: grid = min(#tiles, #CUs); a workgroup walks tiles b, b + grid, ... and its K loop runs on from one
 //    output tile into the next (the last iterations stage the next tile's first K tiles).
+//  * round 4: THREE-stage forms of the same loop -- the ring form (NJ = 2: 256 x 128 tiles) and the deep forms (DEEP = 1 / 2: three
+//    stages for A / for B, two for the other operand) -- because what bounds the two-stage K loop is the latency of its own
+//    LDS-DMA stream ("Round 4: the big-tile GEMM"); gemm_big_try below says which form a product takes.
 // Requirements checked by the launcher: K % 64 == 0, operands addressable with 32-bit byte offsets.
 #include <algorithm>
 #include <type_traits>
