@@ -545,7 +545,8 @@ def test_gemm_big_tile_variants(ops, variant):
     ops.set_option("gemm_big", variant)
     try:
         for (M, N, K) in [(256, 256, 128), (300, 200, 136), (77, 520, 192), (1000, 768, 1024), (2049, 768, 768),
-                          (5000, 1536, 256), (9000, 2304, 256), (4100, 3000, 320), (9000, 1100, 128)]:
+                          (5000, 1536, 256), (9000, 2304, 256), (4100, 3000, 320), (9000, 1100, 128),
+                          (9000, 2304, 448), (9000, 2304, 512), (9000, 2304, 576)]:   # (K tiles mod 6 = 1, 2, 3: every entry of the deep forms' unrolled loop)
             a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
             ad, bd = a.to(D), b.to(D)
             outs = [ops.gemm(ad, bd).clone() for _ in range(3)]
