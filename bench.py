@@ -640,8 +640,9 @@ def main():
                     "achieved_hip_events": round(ach_ev, 1), "avg_launch_us_hip_events": round(1e3 * ms[idx] / per_launch, 2),
                     "measured": how}
 
-        line["roofline"] = roof(0, "gemm_bf16", "bf16 MFMA GEMM, all launches of one step (gemm_bt_kernel 256x256 / 256x192 "
-                                                "tiles, gemm_bf16_nt_kernel 128^2 / 64^2 tiles, split-K reduce)")
+        line["roofline"] = roof(0, "gemm_bf16", "bf16 MFMA GEMM, all launches of one step (gemm_bt_kernel 256x256 / 256x192 / "
+                                                "256x128 tiles in two-stage, deep and ring forms, gemm_bf16_nt_kernel 128^2 / 64^2 "
+                                                "tiles, few-rows kernel, split-K reduce)")
         line["roofline"]["classes"] = classes
         if ms[1] > 0:
             line["roofline_attention"] = roof(1, "flash_d64", "flash_dp2_kernel: ViT attention, 8 chunks x 12 heads x 2049 "
