@@ -63,6 +63,8 @@ u2tok_ctx_t u2tok_ctx_get_current(void);     /* NULL when the thread uses the de
     u2tok_flash_attention_d64 already carries scale * log2 e}, "vit_flash" {0 unfused attention, 1}, "tta_overlap" {0, 1: side
     stream for the TTA k|v projections},
     "tok_flash" {1: the tokenizer's attention cores run the fused kernel of u2tok_tok_attention, 0: GEMM -> softmax -> GEMM},
+    "tok_wide" {1: head dims 256 / 512 of that kernel run its 8-wave form (a wave pair per 16-query block, two waves per SIMD),
+    0: the 4-wave form},
     "profile" {0, 1} */
 int u2tok_set_option(const char* name, int value);
 /* Scratch for split-K partial sums of u2tok_gemm_bf16 calls on `stream` (fp32, slices x M x N), registered on the
@@ -73,8 +75,9 @@ int u2tok_set_gemm_scratch(void* device_ptr, size_t bytes, void* stream);
  * for the flash attention kernel; while attached the kernel runs its s_memtime-instrumented build and ADDS per-phase
  * cycle sums per (workgroup, wave). */
 int u2tok_flash_debug_buffer(void* device_ptr);
-/* Same for u2tok_tok_attention: >= grid*4*8 uint64; slots = cycles in {DMA wait, barrier, K DMA issue, Q K^T, softmax, V DMA
- * issue, P V}, [7] = tiles. */
+/* Same for u2tok_tok_attention: >= grid*4*8 uint64 (grid*8*16 for the 8-wave form of head dims 256 / 512, which also leaves s_memrealtime stamps in slots 8..15); slots = cycles in
+ * {DMA wait, barrier, K DMA issue (8-wave form: all DMA issue), Q K^T, softmax, V DMA issue (8-wave form: unused), P V},
+ * [7] = tiles. */
 int u2tok_tok_attention_debug_buffer(void* device_ptr);
 
 /* With option "profile" = 1 every launch is bracketed by hipEvents on its stream.  Collect (HOST arrays of ncat <= 6

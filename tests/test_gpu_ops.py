@@ -403,7 +403,10 @@ def _tok_attn_ref(q, k, v, H, scale, tbl=None, L=512):
     (2, 37, 53, 4, 64, True, 0),        # tails everywhere: partial query block, partial key tile, 128-byte tile rows
     (2, 37, 53, 4, 64, True, 2),
     (3, 100, 70, 2, 128, False, 3),
-    (1, 1, 1, 1, 64, True, 0), (1, 16, 33, 1, 128, False, 0), (1, 512, 512, 2, 64, True, 4)])
+    (1, 1, 1, 1, 64, True, 0), (1, 16, 33, 1, 128, False, 0), (1, 512, 512, 2, 64, True, 4),
+    # wide heads (8-wave form: a wave pair per 16-query block) with tails everywhere, one-tile and odd tile counts, splits
+    (2, 37, 53, 2, 256, True, 0), (2, 37, 53, 2, 256, True, 2), (1, 100, 70, 1, 512, False, 3), (1, 1, 1, 1, 512, True, 0),
+    (1, 130, 97, 2, 512, True, 0), (3, 64, 32, 1, 256, False, 0), (1, 16, 33, 1, 512, False, 2), (1, 300, 480, 2, 512, True, 5)])
 def test_tok_attention(ops, nb, Sq, Skv, H, d, bias, splits):
     """The fused attention core of the tokenizer (u2tok_tok_attention) against an fp32 softmax(q k^T scale + bias) v of the
     same bf16 inputs; q / k / v are column slices of packed buffers, as the pipeline passes them; three launches must
@@ -424,6 +427,13 @@ def test_tok_attention(ops, nb, Sq, Skv, H, d, bias, splits):
     got = [ops.tok_attention(dq, dk, dv, H, scale, None if tbl is None else tbl.to(D), 512, splits) for _ in range(3)]
     assert torch.equal(got[0], got[1]) and torch.equal(got[0], got[2])
     close_bf16(got[0], _tok_attn_ref(q, k, v, H, scale, tbl))
+    if d >= 256:  # the 4-wave form of the same head dims (option tok_wide = 0) stays a tested path
+        ops.set_option("tok_wide", 0)
+        try:
+            close_bf16(ops.tok_attention(dq, dk, dv, H, scale, None if tbl is None else tbl.to(D), 512, splits),
+                       _tok_attn_ref(q, k, v, H, scale, tbl))
+        finally:
+            ops.set_option("tok_wide", 1)
 
 
 def test_tok_attention_forced_rescale_and_split_merge(ops):

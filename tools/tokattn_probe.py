@@ -43,10 +43,11 @@ def chain(q, k, v, H, scale, tbl):
 
 
 def pmc(layout):
-    """20 launches of the SVR spatial shape at E = 4096 for a rocprofv3 --pmc pass"""
+    """20 launches of the SVR spatial shape at E = 4096 for a rocprofv3 --pmc pass (argument: tok_wide 0 / 1)"""
     ops.device_check()
     torch.set_grad_enabled(False)
-    ops.set_option("tok_flash", layout)
+    ops.set_option("tok_flash", 1)
+    ops.set_option("tok_wide", layout)
     g = torch.Generator(device=D).manual_seed(0)
     E, H = 4096, 8
     qkv = torch.randn((8, 256, 3 * E), device=D, generator=g).to(bf)
@@ -64,17 +65,29 @@ def timed():
     h = _lib.load_library()
     g = torch.Generator(device=D).manual_seed(0)
     E, H = 4096, 8
-    names = ["dma wait", "barrier", "K dma issue", "QK^T", "softmax", "V dma issue", "PV"]
+    wide = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    ops.set_option("tok_wide", wide)
+    nw = 8 if wide else 4   # waves per workgroup: the 8-wave form stamps {DMA wait, barrier, DMA issue, S(t+1), softmax, -, P V}
+    names = ["dma wait", "barrier", "K dma issue" if not wide else "dma issue", "QK^T", "softmax", "V dma issue", "PV"]
     for name, nb, Sq, Skv, ns in (("svr spatial", 8, 256, 256, 1), ("tta visual ns=8", 1, 256, 1792, 8), ("tta visual ns=1", 1, 256, 1792, 1)):
         q = torch.randn((nb, Sq, E), device=D, generator=g).to(bf)
         kv = torch.randn((nb, Skv, 2 * E), device=D, generator=g).to(bf)
         grid = nb * H * ((Sq + 63) // 64) * ns
-        dbg = torch.zeros(grid * 4 * 8, dtype=torch.int64, device=D)
+        ns_ = 16 if wide else 8   # slots per wave (8-wave form: + s_memrealtime at entry / loop start / loop end / exit)
+        dbg = torch.zeros(grid * nw * ns_, dtype=torch.int64, device=D)
         h.u2tok_tok_attention_debug_buffer(dbg.data_ptr())
         ops.tok_attention(q, kv[..., :E], kv[..., E:], H, 1 / math.sqrt(E // H), None, 512, ns)
         torch.cuda.synchronize()
         h.u2tok_tok_attention_debug_buffer(None)
-        d = dbg.view(-1, 8).double().cpu()
+        d = dbg.view(-1, ns_).double().cpu()
+        if wide:  # wall-clock timeline, 10 ns ticks
+            r = d[:, 8:16]
+            t0 = r[:, 0].min()
+            print(f"{name}: prologue us: requests issued {((r[:, 4] - r[:, 0]).mean()).item() / 100:.2f}, K + Q landed {((r[:, 5] - r[:, 4]).mean()).item() / 100:.2f}, "
+                  f"barrier {((r[:, 6] - r[:, 5]).mean()).item() / 100:.2f}, first scores {((r[:, 1] - r[:, 6]).mean()).item() / 100:.2f}")
+            print(f"{name}: timeline us: entry spread {(r[:, 0].max() - t0).item() / 100:.2f}, prologue {((r[:, 1] - r[:, 0]).mean()).item() / 100:.2f}, "
+                  f"loop {((r[:, 2] - r[:, 1]).mean()).item() / 100:.2f} (max {((r[:, 2] - r[:, 1]).max()).item() / 100:.2f}), "
+                  f"epilogue {((r[:, 3] - r[:, 2]).mean()).item() / 100:.2f}, first entry -> last exit {(r[:, 3].max() - t0).item() / 100:.2f}")
         tiles = d[:, 7].mean().item()
         per = d[:, :7].mean(0) / tiles
         print(f"{name}: tiles/wave {tiles:.1f}; cycles per tile: " + ", ".join(f"{n} {x:.0f}" for n, x in zip(names, per.tolist())) +
@@ -90,7 +103,9 @@ def main():
     torch.set_grad_enabled(False)
     layout = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     ops.set_option("tok_flash", layout)
-    print("layout", layout)
+    wide = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    ops.set_option("tok_wide", wide)
+    print("layout", layout, "tok_wide", wide)
     g = torch.Generator(device=D).manual_seed(0)
     for E in (4096, 2048):
         H, d = 8, E // 8

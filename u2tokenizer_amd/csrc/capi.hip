@@ -59,6 +59,7 @@ int u2tok_set_option(const char* name, int value) {
       {"flash_mode", &Options::flash_mode, 0, 7},        {"flash_q_prescaled", &Options::flash_q_prescaled, 0, 1},
       {"vit_flash", &Options::vit_flash, 0, 1},         {"tta_overlap", &Options::tta_overlap, 0, 1},
       {"tok_flash", &Options::tok_flash, 0, 1},
+      {"tok_wide", &Options::tok_wide, 0, 1},
   };
   if (!strcmp(name, "gemm_tile")) {
     if (value != 0 && value != 64 && value != 128) return U2_ERR_ARG;

@@ -28,6 +28,7 @@ struct Options {
   int flash_q_prescaled = 0;  // the q handed to u2tok_flash_attention_d64 already carries scale * log2 e (what the ViT's q|k|v product leaves)
   int vit_flash = 1;        // 0: unfused ViT attention (debug)
   int tok_flash = 1;        // 1: fused attention kernel for the tokenizer's attention cores (tokattn.hip); 0: GEMM chain
+  int tok_wide = 1;         // 1: head dims 256 / 512 of the fused kernel run the 8-wave form (two waves per SIMD, tok_attn2_kernel); 0: the 4-wave form (A/B)
   int tta_overlap = 1;      // k | v projections of the TTA cross attentions on a side stream
   int profile = 0;          // bracket every launch with hipEvents (u2tok_profile_collect)
 };

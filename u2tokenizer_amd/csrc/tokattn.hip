@@ -30,6 +30,7 @@
 //       chunks rotated inside each 256-byte segment by 2 (key & 3) + 8 ((key >> 2) & 1) so that the 8 rows x 32 bytes a
 //       half wave touches fall into 16 different 16-byte slots (the layout family of gemm.hip's K-major operands).
 #include "kernels.h"
+#include "tokattn_pv_asm.inc"
 
 namespace u2 {
 
@@ -361,6 +362,371 @@ __global__ __launch_bounds__(256, DH >= 512 ? 1 : 2) void tok_attn_kernel(const 
   }
 }
 
+// max over the four 16-lane groups of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48) on the VALU: v_permlane32_swap exchanges the
+// wave's halves, v_permlane16_swap the odd / even 16-lane rows -- two instructions instead of two LDS round trips of a shuffle
+__device__ __forceinline__ float row_max4(float v) {
+  typedef unsigned u2x __attribute__((ext_vector_type(2)));
+  const unsigned u = __float_as_uint(v);
+  const u2x a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const unsigned um = __float_as_uint(m);
+  const u2x b = __builtin_amdgcn_permlane16_swap(um, um, false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float row_sum4(float v) {
+  typedef unsigned u2x __attribute__((ext_vector_type(2)));
+  const unsigned u = __float_as_uint(v);
+  const u2x a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const float m = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const unsigned um = __float_as_uint(m);
+  const u2x b = __builtin_amdgcn_permlane16_swap(um, um, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Wide heads (d = 256 / 512), round 5: TWO WAVES PER SIMD.
+//
+// tok_attn_kernel above runs one wave per SIMD at d = 512 (O^T alone is 128 registers) and every wave walks the whole K
+// and V tile: per 32-key tile and wave 32 + 32 MFMAs against 32 ds_read_b128 + 64 ds_read_b64_tr_b16 and a ~70-instruction
+// softmax block, all in one in-order instruction stream -- 5600-6200 cycles per tile against 1088 of matrix-pipe issue
+// (profiles/r03_tokattn_phase_cycles.log: a lone wave gets a fraction of the LDS read rate and issues a dependent VALU
+// instruction every 5-9 cycles).  Here a workgroup is 8 waves; a PAIR of waves owns a 16-query block and splits
+//   * the KEYS of the tile for S^T = K Q^T: wave `half` takes key block `half` (16 keys x 16 q, the whole head dim:
+//     d / 32 MFMAs, half of the K tile read), and
+//   * the HEAD DIM for O^T += V^T P^T: wave `half` owns d / 2 columns (d / 32 accumulator tiles = 64 registers at
+//     d = 512, half of the V tile read).
+// The raw scores cross the pair through 2 KB of LDS (each wave stores its 16 x 16 block as one float4 per lane and
+// both read the pair's two blocks back), after which BOTH waves run the same online softmax on the same 8 scores per
+// lane -- same running max, same row sums, same bf16 probabilities, bit for bit, with no further exchange -- and feed
+// P from their own registers as above.  The loop is software-pipelined so that the exchange costs no extra barrier:
+//
+//   iteration t:  wait DMA | barrier | issue V(t+1), K(t+2) | read scores(t) | softmax(t) | S(t+1) -> exchange | P V(t)
+//
+// i.e. the K ring runs one tile ahead of the V ring, the scores of tile t+1 are written before the barrier of iteration
+// t+1 and read after it, and every DMA has a whole iteration to land.  While one wave of a SIMD is in its softmax
+// block the other one can hold the matrix pipe; every wave issues half the fragment reads per MFMA of the old loop.
+// LDS at d = 512: 2 x 32 KB K stages + 2 x 32 KB V stages + 16 KB exchange (2 parities x 8 waves x 1 KB) + bias window
+// = 146.5 KB, one workgroup per CU; key splits / bias / tails exactly as tok_attn_kernel (same TokAttnArgs, same merge).
+template <int DH, bool TIMED = false>
+__global__ __launch_bounds__(512) void tok_attn2_kernel(const TokAttnArgs a) {
+  unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#define U2_STAMP(i_)                                            \
+  if constexpr (TIMED) {                                        \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    ts[i_] += t_ - tprev;                                       \
+    tprev = t_;                                                 \
+  }
+  unsigned long long rt[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // TIMED: s_memrealtime (100 MHz) at entry / loop start / loop end / exit; [4..7] prologue: requests issued / K(kt0) + Q here / barrier / (spare)
+  if constexpr (TIMED) rt[0] = __builtin_amdgcn_s_memrealtime();
+  constexpr int BK = 32;
+  constexpr int CPR = DH / 8;          // 16-byte chunks per tile row
+  constexpr int ROWB = DH * 2;         // bytes per tile row
+  constexpr int TILE = BK * ROWB;      // bytes per K (or V) tile
+  constexpr int SEG = 16;
+  constexpr int NP = BK * CPR / 512;   // DMA pieces per thread per tile (8 waves)
+  constexpr int KS = DH / 32;          // k steps of Q K^T
+  constexpr int DBH = DH / 32;         // 16-wide d blocks of O^T owned by one wave (half the head dim)
+  static_assert(DH == 256 || DH == 512, "wide heads only");
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // [K stage 0 | K 1 | V 0 | V 1 | exchange | bias window]
+  char* const sKb = lds;
+  char* const sVb = lds + 2 * TILE;
+  char* const xb = lds + 4 * TILE;
+  float* const sbias = reinterpret_cast<float*>(lds + 4 * TILE + 16384);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qb = w >> 1, half = w & 1;
+  const int l15 = lane & 15, g = lane >> 4;
+
+  int bid;
+  {
+    const int nwg = gridDim.x, qn = nwg >> 3, rn = nwg & 7;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+  }
+  const int qblk = bid % a.nqb;
+  const int sp = (bid / a.nqb) % a.ns;
+  const int bh = bid / (a.nqb * a.ns);
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int q0 = qblk * 64;
+  const int Sq = a.Sq, Skv = a.Skv;
+  const int ntile_all = (Skv + BK - 1) / BK;
+  const int kt0 = sp * a.tps, kt1 = min(ntile_all, sp * a.tps + a.tps);
+  const int kbeg = kt0 * BK;
+
+  const int hkv = h / a.kv_group;
+  const bf16_t* kb_ = a.k + (int64_t)b * a.k_bs + hkv * DH;
+  const bf16_t* vb_ = a.v + (int64_t)b * a.v_bs + hkv * DH;
+
+  // ---- LDS-DMA of one tile: piece i of this thread is LDS chunk c = i * 512 + tid = (row c / CPR, position c % CPR).
+  // Full tiles: scalar tile origin + a lane offset computed once (rows never leave the tensor); the partial last tile clamps.
+  // Piece i covers rows row0 + i * RSTEP: the V rotation does not depend on i, the K swizzle (row & 15) alternates when RSTEP = 8 --
+  // so one lane offset for V and two for K serve all pieces, the rest of the address is scalar.
+  constexpr int RSTEP = 512 / CPR;  // 8 (d = 512) / 16 (d = 256)
+  const int row0 = CPR >= 64 ? w : w * 2 + (lane >> 5), cp0 = lane & (CPR - 1);
+  uint32_t koff[2], vofs;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = row0 + j * RSTEP;
+    koff[j] = (uint32_t)row0 * (uint32_t)(a.ldk * 2) + ((cp0 ^ (row & (SEG - 1))) << 4);
+  }
+  vofs = (uint32_t)row0 * (uint32_t)(a.ldv * 2) + (((cp0 & ~(SEG - 1)) | (((cp0 & (SEG - 1)) - tv_rot<SEG>(row0)) & (SEG - 1))) << 4);
+  auto dma_tile = [&](const bf16_t* base, int64_t ld, bool is_k, int kt, char* dst) {
+    const char* const tb = reinterpret_cast<const char*>(base) + (int64_t)kt * BK * ld * 2;
+    if (kt * BK + BK <= Skv) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const char* const rb = tb + (int64_t)(i * RSTEP) * ld * 2;  // scalar
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rb + (is_k ? koff[i & 1] : vofs)),
+                                         (__attribute__((address_space(3))) void*)(dst + (i * 512 + w * 64) * 16), 16, 0, 0);
+      }
+    } else {
+      const int last = Skv - 1 - kt * BK;  // rows past the last key read a copy of it (masked in the softmax)
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int row = row0 + i * RSTEP;
+        const char* const rb = tb + (int64_t)(i * RSTEP) * ld * 2 - (int64_t)(row - min(row, last)) * ld * 2;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rb + (is_k ? koff[i & 1] : vofs)),
+                                         (__attribute__((address_space(3))) void*)(dst + (i * 512 + w * 64) * 16), 16, 0, 0);
+      }
+    }
+  };
+  auto dma_k = [&](int kt, int stage) { dma_tile(kb_, a.ldk, true, kt, sKb + stage * TILE); };
+  auto dma_v = [&](int kt, int stage) { dma_tile(vb_, a.ldv, false, kt, sVb + stage * TILE); };
+
+  // ---- prologue, in the order the memory system should see it: the bias window's table rows (oldest: their wait lets
+  // everything younger fly), K(kt0), the Q fragments, V(kt0), K(kt0 + 1).  S(kt0) starts once K(kt0) and Q are here.
+  const bool has_bias = a.rel_bias != nullptr;
+  const int tmin = kbeg - (q0 + 63) + a.max_len - 1;  // table row of slot 0 of sbias[(j - kbeg) + (q0 + 63 - i)]
+  const int nslot = (kt1 - kt0) * BK + 63;
+  float bias_in[2] = {0.f, 0.f};
+  if (has_bias) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int t = tid + 512 * r, row = tmin + t;
+      if (t < nslot && row >= 0 && row < 2 * a.max_len - 1) bias_in[r] = bf16_to_f32(a.rel_bias[(int64_t)row * a.H + h]);
+    }
+  }
+  dma_k(kt0, 0);
+  // Q fragments (B operand): Q[q][32 ks + 8 g .. + 7]; both waves of a pair hold the same 16 rows
+  const int qrow = q0 + 16 * qb + l15;
+  bf16x8 qf[KS];
+  {
+    const bf16_t* qp = a.q + (int64_t)b * a.q_bs + (int64_t)min(qrow, Sq - 1) * a.ldq + h * DH + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 32);
+  }
+  dma_v(kt0, 0);
+  const bool two = kt0 + 1 < kt1;
+  if (two) dma_k(kt0 + 1, 1);
+  if (has_bias) {  // pre-multiplied by log2 e
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      if (tid + 512 * r < nslot) sbias[tid + 512 * r] = bias_in[r] * 1.44269504088896340736f;
+  }
+
+  // ---- per-lane fragment offsets (layouts of tok_attn_kernel)
+  const int k_off = (16 * half + l15) * ROWB;  // this wave's key block
+  const int k_swz = l15;
+  const int v_row = 4 * g + (l15 >> 2);
+  const int v_rot = tv_rot<SEG>(v_row);
+  const int v_base_off = v_row * ROWB + (l15 & 1) * 8;
+  const int v_cc = (l15 & 3) >> 1;
+  // V^T fragment i of this wave (d block half * DBH + i) = chunk 2 (half * DBH + i) + v_cc rotated inside its 16-chunk segment:
+  // lane offset voff[i & 7] + 256 (i >> 3) from the stage base (+ 16 key rows for the second half of the fragment)
+  uint32_t voff[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) voff[j] = v_base_off + half * (DBH * 32) + (((2 * j + v_cc + v_rot) & (SEG - 1)) << 4);
+  const uint32_t v_lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)sVb;
+  const int x_wr = w * 1024 + lane * 16;        // this wave's score block inside one parity of the exchange
+  const int x_rd = (2 * qb) * 1024 + lane * 16;  // the pair's two blocks: + 0 (keys 0..15), + 1024 (keys 16..31)
+
+  f32x4 o[DBH];
+#pragma unroll
+  for (int i = 0; i < DBH; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  const float c_scale = a.scale_log2e;
+  const int bias_q = q0 + 63 - qrow;
+
+  // S^T block of this wave for the tile in K stage `stage` -> exchange parity `par`, in two parts: the first K1 fragment reads
+  // go out early (the loop puts the softmax of the previous tile between the two parts), the rest ride on the MFMAs.
+  constexpr int K1 = DH >= 512 ? 4 : 8;  // (d = 512: 8 early fragments do not fit the 256 registers next to Q and O^T)
+  bf16x8 kf[KS];
+  auto scores_begin = [&](int stage) {
+    const char* const tK = sKb + stage * TILE + k_off;
+#pragma unroll
+    for (int ks = 0; ks < K1; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(tK + (((ks * 4 + g) ^ k_swz) << 4));
+  };
+  auto scores_end = [&](int stage, int par) {
+    const char* const tK = sKb + stage * TILE + k_off;
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = K1; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(tK + (((ks * 4 + g) ^ k_swz) << 4));
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) acc[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[ks], acc[ks & 3], 0, 0, 0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 0x008 = MFMA, 0x100 = DS read
+      if (ks + K1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x4 sc = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    *reinterpret_cast<f32x4*>(xb + par * 8192 + x_wr) = sc;
+  };
+
+  if constexpr (TIMED) rt[4] = __builtin_amdgcn_s_memrealtime();
+  // K(kt0) and Q are the oldest requests after the bias rows: everything younger (V(kt0), K(kt0 + 1)) may still be in flight
+  if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+  if constexpr (TIMED) rt[5] = __builtin_amdgcn_s_memrealtime();
+  __syncthreads();  // K(kt0) has landed for every wave, the bias window is written
+  if constexpr (TIMED) rt[6] = __builtin_amdgcn_s_memrealtime();
+  scores_begin(0);
+  scores_end(0, 0);
+  if constexpr (TIMED) {
+    rt[1] = __builtin_amdgcn_s_memrealtime();
+    tprev = __builtin_amdgcn_s_memtime();
+  }
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int par = (kt - kt0) & 1;
+    const bool more = kt + 1 < kt1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    U2_STAMP(0)  // wait for K(kt + 1), V(kt)
+    __syncthreads();  // ... landed for every wave; scores(kt) of both halves are in the exchange; V stage par ^ 1 / K stage par are free
+    U2_STAMP(1)  // barrier
+    if (more) dma_v(kt + 1, par ^ 1);
+    if (kt + 2 < kt1) dma_k(kt + 2, par);
+    U2_STAMP(2)  // DMA issue
+    // ---- first fragment reads of S(kt + 1): their latency passes under the softmax below
+    if (more) scores_begin(par ^ 1);
+    // ---- online softmax: lane owns keys kt * 32 + 16 kb + 4 g + r of query row qrow (both waves of the pair alike)
+    constexpr int NX = 8;
+    float x[NX];
+    {
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(xb + par * 8192 + x_rd);
+      const f32x4 s1 = *reinterpret_cast<const f32x4*>(xb + par * 8192 + x_rd + 1024);
+      if (has_bias) {
+        float bb[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) bb[i] = sbias[(kt * BK - kbeg) + (i >> 2) * 16 + 4 * g + (i & 3) + bias_q];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          x[i] = __builtin_fmaf(s0[i], c_scale, bb[i]);
+          x[4 + i] = __builtin_fmaf(s1[i], c_scale, bb[4 + i]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          x[i] = s0[i];
+          x[4 + i] = s1[i];
+        }
+      }
+    }
+    if (kt == ntile_all - 1 && (Skv & (BK - 1))) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+        if (kt * BK + (i >> 2) * 16 + 4 * g + (i & 3) >= Skv) x[i] = -INFINITY;
+    }
+    float mt = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7])));
+    mt = row_max4(mt);  // over the four 16-lane groups (the other keys of this query row)
+    const float xs = has_bias ? 1.0f : c_scale;  // what is left to multiply into x
+    mt *= xs;
+    if (__any(mt > m_run + TOKATTN_RESCALE_THR)) {  // wave-uniform, and the same decision in both waves of the pair
+      const float m_new = fmaxf(m_run, mt);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < DBH; ++i) {
+        o[i][0] *= alpha; o[i][1] *= alpha; o[i][2] *= alpha; o[i][3] *= alpha;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[i], xs, -m_run));
+    l_run += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+    union { bf16x8 v; uint32_t u[4]; } pf;
+    pf.u[0] = pack2_bf16(x[0], x[1]);
+    pf.u[1] = pack2_bf16(x[2], x[3]);
+    pf.u[2] = pack2_bf16(x[4], x[5]);
+    pf.u[3] = pack2_bf16(x[6], x[7]);
+    if constexpr (TIMED) asm volatile("" : "+v"(pf.v));
+    U2_STAMP(4)  // softmax
+    // ---- S^T of the next tile (its K tile landed with this iteration's wait)
+    if (more) scores_end(par ^ 1, par ^ 1);
+    U2_STAMP(3)  // Q K^T
+    // ---- O^T += V^T P^T over this wave's half of the head dim: one asm block (tools/gen_tokattn_asm.py) -- hipcc would put
+    // s_waitcnt vmcnt(0) between this iteration's DMA issue and the first transpose read
+    {
+      const uint32_t tv = v_lds0 + par * TILE;
+#define U2_PV_ADDR [a0] "v"(tv + voff[0]), [a1] "v"(tv + voff[1]), [a2] "v"(tv + voff[2]), [a3] "v"(tv + voff[3]), \
+                   [a4] "v"(tv + voff[4]), [a5] "v"(tv + voff[5]), [a6] "v"(tv + voff[6]), [a7] "v"(tv + voff[7])
+      if constexpr (DBH == 16) {
+        asm volatile(TOKATTN_PV_ASM_TEXT_16
+                     : [o0] "+v"(o[0]), [o1] "+v"(o[1]), [o2] "+v"(o[2]), [o3] "+v"(o[3]), [o4] "+v"(o[4]), [o5] "+v"(o[5]),
+                       [o6] "+v"(o[6]), [o7] "+v"(o[7]), [o8] "+v"(o[8]), [o9] "+v"(o[9]), [o10] "+v"(o[10]), [o11] "+v"(o[11]),
+                       [o12] "+v"(o[12]), [o13] "+v"(o[13]), [o14] "+v"(o[14]), [o15] "+v"(o[15])
+                     : [pf] "v"(pf.v), U2_PV_ADDR
+                     : TOKATTN_PV_ASM_CLOBBERS, "memory");
+      } else {
+        asm volatile(TOKATTN_PV_ASM_TEXT_8
+                     : [o0] "+v"(o[0]), [o1] "+v"(o[1]), [o2] "+v"(o[2]), [o3] "+v"(o[3]), [o4] "+v"(o[4]), [o5] "+v"(o[5]),
+                       [o6] "+v"(o[6]), [o7] "+v"(o[7])
+                     : [pf] "v"(pf.v), U2_PV_ADDR
+                     : TOKATTN_PV_ASM_CLOBBERS, "memory");
+      }
+#undef U2_PV_ADDR
+    }
+    U2_STAMP(6)  // P V
+  }
+  if constexpr (TIMED) rt[2] = __builtin_amdgcn_s_memrealtime();
+#undef U2_STAMP
+  auto timed_out = [&]() {
+    if constexpr (TIMED) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of the epilogue
+      rt[3] = __builtin_amdgcn_s_memrealtime();
+      if (lane == 0 && a.dbg) {
+        unsigned long long* dp = a.dbg + ((size_t)blockIdx.x * 8 + w) * 16;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) dp[i] += ts[i];
+        dp[7] += (unsigned long long)(kt1 - kt0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dp[8 + i] = rt[i];
+      }
+    }
+  };
+
+  // ---- epilogue: lane holds O^T[d = 16 (half * DBH + i) + 4 g + r][q = qrow]
+  const float l_tot = row_sum4(l_run);
+  if (qrow >= Sq) {
+    timed_out();
+    return;
+  }
+  const int d0 = half * (DH / 2) + 4 * g;
+  if (a.ns == 1) {
+    const float inv = 1.f / l_tot;
+    bf16_t* op = a.out + (int64_t)b * a.o_bs + (int64_t)qrow * a.ldo + h * DH + d0;
+#pragma unroll
+    for (int i = 0; i < DBH; ++i)
+      *reinterpret_cast<uint2*>(op + i * 16) =
+          uint2{pack2_bf16(o[i][0] * inv, o[i][1] * inv), pack2_bf16(o[i][2] * inv, o[i][3] * inv)};
+  } else {
+    const int E = a.H * DH;
+    float* pp = a.opart + (((int64_t)sp * a.nb + b) * Sq + qrow) * E + h * DH + d0;
+#pragma unroll
+    for (int i = 0; i < DBH; ++i) *reinterpret_cast<float4*>(pp + i * 16) = float4{o[i][0], o[i][1], o[i][2], o[i][3]};
+    if (g == 0 && half == 0) {
+      float* mp = a.ml + ((((int64_t)sp * a.nb + b) * a.H + h) * Sq + qrow) * 2;
+      mp[0] = m_run;
+      mp[1] = l_tot;
+    }
+  }
+  timed_out();
+}
+
 // out[b][q][e] = sum_s 2^(m_s - m) O_s[b][q][e] / sum_s 2^(m_s - m) l_s over the key splits, s in ascending order
 __global__ __launch_bounds__(256) void tok_attn_combine_kernel(const TokAttnArgs a, int DH) {
   const int E = a.H * DH, e4 = E >> 2;
@@ -475,11 +841,19 @@ int attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out,
     if (a.dbg) hipLaunchKernelGGL((tok_attn_kernel<D_, true>), dim3((unsigned)grid), dim3(256), smem_, stream, a);    \
     else hipLaunchKernelGGL((tok_attn_kernel<D_, false>), dim3((unsigned)grid), dim3(256), smem_, stream, a);         \
   } while (0)
-  if (d == 512) U2_TA(512);
-  else if (d == 256) U2_TA(256);
+#define U2_TA2(D_)                                                                                                     \
+  do {                                                                                                                 \
+    constexpr size_t smem_ = 4 * 32 * (D_) * 2 + 16384 + TOKATTN_BIAS_SLOTS * 4;                                       \
+    if (a.dbg) hipLaunchKernelGGL((tok_attn2_kernel<D_, true>), dim3((unsigned)grid), dim3(512), smem_, stream, a);   \
+    else hipLaunchKernelGGL((tok_attn2_kernel<D_, false>), dim3((unsigned)grid), dim3(512), smem_, stream, a);        \
+  } while (0)
+  const bool wide = d >= 256 && !causal && opts().tok_wide;  // two waves per SIMD (tok_attn2_kernel)
+  if (d == 512) { if (wide) U2_TA2(512); else U2_TA(512); }
+  else if (d == 256) { if (wide) U2_TA2(256); else U2_TA(256); }
   else if (d == 128) U2_TA(128);
   else U2_TA(64);
 #undef U2_TA
+#undef U2_TA2
   if (a.ns > 1) {
     const int64_t total = (int64_t)nb * Sq * (H * d / 4);
     hipLaunchKernelGGL(tok_attn_combine_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, a, d);
