@@ -428,7 +428,7 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the two live rocprofv3 PMC passes behind roofline.traffic")
     ap.add_argument("--cpu-baseline-iters", type=int, default=3)
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
-                    help="library tuning switch for A/B measurements (u2tok_set_option), e.g. --option flash_mode=8")
+                    help="library tuning switch for A/B measurements (u2tok_set_option), e.g. --option flash_mode=7")
     ap.add_argument("--stub-cpu", action="store_true",
                     help="TEST PLUMBING ONLY (tests/test_bench_launcher.py): replace the step by a host no-op and use the "
                          "gloo backend, so that the launcher / barrier / MAX-over-ranks / JSON path can run on a box "
@@ -496,6 +496,7 @@ def main():
     # +2.2 % with it off (tools/ab_bench.py, interleaved on one box, profiles/r02_ab_options.log).  The one-stream run
     # below keeps it on.  An explicit --option tta_overlap=... wins.
     auto_side = streams is not None and not args.stub_cpu and not any(o.startswith("tta_overlap=") for o in args.option)
+    user_tta_overlap = next((int(o.split("=")[1]) for o in args.option if o.startswith("tta_overlap=")), 1)
     if auto_side:
         ops.set_option("tta_overlap", 0)
     times, out = timed_repeats(step, args.steps, args.warmup, args.repeats, sync, rmax)
@@ -588,7 +589,7 @@ def main():
             ops.set_option("profile", 0)
             ops.set_option("tta_overlap", 0)
             t2, _ = timed_repeats(lambda i: step(i, multi=False), args.steps, args.warmup, 2, sync, rmax)
-            ops.set_option("tta_overlap", 1)
+            ops.set_option("tta_overlap", user_tta_overlap)   # what was in effect before (an --option tta_overlap=0 stays)
             wall_serial = statistics.median(t2)
         cls_key = ["gemm_bf16", "flash_d64", "temporal_attention", "row_ops", "data_movement", "tok_attention"]
         kt_ms = {}

@@ -36,18 +36,21 @@ class _WithDead(torch.nn.Sequential):
 def _model(variant="plain"):
     torch.manual_seed(0)
     mods = [torch.nn.Linear(24, 40), torch.nn.GELU(), torch.nn.Linear(40, 40), torch.nn.LayerNorm(40), torch.nn.Linear(40, 7)]
-    return _WithDead(*mods) if variant in ("unused", "wakes") else torch.nn.Sequential(*mods)
+    return _WithDead(*mods) if variant in ("unused", "wakes", "wakes1") else torch.nn.Sequential(*mods)
 
 
 def _steps(variant):
-    return 8 if variant in ("unused", "wakes") else 3
+    return 12 if variant == "wakes1" else 8 if variant in ("unused", "wakes") else 3
 
 
-def _wake(m, variant, step):
+def _wake(m, variant, step, rank=0):
     """variant "wakes": the dead Linear takes part from step 5 on -- after its bucket has been launched early from the learnt
-    subset for a step or two"""
+    subset for a step or two.  "wakes1": ONLY RANK 1 sees it, in steps 5 and 6 (per-rank data: a text-only batch on the other
+    rank) -- ADVICE r4: what a rank does about it must not depend on what that rank alone has seen."""
     if variant == "wakes":
         m.wake = step >= 5
+    elif variant == "wakes1":
+        m.wake = rank == 1 and step in (5, 6)
 
 
 def _data(rank, step):
@@ -71,11 +74,11 @@ def _worker(rank, world, port, q, overlap, bucket, clip=None, accum=1, variant="
                          overlap_comm=overlap, max_grad_norm=clip, gradient_accumulation_steps=accum)
         norms, launched_early = [], []
         for step in range(_steps(variant)):
-            _wake(m, variant, step)
+            _wake(m, variant, step, rank)
             for micro in range(accum):
                 x, y = _data(rank, step * accum + micro)
                 (torch.nn.functional.mse_loss(m(x), y) / accum).backward()
-                if micro < accum - 1 and variant != "wakes":
+                if micro < accum - 1 and variant not in ("wakes", "wakes1"):
                     assert opt._next_launch == 0, "a bucket was reduced before the last micro-batch"
             launched_early.append(opt._next_launch)   # buckets whose reduce-scatter was launched from a hook (overlap)
             opt.step()
@@ -102,12 +105,14 @@ def _reference(world, clip=None, accum=1, variant="plain"):
     norms = []
     for step in range(_steps(variant)):
         opt.zero_grad()
-        _wake(m, variant, step)
+        woke = False
         for rank in range(world):
+            _wake(m, variant, step, rank)
+            woke = woke or bool(getattr(m, "wake", False))
             for micro in range(accum):
                 x, y = _data(rank, step * accum + micro)
                 (torch.nn.functional.mse_loss(m(x), y) / (world * accum)).backward()
-        if variant in ("unused", "wakes") and not m.wake:
+        if variant in ("unused", "wakes", "wakes1") and not woke:
             # a flat ZeRO partition has a (zero) gradient for every element, so AdamW's decoupled weight decay also shrinks
             # parameters that received none -- DeepSpeed's behaviour, unlike torch.optim.AdamW skipping grad-less tensors
             for p in m.dead.parameters():
@@ -203,6 +208,32 @@ def test_zero1_gradient_accumulation_unused_parameters_and_groups():
             assert early[5] == (nb if accum == 1 else 0), early
         else:
             assert all(e == nb for e in early), (variant, early)
+
+
+def test_zero1_one_rank_alone_sees_the_late_gradient():
+    """the learnt "which parameters of a bucket fire" gates early launches, and whether a premature launch must be
+    repeated is a COLLECTIVE decision -- so neither may depend on what one rank alone has seen.  Here only rank 1's batches
+    reach the dead Linear, in steps 5 and 6: in step 5 its bucket has already left from the learnt subset on both ranks (rank 1
+    notices afterwards: every rank reduces it again), in step 6 rank 1's hooks complete the bucket while rank 0 waits for
+    step(); then the subset is learnt again, by both ranks in the same step.  The collective sequences stay paired (no hang,
+    no garbage), the replicas stay bit-identical and equal to one process running AdamW on the mean gradient."""
+    for accum, clip in ((1, None), (2, 0.05)):
+        ref, ref_norms = _reference(2, clip, accum, "wakes1")
+        (r0, p0, nb, _, n0, e0), (r1, p1, _, _, n1, e1) = _run(True, 700, clip, accum, "wakes1")
+        assert n0 == n1
+        for a, b, c in zip(p0, p1, ref):
+            assert torch.equal(a, b)
+            assert torch.allclose(a, c, rtol=2e-5, atol=2e-6), (a - c).abs().max()
+        if clip is not None:
+            for a, b in zip(n0, ref_norms):
+                assert abs(a - b) <= 1e-5 * b
+        # rank 0 never sees the stranger: learnt after 3 steps, forgotten with rank 1 after step 5, learnt again after 7..9
+        assert all(e < nb for e in e0[:3]) and e0[3] == e0[4] == e0[5] == nb, e0
+        assert all(e < nb for e in e0[6:10]) and e0[10] == e0[11] == nb, e0
+        # rank 1: as rank 0, except that in step 6 (all of its parameters fire, subset forgotten) every bucket goes from a hook
+        assert all(e < nb for e in e1[:3]) and e1[3] == e1[4] == nb and e1[6] == nb, e1
+        assert e1[5] == (nb if accum == 1 else 0), e1
+        assert all(e < nb for e in e1[7:10]) and e1[10] == e1[11] == nb, e1
 
 
 @torch.enable_grad()

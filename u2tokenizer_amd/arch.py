@@ -169,6 +169,11 @@ class u2MetaForCausalLM(ABC):
                 # config.u2_fix_embed_copy = True.
                 if getattr(self.config, "u2_fix_embed_copy", False):
                     input_embeddings.copy_(embed_tokens_weight)
+                else:
+                    import warnings
+                    warnings.warn("initialize_vision_tokenizer: the checkpoint's model.embed_tokens.weight has the shape of the "
+                                  "model's table and is NOT loaded (the reference's u2_arch.py:155 rebinds a local name); set "
+                                  "config.u2_fix_embed_copy = True to copy it", stacklevel=2)
             elif embed_tokens_weight.shape[0] == num_new_tokens:
                 input_embeddings[-num_new_tokens:] = embed_tokens_weight
             else:

@@ -421,6 +421,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
       ds.C = d.partial + (int64_t)z * d.M * d.N;
       ds.ldc = d.N;
       ds.alpha = 1.f;
+      ds.nsplit = 0;      // the column-range scale (alpha_lo below nsplit) belongs to the reduce that applies the epilogue,
+      ds.alpha_lo = 1.f;  // not to the raw sums (it would have been applied twice)
       ds.flags = GEMM_OUT_F32 | GEMM_VEC_OK;
       const bt_u32x4 bnone[NJ * 2] = {};
       pp_epilogue<CFG, 0, false>(ds, acc[0], 0, bm0 + wm * 128, bn0, 0, wn, lane, bnone, false);

@@ -212,11 +212,11 @@ class Zero1AdamW:
             b.count[pi] += 1
             if pi not in b.active:
                 # a parameter that used to get no gradient got one in this backward (a data-dependent branch, e.g. a
-                # text-only batch before): forget the learnt subset.  Not launched yet: the bucket waits for step().
-                # Launched already: the reduced piece lacks this gradient -- the bucket buffer still holds every gradient
-                # (the early launch of a learnt subset never reduces in place), so step() reduces it again, after all ranks
-                # agreed on which buckets need it.
-                b.active, b.seen = frozenset(range(len(b.params))), (None, 0)
+                # text-only batch before).  `active` itself is COLLECTIVE state -- it only changes in step(), from values every
+                # rank has seen (below) -- so this rank just stops trusting the subset for the rest of this step.  Not launched
+                # yet: the bucket waits for step().  Launched already: the reduced piece lacks this gradient -- the bucket
+                # buffer still holds every gradient (the early launch of a learnt subset never reduces in place), so step()
+                # reduces it again, after all ranks agreed on which buckets need it.
                 if b.launched and self._multi:
                     b.redo = True
                 else:
@@ -287,6 +287,46 @@ class Zero1AdamW:
             b.work.wait()
         b.work = None
 
+    def _agree_on_subsets(self):
+        """Which parameters of a bucket fire (`active`, what lets a bucket with structurally unused parameters -- e.g.
+        linear_aggregator.wv / dense of the reference, tta.py:47-48,62-65 -- leave from its hooks) and which early launches were
+        premature (`redo`) are decided from ONE small MAX-reduction per step that every rank always takes part in: per parameter
+        "fired on some rank", per bucket "some rank saw a late gradient" and "some rank's hook counts were irregular".  `active`
+        therefore is the same set on every rank at every step, whatever each rank's data did (a rank-local decision
+        gated this very collective): the union of what fired becomes the subset after it has been the same, with regular counts
+        and no repair, for 3 consecutive steps; the moment anything outside it fires anywhere the bucket goes back to all
+        parameters; a premature launch is reduced again here, in bucket order, on every rank."""
+        np_ = [len(b.params) for b in self.buckets]
+        flags = []
+        for b in self.buckets:
+            flags += [1.0 if c else 0.0 for c in b.count]
+        for b in self.buckets:
+            irregular = not all(c in (0, self.accum) for c in b.count) or b.defer
+            flags += [1.0 if b.redo else 0.0, 1.0 if irregular else 0.0]
+        t = torch.tensor(flags, dtype=torch.float32, device=self.buckets[0].flat_grad.device)
+        if self._multi:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        vals = t.tolist()
+        pos, tail = 0, sum(np_)
+        for bi, b in enumerate(self.buckets):
+            fired = frozenset(i for i in range(np_[bi]) if vals[pos + i])
+            pos += np_[bi]
+            redo, irregular = bool(vals[tail + 2 * bi]), bool(vals[tail + 2 * bi + 1])
+            if redo:                      # same reduces, same order, on every rank
+                b.redo = True             # (tells _reduce that the bucket may be reduced in place now)
+                self._finish_reduce(b)
+                self._launch_reduce(b)
+            full = frozenset(range(np_[bi]))
+            if not fired <= b.active:     # a stranger fired somewhere: back to all parameters, on every rank
+                b.active, b.seen = full, (None, 0)
+            elif redo or irregular or fired == b.active:
+                if fired != b.active:
+                    b.seen = (None, 0)
+            else:                         # a strict subset of the current set, cleanly: a candidate
+                b.seen = (fired, b.seen[1] + 1) if b.seen[0] == fired else (fired, 1)
+                if b.seen[1] >= 3:
+                    b.active, b.seen = fired, (None, 0)
+
     # ------------------------------------------------------------------ step
     def _update_piece(self, b: _Bucket, st: dict, out: torch.Tensor, coef: Optional[torch.Tensor]):
         """AdamW on this rank's piece: st (fp32 master / m / v) in place, `out` <- bf16 (parameter dtype) of the new master."""
@@ -318,35 +358,11 @@ class Zero1AdamW:
     @torch.no_grad()
     def step(self):
         self.t += 1
-        # whatever is not in flight yet goes now, in order: no overlap requested, or buckets with parameters that received
-        # no gradient.  Learn from it: a bucket whose hooks fired the same number of times in every micro-batch will be
-        # launched from its hook next time (unused parameters -- e.g. linear_aggregator.wv / dense, tta.py:47-48,62-65 --
-        # no longer cost the overlap).  The set of unused parameters is structural, hence the same on every rank.
-        # A subset is only trusted after it has been the same for 3 consecutive steps, it is forgotten the moment any other
-        # hook fires (the hook above), and an early launch that turns out premature is repaired below.
-        learnt = False
-        for b in self.buckets:
-            fired = frozenset(i for i, c in enumerate(b.count) if c)
-            clean = all(c in (0, self.accum) for c in b.count) and not b.redo and not b.defer
-            if clean and fired != b.active and len(fired) < len(b.params):
-                b.seen = (fired, b.seen[1] + 1) if b.seen[0] == fired else (fired, 1)
-                if b.seen[1] >= 3:
-                    b.active = fired
-            elif not (clean and fired == b.active):
-                b.seen = (None, 0)
-            learnt = learnt or len(b.active) < len(b.params) or b.redo
+        # whatever is not in flight yet goes now, in order: no overlap requested, buckets with parameters that received no
+        # gradient, buckets this rank deferred.
         self._launch_in_order(flush=True)
-        if learnt and self._multi:
-            # which early launches were premature?  One tiny MAX-reduction, so that every rank repeats the same reduces in
-            # the same order even if only one of them saw the late gradient.
-            flags = torch.tensor([1.0 if b.redo else 0.0 for b in self.buckets], device=self.buckets[0].flat_grad.device)
-            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
-            for b, f in zip(self.buckets, flags.tolist()):
-                if f:
-                    b.redo = True
-                    b.active, b.seen = frozenset(range(len(b.params))), (None, 0)
-                    self._finish_reduce(b)
-                    self._launch_reduce(b)
+        if self.overlap:
+            self._agree_on_subsets()
         coef = None
         if self.max_grad_norm is not None:
             for b in self.buckets:

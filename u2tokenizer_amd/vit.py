@@ -228,8 +228,8 @@ class ViT3DTower(ops.Fp16Twin, nn.Module):
                     and torch.equal(img0, images):
                 return out0.clone()   # (both models get their own tensor: an in-place op downstream cannot reach the cache)
         out = self.vision_tower.forward_features(images, keep_cls=self.select_feature == "cls_patch")
-        if key is not None:
-            self._feat_cache = (key, images.detach().clone(), out)
+        if key is not None:   # the cache keeps its OWN tensor: the first caller may write into `out` in place too
+            self._feat_cache = (key, images.detach().clone(), out.clone())
         return out
 
     @property
