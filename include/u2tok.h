@@ -36,6 +36,11 @@ typedef void* u2tok_stream_t; /* hipStream_t */
 /* ---- library identity / gating -------------------------------------------------------------- */
 int u2tok_version(void);               /* MAJOR*10000 + MINOR*100 + PATCH */
 const char* u2tok_arch(void);          /* "gfx950" */
+/* The 16-bit ELEMENT TYPE of this build: "bf16" (libu2tok_hip.so) or "f16" (libu2tok_hip_f16.so -- the same sources compiled
+ * with -DU2_ELEM_F16 for checkpoints loaded in float16, evalscipt/ourmodel_amos.py:33,70).  Wherever this header says "bf16"
+ * (parameter / activation buffers, function names such as u2tok_gemm_bf16) read "the element type of the build": both
+ * libraries export exactly the same symbols, accumulate in fp32 and differ only in the storage format and the MFMA opcode. */
+const char* u2tok_elem(void);
 int u2tok_device_check(void);          /* 0 if the current HIP device is gfx950, else U2TOK_ERR_DEVICE */
 /* ---- execution contexts --------------------------------------------------------------------------------------------
  * Options, the tokenizer's side streams / events (one set per caller stream), split-K scratch registrations and

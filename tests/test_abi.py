@@ -1,4 +1,5 @@
-"""CPU: the C-ABI library builds, loads and exports exactly what include/u2tok.h declares (no compute calls)."""
+"""CPU: the C-ABI library -- both builds of it: bf16 elements (libu2tok_hip.so) and IEEE-half elements (libu2tok_hip_f16.so) --
+builds, loads and exports exactly what include/u2tok.h declares (no compute calls)."""
 import ctypes as C
 import re
 from pathlib import Path
@@ -16,11 +17,13 @@ def _declared():
     return sorted(set(re.findall(r"\b(u2tok_[a-z0-9_]+)\s*\(", text)))
 
 
-@pytest.fixture(scope="module")
-def lib():
-    if not _lib.lib_path().exists():
+@pytest.fixture(scope="module", params=["bf16", "f16"])
+def lib(request):
+    if not all(p.exists() for p in _lib._LIBS.values()):
         _lib.build()
-    return _lib.load_library()
+    h = _lib.load_library(request.param)
+    assert h.u2tok_elem() == request.param.encode()
+    return h
 
 
 def test_every_declared_symbol_is_exported_and_bound(lib):

@@ -28,10 +28,13 @@ def rnd(*shape, scale=1.0, seed=0):
     return (torch.randn(*shape, generator=g) * scale).to(bf)
 
 
+ULP = 2.0 ** -8   # of the element type under test (tests/test_gpu_f16.py re-runs this module's cases with bf = float16, 2^-11)
+
+
 def close_bf16(got, ref, rounds=2):
     got, ref = got.float().cpu(), ref.float()
     assert torch.isfinite(got).all()
-    tol = rounds * 2.0 ** -8 * ref.abs() + 2.0 ** -8 * ref.abs().max()
+    tol = rounds * ULP * ref.abs() + ULP * ref.abs().max()
     bad = (got - ref).abs() > tol
     assert not bad.any(), f"{bad.sum().item()} elements off; worst {(got - ref).abs().max().item():.3e}"
 
@@ -94,19 +97,19 @@ def test_layernorm(ops, C_):
 def test_softmax_rows_scale_bias_and_padding(ops):
     for (Z, R, n) in [(8, 40, 40), (3, 17, 1792), (4, 9, 13), (1, 1, 1)]:
         s = torch.randn(Z, R, n, generator=torch.Generator().manual_seed(n)) * 3
-        got = ops.softmax_rows(s.to(D), scale=0.7)
+        got = ops.softmax_rows(s.to(D), scale=0.7, elem=bf)
         close_bf16(got[:, :, :n], F.softmax(s * 0.7, dim=-1))
         assert got.shape[2] % 8 == 0 and (got[:, :, n:] == 0).all()
         close_f32(got.float().sum(-1), torch.ones(Z, R)) if False else None
     H, L = 4, 512
     tbl = rnd(2 * L - 1, H, scale=0.5, seed=5)
     s = torch.randn(2 * H, 40, 40, generator=torch.Generator().manual_seed(7))
-    got = ops.softmax_rows(s.to(D), scale=0.5, rel_bias=tbl.to(D), heads=H, max_len=L)
+    got = ops.softmax_rows(s.to(D), scale=0.5, rel_bias=tbl.to(D), heads=H, max_len=L, elem=bf)
     pos = torch.arange(40)
     bias = tbl.float()[pos[None, :] - pos[:, None] + L - 1].permute(2, 0, 1)  # rma.py:64-69
     close_bf16(got[:, :, :40], F.softmax(s.view(2, H, 40, 40) * 0.5 + bias[None], dim=-1).view(2 * H, 40, 40))
     with pytest.raises(RuntimeError, match="U2TOK_ERR_ARG"):  # seq_len > max_seq_len cannot index the bias table
-        ops.softmax_rows(torch.zeros(H, 600, 600, device=D), rel_bias=tbl.to(D), heads=H, max_len=L)
+        ops.softmax_rows(torch.zeros(H, 600, 600, device=D), rel_bias=tbl.to(D), heads=H, max_len=L, elem=bf)
 
 
 def test_transpose_and_data_movement_are_bit_exact(ops):
@@ -125,7 +128,7 @@ def test_transpose_and_data_movement_are_bit_exact(ops):
     for dt in (torch.float16, torch.bfloat16, torch.float32):
         vol = torch.rand(2, 1, 8, 32, 32, generator=torch.Generator().manual_seed(3)).to(dt)
         ref = vol.to(bf).reshape(2, 1, 2, 4, 2, 16, 2, 16).permute(0, 2, 4, 6, 3, 5, 7, 1).reshape(2, 8, 1024)
-        assert torch.equal(ops.im2col(vol.to(D), (4, 16, 16)).cpu(), ref)
+        assert torch.equal(ops.im2col(vol.to(D), (4, 16, 16), elem=bf).cpu(), ref)
     table = rnd(100, 64, seed=10)
     ids = torch.randint(0, 100, (2, 12), generator=torch.Generator().manual_seed(1))
     feats = rnd(2, 5, 64, seed=11)
@@ -142,7 +145,7 @@ def test_im2col_full_volume_is_the_reference_permutation(ops):
     """256^3 fp16 volume = 8 chunks of (32,256,256): exact equality with the einops pattern of vit.py:90-99."""
     vol = torch.rand(8, 1, 32, 256, 256, generator=torch.Generator().manual_seed(9)).half()
     ref = vol.to(bf).reshape(8, 1, 8, 4, 16, 16, 16, 16).permute(0, 2, 4, 6, 3, 5, 7, 1).reshape(8, 2048, 1024)
-    assert torch.equal(ops.im2col(vol.to(D), (4, 16, 16)).cpu(), ref)
+    assert torch.equal(ops.im2col(vol.to(D), (4, 16, 16), elem=bf).cpu(), ref)
 
 
 def test_avgpool(ops):
@@ -364,7 +367,7 @@ def test_flash_mode7_log_sum_exp(ops):
 def test_flash_wide_and_narrow_stores_agree(ops):
     """16-byte output stores need 16-byte aligned rows; an output view at an 8-byte offset takes the 8-byte form."""
     from u2tokenizer_amd import _lib
-    h = _lib.load_library()
+    h = _lib.load_library(ops.ELEM_OF[bf])
     nb, S, H = 1, 640, 2
     Hd = 64 * H
     qkv = rnd(nb, S, 3 * Hd, seed=4).to(D)

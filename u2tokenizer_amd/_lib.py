@@ -1,4 +1,8 @@
-"""ctypes binding of libu2tok_hip.so (C ABI: include/u2tok.h)."""
+"""ctypes binding of libu2tok_hip.so / libu2tok_hip_f16.so (C ABI: include/u2tok.h).
+
+Two builds of the same sources export the same symbols: the element type of activations and parameters is bfloat16 in
+libu2tok_hip.so and IEEE half in libu2tok_hip_f16.so (csrc/common.h, U2_ELEM_F16; u2tok_elem() names it).  load_library(elem)
+picks one; ops.py chooses by the dtype of the tensors it is handed."""
 from __future__ import annotations
 
 import ctypes as C
@@ -9,8 +13,9 @@ from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
 _LIB = _PKG / "lib" / "libu2tok_hip.so"
+_LIBS = {"bf16": _LIB, "f16": _PKG / "lib" / "libu2tok_hip_f16.so"}
 _lock = threading.Lock()
-_handle = None
+_handles = {}
 
 
 class LibraryNotBuilt(RuntimeError):
@@ -72,6 +77,7 @@ _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_si
 SIGNATURES = {
     "u2tok_version": (_i32, []),
     "u2tok_arch": (C.c_char_p, []),
+    "u2tok_elem": (C.c_char_p, []),
     "u2tok_device_check": (_i32, []),
     "u2tok_ctx_create": (_i32, [C.POINTER(_vp)]),
     "u2tok_ctx_destroy": (_i32, [_vp]),
@@ -153,22 +159,45 @@ ERRORS = {-1: "U2TOK_ERR_ARG (bad dimension / null pointer / unsupported combina
           -4: "U2TOK_ERR_DEVICE (current device is not gfx950)"}
 
 
-def load_library() -> C.CDLL:
-    """Load libu2tok_hip.so; raises LibraryNotBuilt when it is absent (never falls back to anything)."""
-    global _handle
+def load_library(elem: str = None) -> C.CDLL:
+    """Load the library of element type `elem` ("bf16" / "f16"; None = what the calling thread's current op runs in, bf16
+    outside one); raises LibraryNotBuilt when it is absent (never falls back to anything)."""
+    if elem is None:
+        elem = getattr(_tls, "elem", "bf16")
     with _lock:
-        if _handle is not None:
-            return _handle
-        if not _LIB.exists():
+        h = _handles.get(elem)
+        if h is not None:
+            return h
+        path = _LIBS[elem]
+        if not path.exists():
             raise LibraryNotBuilt(
-                f"{_LIB} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 f"or `make -C {_PKG / 'csrc'}`. There is no CPU fallback for the u2Tokenizer HIP path.")
-        h = C.CDLL(str(_LIB))
+        h = C.CDLL(str(path))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)  # AttributeError here == header/library drift
             fn.restype, fn.argtypes = res, args
-        _handle = h
+        assert h.u2tok_elem() == elem.encode(), (path, h.u2tok_elem())
+        _handles[elem] = h
         return h
+
+
+_tls = threading.local()   # .elem: element type of the op the calling thread is inside (set by ops.on_device)
+
+
+def thread_elem() -> str:
+    return getattr(_tls, "elem", "bf16")
+
+
+def set_thread_elem(elem):
+    """-> previous value (None = unset)."""
+    prev = getattr(_tls, "elem", None)
+    if elem is None:
+        if hasattr(_tls, "elem"):
+            del _tls.elem
+    else:
+        _tls.elem = elem
+    return prev
 
 
 def check(status: int, what: str) -> None:

@@ -106,9 +106,9 @@ class u2MetaForCausalLM(ABC):
         # u2_arch.py:131-135): lookup and splice go through autograd (nn.Embedding + cat, as in the reference) so the
         # table receives its gradient; otherwise the fused HIP gather / splice kernel.
         track = torch.is_grad_enabled() and embed_w.requires_grad
-        # a float16 model (evalscipt/ourmodel_amos.py:33): the path modules run their bf16 copies (ops.Fp16Twin); the decoder's
-        # own embedding table stays what it is, so lookup and splice are the reference's torch ops on the GPU
-        plain = embed_w.dtype != torch.bfloat16
+        # the fused gather / splice kernel takes the table in the path's 16-bit element type (bf16, or fp16 for a model loaded in
+        # float16, evalscipt/ourmodel_amos.py:33); any other table (an fp32 master copy) goes through the reference's torch ops
+        plain = embed_w.dtype not in ops.ELEM_OF
 
         def lookup(ids):
             return embed(ids) if (track or plain) else ops.embed_splice(embed_w, ids)

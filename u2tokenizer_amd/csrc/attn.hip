@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void temporal_attention_kernel(const bf16_t* _
         qa = *reinterpret_cast<const bf16x8*>(qp + ks * 32);
         ka = *reinterpret_cast<const bf16x8*>(kp + ks * 32);
       }
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qa, acc, 0, 0, 0);
+      acc = mfma16(ka, qa, acc);
     }
   }
   // lane: t1 = lane & 15 (query), t2 = 4*(lane>>4) + r (key)
@@ -293,7 +293,7 @@ __device__ __forceinline__ void flash_pass(const FlashArgs& a, char (*lds)[16384
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + kt_off(kbk * 32 + l31, ks * 2 + hi));
 #pragma unroll
           for (int qb = 0; qb < QB; ++qb)
-            sc[qb][kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], sc[qb][kbk], 0, 0, 0);
+            sc[qb][kbk] = mfma32(kf, qf[qb][ks], sc[qb][kbk]);
         }
       }
       if constexpr (TIMED) {
@@ -365,7 +365,7 @@ __device__ __forceinline__ void flash_pass(const FlashArgs& a, char (*lds)[16384
             const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + kt_off(nb * 32 + l31, (kbk * 2 + ks2) * 2 + hi));
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
-              oacc[qb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb].v, oacc[qb][nb], 0, 0, 0);
+              oacc[qb][nb] = mfma32(vf, pf[qb].v, oacc[qb][nb]);
           }
         }
     }
@@ -682,16 +682,19 @@ typedef int i32x4_t __attribute__((ext_vector_type(4)));
 // running max is subtracted by the matrix pipe (C operand of the first Q K^T MFMA = a tuple holding -m), m is only
 // kept within 2^64 of the true running max (an out-of-line path restores that when a row-sum piece says so), and
 // the tile loop is unrolled over the ring so fragment reads are lane base + immediate.
+#if U2_ELEM_IS_F16
+#include "build_f16/flash_dp2_asm.inc"  // derived at build time: tools/asm_elem_f16.py
+#else
 #include "flash_dp2_asm.inc"
+#endif
 
 
 // Extra query row of head (b, h) for the double pipeline of round 4 (NT threads).  The first form (flash_extra_row above)
 // took ~40 us per row -- 64 dependent 16-byte loads per thread -- and sat on the kernel's tail.  Scores: 8 lanes per key
 // (16-byte K chunks, fully coalesced rows), 16 keys per thread in flight; softmax through LDS; P V: 16 lanes per V^T
 // row, 16 independent 16-byte loads per thread in flight.
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-__device__ __forceinline__ float dot2_bf16(const uint32_t a, const uint32_t b, const float c) {  // v_dot2c_f32_bf16
-  return __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const bf16x2_t*>(&a), *reinterpret_cast<const bf16x2_t*>(&b), c, false);
+__device__ __forceinline__ float dot2_bf16(const uint32_t a, const uint32_t b, const float c) {  // v_dot2c_f32_bf16 / _f16
+  return dot2_elem(a, b, c);
 }
 template <int NT>
 __device__ __forceinline__ void flash_extra_row2(const FlashArgs& a, float* sbuf, const int b, const int h, const int tid,

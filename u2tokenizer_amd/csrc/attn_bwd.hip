@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const FlashBwdArgs
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + tile_off(kbk * 32 + l31, ks * 2 + hi));
-            sc[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks].v, sc[kbk], 0, 0, 0);
+            sc[kbk] = mfma32(kf, qf[ks].v, sc[kbk]);
           }
         }
         // lane owns keys t*64 + kbk*32 + (r&3) + 8*(r>>2) + 4*hi
@@ -246,9 +246,9 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const FlashBwdArgs
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + tile_off(kbk * 32 + l31, ks * 2 + hi));
-          sc[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks].v, sc[kbk], 0, 0, 0);
+          sc[kbk] = mfma32(kf, qf[ks].v, sc[kbk]);
           const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + tile_off(kbk * 32 + l31, ks * 2 + hi));
-          dp[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks].v, dp[kbk], 0, 0, 0);
+          dp[kbk] = mfma32(vf, dof[ks].v, dp[kbk]);
         }
       }
       if (ragged && t == ntile - 1) {
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const FlashBwdArgs
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb) {
             const bf16x8 tf = tr_frag(sK, lane, nb, kbk * 32 + ks2 * 16);
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, pf.v, acc[nb], 0, 0, 0);
+            acc[nb] = mfma32(tf, pf.v, acc[nb]);
           }
         }
     }
@@ -394,9 +394,9 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const FlashBwdArg
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const bf16x8 qa = *reinterpret_cast<const bf16x8*>(sQ + tile_off(qbk * 32 + l31, ks * 2 + hi));
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks].v, s, 0, 0, 0);
+          s = mfma32(qa, kf[ks].v, s);
           const bf16x8 ga = *reinterpret_cast<const bf16x8*>(sG + tile_off(qbk * 32 + l31, ks * 2 + hi));
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vf[ks].v, dp, 0, 0, 0);
+          dp = mfma32(ga, vf[ks].v, dp);
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -423,9 +423,9 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const FlashBwdArg
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb) {
             const bf16x8 gt = tr_frag(sG, lane, nb, qbk * 32 + ks2 * 16);
-            accV[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gt, pp.v, accV[nb], 0, 0, 0);
+            accV[nb] = mfma32(gt, pp.v, accV[nb]);
             const bf16x8 qt = tr_frag(sQ, lane, nb, qbk * 32 + ks2 * 16);
-            accK[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, ps.v, accK[nb], 0, 0, 0);
+            accK[nb] = mfma32(qt, ps.v, accK[nb]);
           }
         }
       }

@@ -18,6 +18,7 @@ extern "C" {
 
 int u2tok_version(void) { return 100; /* 0.1.0 */ }
 const char* u2tok_arch(void) { return "gfx950"; }
+const char* u2tok_elem(void) { return U2_ELEM_ASM; }
 
 int u2tok_device_check(void) {
   int dev = 0;

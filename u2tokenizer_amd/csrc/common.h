@@ -22,6 +22,40 @@ enum : int {
   U2_ERR_DEVICE = -4,    // not a gfx950 device
 };
 
+// ---- the ELEMENT TYPE of the build.  Every kernel of this library stores activations and parameters as 16-bit elements and
+// accumulates in fp32; which 16-bit format is a property of the build: bfloat16 (libu2tok_hip.so, the default) or IEEE half
+// (libu2tok_hip_f16.so, compiled from the same sources with -DU2_ELEM_F16 -- evalscipt/ourmodel_amos.py:33,70 loads fp16 weights).
+// The two differ in exactly these places: the conversions below, the MFMA opcode (same shapes, same rate, same fragment
+// layouts on gfx950), the conversion / MFMA / dot2 opcodes inside the generated asm loops (U2_ELEM_ASM), and the flash loop's
+// stale-max bound (U2_FLASH_THR_BITS: half has 5 exponent bits).  Names keep their historical "bf16": bf16_t = "the 16-bit
+// element", pack2_bf16 = "round two floats to elements", ...
+#if defined(U2_ELEM_F16)
+#define U2_ELEM_ASM "f16"
+#define U2_ELEM_IS_F16 1
+typedef __attribute__((ext_vector_type(2))) _Float16 elem_x2_hw;
+typedef __attribute__((ext_vector_type(8))) _Float16 elem_x8_hw;
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+// Round-to-nearest-even (v_cvt_f16_f32); values beyond 65504 become +-inf, as in torch.
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+  f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, elem_x2_hw));  // v_cvt_pk_f16_f32 (RNE)
+}
+__device__ __forceinline__ float bf16lo(uint32_t u) { return (float)__builtin_bit_cast(elem_x2_hw, u)[0]; }
+__device__ __forceinline__ float bf16hi(uint32_t u) { return (float)__builtin_bit_cast(elem_x2_hw, u)[1]; }
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(elem_x8_hw, a), __builtin_bit_cast(elem_x8_hw, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(elem_x8_hw, a), __builtin_bit_cast(elem_x8_hw, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ float dot2_elem(uint32_t a, uint32_t b, float c) {  // c + a.lo b.lo + a.hi b.hi
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(elem_x2_hw, a), __builtin_bit_cast(elem_x2_hw, b), c, false);
+}
+#else
+#define U2_ELEM_ASM "bf16"
+#define U2_ELEM_IS_F16 0
+typedef __attribute__((ext_vector_type(2))) __bf16 elem_x2_hw;
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
   return __uint_as_float(((uint32_t)v) << 16);
 }
@@ -37,6 +71,16 @@ __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
 }
 __device__ __forceinline__ float bf16lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float dot2_elem(uint32_t a, uint32_t b, float c) {  // c + a.lo b.lo + a.hi b.hi
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(elem_x2_hw, a), __builtin_bit_cast(elem_x2_hw, b), c, false);
+}
+#endif
+
+// VOXEL formats are data formats, not the build's element type: a bfloat16 volume is bfloat16 in either build.
+__device__ __forceinline__ float voxel_bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ uint16_t f32_to_voxel_bf16(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = mfma16(wf[ni], xf[mi], acc[mi][ni]);
     }
   };
 
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows16_kernel(GemmDesc d) {
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if (sb + u < s1) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf[u], acc, 0, 0, 0);
+      if (sb + u < s1) acc = mfma16(wf[u], xf[u], acc);
   }
   // lane holds C[m = l15][n = n0 + 4 g + r]
   red[wv][lane][0] = acc[0]; red[wv][lane][1] = acc[1]; red[wv][lane][2] = acc[2]; red[wv][lane][3] = acc[3];

@@ -252,7 +252,11 @@ __device__ __forceinline__ void pp_epilogue(const GemmDesc& d, f32x16 (&acc)[2][
 // and fragment read sits in the shadow of an MFMA, and a 256^2 tile needs half the LDS fill bandwidth per flop of
 // the 128^2 kernel (the measured limit of the CU's L2 -> LDS path, ~50 B/clk, profiles/r01_stage_bw.log).
 // Requirements checked by the launcher: K % 64 == 0, operands addressable with 32-bit byte offsets.
+#if U2_ELEM_IS_F16
+#include "build_f16/gemm_bt_asm.inc"  // derived at build time: tools/asm_elem_f16.py
+#else
 #include "gemm_bt_asm.inc"
+#endif
 typedef int bt_i32x4 __attribute__((ext_vector_type(4)));
 
 // NJ = 2 is the RING form (256 x 128 tiles, variant 22): three LDS stages of 48 KB, K tile t + 2 issued during iteration t and

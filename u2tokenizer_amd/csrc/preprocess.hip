@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void pre_resize_kernel(const float* __restrict
                    l1[1] * (l0w * at(i1[0], i1[1], i0[2]) + l1[2] * at(i1[0], i1[1], i1[2])));
     }
     if constexpr (DT == VOL_F32) reinterpret_cast<float*>(out)[i] = v;
-    else if constexpr (DT == VOL_BF16) reinterpret_cast<bf16_t*>(out)[i] = f32_to_bf16(v);
+    else if constexpr (DT == VOL_BF16) reinterpret_cast<uint16_t*>(out)[i] = f32_to_voxel_bf16(v);
     else reinterpret_cast<_Float16*>(out)[i] = (_Float16)v;
   }
 }

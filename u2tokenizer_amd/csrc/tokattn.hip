@@ -30,7 +30,11 @@
 //       chunks rotated inside each 256-byte segment by 2 (key & 3) + 8 ((key >> 2) & 1) so that the 8 rows x 32 bytes a
 //       half wave touches fall into 16 different 16-byte slots (the layout family of gemm.hip's K-major operands).
 #include "kernels.h"
+#if U2_ELEM_IS_F16
+#include "build_f16/tokattn_pv_asm.inc"  // derived at build time: tools/asm_elem_f16.py
+#else
 #include "tokattn_pv_asm.inc"
+#endif
 
 namespace u2 {
 
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(256, DH >= 512 ? 1 : 2) void tok_attn_kernel(const 
 #pragma unroll
       for (int i = 0; i < NQK; ++i)
         acc[i % NKB][(i / NKB) & 1] =
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i], qf[i / NKB], acc[i % NKB][(i / NKB) & 1], 0, 0, 0);
+            mfma16(kf[i], qf[i / NKB], acc[i % NKB][(i / NKB) & 1]);
       __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);  // 0x100 = DS read, 0x008 = MFMA
 #pragma unroll
       for (int i = 0; i < NQK; ++i) {
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(256, DH >= 512 ? 1 : 2) void tok_attn_kernel(const 
       }
 #pragma unroll
       for (int i = 0; i < NPV; ++i)
-        o[i % DB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[i], pf[i / DB].v, o[i % DB], 0, 0, 0);
+        o[i % DB] = mfma16(vf[i], pf[i / DB].v, o[i % DB]);
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * PD, 0);
 #pragma unroll
       for (int i = 0; i < NPV; ++i) {
@@ -567,7 +571,7 @@ __global__ __launch_bounds__(512) void tok_attn2_kernel(const TokAttnArgs a) {
 #pragma unroll
     for (int ks = K1; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(tK + (((ks * 4 + g) ^ k_swz) << 4));
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) acc[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[ks], acc[ks & 3], 0, 0, 0);
+    for (int ks = 0; ks < KS; ++ks) acc[ks & 3] = mfma16(kf[ks], qf[ks], acc[ks & 3]);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 0x008 = MFMA, 0x100 = DS read

@@ -24,8 +24,13 @@ __global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ vo
     const int p1i = rr / p2, p2i = rr - p1i * p2;
     const int64_t off = vbase + ((int64_t)(h_i * p1 + p1i) * H + (w_i * p2 + p2i)) * W + col;
     uint4 o;
-    if constexpr (DT == VOL_BF16) {
+    if constexpr (DT == (U2_ELEM_IS_F16 ? VOL_F16 : VOL_BF16)) {  // voxels already in the element type of the build
       o = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(vol) + off);
+    } else if constexpr (DT == VOL_BF16) {
+      const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(vol) + off);
+      const uint16_t* hp = reinterpret_cast<const uint16_t*>(&u);
+      o = uint4{pack2_bf16(voxel_bf16_to_f32(hp[0]), voxel_bf16_to_f32(hp[1])), pack2_bf16(voxel_bf16_to_f32(hp[2]), voxel_bf16_to_f32(hp[3])),
+                pack2_bf16(voxel_bf16_to_f32(hp[4]), voxel_bf16_to_f32(hp[5])), pack2_bf16(voxel_bf16_to_f32(hp[6]), voxel_bf16_to_f32(hp[7]))};
     } else if constexpr (DT == VOL_F16) {
       const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const _Float16*>(vol) + off);
       const _Float16* hp = reinterpret_cast<const _Float16*>(&u);

@@ -21,27 +21,49 @@ class Context:
     """One execution context of the library (include/u2tok.h, "execution contexts"): its own option set, tokenizer side
     streams + events, split-K scratch table and profiling records.  Every GPU gets a default context on first use;
     `with ops.Context() as c:` runs the enclosed calls of this thread on a private one (e.g. a second model with other
-    options, or a worker thread)."""
+    options, or a worker thread).  The bf16 and the f16 build of the library (_lib.load_library) each keep their own native
+    context behind this object, created on first use; options set here reach both."""
 
     def __init__(self):
-        h = _lib.load_library()
-        handle = C.c_void_p()
-        _lib.check(h.u2tok_ctx_create(C.byref(handle)), "u2tok_ctx_create")
-        self.handle = handle
+        self._handles = {}     # element type -> native handle
+        self._options = {}
+        self._lock = threading.Lock()
+        self.handle_for("bf16")
+
+    def handle_for(self, elem: str):
+        with self._lock:
+            hd = self._handles.get(elem)
+            if hd is None:
+                h = _lib.load_library(elem)
+                hd = C.c_void_p()
+                _lib.check(h.u2tok_ctx_create(C.byref(hd)), "u2tok_ctx_create")
+                self._handles[elem] = hd
+                for name, value in self._options.items():
+                    self._set(h, hd, name, value)
+            return hd
+
+    @property
+    def handle(self):
+        return self.handle_for(_lib.thread_elem())
 
     def close(self) -> None:
-        if self.handle:
-            _lib.load_library().u2tok_ctx_destroy(self.handle)
-            self.handle = None
+        for elem, hd in self._handles.items():
+            _lib.load_library(elem).u2tok_ctx_destroy(hd)
+        self._handles = {}
 
-    def set_option(self, name: str, value: int) -> None:
-        h = _lib.load_library()
+    @staticmethod
+    def _set(h, hd, name, value):
         prev = h.u2tok_ctx_get_current()
-        h.u2tok_ctx_set_current(self.handle)
+        h.u2tok_ctx_set_current(hd)
         try:
             _lib.check(h.u2tok_set_option(name.encode(), int(value)), f"u2tok_set_option({name})")
         finally:
             h.u2tok_ctx_set_current(prev)
+
+    def set_option(self, name: str, value: int) -> None:
+        for elem, hd in list(self._handles.items()):
+            self._set(_lib.load_library(elem), hd, name, value)
+        self._options[name] = int(value)
 
     def __enter__(self):
         stack = getattr(_tls, "stack", None)
@@ -73,28 +95,55 @@ def active_context(device=None) -> Context:
     return c
 
 
+ELEM_OF = {torch.bfloat16: "bf16", torch.float16: "f16"}
+ELEM_DTYPE = {"bf16": torch.bfloat16, "f16": torch.float16}
+
+
+def elem_dtype() -> torch.dtype:
+    """The 16-bit element type of the op the calling thread is inside (bf16 outside one): what its buffers must be."""
+    return ELEM_DTYPE[_lib.thread_elem()]
+
+
 @contextlib.contextmanager
-def on_device(t: torch.Tensor):
+def on_device(t: torch.Tensor, elem=None):
     """Entry guard of every wrapper: makes the tensor's GPU the current HIP device (the library launches on the current
-    device; a model on cuda:1 must not launch on cuda:0), binds the active context and yields (library handle, the
-    current torch stream OF THAT DEVICE)."""
+    device; a model on cuda:1 must not launch on cuda:0), picks the library build by ELEMENT TYPE -- `elem` (a dtype: what the
+    module's parameters are), else t's dtype if it is bf16 / fp16, else what an enclosing guard chose -- binds the active
+    context and yields (library handle, the current torch stream OF THAT DEVICE)."""
     if not t.is_cuda:
         raise RuntimeError("expected a GPU tensor (the u2tok HIP path has no CPU fallback)")
-    h = _lib.load_library()
-    with torch.cuda.device(t.device):
-        h.u2tok_ctx_set_current(active_context(t.device).handle)
-        yield h, torch.cuda.current_stream(t.device).cuda_stream
+    dt = elem if elem is not None else t.dtype
+    name = ELEM_OF.get(dt)
+    if name is None and elem is not None:
+        raise RuntimeError(f"the u2tok HIP path computes on bfloat16 or float16 parameters, got {elem}")
+    prev = _lib.set_thread_elem(name) if name is not None else None
+    try:
+        h = _lib.load_library()
+        with torch.cuda.device(t.device):
+            h.u2tok_ctx_set_current(active_context(t.device).handle)
+            yield h, torch.cuda.current_stream(t.device).cuda_stream
+    finally:
+        if name is not None:
+            _lib.set_thread_elem(prev)
 
 
-def _guarded(fn):
-    """Runs a building-block wrapper under on_device(first tensor argument); _stream() is that device's stream."""
+def _guarded(fn=None, *, infer=True):
+    """Runs a building-block wrapper under on_device(first tensor argument); _stream() is that device's stream.  Element type
+    of the op = the keyword `elem` (a dtype) if the caller names one, else the first bf16 / fp16 tensor argument's; wrappers
+    whose 16-bit operand is not an argument (infer=False: im2col's voxels may be fp16 under a bf16 model, softmax_rows takes fp32
+    scores) default to bf16."""
+    if fn is None:
+        return functools.partial(_guarded, infer=infer)
 
     @functools.wraps(fn)
-    def wrapper(*args, **kwargs):
-        t = next((a for a in list(args) + list(kwargs.values()) if torch.is_tensor(a)), None)
+    def wrapper(*args, elem=None, **kwargs):
+        ts = [a for a in list(args) + list(kwargs.values()) if torch.is_tensor(a)]
+        t = ts[0] if ts else None
         if t is None or not t.is_cuda:
             raise RuntimeError(f"{fn.__name__}: expected GPU tensors (the u2tok HIP path has no CPU fallback)")
-        with on_device(t) as (_, st):
+        if elem is None:
+            elem = next((a.dtype for a in ts if a.dtype in ELEM_OF), None) if infer else torch.bfloat16
+        with on_device(t, elem) as (_, st):
             prev = getattr(_tls, "stream", None)
             _tls.stream = st
             try:
@@ -114,45 +163,23 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
-class Fp16Twin:
-    """Mixin of the three path modules (ViT3DTower, SpatialPoolingProjector, u2Tokenizer) for float16 PARAMETERS --
-    evalscipt/ourmodel_amos.py:33 loads the whole model with torch_dtype=float16 and generates under autocast.  The HIP
-    kernels compute in bf16 (fp32 accumulation): a module whose parameters are fp16 keeps a bf16 copy of itself (rebuilt
-    when a parameter's storage or version changes; inference only), runs that on bf16-rounded inputs and hands the result
-    back as fp16.  The interface of the fp16 entry point, the arithmetic of the bf16 one: three mantissa bits fewer than a
-    true fp16 run (documented in DESIGN.md section 5); bf16 parameters under `torch.autocast` (green_refactored/lu2_model.py:
-    30,62) take the normal path, the kernels are not autocast-aware."""
-
-    def _fp16_twin(self):
-        ps = list(self.parameters())
-        if not ps or ps[0].dtype != torch.float16:
-            return None
-        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in ps):
-            raise RuntimeError(f"{type(self).__name__}: float16 parameters are supported for inference only (train in bf16, "
-                               "as train_stage1.py / config/ds_config.json do)")
-        key = tuple((p.data_ptr(), p._version) for p in ps)
-        if self.__dict__.get("_twin_key") != key:
-            import copy
-            self.__dict__.pop("_twin_mod", None)
-            self.__dict__.pop("_twin_key", None)
-            with torch.no_grad():
-                twin = copy.deepcopy(self).to(torch.bfloat16)
-            for q in twin.parameters():
-                q.requires_grad_(False)
-            self.__dict__["_twin_mod"], self.__dict__["_twin_key"] = twin, key   # (not a registered submodule: not in state_dict)
-        return self.__dict__["_twin_mod"]
-
-    @staticmethod
-    def _to_bf16(t):
-        return t.to(torch.bfloat16) if torch.is_tensor(t) and t.is_floating_point() and t.dtype != torch.bfloat16 else t
+ELEM = "element type of the running op"   # _need(t, ELEM, ...): bf16 in the bf16 build's ops, fp16 in the f16 build's
 
 
 def _need(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
     if not t.is_cuda:
         raise RuntimeError(f"{name}: expected a GPU tensor (the u2tok HIP path has no CPU fallback)")
+    if dtype is ELEM:
+        dtype = elem_dtype()
     if t.dtype != dtype:
         raise RuntimeError(f"{name}: expected {dtype}, got {t.dtype}")
     return t
+
+
+def training_needs_bf16(dtype, who: str) -> None:
+    if dtype != torch.bfloat16:
+        raise RuntimeError(f"{who}: float16 parameters are supported for inference only (train in bf16, as train_stage1.py / "
+                           "config/ds_config.json do)")
 
 
 def set_option(name: str, value: int) -> None:
@@ -189,11 +216,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, bias_m=F
     if b_ktile:
         kt, n_, _ = b.shape
         h = _lib.load_library()
-        a2 = _need(a, torch.bfloat16, "A").reshape(-1, a.shape[-1]).contiguous()
+        a2 = _need(a, ELEM, "A").reshape(-1, a.shape[-1]).contiguous()
         M, K = a2.shape
         assert kt * 64 == K
         if out is None:
-            out = torch.empty((M, n_), dtype=torch.float32 if out_f32 else torch.bfloat16, device=a.device)
+            out = torch.empty((M, n_), dtype=torch.float32 if out_f32 else elem_dtype(), device=a.device)
         flags = GEMM_B_KTILE | (GEMM_OUT_F32 if out_f32 else 0) | (GEMM_GELU if gelu else 0)
         if bias is not None:
             flags |= GEMM_BIAS_M if bias_m else GEMM_BIAS_N
@@ -205,7 +232,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, bias_m=F
         _lib.check(st, "u2tok_gemm_bf16")
         return out
     h = _lib.load_library()
-    _need(a, torch.bfloat16, "A"), _need(b, torch.bfloat16, "B")
+    _need(a, ELEM, "A"), _need(b, ELEM, "B")
     a3 = a.reshape(-1, a.shape[-2], a.shape[-1]) if b.dim() == 3 else a.reshape(1, -1, a.shape[-1])
     a3 = a3.contiguous()
     b = b.contiguous()
@@ -213,7 +240,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, bias_m=F
     N = b.shape[-2]
     assert b.shape[-1] == K
     if out is None:
-        out = torch.empty((Z, M, N), dtype=torch.float32 if out_f32 else torch.bfloat16, device=a.device)
+        out = torch.empty((Z, M, N), dtype=torch.float32 if out_f32 else elem_dtype(), device=a.device)
     flags = (GEMM_OUT_F32 if out_f32 else 0) | (GEMM_GELU if gelu else 0)
     if bias is not None:
         flags |= GEMM_BIAS_M if bias_m else GEMM_BIAS_N
@@ -241,7 +268,7 @@ def gemm_swiglu(a: torch.Tensor, w_gate_up: torch.Tensor, out: Optional[torch.Te
     """(rows, I) = bf16(silu(a @ gate^T)) * (a @ up^T) for w_gate_up (2 I, K) = gate rows then up rows: the values of
     `swiglu(gemm(a, w_gate_up))` bit for bit, the (rows, 2 I) intermediate never written (LlamaMLP / Qwen3MLP)."""
     h = _lib.load_library()
-    _need(a, torch.bfloat16, "A"), _need(w_gate_up, torch.bfloat16, "W")
+    _need(a, ELEM, "A"), _need(w_gate_up, ELEM, "W")
     a2 = a.reshape(-1, a.shape[-1]).contiguous()
     w = w_gate_up.contiguous()
     M, K = a2.shape
@@ -250,7 +277,7 @@ def gemm_swiglu(a: torch.Tensor, w_gate_up: torch.Tensor, out: Optional[torch.Te
     if w.shape[1] != K or N % 2 or not gemm_swiglu_supported(M, K, I):
         raise RuntimeError(f"gemm_swiglu: unsupported shape rows {M}, K {K}, 2I {N}")
     if out is None:
-        out = torch.empty((M, I), dtype=torch.bfloat16, device=a.device)
+        out = torch.empty((M, I), dtype=elem_dtype(), device=a.device)
     st = h.u2tok_gemm_bf16(_ptr(a2), _ptr(w), _ptr(out), None, None, M, N, K, K, K, out.stride(0), 0, 1, 1,
                            0, 0, 0, 0, 0, 0, 0, 0, 1.0, GEMM_SWIGLU, _stream())
     _lib.check(st, "u2tok_gemm_bf16 (swiglu pair)")
@@ -264,13 +291,13 @@ def gemm_kmajor(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool, alpha=1.0, 
          a_kmajor = True:   C (M, N) = A (K, M)^T @ B (K, N)        -- dW = dY^T X
     Dense 2-D bf16 operands; the K-major dimensions (N, and M when a_kmajor) must be multiples of 8."""
     h = _lib.load_library()
-    a = _need(a, torch.bfloat16, "A").contiguous()
-    b = _need(b, torch.bfloat16, "B").contiguous()
+    a = _need(a, ELEM, "A").contiguous()
+    b = _need(b, ELEM, "B").contiguous()
     K, N = b.shape
     M = a.shape[1] if a_kmajor else a.shape[0]
     if (a.shape[0] if a_kmajor else a.shape[1]) != K:
         raise RuntimeError(f"gemm_kmajor: contraction sizes differ ({tuple(a.shape)}, {tuple(b.shape)}, a_kmajor={a_kmajor})")
-    out = torch.empty((M, N), dtype=torch.float32 if out_f32 else torch.bfloat16, device=a.device)
+    out = torch.empty((M, N), dtype=torch.float32 if out_f32 else elem_dtype(), device=a.device)
     flags = GEMM_B_KMAJOR | (GEMM_A_KMAJOR if a_kmajor else 0) | (GEMM_OUT_F32 if out_f32 else 0)
     st = h.u2tok_gemm_bf16(_ptr(a), _ptr(b), _ptr(out), None, None, M, N, K, a.shape[1], N, N, N, 1, 1,
                            0, 0, 0, 0, 0, 0, 0, 0, float(alpha), flags, _stream())
@@ -293,7 +320,7 @@ def set_gemm_scratch(buf: Optional[torch.Tensor]) -> None:
 @_guarded
 def layernorm(x, w, b, residual=None, eps=1e-5):
     h = _lib.load_library()
-    x = _need(x, torch.bfloat16, "x").contiguous()
+    x = _need(x, ELEM, "x").contiguous()
     y = torch.empty_like(x)
     rows = x.numel() // x.shape[-1]
     if residual is not None:
@@ -303,14 +330,14 @@ def layernorm(x, w, b, residual=None, eps=1e-5):
     return y
 
 
-@_guarded
+@_guarded(infer=False)
 def softmax_rows(s: torch.Tensor, scale=1.0, rel_bias=None, heads=1, max_len=0, ldp=None):
-    """s: (Z, R, n) fp32 -> (Z, R, ldp) bf16 (columns >= n are zero)."""
+    """s: (Z, R, n) fp32 -> (Z, R, ldp) elements (bf16, or `elem=torch.float16`; columns >= n are zero); rel_bias in that type."""
     h = _lib.load_library()
     s = _need(s, torch.float32, "S").contiguous()
     Z, R, n = s.shape
     ldp = ldp or (n + 7) // 8 * 8
-    p = torch.empty((Z, R, ldp), dtype=torch.bfloat16, device=s.device)
+    p = torch.empty((Z, R, ldp), dtype=elem_dtype(), device=s.device)
     _lib.check(h.u2tok_softmax_rows(_ptr(s), _ptr(p), Z, R, n, n, ldp, float(scale), _ptr(rel_bias), heads, max_len,
                                     _stream()), "u2tok_softmax_rows")
     return p
@@ -320,24 +347,25 @@ def softmax_rows(s: torch.Tensor, scale=1.0, rel_bias=None, heads=1, max_len=0, 
 def transpose(x: torch.Tensor, ld_out=None, perm16=False):
     """x: (Z, R, C) bf16 -> (Z, C, ld_out) with zero padding."""
     h = _lib.load_library()
-    x = _need(x, torch.bfloat16, "x").contiguous()
+    x = _need(x, ELEM, "x").contiguous()
     Z, R, Cc = x.shape
     ld_out = ld_out or R
-    y = torch.empty((Z, Cc, ld_out), dtype=torch.bfloat16, device=x.device)
+    y = torch.empty((Z, Cc, ld_out), dtype=elem_dtype(), device=x.device)
     _lib.check(h.u2tok_transpose_bf16(_ptr(x), _ptr(y), Z, R, Cc, Cc, ld_out, R * Cc, Cc * ld_out, int(perm16),
                                       _stream()), "u2tok_transpose_bf16")
     return y
 
 
-@_guarded
+@_guarded(infer=False)
 def im2col(vol: torch.Tensor, patch):
+    """voxels (fp16 / bf16 / fp32) -> patch rows in the element type (bf16, or `elem=torch.float16`)."""
     h = _lib.load_library()
     vol = vol.contiguous()
     nchunk = vol.shape[0]
     D, H, W = vol.shape[-3:]
     p1, p2, p3 = patch
     ntok = (D // p1) * (H // p2) * (W // p3)
-    out = torch.empty((nchunk, ntok, p1 * p2 * p3), dtype=torch.bfloat16, device=vol.device)
+    out = torch.empty((nchunk, ntok, p1 * p2 * p3), dtype=elem_dtype(), device=vol.device)
     _lib.check(h.u2tok_im2col_patches(_ptr(vol), vol_dtype_code(vol.dtype), _ptr(out), nchunk, D, H, W, p1, p2, p3,
                                       _stream()), "u2tok_im2col_patches")
     return out
@@ -346,11 +374,11 @@ def im2col(vol: torch.Tensor, patch):
 @_guarded
 def avgpool3d_tokens(x: torch.Tensor, grid, window):
     h = _lib.load_library()
-    x = _need(x, torch.bfloat16, "x").contiguous()
+    x = _need(x, ELEM, "x").contiguous()
     nb, _, Cc = x.shape
     g1, g2, g3 = grid
     w1, w2, w3 = window
-    y = torch.empty((nb, (g1 // w1) * (g2 // w2) * (g3 // w3), Cc), dtype=torch.bfloat16, device=x.device)
+    y = torch.empty((nb, (g1 // w1) * (g2 // w2) * (g3 // w3), Cc), dtype=elem_dtype(), device=x.device)
     _lib.check(h.u2tok_avgpool3d_tokens(_ptr(x), _ptr(y), nb, g1, g2, g3, w1, w2, w3, Cc, _stream()),
                "u2tok_avgpool3d_tokens")
     return y
@@ -360,7 +388,7 @@ def avgpool3d_tokens(x: torch.Tensor, grid, window):
 def embed_splice(table: torch.Tensor, ids: torch.Tensor, feats: Optional[torch.Tensor] = None):
     """embed_tokens(ids) with feats (B, nfeat, E) spliced over positions 1..nfeat (u2_arch.py:109,113-116)."""
     h = _lib.load_library()
-    table = _need(table, torch.bfloat16, "embed_tokens.weight")
+    table = _need(table, ELEM, "embed_tokens.weight")
     if not table.is_contiguous():
         raise RuntimeError("embed_tokens.weight must be contiguous")
     ids = _need(ids, torch.int64, "ids").contiguous()
@@ -368,9 +396,9 @@ def embed_splice(table: torch.Tensor, ids: torch.Tensor, feats: Optional[torch.T
     E = table.shape[1]
     nfeat = 0
     if feats is not None:
-        feats = _need(feats, torch.bfloat16, "feats").contiguous()
+        feats = _need(feats, ELEM, "feats").contiguous()
         nfeat = feats.shape[1]
-    out = torch.empty((B, S, E), dtype=torch.bfloat16, device=table.device)
+    out = torch.empty((B, S, E), dtype=elem_dtype(), device=table.device)
     _lib.check(h.u2tok_embed_splice(_ptr(table), _ptr(ids), _ptr(feats), _ptr(out), B, S, E, nfeat, table.shape[0],
                                     _stream()), "u2tok_embed_splice")
     return out
@@ -379,7 +407,7 @@ def embed_splice(table: torch.Tensor, ids: torch.Tensor, feats: Optional[torch.T
 @_guarded
 def score_gemv(x, w, bias):
     h = _lib.load_library()
-    x = _need(x, torch.bfloat16, "x").contiguous()
+    x = _need(x, ELEM, "x").contiguous()
     rows = x.numel() // x.shape[-1]
     s = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
     _lib.check(h.u2tok_score_gemv(_ptr(x), _ptr(w), _ptr(bias), _ptr(s), rows, x.shape[-1], _stream()),
@@ -400,10 +428,10 @@ def topk_sorted(scores: torch.Tensor, k: int):
 @_guarded
 def gather_rows(x, idx):
     h = _lib.load_library()
-    x = _need(x, torch.bfloat16, "x").contiguous()
+    x = _need(x, ELEM, "x").contiguous()
     B, n, E = x.shape
     k = idx.shape[1]
-    out = torch.empty((B, k, E), dtype=torch.bfloat16, device=x.device)
+    out = torch.empty((B, k, E), dtype=elem_dtype(), device=x.device)
     _lib.check(h.u2tok_gather_rows(_ptr(x), _ptr(idx.contiguous()), _ptr(out), B, n, k, E, _stream()),
                "u2tok_gather_rows")
     return out
@@ -412,9 +440,9 @@ def gather_rows(x, idx):
 @_guarded
 def multiscale_pool(x, gate_w=None, gate_b=None):
     h = _lib.load_library()
-    x = _need(x, torch.bfloat16, "x").contiguous()
+    x = _need(x, ELEM, "x").contiguous()
     B, k, E = x.shape
-    out = torch.empty((B, k + k // 2 + k // 4, E), dtype=torch.bfloat16, device=x.device)
+    out = torch.empty((B, k + k // 2 + k // 4, E), dtype=elem_dtype(), device=x.device)
     ws = torch.empty((B * 3 * 16 * ((E + 255) // 256),), dtype=torch.float32, device=x.device)
     _lib.check(h.u2tok_multiscale_pool(_ptr(x), _ptr(out), B, k, E, _ptr(gate_w), _ptr(gate_b), _ptr(ws), _stream()),
                "u2tok_multiscale_pool")
@@ -426,7 +454,7 @@ def temporal_attention(q, k, v, B, T, N, H, scale, rel_bias=None, max_len=512):
     """q/k/v: (B*T*N, E) rows in (b t n) order."""
     h = _lib.load_library()
     E = q.shape[-1]
-    out = torch.empty((B * T * N, E), dtype=torch.bfloat16, device=q.device)
+    out = torch.empty((B * T * N, E), dtype=elem_dtype(), device=q.device)
     _lib.check(h.u2tok_temporal_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, T, N, H, E // H, q.stride(0),
                                           E, float(scale), _ptr(rel_bias), max_len, _stream()),
                "u2tok_temporal_attention")
@@ -439,18 +467,18 @@ def flash_attention_d64(qkv: torch.Tensor, heads: int, scale: float, extra_last:
     every batch through the kernel's "extra row" path (how the ViT tower feeds its cls token); same result.
     return_lse: also the row statistics (nb * heads, S rounded up to 64) fp32 that flash_attention_d64_bwd takes."""
     h = _lib.load_library()
-    qkv = _need(qkv, torch.bfloat16, "qkv").contiguous()
+    qkv = _need(qkv, ELEM, "qkv").contiguous()
     nb, S, three = qkv.shape
     Hd = three // 3
     Sm = S - 1 if extra_last else S
     if Sm < 1:
         raise RuntimeError("flash_attention_d64: at least one main row is required")
     S_pad = (Sm + 63) // 64 * 64
-    vt = torch.empty((nb, Hd, S_pad), dtype=torch.bfloat16, device=qkv.device)
+    vt = torch.empty((nb, Hd, S_pad), dtype=elem_dtype(), device=qkv.device)
     v_view = qkv[:, :, 2 * Hd:]
     _lib.check(h.u2tok_transpose_bf16(v_view.data_ptr(), _ptr(vt), nb, Sm, Hd, 3 * Hd, S_pad, S * 3 * Hd, Hd * S_pad,
                                       1, _stream()), "u2tok_transpose_bf16")
-    out = torch.empty((nb, S, Hd), dtype=torch.bfloat16, device=qkv.device)
+    out = torch.empty((nb, S, Hd), dtype=elem_dtype(), device=qkv.device)
     es = qkv.element_size()
     x0 = qkv.data_ptr() + (S - 1) * 3 * Hd * es
     args = (qkv.data_ptr(), qkv.data_ptr() + Hd * es, _ptr(vt), _ptr(out), nb, Sm, heads, 3 * Hd, S * 3 * Hd, Hd, S * Hd,
@@ -473,9 +501,9 @@ def flash_attention_d64_bwd(qkv: torch.Tensor, out: torch.Tensor, d_out: torch.T
     bf16 -> d_qkv like qkv (u2tok_flash_attention_d64_bwd: two flash-style kernels, no (S x S) tensor in HBM).  lse: the
     forward's row statistics (flash_attention_d64(..., return_lse=True)); without them the backward rebuilds them."""
     h = _lib.load_library()
-    qkv = _need(qkv, torch.bfloat16, "qkv").contiguous()
-    out = _need(out, torch.bfloat16, "out").contiguous()
-    d_out = _need(d_out, torch.bfloat16, "d_out").contiguous()
+    qkv = _need(qkv, ELEM, "qkv").contiguous()
+    out = _need(out, ELEM, "out").contiguous()
+    d_out = _need(d_out, ELEM, "d_out").contiguous()
     nb, S, three = qkv.shape
     Hd = three // 3
     if Hd != heads * 64 or out.shape != (nb, S, Hd) or d_out.shape != out.shape:
@@ -505,7 +533,7 @@ def tok_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
     buffer) -> softmax(q k^T scale + rel_bias[j - i + max_len - 1][h]) v as (nb, Sq, E).  splits: 0 = heuristic key split."""
     h = _lib.load_library()
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
-        _need(t, torch.bfloat16, n)
+        _need(t, ELEM, n)
         if t.dim() != 3 or t.stride(2) != 1:
             raise RuntimeError(f"tok_attention: {n} must be (nb, S, E) with a contiguous last dim")
     nb, Sq, E = q.shape
@@ -513,7 +541,7 @@ def tok_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
     if k.shape != (nb, Skv, E) or v.shape != (nb, Skv, E) or E % heads:
         raise RuntimeError(f"tok_attention: shapes {tuple(q.shape)}, {tuple(k.shape)}, {tuple(v.shape)}, heads {heads}")
     d = E // heads
-    out = torch.empty((nb, Sq, E), dtype=torch.bfloat16, device=q.device)
+    out = torch.empty((nb, Sq, E), dtype=elem_dtype(), device=q.device)
     nbytes = h.u2tok_tok_attention_workspace_bytes(nb, heads, Sq, Skv, d)
     if splits > 1:
         nbytes = max(nbytes, splits * nb * Sq * (E * 4 + heads * 8))
@@ -535,7 +563,7 @@ def attention_gqa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
     query rows over a long KV cache (decode steps)."""
     h = _lib.load_library()
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
-        _need(t, torch.bfloat16, n)
+        _need(t, ELEM, n)
         if t.dim() != 3 or t.stride(2) != 1:
             raise RuntimeError(f"attention_gqa: {n} must be (nb, S, H * d) with a contiguous last dim")
     nb, Sq, Eq = q.shape
@@ -543,7 +571,7 @@ def attention_gqa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
     d = Eq // heads
     if Eq % heads or k.shape != (nb, Skv, kv_heads * d) or v.shape != k.shape or heads % kv_heads:
         raise RuntimeError(f"attention_gqa: shapes {tuple(q.shape)}, {tuple(k.shape)}, {tuple(v.shape)}, heads {heads}/{kv_heads}")
-    out = torch.empty((nb, Sq, Eq), dtype=torch.bfloat16, device=q.device)
+    out = torch.empty((nb, Sq, Eq), dtype=elem_dtype(), device=q.device)
     if split_keys and not causal:
         nbytes = h.u2tok_tok_attention_workspace_bytes(nb, heads, Sq, Skv, d)
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=q.device)
@@ -562,11 +590,11 @@ def attention_gqa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
 def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
     """LlamaRMSNorm / Qwen3RMSNorm over the last dim of x (rows, C) bf16."""
     h = _lib.load_library()
-    x = _need(x, torch.bfloat16, "x")
+    x = _need(x, ELEM, "x")
     if x.dim() != 2 or x.stride(1) != 1:
         raise RuntimeError("rmsnorm: x must be (rows, C) with a contiguous last dim")
-    y = torch.empty((x.shape[0], x.shape[1]), dtype=torch.bfloat16, device=x.device)
-    _lib.check(h.u2tok_rmsnorm_bf16(_ptr(x), _ptr(_need(w, torch.bfloat16, "w")), _ptr(y), x.shape[0], x.shape[1], x.stride(0),
+    y = torch.empty((x.shape[0], x.shape[1]), dtype=elem_dtype(), device=x.device)
+    _lib.check(h.u2tok_rmsnorm_bf16(_ptr(x), _ptr(_need(w, ELEM, "w")), _ptr(y), x.shape[0], x.shape[1], x.stride(0),
                                     x.shape[1], float(eps), _stream()), "u2tok_rmsnorm_bf16")
     return y
 
@@ -581,11 +609,11 @@ def qk_norm_rope(qkv: torch.Tensor, q_norm_w, k_norm_w, cos: torch.Tensor, sin: 
     kv_out = (k_buf, v_buf): write them instead at positions kv_pos .. kv_pos + S - 1 of (batch, kv_heads, capacity, head_dim)
     buffers (an append-in-place cache)."""
     h = _lib.load_library()
-    _need(qkv, torch.bfloat16, "qkv")
+    _need(qkv, ELEM, "qkv")
     rows = qkv.shape[0]
     if qkv.dim() != 2 or qkv.stride(1) != 1 or qkv.shape[1] != (heads + 2 * kv_heads) * head_dim:
         raise RuntimeError("qk_norm_rope: qkv must be (rows, (heads + 2 kv_heads) * head_dim)")
-    if cos.dtype != sin.dtype or cos.dtype not in (torch.float32, torch.bfloat16) or cos.shape != (rows, head_dim) \
+    if cos.dtype != sin.dtype or cos.dtype not in (torch.float32, elem_dtype()) or cos.shape != (rows, head_dim) \
             or sin.shape != cos.shape or cos.stride(1) != 1 or sin.stride(1) != 1 or cos.stride(0) != sin.stride(0):
         raise RuntimeError("qk_norm_rope: cos / sin must be (rows, head_dim) fp32 or bf16 with equal strides")
     if kv_cache_seq:
@@ -596,7 +624,7 @@ def qk_norm_rope(qkv: torch.Tensor, q_norm_w, k_norm_w, cos: torch.Tensor, sin: 
         if kv_out is not None:
             kc, vc = kv_out
             for t in (kc, vc):
-                _need(t, torch.bfloat16, "kv_out")
+                _need(t, ELEM, "kv_out")
                 if t.dim() != 4 or t.shape[0] != rows // S or t.shape[1] != kv_heads or t.shape[3] != head_dim or t.stride(3) != 1 \
                         or t.stride(2) != head_dim or t.stride(0) != kv_heads * t.stride(1) or kv_pos + S > t.shape[2]:
                     raise RuntimeError("qk_norm_rope: kv_out must be (batch, kv_heads, capacity, head_dim) buffers with room")
@@ -604,7 +632,7 @@ def qk_norm_rope(qkv: torch.Tensor, q_norm_w, k_norm_w, cos: torch.Tensor, sin: 
                 raise RuntimeError("qk_norm_rope: the two kv_out buffers must have the same capacity")
             kvs, pos = kc.stride(1), int(kv_pos)
         else:
-            kc = torch.empty((rows // S, kv_heads, S, head_dim), dtype=torch.bfloat16, device=qkv.device)
+            kc = torch.empty((rows // S, kv_heads, S, head_dim), dtype=elem_dtype(), device=qkv.device)
             vc = torch.empty_like(kc)
         _lib.check(h.u2tok_qk_norm_rope_kv(_ptr(qkv), _ptr(q_norm_w), _ptr(k_norm_w), _ptr(cos), _ptr(sin),
                                            int(cos.dtype == torch.float32), rows, heads, kv_heads, head_dim, qkv.stride(0),
@@ -621,9 +649,9 @@ def qk_norm_rope(qkv: torch.Tensor, q_norm_w, k_norm_w, cos: torch.Tensor, sin: 
 def swiglu(gate_up: torch.Tensor) -> torch.Tensor:
     """(rows, 2 I) packed gate | up -> silu(gate) * up (rows, I)  (u2tok_swiglu_bf16)."""
     h = _lib.load_library()
-    _need(gate_up, torch.bfloat16, "gate_up")
+    _need(gate_up, ELEM, "gate_up")
     rows, two_i = gate_up.shape
-    out = torch.empty((rows, two_i // 2), dtype=torch.bfloat16, device=gate_up.device)
+    out = torch.empty((rows, two_i // 2), dtype=elem_dtype(), device=gate_up.device)
     _lib.check(h.u2tok_swiglu_bf16(_ptr(gate_up), _ptr(out), rows, two_i // 2, gate_up.stride(0), two_i // 2, _stream()),
                "u2tok_swiglu_bf16")
     return out
@@ -646,7 +674,7 @@ def gemm_strided(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, M, N, K
     a / b / out are the STORAGES (any shape); *_off are element offsets into them.  b_kmajor: B[z] is stored (K, N) with
     row stride ldb; a_kmajor (with b_kmajor): A[z] is stored (K, M) with row stride lda."""
     h = _lib.load_library()
-    _need(a, torch.bfloat16, "A"), _need(b, torch.bfloat16, "B")
+    _need(a, ELEM, "A"), _need(b, ELEM, "B")
     flags = (GEMM_OUT_F32 if out_f32 else 0) | (GEMM_A_KMAJOR if a_kmajor else 0) | (GEMM_B_KMAJOR if b_kmajor else 0)
     if bias is not None:
         flags |= GEMM_BIAS_M if bias_m else GEMM_BIAS_N
@@ -664,7 +692,7 @@ def transpose_ex(x: torch.Tensor, nz: int, R: int, Cc: int, ld_in: int, in_zs: i
     (nz, Cc, ld_out) with ld_out = R rounded up to 8, padding zeroed."""
     h = _lib.load_library()
     ld_out = ld_out or (R + 7) // 8 * 8
-    y = torch.empty((nz, Cc, ld_out), dtype=torch.bfloat16, device=x.device)
+    y = torch.empty((nz, Cc, ld_out), dtype=elem_dtype(), device=x.device)
     _lib.check(h.u2tok_transpose_bf16(x.data_ptr() + 2 * x_off, _ptr(y), nz, R, Cc, ld_in, ld_out, in_zs, Cc * ld_out, 0,
                                       _stream()), "u2tok_transpose_bf16")
     return y
@@ -673,7 +701,7 @@ def transpose_ex(x: torch.Tensor, nz: int, R: int, Cc: int, ld_in: int, in_zs: i
 @_guarded
 def gelu_fwd(z: torch.Tensor) -> torch.Tensor:
     h = _lib.load_library()
-    z = _need(z, torch.bfloat16, "z").contiguous()
+    z = _need(z, ELEM, "z").contiguous()
     y = torch.empty_like(z)
     _lib.check(h.u2tok_gelu_fwd(_ptr(z), _ptr(y), z.numel(), _stream()), "u2tok_gelu_fwd")
     return y
@@ -682,20 +710,20 @@ def gelu_fwd(z: torch.Tensor) -> torch.Tensor:
 @_guarded
 def gelu_bwd(z: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     h = _lib.load_library()
-    z, dy = _need(z, torch.bfloat16, "z").contiguous(), _need(dy, torch.bfloat16, "dy").contiguous()
+    z, dy = _need(z, ELEM, "z").contiguous(), _need(dy, ELEM, "dy").contiguous()
     dz = torch.empty_like(z)
     _lib.check(h.u2tok_gelu_bwd(_ptr(z), _ptr(dy), _ptr(dz), z.numel(), _stream()), "u2tok_gelu_bwd")
     return dz
 
 
 @_guarded
-def colsum(x: torch.Tensor, y: Optional[torch.Tensor] = None, out_dtype=torch.bfloat16) -> torch.Tensor:
+def colsum(x: torch.Tensor, y: Optional[torch.Tensor] = None, out_dtype=elem_dtype()) -> torch.Tensor:
     """sum over rows of x (* y): x (rows, C) bf16 -> (C,) in out_dtype (bf16 or fp32); fp32 accumulation, fixed order."""
     h = _lib.load_library()
-    x = _need(x, torch.bfloat16, "x").contiguous()
+    x = _need(x, ELEM, "x").contiguous()
     rows, Cc = x.shape
     if y is not None:
-        y = _need(y, torch.bfloat16, "y").contiguous()
+        y = _need(y, ELEM, "y").contiguous()
     ws = torch.empty(h.u2tok_colsum_workspace_bytes(rows, Cc), dtype=torch.uint8, device=x.device)
     out = torch.empty(Cc, dtype=out_dtype, device=x.device)
     f32 = out_dtype == torch.float32
@@ -708,7 +736,7 @@ def colsum(x: torch.Tensor, y: Optional[torch.Tensor] = None, out_dtype=torch.bf
 def layernorm_bwd(x: torch.Tensor, residual: Optional[torch.Tensor], w: torch.Tensor, dy: torch.Tensor, eps=1e-5):
     """-> (dv bf16 like x, dw fp32 (C,), db fp32 (C,)) for y = LN(x (+ residual)) * w + b."""
     h = _lib.load_library()
-    x, dy = _need(x, torch.bfloat16, "x").contiguous(), _need(dy, torch.bfloat16, "dy").contiguous()
+    x, dy = _need(x, ELEM, "x").contiguous(), _need(dy, ELEM, "dy").contiguous()
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     if residual is not None:
@@ -726,7 +754,7 @@ def layernorm_bwd(x: torch.Tensor, residual: Optional[torch.Tensor], w: torch.Te
 def softmax_bwd(p: torch.Tensor, dp: torch.Tensor, n: int) -> torch.Tensor:
     """p: (..., ldp) bf16 probabilities (pad columns >= n), dp: (..., lddp) fp32 -> dS (..., ldp) bf16."""
     h = _lib.load_library()
-    p, dp = _need(p, torch.bfloat16, "P").contiguous(), _need(dp, torch.float32, "dP").contiguous()
+    p, dp = _need(p, ELEM, "P").contiguous(), _need(dp, torch.float32, "dP").contiguous()
     ldp, lddp = p.shape[-1], dp.shape[-1]
     ds = torch.empty_like(p)
     _lib.check(h.u2tok_softmax_bwd(_ptr(p), _ptr(dp), _ptr(ds), p.numel() // ldp, n, ldp, lddp, _stream()),
@@ -738,7 +766,7 @@ def softmax_bwd(p: torch.Tensor, dp: torch.Tensor, n: int) -> torch.Tensor:
 def relbias_grad(ds: torch.Tensor, dtable: torch.Tensor, S: int, H: int, max_len: int) -> None:
     """ds: (nz, S, ldp) bf16; dtable: (2 * max_len - 1, H) fp32, accumulated into."""
     h = _lib.load_library()
-    ds = _need(ds, torch.bfloat16, "dS").contiguous()
+    ds = _need(ds, ELEM, "dS").contiguous()
     _need(dtable, torch.float32, "dtable")
     nz = ds.numel() // (S * ds.shape[-1])
     _lib.check(h.u2tok_relbias_grad(_ptr(ds), _ptr(dtable), nz, S, H, ds.shape[-1], max_len, _stream()),
@@ -793,8 +821,8 @@ def weight_table(tensors) -> "C.Array":
         if t is None:
             arr[i] = None
             continue
-        if not t.is_cuda or t.dtype != torch.bfloat16 or not t.is_contiguous():
-            raise RuntimeError("u2tok HIP path needs contiguous bf16 parameters on the GPU "
-                               f"(got {t.dtype} on {t.device}); call model.to(torch.bfloat16).cuda()")
+        if not t.is_cuda or t.dtype != elem_dtype() or not t.is_contiguous():
+            raise RuntimeError(f"u2tok HIP path needs contiguous {elem_dtype()} parameters on the GPU, all of one 16-bit type "
+                               f"(got {t.dtype} on {t.device}); call model.to(torch.bfloat16).cuda() or model.half().cuda()")
         arr[i] = t.data_ptr()
     return arr

@@ -10,7 +10,7 @@ import torch.nn as nn
 from . import _lib, ops
 
 
-class SpatialPoolingProjector(ops.Fp16Twin, nn.Module):
+class SpatialPoolingProjector(nn.Module):
     def __init__(self, image_size, patch_size, in_dim, out_dim, layer_type, layer_num, pooling_type="spatial",
                  pooling_size=2):
         super().__init__()
@@ -42,16 +42,19 @@ class SpatialPoolingProjector(ops.Fp16Twin, nn.Module):
         self._ws = ops._Workspace()
 
     def forward(self, x):
-        twin = self._fp16_twin()
-        if twin is not None:
-            return twin(self._to_bf16(x)).to(torch.float16)
+        pd = next(self.parameters()).dtype   # bf16, or fp16 for a model loaded in float16 (the f16 build of the library)
+        with ops.on_device(x, elem=pd):
+            return self._forward(x, pd)
+
+    def _forward(self, x, pd):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             from . import autograd as AG  # training: the same kernels behind torch.autograd.Function
+            ops.training_needs_bf16(pd, "SpatialPoolingProjector")
             ops._need(x, torch.bfloat16, "image_features")
             with ops.on_device(x):
                 return AG.spp_forward(self, x)
         h = _lib.load_library()
-        x = ops._need(x, torch.bfloat16, "image_features").contiguous()
+        x = ops._need(x, ops.ELEM, "image_features").contiguous()
         nchunk, n, dim = x.shape
         g = self.num_patches_pre
         if dim != self.in_dim or n != g[0] * g[1] * g[2]:
@@ -68,7 +71,7 @@ class SpatialPoolingProjector(ops.Fp16Twin, nn.Module):
         n_out = self.proj_out_num if self.pooling_type == "spatial" else n // self.pooling_size ** 3
         with ops.on_device(x) as (h, stream):
             ws = self._ws.get(nbytes, x.device)
-            out = torch.empty((nchunk, n_out, self.out_dim), dtype=torch.bfloat16, device=x.device)
+            out = torch.empty((nchunk, n_out, self.out_dim), dtype=pd, device=x.device)
             _lib.check(h.u2tok_spp_forward(C.byref(cfg), table, x.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
                                            stream), "u2tok_spp_forward")
         return out

@@ -216,7 +216,7 @@ def _unshare_packed(module, state_dict, prefix, local_metadata):
     return state_dict
 
 
-class u2Tokenizer(ops.Fp16Twin, nn.Module):
+class u2Tokenizer(nn.Module):
     """Same constructor and forward as the reference (u2Tokenizer.py:6-47)."""
 
     def __init__(self, embed_size, num_heads, num_layers, top_k, use_multi_scale, num_3d_query_token, hidden_size,
@@ -329,10 +329,14 @@ class u2Tokenizer(ops.Fp16Twin, nn.Module):
         ("teacher forcing": svr_in / tta_in are lists of num_layers tensors or None entries, visual_in replaces the tokens
         the aggregation stage attends to) and every layer's output copied out.  Returns (out, taps) with taps =
         {"svr_out": [...], "visual_out": tensor, "tta_out": [...]}."""
+        with ops.on_device(v_token, elem=self.query_tokens.dtype):
+            return self._forward_with_taps(v_token, t_token, svr_in, visual_in, tta_in)
+
+    def _forward_with_taps(self, v_token, t_token, svr_in, visual_in, tta_in):
         h = _lib.load_library()
         self.pack_weights()
-        v_token = ops._need(v_token, torch.bfloat16, "v_token").contiguous()
-        t_token = ops._need(t_token, torch.bfloat16, "t_token").contiguous()
+        v_token = ops._need(v_token, ops.ELEM, "v_token").contiguous()
+        t_token = ops._need(t_token, ops.ELEM, "t_token").contiguous()
         (B, T, N, E) = v_token.size()
         self._check_envelope(B, T, N, E, t_token.shape[1])
         L, Q, dev = self.num_layers, self.num_query, v_token.device
@@ -347,24 +351,24 @@ class u2Tokenizer(ops.Fp16Twin, nn.Module):
             for i in range(L):
                 t = tensors[i] if tensors is not None and i < len(tensors) else None
                 if t is not None:
-                    t = ops._need(t, torch.bfloat16, "tap").contiguous()
+                    t = ops._need(t, ops.ELEM, "tap").contiguous()
                     assert tuple(t.shape) == shape, (tuple(t.shape), shape)
                     keep.append(t)
                     arr[i] = t.data_ptr()
             return arr
 
-        svr_out = [torch.empty((B, T, N, E), dtype=torch.bfloat16, device=dev) for _ in range(L)]
-        tta_out = [torch.empty((B, Q, E), dtype=torch.bfloat16, device=dev) for _ in range(L)]
-        visual_out = torch.empty((B, Lv, E), dtype=torch.bfloat16, device=dev)
+        svr_out = [torch.empty((B, T, N, E), dtype=ops.elem_dtype(), device=dev) for _ in range(L)]
+        tta_out = [torch.empty((B, Q, E), dtype=ops.elem_dtype(), device=dev) for _ in range(L)]
+        visual_out = torch.empty((B, Lv, E), dtype=ops.elem_dtype(), device=dev)
         if visual_in is not None:
-            visual_in = ops._need(visual_in, torch.bfloat16, "visual_in").contiguous()
+            visual_in = ops._need(visual_in, ops.ELEM, "visual_in").contiguous()
             assert tuple(visual_in.shape) == (B, Lv, E)
         taps = _lib.TokTaps(svr_in=ptr_array(svr_in, (B, T, N, E)), svr_out=ptr_array(svr_out, (B, T, N, E)),
                             visual_in=None if visual_in is None else visual_in.data_ptr(), visual_out=visual_out.data_ptr(),
                             tta_in=ptr_array(tta_in, (B, Q, E)), tta_out=ptr_array(tta_out, (B, Q, E)))
         with ops.on_device(v_token) as (h, stream):
             ws = self._ws.get(nbytes, dev)
-            out = torch.empty((B, Q, E), dtype=torch.bfloat16, device=dev)
+            out = torch.empty((B, Q, E), dtype=ops.elem_dtype(), device=dev)
             idx = None if self.enable_diffts else torch.empty((B, self.top_k), dtype=torch.int64, device=dev)
             _lib.check(h.u2tok_tokenizer_forward_taps(C.byref(cfg), table, v_token.data_ptr(), t_token.data_ptr(),
                                                       out.data_ptr(), None if idx is None else idx.data_ptr(),
@@ -382,16 +386,17 @@ class u2Tokenizer(ops.Fp16Twin, nn.Module):
                               ln_eps=1e-5)
 
     def forward(self, v_token, t_token):
-        twin = self._fp16_twin()
-        if twin is not None:
-            out = twin(self._to_bf16(v_token), self._to_bf16(t_token)).to(torch.float16)
-            self.last_topk_indices = getattr(twin, "last_topk_indices", None)
-            return out
+        # parameters in bf16, or in fp16 for a model loaded in float16 (evalscipt/ourmodel_amos.py:33): the f16 build of the library
+        with ops.on_device(v_token, elem=self.query_tokens.dtype):
+            return self._forward(v_token, t_token)
+
+    def _forward(self, v_token, t_token):
         if torch.is_grad_enabled() and (v_token.requires_grad or t_token.requires_grad
                                         or any(p.requires_grad for p in self.parameters())):
             # training: the same kernels sequenced op by op behind torch.autograd.Function (autograd.py)
             from . import autograd as AG
-            ops._need(v_token, torch.bfloat16, "v_token"), ops._need(t_token, torch.bfloat16, "t_token")
+            ops.training_needs_bf16(self.query_tokens.dtype, "u2Tokenizer")
+            ops._need(v_token, ops.ELEM, "v_token"), ops._need(t_token, ops.ELEM, "t_token")
             (B, T, N, E) = v_token.size()
             self._check_envelope(B, T, N, E, t_token.shape[1])
             with ops.on_device(v_token):
@@ -399,8 +404,8 @@ class u2Tokenizer(ops.Fp16Twin, nn.Module):
         h = _lib.load_library()
         if self.query_tokens.is_cuda:
             self.pack_weights()
-        v_token = ops._need(v_token, torch.bfloat16, "v_token").contiguous()
-        t_token = ops._need(t_token, torch.bfloat16, "t_token").contiguous()
+        v_token = ops._need(v_token, ops.ELEM, "v_token").contiguous()
+        t_token = ops._need(t_token, ops.ELEM, "t_token").contiguous()
         (B, T, N, E) = v_token.size()
         if E != self.embed_size or t_token.shape[0] != B or t_token.shape[2] != E:
             raise RuntimeError(f"shape mismatch: v_token {tuple(v_token.shape)}, t_token {tuple(t_token.shape)}")
@@ -414,11 +419,11 @@ class u2Tokenizer(ops.Fp16Twin, nn.Module):
         idx = svr = None
         with ops.on_device(v_token) as (h, stream):
             ws = self._ws.get(nbytes, v_token.device)
-            out = torch.empty((B, self.num_query, E), dtype=torch.bfloat16, device=v_token.device)
+            out = torch.empty((B, self.num_query, E), dtype=ops.elem_dtype(), device=v_token.device)
             if not self.enable_diffts:
                 idx = torch.empty((B, self.top_k), dtype=torch.int64, device=v_token.device)
             if self.capture_svr_tokens:
-                svr = torch.empty((B, T * N, E), dtype=torch.bfloat16, device=v_token.device)
+                svr = torch.empty((B, T * N, E), dtype=ops.elem_dtype(), device=v_token.device)
             _lib.check(h.u2tok_tokenizer_forward(C.byref(cfg), table, v_token.data_ptr(), t_token.data_ptr(),
                                                  out.data_ptr(), None if idx is None else idx.data_ptr(),
                                                  None if svr is None else svr.data_ptr(), ws.data_ptr(), ws.numel(),

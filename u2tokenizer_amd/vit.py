@@ -131,14 +131,23 @@ class ViT(nn.Module):
         return w
 
     def forward_features(self, x: torch.Tensor, keep_cls: bool) -> torch.Tensor:
-        """x: (nchunk, 1, D, H, W) fp16/bf16/fp32 on the GPU -> (nchunk, ntok[+1], hidden) bf16."""
+        """x: (nchunk, 1, D, H, W) fp16/bf16/fp32 on the GPU -> (nchunk, ntok[+1], hidden) in the parameters' 16-bit type
+        (bf16, or fp16 for a model loaded in float16 -- evalscipt/ourmodel_amos.py:33: the f16 build of the library)."""
+        pd = self.norm.weight.dtype
+        if not x.is_cuda:
+            raise RuntimeError("images: expected a GPU tensor (the u2tok HIP path has no CPU fallback)")
+        with ops.on_device(x, elem=pd):
+            return self._forward_features(x, keep_cls, pd)
+
+    def _forward_features(self, x, keep_cls, pd):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            ops.training_needs_bf16(pd, "ViT")
             # training (train_stage1.py:42 runs with freeze_vision_tower False): autograd path, same kernels (autograd.py)
             from . import autograd as AG
             if x.dim() != 5 or x.shape[1] != 1 or list(x.shape[2:]) != self.img_size or not x.is_cuda:
                 raise RuntimeError(f"expected GPU images of shape (N,1,{self.img_size}), got {tuple(x.shape)} on {x.device}")
             self._weights()  # (raises for the variant without a cls token)
-            with ops.on_device(x):
+            with ops.on_device(x, elem=pd):
                 return AG.vit_forward(self, x, keep_cls)
         h = _lib.load_library()
         if x.dim() != 5 or x.shape[1] != 1 or list(x.shape[2:]) != self.img_size:
@@ -156,9 +165,9 @@ class ViT(nn.Module):
         if nbytes == 0:
             raise RuntimeError("u2tok_vit_workspace_bytes rejected the configuration")
         ntok = self.patch_embedding.n_patches + (1 if keep_cls else 0)
-        with ops.on_device(x) as (h, stream):
+        with ops.on_device(x, elem=pd) as (h, stream):
             ws = self._ws.get(nbytes, x.device)
-            out = torch.empty((nchunk, ntok, self.hidden_size), dtype=torch.bfloat16, device=x.device)
+            out = torch.empty((nchunk, ntok, self.hidden_size), dtype=pd, device=x.device)
             _lib.check(h.u2tok_vit_forward(C.byref(cfg), table, x.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
                                            stream), "u2tok_vit_forward")
         return out
@@ -170,7 +179,7 @@ class ViT(nn.Module):
         return self.forward_features(x, keep_cls=True), []
 
 
-class ViT3DTower(ops.Fp16Twin, nn.Module):
+class ViT3DTower(nn.Module):
     """Drop-in for ViT3DTower (vit.py:132-176)."""
 
     def __init__(self, config):
@@ -218,9 +227,6 @@ class ViT3DTower(ops.Fp16Twin, nn.Module):
             raise ValueError(f"Unexpected select layer: {self.select_layer}")
         if self.select_feature not in ("patch", "cls_patch"):
             raise ValueError(f"Unexpected select feature: {self.select_feature}")
-        twin = self._fp16_twin()
-        if twin is not None:
-            return twin(images).to(torch.float16)
         key = self._frozen_key() if self.share_frozen_features else None
         if key is not None and self._feat_cache is not None:
             k0, img0, out0 = self._feat_cache
