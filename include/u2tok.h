@@ -67,6 +67,7 @@ u2tok_ctx_t u2tok_ctx_get_current(void);     /* NULL when the thread uses the de
     "flash_mode" {0 pick, 1 plain 128-row units, 7 double pipeline (generated asm KV loop)}, "flash_q_prescaled" {1: the q handed to
     u2tok_flash_attention_d64 already carries scale * log2 e}, "vit_flash" {0 unfused attention, 1}, "tta_overlap" {0, 1: side
     stream for the TTA k|v projections},
+    "vit_vt_epilogue" {1: the ViT's q|k|v product leaves V^T (the flash kernel's operand) from its own V tiles, 0: a transpose launch},
     "tok_flash" {1: the tokenizer's attention cores run the fused kernel of u2tok_tok_attention, 0: GEMM -> softmax -> GEMM},
     "tok_wide" {1: head dims 256 / 512 of that kernel run its 8-wave form (a wave pair per 16-query block, two waves per SIMD),
     0: the 4-wave form},

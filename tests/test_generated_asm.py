@@ -187,9 +187,9 @@ def test_gemm_bt_deep_forms_schedule_and_layout():
     t mod 2) stage pair, behind the barrier from the next pair; the fragment reads return what the DMA pieces wrote."""
     import re
     text = (CSRC / "gemm_bt_asm.inc").read_text()
-    for nj in (3, 4):
-        for deep in "ab":
-            body = re.search(rf"#define GEMM_BT_ASM_TEXT_NJ{nj}_D{deep.upper()} \\\n(.*?)\n#define", text, re.S).group(1)
+    for nj, sfx in ((3, ""), (4, ""), (3, "_T")):       # ("_T": the transposed-tile twin, checked against its sibling below)
+        for deep in "b":
+            body = re.search(rf"#define GEMM_BT_ASM_TEXT_NJ{nj}_D{deep.upper()}{sfx} \\\n(.*?)\n#define", text, re.S).group(1)
             lines = re.findall(r'"(.*)\\n"', body)
             SA, SB = (3, 2) if deep == "a" else (2, 3)
             offb, bstg = 32768 * SA, nj * 8192
@@ -260,6 +260,54 @@ def test_gemm_bt_deep_forms_schedule_and_layout():
                         addr = ((base + abk0) ^ (kk << 5)) + off          # (+ st: the same bytes of another stage)
                         want_row = (wm * 128 if mat == "a" else wn * 32 * nj) + (off // 4096) * 32 + l31
                         assert lds0[addr] == (mat, want_row, kk * 2 + hi)
+
+
+def test_gemm_bt_transposed_tile_twin_only_exchanges_the_mfma_operands():
+    """GEMM_BT_ASM_TEXT_NJ3_DB_T (the ViT's q|k|v product writes V^T from its V tiles): the deep 256 x 192 loop line for line,
+    except that every MFMA takes (A fragment, B fragment) instead of (B fragment, A fragment) -- the accumulator tile comes out
+    transposed, nothing else moves.  And the A-deep twins of round 4 are gone from the build."""
+    import re
+    text = (CSRC / "gemm_bt_asm.inc").read_text()
+    grab = lambda name: re.findall(r'"(.*)\\n"', re.search(rf"#define {name} \\\n(.*?)\n#define", text, re.S).group(1))
+    plain, twin = grab("GEMM_BT_ASM_TEXT_NJ3_DB"), grab("GEMM_BT_ASM_TEXT_NJ3_DB_T")
+    assert len(plain) == len(twin)
+    n = 0
+    for a, b in zip(plain, twin):
+        if a.startswith("v_mfma"):
+            op, rest = a.split(" ", 1)
+            acc, x, y, c = [t.strip() for t in re.split(r",\s*(?![^\[]*\])", rest)]
+            assert b == f"{op} {acc}, {y}, {x}, {c}", (a, b)
+            n += 1
+        else:
+            assert a == b
+    assert n == 6 * 4 * 48                      # 6 unrolled bodies x 4 waves x 48 MFMAs per K tile
+    assert "_DA" not in text
+
+
+def test_tokattn_pv_asm_is_generated_and_counts_its_waits(tmp_path):
+    """tools/gen_tokattn_asm.py: the P V phase of tok_attn2_kernel (16 / 8 accumulator tiles, 6 transposed fragments in flight).
+    The committed text is what the generator writes; every MFMA waits for exactly its own fragment (two ds_read_b64_tr_b16 per
+    fragment, LDS returns in order): lgkmcnt = 2 x (fragments requested after it), and the last one drains."""
+    import re
+    import subprocess
+    import sys
+    dst = tmp_path / "pv.inc"
+    subprocess.run([sys.executable, str(ROOT / "tools" / "gen_tokattn_asm.py"), str(dst)], check=True)
+    text = (CSRC / "tokattn_pv_asm.inc").read_text()
+    assert dst.read_text() == text
+    for nb in (16, 8):
+        body = re.search(rf"#define TOKATTN_PV_ASM_TEXT_{nb} \\\n(.*?)\n#define", text, re.S).group(1)
+        lines = re.findall(r'"(.*)\\n"', body)
+        issued = done = 0
+        for l in lines:
+            if l.startswith("ds_read_b64_tr_b16"):
+                issued += 1
+            elif l.startswith("s_waitcnt lgkmcnt"):
+                allowed = int(re.search(r"\((\d+)\)", l).group(1))
+                assert issued - allowed == 2 * (done + 1), (l, issued, done)   # fragment `done` (both halves) has landed
+            elif l.startswith("v_mfma"):
+                done += 1
+        assert done == nb and issued == 2 * nb and lines[-1].startswith("s_nop")
 
 
 def test_flash_dp2_asm_is_generated():
@@ -338,7 +386,7 @@ def test_generated_asm_passes_the_hazard_lint():
             seen += 1
             assert len(lines) > 200
             assert asm_lint.lint(name, lines) == []
-    assert seen == 12  # flash KV loop (exact / pre-scaled x plain / timed), GEMM K loop NJ = 4, NJ = 3, NJ = 3 SwiGLU-pair, NJ = 2 ring, four deep forms
+    assert seen == 11  # flash KV loop (exact / pre-scaled x plain / timed), GEMM K loop NJ = 4, NJ = 3, NJ = 3 SwiGLU-pair, NJ = 2 ring, two deep forms + the transposed-tile twin
     # the linter itself: each rule fires on a minimal violation
     bad = {
         "R1": ["v_exp_f32 v1, v1", "v_add_f32 v2, v1, v1"],

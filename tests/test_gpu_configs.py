@@ -606,7 +606,7 @@ def test_hard_topk_end_to_end_agreement(layers, qk_gain):
     rounding error and the residual-free SVR stack amplifies that (measured here: 1 layer keeps most of the set, 4
     selective layers scramble it to chance level for the reference's own bf16 run as well), so the yardstick is the
     reference's bf16 run: the HIP indices must agree with the fp32 ones at least as well as the bf16 oracle's do
-    (set overlap, minus 2 % slack).  Bit-exactness given identical inputs is pinned by test_hard_topk_full_size_replay
+    (set overlap, minus 2 % slack; at chance level: inside the 4-sigma band around k/n).  Bit-exactness given identical inputs is pinned by test_hard_topk_full_size_replay
     and test_tokenizer_vs_reference."""
     from helpers import module_sd
     from u2tokenizer_amd.tokenizer import u2Tokenizer
@@ -638,7 +638,14 @@ def test_hard_topk_end_to_end_agreement(layers, qk_gain):
     record(f"hard_topk_end_to_end_L{layers}", {"hip_vs_fp32": {"set_overlap": hs, "same_position": ho},
                                                "oracle_bf16_vs_fp32": {"set_overlap": os_, "same_position": oo},
                                                "k": k, "n": 2048, "chance_overlap": k / 2048, "qk_gain": qk_gain})
-    assert hs >= os_ - 0.02, (hs, os_)
+    # Two k-subsets of n drawn independently overlap in k/n of their elements, +- sigma (hypergeometric).  Once the reference's
+    # own bf16 run has fallen to that level (four selective layers), it and the HIP run are two independent draws around it: the
+    # minimum over the batch rows then only has to stay inside the band (4 sigma), it cannot be asked to beat another draw by 2 %
+    # (round 5: the 8-wave attention kernel sums in another order and drew 0.469 against 0.497).
+    n, chance = 2048, k / 2048
+    sigma = (k * chance * (1 - chance) * (n - k) / (n - 1)) ** 0.5 / k
+    floor = os_ - 0.02 if os_ > chance + 4 * sigma else min(os_ - 0.02, chance - 4 * sigma)
+    assert hs >= floor, (hs, os_, chance, sigma)
 
 
 def test_frozen_vision_tower_is_shared_between_policy_and_reference():

@@ -293,3 +293,38 @@ def test_vit_full_size_properties():
         ops.set_option("vit_flash", 1)
     e = err_stats(b.float().cpu(), a[:2].float().cpu())
     assert e["rel_rms"] < 2e-2, e
+
+
+def test_vit_qkv_product_writes_v_transposed_bit_identically():
+    """Round 5: at the benchmark's size the ViT's q|k|v product runs its V tiles with the MFMA operands exchanged and stores the
+    transposed accumulators as the flash kernel's V^T operand (gemm_bt.hip: vt_epilogue; option vit_vt_epilogue) -- the 12
+    transpose launches per volume go.  Same products, same summation order: the tower's output must be BIT-identical with the
+    option off, and the profile must show the launches gone (so the comparison is not the old path against itself)."""
+    import ctypes as C
+    from u2tokenizer_amd import _lib, ops
+    from u2tokenizer_amd.vit import ViT3DTower
+    m = ViT3DTower(NS(vision_select_layer=-1, vision_select_feature="patch", image_channel=1,
+                      image_size=[32, 256, 256], patch_size=[4, 16, 16]))
+    synth.fill_module_(m, seed=5, prefix="vision_tower.")
+    m = m.to(bf).to(D)
+    vol = synth.synth_volume(1, 8, [32, 256, 256], seed=5, dtype=torch.float16).view(8, 1, 32, 256, 256).to(D)
+
+    def run(opt):
+        ops.set_option("vit_vt_epilogue", opt)
+        ops.set_option("profile", 1)
+        try:
+            out = m(vol)
+            torch.cuda.synchronize()
+            h = _lib.load_library()
+            h.u2tok_ctx_set_current(ops.active_context(vol.device).handle)
+            ms, fl, by, cnt = (C.c_double * 6)(), (C.c_double * 6)(), (C.c_double * 6)(), (C.c_int64 * 6)()
+            _lib.check(h.u2tok_profile_collect2(ms, fl, by, cnt, 6), "u2tok_profile_collect2")
+        finally:
+            ops.set_option("profile", 0)
+            ops.set_option("vit_vt_epilogue", 1)
+        return out, cnt[4]                      # class 4 = data movement (im2col, transposes, fills)
+
+    fused, n_fused = run(1)
+    plain, n_plain = run(0)
+    assert n_plain - n_fused == 12, (n_plain, n_fused)
+    assert torch.equal(fused, plain)

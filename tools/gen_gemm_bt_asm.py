@@ -139,6 +139,9 @@ def frag_waits():
     return waits
 
 
+SWAP = [False]   # True: MFMA operands exchanged -> the accumulator tile comes out TRANSPOSED (lane = column n, registers = rows m)
+
+
 def mfma_block(b, extra, a=None, bb=None):
     """the 4 NJ MFMAs of one k16 step out of buffer b; extra(slot) emits the slot's companion instruction(s)"""
     a, bb = a or afrag, bb or bfrag
@@ -147,7 +150,10 @@ def mfma_block(b, extra, a=None, bb=None):
         i, j = slot // NJ, slot % NJ
         if slot in waits:
             e(f"s_waitcnt lgkmcnt({waits[slot]})")
-        e(f"v_mfma_f32_32x32x16_bf16 {acc(i, j)}, {bb(b, j)}, {a(b, i)}, {acc(i, j)}")
+        if SWAP[0]:
+            e(f"v_mfma_f32_32x32x16_bf16 {acc(i, j)}, {a(b, i)}, {bb(b, j)}, {acc(i, j)}")
+        else:
+            e(f"v_mfma_f32_32x32x16_bf16 {acc(i, j)}, {bb(b, j)}, {a(b, i)}, {acc(i, j)}")
         extra(slot)
 
 
@@ -656,15 +662,21 @@ gen_ring(2)
 print("#define GEMM_BT_ASM_TEXT_NJ2_RING \\")
 for i, line in enumerate(out):
     print(f'  "{line}\\n"' + (" \\" if i + 1 < len(out) else ""))
+# deep forms: B (the weight operand) keeps three stages.  The A-deep twins of round 4 measured the same or slower on every shape and
+# were never selected: gone.  "_T" = the same loop with the MFMA operands exchanged: the accumulator tile comes out
+# transposed, which is how the ViT's q|k|v product writes V^T (the flash kernel's operand) straight from its V tiles -- a lane then
+# holds 8 keys of one head-dim column in exactly the [0-3, 8-11 | 4-7, 12-15] order of that layout (gemm_bt.hip: vt_epilogue).
 deep_hi = {}
-for nj, deep in ((3, "a"), (3, "b"), (4, "a"), (4, "b")):
+for nj, deep, swap in ((3, "b", False), (4, "b", False), (3, "b", True)):
     ABL.clear()
+    SWAP[0] = swap
     deep_hi[(nj, deep)] = gen_deep(nj, deep)
-    print(f"#define GEMM_BT_ASM_TEXT_NJ{nj}_D{deep.upper()} \\")
+    SWAP[0] = False
+    print(f"#define GEMM_BT_ASM_TEXT_NJ{nj}_D{deep.upper()}{'_T' if swap else ''} \\")
     for i, line in enumerate(out):
         print(f'  "{line}\\n"' + (" \\" if i + 1 < len(out) else ""))
 for name, lo, hi in (("GEMM_BT_ASM_CLOBBERS", VLO, VHI), ("GEMM_BT_ASM_CLOBBERS_RING", RVLO, RVHI),
-                     ("GEMM_BT_ASM_CLOBBERS_NJ3_DEEP", 56, deep_hi[(3, "a")]), ("GEMM_BT_ASM_CLOBBERS_NJ4_DEEP", 56, deep_hi[(4, "a")])):
+                     ("GEMM_BT_ASM_CLOBBERS_NJ3_DEEP", 56, deep_hi[(3, "b")]), ("GEMM_BT_ASM_CLOBBERS_NJ4_DEEP", 56, deep_hi[(4, "b")])):
     clob = [f'"v{i}"' for i in range(lo, hi + 1)] + [f'"s{i}"' for i in range(SLO, SHI + 1)] + ['"scc"', '"memory"']
     print(f"#define {name} \\")
     for i in range(0, len(clob), 12):

@@ -25,7 +25,9 @@ run svr_qkv_bt192_two_stage gemmsvr 8 21
 run svr_qkv_bt192_deep gemmsvr 8 24
 run svr_out_ring gemm4k 8 22
 run fc1_gelu128 gemmmlp 3 -1
+run fc1_gelu_bt256 gemmmlp 3 0
 run skinny64 gemm256 16 0
 run tokattn tokattn 5
+run tokattn_4wave tokattn 5 1
 # (unchanged kernels keep their round-3 rows in profiles/r03_kernel_pmc.json: flashbwd, prefillattn, kmajor_dw -- add them back here to refresh)
 cd $R && python tools/pmc_kernels.py $O > $R/gpurun_out/kernel_pmc.json && cat $R/gpurun_out/kernel_pmc.json | head -80

@@ -28,6 +28,7 @@ elif what == "flashbwd":
     for _ in range(iters):
         ops.flash_attention_d64_bwd(qkv, out, dout, 12, 0.125)
 elif what == "tokattn":
+    ops.set_option("tok_wide", 1 if variant == 0 else 0)   # (third argument 1: the 4-wave form)
     # the SVR's spatial attention core at E = 4096: 8 chunks, 8 heads of 512, 256 x 256, relative bias; packed q | k | v
     E, H = 4096, 8
     qkv = (torch.randn(8, 256, 3 * E, device="cuda") * 0.5).to(bf)
@@ -60,5 +61,8 @@ elif what.startswith("gemm"):
         scratch = torch.empty(24 << 20, dtype=torch.uint8, device="cuda")
         ops.set_gemm_scratch(scratch)
     for i in range(iters):
-        ops.gemm(a, ws[i % nw], bias=bias if what == "gemm256" else None, out=out)
+        if what == "gemmmlp":   # the ViT's fc1 as the pipeline runs it: + bias + GELU in the epilogue
+            ops.gemm(a, ws[i % nw], bias=bias, gelu=True, out=out)
+        else:
+            ops.gemm(a, ws[i % nw], bias=bias if what == "gemm256" else None, out=out)
 torch.cuda.synchronize()

@@ -59,6 +59,7 @@ int u2tok_set_option(const char* name, int value) {
        {"kmajor_b", &Options::kmajor_b, 0, 1},
       {"flash_mode", &Options::flash_mode, 0, 7},        {"flash_q_prescaled", &Options::flash_q_prescaled, 0, 1},
       {"vit_flash", &Options::vit_flash, 0, 1},         {"tta_overlap", &Options::tta_overlap, 0, 1},
+      {"vit_vt_epilogue", &Options::vit_vt_epilogue, 0, 1},
       {"tok_flash", &Options::tok_flash, 0, 1},
       {"tok_wide", &Options::tok_wide, 0, 1},
   };

@@ -27,6 +27,7 @@ struct Options {
   int flash_mode = 0;       // 0 pick, 1 plain 128-row units, 7 double pipeline (generated asm KV loop)
   int flash_q_prescaled = 0;  // the q handed to u2tok_flash_attention_d64 already carries scale * log2 e (what the ViT's q|k|v product leaves)
   int vit_flash = 1;        // 0: unfused ViT attention (debug)
+  int vit_vt_epilogue = 1;  // 1: the ViT's q|k|v product writes V^T from its own V tiles (transposed-tile form of the 256 x 192 kernel); 0: transpose launch
   int tok_flash = 1;        // 1: fused attention kernel for the tokenizer's attention cores (tokattn.hip); 0: GEMM chain
   int tok_wide = 1;         // 1: head dims 256 / 512 of the fused kernel run the 8-wave form (two waves per SIMD, tok_attn2_kernel); 0: the 4-wave form (A/B)
   int tta_overlap = 1;      // k | v projections of the TTA cross attentions on a side stream

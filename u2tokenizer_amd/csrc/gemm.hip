@@ -539,6 +539,7 @@ int gemm_bf16(GemmDesc d, hipStream_t stream) {
     const int big = gemm_big_try(d, stream);  // large products: the big-tile kernel (gemm_bt.hip)
     if (big != 0) return big > 0 ? U2_OK : big;
   }
+  if (d.vt) return U2_ERR_ARG;  // (a transposed side output only exists in the big-tile kernel: ask gemm_vt_supported first)
   return gemm_classic(d, stream);
 }
 

@@ -245,6 +245,35 @@ __device__ __forceinline__ void pp_epilogue(const GemmDesc& d, f32x16 (&acc)[2][
   }
 }
 
+// Epilogue of a TRANSPOSED tile (the K loop ran with the MFMA operands exchanged): lane (l31, hi) holds column
+//   n = n_wave + 32 ni + l31,  rows m = m_wave + 64 h + 32 mi + (r & 3) + 8 (r >> 2) + 4 hi  in register r of acc[h][mi][ni].
+// Target: d.vt[chunk][n - vt_n0][key] with m = chunk * vt_rows + key, the V^T operand of the flash kernel, whose key order inside
+// every group of 16 is [0-3, 8-11, 4-7, 12-15] (kernels.h: transpose_bf16, perm16) -- which is the order the registers have:
+// registers 0..7 of a lane are keys {0-3, 8-11} (hi = 0) / {4-7, 12-15} (hi = 1) of the group = positions 8 hi .. 8 hi + 7, registers
+// 8..15 the same of the next group.  So a lane stores two 16-byte vectors per accumulator; no permute, no bias, no residual.
+template <int NJ>
+__device__ __forceinline__ void vt_epilogue(const GemmDesc& d, f32x16 (&acc)[2][2][NJ], int m_wave, int n_wave, int lane) {
+  const int hi = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int m0 = m_wave + 64 * h + 32 * mi;
+      const int chunk = m0 / d.vt_rows, key0 = m0 - chunk * d.vt_rows;
+#pragma unroll
+      for (int ni = 0; ni < NJ; ++ni) {
+        const int n = n_wave + 32 * ni + l31 - d.vt_n0;
+        bf16_t* p = d.vt + (int64_t)chunk * d.vt_bs + (int64_t)n * d.vt_ld + key0 + 8 * hi;
+        const f32x16& a = acc[h][mi][ni];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+          *reinterpret_cast<bt_u32x4*>(p + 16 * g) =
+              bt_u32x4{pack2_bf16(a[8 * g + 0] * d.alpha, a[8 * g + 1] * d.alpha), pack2_bf16(a[8 * g + 2] * d.alpha, a[8 * g + 3] * d.alpha),
+                       pack2_bf16(a[8 * g + 4] * d.alpha, a[8 * g + 5] * d.alpha), pack2_bf16(a[8 * g + 6] * d.alpha, a[8 * g + 7] * d.alpha)};
+      }
+    }
+}
+
 // "Big tile" kernel (variant 20): 256 x 256 x 64 tiles, ONE workgroup of 4 waves per CU, each wave a 128 x 128 output
 // tile (4 x 4 MFMA accumulators = 256 AccVGPRs), its K loop one generated asm block (gemm_bt_asm.inc, written by
 // tools/gen_gemm_bt_asm.py, which documents the slot schedule).  What it is after: with one wave per SIMD and a
@@ -262,11 +291,14 @@ typedef int bt_i32x4 __attribute__((ext_vector_type(4)));
 // NJ = 2 is the RING form (256 x 128 tiles, variant 22): three LDS stages of 48 KB, K tile t + 2 issued during iteration t and
 // waited for with a counted vmcnt one iteration later (tools/gen_gemm_bt_asm.py, gen_ring) -- the tile for products whose
 // 256-wide tiles would leave half of the CUs without work (M = 2048 / 1024 against E x E and E x 2E weights: 256 tiles).
-// DEEP = 1 / 2 (variants 23 / 24 at 256 x 192, 25 / 26 at 256 x 256): the A / the B operand streams -- it gets THREE LDS stages and
-// the ring's schedule, the other operand keeps two (gen_deep of the generator has the schedule and the in-order argument).
-template <int NJ, bool PAIR = false, bool SPLIT = false, int DEEP = 0>  // 32-column blocks per wave: tile = 256 x (64 NJ)
+// DEEP = 2 (variant 24 at 256 x 192, 26 at 256 x 256): the B operand (the weights) streams through THREE LDS stages on the ring's
+// schedule, A keeps two (gen_deep of the generator has the schedule and the in-order argument; the A-deep twins of round 4 never won
+// a shape and are gone).  VT (256 x 192, deep): output tiles at columns >= d.vt_n0 run the loop with the MFMA operands exchanged and
+// leave their TRANSPOSED tile in d.vt (vt_epilogue) instead of C -- the ViT's q|k|v product writes V^T for the flash kernel itself.
+template <int NJ, bool PAIR = false, bool SPLIT = false, int DEEP = 0, bool VT = false>  // 32-column blocks per wave: tile = 256 x (64 NJ)
 __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
-  static_assert(DEEP == 0 || (NJ >= 3 && !PAIR && !SPLIT), "the deep forms are plain 256 x 192 / 256 x 256 kernels");
+  static_assert(DEEP == 0 || (DEEP == 2 && NJ >= 3 && !PAIR && !SPLIT), "the deep forms are plain 256 x 192 / 256 x 256 kernels");
+  static_assert(!VT || (DEEP == 2 && NJ == 3), "the transposed-tile form exists for 256 x 192 deep tiles");
   static_assert(!(PAIR && SPLIT), "the pair form is not sliced");
   static_assert(!PAIR || NJ == 3, "the pair form exists for 256 x 192 tiles");
   static_assert(NJ == 2 || NJ == 3 || NJ == 4, "256 x 128 (ring) / 256 x 192 / 256 x 256 tiles");
@@ -276,8 +308,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
   using CFG = BTCfg<BN>;
   // two stages: [stage][A tile 32 KB | B tile <= 32 KB];  ring: three stages of [A tile 32 KB | B tile 16 KB]
   // deep forms: [A stages of 32 KB][B stages of 8 NJ KB], three of the deep operand and two of the other
-  constexpr int OFFB = DEEP == 1 ? 3 * 32768 : DEEP == 2 ? 2 * 32768 : 32768;
-  constexpr int LDS_BYTES = DEEP == 1 ? 3 * 32768 + 2 * NJ * 8192 : DEEP == 2 ? 2 * 32768 + 3 * NJ * 8192 : RING ? 147456 : 131072;
+  constexpr int OFFB = DEEP == 2 ? 2 * 32768 : 32768;
+  constexpr int LDS_BYTES = DEEP == 2 ? 2 * 32768 + 3 * NJ * 8192 : RING ? 147456 : 131072;
   __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -369,9 +401,10 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
   [va0] "v"(va0), [va1] "v"(va1), [vb0] "v"(vb0), [vb1] "v"(vb1), [aa0] "v"(aa0), [ab0] "v"(ab0), [rsa] "s"(rsa),     \
       [rsb] "s"(rsb), [lda16] "s"(lda16), [nkt] "s"(nkt), [wave] "s"(wave), [st0] "s"(st0_s), [first] "s"(first_s),   \
       [base_a] "s"(base_a), [base_b] "s"(base_b), [nbase_a] "s"(nbase_a), [nbase_b] "s"(nbase_b)
+    [[maybe_unused]] const bool vt_tile = VT && bn0 >= d.vt_n0;  // (uniform) this tile's accumulators come out transposed
     if constexpr (DEEP != 0 && NJ == 3) {
-      if constexpr (DEEP == 1)
-        asm volatile(GEMM_BT_ASM_TEXT_NJ3_DA
+      if (VT && vt_tile)
+        asm volatile(GEMM_BT_ASM_TEXT_NJ3_DB_T
                      : BT_ACC3(0, 0), BT_ACC3(0, 1), BT_ACC3(1, 0), BT_ACC3(1, 1)
                      : BT_IN, [ldb16] "s"(ldb16)
                      : GEMM_BT_ASM_CLOBBERS_NJ3_DEEP);
@@ -381,18 +414,11 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
                      : BT_IN, [ldb16] "s"(ldb16)
                      : GEMM_BT_ASM_CLOBBERS_NJ3_DEEP);
     } else if constexpr (DEEP != 0) {
-      if constexpr (DEEP == 1)
-        asm volatile(GEMM_BT_ASM_TEXT_NJ4_DA
-                     : BT_ACC3(0, 0), [c003] "+a"(acc[0][0][3]), BT_ACC3(0, 1), [c013] "+a"(acc[0][1][3]), BT_ACC3(1, 0),
-                       [c103] "+a"(acc[1][0][3]), BT_ACC3(1, 1), [c113] "+a"(acc[1][1][3])
-                     : BT_IN, [ldb16] "s"(ldb16)
-                     : GEMM_BT_ASM_CLOBBERS_NJ4_DEEP);
-      else
-        asm volatile(GEMM_BT_ASM_TEXT_NJ4_DB
-                     : BT_ACC3(0, 0), [c003] "+a"(acc[0][0][3]), BT_ACC3(0, 1), [c013] "+a"(acc[0][1][3]), BT_ACC3(1, 0),
-                       [c103] "+a"(acc[1][0][3]), BT_ACC3(1, 1), [c113] "+a"(acc[1][1][3])
-                     : BT_IN, [ldb16] "s"(ldb16)
-                     : GEMM_BT_ASM_CLOBBERS_NJ4_DEEP);
+      asm volatile(GEMM_BT_ASM_TEXT_NJ4_DB
+                   : BT_ACC3(0, 0), [c003] "+a"(acc[0][0][3]), BT_ACC3(0, 1), [c013] "+a"(acc[0][1][3]), BT_ACC3(1, 0),
+                     [c103] "+a"(acc[1][0][3]), BT_ACC3(1, 1), [c113] "+a"(acc[1][1][3])
+                   : BT_IN, [ldb16] "s"(ldb16)
+                   : GEMM_BT_ASM_CLOBBERS_NJ4_DEEP);
     } else if constexpr (NJ == 2) {
       asm volatile(GEMM_BT_ASM_TEXT_NJ2_RING
                    : [c000] "+a"(acc[0][0][0]), [c001] "+a"(acc[0][0][1]), [c010] "+a"(acc[0][1][0]), [c011] "+a"(acc[0][1][1]),
@@ -431,6 +457,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
       const bt_u32x4 bnone[NJ * 2] = {};
       pp_epilogue<CFG, 0, false>(ds, acc[0], 0, bm0 + wm * 128, bn0, 0, wn, lane, bnone, false);
       pp_epilogue<CFG, 0, false>(ds, acc[1], 0, bm0 + wm * 128, bn0, 1, wn, lane, bnone, false);
+    } else if (VT && vt_tile) {
+      vt_epilogue<NJ>(d, acc, bm0 + wm * 128, bn0 + wn * (BN / 2), lane);
     } else {
       auto fast_tile = [&]() {  // (evaluated again after the K loop instead of living in an SGPR across it: none to spare)
         // (256 x 192 tiles only: with 256 accumulator registers the 256-wide form has no room for the residual batch)
@@ -464,6 +492,13 @@ static int bt_launch_deep(GemmDesc d, hipStream_t stream) {
   const int64_t total = (int64_t)d.tiles_m * d.tiles_n * d.nz;
   if (total > 0x3fffffff) return U2_ERR_ARG;
   const int grid = (int)std::min<int64_t>(total, opts().gemm_big_grid);
+  if constexpr (NJ == 3 && DEEP == 2) {
+    if (d.vt) {
+      hipLaunchKernelGGL((gemm_bt_kernel<3, false, false, 2, true>), dim3(grid), dim3(256), 0, stream, d);
+      return launch_status();
+    }
+  }
+  if (d.vt) return U2_ERR_ARG;
   hipLaunchKernelGGL((gemm_bt_kernel<NJ, false, false, DEEP>), dim3(grid), dim3(256), 0, stream, d);
   return launch_status();
 }
@@ -515,14 +550,13 @@ static int bt_slices(GemmDesc& d, int64_t tiles, int want, hipStream_t stream) {
   return 1;
 }
 
-// variants: 20 = 256 x 256, 21 = 256 x 192, 22 = 256 x 128 tiles (ring form); 23 / 24 = 256 x 192 with A / B deep, 25 / 26 = 256 x 256
+// variants: 20 = 256 x 256, 21 = 256 x 192, 22 = 256 x 128 tiles (ring form); 24 = 256 x 192 with B deep, 26 = 256 x 256 with B deep
 static int bt_launch_variant(int v, const GemmDesc& d, hipStream_t stream) {
   switch (v) {
     case 20: return bt_launch<4>(d, stream);
     case 22: return bt_launch<2>(d, stream);
-    case 23: return bt_launch_deep<3, 1>(d, stream);
+    case 23: case 25: return U2_ERR_ARG;  // (the A-deep twins of round 4: removed)
     case 24: return bt_launch_deep<3, 2>(d, stream);
-    case 25: return bt_launch_deep<4, 1>(d, stream);
     case 26: return bt_launch_deep<4, 2>(d, stream);
     default: return bt_launch<3>(d, stream);
   }
@@ -596,9 +630,25 @@ static int bt_pick_sliced(const GemmDesc& d) {
   return 0;
 }
 
+// Can the product leave its columns [vt_n0, N) TRANSPOSED in d.vt (GemmDesc::vt) instead of C?  Only the 256 x 192 deep form does that,
+// so: the heuristic must pick it for the many-row part of the product (a cls-row tail goes to the few-rows kernel and is written to
+// C as usual), nothing forced / sliced, plain bf16 output without bias or residual, whole tiles on both sides of vt_n0, and 256-row
+// tiles that do not straddle a chunk of vt_rows keys.  The pipeline asks before it sets d.vt (and runs transpose_bf16 otherwise).
+bool gemm_vt_supported(const GemmDesc& d, int vt_n0, int vt_rows) {
+  if (opts().gemm_big != 0 || !opts().gemm_big_deep || d.nz != 1 || d.flags & ~GEMM_VEC_OK) return false;
+  const int rem = d.M & 255, Mm = d.M - rem;
+  if (rem > 64 || Mm < 512 || d.N < 256 || d.K < 128) return false;
+  if (vt_n0 % 192 || (d.N - vt_n0) % 192 || vt_n0 <= 0 || vt_n0 >= d.N || vt_rows % 256 || Mm % vt_rows || (d.nsplit > vt_n0)) return false;
+  GemmDesc m = d;
+  m.M = Mm;
+  if (opts().gemm_big_ring && bt_pick(m) == 0 && bt_pick_ring(m) == 22) return false;
+  return bt_pick(m) == 21;
+}
+
 // Returns 1 when the product was launched here, 0 when the caller should use gemm.hip's kernel, < 0 on error.
 // `d` has been validated by gemm_bf16 (alignment of A / B, GEMM_VEC_OK resolved).
 int gemm_big_try(const GemmDesc& d, hipStream_t stream) {
+  if (d.vt && !gemm_vt_supported(d, d.vt_n0, d.vt_rows)) return U2_ERR_ARG;  // (the caller did not ask first)
   if (d.flags & GEMM_SWIGLU) {  // only this kernel has the pair form (256 x 192 tiles = 96 output columns); gemm_bf16 validated
     if (!bt_legal(d)) return U2_ERR_ARG;
     const int e = bt_launch<3, true>(d, stream);

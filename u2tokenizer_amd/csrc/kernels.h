@@ -59,6 +59,12 @@ struct GemmDesc {
   // fp32 sums in partial[s][z][m][n] (dense, ld = N); gemm_splitk_reduce_kernel applies the epilogue
   int ksplit = 1, kt_per = 0;
   float* partial = nullptr;
+  // transposed side output (gemm_vt_supported() first): columns n >= vt_n0 are NOT written to C but, transposed, to
+  // vt[m / vt_rows][n - vt_n0][m % vt_rows] (leading dim vt_ld keys, chunk stride vt_bs) in the flash kernel's key order
+  // (perm16 of transpose_bf16) -- the ViT's q|k|v product writes V^T itself.  Rows of a few-rows tail still go to C.
+  bf16_t* vt = nullptr;
+  int vt_n0 = 0, vt_rows = 0;
+  int64_t vt_ld = 0, vt_bs = 0;
 };
 
 // Options (tile, split-K, big-tile selection) and the split-K scratch registration of the launch stream come from the
@@ -67,6 +73,7 @@ int gemm_bf16(GemmDesc d, hipStream_t stream);
 // internal: the kernels behind gemm_bf16 (descriptor already validated there)
 int gemm_classic(GemmDesc d, hipStream_t stream);        // gemm.hip: 128^2 / 64^2 tiles, 2+ workgroups per CU
 int gemm_big_try(const GemmDesc& d, hipStream_t stream);  // gemm_bt.hip: 1 launched, 0 not applicable, < 0 error
+bool gemm_vt_supported(const GemmDesc& d, int vt_n0, int vt_rows);  // gemm_bt.hip: may d.vt be set for this product?
 int gemm_splitk_reduce(const GemmDesc& d, hipStream_t stream);  // gemm.hip: epilogue over d.partial[ksplit][nz][M][N]
 
 // ------------------------------------------------------------------ row ops (rowops.hip)

@@ -58,16 +58,21 @@ struct ScratchScope {
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 // y[rows][ldy] = x[rows][ldx] @ W[out][in]^T + b  (+GELU) (+R)
-int linear(const bf16_t* x, int64_t ldx, const bf16_t* w, const bf16_t* b, bf16_t* y, int64_t ldy, int64_t rows,
-           int in, int out, int extra_flags, const bf16_t* R, int64_t ldr, hipStream_t st, int nsplit = 0,
-           float alpha_lo = 1.f) {
+static GemmDesc linear_desc(const bf16_t* x, int64_t ldx, const bf16_t* w, const bf16_t* b, bf16_t* y, int64_t ldy, int64_t rows,
+                            int in, int out, int extra_flags, const bf16_t* R, int64_t ldr, int nsplit, float alpha_lo) {
   GemmDesc g;
   g.A = x; g.B = w; g.C = y; g.bias = b; g.R = R;
   g.M = (int)rows; g.N = out; g.K = in;
   g.lda = ldx; g.ldb = in; g.ldc = ldy; g.ldr = ldr;
   g.flags = (b ? GEMM_BIAS_N : 0) | extra_flags | (R ? GEMM_RESIDUAL : 0);
   g.nsplit = nsplit; g.alpha_lo = alpha_lo;  // columns [0, nsplit) scaled by alpha_lo (before the bias)
-  return gemm_bf16(g, st);
+  return g;
+}
+
+int linear(const bf16_t* x, int64_t ldx, const bf16_t* w, const bf16_t* b, bf16_t* y, int64_t ldy, int64_t rows,
+           int in, int out, int extra_flags, const bf16_t* R, int64_t ldr, hipStream_t st, int nsplit = 0,
+           float alpha_lo = 1.f) {
+  return gemm_bf16(linear_desc(x, ldx, w, b, y, ldy, rows, in, out, extra_flags, R, ldr, nsplit, alpha_lo), st);
 }
 
 struct AttnCore {
@@ -226,10 +231,19 @@ int vit_forward(const VitConfig& c, const void* const* W, const void* volume, bf
     // the double pipeline reads q already multiplied by softmax scale * log2 e: the product scales its q columns from the
     // fp32 accumulator (one rounding, as for the unscaled q of vit.py:100-105; the SABlock qkv projection has no bias)
     const bool q_pre = opts().vit_flash && ntok >= 512 && (opts().flash_mode == 0 || opts().flash_mode == 7);
-    U2_RUN(linear(xn, Hd, w(b0 + 2), nullptr, qkv, 3 * Hd, rows, Hd, 3 * Hd, 0, nullptr, 0, st, q_pre ? Hd : 0,
-                  scale * 1.44269504088896340736f));
+    // ... and, where the 256 x 192 deep form runs the product (round 5), the V tiles leave V^T for the flash kernel themselves:
+    // their K loop runs with the MFMA operands exchanged and the transposed accumulators are stored in that operand's key order
+    // (gemm_bt.hip: vt_epilogue) -- no row-major V of the patch rows, no transpose launch (12 per volume).  Same values, bit for bit.
+    GemmDesc gq = linear_desc(xn, Hd, w(b0 + 2), nullptr, qkv, 3 * Hd, rows, Hd, 3 * Hd, 0, nullptr, 0, q_pre ? Hd : 0,
+                              scale * 1.44269504088896340736f);
+    const bool vt_fused = opts().vit_flash && opts().vit_vt_epilogue && S_pad == ntok && gemm_vt_supported(gq, 2 * Hd, ntok);
+    if (vt_fused) {
+      gq.vt = vt; gq.vt_n0 = 2 * Hd; gq.vt_rows = ntok; gq.vt_ld = S_pad; gq.vt_bs = (int64_t)Hd * S_pad;
+    }
+    U2_RUN(gemm_bf16(gq, st));
     if (opts().vit_flash) {
-      U2_RUN(transpose_bf16(qkv + 2 * Hd, vt, nc, ntok, Hd, 3 * Hd, S_pad, (int64_t)ntok * 3 * Hd, (int64_t)Hd * S_pad, 1, st));
+      if (!vt_fused)
+        U2_RUN(transpose_bf16(qkv + 2 * Hd, vt, nc, ntok, Hd, 3 * Hd, S_pad, (int64_t)ntok * 3 * Hd, (int64_t)Hd * S_pad, 1, st));
       const bf16_t* xq = qkv + prow * 3 * Hd;  // q | k | v of the cls rows
       U2_RUN(flash_attention_d64(qkv, qkv + Hd, vt, att, nc, ntok, c.heads, 3 * Hd, (int64_t)ntok * 3 * Hd, Hd,
                                  (int64_t)ntok * Hd, S_pad, scale, xq, xq + Hd, xq + 2 * Hd, att + prow * Hd, 3 * Hd, Hd,
