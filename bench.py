@@ -346,6 +346,29 @@ def decoder_after_path(timeout=240):
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
+def batched_throughput(E, options, batch=4, timeout=240):
+    """Context, not `value`: the same path with `batch` volumes per call (two calls in flight) -- what a serving layer that
+    coalesces queued requests would see.  BASELINE configs[2] is batch 1, so the headline stays two concurrent batch-1 calls; with
+    more rows per launch the ViT attention fills whole rounds of its 512 workgroup slots (768 units per volume = 1.5 rounds),
+    the M = 256 products of the TTA chain become M = 256 x batch, and the tokenizer's attention needs no key splits.  A CHILD of
+    this command (`--batch N --streams 2`, no profiling legs)."""
+    try:
+        torch.cuda.empty_cache()
+        cmd = [sys.executable, str(Path(__file__).resolve()), "--batch", str(batch), "--streams", "2", "--steps", "10", "--warmup", "2",
+               "--repeats", "3", "--hidden", str(E), "--no-cpu-baseline", "--no-roofline", "--no-train-step"]
+        for o in options:
+            cmd += ["--option", o]
+        r = subprocess.run(cmd, env=_child_env(), capture_output=True, text=True, timeout=timeout)
+        for ln in reversed(r.stdout.splitlines()):
+            if ln.startswith("{"):
+                d = json.loads(ln)
+                return {"batch": batch, "calls_in_flight": 2, "volumes_per_s": d["value"], "ms_per_call": d["ms_per_step"],
+                        "what": "same path, `batch` volumes per call; not the BASELINE configuration (batch 1), not part of `value`"}
+        return {"error": (r.stderr or "no output")[-300:]}
+    except (OSError, subprocess.SubprocessError, ValueError, KeyError) as e:
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def train_step(path, ids, qids, vol, E, iters=3):
     """Forward under autograd + backward of the path (ViT, projector, tokenizer, embedding table) on the benchmark
     configuration with a dummy loss on the spliced embeddings (the decoder and the optimiser are not part
@@ -681,6 +704,7 @@ def main():
         except Exception as e:  # never lose the inference line to the extra
             line["train_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0 and world == 1 and not args.no_train_step and not args.stub_cpu and B == 1 and E == 4096:
+        line["batched_calls"] = batched_throughput(E, args.option)
         line["train_step_full"] = train_step_full()
         line["decoder_after_path"] = decoder_after_path()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stub_cpu:
