@@ -63,7 +63,8 @@ u2tok_ctx_t u2tok_ctx_get_current(void);     /* NULL when the thread uses the de
     the big-tile kernel, 0: never}, "gemm_big_ring" / "gemm_big_deep" {1: the heuristic may pick the ring / launches the deep
     forms, 0: two-stage forms only}, "gemm_big_splitk" {K slices of a FORCED big-tile launch}, "gemm_big_skinny" {1: partial-round
     products may take the big-tile kernel with K slices}, "kmajor_b" {1: P V and the DiffTS aggregation read V / X in place as
-    K-major operands, 0: through transposed copies},
+    K-major operands, 0: through transposed copies}, "gemm_tail_fused" {1: <= 16 rows behind a multiple of 256 rows (the ViT's cls
+    rows) are computed inside the big-tile launch by the few-rows kernel's arithmetic, 0: a few-rows launch of their own},
     "flash_mode" {0 pick, 1 plain 128-row units, 7 double pipeline (generated asm KV loop)}, "flash_q_prescaled" {1: the q handed to
     u2tok_flash_attention_d64 already carries scale * log2 e}, "vit_flash" {0 unfused attention, 1}, "tta_overlap" {0, 1: side
     stream for the TTA k|v projections},

@@ -328,3 +328,39 @@ def test_vit_qkv_product_writes_v_transposed_bit_identically():
     plain, n_plain = run(0)
     assert n_plain - n_fused == 12, (n_plain, n_fused)
     assert torch.equal(fused, plain)
+
+
+def test_vit_cls_rows_ride_in_the_big_tile_launch_bit_identically():
+    """Round 5: the 8 cls rows behind the 16384 patch rows of every ViT product (q|k|v, out-projection, fc1, fc2) are computed inside
+    the big-tile launch -- by the few-rows kernel's own arithmetic (csrc/rows16.h: same K slices, same order) -- instead of 48
+    launches of their own per volume (option gemm_tail_fused).  The tower's output is BIT-identical either way, and the profile
+    shows the 48 GEMM launches gone."""
+    import ctypes as C
+    from u2tokenizer_amd import _lib, ops
+    from u2tokenizer_amd.vit import ViT3DTower
+    m = ViT3DTower(NS(vision_select_layer=-1, vision_select_feature="cls_patch", image_channel=1,
+                      image_size=[32, 256, 256], patch_size=[4, 16, 16]))
+    synth.fill_module_(m, seed=6, prefix="vision_tower.")
+    m = m.to(bf).to(D)
+    vol = synth.synth_volume(1, 8, [32, 256, 256], seed=6, dtype=torch.float16).view(8, 1, 32, 256, 256).to(D)
+
+    def run(opt):
+        ops.set_option("gemm_tail_fused", opt)
+        ops.set_option("profile", 1)
+        try:
+            out = m(vol)
+            torch.cuda.synchronize()
+            h = _lib.load_library()
+            h.u2tok_ctx_set_current(ops.active_context(vol.device).handle)
+            ms, fl, by, cnt = (C.c_double * 6)(), (C.c_double * 6)(), (C.c_double * 6)(), (C.c_int64 * 6)()
+            _lib.check(h.u2tok_profile_collect2(ms, fl, by, cnt, 6), "u2tok_profile_collect2")
+        finally:
+            ops.set_option("profile", 0)
+            ops.set_option("gemm_tail_fused", 1)
+        return out, cnt[0], fl[0]                # class 0 = GEMM launches (as the profile counts them: one per product)
+
+    fused, n_fused, f_fused = run(1)
+    plain, n_plain, f_plain = run(0)
+    assert fused.shape == (8, 2049, 768)         # cls_patch: the cls rows are part of the output
+    assert torch.equal(fused, plain)
+    assert f_fused == f_plain                    # the same algorithmic work was accounted

@@ -23,6 +23,7 @@ struct Options {
   int gemm_big_deep = 1;    // 1: unsliced 256 x 192 / 256 x 256 products take the deep form (three LDS stages for B, two for A); 0: two stages (A/B)
   int gemm_big_ring = 1;    // 1: products that make one round of 256 x 128 tiles take the ring form (bt_pick_ring); 0: never (A/B)
   int gemm_big_skinny = 1;  // 1: partial-round products may take the big-tile kernel with K slices (bt_pick_sliced); 0: never
+  int gemm_tail_fused = 1;  // 1: <= 16 rows behind a multiple of 256 (the ViT's cls rows) are computed inside the big-tile launch; 0: few-rows launch
   int kmajor_b = 1;         // 1: P V / DiffTS aggregation read V / X in place as K-major B operands; 0: transposed copies
   int flash_mode = 0;       // 0 pick, 1 plain 128-row units, 7 double pipeline (generated asm KV loop)
   int flash_q_prescaled = 0;  // the q handed to u2tok_flash_attention_d64 already carries scale * log2 e (what the ViT's q|k|v product leaves)

@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include "kernels.h"
+#include "rows16.h"
 
 namespace u2 {
 
@@ -410,20 +411,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows16_kernel(GemmDesc d) {
   const int mrow = min(l15, d.M - 1);
   const bf16_t* wp = d.B + (int64_t)nrow * d.ldb + g * 8;
   const bf16_t* xp = d.A + (int64_t)mrow * d.lda + g * 8;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  constexpr int U = 8;  // steps in flight per batch: 16 x 16-byte loads per lane
-  for (int sb = s0; sb < s1; sb += U) {
-    bf16x8 wf[U], xf[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int st = min(sb + u, s1 - 1);
-      wf[u] = *reinterpret_cast<const bf16x8*>(wp + st * 32);
-      xf[u] = *reinterpret_cast<const bf16x8*>(xp + st * 32);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (sb + u < s1) acc = mfma16(wf[u], xf[u], acc);
-  }
+  const f32x4 acc = rows16_slice(wp, xp, s0, s1);   // (rows16.h: shared with the big-tile kernel's in-launch tail)
   // lane holds C[m = l15][n = n0 + 4 g + r]
   red[wv][lane][0] = acc[0]; red[wv][lane][1] = acc[1]; red[wv][lane][2] = acc[2]; red[wv][lane][3] = acc[3];
   __syncthreads();
@@ -433,7 +421,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows16_kernel(GemmDesc d) {
   for (int w = 0; w < NW; ++w)
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] += red[w][lane][r];
-  const bool out_f32 = d.flags & GEMM_OUT_F32;
   const int m = l15;
   if constexpr (PAIR) {  // (wave 0, all 64 lanes: lanes of rows >= M carry copies of row M - 1 and write nothing)
 #pragma unroll
@@ -448,18 +435,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows16_kernel(GemmDesc d) {
     }
     return;
   }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int n = n0 + 4 * g + r;
-    if (n >= d.N) break;
-    float x = v[r] * (n < d.nsplit ? d.alpha_lo : d.alpha);
-    if (d.flags & GEMM_BIAS_M) x += bf16_to_f32(d.bias[m]);
-    if (d.flags & GEMM_BIAS_N) x += bf16_to_f32(d.bias[n]);
-    if (d.flags & GEMM_GELU) x = gelu_fast(x);
-    if (d.flags & GEMM_RESIDUAL) x += bf16_to_f32(d.R[(int64_t)m * d.ldr + n]);
-    if (out_f32) reinterpret_cast<float*>(d.C)[(int64_t)m * d.ldc + n] = x;
-    else reinterpret_cast<bf16_t*>(d.C)[(int64_t)m * d.ldc + n] = f32_to_bf16(x);
-  }
+  rows16_store(d, v, m, n0 + 4 * g, reinterpret_cast<char*>(d.C), d.R);
 }
 
 // M <= 16, one batch entry, K-contiguous operands, K % 32 == 0: returns 1 when launched, 0 when not applicable

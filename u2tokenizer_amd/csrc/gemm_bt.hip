@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <type_traits>
 #include "kernels.h"
+#include "rows16.h"
 
 namespace u2 {
 
@@ -295,8 +296,41 @@ typedef int bt_i32x4 __attribute__((ext_vector_type(4)));
 // schedule, A keeps two (gen_deep of the generator has the schedule and the in-order argument; the A-deep twins of round 4 never won
 // a shape and are gone).  VT (256 x 192, deep): output tiles at columns >= d.vt_n0 run the loop with the MFMA operands exchanged and
 // leave their TRANSPOSED tile in d.vt (vt_epilogue) instead of C -- the ViT's q|k|v product writes V^T for the flash kernel itself.
-template <int NJ, bool PAIR = false, bool SPLIT = false, int DEEP = 0, bool VT = false>  // 32-column blocks per wave: tile = 256 x (64 NJ)
+// TAIL: d.tail_rows rows behind the M rows of the tiles (the cls rows of the ViT: 8 behind 16384) are computed IN this launch, before the
+// first tile, by the few-rows arithmetic of rows16.h -- workgroup b takes the 16-column blocks b, b + grid, ...; its four waves run the
+// slices the few-rows kernel's 4 / 8 / 16 waves would, so the values are those of a gemm_rows16 launch bit for bit, which it replaces
+// (48 launches of ~7-10 us per volume; the workgroups concerned start their tiles ~2 us later).
+template <int NWV>
+__device__ __forceinline__ void bt_tail_block(const GemmDesc& d, int n0, float (*red)[64][4], int wv, int lane) {
+  const int l15 = lane & 15, g = lane >> 4;
+  const bool f32 = d.flags & GEMM_OUT_F32;
+  const bf16_t* At = d.A + (int64_t)d.M * d.lda;
+  char* Ct = reinterpret_cast<char*>(d.C) + (int64_t)d.M * d.ldc * (f32 ? 4 : 2);
+  const bf16_t* Rt = (d.flags & GEMM_RESIDUAL) ? d.R + (int64_t)d.M * d.ldr : nullptr;
+  const int nsteps = d.K >> 5, per = (nsteps + NWV - 1) / NWV;
+  const int nrow = min(n0 + l15, d.N - 1), mrow = min(l15, d.tail_rows - 1);
+  const bf16_t* wp = d.B + (int64_t)nrow * d.ldb + g * 8;
+  const bf16_t* xp = At + (int64_t)mrow * d.lda + g * 8;
+  for (int vw = wv; vw < NWV; vw += 4) {   // the slices of "waves" wv, wv + 4, ...
+    const int s0 = vw * per, s1 = min(nsteps, s0 + per);
+    const f32x4 acc = rows16_slice(wp, xp, s0, s1);
+    red[vw][lane][0] = acc[0]; red[vw][lane][1] = acc[1]; red[vw][lane][2] = acc[2]; red[vw][lane][3] = acc[3];
+  }
+  __syncthreads();
+  if (wv == 0 && l15 < d.tail_rows) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NWV; ++w)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += red[w][lane][r];
+    rows16_store(d, v, l15, n0 + 4 * g, Ct, Rt);
+  }
+  __syncthreads();  // red is free again
+}
+
+template <int NJ, bool PAIR = false, bool SPLIT = false, int DEEP = 0, bool VT = false, bool TAIL = false>  // 32-column blocks per wave: tile = 256 x (64 NJ)
 __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
+  static_assert(!TAIL || (!PAIR && !SPLIT), "the in-launch tail exists for the plain forms");
   static_assert(DEEP == 0 || (DEEP == 2 && NJ >= 3 && !PAIR && !SPLIT), "the deep forms are plain 256 x 192 / 256 x 256 kernels");
   static_assert(!VT || (DEEP == 2 && NJ == 3), "the transposed-tile form exists for 256 x 192 deep tiles");
   static_assert(!(PAIR && SPLIT), "the pair form is not sliced");
@@ -321,6 +355,17 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
   constexpr bool split = SPLIT;
   const int total = tiles_mn * (split ? d.ksplit : d.nz);
   const int gd = gridDim.x, bid = blockIdx.x;
+  if constexpr (TAIL) {
+    if (d.tail_rows > 0) {  // (uniform) before the first DMA of the K loop touches the LDS
+      float (*red)[64][4] = reinterpret_cast<float (*)[64][4]>(lds);
+      const int nblk = (d.N + 15) >> 4, nsl = rows16_slices(d.K >> 5);
+      for (int blk = bid; blk < nblk; blk += gd) {
+        if (nsl == 16) bt_tail_block<16>(d, blk * 16, red, wave, lane);
+        else if (nsl == 8) bt_tail_block<8>(d, blk * 16, red, wave, lane);
+        else bt_tail_block<4>(d, blk * 16, red, wave, lane);
+      }
+    }
+  }
   const int my_tiles = (total - bid + gd - 1) / gd;  // >= 1: grid <= total
   // DMA pieces of this wave: rows [64 w, 64 w + 64) of the A tile and [16 NJ w, ..) of the B tile, 8 rows x 128 B per
   // piece; LDS position p of row r holds global chunk p ^ ((r >> 1) & 7): even / odd pieces differ by 4 in that term.
@@ -494,11 +539,16 @@ static int bt_launch_deep(GemmDesc d, hipStream_t stream) {
   const int grid = (int)std::min<int64_t>(total, opts().gemm_big_grid);
   if constexpr (NJ == 3 && DEEP == 2) {
     if (d.vt) {
-      hipLaunchKernelGGL((gemm_bt_kernel<3, false, false, 2, true>), dim3(grid), dim3(256), 0, stream, d);
+      if (d.tail_rows) hipLaunchKernelGGL((gemm_bt_kernel<3, false, false, 2, true, true>), dim3(grid), dim3(256), 0, stream, d);
+      else hipLaunchKernelGGL((gemm_bt_kernel<3, false, false, 2, true>), dim3(grid), dim3(256), 0, stream, d);
+      return launch_status();
+    }
+    if (d.tail_rows) {
+      hipLaunchKernelGGL((gemm_bt_kernel<3, false, false, 2, false, true>), dim3(grid), dim3(256), 0, stream, d);
       return launch_status();
     }
   }
-  if (d.vt) return U2_ERR_ARG;
+  if (d.vt || d.tail_rows) return U2_ERR_ARG;
   hipLaunchKernelGGL((gemm_bt_kernel<NJ, false, false, DEEP>), dim3(grid), dim3(256), 0, stream, d);
   return launch_status();
 }
@@ -517,6 +567,13 @@ static int bt_launch(GemmDesc d, hipStream_t stream) {
       return gemm_splitk_reduce(d, stream);
     }
   }
+  if constexpr (NJ == 4 && !PAIR) {
+    if (d.tail_rows) {
+      hipLaunchKernelGGL((gemm_bt_kernel<4, false, false, 0, false, true>), dim3(grid), dim3(256), 0, stream, d);
+      return launch_status();
+    }
+  }
+  if (d.tail_rows) return U2_ERR_ARG;
   hipLaunchKernelGGL((gemm_bt_kernel<NJ, PAIR>), dim3(grid), dim3(256), 0, stream, d);
   return launch_status();
 }
@@ -688,8 +745,13 @@ int gemm_big_try(const GemmDesc& d, hipStream_t stream) {
     if (d.flags & GEMM_RESIDUAL) tail.R = d.R + (int64_t)main.M * d.ldr;
   }
   auto launch = [&](int v) {
+    // <= 16 tail rows ride in the launch of the plain 256 x 256 (20) and deep 256 x 192 (24) forms -- what the ViT's products run
+    const bool in_launch = split_tail && rem <= 16 && !(d.K & 31) && !(d.flags & GEMM_BIAS_M) && (v == 20 || v == 24) &&
+                           opts().gemm_tail_fused && main.ksplit <= 1;
+    if (in_launch) main.tail_rows = rem;
     int e = bt_launch_variant(v, main, stream);
-    if (e == U2_OK && split_tail) e = gemm_classic(tail, stream);
+    main.tail_rows = 0;
+    if (e == U2_OK && split_tail && !in_launch) e = gemm_classic(tail, stream);
     return e == U2_OK ? 1 : e;
   };
   // (ahead of the sliced forms: 192 ring tiles beat 2 x 128 sliced ones)

@@ -65,6 +65,9 @@ struct GemmDesc {
   bf16_t* vt = nullptr;
   int vt_n0 = 0, vt_rows = 0;
   int64_t vt_ld = 0, vt_bs = 0;
+  // in-launch tail (filled by the big-tile launcher): rows [M, M + tail_rows) of A / C / R (<= 16: the ViT's cls rows behind the
+  // patch rows) are computed inside the same launch by the few-rows arithmetic (rows16.h) instead of a launch of their own
+  int tail_rows = 0;
 };
 
 // Options (tile, split-K, big-tile selection) and the split-K scratch registration of the launch stream come from the
