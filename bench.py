@@ -274,6 +274,10 @@ def measure_kernels(E, options, timeout=300):
                 a[0] += 1
                 a[1] += (en - st) / 1e3
             out = {name: (c / (nvol - 1), us / c) for name, (c, us) in agg.items()}
+            # the span of the same dispatches IN THE PROFILER'S OWN CLOCK (first start to last end of the timed volumes): kernels issued
+            # one behind the other on one stream cannot add up to more than that -- one process, ONE clock.  (Against the host's
+            # wall clock of the same steps the GPU timestamps run ~1 % fast on this pool: the ratio is reported, not allowed for.)
+            out["__span_ms__"] = (max(en for _, en, _ in rows[per:]) - rows[per][0]) / 1e6 / (nvol - 1)
         else:  # (trace missing or ragged: the profiler's own summary over all 7 volumes)
             for f in glob.glob(os.path.join(tmp, "**", "*kernel_stats.csv"), recursive=True):
                 with open(f) as fh:
@@ -638,6 +642,7 @@ def main():
         serial_opts = [o for o in args.option if not o.startswith("tta_overlap=")] + ["tta_overlap=0"]
         ktab = measure_kernels(E, serial_opts) if (B == 1 and world == 1 and not args.no_traffic) else None
         child_wall_ms = ktab.pop("__child_wall_ms__", None) if ktab else None
+        span_ms = ktab.pop("__span_ms__", None) if ktab else None
         wall_serial = None
         if ktab:
             ops.set_option("profile", 0)
@@ -672,7 +677,11 @@ def main():
                 # Both sides from ONE process: the profiled child times its own 6 volumes (its ms_per_step) while the profiler
                 # records the kernels of those very volumes -- no allowance.  (The un-profiled wall of this process is beside it.)
                 "one_stream_serial_wall_ms_per_volume_profiled_child": (round(child_wall_ms, 4) if child_wall_ms else None),
-                "sum_le_wall": (bool(total_ms <= child_wall_ms) if child_wall_ms else None)}
+                # one process, one clock: the summed durations of the timed volumes' kernels against the span of those very dispatches
+                # in the profiler's timestamps (no allowance); the host-side wall of the same steps beside it
+                "profiler_span_ms_per_volume": (round(span_ms, 4) if span_ms else None),
+                "profiler_clock_over_host_clock": (round(span_ms / child_wall_ms, 4) if span_ms and child_wall_ms else None),
+                "sum_le_wall": (bool(total_ms <= span_ms) if span_ms else (bool(total_ms <= child_wall_ms) if child_wall_ms else None))}
 
         def roof(idx, key, kernel):
             ach_ev = flops[idx] / ms[idx] / 1e9
