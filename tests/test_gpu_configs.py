@@ -323,7 +323,8 @@ def test_config3_end_to_end_first_step_logits_and_greedy_ids():
 def test_float16_model_under_autocast():
     """evalscipt/ourmodel_amos.py:33,70: the whole model in float16, generate under torch.autocast.  Round 5: the path modules
     run the IEEE-half build of the library on the fp16 parameters themselves (fp32 accumulation; round 4 computed through a
-    bf16 copy and landed 17 x further from fp32 than the reference's own fp16 run); the decoder is stock HF in fp16.  Against
+    bf16 copy and landed 17 x further from fp32 than the reference's own fp16 run); the decoder's prefill / decode steps run the
+    fused HIP layers of the same build.  Against
     the oracle + HF decoder in fp32 on the SAME (fp16-representable) weights: the spliced embeddings must be as close to fp32
     as the reference's own FLOAT16 run is (1.2 x its relative RMS distance; the bf16 run's distance is recorded beside it),
     greedy ids as in the bf16 test."""

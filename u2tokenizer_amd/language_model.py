@@ -59,12 +59,12 @@ class _u2CausalLMMixin(u2MetaForCausalLM):
 
     def _maybe_fuse_prefill(self) -> None:
         """The prefill of the spliced embeddings through the HIP decoder layers (u2tokenizer_amd/prefill.py)
-        unless `config.u2_fused_prefill` is False: patched once, when the decoder sits on the GPU in bf16.  Training,
+        unless `config.u2_fused_prefill` is False: patched once, when the decoder sits on the GPU in bf16 (or fp16: the f16 build).  Training,
         decode steps, padded batches and CPU runs keep the stock HuggingFace layers."""
         if getattr(self, "_u2_prefill_checked", False) or not getattr(self.config, "u2_fused_prefill", True):
             return
         p = next(self.model.layers[0].parameters(), None) if len(self.model.layers) else None
-        if p is not None and p.is_cuda and p.dtype == torch.bfloat16:
+        if p is not None and p.is_cuda and p.dtype in (torch.bfloat16, torch.float16):   # (either build of the library)
             from .prefill import enable_fused_prefill
             enable_fused_prefill(self, strict=False)   # (layers of another layout -- Phi3 -- stay stock)
             self._u2_prefill_checked = True

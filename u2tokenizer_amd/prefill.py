@@ -96,7 +96,8 @@ def _layer_forward(self, hidden_states, *args, **kwargs):
     # `past_key_value` (singular) is the layer protocol of transformers 4.46 .. 4.5x, whose layers also return tuples: never
     # patched (enable_fused_prefill checks the signature), and a caller that passes it anyway gets the stock layer
     common = (not args and "past_key_value" not in kwargs and not kwargs.get("output_attentions")
-              and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 3
+              and not torch.is_grad_enabled() and x.is_cuda and x.dtype in ops.ELEM_OF and x.dim() == 3
+              and att.q_proj.weight.dtype == x.dtype      # (bf16 weights under an fp16 autocast hand fp16 activations on: stock layers)
               and pe is not None and st["owner"]._u2_prefill_mask_ok and _is_stock(self)
               and getattr(att, "sliding_window", None) is None and att.head_dim in (64, 128))
     if common and x.shape[1] == 1 and x.shape[0] <= 16 and st["owner"]._u2_fused_decode \
@@ -246,14 +247,17 @@ def _decode_state(self, B: int, device):
     # (per model, batch size AND stream: two generate() calls in flight on different streams must not share the step's scratch)
     stream = torch.cuda.current_stream(device).cuda_stream
     pool = owner.__dict__.setdefault("_u2_decode_scratch", {})
+    edt = self.input_layernorm.weight.dtype      # bf16, or fp16 for a decoder loaded in float16 (the f16 build of the library)
     sc = pool.get((B, device, stream))
+    if sc is not None and sc["qkv"].dtype != edt:
+        sc = None
     if sc is None:
         if len(pool) >= 8:
             pool.clear()
         sc = {"B": B, "device": device, "ws": None, "T": 0,
-              "qkv": torch.empty((B, d["nq"]), dtype=torch.bfloat16, device=device),
-              "kc": torch.empty((B, d["Hkv"], 1, d["hd"]), dtype=torch.bfloat16, device=device),
-              "vc": torch.empty((B, d["Hkv"], 1, d["hd"]), dtype=torch.bfloat16, device=device)}
+              "qkv": torch.empty((B, d["nq"]), dtype=edt, device=device),
+              "kc": torch.empty((B, d["Hkv"], 1, d["hd"]), dtype=edt, device=device),
+              "vc": torch.empty((B, d["Hkv"], 1, d["hd"]), dtype=edt, device=device)}
         pool[(B, device, stream)] = sc
     return d, sc
 
@@ -279,7 +283,7 @@ def _decode_step(self, x, pe, cache):
         cos, sin = pe
         cos = cos.expand(B, 1, hd).reshape(B, hd)
         sin = sin.expand(B, 1, hd).reshape(B, hd)
-        if cos.dtype != sin.dtype or cos.dtype not in (torch.float32, torch.bfloat16) or cos.stride(1) != 1 or sin.stride(1) != 1 \
+        if cos.dtype != sin.dtype or cos.dtype not in (torch.float32, x.dtype) or cos.stride(1) != 1 or sin.stride(1) != 1 \
                 or cos.stride(0) != sin.stride(0):
             cos, sin = cos.float().contiguous(), sin.float().contiguous()
         T1 = cache.get_seq_length(att.layer_idx) + 1
@@ -290,7 +294,7 @@ def _decode_step(self, x, pe, cache):
             sc["T"] = Tcap
         ws, nws = sc["ws"].data_ptr(), sc["ws"].numel()
         lay = cache.layers[att.layer_idx]
-        out = torch.empty((B, 1, E), dtype=torch.bfloat16, device=x.device)
+        out = torch.empty((B, 1, E), dtype=x.dtype, device=x.device)
         if type(lay) is _APPEND_LAYER and lay._kb is not None and lay._kb.shape[0] == B:
             # append in place: the rotary kernel writes the step's keys / values at position T0 of the layer's buffers
             T0 = lay._room(1, sc["kc"])
