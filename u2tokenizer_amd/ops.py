@@ -27,6 +27,7 @@ class Context:
     def __init__(self):
         self._handles = {}     # element type -> native handle
         self._options = {}
+        self._scratch = {}     # (device index, stream) -> (pointer, bytes): split-K scratch registrations, replayed on every build
         self._lock = threading.Lock()
         self.handle_for("bf16")
 
@@ -40,7 +41,31 @@ class Context:
                 self._handles[elem] = hd
                 for name, value in self._options.items():
                     self._set(h, hd, name, value)
+                for (dev, stream), (ptr, nbytes) in self._scratch.items():
+                    self._register_scratch(h, hd, dev, stream, ptr, nbytes)
             return hd
+
+    @staticmethod
+    def _register_scratch(h, hd, dev, stream, ptr, nbytes):
+        prev = h.u2tok_ctx_get_current()
+        with torch.cuda.device(dev):
+            h.u2tok_ctx_set_current(hd)
+            try:
+                _lib.check(h.u2tok_set_gemm_scratch(ptr, nbytes, stream), "u2tok_set_gemm_scratch")
+            finally:
+                h.u2tok_ctx_set_current(prev)
+
+    def set_gemm_scratch(self, dev, stream, ptr, nbytes) -> None:
+        """split-K scratch of `stream` on device index `dev` (ptr None removes it): registered with every build of the library this
+        context has a native handle for, and replayed on the ones created later (a bf16 path and an fp16 decoder share it)."""
+        with self._lock:
+            if ptr is None:
+                self._scratch.pop((dev, stream), None)
+            else:
+                self._scratch[(dev, stream)] = (ptr, nbytes)
+            handles = list(self._handles.items())
+        for elem, hd in handles:
+            self._register_scratch(_lib.load_library(elem), hd, dev, stream, ptr, 0 if ptr is None else nbytes)
 
     @property
     def handle(self):
@@ -308,13 +333,11 @@ def gemm_kmajor(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool, alpha=1.0, 
 def set_gemm_scratch(buf: Optional[torch.Tensor]) -> None:
     """Registers `buf` (any dtype, on the GPU) as split-K scratch for gemm() calls on the current stream; None removes
     it.  The caller keeps the tensor alive while products may be in flight."""
-    h = _lib.load_library()
     dev = buf.device if buf is not None else torch.device("cuda", torch.cuda.current_device())
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
     with torch.cuda.device(dev):
-        h.u2tok_ctx_set_current(active_context(dev).handle)
-        st = h.u2tok_set_gemm_scratch(_ptr(buf), 0 if buf is None else buf.numel() * buf.element_size(),
-                                      torch.cuda.current_stream(dev).cuda_stream)
-    _lib.check(st, "u2tok_set_gemm_scratch")
+        stream = torch.cuda.current_stream(dev).cuda_stream
+    active_context(dev).set_gemm_scratch(idx, stream, _ptr(buf), 0 if buf is None else buf.numel() * buf.element_size())
 
 
 @_guarded
