@@ -72,9 +72,10 @@ class Context:
         return self.handle_for(_lib.thread_elem())
 
     def close(self) -> None:
-        for elem, hd in self._handles.items():
+        with self._lock:
+            handles, self._handles = self._handles, {}
+        for elem, hd in handles.items():
             _lib.load_library(elem).u2tok_ctx_destroy(hd)
-        self._handles = {}
 
     @staticmethod
     def _set(h, hd, name, value):
@@ -86,9 +87,11 @@ class Context:
             h.u2tok_ctx_set_current(prev)
 
     def set_option(self, name: str, value: int) -> None:
-        for elem, hd in list(self._handles.items()):
+        with self._lock:       # recorded first: a build whose native context is created meanwhile replays it (handle_for)
+            self._options[name] = int(value)
+            handles = list(self._handles.items())
+        for elem, hd in handles:
             self._set(_lib.load_library(elem), hd, name, value)
-        self._options[name] = int(value)
 
     def __enter__(self):
         stack = getattr(_tls, "stack", None)
