@@ -769,7 +769,7 @@ def test_dpo_duplicate_image_batch_at_benchmark_size():
         emb = path.prepare_inputs_for_multimodal(ids, None, None, None, None, vol2, qids2)[4]
         (emb.float() * w).sum().backward()
         torch.cuda.synchronize()
-        ms[flag] = (time.perf_counter() - t0) * 1e3
+        ms[flag] = min(ms.get(flag, float("inf")), (time.perf_counter() - t0) * 1e3)   # best of the two passes (a host stall is not the subject)
         res[flag] = (emb.detach(), {k: p.grad.float() for k, p in path.holder.named_parameters() if p.grad is not None})
     path.config.u2_dedup_duplicate_images = True
 
