@@ -425,6 +425,7 @@ def test_vit_and_projector_gradients_vs_oracle():
     check_grads(got, grads[torch.float32][1], grads[bf][1], what="vit + spp")
 
 
+@pytest.mark.host_heavy(39)   # nominal seconds, mostly host (tests/suite_budget.py)
 def test_gradients_at_full_width():
     """The training path at the real WIDTH of BASELINE configs 3 / 4 (reduced depth so that torch.autograd over the CPU oracle
     stays within seconds): two ViT blocks on two 32 x 256 x 256 chunks (2049 tokens per chunk: the fused attention backward,

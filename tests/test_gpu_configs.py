@@ -210,6 +210,7 @@ def run_full_config(name, c, B, C, S, Lt, seed, vocab=4096):
 # selective layer at full width, where bf16 noise is 5-20 % and any indexing mistake is 100 %.
 
 
+@pytest.mark.host_heavy(62)   # nominal seconds, mostly host (tests/suite_budget.py)
 def test_config3_full_path_vs_oracle():
     """BASELINE configs[2] -- the benchmark's configuration: u2Qwen3-8B shape (E = 4096), one 256^3 volume = 8 chunks
     of (32,256,256) fp16, ViT-B x12, SPP, 4-layer rma + DiffTS(1024) + DMTP tokenizer, 256 queries, text 1024, prompt
@@ -218,12 +219,7 @@ def test_config3_full_path_vs_oracle():
     run_full_config("config3_E4096_256cube", c, B=1, C=8, S=1024, Lt=1024, seed=71)
 
 
-def _greedy_reference(m, e32, new):
-    """fp32 reference on the host: greedy ids, the top-2 margin of every decision, the first-step logits."""
-    from transformers import Qwen3ForCausalLM
-    g = Qwen3ForCausalLM.generate(m, inputs_embeds=e32, max_new_tokens=new, do_sample=False, output_scores=True,
-                                  return_dict_in_generate=True)
-    return g.sequences[0].tolist(), fp32_top2_margins(g.scores), g.scores[0][0].float()
+from e2e_config3 import _greedy_reference  # noqa: E402  (one definition: the fixture maker uses it too)
 
 
 def _id_gate(rep, vols_hip_ids, refs, thrs, need=3):
@@ -246,6 +242,7 @@ def _id_gate(rep, vols_hip_ids, refs, thrs, need=3):
     assert vols_hip_ids["noise"][part[0]] != vols_hip_ids["smooth"][part[0]]   # ... and the HIP path follows the image
 
 
+@pytest.mark.host_heavy(65)   # nominal seconds, mostly host (tests/suite_budget.py)
 def test_config3_end_to_end_first_step_logits_and_greedy_ids():
     """SURVEY 8(d) at the benchmark's configuration, end to end (u2llama.py:76-87,123-126): one 256^3 volume through the HIP
     ViT / SPP / 4-layer tokenizer, spliced into 1024 embeddings, then a Qwen3-8B-WIDTH decoder (hidden 4096, 32 / 8 heads of
@@ -255,39 +252,22 @@ def test_config3_end_to_end_first_step_logits_and_greedy_ids():
     Round 5: the decoder is drawn so that the reference's decisions are clear (helpers.decisive_decoder_) and the
     ids are compared for TWO volumes -- the benchmark's noise volume and a smooth one whose tokens differ by ~80 % -- whose
     reference ids must differ: a path that ignored the image could not pass."""
-    from u2tokenizer_amd.language_model import u2Qwen3Config, u2Qwen3ForCausalLM
-    E, vocab, S, Lt, seed, dseed = 4096, 4096, 1024, 1024, 75, 0
-    c = mm_config(E, [32, 256, 256])
-    cfg = u2Qwen3Config(vocab_size=vocab, hidden_size=E, intermediate_size=12288, num_hidden_layers=4,
-                        num_attention_heads=32, num_key_value_heads=8, head_dim=128, max_position_embeddings=2048,
-                        tie_word_embeddings=False, pad_token_id=0, bos_token_id=1, eos_token_id=2)
-    for k, v in c.items():
-        if k != "hidden_size":
-            setattr(cfg, k, v)
-    m = u2Qwen3ForCausalLM(cfg).eval()
-    synth.fill_module_(m, seed=seed, lively=True)
-    decisive_decoder_(m, dseed)
-    sd32 = {k: v.clone() for k, v in m.state_dict().items() if v.is_floating_point()}
-    sd16 = {k: v.to(bf) for k, v in sd32.items()}
-    vols = {"noise": synth.synth_volume(1, 8, c["image_size"], seed=seed, dtype=torch.float16),
-            "smooth": smooth_volume(1, 8, c["image_size"])}
-    ids = synth.synth_ids(1, S, S - 24, vocab, seed=seed, name="input_ids")
-    qids = synth.synth_ids(1, Lt, 40, vocab, seed=seed, name="question_ids")
-    oc = oracle_cfg(c)
-    new = 4
-    e32, refs = {}, {}
-    for v, vol in vols.items():
-        e32[v], _ = O.prepare_inputs_for_multimodal(sd32, sd32["model.embed_tokens.weight"], ids, vol.float(), qids, oc)
-        refs[v] = _greedy_reference(m, e32[v], new)
-    logits32 = m(inputs_embeds=e32["noise"]).logits[:, -1]
-    m16 = m.to(bf)
-    e16, thrs = {}, {}
-    for v, vol in vols.items():
-        e16[v], _ = O.prepare_inputs_for_multimodal(sd16, sd16["model.embed_tokens.weight"], ids, vol.to(bf), qids, oc)
-        l16 = m16(inputs_embeds=e16[v]).logits[0, -1].float()
-        thrs[v] = 4 * float((l16 - refs[v][2]).abs().max())
-        if v == "noise":
-            logits16 = l16[None]
+    import e2e_config3 as R
+    # The HOST reference is four full-size oracle passes + four decoder runs on the CPU (fp32 and bf16, both volumes).  Its fp32
+    # side and the two flip thresholds depend on seeds only: tests/golden/config3_e2e_ref.npz holds them (made by
+    # tests/golden/make_config3_e2e.py from R.reference_live -- the definition used here when the fixture is absent or
+    # U2_LIVE_ORACLE=1 asks for the whole live run, 2 to 5 minutes of host time).  The bf16 run the distances are measured
+    # against stays live, on this host, next to the HIP run (R.bf16_noise_run: one oracle pass + one decoder forward).
+    s = R.setup(mm_config, oracle_cfg)
+    ref = R.load(s)
+    reference_source = "fp32 side + thresholds: tests/golden/config3_e2e_ref.npz; bf16 yardstick: live on this host"
+    if ref is None:
+        ref, reference_source = R.reference_live(s), "computed live on this host"
+    else:
+        ref.update(R.bf16_noise_run(s))
+    vols, ids, qids, new = s.vols, s.ids, s.qids, R.NEW
+    e32n, e16n, logits32, logits16, refs, thrs = (ref[k] for k in ("e32_noise", "e16_noise", "logits32", "logits16", "refs", "thrs"))
+    m16 = s.m.to(bf)
     mg = m16.to(D)
     vol = vols["noise"]
     out = mg(images=vol.to(D), input_ids=ids.to(D), question_ids=qids.to(D))
@@ -297,7 +277,7 @@ def test_config3_end_to_end_first_step_logits_and_greedy_ids():
            for v, x in vols.items()}
     # how far apart equally correct bf16 orderings of the ViT attention land after the chain (see gate(chained=True))
     from u2tokenizer_amd import ops
-    spread = {"flash_double_pipeline (default)": {"vs_o32": err_stats(emb.float().cpu(), e32["noise"])["rel_rms"]}}
+    spread = {"flash_double_pipeline (default)": {"vs_o32": err_stats(emb.float().cpu(), e32n)["rel_rms"]}}
     for name, opt, val, back in (("flash_128_row_units", "flash_mode", 1, 0), ("unfused_attention", "vit_flash", 0, 1)):
         ops.set_option(opt, val)
         try:
@@ -306,12 +286,11 @@ def test_config3_end_to_end_first_step_logits_and_greedy_ids():
         finally:
             ops.set_option(opt, back)
             mg.get_model().get_vision_tower().invalidate_feature_cache()
-        spread[name] = {"vs_o32": err_stats(alt, e32["noise"])["rel_rms"], "vs_default": err_stats(alt, emb.float().cpu())["rel_rms"]}
-    tn, ts = e32["noise"][0, 1:257], e32["smooth"][0, 1:257]
-    rep = {"hip_rounding_spread_inputs_embeds": spread, "decoder": "Qwen3-8B width (4096 / 12288, 32 q / 8 kv heads of 128), 4 layers, "
+        spread[name] = {"vs_o32": err_stats(alt, e32n)["rel_rms"], "vs_default": err_stats(alt, emb.float().cpu())["rel_rms"]}
+    rep = {"hip_rounding_spread_inputs_embeds": spread, "host_reference": reference_source, "decoder": "Qwen3-8B width (4096 / 12288, 32 q / 8 kv heads of 128), 4 layers, "
            "helpers.decisive_decoder_(dseed 0); fused HIP prefill + decode",
-           "inputs_embeds": three_way(emb, e32["noise"], e16["noise"]), "logits_last": three_way(out.logits[:, -1], logits32, logits16),
-           "aligned_tokens_smooth_vs_noise_rel_rms": float((tn - ts).pow(2).mean().sqrt() / tn.pow(2).mean().sqrt())}
+           "inputs_embeds": three_way(emb, e32n, e16n), "logits_last": three_way(out.logits[:, -1], logits32, logits16),
+           "aligned_tokens_smooth_vs_noise_rel_rms": ref["aligned_rel_rms"]}
     try:
         _id_gate(rep, gen, refs, thrs)
     finally:
@@ -320,6 +299,7 @@ def test_config3_end_to_end_first_step_logits_and_greedy_ids():
     gate(rep["logits_last"], "config3 e2e logits", chained=True)
 
 
+@pytest.mark.host_heavy(15)   # nominal seconds, mostly host (tests/suite_budget.py)
 def test_float16_model_under_autocast():
     """evalscipt/ourmodel_amos.py:33,70: the whole model in float16, generate under torch.autocast.  Round 5: the path modules
     run the IEEE-half build of the library on the fp16 parameters themselves (fp32 accumulation; round 4 computed through a
@@ -383,6 +363,7 @@ def test_float16_model_under_autocast():
     assert n >= 3 and gen.shape == gen32.sequences.shape, (gen, gen32.sequences, margins, thr)
 
 
+@pytest.mark.host_heavy(28)   # nominal seconds, mostly host (tests/suite_budget.py)
 def test_config2_full_path_vs_oracle():
     """BASELINE configs[1]: E = 2048, 128^3 volumes = 4 chunks of (32,128,128), batch 4, full tokenizer."""
     c = mm_config(2048, [32, 128, 128])
@@ -481,6 +462,7 @@ def test_tokenizer_one_layer_full_width(E):
     assert d["hip_vs_o32"]["rel_rms"] < 0.5 * d["permuted_rows_vs_o32"]["rel_rms"], d
 
 
+@pytest.mark.host_heavy(39)
 @pytest.mark.parametrize("E", [4096])
 def test_tokenizer_layers_teacher_forced_full_width(E):
     """Every layer of the 4-layer tokenizer at full width on NON-collapsed inputs, in ONE forward of the product path.
