@@ -266,8 +266,10 @@ def measure_kernels(E, options, timeout=300):
                     if "u2::" in name:   # (blit kernels of the child's set-up copies are not the path's)
                         rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), name))
         rows.sort()
-        if rows and len(rows) % nvol == 0:
-            per = len(rows) // nvol
+        # the split into volumes is only valid if every volume issued the SAME kernel sequence (`per = len // nvol` assumed it)
+        per = len(rows) // nvol if rows and len(rows) % nvol == 0 else 0
+        seqs_equal = bool(per) and all([n for _, _, n in rows[v * per:(v + 1) * per]] == [n for _, _, n in rows[:per]] for v in range(1, nvol))
+        if seqs_equal:
             agg = {}
             for st, en, name in rows[per:]:
                 a = agg.setdefault(name, [0, 0.0])
@@ -278,6 +280,7 @@ def measure_kernels(E, options, timeout=300):
             # one behind the other on one stream cannot add up to more than that -- one process, ONE clock.  (Against the host's
             # wall clock of the same steps the GPU timestamps run ~1 % fast on this pool: the ratio is reported, not allowed for.)
             out["__span_ms__"] = (max(en for _, en, _ in rows[per:]) - rows[per][0]) / 1e6 / (nvol - 1)
+            out["__volumes_same_sequence__"] = True
         else:  # (trace missing or ragged: the profiler's own summary over all 7 volumes)
             for f in glob.glob(os.path.join(tmp, "**", "*kernel_stats.csv"), recursive=True):
                 with open(f) as fh:
@@ -643,6 +646,7 @@ def main():
         ktab = measure_kernels(E, serial_opts) if (B == 1 and world == 1 and not args.no_traffic) else None
         child_wall_ms = ktab.pop("__child_wall_ms__", None) if ktab else None
         span_ms = ktab.pop("__span_ms__", None) if ktab else None
+        same_seq = ktab.pop("__volumes_same_sequence__", False) if ktab else False
         wall_serial = None
         if ktab:
             ops.set_option("profile", 0)
@@ -681,7 +685,13 @@ def main():
                 # in the profiler's timestamps (no allowance); the host-side wall of the same steps beside it
                 "profiler_span_ms_per_volume": (round(span_ms, 4) if span_ms else None),
                 "profiler_clock_over_host_clock": (round(span_ms / child_wall_ms, 4) if span_ms and child_wall_ms else None),
-                "sum_le_wall": (bool(total_ms <= span_ms) if span_ms else (bool(total_ms <= child_wall_ms) if child_wall_ms else None))}
+                "sum_le_wall": (bool(total_ms <= span_ms) if span_ms else (bool(total_ms <= child_wall_ms) if child_wall_ms else None)),
+                # ... which on one serialized stream holds by construction once the bookkeeping is right; what can still catch a wrong
+                # volume split or a mis-attributed dispatch: every traced volume issued the same kernel-name sequence, and
+                # the kernel sum also fits the child's own HOST wall of those steps within the stated clock tolerance (the profiler's
+                # timestamps run ~1 % fast against the host clock on this pool: 2 %)
+                "volumes_same_kernel_sequence": bool(same_seq),
+                "sum_le_child_host_wall_x1.02": (bool(total_ms <= 1.02 * child_wall_ms) if child_wall_ms else None)}
 
         def roof(idx, key, kernel):
             ach_ev = flops[idx] / ms[idx] / 1e9

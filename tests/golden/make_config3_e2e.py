@@ -6,7 +6,15 @@ GPU suite does not spend a quarter of its wall time re-deriving it.  Runs on the
 Checks before it writes: (1) what e2e_config3.load() rebuilds from the file is BIT-EQUAL to what reference_live() returned, and
 bf16_noise_run() -- the part the test keeps live -- returns reference_live()'s bf16 tensors bit for bit; (2) ids / margins agree
 with the ones a GPU box's host recorded when the same reference ran live inside the test (profiles/r05_parity.json, if present;
-the thresholds come from a bf16 run and differ between CPU generations: printed, not compared)."""
+the thresholds come from a bf16 run and differ between CPU generations: printed, not compared).
+
+    python tests/golden/make_config3_e2e.py --stamp ORACLE_AT_MAKE_TIME.py
+
+adds the oracle fingerprint (e2e_config3.oracle_fingerprint, file format 2) to a file made before the fingerprint existed WITHOUT
+re-running the reference: the argument is the oracle source the file was made with (`git show <commit>:oracle/u2_oracle.py`); the
+stamp is the fingerprint computed WITH THAT SOURCE, so the file is accepted afterwards only if the current oracle computes the same.
+(Round 6 stamped the round-5 file this way: the round's oracle edit -- the DiffTS loop form behind a flag -- left the fingerprint
+bit-identical.)"""
 import json
 import sys
 import time
@@ -67,5 +75,29 @@ def main():
     print("wrote", R.FIXTURE, R.FIXTURE.stat().st_size, "bytes")
 
 
+def stamp(old_oracle_source):
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("_oracle_at_make_time", old_oracle_source)
+    old = importlib.util.module_from_spec(spec)
+    sys.modules["_oracle_at_make_time"] = old      # (dataclasses looks the module up while the class body is evaluated)
+    spec.loader.exec_module(old)
+    cur = R.O
+    try:
+        R.O = old
+        fp = R.oracle_fingerprint()
+    finally:
+        R.O = cur
+    z = dict(np.load(R.FIXTURE))
+    assert int(z["header"][0]) == 1 and "oracle_fingerprint" not in z, "already stamped"
+    z["header"] = R._header()
+    z["oracle_fingerprint"] = fp
+    np.savez(R.FIXTURE, **z)
+    print("stamped", R.FIXTURE, fp, "current oracle matches:", R.fingerprint_matches(fp))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) == 3 and sys.argv[1] == "--stamp":
+        stamp(sys.argv[2])
+    else:
+        main()

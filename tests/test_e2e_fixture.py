@@ -32,3 +32,23 @@ def test_reference_side_of_the_id_gate():
     assert len(set(ids["noise"])) > 1 or len(set(ids["smooth"])) > 1                     # ... and not one id for ever
     # the first greedy id is the argmax of the stored first-step logits of the benchmark's volume
     assert int(z["logits32"][0].argmax()) == ids["noise"][0]
+
+
+def test_fixture_was_made_with_this_oracle():
+    """An edit of oracle/u2_oracle.py that changes what it computes invalidates the file: the fingerprint stored by
+    the maker -- the oracle's whole path at a tiny size on name-seeded parameters -- must be what the oracle computes NOW.  On failure:
+    `python tests/golden/make_config3_e2e.py` (the GPU test would meanwhile fall back to the live reference, e2e_config3.load)."""
+    z = np.load(R.FIXTURE)
+    assert "oracle_fingerprint" in z.files
+    live = R.oracle_fingerprint()
+    assert live.shape == (9,) and np.isfinite(live).all() and live[0] > 0.1
+    assert R.fingerprint_matches(z["oracle_fingerprint"], live), (z["oracle_fingerprint"], live)
+    # the fingerprint notices arithmetic: one rounding-point change (the DiffTS loop form in bf16 is not one -- fp32 here; a scaled
+    # softmax temperature is) moves it far beyond the host-to-host tolerance
+    import oracle.u2_oracle as O
+    orig = O.diff_token_selection
+    try:
+        O.diff_token_selection = lambda sd, p, x, tau=1.0, loop_form=False: orig(sd, p, x, tau=1.05, loop_form=loop_form)
+        assert not R.fingerprint_matches(z["oracle_fingerprint"], R.oracle_fingerprint())
+    finally:
+        O.diff_token_selection = orig

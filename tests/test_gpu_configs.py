@@ -3,7 +3,7 @@ host (same name-seeded "lively" parameters, same inputs), stage by stage.
 
 For every stage the three distances SURVEY.md section 8(d) asks for are computed -- |hip - oracle_fp32|,
 |hip - oracle_bf16|, |oracle_bf16 - oracle_fp32| -- gated with the bar of tests/test_gpu_path.py (the HIP path may be no
-further from the fp32 reference than 1.5x the bf16 reference run is) and written to gpurun_out/r05_parity.json, from
+further from the fp32 reference than 1.5x the bf16 reference run is) and written to gpurun_out/r06_parity.json, from
 where the round's copy under profiles/ is taken.
 """
 import json
@@ -34,17 +34,7 @@ def _gpu():
     yield
 
 
-def record(key, value):
-    """Merge {key: value} into gpurun_out/r05_parity.json (best effort: the numbers are also asserted)."""
-    out = ROOT / "gpurun_out"
-    try:
-        out.mkdir(exist_ok=True)
-        p = out / "r05_parity.json"
-        data = json.loads(p.read_text()) if p.exists() else {}
-        data[key] = value
-        p.write_text(json.dumps(data, indent=1, sort_keys=True))
-    except OSError:
-        pass
+from suite_budget import record  # noqa: E402  (merges {key: value} into gpurun_out/r06_parity.json)
 
 
 def three_way(hip, o32, o16):
@@ -192,6 +182,19 @@ def run_full_config(name, c, B, C, S, Lt, seed, vocab=4096):
            "host_threads": torch.get_num_threads(), "stages": {}}
     for st in ("vit", "spp", "tokenizer", "inputs_embeds"):
         rep["stages"][st] = three_way(hip[st], o32[st], o16[st])
+    # The bf16 yardstick's DiffTS in the REFERENCE's own bf16 arithmetic (svr.py:112-115 rounds every w * x product to bf16; the oracle's
+    # default is one matmul, which is more accurate -- VERDICT r5 weak #6): where the 1024-head loop is affordable on the host, the
+    # tokenizer stage of the bf16 run is redone in that form and both distances are reported; the gate below keeps the matmul form,
+    # whose distance is the smaller (stricter) denominator.
+    spp16 = o16["spp"].view(B, C, -1, o16["spp"].shape[-1])
+    if c["enable_diffts"] and B * C * spp16.shape[2] * c["u2t_top_k"] * c["hidden_size"] <= 5e9:
+        import dataclasses
+        tt = torch.nn.functional.embedding(qids, sd16["model.embed_tokens.weight"])
+        t0 = time.perf_counter()
+        o16l, _ = O.tokenizer_forward(sd16, "model.u2tokenizer", spp16, tt, dataclasses.replace(oc, diffts_loop_form=True))
+        rep["stages"]["tokenizer"]["diffts_loop_form_yardstick"] = {
+            "o16loop_vs_o32": err_stats(o16l.float(), o32["tokenizer"]), "o16loop_vs_o16": err_stats(o16l.float(), o16["tokenizer"].float()),
+            "hip_vs_o16loop": err_stats(hip["tokenizer"].float().cpu(), o16l.float()), "seconds": time.perf_counter() - t0}
     record(name, rep)
     for st in rep["stages"]:
         assert torch.isfinite(hip[st].float()).all(), st
@@ -396,7 +399,7 @@ def test_config1_survey_size_through_qwen3():
     qids = synth.synth_ids(1, Lt, 40, vocab, seed=seed, name="question_ids")
     oc = oracle_cfg(c)
     new = 4
-    e32, refs, idx32 = {}, {}, None
+    e32, refs, idx32, idx16 = {}, {}, None, None
     for v, vol in vols.items():
         e32[v], idx = O.prepare_inputs_for_multimodal(sd32, sd32["model.embed_tokens.weight"], ids, vol.float(), qids, oc)
         idx32 = idx if v == "noise" else idx32
@@ -405,22 +408,42 @@ def test_config1_survey_size_through_qwen3():
     m16 = m.to(bf)
     e16, thrs = {}, {}
     for v, vol in vols.items():
-        e16[v], _ = O.prepare_inputs_for_multimodal(sd16, sd16["model.embed_tokens.weight"], ids, vol.to(bf), qids, oc)
+        e16[v], idx = O.prepare_inputs_for_multimodal(sd16, sd16["model.embed_tokens.weight"], ids, vol.to(bf), qids, oc)
+        idx16 = idx if v == "noise" else idx16
         l16 = m16(inputs_embeds=e16[v]).logits[0, -1].float()
         thrs[v] = 4 * float((l16 - refs[v][2]).abs().max())
         if v == "noise":
             logits16 = l16[None]
     mg = m16.to(D)
     vol = vols["noise"]
+    tok = mg.get_u2tokenizer()
+    tok.capture_svr_tokens = True
     r = mg.prepare_inputs_for_multimodal(ids.to(D), None, None, None, None, vol.to(D), qids.to(D))
     assert r[0] is None and r[4].shape == (1, S, E)
+    # north_star's "bit-exact token indices" AT THE PATH: the indices the HIP path selected inside this whole
+    # forward are, index for index and in order, what the oracle's TokenSelection (svr.py:75-91) selects from the refined tokens the
+    # HIP selection stage itself saw.  Against the fp32 run end to end the measure can only be SET agreement -- and the yardstick for
+    # that is the reference's own bf16 run, recorded beside it (is ITS index list equal to the fp32 one on these inputs?).
+    ih = tok.last_topk_indices.cpu()
+    svr = tok.last_svr_tokens.cpu()
+    T_ = vol.shape[1]
+    _, oidx = O.token_selection(sd16, "model.u2tokenizer.svt_module.token_selection",
+                                svr.view(1, T_, svr.shape[1] // T_, E), c["u2t_top_k"])
+    assert torch.equal(ih, oidx), "hard top-k indices differ from the oracle's selection on the HIP path's own SVR output"
+    tok.capture_svr_tokens = False
     out = mg(images=vol.to(D), input_ids=ids.to(D), question_ids=qids.to(D))
-    topk_equal = bool(torch.equal(mg.get_u2tokenizer().last_topk_indices.cpu(), idx32))
+    topk_equal = bool(torch.equal(tok.last_topk_indices.cpu(), idx32))
+    k_ = c["u2t_top_k"]
+    ov = lambda a, b: len(set(a[0].tolist()) & set(b[0].tolist())) / k_  # noqa: E731
     gen = {v: mg.generate(x.to(D), ids.to(D), question_ids=qids.to(D), max_new_tokens=new, do_sample=False).cpu()[0].tolist()
            for v, x in vols.items()}
     rep = {"inputs_embeds": three_way(r[4], e32["noise"], e16["noise"]), "logits_last": three_way(out.logits[:, -1], logits32, logits16),
-           "topk_idx_equal_fp32": topk_equal}
+           "topk_idx_equal_fp32": topk_equal, "topk_idx_equal_fp32_of_the_bf16_oracle": bool(torch.equal(idx16, idx32)),
+           "topk_set_overlap_fp32": ov(ih, idx32), "topk_set_overlap_fp32_of_the_bf16_oracle": ov(idx16, idx32),
+           "topk_idx_equal_oracle_on_own_svr_output": True}
     try:
+        # end to end the HIP selection is as close to the fp32 one as the reference's own bf16 run is (one index of slack)
+        assert rep["topk_set_overlap_fp32"] >= rep["topk_set_overlap_fp32_of_the_bf16_oracle"] - 1.0 / k_ - 1e-9, rep
         _id_gate(rep, gen, refs, thrs)
     finally:
         record("config1_E2048_64cube_qwen3", rep)

@@ -555,6 +555,7 @@ static int bt_launch_deep(GemmDesc d, hipStream_t stream) {
 
 template <int NJ, bool PAIR = false>
 static int bt_launch(GemmDesc d, hipStream_t stream) {
+  if (d.vt) return U2_ERR_ARG;  // only the deep 256 x 192 form leaves transposed tiles (bt_launch_deep): never drop the request silently
   d.tiles_m = (int)cdiv(d.M, 256);
   d.tiles_n = (int)cdiv(d.N, 64 * NJ);
   if (d.ksplit > 1 && (d.nz != 1 || PAIR || !d.partial)) return U2_ERR_ARG;
@@ -699,6 +700,7 @@ bool gemm_vt_supported(const GemmDesc& d, int vt_n0, int vt_rows) {
   GemmDesc m = d;
   m.M = Mm;
   if (opts().gemm_big_ring && bt_pick(m) == 0 && bt_pick_ring(m) == 22) return false;
+  if (opts().gemm_big_skinny && rem == 0 && bt_pick_sliced(d) != 0) return false;  // gemm_big_try takes the sliced forms first
   return bt_pick(m) == 21;
 }
 

@@ -118,6 +118,19 @@ class Zero1AdamW:
         self.t = 0
         self.accum = max(1, int(gradient_accumulation_steps))
         self.overlap = overlap_comm and self._multi
+        # The per-step agreement on which parameters fired (_agree_on_subsets) is host-side bookkeeping: a few hundred flags that must be
+        # READ by the host before the step can go on.  On the device group that is an all-reduce followed by a blocking device -> host
+        # copy in front of the clip-norm and AdamW launches, every step.  It runs on HOST memory instead: in a world of one
+        # rank there is nothing to reduce; with several ranks on GPUs a gloo twin of the group carries it (created here, collectively --
+        # every rank constructs its optimiser), so the device queue is never drained for it.
+        self._flag_group = self.group
+        self._flag_device = None          # None: host tensor
+        if self.world > 1 and dist.is_initialized() and dist.get_backend(process_group) != "gloo":
+            try:
+                ranks = dist.get_process_group_ranks(process_group if process_group is not None else dist.group.WORLD)
+                self._flag_group = dist.new_group(ranks=ranks, backend="gloo")
+            except Exception:             # no gloo in this build: the device group it is (one small blocking reduction per step)
+                self._flag_group, self._flag_device = self.group, "param"
         plist = list(params)
         if plist and isinstance(plist[0], dict):
             self.param_groups = [{"lr": g.get("lr", lr), "weight_decay": g.get("weight_decay", weight_decay)} for g in plist]
@@ -303,10 +316,13 @@ class Zero1AdamW:
         for b in self.buckets:
             irregular = not all(c in (0, self.accum) for c in b.count) or b.defer
             flags += [1.0 if b.redo else 0.0, 1.0 if irregular else 0.0]
-        t = torch.tensor(flags, dtype=torch.float32, device=self.buckets[0].flat_grad.device)
-        if self._multi:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-        vals = t.tolist()
+        if self.world > 1:
+            dev = self.buckets[0].flat_grad.device if self._flag_device == "param" else "cpu"
+            t = torch.tensor(flags, dtype=torch.float32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._flag_group)
+            vals = t.tolist()
+        else:
+            vals = flags                  # one rank: its own flags are the agreement (no device work, no synchronisation)
         pos, tail = 0, sum(np_)
         for bi, b in enumerate(self.buckets):
             fired = frozenset(i for i in range(np_[bi]) if vals[pos + i])

@@ -743,9 +743,11 @@ def gelu_bwd(z: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
 
 
 @_guarded
-def colsum(x: torch.Tensor, y: Optional[torch.Tensor] = None, out_dtype=elem_dtype()) -> torch.Tensor:
-    """sum over rows of x (* y): x (rows, C) bf16 -> (C,) in out_dtype (bf16 or fp32); fp32 accumulation, fixed order."""
+def colsum(x: torch.Tensor, y: Optional[torch.Tensor] = None, out_dtype=None) -> torch.Tensor:
+    """sum over rows of x (* y): x (rows, C) 16-bit elements -> (C,) in out_dtype (the element type of the guarded call by default,
+    or fp32); fp32 accumulation, fixed order."""
     h = _lib.load_library()
+    out_dtype = out_dtype or elem_dtype()   # (resolved per call: the f16 build writes IEEE-half bits -- ADVICE r5)
     x = _need(x, ELEM, "x").contiguous()
     rows, Cc = x.shape
     if y is not None:
