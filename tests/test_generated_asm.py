@@ -384,9 +384,11 @@ def test_generated_asm_passes_the_hazard_lint():
     for inc in ("flash_dp2_asm.inc", "gemm_bt_asm.inc"):
         for name, lines in asm_lint.blocks(str(CSRC / inc)):
             seen += 1
-            assert len(lines) > 200
+            assert len(lines) > 190
             assert asm_lint.lint(name, lines) == []
-    assert seen == 11  # flash KV loop (exact / pre-scaled x plain / timed), GEMM K loop NJ = 4, NJ = 3, NJ = 3 SwiGLU-pair, NJ = 2 ring, two deep forms + the transposed-tile twin
+    # flash KV loop (exact / pre-scaled x plain / timed), GEMM K loop NJ = 4, NJ = 3, NJ = 3 SwiGLU-pair, NJ = 2 ring, two deep forms + the
+    # transposed-tile twin; round 6: the deep 256 x 192 loop on literal accumulators (+ twin), three drain forms, accumulator zero / read-out
+    assert seen == 18
     # the linter itself: each rule fires on a minimal violation
     bad = {
         "R1": ["v_exp_f32 v1, v1", "v_add_f32 v2, v1, v1"],
@@ -394,7 +396,234 @@ def test_generated_asm_passes_the_hazard_lint():
         "R3": ["v_mfma_f32_32x32x16_bf16 v[16:31], v[0:3], v[4:7], 0", "v_max3_f32 v50, v16, v17, v18"],
         "R4": ["v_mov_b32 v2, v3", "v_permlane32_swap_b32 v2, v3"],
         "R5": ["ds_read_b128 v[0:3], v9 offset:0", "s_waitcnt lgkmcnt(2)"],
+        "R6": ["v_pk_mul_f32 v[2:3], v[2:3], v[2:3]", "v_rcp_f32 v2, v2"],
     }
+    assert len(asm_lint.lint("R3a", ["v_mfma_f32_32x32x16_bf16 a[0:15], v[0:3], v[4:7], a[0:15]", "v_accvgpr_read_b32 v9, a3"])) == 1
     for rule, text in bad.items():
         errs = asm_lint.lint(rule, text)
         assert len(errs) == 1 and rule in errs[0]
+
+
+# ---- round 6: the drain forms of the deep 256 x 192 loop (tools/gen_gemm_bt_asm.py: gen_deep_drain) ---------------------------------
+def _grab(name):
+    import re
+    text = (CSRC / "gemm_bt_asm.inc").read_text()
+    return re.findall(r'"(.*)\\n"', re.search(rf"#define {name} \\\n(.*?)\n#define", text, re.S).group(1))
+
+
+def test_gemm_bt_literal_accumulator_twins():
+    """GEMM_BT_ASM_TEXT_NJ3_DB_FX / _FX_T (the first tile of a drain-kernel workgroup): the deep 256 x 192 loops line for line, with
+    accumulator (i, j) = the literal tuple a[16 (3 i + j) : + 15] instead of an operand."""
+    import re
+    for sfx in ("", "_T"):
+        ref, fx = _grab("GEMM_BT_ASM_TEXT_NJ3_DB" + sfx), _grab("GEMM_BT_ASM_TEXT_NJ3_DB_FX" + sfx)
+        assert len(ref) == len(fx)
+        for a, b in zip(ref, fx):
+            want = re.sub(r"%\[c(\d)(\d)(\d)\]", lambda m: "a[%d:%d]" % (16 * (3 * (2 * int(m.group(1)) + int(m.group(2))) + int(m.group(3))),
+                                                                       16 * (3 * (2 * int(m.group(1)) + int(m.group(2))) + int(m.group(3))) + 15), a)
+            assert b == want, (a, b)
+
+
+def _drain_parts(name):
+    """-> (lines before the per-wave loops, {wave: {body label: lines}})"""
+    lines = _grab(name)
+    head = lines[:lines.index("s_cmp_eq_u32 %[wave], 1")]
+    bodies = {w: {} for w in range(4)}
+    import re
+    cur = None
+    for l in lines:
+        m = re.match(r"\.Lbd_([db])(\d)_(\d+)_%=:", l)
+        if m:
+            cur = (int(m.group(2)), m.group(1) + m.group(3))
+            bodies[cur[0]][cur[1]] = []
+        elif l.startswith(".Lbd_w") or l.startswith(".Lbd_done"):
+            cur = None
+        elif cur:
+            bodies[cur[0]][cur[1]].append(l)
+    return head, bodies
+
+
+def test_gemm_bt_drain_schedule_stores_and_counted_waits():
+    """Per wave: twelve drain bodies (two turns of the six stage pairs) + the six plain bodies; every body is a K iteration of the deep
+    loop (48 MFMAs, 8 + 6 pieces, 28 fragment reads, one barrier).  Each of the 24 hold groups is stored exactly once, 16 bytes per lane from its
+    own four registers, even groups at offset 0 and odd ones at 32 of the running scalar offset, which advances once per pair; the stores sit
+    between the iteration's last shallow piece and the counted wait, which names exactly the deep pieces + the stores in front of it (so
+    that "everything older has landed" still holds on the one in-order counter).  The GELU form stores pair b from body b + 1 (its
+    instructions fill body b) and the last pair behind D11."""
+    import re
+    for name, gelu in (("GEMM_BT_ASM_TEXT_NJ3_DB_DRAIN", False), ("GEMM_BT_ASM_TEXT_NJ3_DB_DRAIN_T", False),
+                       ("GEMM_BT_ASM_TEXT_NJ3_DB_DRAIN_GELU", True)):
+        head, bodies = _drain_parts(name)
+        sda = int(re.search(r"s_lshl_b32 s(\d+), %\[wave\], 13", "\n".join(head)).group(1))
+        for w in range(4):
+            assert list(bodies[w]) == [f"d{b}" for b in range(12)] + [f"b{u}" for u in range(6)]
+            stored = []
+            for lab, bl in bodies[w].items():
+                assert sum(l.startswith("v_mfma") for l in bl) == 48 and sum(l.startswith("ds_read_b128") for l in bl) == 28
+                assert sum(l.startswith("buffer_load_dwordx4") for l in bl) == 14 and bl.count("s_barrier") == 1
+                bar = bl.index("s_barrier")
+                st = [k for k, l in enumerate(bl) if l.startswith("buffer_store_dwordx4")]
+                in_front = [k for k in st if k < bar]
+                assert bl[bar - 1] == f"s_waitcnt vmcnt({6 + len(in_front)})"
+                # the stores in front of the wait come behind the last SHALLOW (A) piece in front of it
+                a_pieces = [k for k, l in enumerate(bl[:bar]) if re.match(rf"s_add_u32 m0, s{sda}, ", l)]
+                assert not in_front or min(in_front) > max(a_pieces)
+                for k in st:
+                    m = re.match(r"buffer_store_dwordx4 v\[(\d+):(\d+)\], %\[voff\], s\[72:75\], s57 offen offset:(\d+)", bl[k])
+                    g, rem = divmod(int(m.group(1)) - 132, 4)
+                    assert rem == 0 and int(m.group(2)) == int(m.group(1)) + 3 and int(m.group(3)) == 32 * (g & 1)
+                    stored.append((lab, g, k > bar))
+                if lab.startswith("b"):
+                    assert not st
+                # the running store offset advances once per stored pair: + the column-block stride twice, then the row-block adjustment
+                adv = [l for l in bl if l.startswith("s_add_u32 s57, s57,")]
+                b = int(lab[1:]) if lab.startswith("d") else None
+                pair = None if b is None else (b - 1 if gelu else b)
+                if pair is not None and pair >= 0:
+                    assert adv == [f"s_add_u32 s57, s57, {'s78' if pair % 3 < 2 else 's58'}"], (lab, adv)
+                else:
+                    assert adv == []
+            assert sorted(g for _, g, _ in stored) == list(range(24))
+            for lab, g, behind in stored:
+                b = int(lab[1:])
+                assert g // 2 == (b - 1 if gelu and not (b == 11 and behind) else b) or (gelu and b == 11 and behind and g // 2 == 11), (lab, g)
+        if gelu:       # every hold register of pair b is rewritten (packed GELU results) inside body b, before its stores one body later
+            for w in range(4):
+                for b in range(12):
+                    bl = bodies[w][f"d{b}"]
+                    cv = [int(re.match(r"v_cvt_pk_bf16_f32 v(\d+),", l).group(1)) for l in bl if l.startswith("v_cvt_pk_bf16_f32")]
+                    assert sorted(cv) == list(range(132 + 8 * b, 132 + 8 * b + 8))
+                    assert sum(l.startswith("v_rcp_f32") for l in bl) == 16
+
+
+def test_gemm_bt_drain_convert_puts_every_element_where_its_store_writes_it():
+    """Executable spec of CONVERT + the drain stores: the accumulator layout of v_mfma_f32_32x32x16 (lane = row / column, register r =
+    (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the other index) is pushed symbolically through every flavour's instruction stream --
+    v_accvgpr_read, packed math (element-wise), v_cvt_pk (pairs), v_permlane32_swap (upper half of the first operand <-> lower half of the
+    second), the bias reads -- and through the store addressing (lane offset + running scalar offset + immediate).  Row-major flavours must
+    deliver C[m][n] for all 128 x 96 elements of the wave tile with bias[n] added to column n; the transposed flavour the V^T layout of
+    vt_epilogue (gemm_bt.hip): element (m, n) at n * vt_ld + position, position = 16-key group order [0-3, 8-11, 4-7, 12-15]."""
+    import re
+    head, bodies = _drain_parts("GEMM_BT_ASM_TEXT_NJ3_DB_DRAIN")
+    i0 = next(k for k, l in enumerate(head) if l.startswith("s_cmp_eq_u32 s80,"))
+    conv = head[i0:]
+    # flavour code -> its straight-line instruction list
+    labels = {int(m.group(1)): k for k, l in enumerate(conv) for m in [re.match(r"\.Lcv_(\d+)_%=:", l)] if m}
+    first = next(k for k, l in enumerate(conv) if l.startswith("v_accvgpr_read_b32"))
+    starts = dict(labels)
+    starts[0] = first - 1
+    ldc, vt_ld = 1000, 5000
+    for code in (0, 2, 4, 6, 1, 3):
+        vt, bias = bool(code & 1), bool(code & 4)
+        k = starts[code] + 1
+        V = {}                                       # (vgpr, lane) -> symbolic value
+        B = {}                                       # pending bias reads: handled immediately (LDS returns in order, waits are the lint's job)
+        zeroed, read = set(), set()
+        while not (conv[k].startswith("s_branch") or conv[k].startswith(".Lcv_")):
+            l = conv[k]
+            k += 1
+            m = re.match(r"v_accvgpr_read_b32 v(\d+), a(\d+)", l)
+            if m:
+                a = int(m.group(2))
+                read.add(a)
+                i, j, r = a // 48, (a // 16) % 3, a % 16
+                for lane in range(64):
+                    other = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+                    V[int(m.group(1)), lane] = {"m": 32 * i + (other if vt else (lane & 31)), "n": 32 * j + ((lane & 31) if vt else other), "bias": None}
+                continue
+            m = re.match(r"v_accvgpr_write_b32 a(\d+), 0", l)
+            if m:
+                assert int(m.group(1)) in read
+                zeroed.add(int(m.group(1)))
+                continue
+            m = re.match(r"ds_read_b128 v\[(\d+):\d+\], %\[vbias\] offset:(\d+)", l)
+            if m:
+                for q in range(4):
+                    for lane in range(64):
+                        V[int(m.group(1)) + q, lane] = ("biasval", int(m.group(2)) // 4 + 4 * (lane >> 5) + q)   # vbias carries 16 hi bytes
+                continue
+            m = re.match(r"v_pk_(mul|add|fma)_f32 v\[(\d+):\d+\], v\[(\d+):\d+\], v\[(\d+):\d+\](?:, v\[(\d+):\d+\])?", l)
+            if m:
+                d, a_, b_ = int(m.group(2)), int(m.group(3)), int(m.group(4))
+                breg = {"add": b_, "fma": int(m.group(5)) if m.group(5) else None, "mul": None}[m.group(1)]
+                for q in range(2):
+                    for lane in range(64):
+                        x = dict(V[a_ + q, lane])
+                        if breg is not None:
+                            tag, n = V[breg + q, lane]
+                            assert tag == "biasval" and x["bias"] is None
+                            x["bias"] = n
+                        V[d + q, lane] = x
+                continue
+            m = re.match(r"v_cvt_pk_bf16_f32 v(\d+), v(\d+), v(\d+)", l)
+            if m:
+                for lane in range(64):
+                    V[int(m.group(1)), lane] = (V[int(m.group(2)), lane], V[int(m.group(3)), lane])
+                continue
+            m = re.match(r"v_permlane32_swap_b32 v(\d+), v(\d+)", l)
+            if m:
+                a_, b_ = int(m.group(1)), int(m.group(2))
+                for lane in range(32):
+                    V[a_, lane + 32], V[b_, lane] = V[b_, lane], V[a_, lane + 32]
+                continue
+            assert l.startswith(("s_waitcnt lgkmcnt", "s_nop")), l
+        assert read == zeroed == set(range(192))
+        # the stores of wave 0's drain bodies: pair b at scalar offset s_base + rb * S_rb + ni * S_ni (S: strides of the flavour), + 32 t
+        S_rb, S_ni = (64, 2 * 32 * vt_ld) if vt else (2 * 32 * ldc, 64)
+        seen = {}
+        for b in range(12):
+            for l in bodies[0][f"d{b}"]:
+                m = re.match(r"buffer_store_dwordx4 v\[(\d+):\d+\],.* offset:(\d+)", l)
+                if not m:
+                    continue
+                soff = (b // 3) * S_rb + (b % 3) * S_ni + int(m.group(2))
+                for lane in range(64):
+                    l31, hi = lane & 31, lane >> 5
+                    voff = 2 * ((l31 * vt_ld + 8 * hi) if vt else (l31 * ldc + 8 * hi))
+                    for q in range(4):
+                        for half in range(2):
+                            e_ = V[int(m.group(1)) + q, lane][half]
+                            addr = (voff + soff) // 2 + 2 * q + half           # element index relative to the wave tile's origin
+                            assert addr not in seen
+                            seen[addr] = e_
+        assert len(seen) == 128 * 96
+        for addr, e_ in seen.items():
+            if vt:
+                n, pos = divmod(addr, vt_ld)
+                grp, p = divmod(pos, 16)
+                key = 16 * grp + [0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15][p]
+                assert (e_["m"], e_["n"], e_["bias"]) == (key, n, None), (code, addr, e_)
+            else:
+                m_, n = divmod(addr, ldc)
+                assert (e_["m"], e_["n"]) == (m_, n) and e_["bias"] == (n if bias else None), (code, addr, e_)
+
+
+def test_gemm_bt_drain_kernel_keeps_the_compiler_out_of_the_accumulator_file(tmp_path):
+    """gemm_bt_drain_kernel names a0 .. a191 literally and lists them as clobbers of its statements -- no C++ object holds the
+    accumulators, so nothing but an audit of the compiled kernel can show that hipcc leaves them alone between the statements (a spill into the
+    accumulator file, a v_accvgpr_* of its own): between the zeroing statement and the read-out, every instruction that touches an AGPR, and
+    every scratch access, must sit inside an asm statement.  (cdna_hip_programming.md section 5.7, item 4.)"""
+    import re
+    out = tmp_path / "gemm_bt.s"
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", str(CSRC / "gemm_bt.hip"),
+                    "-o", str(out)], check=True, capture_output=True, cwd=CSRC, timeout=900)
+    text = out.read_text()
+    kernels = re.findall(r"^(_ZN2u220gemm_bt_drain_kernel\w+):.*?s_endpgm", text, re.S | re.M)
+    assert len(kernels) == 6
+    for k in kernels:
+        body = text[text.index("\n" + k + ":"):]
+        body = body[:body.index("s_endpgm")].splitlines()
+        marks = [i for i, l in enumerate(body) if "#ASMSTART" in l or "#ASMEND" in l]
+        assert len(marks) % 2 == 0 and len(marks) >= 12
+        inside = [False] * len(body)
+        for a, b in zip(marks[::2], marks[1::2]):
+            for i in range(a, b + 1):
+                inside[i] = True
+        # the read-out statement is the last one that names an accumulator register
+        last_acc_stmt = max(b for a, b in zip(marks[::2], marks[1::2]) if any("v_accvgpr_read_b32" in l for l in body[a:b]))
+        for i in range(marks[0], last_acc_stmt):
+            if not inside[i]:
+                code = body[i].split(";")[0]
+                touched = [int(x) for x in re.findall(r"\ba(\d+)\b", code)] + [int(x) for pr in re.findall(r"\ba\[(\d+):(\d+)\]", code) for x in pr]
+                # (a192 and up are the compiler's: it parks VGPRs there around the statements, which clobber v56 .. v255)
+                assert all(a >= 192 for a in touched) and "scratch_" not in code, (k, i, body[i])

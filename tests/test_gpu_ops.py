@@ -581,6 +581,66 @@ def test_gemm_big_tile_variants(ops, variant):
         ops.set_option("gemm_big", 0)
 
 
+@pytest.mark.parametrize("M,N,K,grid", [(1024, 768, 768, 4), (512, 1536, 1536, 4), (2048, 384, 768, 3), (768, 1152, 2304, 2)])
+def test_gemm_big_tile_drain_form(ops, M, N, K, grid):
+    """Round 6, gemm_bt_drain_kernel (variant 27): tile i's epilogue under tile i + 1's K loop -- CONVERT packs the accumulators into 96
+    registers at the start of the next tile's asm statement, the K loop's first twelve iterations store them (and, in the GELU form,
+    evaluate the GELU on the held values from the MFMA slots).  A small persistent grid gives every workgroup 2-5 tiles at test size
+    (first tile: plain deep loop; middle tiles: CONVERT + drain loop, K = 768 exits behind the twelfth drain body, K = 1536 / 2304 run on
+    into the plain bodies; last tile: the exposed epilogue in HIP).
+    Plain / bias / alpha forms: the arithmetic of the deep 256 x 192 form (variant 24) -- BIT-identical outputs.
+    GELU form: the pre-activation is rounded to the element type first (the reference's own rounding point: nn.Linear hands nn.GELU a
+    bf16 tensor) -- bit-identical to `gelu_fwd(gemm(..., bias))`, i.e. the library's GELU kernel on the stored pre-activation."""
+    a, b, bias = rnd(M, K, seed=51), rnd(N, K, scale=0.05, seed=52), rnd(N, seed=53)
+    ad, bd, biasd = a.to(D), b.to(D), bias.to(D)
+    base = a.float() @ b.float().t()
+    ops.set_option("gemm_big_grid", grid)
+    try:
+        got, ref = {}, {}
+        for variant, res in ((24, ref), (27, got)):
+            ops.set_option("gemm_big", variant)
+            res["plain"] = [ops.gemm(ad, bd).clone() for _ in range(3)]
+            res["bias"] = [ops.gemm(ad, bd, bias=biasd).clone() for _ in range(3)]
+            res["alpha"] = [ops.gemm(ad, bd, alpha=0.37).clone()]
+            res["alpha_bias"] = [ops.gemm(ad, bd, bias=biasd, alpha=0.37).clone()]
+            if variant == 27:
+                res["gelu"] = [ops.gemm(ad, bd, bias=biasd, gelu=True).clone() for _ in range(3)]
+        for k, outs in got.items():
+            assert all(torch.equal(outs[0], o) for o in outs[1:]), k            # repeatable
+        for k in ("plain", "bias", "alpha", "alpha_bias"):
+            assert torch.equal(got[k][0], ref[k][0]), (k, (got[k][0].float() - ref[k][0].float()).abs().max().item())
+        close_bf16(got["plain"][0], base)
+        close_bf16(got["alpha_bias"][0], 0.37 * base + bias.float())
+        assert torch.equal(got["gelu"][0], ops.gelu_fwd(ref["bias"][0]))
+        close_bf16(got["gelu"][0], F.gelu(base + bias.float()), rounds=4)
+    finally:
+        ops.set_option("gemm_big", 0)
+        ops.set_option("gemm_big_grid", 256)
+
+
+def test_gemm_drain_form_by_heuristic_with_cls_rows(ops):
+    """The heuristic's own choice at the ViT's row count shape (rows = k 256 + 8 cls rows, K = 768): with gemm_big_drain on, the many-row
+    part runs the drain form and the 8 tail rows ride in the same launch; outputs equal the drain-less launch bit for bit (plain and
+    bias epilogues), the GELU product equals the library's GELU kernel on the stored pre-activation in its many rows."""
+    M, N, K = 8 * 256 + 8, 1536, 768
+    a, b, bias = rnd(M, K, seed=61), rnd(N, K, scale=0.05, seed=62), rnd(N, seed=63)
+    ad, bd, biasd = a.to(D), b.to(D), bias.to(D)
+    ops.set_option("gemm_big_grid", 16)        # 8 x 8 tiles on 16 workgroups: four tiles each
+    try:
+        res = {}
+        for drain in (0, 1):
+            ops.set_option("gemm_big_drain", drain)
+            res[drain] = (ops.gemm(ad, bd).clone(), ops.gemm(ad, bd, bias=biasd).clone(), ops.gemm(ad, bd, bias=biasd, gelu=True).clone())
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        close_bf16(res[1][1], a.float() @ b.float().t() + bias.float())
+        assert torch.equal(res[1][2][:M - 8], ops.gelu_fwd(res[0][1])[:M - 8])
+        close_bf16(res[1][2], F.gelu(a.float() @ b.float().t() + bias.float()), rounds=4)
+        assert torch.equal(res[1][2][M - 8:], res[0][2][M - 8:])      # the cls rows: the few-rows arithmetic either way
+    finally:
+        ops.set_option("gemm_big_drain", 1)
+        ops.set_option("gemm_big_grid", 256)
+
+
 @pytest.mark.parametrize("variant,slices", [(21, 2), (21, 8), (20, 5), (21, 3), (20, 2), (22, 8), (22, 3)])
 def test_gemm_big_tile_k_slices(ops, variant, slices):
     """The big-tile kernel with its K range cut into slices (fp32 partial sums in the stream's scratch, epilogue applied by the

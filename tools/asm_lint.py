@@ -14,6 +14,9 @@ place them by hand.  This linter re-checks the rules those generators rely on, o
   R4  v_permlane32_swap needs 2 wait states after a VALU write of one of its operands, and its results 2 before use.
   R5  every s_waitcnt lgkmcnt(N) inside an MFMA slot sequence must have N <= number of LDS reads issued since the last
       lgkmcnt(0) drain (a larger N would be a wait that can never protect anything: a generator bug).
+  R6  the result of a packed-fp32 instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two passes) must not be read by the
+      very next instruction (hipcc separates such pairs with `s_nop 0`; the drain forms' GELU interleaves four chains instead).
+Accumulator registers named literally (a5, a[16:31]: the drain forms) are tracked like VGPRs for R3.
 
     python tools/asm_lint.py u2tokenizer_amd/csrc/flash_dp_asm.inc u2tokenizer_amd/csrc/gemm_bt_asm.inc
 """
@@ -25,13 +28,13 @@ TRANS = ("v_exp_f32", "v_rcp_f32", "v_log_f32", "v_rsq_f32", "v_sqrt_f32")
 
 def regs(tok):
     """registers named by one operand token: 'v12' -> {v12}; 'v[4:7]' -> {v4..v7}; '-%[mr0]' -> {%mr0}; else empty"""
-    tok = tok.strip().lstrip("-")
-    m = re.fullmatch(r"v(\d+)", tok)
+    tok = tok.strip().lstrip("-").strip("|").split(" ")[0]
+    m = re.fullmatch(r"([va])(\d+)", tok)
     if m:
-        return {f"v{m.group(1)}"}
-    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        return {f"{m.group(1)}{m.group(2)}"}
+    m = re.fullmatch(r"([va])\[(\d+):(\d+)\]", tok)
     if m:
-        return {f"v{i}" for i in range(int(m.group(1)), int(m.group(2)) + 1)}
+        return {f"{m.group(1)}{i}" for i in range(int(m.group(2)), int(m.group(3)) + 1)}
     m = re.fullmatch(r"%\[(\w+)\]", tok)
     if m:
         return {"%" + m.group(1)}
@@ -41,7 +44,7 @@ def regs(tok):
 def parse(line):
     """-> (opcode, dst register set, src register set)"""
     op, _, rest = line.partition(" ")
-    rest = re.sub(r"\boffset:\d+|\boffen\b|\blds\b|\boff\b", "", rest)
+    rest = re.sub(r"\boffset:\d+|\boffen\b|\blds\b|\boff\b|\b(op_sel_hi|op_sel|neg_lo|neg_hi):\[[\d,]+\]|\bclamp\b", "", rest)
     toks = [t for t in re.split(r",\s*", rest.strip()) if t]
     if not toks:
         return op, set(), set()
@@ -56,6 +59,7 @@ def parse(line):
 def lint(name, lines):
     errs = []
     last_trans = None            # registers written by the previous instruction if it was transcendental
+    last_pk = None               # ... if it was packed fp32 math
     prev_wrote_m0 = False
     mfma_age = {}                # vgpr -> wait states since an MFMA wrote it
     valu_age = {}                # vgpr -> wait states since a VALU wrote it (for R4)
@@ -76,6 +80,7 @@ def lint(name, lines):
                     for r, a in snap.items():
                         cur[r] = min(cur.get(r, 10 ** 9), a)
             last_trans = None
+            last_pk = None
             prev_wrote_m0 = False
             continue
         mb = re.match(r"s_c?branch\w* (\S+)$", line)
@@ -94,6 +99,9 @@ def lint(name, lines):
         # R1
         if last_trans and is_valu and (src & last_trans):
             errs.append(f"{name}:{n}: R1 '{line}' reads a transcendental result without a wait state")
+        # R6
+        if last_pk and (is_valu or is_mem or op.startswith("v_mfma")) and (src & last_pk):
+            errs.append(f"{name}:{n}: R6 '{line}' reads a packed-math result in the next issue slot")
         # R2
         if prev_wrote_m0 and " lds" in line + " ":
             errs.append(f"{name}:{n}: R2 '{line}' directly follows the M0 write")
@@ -136,7 +144,8 @@ def lint(name, lines):
             for r in dst:
                 valu_age[r] = 0
                 mfma_age.pop(r, None)
-        last_trans = dst if op in TRANS else None
+        last_trans = dst if op.split("_e64")[0] in TRANS else None
+        last_pk = dst if op.startswith(("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32")) else None
         prev_wrote_m0 = bool(re.match(r"s_(mov_b32|add_u32) m0,", line))
     return errs
 

@@ -87,7 +87,12 @@ def bfrag(b, j):
     return vr(BUF + 32 * b + 16 + 4 * j, 4)
 
 
+FIXED_ACC = [False]   # True: accumulator (i, j) is the literal tuple a[16 (NJ i + j) : +15] (the drain forms pin the accumulator file)
+
+
 def acc(i, j):
+    if FIXED_ACC[0]:
+        return f"a[{16 * (NJ * i + j)}:{16 * (NJ * i + j) + 15}]"
     return f"%[c{i >> 1}{i & 1}{j}]"
 
 
@@ -636,6 +641,319 @@ def gen_deep(nj, deep):
     return vhi
 
 
+# ---- drain forms (round 6): tile i's epilogue under the K loop of tile i + 1 ------------------------------------------------
+# What the K = 768 products of the ViT lose is not their K loop but the seam between two output tiles of a workgroup: the accumulators
+# are the only copy of the tile, so swap -> scale / bias (-> GELU) -> pack -> store (25 MB per round of tiles, all 256 workgroups at
+# once) runs with the matrix pipe idle, and the next tile's first vmcnt wait queues behind the stores (profiles/r03_bt_epilogue_*.log:
+# 15 of the q|k|v product's 70 us are its three store bursts; fc1 + GELU 115 us against 80 for the plain product).  The drain forms of
+# the deep 256 x 192 loop split the epilogue in two:
+#   CONVERT  (exposed, ~1 us per tile): at the START of the asm statement of tile i + 1 the 192 accumulator registers of tile i are
+#            read, scaled / biased in fp32 and packed to 96 registers of 16-bit elements (v132..v227, "hold"; 24 groups of 4 = 24
+#            16-byte stores), in the row-major order a store wants (v_permlane32_swap on the PACKED pairs: 2 per group instead of 4);
+#            the accumulators are zeroed on the way.  A transposed tile (the q|k|v product's V tiles) packs 8 keys of one column.
+#   DRAIN    (hidden): K iteration b (0..11) of tile i + 1 stores groups 2 b, 2 b + 1 from two MFMA slots; in the GELU form it first
+#            runs gelu_fast2's instruction sequence (common.h; the very opcodes hipcc emits for it, four pairs interleaved) on the
+#            held pre-activations from the slots of the whole iteration.  The held pre-activation is ROUNDED to the element type
+#            first -- the reference's own rounding point (its nn.Linear returns bf16 before nn.GELU sees it).
+# Static placement needs the iteration index in the code: the loop is unrolled over 12 "drain" bodies D0..D11 (two turns of the 6
+# stage pairs) followed by the 6 plain bodies for longer K; a tile must start at stage pair 0, i.e. nkt % 6 == 0 and nkt >= 12 (the
+# ViT: K = 768, 3072), and the statement is only used for the second and later tiles of a workgroup (first = 0: K tile 0 landed, K
+# tile 1 in flight).  The stores ride the vector-memory counter the counted waits rely on: they are issued behind the iteration's
+# last shallow-operand piece, so vmcnt(6 + 2) in front of the barrier still means "everything older has landed" (gfx9: loads and
+# stores retire in order on one counter), and they have a whole iteration to complete.
+# Registers: accumulators are the literal a[0:191] (operands pin them: "+{a[32 k : 32 k + 31]}"), hold v132..v227, temporaries
+# v228..v255, s57..s71, parameters of the tile being drained in the pinned block s[72:87].
+HOLD, TMP = 132, 228
+S_CUR, S_ADJ, S_F = 57, 58, 59
+SG_C, SG_MASK, SG_P6, SG_P4, SG_P3, SG_P2, SG_P1 = 60, 61, 62, 64, 66, 68, 70
+PRM = 72            # s[72:75] store descriptor, s76 byte offset of the wave tile, s77 / s78 strides per 32-row block / 32-column block,
+                    # s79 alpha (bits), s80 flags: 1 = transposed tile, 2 = alpha != 1, 4 = bias
+V_P5 = TMP + 24
+GELU_BLOCKS = [int(c) for c in (sys.argv[sys.argv.index("--gelu-blocks") + 1] if "--gelu-blocks" in sys.argv else "12")]
+V_AL = TMP + 26
+GELU_CONST = {SG_C: 0x3f3504f3, SG_MASK: 0x7fffffff, SG_P6: 0x38349f67, SG_P4: 0x391f6607, SG_P3: 0x3c17e369, SG_P2: 0x3d2d2fe7,
+              SG_P1: 0x3d906e67}
+P5_BITS = 0x39910039
+
+
+def hold(g, k=0):
+    return HOLD + 4 * g + k
+
+
+def convert(vt, scale, bias):
+    """accumulators -> hold, one flavour.  Group g = 2 (3 rb + ni) + t: registers 8 t .. 8 t + 7 of accumulator (rb, ni)."""
+    T = [TMP + k for k in range(8)]
+    B = [[TMP + 8 + k for k in range(8)], [TMP + 16 + k for k in range(8)]]
+
+    def bias_reads(g):
+        rb_ni, t = divmod(g, 2)
+        ni = rb_ni % 3
+        off = (32 * ni + 16 * t) * 4
+        e(f"ds_read_b128 {vr(B[g & 1][0], 4)}, %[vbias] offset:{off}")
+        e(f"ds_read_b128 {vr(B[g & 1][4], 4)}, %[vbias] offset:{off + 32}")
+
+    if bias:
+        bias_reads(0)
+    for g in range(24):
+        a0 = 16 * (g >> 1) + 8 * (g & 1)
+        for k in range(8):
+            e(f"v_accvgpr_read_b32 {v(T[k])}, a{a0 + k}")
+        if bias and g + 1 < 24:
+            bias_reads(g + 1)
+        for k in range(8):
+            e(f"v_accvgpr_write_b32 a{a0 + k}, 0")
+        if scale and not bias:
+            for k in range(0, 8, 2):
+                e(f"v_pk_mul_f32 {vr(T[k], 2)}, {vr(T[k], 2)}, {vr(V_AL, 2)}")
+        if bias:
+            e(f"s_waitcnt lgkmcnt({2 if g + 1 < 24 else 0})")
+            for k in range(0, 8, 2):
+                if scale:   # acc * alpha + bias as ONE fused multiply-add: what hipcc makes of the other forms' epilogues (fp contraction)
+                    e(f"v_pk_fma_f32 {vr(T[k], 2)}, {vr(T[k], 2)}, {vr(V_AL, 2)}, {vr(B[g & 1][k], 2)}")
+                else:
+                    e(f"v_pk_add_f32 {vr(T[k], 2)}, {vr(T[k], 2)}, {vr(B[g & 1][k], 2)}")
+        for k in range(4):
+            e(f"v_cvt_pk_bf16_f32 {v(hold(g, k))}, {v(T[2 * k])}, {v(T[2 * k + 1])}")
+        if not vt:
+            e("s_nop 1")
+            e(f"v_permlane32_swap_b32 {v(hold(g, 0))}, {v(hold(g, 2))}")
+            e(f"v_permlane32_swap_b32 {v(hold(g, 1))}, {v(hold(g, 3))}")
+
+
+def gelu_chunk(g):
+    """gelu_fast2 (common.h) on the 8 held values of group g, in place: the instruction sequence hipcc emits for it, the four pairs
+    interleaved (a packed-math result is read 4 issues later: its one wait state and the transcendental's are both covered)."""
+    X = [TMP + 2 * q for q in range(4)]          # pairs: x, then the result
+    A = [TMP + 8 + 2 * q for q in range(4)]
+    P = [TMP + 16 + 2 * q for q in range(4)]
+    ins = []
+    for q in range(4):
+        ins.append(f"v_lshlrev_b32 {v(X[q])}, 16, {v(hold(g, q))}")
+        ins.append(f"v_and_b32 {v(X[q] + 1)}, 0xffff0000, {v(hold(g, q))}")
+    steps = [
+        lambda q: f"v_mul_f32_e64 {v(A[q])}, |{v(X[q])}|, {s(SG_C)}",
+        lambda q: f"v_mul_f32_e64 {v(A[q] + 1)}, |{v(X[q] + 1)}|, {s(SG_C)}",
+        lambda q: f"v_pk_fma_f32 {vr(P[q], 2)}, {vr(A[q], 2)}, s[{SG_P6}:{SG_P6 + 1}], {vr(V_P5, 2)} op_sel_hi:[1,0,0]",
+        lambda q: f"v_pk_fma_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, {vr(A[q], 2)}, s[{SG_P4}:{SG_P4 + 1}] op_sel_hi:[1,1,0]",
+        lambda q: f"v_pk_mul_f32 {vr(X[q], 2)}, {vr(X[q], 2)}, 0.5 op_sel_hi:[1,0]",
+        lambda q: f"v_pk_fma_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, {vr(A[q], 2)}, s[{SG_P3}:{SG_P3 + 1}] op_sel_hi:[1,1,0]",
+        lambda q: f"v_pk_fma_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, {vr(A[q], 2)}, s[{SG_P2}:{SG_P2 + 1}] op_sel_hi:[1,1,0]",
+        lambda q: f"v_pk_fma_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, {vr(A[q], 2)}, s[{SG_P1}:{SG_P1 + 1}] op_sel_hi:[1,1,0]",
+        lambda q: f"v_pk_fma_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, {vr(A[q], 2)}, 1.0 op_sel_hi:[1,1,0]",
+        lambda q: f"v_pk_mul_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, {vr(P[q], 2)}",
+        lambda q: f"v_pk_mul_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, {vr(P[q], 2)}",
+        lambda q: f"v_pk_mul_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, {vr(P[q], 2)}",
+        lambda q: f"v_pk_mul_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, {vr(P[q], 2)}",
+        lambda q: f"v_rcp_f32 {v(P[q])}, {v(P[q])}",
+        lambda q: f"v_rcp_f32 {v(P[q] + 1)}, {v(P[q] + 1)}",
+        lambda q: f"v_pk_add_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, 1.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]",
+        # (the sign of z = x / sqrt 2 is the sign of 0.5 x: the un-halved x is gone by now, its half has the same sign bit)
+        lambda q: f"v_bfi_b32 {v(P[q] + 1)}, {s(SG_MASK)}, {v(P[q] + 1)}, {v(X[q] + 1)}",
+        lambda q: f"v_bfi_b32 {v(P[q])}, {s(SG_MASK)}, {v(P[q])}, {v(X[q])}",
+        lambda q: f"v_pk_add_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, 1.0 op_sel_hi:[1,0]",
+        lambda q: f"v_pk_mul_f32 {vr(X[q], 2)}, {vr(X[q], 2)}, {vr(P[q], 2)}",
+    ]
+    for st in steps:
+        for q in range(4):
+            ins.append(st(q))
+    for q in range(4):
+        ins.append(f"v_cvt_pk_bf16_f32 {v(hold(g, q))}, {v(X[q])}, {v(X[q] + 1)}")
+    return ins
+
+
+def store(g):
+    return f"buffer_store_dwordx4 {vr(hold(g), 4)}, %[voff], s[{PRM}:{PRM + 3}], {s(S_CUR)} offen offset:{32 * (g & 1)}"
+
+
+def gen_deep_drain(swap, gelu):
+    global NJ
+    NJ = 3
+    del out[:]
+    FIXED_ACC[0] = True
+    SWAP[0] = swap
+    SA, SB, L = 2, 3, 6
+    nslot, nread, npb = 4 * NJ, 4 + NJ, 2 * NJ
+    BSTG, OFFB, VB = NJ * 8192, 32768 * SA, 56
+    XAA = [[VB + 4 * st + k for k in range(4)] for st in range(SA)]
+    XAB = [[VB + 4 * SA + 4 * st + k for k in range(4)] for st in range(SB)]
+    XBUF = VB + 4 * (SA + SB)
+    assert XBUF + 2 * nread * 4 == HOLD
+
+    def xa(b, i):
+        return vr(XBUF + 4 * nread * b + 4 * i, 4)
+
+    def xb(b, j):
+        return vr(XBUF + 4 * nread * b + 16 + 4 * j, 4)
+
+    def xread(b, sa, sb, kk, n):
+        order = [("a", 0)] + [("b", j) for j in range(NJ)] + [("a", 1), ("a", 2), ("a", 3)]
+        m, idx = order[n]
+        if m == "a":
+            e(f"ds_read_b128 {xa(b, idx)}, {v(XAA[sa][kk])} offset:{4096 * idx}")
+        else:
+            e(f"ds_read_b128 {xb(b, idx)}, {v(XAB[sb][kk])} offset:{4096 * idx}")
+
+    def xpiece(mat, p, st, s_k):
+        if mat == "a":
+            e(f"s_add_u32 m0, {s(S_DA)}, {32768 * st + 1024 * p}")
+        else:
+            e(f"s_add_u32 m0, {s(S_DB)}, {BSTG * st + 1024 * p}")
+        row = (S_ROWA if mat == "a" else S_ROWB)[p >> 1]
+        e(f"s_add_u32 {s(S_TMP)}, {s(s_k[0] if mat == 'a' else s_k[1])}, {s(row)}")
+        e(f"buffer_load_dwordx4 %[v{mat}{p & 1}], %[rs{mat}], {s(S_TMP)} offen lds")
+
+    dmat, smat = "b", "a"
+    npc = {"a": 8, "b": npb}
+    window = 2 * nslot
+    sched = {m: {w: {} for w in range(4)} for m in "ab"}
+    for m in "ab":
+        for i in range(npc[m]):
+            for w in range(4):
+                g = (i * 4 + w) * window // (4 * npc[m])
+                sched[m][w].setdefault(g, []).append(i)
+    K1, K2 = (S_K1A, S_K1B), (S_K2A, S_K2B)
+    # ---- setup (common)
+    for k in range(4):
+        if k:
+            e(f"v_xor_b32 {v(XAA[0][k])}, {32 * k}, %[aa0]")
+            e(f"v_xor_b32 {v(XAB[0][k])}, {32 * k}, %[ab0]")
+        else:
+            e(f"v_mov_b32 {v(XAA[0][0])}, %[aa0]")
+            e(f"v_mov_b32 {v(XAB[0][0])}, %[ab0]")
+    for st in range(1, SA):
+        for k in range(4):
+            e(f"v_add_u32 {v(XAA[st][k])}, {32768 * st}, {v(XAA[0][k])}")
+    for st in range(1, SB):
+        for k in range(4):
+            e(f"v_add_u32 {v(XAB[st][k])}, {BSTG * st}, {v(XAB[0][k])}")
+    e(f"s_mov_b32 {s(S_ROWA[0])}, 0")
+    for q in (1, 2, 3):
+        e(f"s_add_u32 {s(S_ROWA[q])}, {s(S_ROWA[q - 1])}, %[lda16]")
+    e(f"s_mov_b32 {s(S_ROWB[0])}, 0")
+    for q in (1, 2, 3):
+        e(f"s_add_u32 {s(S_ROWB[q])}, {s(S_ROWB[q - 1])}, %[ldb16]")
+    e(f"s_mov_b32 {s(S_KT)}, 0")
+    e(f"s_lshl_b32 {s(S_DA)}, %[wave], 13")
+    e(f"s_mul_i32 {s(S_DB)}, %[wave], {2048 * NJ}")
+    e(f"s_add_u32 {s(S_DB)}, {s(S_DB)}, {OFFB}")
+    e(f"s_add_u32 {s(S_K1A)}, %[base_a], 128")
+    e(f"s_add_u32 {s(S_K1B)}, %[base_b], 128")
+    e(f"s_add_u32 {s(S_K2A)}, %[base_a], 256")
+    e(f"s_add_u32 {s(S_K2B)}, %[base_b], 256")
+    # store offsets of the tile being drained: pair b = (32-row block b / 3, 32-column block b % 3)
+    e(f"s_mov_b32 {s(S_CUR)}, {s(PRM + 4)}")
+    e(f"s_lshl_b32 {s(S_ADJ)}, {s(PRM + 6)}, 1")
+    e(f"s_sub_u32 {s(S_ADJ)}, {s(PRM + 5)}, {s(S_ADJ)}")
+    if gelu:
+        for r, bits in GELU_CONST.items():
+            e(f"s_mov_b32 {s(r)}, 0x{bits:08x}")
+    # ---- CONVERT: the accumulators hold the previous tile of this workgroup (18 wait states behind its last MFMA: the previous
+    # statement ended with s_nop 15 / s_nop 7)
+    e(f"v_mov_b32 {v(V_AL)}, {s(PRM + 7)}")
+    e(f"v_mov_b32 {v(V_AL + 1)}, {s(PRM + 7)}")
+    flavours = [(0, 0, 0, 0), (2, 0, 1, 0), (4, 0, 0, 1), (6, 0, 1, 1)] + ([] if gelu else [(1, 1, 0, 0), (3, 1, 1, 0)])
+    for (code, vt, sc, bi) in flavours[1:]:
+        e(f"s_cmp_eq_u32 {s(PRM + 8)}, {code}")
+        e(f"s_cbranch_scc1 .Lcv_{code}_%=")
+    for n, (code, vt, sc, bi) in enumerate(flavours):
+        if n:
+            e(f".Lcv_{code}_%=:")
+        convert(vt, sc, bi)
+        if n + 1 < len(flavours):
+            e("s_branch .Lcv_done_%=")
+    e(".Lcv_done_%=:")
+    if gelu:
+        e(f"v_mov_b32 {v(V_P5)}, 0x{P5_BITS:08x}")     # (behind CONVERT: its bias double buffer uses the register)
+    for w in (1, 2, 3):
+        e(f"s_cmp_eq_u32 %[wave], {w}")
+        e(f"s_cbranch_scc1 .Lbd_w{w}_%=")
+    for w in range(4):
+        if w:
+            e(f".Lbd_w{w}_%=:")
+        e("s_waitcnt lgkmcnt(0)")
+        for n in range(nread):
+            xread(0, 0, 0, 0, n)
+        st_slot = (nread + (w + 2) % 4)      # the store's slot in k16 steps 1 and 2: no fragment read, none of this wave's pieces
+        for body in range(12 + L):
+            drain = body < 12
+            u = body % L
+            e(f".Lbd_{'d' if drain else 'b'}{w}_{body if drain else u}_%=:")
+            sa, sb = u % SA, u % SB
+            na, nb = (u + 1) % SA, (u + 1) % SB
+            st_of = {"a": sa, "b": sb}
+            shallow_next = (st_of[smat] + 1) % 2
+            deep_tgt = (st_of[dmat] + 2) % 3
+            # drain work of this body: slot (0..47, k16 step major) -> instructions
+            work = {}
+            nstore = 0
+            if drain:
+                if gelu:
+                    ins = gelu_chunk(2 * body) + gelu_chunk(2 * body + 1)
+                    # Which k16 steps carry the GELU instructions (--gelu-blocks, default "12"): an iteration is as long as the latency
+                    # of the SHALLOW operand's K tile, whose last pieces leave in step 0 and are waited for behind step 2 -- steps 1 and
+                    # 2 run in that latency's shadow, instructions in steps 3 and 0 sit in front of the pieces and stretch the chain
+                    # (measured: spread over all four steps the GELU costs what it costs exposed, profiles/r06_drain_probe.log)
+                    slots = [b_ * nslot + sl for b_ in GELU_BLOCKS for sl in range(nslot)]
+                    for n_, sl in enumerate(slots):
+                        work[sl] = ins[n_ * len(ins) // len(slots):(n_ + 1) * len(ins) // len(slots)]
+                    if body:                                   # the pair finished by the previous body
+                        work[nslot + st_slot] = work.get(nslot + st_slot, []) + [store(2 * body - 2)]
+                        work[2 * nslot + st_slot] = work.get(2 * nslot + st_slot, []) + [store(2 * body - 1)]
+                        nstore = 2
+                else:
+                    work[nslot + st_slot] = [store(2 * body)]
+                    work[2 * nslot + st_slot] = [store(2 * body + 1)]
+                    nstore = 2
+
+            def xk(blk, items, rb, rsa, rsb, rkk):
+                def f(slot):
+                    if slot < nread:
+                        xread(rb, rsa, rsb, rkk, slot)
+                    for (m, i, st, s_k) in items.get(slot, []):
+                        xpiece(m, i, st, s_k)
+                    for ins_ in work.get(blk * nslot + slot, []):
+                        e(ins_)
+                return f
+
+            def win(m, half, st, s_k):
+                return {slot: [(m, i, st, s_k) for i in sched[m][w].get(half * nslot + slot, [])] for slot in range(nslot)}
+
+            IN_LOOP[0] = True
+            mfma_block(0, xk(0, win(smat, 1, shallow_next, K1), 1, sa, sb, 1), xa, xb)
+            mfma_block(1, xk(1, win(dmat, 0, deep_tgt, K2), 0, sa, sb, 2), xa, xb)
+            mfma_block(0, xk(2, win(dmat, 1, deep_tgt, K2), 1, sa, sb, 3), xa, xb)
+            e(f"s_waitcnt vmcnt({npc[dmat] + nstore})")
+            e("s_barrier")
+            mfma_block(1, xk(3, win(smat, 0, st_of[smat], K2), 0, na, nb, 0), xa, xb)
+            IN_LOOP[0] = False
+            if drain and (not gelu or body):
+                e(f"s_add_u32 {s(S_CUR)}, {s(S_CUR)}, {s(PRM + 6) if ((body - 1 if gelu else body) % 3) < 2 else s(S_ADJ)}")
+            if gelu and body == 11:
+                e(store(22))
+                e(store(23))
+            e(f"s_add_u32 {s(S_KT)}, {s(S_KT)}, 1")
+            e(f"s_mov_b32 {s(S_K1A)}, {s(S_K2A)}")
+            e(f"s_mov_b32 {s(S_K1B)}, {s(S_K2B)}")
+            e(f"s_add_u32 {s(S_K2A)}, {s(S_K2A)}, 128")
+            e(f"s_add_u32 {s(S_K2B)}, {s(S_K2B)}, 128")
+            e(f"s_add_u32 {s(S_TMP)}, {s(S_KT)}, 2")
+            e(f"s_cmp_eq_u32 {s(S_TMP)}, %[nkt]")
+            e(f"s_cselect_b32 {s(S_K2A)}, %[nbase_a], {s(S_K2A)}")
+            e(f"s_cselect_b32 {s(S_K2B)}, %[nbase_b], {s(S_K2B)}")
+            if body == 11 or (not drain and u == L - 1):
+                e(f"s_cmp_lt_u32 {s(S_KT)}, %[nkt]")
+                e(f"s_cbranch_scc{'0' if body == 11 else '1'} .Lbd_{'done' if body == 11 else f'b{w}_0'}_%=")
+            # (a tile ends behind D11 or behind the last plain body: nkt is a multiple of 6 and at least 12)
+        if w < 3:
+            e("s_branch .Lbd_done_%=")
+    e(".Lbd_done_%=:")
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_nop 15")
+    e("s_nop 7")
+    FIXED_ACC[0] = False
+    SWAP[0] = False
+
+
 # ---- measured and removed in round 4 (history: commits "eight-wave forms ...", "L2-prefetch trial ...") ----------------------------
 #  * eight-wave forms of all three tile widths (two waves per SIMD, 128 x 64 / 64 x 96 / 64 x 64 accumulators per wave): tie the
 #    four-wave loops on every shape (profiles/r04_bt8_vit.log, r04_bt8_tok.log) -- the K loop is not bound by one wave's in-order issue.
@@ -675,6 +993,22 @@ for nj, deep, swap in ((3, "b", False), (4, "b", False), (3, "b", True)):
     print(f"#define GEMM_BT_ASM_TEXT_NJ{nj}_D{deep.upper()}{'_T' if swap else ''} \\")
     for i, line in enumerate(out):
         print(f'  "{line}\\n"' + (" \\" if i + 1 < len(out) else ""))
+# round 6: the deep 256 x 192 loops on the PINNED accumulator file (a[0:191] literal) -- the first tile of a workgroup of the drain kernel --
+# and the drain forms (gen_deep_drain): plain, transposed tile, GELU
+for swap in (False, True):
+    ABL.clear()
+    FIXED_ACC[0], SWAP[0] = True, swap
+    gen_deep(3, "b")
+    FIXED_ACC[0], SWAP[0] = False, False
+    print(f"#define GEMM_BT_ASM_TEXT_NJ3_DB_FX{'_T' if swap else ''} \\")
+    for i, line in enumerate(out):
+        print(f'  "{line}\\n"' + (" \\" if i + 1 < len(out) else ""))
+for swap, gelu in ((False, False), (True, False), (False, True)):
+    ABL.clear()
+    gen_deep_drain(swap, gelu)
+    print(f"#define GEMM_BT_ASM_TEXT_NJ3_DB_DRAIN{'_T' if swap else ''}{'_GELU' if gelu else ''} \\")
+    for i, line in enumerate(out):
+        print(f'  "{line}\\n"' + (" \\" if i + 1 < len(out) else ""))
 for name, lo, hi in (("GEMM_BT_ASM_CLOBBERS", VLO, VHI), ("GEMM_BT_ASM_CLOBBERS_RING", RVLO, RVHI),
                      ("GEMM_BT_ASM_CLOBBERS_NJ3_DEEP", 56, deep_hi[(3, "b")]), ("GEMM_BT_ASM_CLOBBERS_NJ4_DEEP", 56, deep_hi[(4, "b")])):
     clob = [f'"v{i}"' for i in range(lo, hi + 1)] + [f'"s{i}"' for i in range(SLO, SHI + 1)] + ['"scc"', '"memory"']
@@ -682,4 +1016,25 @@ for name, lo, hi in (("GEMM_BT_ASM_CLOBBERS", VLO, VHI), ("GEMM_BT_ASM_CLOBBERS_
     for i in range(0, len(clob), 12):
         tail = ", \\" if i + 12 < len(clob) else ""
         print("  " + ", ".join(clob[i:i + 12]) + tail)
+# the drain statements: the K loop's registers, the hold and the temporaries, s36..s71 (the accumulators are pinned operands)
+clob = [f'"v{i}"' for i in range(56, 256)] + [f'"s{i}"' for i in range(SLO, 72)] + ['"scc"', '"memory"']
+print("#define GEMM_BT_ASM_CLOBBERS_DRAIN \\")
+for i in range(0, len(clob), 12):
+    print("  " + ", ".join(clob[i:i + 12]) + (", \\" if i + 12 < len(clob) else ""))
+# the accumulator file of the drain kernel: named literally by its statements, which list it as clobbered (no operand carries it: the
+# compiler would shuttle 192 loop-carried values through VGPRs and scratch around every statement) -- gemm_bt.hip, gemm_bt_drain_kernel
+clob = [f'"a{i}"' for i in range(192)]
+print("#define GEMM_BT_ASM_CLOBBERS_ACC192 \\")
+for i in range(0, len(clob), 12):
+    print("  " + ", ".join(clob[i:i + 12]) + (", \\" if i + 12 < len(clob) else ""))
+print("#define GEMM_BT_ASM_TEXT_ACC192_ZERO \\")
+for i in range(192):
+    print(f'  "v_accvgpr_write_b32 a{i}, 0\\n"' + (" \\" if i < 191 else ""))
+# read-out of the accumulator file into the pinned VGPR tuples v[56 + 16 k : 71 + 16 k] (k = 3 i + j: accumulator (i, j)); opens with the
+# wait states an MFMA result needs before a VALU may read it (the K loop's own tail has them too: harmless twice)
+print("#define GEMM_BT_ASM_TEXT_ACC192_READ \\")
+print('  "s_nop 15\\n" \\')
+print('  "s_nop 7\\n" \\')
+for i in range(192):
+    print(f'  "v_accvgpr_read_b32 v{56 + i}, a{i}\\n"' + (" \\" if i < 191 else ""))
 print("// clang-format on")

@@ -6,6 +6,6 @@
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); D=$1; shift
 T=$(mktemp -d); cp -r $R/u2tokenizer_amd $T/; cp -r $R/include $T/
-(cd $T/u2tokenizer_amd/csrc && python $R/tools/gen_gemm_bt_asm.py "$@" > gemm_bt_asm.inc && rm -f build/gemm_bt.o && make > /dev/null 2>&1)
+(cd $T/u2tokenizer_amd/csrc && python $R/tools/gen_gemm_bt_asm.py "$@" > gemm_bt_asm.inc && rm -f build/gemm_bt.o && make -j3 ../lib/libu2tok_hip.so > /dev/null 2>&1)
 rm -rf $R/$D; mkdir -p $R/$D; cp -r $T/u2tokenizer_amd $R/$D/; rm -rf $R/$D/u2tokenizer_amd/csrc $R/$D/u2tokenizer_amd/__pycache__ $T
 echo "$D: $(ls -la $R/$D/u2tokenizer_amd/lib/libu2tok_hip.so | awk '{print $5}') bytes"

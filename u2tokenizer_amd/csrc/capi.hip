@@ -52,10 +52,11 @@ int u2tok_set_option(const char* name, int value) {
   Options& o = ctx().opt;
   struct Opt { const char* name; int Options::*field; int lo, hi; };
   static const Opt table[] = {
-      {"gemm_splitk", &Options::gemm_splitk, -1, 16},   {"gemm_big", &Options::gemm_big, -1, 26},
+      {"gemm_splitk", &Options::gemm_splitk, -1, 16},   {"gemm_big", &Options::gemm_big, -1, 27},
       {"gemm_big_grid", &Options::gemm_big_grid, 1, 4096}, {"gemm_big_gelu", &Options::gemm_big_gelu, 0, 1},
       {"gemm_big_splitk", &Options::gemm_big_splitk, 0, 16}, {"gemm_big_skinny", &Options::gemm_big_skinny, 0, 1},
       {"gemm_big_ring", &Options::gemm_big_ring, 0, 1},   {"gemm_big_deep", &Options::gemm_big_deep, 0, 1},
+      {"gemm_big_drain", &Options::gemm_big_drain, 0, 2},
        {"kmajor_b", &Options::kmajor_b, 0, 1},            {"gemm_tail_fused", &Options::gemm_tail_fused, 0, 1},
       {"flash_mode", &Options::flash_mode, 0, 7},        {"flash_q_prescaled", &Options::flash_q_prescaled, 0, 1},
       {"vit_flash", &Options::vit_flash, 0, 1},         {"tta_overlap", &Options::tta_overlap, 0, 1},
@@ -72,7 +73,7 @@ int u2tok_set_option(const char* name, int value) {
   for (const Opt& t : table)
     if (!strcmp(name, t.name)) {
       if (value < t.lo || value > t.hi) return U2_ERR_ARG;
-      if (t.field == &Options::gemm_big && value > 0 && !(value >= 20 && value <= 26)) return U2_ERR_ARG;
+      if (t.field == &Options::gemm_big && value > 0 && !(value >= 20 && value <= 27)) return U2_ERR_ARG;
       if (t.field == &Options::flash_mode && value != 0 && value != 1 && value != 7) return U2_ERR_ARG;
       o.*(t.field) = value;
       return U2_OK;

@@ -141,6 +141,20 @@ __device__ __forceinline__ void gelu_fast2(float& x0, float& x1) {
   x1 = r.y;
 }
 
+// The GELU of the GEMM epilogues (every form: big-tile, drain, small-tile, few-rows, split-K reduce): the pre-activation is ROUNDED TO THE
+// ELEMENT TYPE FIRST, then gelu_fast -- "as if the Linear had stored its output and the GELU read it back", which is what the reference
+// does (MONAI MLPBlock: nn.Linear returns a bf16 tensor, nn.GELU rounds again; /root/reference/src/model/multimodal_encoder/vit.py:100-105)
+// and what this library's training path has always done (u2tok_gelu_fwd on the stored pre-activation).  Round 6: the drain form of the
+// big-tile kernel holds a tile's pre-activations as packed elements while the next tile's K loop runs, so the rounding point is a
+// property of that form; making it the rule keeps a row's bits independent of which form computed it (tests/test_gpu_path.py:
+// chunk-count independence) and makes all forms agree bit for bit on equal accumulators.
+__device__ __forceinline__ float gelu_epi(float x) { return gelu_fast(bf16_to_f32(f32_to_bf16(x))); }
+__device__ __forceinline__ void gelu_epi2(float& x0, float& x1) {
+  x0 = bf16_to_f32(f32_to_bf16(x0));
+  x1 = bf16_to_f32(f32_to_bf16(x1));
+  gelu_fast2(x0, x1);
+}
+
 static inline int launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? U2_OK : U2_ERR_LAUNCH;

@@ -16,11 +16,12 @@ namespace u2 {
 struct Options {
   int gemm_tile = 0;        // 0 heuristic, 64 / 128 force the small-tile kernel's tile
   int gemm_splitk = 0;      // -1 never, 0 heuristic, 2..16 force that many K slices where scratch allows
-  int gemm_big = 0;         // -1 never, 0 heuristic, 20 / 21 / 22 force the 256x256 / 256x192 / 256x128 (ring) big-tile kernel
+  int gemm_big = 0;         // -1 never, 0 heuristic, 20 / 21 / 22 force the 256x256 / 256x192 / 256x128 (ring) big-tile kernel, 24 / 26 the deep forms, 27 the drain form
   int gemm_big_grid = 256;  // persistent workgroups of the big-tile kernel
   int gemm_big_gelu = 1;    // 1: GELU products may take the big-tile kernel too (two-stage form); 0: always the 128^2 kernel
   int gemm_big_splitk = 0;  // K slices of a FORCED big-tile launch (gemm_big = 20 / 21): measurements, tests
   int gemm_big_deep = 1;    // 1: unsliced 256 x 192 / 256 x 256 products take the deep form (three LDS stages for B, two for A); 0: two stages (A/B)
+  int gemm_big_drain = 1;   // 1: deep 256 x 192 products with >= 2 tiles per workgroup run the drain form (tile i's epilogue under tile i + 1's K loop; GELU products too); 2: the same without the GELU products (whose drain form rounds the pre-activation first); 0: never (A/B)
   int gemm_big_ring = 1;    // 1: products that make one round of 256 x 128 tiles take the ring form (bt_pick_ring); 0: never (A/B)
   int gemm_big_skinny = 1;  // 1: partial-round products may take the big-tile kernel with K slices (bt_pick_sliced); 0: never
   int gemm_tail_fused = 1;  // 1: <= 16 rows behind a multiple of 256 (the ViT's cls rows) are computed inside the big-tile launch; 0: few-rows launch

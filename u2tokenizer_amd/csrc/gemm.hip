@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
         const float al = n0 < d.nsplit ? d.alpha_lo : d.alpha;
         float v0 = acc[mi][ni][0] * al, v1 = acc[mi][ni][1] * al, v2 = acc[mi][ni][2] * al, v3 = acc[mi][ni][3] * al;
         if constexpr (decltype(BN_)::value) { v0 += bn[ni].x; v1 += bn[ni].y; v2 += bn[ni].z; v3 += bn[ni].w; }
-        if constexpr (decltype(GELU_)::value) { gelu_fast2(v0, v1); gelu_fast2(v2, v3); }
+        if constexpr (decltype(GELU_)::value) { gelu_epi2(v0, v1); gelu_epi2(v2, v3); }
         if constexpr (decltype(RES_)::value) {
           const uint2 r2 = *reinterpret_cast<const uint2*>(Rz + (int64_t)m * d.ldr + n0);
           v0 += bf16lo(r2.x); v1 += bf16hi(r2.x); v2 += bf16lo(r2.y); v3 += bf16hi(r2.y);
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
         if (n >= d.N) break;
         float x = acc[mi][ni][r] * (n < d.nsplit ? d.alpha_lo : d.alpha) + bm_v;
         if (d.flags & GEMM_BIAS_N) x += bf16_to_f32(d.bias[n]);
-        if (d.flags & GEMM_GELU) x = gelu_erf(x);
+        if (d.flags & GEMM_GELU) x = gelu_epi(x);
         if (Rz) x += bf16_to_f32(Rz[(int64_t)m * d.ldr + n]);
         if (out_f32) reinterpret_cast<float*>(Cz)[(int64_t)m * d.ldc + n] = x;
         else reinterpret_cast<bf16_t*>(Cz)[(int64_t)m * d.ldc + n] = f32_to_bf16(x);
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmDesc d) {
     if (n >= d.N) break;
     float x = v[r] * (n < d.nsplit ? d.alpha_lo : d.alpha) + bm_v;
     if (d.flags & GEMM_BIAS_N) x += bf16_to_f32(d.bias[n]);
-    if (d.flags & GEMM_GELU) x = gelu_erf(x);
+    if (d.flags & GEMM_GELU) x = gelu_epi(x);
     if (Rz) x += bf16_to_f32(Rz[n]);
     if (out_f32) reinterpret_cast<float*>(Cz)[n] = x;
     else reinterpret_cast<bf16_t*>(Cz)[n] = f32_to_bf16(x);

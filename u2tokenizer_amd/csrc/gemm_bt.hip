@@ -200,7 +200,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmDesc& d, f32x16 (&acc)[2][
           }
           if constexpr (decltype(GELU_)::value) {
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) gelu_fast2(v[e], v[e + 1]);
+            for (int e = 0; e < 8; e += 2) gelu_epi2(v[e], v[e + 1]);
           }
           if constexpr (decltype(RES_)::value) {
             const uint4 r4 = *reinterpret_cast<const uint4*>(Rz + (int64_t)m * d.ldr + n0);
@@ -529,6 +529,245 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last K loop's prefetch into LDS
 }
 
+
+// ---- round 6: the DRAIN form of the deep 256 x 192 kernel (variant 27): tile i's epilogue under the K loop of tile i + 1 ----------------
+// (tools/gen_gemm_bt_asm.py, "drain forms", has the mechanism and the register map.)  For products whose workgroups walk SEVERAL output
+// tiles -- the ViT's q|k|v (three rounds of tiles; MONAI SABlock.qkv, /root/reference/src/model/multimodal_encoder/vit.py:100-105) and
+// fc1 + bias + GELU (MLPBlock.linear1: four rounds of 192-wide tiles) -- the asm statement of tile r >= 1 opens with CONVERT (tile r - 1's
+// accumulators -> 96 registers of packed 16-bit elements, ~1 us) and stores them, 16 bytes per lane and MFMA slot, from the first twelve
+// iterations of tile r's K loop; the GELU form evaluates gelu_fast2 on the held values in those iterations' spare issue slots.  Only the
+// workgroup's LAST tile still pays an exposed epilogue (drain_final_epilogue, the same arithmetic in HIP).
+// The accumulator file is pinned (operands "+{a[32 k : 32 k + 31]}": the asm text names a0..a191 literally); nothing else lives in a
+// clobbered register across two statements.  Requirements (bt_drain_ok): nz = 1, K a multiple of 384 and >= 768 (the loop's twelve drain
+// bodies start at LDS stage pair 0), whole 256 x 192 tiles, bf16 output with alpha / alpha_lo, bias[n] and GELU only, nsplit a multiple
+// of 192, N <= 6144 with a bias (its fp32 copy sits in the 24 KB of LDS behind the stages).
+// GELU rounding point: the pre-activation is rounded to the element type BEFORE the GELU (gelu_epi, common.h: the rule of every GEMM
+// epilogue of this library since round 6, and the reference's own rounding point).
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+typedef int bt_i32x16 __attribute__((ext_vector_type(16)));
+
+template <bool GELU>
+__device__ __forceinline__ void drain_final_epilogue(const GemmDesc& d, f32x16 (&acc)[4][3], int m_wave, int n_wave, int lane, float al,
+                                                     const float* lds_bias) {
+  const int hi = lane >> 5, l31 = lane & 31;
+  bf16_t* C = reinterpret_cast<bf16_t*>(d.C);
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+    for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float v[8], raw[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[rb][ni][8 * t + e]),
+                                                          __float_as_uint(acc[rb][ni][8 * t + 4 + e]), false, false);
+          raw[e] = __uint_as_float(r[0]);
+          raw[4 + e] = __uint_as_float(r[1]);
+          v[e] = raw[e] * al;
+          v[4 + e] = raw[4 + e] * al;
+        }
+        const int n0 = n_wave + ni * 32 + t * 16 + 8 * hi;
+        if (lds_bias) {   // (acc * alpha + bias as one fused multiply-add, like CONVERT and like the other forms' compiled epilogues)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaf(raw[e], al, lds_bias[n0 + e]);
+        }
+        if constexpr (GELU) {
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) gelu_epi2(v[e], v[e + 1]);
+        }
+        *reinterpret_cast<bt_u32x4*>(C + (int64_t)(m_wave + rb * 32 + l31) * d.ldc + n0) =
+            bt_u32x4{pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])};
+      }
+}
+
+template <bool GELU, bool VT, bool TAIL>
+__global__ __launch_bounds__(256, 1) void gemm_bt_drain_kernel(GemmDesc d) {
+  static_assert(!(GELU && VT), "the GELU form has no transposed tiles");
+  constexpr int NJ = 3, BN = 192, OFFB = 2 * 32768, STAGES = 2 * 32768 + 3 * NJ * 8192, LDS_BYTES = 163840;
+  __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int tiles_mn = d.tiles_m * d.tiles_n;
+  const int total = tiles_mn;
+  const int gd = gridDim.x, bid = blockIdx.x;
+  if constexpr (TAIL) {
+    if (d.tail_rows > 0) {
+      float (*red)[64][4] = reinterpret_cast<float (*)[64][4]>(lds);
+      const int nblk = (d.N + 15) >> 4, nsl = rows16_slices(d.K >> 5);
+      for (int blk = bid; blk < nblk; blk += gd) {
+        if (nsl == 16) bt_tail_block<16>(d, blk * 16, red, wave, lane);
+        else if (nsl == 8) bt_tail_block<8>(d, blk * 16, red, wave, lane);
+        else bt_tail_block<4>(d, blk * 16, red, wave, lane);
+      }
+    }
+  }
+  // fp32 copy of the bias behind the stages (CONVERT reads it with two ds_read_b128 per group): requested here, 8 elements per lane and
+  // piece (N <= 6144: three pieces), written to the LDS behind the first tile's K loop, which hides the latency
+  float* lds_bias = reinterpret_cast<float*>(lds + STAGES);
+  const bool have_bias = (d.flags & GEMM_BIAS_N) != 0;
+  bt_u32x4 braw[3] = {};
+  if (have_bias) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (tid * 8 + q * 2048 < d.N) braw[q] = *reinterpret_cast<const bt_u32x4*>(d.bias + tid * 8 + q * 2048);
+  }
+  const int my_tiles = (total - bid + gd - 1) / gd;
+  const int pr = lane >> 3, sw0 = (lane >> 4) & 3, pc = lane & 7;
+  const int ra = wave * 64 + pr;
+  const int va0 = (ra * (int)d.lda + ((pc ^ sw0) << 3)) * 2;
+  const int va1 = ((ra + 8) * (int)d.lda + ((pc ^ sw0 ^ 4) << 3)) * 2;
+  const int rb_ = wave * (16 * NJ) + pr;
+  const int vb0 = (rb_ * (int)d.ldb + ((pc ^ sw0) << 3)) * 2;
+  const int vb1 = ((rb_ + 8) * (int)d.ldb + ((pc ^ sw0 ^ 4) << 3)) * 2;
+  const uint32_t lds_u32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&lds[0];
+  const uint32_t abk0 = (uint32_t)(l31 * 128 + ((hi ^ ((l31 >> 1) & 7)) << 4));
+  const int lda16 = 16 * (int)d.lda * 2, ldb16 = 16 * (int)d.ldb * 2;
+  const int nkt = __builtin_amdgcn_readfirstlane(d.K >> 6);
+  const uint32_t aa0 = lds_u32 + wm * 16384 + abk0;
+  const uint32_t ab0 = lds_u32 + OFFB + wn * (NJ * 4096) + abk0;
+  // lane parts of the store addresses of a drained tile: row-major C / transposed V^T
+  const int voff_c = (l31 * (int)d.ldc + 8 * hi) * 2;
+  [[maybe_unused]] const int voff_t = (l31 * (int)d.vt_ld + 8 * hi) * 2;
+  // MUBUF descriptors: operands (rows past M / N read as zero) and the two store targets
+  bt_i32x4 rsa, rsb;
+  {
+    const uint64_t aaddr = (uint64_t)(uintptr_t)d.A, baddr = (uint64_t)(uintptr_t)d.B;
+    rsa[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)aaddr);
+    rsa[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(aaddr >> 32));
+    rsa[2] = (int)((((int64_t)d.M - 1) * d.lda + d.K) * 2);
+    rsa[3] = 0x00020000;
+    rsb[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)baddr);
+    rsb[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(baddr >> 32));
+    rsb[2] = (int)((((int64_t)d.N - 1) * d.ldb + d.K) * 2);
+    rsb[3] = 0x00020000;
+  }
+  const uint64_t caddr = (uint64_t)(uintptr_t)d.C, taddr = (uint64_t)(uintptr_t)d.vt;
+  const int c_bytes = (int)((((int64_t)d.M - 1) * d.ldc + d.N) * 2);
+  [[maybe_unused]] const int t_bytes = VT ? (int)((int64_t)(d.M / d.vt_rows) * d.vt_bs * 2) : 0;
+  // accumulator (i, j) = 32-row block i of the wave's 128 rows x 32-column block j: registers a[16 (3 i + j) : +15], named literally by
+  // the statements below and listed as their clobbers -- no C++ object holds them (tests/test_generated_asm.py audits the compiled
+  // kernel: no compiler instruction touches an accumulator register between the first statement and the read-out)
+  asm volatile(GEMM_BT_ASM_TEXT_ACC192_ZERO ::: GEMM_BT_ASM_CLOBBERS_ACC192);
+  int z, bm0, bn0;
+  pp_tile<BN>(d, 0, gd, bid, total, tiles_mn, z, bm0, bn0);
+  // the tile whose accumulators are waiting (drained by the next statement): (pbm0, pbn0) -- its parameter block is built from
+  // wave-uniform scalars right in front of the statement (a loop-carried vector would live in VGPRs)
+  int pbm0 = 0, pbn0 = 0;
+  for (int r = 0; r < my_tiles; ++r) {
+    int zn = z, bm0n = bm0, bn0n = bn0;
+    if (r + 1 < my_tiles) pp_tile<BN>(d, r + 1, gd, bid, total, tiles_mn, zn, bm0n, bn0n);
+    const int first = r == 0 ? 1 : 0;
+    const int base_a = __builtin_amdgcn_readfirstlane((bm0 * (int)d.lda) * 2);
+    const int base_b = __builtin_amdgcn_readfirstlane((bn0 * (int)d.ldb) * 2);
+    const int nbase_a = __builtin_amdgcn_readfirstlane((bm0n * (int)d.lda) * 2);
+    const int nbase_b = __builtin_amdgcn_readfirstlane((bn0n * (int)d.ldb) * 2);
+    int st0_s, first_s;  // (opaque to the optimiser: a folded literal is not a legal operand everywhere the text uses them)
+    asm volatile("s_mov_b32 %0, 0\n\ts_mov_b32 %1, %2" : "=&s"(st0_s), "=&s"(first_s) : "s"(__builtin_amdgcn_readfirstlane(first)));
+    [[maybe_unused]] const bool vt_tile = VT && bn0 >= d.vt_n0;
+    // parameters of the PREVIOUS tile (garbage for r = 0: not read)
+    const int pm_wave = __builtin_amdgcn_readfirstlane(pbm0 + wm * 128), pn_wave = __builtin_amdgcn_readfirstlane(pbn0 + wn * (BN / 2));
+    const bool pvt = VT && pbn0 >= d.vt_n0;
+    const float pal = pvt ? d.alpha : (pbn0 < d.nsplit ? d.alpha_lo : d.alpha);
+    int p0, p1, p2, p4, p5, p6;
+    if (pvt) {
+      const int chunk = pm_wave / d.vt_rows, key0 = pm_wave - chunk * d.vt_rows;
+      p0 = (int)(uint32_t)taddr; p1 = (int)(uint32_t)(taddr >> 32); p2 = t_bytes;
+      p4 = (int)(((int64_t)chunk * d.vt_bs + (int64_t)(pn_wave - d.vt_n0) * d.vt_ld + key0) * 2);
+      p5 = 64; p6 = (int)(32 * d.vt_ld * 2);
+    } else {
+      p0 = (int)(uint32_t)caddr; p1 = (int)(uint32_t)(caddr >> 32); p2 = c_bytes;
+      p4 = (int)(((int64_t)pm_wave * d.ldc + pn_wave) * 2);
+      p5 = (int)(32 * d.ldc * 2); p6 = 64;
+    }
+    const int p7 = (int)__float_as_uint(pal);
+    const int p8 = (pvt ? 1 : 0) | (pal != 1.0f ? 2 : 0) | ((have_bias && !pvt) ? 4 : 0);
+#define U2_RFL(x) __builtin_amdgcn_readfirstlane(x)
+    const bt_i32x16 prm = {U2_RFL(p0), U2_RFL(p1), U2_RFL(p2), 0x00020000, U2_RFL(p4), U2_RFL(p5), U2_RFL(p6), U2_RFL(p7),
+                           U2_RFL(p8), 0, 0, 0, 0, 0, 0, 0};
+#undef U2_RFL
+    const int voff_prev = pvt ? voff_t : voff_c;
+    const int vbias_prev = (int)(lds_u32 + STAGES + (pbn0 + wn * (BN / 2)) * 4 + 16 * hi);
+#define DR_IN                                                                                                               \
+  [va0] "v"(va0), [va1] "v"(va1), [vb0] "v"(vb0), [vb1] "v"(vb1), [aa0] "v"(aa0), [ab0] "v"(ab0), [rsa] "s"(rsa),           \
+      [rsb] "s"(rsb), [lda16] "s"(lda16), [ldb16] "s"(ldb16), [nkt] "s"(nkt), [wave] "s"(wave), [st0] "s"(st0_s),           \
+      [first] "s"(first_s), [base_a] "s"(base_a), [base_b] "s"(base_b), [nbase_a] "s"(nbase_a), [nbase_b] "s"(nbase_b)
+#define DR_PREV [voff] "v"(voff_prev), [vbias] "v"(vbias_prev), [prm] "{s[72:87]}"(prm)
+    if (r == 0) {
+      if (VT && vt_tile) asm volatile(GEMM_BT_ASM_TEXT_NJ3_DB_FX_T : : DR_IN : GEMM_BT_ASM_CLOBBERS_NJ3_DEEP, GEMM_BT_ASM_CLOBBERS_ACC192);
+      else asm volatile(GEMM_BT_ASM_TEXT_NJ3_DB_FX : : DR_IN : GEMM_BT_ASM_CLOBBERS_NJ3_DEEP, GEMM_BT_ASM_CLOBBERS_ACC192);
+    } else if constexpr (GELU) {
+      asm volatile(GEMM_BT_ASM_TEXT_NJ3_DB_DRAIN_GELU : : DR_IN, DR_PREV : GEMM_BT_ASM_CLOBBERS_DRAIN, GEMM_BT_ASM_CLOBBERS_ACC192);
+    } else {
+      if (VT && vt_tile) asm volatile(GEMM_BT_ASM_TEXT_NJ3_DB_DRAIN_T : : DR_IN, DR_PREV : GEMM_BT_ASM_CLOBBERS_DRAIN, GEMM_BT_ASM_CLOBBERS_ACC192);
+      else asm volatile(GEMM_BT_ASM_TEXT_NJ3_DB_DRAIN : : DR_IN, DR_PREV : GEMM_BT_ASM_CLOBBERS_DRAIN, GEMM_BT_ASM_CLOBBERS_ACC192);
+    }
+#undef DR_IN
+#undef DR_PREV
+    if (r == 0) {
+      if (have_bias) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          if (tid * 8 + q * 2048 < d.N) {
+            float* bp = lds_bias + tid * 8 + q * 2048;
+            bp[0] = bf16lo(braw[q].x); bp[1] = bf16hi(braw[q].x); bp[2] = bf16lo(braw[q].y); bp[3] = bf16hi(braw[q].y);
+            bp[4] = bf16lo(braw[q].z); bp[5] = bf16hi(braw[q].z); bp[6] = bf16lo(braw[q].w); bp[7] = bf16hi(braw[q].w);
+          }
+      }
+      __syncthreads();   // (the statement's prefetched K tiles are LDS-DMA in flight: the fence waits for them, as the next loop would)
+    }
+    if (r + 1 == my_tiles) {
+      // the workgroup's last tile: nothing left to hide it under
+      const int m_wave = bm0 + wm * 128, n_wave = bn0 + wn * (BN / 2);
+      const float al = vt_tile ? d.alpha : (bn0 < d.nsplit ? d.alpha_lo : d.alpha);
+      f32x16 a16[4][3];
+      asm volatile(GEMM_BT_ASM_TEXT_ACC192_READ
+                   : "={v[56:71]}"(a16[0][0]), "={v[72:87]}"(a16[0][1]), "={v[88:103]}"(a16[0][2]), "={v[104:119]}"(a16[1][0]),
+                     "={v[120:135]}"(a16[1][1]), "={v[136:151]}"(a16[1][2]), "={v[152:167]}"(a16[2][0]), "={v[168:183]}"(a16[2][1]),
+                     "={v[184:199]}"(a16[2][2]), "={v[200:215]}"(a16[3][0]), "={v[216:231]}"(a16[3][1]), "={v[232:247]}"(a16[3][2]));
+      if (VT && vt_tile) {
+        f32x16 (&av)[2][2][3] = reinterpret_cast<f32x16 (&)[2][2][3]>(a16);
+        vt_epilogue<NJ>(d, av, m_wave, n_wave, lane);
+      } else {
+        drain_final_epilogue<GELU>(d, a16, m_wave, n_wave, lane, al, have_bias ? lds_bias : nullptr);
+      }
+    }
+    pbm0 = bm0; pbn0 = bn0;
+    z = zn; bm0 = bm0n; bn0 = bn0n;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// May the deep 256 x 192 launch of `d` (many-row part: M a multiple of 256) run as the drain form?
+static bool bt_drain_ok(const GemmDesc& d) {
+  if (!opts().gemm_big_drain || !opts().gemm_big_deep || d.nz != 1 || d.ksplit > 1) return false;
+  if ((d.flags & GEMM_GELU) && opts().gemm_big_drain == 2) return false;  // (2: the forms whose arithmetic is that of the plain deep form only)
+  if (d.flags & ~(GEMM_VEC_OK | GEMM_BIAS_N | GEMM_GELU)) return false;
+  if (d.K % 384 || d.K < 768 || d.M % 256 || d.N % 192 || d.nsplit % 192) return false;
+  if ((d.flags & GEMM_BIAS_N) && d.N > 6144) return false;
+  if ((d.flags & GEMM_GELU) && d.vt) return false;
+  if (((int64_t)d.M - 1) * d.ldc + d.N >= (1ll << 30)) return false;
+  if (d.vt && (int64_t)(d.M / d.vt_rows) * d.vt_bs >= (1ll << 30)) return false;
+  const int64_t tiles = (int64_t)(d.M / 256) * (d.N / 192);
+  return tiles >= 2 * (int64_t)opts().gemm_big_grid;   // every workgroup has a tile to hide the previous one under
+}
+
+static int bt_launch_drain(GemmDesc d, hipStream_t stream) {
+  d.tiles_m = d.M / 256;
+  d.tiles_n = d.N / 192;
+  const int64_t total = (int64_t)d.tiles_m * d.tiles_n;
+  const int grid = (int)std::min<int64_t>(total, opts().gemm_big_grid);
+  const bool tail = d.tail_rows > 0;
+#define U2_DRAIN(G_, V_, T_) hipLaunchKernelGGL((gemm_bt_drain_kernel<G_, V_, T_>), dim3(grid), dim3(256), 0, stream, d)
+  if (d.flags & GEMM_GELU) { if (tail) U2_DRAIN(true, false, true); else U2_DRAIN(true, false, false); }
+  else if (d.vt) { if (tail) U2_DRAIN(false, true, true); else U2_DRAIN(false, true, false); }
+  else { if (tail) U2_DRAIN(false, false, true); else U2_DRAIN(false, false, false); }
+#undef U2_DRAIN
+  return launch_status();
+}
+
 template <int NJ, int DEEP>
 static int bt_launch_deep(GemmDesc d, hipStream_t stream) {
   if (d.ksplit > 1) return U2_ERR_ARG;
@@ -608,7 +847,8 @@ static int bt_slices(GemmDesc& d, int64_t tiles, int want, hipStream_t stream) {
   return 1;
 }
 
-// variants: 20 = 256 x 256, 21 = 256 x 192, 22 = 256 x 128 tiles (ring form); 24 = 256 x 192 with B deep, 26 = 256 x 256 with B deep
+// variants: 20 = 256 x 256, 21 = 256 x 192, 22 = 256 x 128 tiles (ring form); 24 = 256 x 192 with B deep, 26 = 256 x 256 with B deep,
+// 27 = 24 as the drain form (tile i's epilogue under tile i + 1's K loop)
 static int bt_launch_variant(int v, const GemmDesc& d, hipStream_t stream) {
   switch (v) {
     case 20: return bt_launch<4>(d, stream);
@@ -616,6 +856,7 @@ static int bt_launch_variant(int v, const GemmDesc& d, hipStream_t stream) {
     case 23: case 25: return U2_ERR_ARG;  // (the A-deep twins of round 4: removed)
     case 24: return bt_launch_deep<3, 2>(d, stream);
     case 26: return bt_launch_deep<4, 2>(d, stream);
+    case 27: return bt_drain_ok(d) ? bt_launch_drain(d, stream) : U2_ERR_ARG;
     default: return bt_launch<3>(d, stream);
   }
 }
@@ -730,6 +971,7 @@ int gemm_big_try(const GemmDesc& d, hipStream_t stream) {
     if (!bt_legal(d)) return 0;
     GemmDesc ds = d;
     if (mode <= 22) bt_slices(ds, 0, opts().gemm_big_splitk, stream);
+    if (mode == 27 && !bt_drain_ok(ds)) return 0;
     const int e = bt_launch_variant(mode, ds, stream);
     return e == U2_OK ? 1 : e;
   }
@@ -748,7 +990,7 @@ int gemm_big_try(const GemmDesc& d, hipStream_t stream) {
   }
   auto launch = [&](int v) {
     // <= 16 tail rows ride in the launch of the plain 256 x 256 (20) and deep 256 x 192 (24) forms -- what the ViT's products run
-    const bool in_launch = split_tail && rem <= 16 && !(d.K & 31) && !(d.flags & GEMM_BIAS_M) && (v == 20 || v == 24) &&
+    const bool in_launch = split_tail && rem <= 16 && !(d.K & 31) && !(d.flags & GEMM_BIAS_M) && (v == 20 || v == 24 || v == 27) &&
                            opts().gemm_tail_fused && main.ksplit <= 1;
     if (in_launch) main.tail_rows = rem;
     int e = bt_launch_variant(v, main, stream);
@@ -771,7 +1013,17 @@ int gemm_big_try(const GemmDesc& d, hipStream_t stream) {
   if (d.M < 512 || d.N < 256 || d.K < 128) return 0;
   const int v = bt_pick(main);
   if (v == 0) return 0;
-  return launch(bt_deep_of(v, d.flags));
+  int vv = bt_deep_of(v, d.flags);
+  // round 6, the drain form: products whose workgroups walk two or more 256 x 192 tiles hide tile i's epilogue under tile i + 1's K
+  // loop.  A GELU product prefers it over the 256-wide two-stage form whenever its 192-wide tiles fill their rounds (fc1 of the ViT:
+  // four whole rounds instead of three with 256 GELUs per lane exposed in each).
+  if (bt_drain_ok(main)) {
+    const int gmax = opts().gemm_big_grid;
+    const int64_t t3 = (int64_t)(main.M / 256) * (main.N / 192);
+    const double fill3 = (double)t3 / ((double)cdiv(t3, gmax) * gmax);
+    if (vv == 24 || ((d.flags & GEMM_GELU) && fill3 >= 0.7)) vv = 27;
+  }
+  return launch(vv);
 }
 
 }  // namespace u2

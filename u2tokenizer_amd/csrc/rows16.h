@@ -39,7 +39,7 @@ __device__ __forceinline__ void rows16_store(const GemmDesc& d, const float (&v)
     float x = v[r] * (n < d.nsplit ? d.alpha_lo : d.alpha);
     if (d.flags & GEMM_BIAS_M) x += bf16_to_f32(d.bias[m]);
     if (d.flags & GEMM_BIAS_N) x += bf16_to_f32(d.bias[n]);
-    if (d.flags & GEMM_GELU) x = gelu_fast(x);
+    if (d.flags & GEMM_GELU) x = gelu_epi(x);
     if (d.flags & GEMM_RESIDUAL) x += bf16_to_f32(R[(int64_t)m * d.ldr + n]);
     if (out_f32) reinterpret_cast<float*>(C)[(int64_t)m * d.ldc + n] = x;
     else reinterpret_cast<bf16_t*>(C)[(int64_t)m * d.ldc + n] = f32_to_bf16(x);
