@@ -667,6 +667,44 @@ def test_gemm_big_tile_k_slices(ops, variant, slices):
         torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 4096, 4096), (200, 2048, 2048), (129, 4096, 1024), (256, 2048, 8192), (65, 3072, 1536)])
+def test_gemm_skinny_in_launch_reduction(ops, M, N, K):
+    """Round 6, gemm_skinny.hip: 64 < M <= 256 rows against a 2048 .. 4096-column weight run ALL rows x 64 columns per workgroup with the
+    K range cut into slices whose fp32 tiles are combined IN the launch (ticket per column strip in the zeroed header of the stream's
+    scratch, the last arriver adds the slabs in slice order).  Every epilogue; rows past M; launched four times in a row (the tickets
+    must come back to zero) and bit-repeatable -- also against the launch order of the slices, which differs from run to run; without
+    a scratch the product takes the other kernels and gives the same values up to summation order."""
+    a, b, bias, res = rnd(M, K, seed=71), rnd(N, K, scale=0.05, seed=72), rnd(N, seed=73), rnd(M, N, seed=74)
+    ad, bd, biasd, resd = a.to(D), b.to(D), bias.to(D), res.to(D)
+    base = a.float() @ b.float().t()
+    scratch = torch.empty(64 << 20, dtype=torch.uint8, device=D)
+    ops.set_gemm_scratch(scratch)
+    try:
+        ops.set_option("profile", 1)
+        outs = [ops.gemm(ad, bd, bias=biasd).clone() for _ in range(4)]
+        ops.set_option("profile", 0)
+        assert all(torch.equal(outs[0], o) for o in outs[1:])
+        close_bf16(outs[0], base + bias.float())
+        close_bf16(ops.gemm(ad, bd), base)
+        close_bf16(ops.gemm(ad, bd, bias=biasd, residual=resd), base + bias.float() + res.float())
+        close_bf16(ops.gemm(ad, bd, bias=biasd, gelu=True), F.gelu(base + bias.float()), rounds=4)
+        close_f32(ops.gemm(ad, bd, bias=biasd, out_f32=True, alpha=0.5), 0.5 * base + bias.float())
+        # the header of the scratch holds the tickets: all back at zero
+        torch.cuda.synchronize()
+        assert int(scratch[:4096].view(torch.int32).abs().sum()) == 0
+        # the same product on the round-5 path (64 x 64 tiles + reduce launch): equal up to the summation order
+        ops.set_option("gemm_skinny", 0)
+        old = ops.gemm(ad, bd, bias=biasd)
+        ops.set_option("gemm_skinny", 1)
+        close_bf16(old, base + bias.float())
+        assert (old.float() - outs[0].float()).abs().max() <= 2 * ULP * (base + bias.float()).abs().max()
+    finally:
+        ops.set_option("gemm_skinny", 1)
+        ops.set_option("profile", 0)
+        ops.set_gemm_scratch(None)
+        torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("M,N,K", [(8, 2304, 768), (8, 768, 3072), (1, 40, 64), (16, 4096, 4096), (5, 24, 96), (8, 768, 768)])
 def test_gemm_few_rows(ops, M, N, K):
     """M <= 16 (the ViT's 8 cls rows behind the big-tile launches): gemm_rows16_kernel -- waves split K, partial tiles are

@@ -512,6 +512,8 @@ int gemm_bf16(GemmDesc d, hipStream_t stream) {
                2.0 * d.M * d.K * zA + 2.0 * d.N * d.K * zB +
                    d.nz * ((out_f32 ? 4.0 : 2.0) * d.M * d.N + ((d.flags & GEMM_RESIDUAL) ? 2.0 * d.M * d.N : 0.0)));
   if (d.ldbk == 0) {  // (the 256-wide-tile kernels read row-major B only)
+    const int sk = gemm_skinny_try(d, stream);  // <= 256 rows against a cold E x E weight: all rows x 64 columns per workgroup, slices combined in the launch
+    if (sk != 0) return sk > 0 ? U2_OK : sk;
     const int big = gemm_big_try(d, stream);  // large products: the big-tile kernel (gemm_bt.hip)
     if (big != 0) return big > 0 ? U2_OK : big;
   }

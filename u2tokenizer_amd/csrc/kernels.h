@@ -76,6 +76,7 @@ int gemm_bf16(GemmDesc d, hipStream_t stream);
 // internal: the kernels behind gemm_bf16 (descriptor already validated there)
 int gemm_classic(GemmDesc d, hipStream_t stream);        // gemm.hip: 128^2 / 64^2 tiles, 2+ workgroups per CU
 int gemm_big_try(const GemmDesc& d, hipStream_t stream);  // gemm_bt.hip: 1 launched, 0 not applicable, < 0 error
+int gemm_skinny_try(const GemmDesc& d, hipStream_t stream);  // gemm_skinny.hip (M <= 256 against a cold weight): same convention
 bool gemm_vt_supported(const GemmDesc& d, int vt_n0, int vt_rows);  // gemm_bt.hip: may d.vt be set for this product?
 int gemm_splitk_reduce(const GemmDesc& d, hipStream_t stream);  // gemm.hip: epilogue over d.partial[ksplit][nz][M][N]
 
