@@ -581,6 +581,31 @@ def test_gemm_big_tile_variants(ops, variant):
         ops.set_option("gemm_big", 0)
 
 
+def test_gelu_fwd_over_all_bf16_inputs(ops):
+    """u2tok_gelu_fwd (= the GEMM epilogues' gelu_fast, csrc/common.h: the logistic-polynomial form of round 6) on EVERY finite input of the
+    element type with |x| <= 30 against float64 x Phi(x): the output is the correctly rounded value or its neighbour, the neighbour for at
+    most 0.3 % of the inputs with |y| >= 0.01 (CPU restatement: 0.09 % in bf16; the hardware's exp / rcp add their ulp), and exact x / -0
+    beyond saturation."""
+    bits = torch.arange(65536, dtype=torch.int32).to(torch.int16)
+    x = bits.view(bf)
+    x = x[torch.isfinite(x.float()) & (x.float().abs() <= 30)]
+    pad = (-x.numel()) % 8
+    x = torch.cat([x, x[:pad]])
+    y = ops.gelu_fwd(x.to(D)).cpu()
+    xd = x.double()
+    ref = xd * 0.5 * (1 + torch.erf(xd / math.sqrt(2.0)))
+    rb = ref.to(bf)
+    big = ref.abs() >= 1e-2
+    ulp = torch.exp2(torch.floor(torch.log2(rb[big].double().abs())) - (7 if bf == torch.bfloat16 else 10))
+    assert ((y[big].double() - rb[big].double()).abs() <= ulp).all()
+    frac = (y[big] != rb[big]).double().mean().item()
+    assert frac <= (3e-3 if bf == torch.bfloat16 else 3e-2), frac
+    assert ((y.double() - ref).abs() <= 2.0 ** -8 * ref.abs() + 1e-5).all()
+    far = torch.tensor([40.0, 1e4, -40.0, -1e4, 0.0, 0.0, 0.0, 0.0]).to(bf)
+    out = ops.gelu_fwd(far.to(D)).cpu().float()
+    assert out[:2].tolist() == [40.0, float(far[1])] and (out[2:] == 0).all()
+
+
 @pytest.mark.parametrize("M,N,K,grid", [(1024, 768, 768, 4), (512, 1536, 1536, 4), (2048, 384, 768, 3), (768, 1152, 2304, 2)])
 def test_gemm_big_tile_drain_form(ops, M, N, K, grid):
     """Round 6, gemm_bt_drain_kernel (variant 27): tile i's epilogue under tile i + 1's K loop -- CONVERT packs the accumulators into 96

@@ -347,3 +347,47 @@ def test_append_in_place_cache_layer_behaves_like_dynamic_layer():
     a.batch_repeat_interleave(3), d.batch_repeat_interleave(3)
     step(3, 1)
 
+
+
+def test_gelu_logistic_polynomial_accuracy_over_all_bf16_inputs():
+    """csrc/common.h: gelu_fast = x / (1 + 2^(x P(x^2))), P of degree 4 (round 6: 12 instructions per pair of values instead of the 20 of
+    the Abramowitz & Stegun 7.1.28 form).  Its arithmetic restated in numpy float32 (fma = one rounding of the float64 result; exp2 / rcp
+    correctly rounded here, one ulp on the hardware), over EVERY finite bf16 input with |x| <= 30, against float64 x Phi(x): the table
+    the header quotes.  The GPU side of the same check is tests/test_gpu_ops.py::test_gelu_fwd_over_all_bf16_inputs."""
+    import numpy as np
+    from scipy.special import ndtr
+    f32 = np.float32
+    bits = np.arange(65536, dtype=np.uint32)
+    x = (bits << np.uint32(16)).view(f32)
+    x = x[np.isfinite(x) & (np.abs(x) <= 30)]
+
+    def fma(a, b, c):
+        return (a.astype(np.float64) * b.astype(np.float64) + np.float64(c)).astype(f32)
+
+    x2 = (x * x).astype(f32)
+    p = np.full_like(x, f32(-3.2607881621515844e-06))
+    for c in (8.898991654859856e-05, 0.0003546576772350818, -0.10521142929792404, -2.3020575046539307):
+        p = fma(p, x2, f32(c))
+    with np.errstate(over="ignore"):
+        e = np.exp2((p * x).astype(f32).astype(np.float64)).astype(f32)
+        y = (x * (f32(1) / (f32(1) + e).astype(f32)).astype(f32)).astype(f32)
+    ref = x.astype(np.float64) * ndtr(x.astype(np.float64))
+    assert np.abs(y - ref).max() <= 4e-6
+    to_bf = lambda v: torch.from_numpy(v.astype(f32)).bfloat16().float().numpy()   # noqa: E731
+    big = np.abs(ref) >= 1e-2
+    yb, rb = to_bf(y), to_bf(ref.astype(f32))
+    ulp = 2.0 ** (np.floor(np.log2(np.abs(rb[big]))) - 7)
+    assert (np.abs(yb[big] - rb[big]) <= ulp).all()                                   # never more than one ulp
+    assert (yb[big] != rb[big]).mean() <= 2e-3                                          # ... and for 0.09 % of the inputs
+    yh, rh = y.astype(np.float16), ref.astype(f32).astype(np.float16)
+    assert (yh[big] != rh[big]).mean() <= 1.5e-2                                        # fp16 outputs: 1.0 %
+    # saturation: exact identity / exact zero for large |x|, no NaN from the overflowing exponent
+    big_x = np.array([40.0, 1e4, 3e38, -40.0, -1e4, -3e38], dtype=f32)
+    x2 = (big_x * big_x).astype(f32)
+    with np.errstate(over="ignore", invalid="ignore"):
+        p = np.full_like(big_x, f32(-3.2607881621515844e-06))
+        for c in (8.898991654859856e-05, 0.0003546576772350818, -0.10521142929792404, -2.3020575046539307):
+            p = fma(p, x2, f32(c))
+        e = np.exp2(np.clip((p * big_x).astype(np.float64), -1e4, 1e4)).astype(f32)
+        y = big_x * (f32(1) / (f32(1) + e))
+    assert (y[:3] == big_x[:3]).all() and (y[3:] == 0).all()

@@ -665,15 +665,15 @@ def gen_deep(nj, deep):
 # v228..v255, s57..s71, parameters of the tile being drained in the pinned block s[72:87].
 HOLD, TMP = 132, 228
 S_CUR, S_ADJ, S_F = 57, 58, 59
-SG_C, SG_MASK, SG_P6, SG_P4, SG_P3, SG_P2, SG_P1 = 60, 61, 62, 64, 66, 68, 70
+SG_C4, SG_C2, SG_C1, SG_C0 = 60, 62, 64, 66
 PRM = 72            # s[72:75] store descriptor, s76 byte offset of the wave tile, s77 / s78 strides per 32-row block / 32-column block,
                     # s79 alpha (bits), s80 flags: 1 = transposed tile, 2 = alpha != 1, 4 = bias
-V_P5 = TMP + 24
-GELU_BLOCKS = [int(c) for c in (sys.argv[sys.argv.index("--gelu-blocks") + 1] if "--gelu-blocks" in sys.argv else "12")]
+V_C3 = TMP + 24
 V_AL = TMP + 26
-GELU_CONST = {SG_C: 0x3f3504f3, SG_MASK: 0x7fffffff, SG_P6: 0x38349f67, SG_P4: 0x391f6607, SG_P3: 0x3c17e369, SG_P2: 0x3d2d2fe7,
-              SG_P1: 0x3d906e67}
-P5_BITS = 0x39910039
+GELU_BLOCKS = [int(c) for c in (sys.argv[sys.argv.index("--gelu-blocks") + 1] if "--gelu-blocks" in sys.argv else "12")]
+# gelu_fast2 (common.h): x / (1 + 2^(x (c0 + c1 x^2 + c2 x^4 + c3 x^6 + c4 x^8))), the c_k carrying -log2 e
+GELU_CONST = {SG_C4: 0xb65ad3ea, SG_C2: 0x39b9f159, SG_C1: 0xbdd77917, SG_C0: 0xc01354e9}
+C3_BITS = 0x38baa019
 
 
 def hold(g, k=0):
@@ -724,33 +724,24 @@ def gelu_chunk(g):
     """gelu_fast2 (common.h) on the 8 held values of group g, in place: the instruction sequence hipcc emits for it, the four pairs
     interleaved (a packed-math result is read 4 issues later: its one wait state and the transcendental's are both covered)."""
     X = [TMP + 2 * q for q in range(4)]          # pairs: x, then the result
-    A = [TMP + 8 + 2 * q for q in range(4)]
+    X2 = [TMP + 8 + 2 * q for q in range(4)]
     P = [TMP + 16 + 2 * q for q in range(4)]
     ins = []
     for q in range(4):
         ins.append(f"v_lshlrev_b32 {v(X[q])}, 16, {v(hold(g, q))}")
         ins.append(f"v_and_b32 {v(X[q] + 1)}, 0xffff0000, {v(hold(g, q))}")
     steps = [
-        lambda q: f"v_mul_f32_e64 {v(A[q])}, |{v(X[q])}|, {s(SG_C)}",
-        lambda q: f"v_mul_f32_e64 {v(A[q] + 1)}, |{v(X[q] + 1)}|, {s(SG_C)}",
-        lambda q: f"v_pk_fma_f32 {vr(P[q], 2)}, {vr(A[q], 2)}, s[{SG_P6}:{SG_P6 + 1}], {vr(V_P5, 2)} op_sel_hi:[1,0,0]",
-        lambda q: f"v_pk_fma_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, {vr(A[q], 2)}, s[{SG_P4}:{SG_P4 + 1}] op_sel_hi:[1,1,0]",
-        lambda q: f"v_pk_mul_f32 {vr(X[q], 2)}, {vr(X[q], 2)}, 0.5 op_sel_hi:[1,0]",
-        lambda q: f"v_pk_fma_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, {vr(A[q], 2)}, s[{SG_P3}:{SG_P3 + 1}] op_sel_hi:[1,1,0]",
-        lambda q: f"v_pk_fma_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, {vr(A[q], 2)}, s[{SG_P2}:{SG_P2 + 1}] op_sel_hi:[1,1,0]",
-        lambda q: f"v_pk_fma_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, {vr(A[q], 2)}, s[{SG_P1}:{SG_P1 + 1}] op_sel_hi:[1,1,0]",
-        lambda q: f"v_pk_fma_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, {vr(A[q], 2)}, 1.0 op_sel_hi:[1,1,0]",
-        lambda q: f"v_pk_mul_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, {vr(P[q], 2)}",
-        lambda q: f"v_pk_mul_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, {vr(P[q], 2)}",
-        lambda q: f"v_pk_mul_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, {vr(P[q], 2)}",
-        lambda q: f"v_pk_mul_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, {vr(P[q], 2)}",
+        lambda q: f"v_pk_mul_f32 {vr(X2[q], 2)}, {vr(X[q], 2)}, {vr(X[q], 2)}",
+        lambda q: f"v_pk_fma_f32 {vr(P[q], 2)}, {vr(X2[q], 2)}, s[{SG_C4}:{SG_C4 + 1}], {vr(V_C3, 2)} op_sel_hi:[1,0,0]",
+        lambda q: f"v_pk_fma_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, {vr(X2[q], 2)}, s[{SG_C2}:{SG_C2 + 1}] op_sel_hi:[1,1,0]",
+        lambda q: f"v_pk_fma_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, {vr(X2[q], 2)}, s[{SG_C1}:{SG_C1 + 1}] op_sel_hi:[1,1,0]",
+        lambda q: f"v_pk_fma_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, {vr(X2[q], 2)}, s[{SG_C0}:{SG_C0 + 1}] op_sel_hi:[1,1,0]",
+        lambda q: f"v_pk_mul_f32 {vr(P[q], 2)}, {vr(X[q], 2)}, {vr(P[q], 2)}",
+        lambda q: f"v_exp_f32 {v(P[q])}, {v(P[q])}",
+        lambda q: f"v_exp_f32 {v(P[q] + 1)}, {v(P[q] + 1)}",
+        lambda q: f"v_pk_add_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, 1.0 op_sel_hi:[1,0]",
         lambda q: f"v_rcp_f32 {v(P[q])}, {v(P[q])}",
         lambda q: f"v_rcp_f32 {v(P[q] + 1)}, {v(P[q] + 1)}",
-        lambda q: f"v_pk_add_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, 1.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]",
-        # (the sign of z = x / sqrt 2 is the sign of 0.5 x: the un-halved x is gone by now, its half has the same sign bit)
-        lambda q: f"v_bfi_b32 {v(P[q] + 1)}, {s(SG_MASK)}, {v(P[q] + 1)}, {v(X[q] + 1)}",
-        lambda q: f"v_bfi_b32 {v(P[q])}, {s(SG_MASK)}, {v(P[q])}, {v(X[q])}",
-        lambda q: f"v_pk_add_f32 {vr(P[q], 2)}, {vr(P[q], 2)}, 1.0 op_sel_hi:[1,0]",
         lambda q: f"v_pk_mul_f32 {vr(X[q], 2)}, {vr(X[q], 2)}, {vr(P[q], 2)}",
     ]
     for st in steps:
@@ -863,7 +854,7 @@ def gen_deep_drain(swap, gelu):
             e("s_branch .Lcv_done_%=")
     e(".Lcv_done_%=:")
     if gelu:
-        e(f"v_mov_b32 {v(V_P5)}, 0x{P5_BITS:08x}")     # (behind CONVERT: its bias double buffer uses the register)
+        e(f"v_mov_b32 {v(V_C3)}, 0x{C3_BITS:08x}")     # (behind CONVERT: its bias double buffer uses the register)
     for w in (1, 2, 3):
         e(f"s_cmp_eq_u32 %[wave], {w}")
         e(f"s_cbranch_scc1 .Lbd_w{w}_%=")

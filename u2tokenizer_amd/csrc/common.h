@@ -101,42 +101,41 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
-// erf-GELU for the GEMM epilogues: erf by Abramowitz & Stegun 7.1.28, 1 - (1 + a1 x + ... + a6 x^6)^-16 (|err| < 3e-7
-// in exact arithmetic, 2e-6 in fp32 -- three orders below one bf16 ulp of the result), 14 VALU + 1 v_rcp instead of
-// the ~32 instructions and two divergent branches of ocml's erff: the MLP epilogue of the ViT evaluates 50 M of them
-// per layer.  Overflow of the 16th power for |x| > ~25 gives rcp(inf) = 0, i.e. erf = +-1 exactly.
+// erf-GELU for the GEMM epilogues and u2tok_gelu_fwd: GELU(x) = x Phi(x) with the normal CDF as a logistic function of an odd
+// polynomial,  Phi(x) = 1 / (1 + 2^(x (c0 + c1 x^2 + c2 x^4 + c3 x^6 + c4 x^8)))  (the c_k carry -log2 e; minimax fit of round 6, weight |x|,
+// over [0, 9.5]: |dPhi| <= 6.2e-6, |d GELU| <= 3.3e-6 everywhere; the leading coefficient makes the exponent monotone beyond the fit, so
+// 2^t -> 0 / inf and Phi -> 1 / 0 exactly for large |x|).  12 instructions per PAIR of values (4 packed FMAs, 3 packed multiplies, 1 packed
+// add, 2 v_exp_f32, 2 v_rcp_f32) against 20 for the Abramowitz & Stegun 7.1.28 form of rounds 1-5 (|d GELU| <= 7.5e-7), and ~32 + two
+// divergent branches for ocml's erff: the GELU of the ViT's MLP is 50 M evaluations per layer whose issue time ADDS to the K loop of a
+// one-wave-per-SIMD GEMM wherever it is placed (profiles/r06_drain_probe_gelu_placement.log: four placements, 103.0-104.5 us).
+// What the cheaper form costs, over ALL bf16 inputs (tests/test_host_modules.py re-derives this table in fp32 arithmetic): of the outputs with
+// |y| >= 0.01, 0.09 % differ from the correctly rounded bf16 value (by one ulp; the 7.1.28 form: 0.00 %), 1.0 % of the fp16 outputs (0.27 %).
 __device__ __forceinline__ float gelu_fast(float x) {
-  const float z = x * 0.70710678118654752440f, a = fabsf(z);
-  float p = 0.0000430638f;
-  p = __builtin_fmaf(p, a, 0.0002765672f);
-  p = __builtin_fmaf(p, a, 0.0001520143f);
-  p = __builtin_fmaf(p, a, 0.0092705272f);
-  p = __builtin_fmaf(p, a, 0.0422820123f);
-  p = __builtin_fmaf(p, a, 0.0705230784f);
-  p = __builtin_fmaf(p, a, 1.0f);
-  p = p * p; p = p * p; p = p * p; p = p * p;
-  const float e = __builtin_copysignf(1.0f - __builtin_amdgcn_rcpf(p), z);
-  return 0.5f * x * (1.0f + e);
+  const float x2 = x * x;
+  float p = -3.2607881621515844e-06f;
+  p = __builtin_fmaf(p, x2, 8.898991654859856e-05f);
+  p = __builtin_fmaf(p, x2, 0.0003546576772350818f);
+  p = __builtin_fmaf(p, x2, -0.10521142929792404f);
+  p = __builtin_fmaf(p, x2, -2.3020575046539307f);
+  const float e = __builtin_amdgcn_exp2f(p * x);
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 // Two values per instruction (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: the same IEEE operations per half, so the results are
-// those of gelu_fast bit for bit): 21 instructions per PAIR instead of 19 per value in the GEMM epilogues.
+// those of gelu_fast bit for bit) -- the form the GEMM epilogues use, and the instruction sequence the drain form of the big-tile
+// kernel carries in its K loop (tools/gen_gemm_bt_asm.py: gelu_chunk).
 typedef float gelu_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void gelu_fast2(float& x0, float& x1) {
   const gelu_f32x2 x = {x0, x1};
-  const gelu_f32x2 z = x * 0.70710678118654752440f;
-  const gelu_f32x2 a = {fabsf(z.x), fabsf(z.y)};
-  gelu_f32x2 p = {0.0000430638f, 0.0000430638f};
-  p = __builtin_elementwise_fma(p, a, (gelu_f32x2){0.0002765672f, 0.0002765672f});
-  p = __builtin_elementwise_fma(p, a, (gelu_f32x2){0.0001520143f, 0.0001520143f});
-  p = __builtin_elementwise_fma(p, a, (gelu_f32x2){0.0092705272f, 0.0092705272f});
-  p = __builtin_elementwise_fma(p, a, (gelu_f32x2){0.0422820123f, 0.0422820123f});
-  p = __builtin_elementwise_fma(p, a, (gelu_f32x2){0.0705230784f, 0.0705230784f});
-  p = __builtin_elementwise_fma(p, a, (gelu_f32x2){1.0f, 1.0f});
-  p = p * p; p = p * p; p = p * p; p = p * p;
-  const gelu_f32x2 e = {__builtin_copysignf(1.0f - __builtin_amdgcn_rcpf(p.x), z.x),
-                        __builtin_copysignf(1.0f - __builtin_amdgcn_rcpf(p.y), z.y)};
-  const gelu_f32x2 r = 0.5f * x * (1.0f + e);
+  const gelu_f32x2 x2 = x * x;
+  gelu_f32x2 p = {-3.2607881621515844e-06f, -3.2607881621515844e-06f};
+  p = __builtin_elementwise_fma(p, x2, (gelu_f32x2){8.898991654859856e-05f, 8.898991654859856e-05f});
+  p = __builtin_elementwise_fma(p, x2, (gelu_f32x2){0.0003546576772350818f, 0.0003546576772350818f});
+  p = __builtin_elementwise_fma(p, x2, (gelu_f32x2){-0.10521142929792404f, -0.10521142929792404f});
+  p = __builtin_elementwise_fma(p, x2, (gelu_f32x2){-2.3020575046539307f, -2.3020575046539307f});
+  const gelu_f32x2 t = p * x;
+  const gelu_f32x2 d = (gelu_f32x2){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
+  const gelu_f32x2 r = x * (gelu_f32x2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
   x0 = r.x;
   x1 = r.y;
 }
