@@ -202,11 +202,11 @@ def cpu_baseline(E, Lt, iters=3, sample_chunks=1):
 
 
 # ---------------------------------------------------------------------------------------------------- HBM traffic (PMC)
-PMC_CLASSES = [("gemm_bf16_nt_kernel", "gemm_bf16"), ("gemm_bt_kernel", "gemm_bf16"), ("gemm_splitk", "gemm_bf16"),
-               ("gemm_rows16", "gemm_bf16"), ("flash_", "flash_d64"), ("tok_attn", "tok_attention")]
+PMC_CLASSES = [("gemm_bf16_nt_kernel", "gemm_bf16"), ("gemm_bt_kernel", "gemm_bf16"), ("gemm_bt_drain_kernel", "gemm_bf16"),
+               ("gemm_skinny_kernel", "gemm_bf16"), ("gemm_splitk", "gemm_bf16"), ("gemm_rows16", "gemm_bf16"), ("flash_", "flash_d64"), ("tok_attn", "tok_attention")]
 # kernel name fragment -> class of the per-kernel table (order matters: first match)
-KERNEL_CLASSES = [("gemm_bf16_nt_kernel", "gemm_bf16"), ("gemm_bt_kernel", "gemm_bf16"), ("gemm_bt_drain_kernel", "gemm_bf16"), ("gemm_splitk", "gemm_bf16"),
-                  ("gemm_rows16", "gemm_bf16"),
+KERNEL_CLASSES = [("gemm_bf16_nt_kernel", "gemm_bf16"), ("gemm_bt_kernel", "gemm_bf16"), ("gemm_bt_drain_kernel", "gemm_bf16"), ("gemm_skinny_kernel", "gemm_bf16"),
+                  ("gemm_splitk", "gemm_bf16"), ("gemm_rows16", "gemm_bf16"),
                   ("flash_", "flash_d64"), ("tok_attn", "tok_attention"), ("temporal_attention", "temporal_attention"),
                   ("layernorm", "row_ops"), ("softmax", "row_ops"), ("rope", "row_ops"), ("score_gemv", "row_ops"),
                   ("topk", "row_ops"), ("multiscale_pool", "row_ops"), ("dmtp_gate", "row_ops"), ("avgpool3d", "row_ops"),
@@ -717,7 +717,8 @@ def main():
                     "measured": how}
 
         line["roofline"] = roof(0, "gemm_bf16", "bf16 MFMA GEMM, all launches of one step (gemm_bt_kernel 256x256 / 256x192 / "
-                                                "256x128 tiles in two-stage, deep and ring forms, gemm_bf16_nt_kernel 128^2 / 64^2 "
+                                                "256x128 tiles in two-stage, deep and ring forms, gemm_bt_drain_kernel = the deep 256x192 form with "
+                                                "tile i's epilogue under tile i+1's K loop (q|k|v, fc1 + GELU), gemm_bf16_nt_kernel 128^2 / 64^2 "
                                                 "tiles, few-rows kernel, split-K reduce)")
         line["roofline"]["classes"] = classes
         if ms[1] > 0:

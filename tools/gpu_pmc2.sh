@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 counter passes (counters + kernel trace only) for the hot kernels (-> profiles/rNN_kernel_pmc.json): flash
 #   attention (double pipeline), big-tile GEMM on the ViT qkv shape and the SVR's packed q|k|v (256x192 tiles, two-stage and
-#   deep forms), the ring form on the SVR output projection, the 128^2 kernel on the fc1 shape, and
+#   deep forms; round 6: the drain forms the heuristic now picks for q|k|v and fc1 + GELU), the ring form on the SVR output projection, the 128^2 kernel on the fc1 shape, and
 #   the 64^2 split-K kernel on the M = 256 query-side product of the TTA with cold weights.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/pmc2; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 run() {  # name, driver args..., then counter sets come from PASSES
@@ -21,11 +21,13 @@ PASSES=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MF
 PASSES+=("FETCH_SIZE" "WRITE_SIZE")
 run flash7pre flash 3 0 7 1
 run qkv_bt192_deep gemm 3 24
+run qkv_drain gemm 3 0
 run svr_qkv_bt192_two_stage gemmsvr 8 21
 run svr_qkv_bt192_deep gemmsvr 8 24
 run svr_out_ring gemm4k 8 22
 run fc1_gelu128 gemmmlp 3 -1
-run fc1_gelu_bt256 gemmmlp 3 0
+run fc1_gelu_bt256 gemmmlp 3 20
+run fc1_gelu_drain gemmmlp 3 0
 run skinny64 gemm256 16 0
 run tokattn tokattn 5
 run tokattn_4wave tokattn 5 1

@@ -22,6 +22,7 @@ python tools/pmc_traffic.py $O/pmc_bench 23 > $O/traffic.json 2> $O/traffic.err
 find $O/prof $O/pmc_bench -name "*kernel_trace*" -size +8M -delete 2>/dev/null
 find $O/pmc_bench -name "*counter_collection*" -size +8M -delete 2>/dev/null
 tail -4 $O/pytest_gpu.log; tail -2 $O/smoke.log; tail -2 $O/bench.log; tail -4 $O/rocprof.log; head -c 1500 $O/traffic.json
+# (round 6: the parity record of the suite is gpurun_out/r06_parity.json)
 # extras of round 3: decoder prefill probe, whole stage-1 step (also in the bench line), optimiser probe
 timeout 300 python tools/prefill_probe.py 2>&1 | grep -v Warn | tail -3 > $O/prefill_probe.log
 timeout 300 python tools/adamw_probe.py 2>&1 | grep -v Warn | tail -3 > $O/adamw_probe.log

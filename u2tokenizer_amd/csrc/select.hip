@@ -182,19 +182,33 @@ __global__ __launch_bounds__(256) void multiscale_pool_kernel(const bf16_t* __re
                                                               int E, const float* __restrict__ ws, const bf16_t* __restrict__ gate_b,
                                                               int ncg, int use_gate) {
   __shared__ float wsm[3];
+  __shared__ float part[3][512];   // the partial gate logits of this batch element (ncg * DMTP_SLABS <= 512: E <= 8192)
   const int b = blockIdx.y;
   const int L1 = k, L2 = k / 2, L4 = k / 4;
   const int Lout = L1 + L2 + L4;
+  // Round 6: every workgroup used to have its thread 0 read the 3 x 256 partial logits one by one from global memory before anybody
+  // could start (63 us for a 23 MB kernel); now the workgroup fetches them together and ONE thread per scale adds them from LDS in the
+  // same ascending order (bit-identical gates)
+  const int np = ncg * DMTP_SLABS, ns_ = 1 + (k >= 2) + (k >= 4);
+  if (use_gate) {
+    for (int s = 0; s < ns_; ++s)
+      for (int c = threadIdx.x; c < np; c += 256) part[s][c] = ws[((int64_t)b * 3 + s) * np + c];
+    __syncthreads();
+    if (threadIdx.x < ns_) {
+      float a = 0.f;
+      for (int c = 0; c < np; ++c) a += part[threadIdx.x][c];
+      part[threadIdx.x][0] = a;
+    }
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
     float w[3] = {1.f, 1.f, 1.f};
     if (use_gate) {
       float g[3];
-      const int ns = 1 + (k >= 2) + (k >= 4);
+      const int ns = ns_;
       float m = -INFINITY;
       for (int s = 0; s < ns; ++s) {
-        float a = 0.f;
-        for (int c = 0; c < ncg * DMTP_SLABS; ++c) a += ws[((int64_t)b * 3 + s) * ncg * DMTP_SLABS + c];
-        g[s] = a + bf16_to_f32(gate_b[0]);
+        g[s] = part[s][0] + bf16_to_f32(gate_b[0]);
         m = fmaxf(m, g[s]);
       }
       float den = 0.f;
@@ -236,7 +250,7 @@ int multiscale_pool(const bf16_t* x, bf16_t* out, int B, int k, int E, const bf1
   const int use_gate = gate_w != nullptr;
   ProfScope ps(PROF_ROWOP, 0, stream);
   if (use_gate) {
-    if (!gate_b || !ws) return U2_ERR_ARG;
+    if (!gate_b || !ws || ncg * DMTP_SLABS > 512) return U2_ERR_ARG;   // (E <= 8192: the pooling kernel stages the partial logits in LDS)
     hipLaunchKernelGGL(dmtp_gate_partial_kernel, dim3(ncg, B, DMTP_SLABS), dim3(256), 0, stream, x, gate_w, ws, k, E, ncg);
     if (launch_status() != U2_OK) return U2_ERR_LAUNCH;
   }
