@@ -484,6 +484,11 @@ def test_gemm_bt_drain_schedule_stores_and_counted_waits():
                 else:
                     assert adv == []
             assert sorted(g for _, g, _ in stored) == list(range(24))
+            # a tile's accumulators are OPENED by the first k16 step of D0 (C = 0: CONVERT zeroes nothing), accumulated into everywhere else
+            for lab, bl in bodies[w].items():
+                mf = [l for l in bl if l.startswith("v_mfma")]
+                opened = [l.endswith(", 0") for l in mf]
+                assert opened == ([True] * 12 + [False] * 36 if lab == "d0" else [False] * 48), lab
             for lab, g, behind in stored:
                 b = int(lab[1:])
                 assert g // 2 == (b - 1 if gelu and not (b == 11 and behind) else b) or (gelu and b == 11 and behind and g // 2 == 11), (lab, g)
@@ -518,7 +523,7 @@ def test_gemm_bt_drain_convert_puts_every_element_where_its_store_writes_it():
         k = starts[code] + 1
         V = {}                                       # (vgpr, lane) -> symbolic value
         B = {}                                       # pending bias reads: handled immediately (LDS returns in order, waits are the lint's job)
-        zeroed, read = set(), set()
+        read = set()
         while not (conv[k].startswith("s_branch") or conv[k].startswith(".Lcv_")):
             l = conv[k]
             k += 1
@@ -530,11 +535,6 @@ def test_gemm_bt_drain_convert_puts_every_element_where_its_store_writes_it():
                 for lane in range(64):
                     other = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
                     V[int(m.group(1)), lane] = {"m": 32 * i + (other if vt else (lane & 31)), "n": 32 * j + ((lane & 31) if vt else other), "bias": None}
-                continue
-            m = re.match(r"v_accvgpr_write_b32 a(\d+), 0", l)
-            if m:
-                assert int(m.group(1)) in read
-                zeroed.add(int(m.group(1)))
                 continue
             m = re.match(r"ds_read_b128 v\[(\d+):\d+\], %\[vbias\] offset:(\d+)", l)
             if m:
@@ -567,7 +567,7 @@ def test_gemm_bt_drain_convert_puts_every_element_where_its_store_writes_it():
                     V[a_, lane + 32], V[b_, lane] = V[b_, lane], V[a_, lane + 32]
                 continue
             assert l.startswith(("s_waitcnt lgkmcnt", "s_nop")), l
-        assert read == zeroed == set(range(192))
+        assert read == set(range(192))
         # the stores of wave 0's drain bodies: pair b at scalar offset s_base + rb * S_rb + ni * S_ni (S: strides of the flavour), + 32 t
         S_rb, S_ni = (64, 2 * 32 * vt_ld) if vt else (2 * 32 * ldc, 64)
         seen = {}

@@ -147,18 +147,20 @@ def frag_waits():
 SWAP = [False]   # True: MFMA operands exchanged -> the accumulator tile comes out TRANSPOSED (lane = column n, registers = rows m)
 
 
-def mfma_block(b, extra, a=None, bb=None):
-    """the 4 NJ MFMAs of one k16 step out of buffer b; extra(slot) emits the slot's companion instruction(s)"""
+def mfma_block(b, extra, a=None, bb=None, zero_c=False):
+    """the 4 NJ MFMAs of one k16 step out of buffer b; extra(slot) emits the slot's companion instruction(s); zero_c: the step OPENS an
+    output tile -- C = 0 instead of the accumulator (the drain forms: nobody has to zero 192 registers between two tiles)"""
     a, bb = a or afrag, bb or bfrag
     waits = frag_waits() if COUNTED else {0: 0}
     for slot in range(4 * NJ):
         i, j = slot // NJ, slot % NJ
         if slot in waits:
             e(f"s_waitcnt lgkmcnt({waits[slot]})")
+        c = "0" if zero_c else acc(i, j)
         if SWAP[0]:
-            e(f"v_mfma_f32_32x32x16_bf16 {acc(i, j)}, {a(b, i)}, {bb(b, j)}, {acc(i, j)}")
+            e(f"v_mfma_f32_32x32x16_bf16 {acc(i, j)}, {a(b, i)}, {bb(b, j)}, {c}")
         else:
-            e(f"v_mfma_f32_32x32x16_bf16 {acc(i, j)}, {bb(b, j)}, {a(b, i)}, {acc(i, j)}")
+            e(f"v_mfma_f32_32x32x16_bf16 {acc(i, j)}, {bb(b, j)}, {a(b, i)}, {c}")
         extra(slot)
 
 
@@ -650,7 +652,7 @@ def gen_deep(nj, deep):
 #   CONVERT  (exposed, ~1 us per tile): at the START of the asm statement of tile i + 1 the 192 accumulator registers of tile i are
 #            read, scaled / biased in fp32 and packed to 96 registers of 16-bit elements (v132..v227, "hold"; 24 groups of 4 = 24
 #            16-byte stores), in the row-major order a store wants (v_permlane32_swap on the PACKED pairs: 2 per group instead of 4);
-#            the accumulators are zeroed on the way.  A transposed tile (the q|k|v product's V tiles) packs 8 keys of one column.
+#            the first k16 step of the tile's K loop takes C = 0, so nobody zeroes them.  A transposed tile (the q|k|v product's V tiles) packs 8 keys of one column.
 #   DRAIN    (hidden): K iteration b (0..11) of tile i + 1 stores groups 2 b, 2 b + 1 from two MFMA slots; in the GELU form it first
 #            runs gelu_fast2's instruction sequence (common.h; the very opcodes hipcc emits for it, four pairs interleaved) on the
 #            held pre-activations from the slots of the whole iteration.  The held pre-activation is ROUNDED to the element type
@@ -700,8 +702,6 @@ def convert(vt, scale, bias):
             e(f"v_accvgpr_read_b32 {v(T[k])}, a{a0 + k}")
         if bias and g + 1 < 24:
             bias_reads(g + 1)
-        for k in range(8):
-            e(f"v_accvgpr_write_b32 a{a0 + k}, 0")
         if scale and not bias:
             for k in range(0, 8, 2):
                 e(f"v_pk_mul_f32 {vr(T[k], 2)}, {vr(T[k], 2)}, {vr(V_AL, 2)}")
@@ -910,7 +910,8 @@ def gen_deep_drain(swap, gelu):
                 return {slot: [(m, i, st, s_k) for i in sched[m][w].get(half * nslot + slot, [])] for slot in range(nslot)}
 
             IN_LOOP[0] = True
-            mfma_block(0, xk(0, win(smat, 1, shallow_next, K1), 1, sa, sb, 1), xa, xb)
+            # (D0 is always a tile's first iteration: its first k16 step opens the accumulators with C = 0)
+            mfma_block(0, xk(0, win(smat, 1, shallow_next, K1), 1, sa, sb, 1), xa, xb, zero_c=(body == 0))
             mfma_block(1, xk(1, win(dmat, 0, deep_tgt, K2), 0, sa, sb, 2), xa, xb)
             mfma_block(0, xk(2, win(dmat, 1, deep_tgt, K2), 1, sa, sb, 3), xa, xb)
             e(f"s_waitcnt vmcnt({npc[dmat] + nstore})")

@@ -187,18 +187,20 @@ __global__ __launch_bounds__(256) void multiscale_pool_kernel(const bf16_t* __re
   const int L1 = k, L2 = k / 2, L4 = k / 4;
   const int Lout = L1 + L2 + L4;
   // Round 6: every workgroup used to have its thread 0 read the 3 x 256 partial logits one by one from global memory before anybody
-  // could start (63 us for a 23 MB kernel); now the workgroup fetches them together and ONE thread per scale adds them from LDS in the
-  // same ascending order (bit-identical gates)
+  // could start (63 us for a 23 MB kernel); now the workgroup fetches them together and one WAVE per scale adds them (lane sums of a
+  // 64-stride, then the xor butterfly: a fixed order)
   const int np = ncg * DMTP_SLABS, ns_ = 1 + (k >= 2) + (k >= 4);
   if (use_gate) {
     for (int s = 0; s < ns_; ++s)
       for (int c = threadIdx.x; c < np; c += 256) part[s][c] = ws[((int64_t)b * 3 + s) * np + c];
     __syncthreads();
-    if (threadIdx.x < ns_) {
-      float a = 0.f;
-      for (int c = 0; c < np; ++c) a += part[threadIdx.x][c];
-      part[threadIdx.x][0] = a;
-    }
+    float a = 0.f;
+    const int sc = threadIdx.x >> 6, ln = threadIdx.x & 63;       // wave `sc` adds scale `sc`: lane sums of a 64-stride, then the butterfly
+    if (sc < ns_)
+      for (int c = ln; c < np; c += 64) a += part[sc][c];
+    a = wave_sum(a);                                               // (a fixed order: the gates repeat bit for bit)
+    __syncthreads();
+    if (sc < ns_ && ln == 0) part[sc][0] = a;
     __syncthreads();
   }
   if (threadIdx.x == 0) {
