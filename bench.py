@@ -203,9 +203,9 @@ def cpu_baseline(E, Lt, iters=3, sample_chunks=1):
 
 # ---------------------------------------------------------------------------------------------------- HBM traffic (PMC)
 PMC_CLASSES = [("gemm_bf16_nt_kernel", "gemm_bf16"), ("gemm_bt_kernel", "gemm_bf16"), ("gemm_bt_drain_kernel", "gemm_bf16"),
-               ("gemm_skinny_kernel", "gemm_bf16"), ("gemm_splitk", "gemm_bf16"), ("gemm_rows16", "gemm_bf16"), ("flash_", "flash_d64"), ("tok_attn", "tok_attention")]
+               ("gemm_skinny", "gemm_bf16"), ("gemm_splitk", "gemm_bf16"), ("gemm_rows16", "gemm_bf16"), ("flash_", "flash_d64"), ("tok_attn", "tok_attention")]
 # kernel name fragment -> class of the per-kernel table (order matters: first match)
-KERNEL_CLASSES = [("gemm_bf16_nt_kernel", "gemm_bf16"), ("gemm_bt_kernel", "gemm_bf16"), ("gemm_bt_drain_kernel", "gemm_bf16"), ("gemm_skinny_kernel", "gemm_bf16"),
+KERNEL_CLASSES = [("gemm_bf16_nt_kernel", "gemm_bf16"), ("gemm_bt_kernel", "gemm_bf16"), ("gemm_bt_drain_kernel", "gemm_bf16"), ("gemm_skinny", "gemm_bf16"),
                   ("gemm_splitk", "gemm_bf16"), ("gemm_rows16", "gemm_bf16"),
                   ("flash_", "flash_d64"), ("tok_attn", "tok_attention"), ("temporal_attention", "temporal_attention"),
                   ("layernorm", "row_ops"), ("softmax", "row_ops"), ("rope", "row_ops"), ("score_gemv", "row_ops"),

@@ -693,36 +693,34 @@ def test_gemm_big_tile_k_slices(ops, variant, slices):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 4096, 4096), (200, 2048, 2048), (129, 4096, 1024), (256, 2048, 8192), (65, 3072, 1536)])
-def test_gemm_skinny_in_launch_reduction(ops, M, N, K):
-    """Round 6, gemm_skinny.hip: 64 < M <= 256 rows against a 2048 .. 4096-column weight run ALL rows x 64 columns per workgroup with the
-    K range cut into slices whose fp32 tiles are combined IN the launch (ticket per column strip in the zeroed header of the stream's
-    scratch, the last arriver adds the slabs in slice order).  Every epilogue; rows past M; launched four times in a row (the tickets
-    must come back to zero) and bit-repeatable -- also against the launch order of the slices, which differs from run to run; without
-    a scratch the product takes the other kernels and gives the same values up to summation order."""
+def test_gemm_skinny_unsplit_form(ops, M, N, K):
+    """Round 6, gemm_skinny.hip (option gemm_skinny, default 1): 64 < M <= 256 rows against a 2048 .. 4096-column weight run 64 x 64 tiles
+    over the WHOLE K in 128-wide K tiles (256-byte LDS rows swizzled by row & 15, three stages, one counted wait per tile) -- no K
+    slices, no partial sums, no reduce launch.  Every epilogue; rows past M; bit-repeatable; with the option off the round-5 path (64 x 64
+    tiles x K slices + reduce, needs the scratch) gives the same values up to summation order (that the new kernel RUNS is what the bench line's
+    kernel table and tools/skinny_probe.py show: 21 gemm_skinny64_kernel launches per volume, 21 reduce launches fewer)."""
     a, b, bias, res = rnd(M, K, seed=71), rnd(N, K, scale=0.05, seed=72), rnd(N, seed=73), rnd(M, N, seed=74)
     ad, bd, biasd, resd = a.to(D), b.to(D), bias.to(D), res.to(D)
     base = a.float() @ b.float().t()
     scratch = torch.empty(64 << 20, dtype=torch.uint8, device=D)
     ops.set_gemm_scratch(scratch)
+
     try:
-        ops.set_option("profile", 1)
+        ops.set_option("gemm_skinny", 1)
         outs = [ops.gemm(ad, bd, bias=biasd).clone() for _ in range(4)]
-        ops.set_option("profile", 0)
+        ops.set_option("gemm_skinny", 0)
+        old = [ops.gemm(ad, bd, bias=biasd).clone()]
         assert all(torch.equal(outs[0], o) for o in outs[1:])
         close_bf16(outs[0], base + bias.float())
+        close_bf16(old[0], base + bias.float())
+        assert (old[0].float() - outs[0].float()).abs().max() <= 2 * ULP * (base + bias.float()).abs().max()
+        ops.set_option("gemm_skinny", 1)
         close_bf16(ops.gemm(ad, bd), base)
         close_bf16(ops.gemm(ad, bd, bias=biasd, residual=resd), base + bias.float() + res.float())
         close_bf16(ops.gemm(ad, bd, bias=biasd, gelu=True), F.gelu(base + bias.float()), rounds=4)
         close_f32(ops.gemm(ad, bd, bias=biasd, out_f32=True, alpha=0.5), 0.5 * base + bias.float())
-        # the header of the scratch holds the tickets: all back at zero
-        torch.cuda.synchronize()
-        assert int(scratch[:4096].view(torch.int32).abs().sum()) == 0
-        # the same product on the round-5 path (64 x 64 tiles + reduce launch): equal up to the summation order
-        ops.set_option("gemm_skinny", 0)
-        old = ops.gemm(ad, bd, bias=biasd)
-        ops.set_option("gemm_skinny", 1)
-        close_bf16(old, base + bias.float())
-        assert (old.float() - outs[0].float()).abs().max() <= 2 * ULP * (base + bias.float()).abs().max()
+        ops.set_gemm_scratch(None)                 # the unsplit form needs no scratch
+        assert torch.equal(ops.gemm(ad, bd, bias=biasd), outs[0])
     finally:
         ops.set_option("gemm_skinny", 1)
         ops.set_option("profile", 0)

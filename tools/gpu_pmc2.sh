@@ -28,7 +28,8 @@ run svr_out_ring gemm4k 8 22
 run fc1_gelu128 gemmmlp 3 -1
 run fc1_gelu_bt256 gemmmlp 3 20
 run fc1_gelu_drain gemmmlp 3 0
-run skinny64 gemm256 16 0
+run tta_query_unsplit gemm256 16 0
+run skinny64 gemm256old 16 0
 run tokattn tokattn 5
 run tokattn_4wave tokattn 5 1
 # (unchanged kernels keep their round-3 rows in profiles/r03_kernel_pmc.json: flashbwd, prefillattn, kmajor_dw -- add them back here to refresh)

@@ -10,7 +10,7 @@ from u2tokenizer_amd import ops  # noqa: E402
 
 dev, bf = torch.device("cuda:0"), torch.bfloat16
 _scratch = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
-ops.set_gemm_scratch(_scratch)      # as in the pipeline: the skinny products' K slices (split-K scratch of the tokenizer forward)
+ops.set_gemm_scratch(_scratch)      # as in the pipeline (the split-K scratch of the tokenizer forward: the sliced big-tile products)
 
 
 def timeit(fn, iters=10, warm=3):

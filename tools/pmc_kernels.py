@@ -9,7 +9,7 @@ import os
 import sys
 
 root = sys.argv[1]
-KEYS = ("tok_attn2_kernel", "tok_attn_kernel", "tok_attn_combine", "flash_dp2_kernel", "flash_dp_kernel", "flash_d64_kernel", "flash_bwd_dq_kernel", "flash_bwd_dkv_kernel", "gemm_bt_drain_kernel", "gemm_bt_kernel", "gemm_bf16_nt_kernel<64", "gemm_bf16_nt_kernel<128, 128, true", "gemm_bf16_nt_kernel<128", "gemm_splitk_reduce")
+KEYS = ("tok_attn2_kernel", "tok_attn_kernel", "tok_attn_combine", "flash_dp2_kernel", "flash_dp_kernel", "flash_d64_kernel", "flash_bwd_dq_kernel", "flash_bwd_dkv_kernel", "gemm_bt_drain_kernel", "gemm_skinny64_kernel", "gemm_bt_kernel", "gemm_bf16_nt_kernel<64", "gemm_bf16_nt_kernel<128, 128, true", "gemm_bf16_nt_kernel<128", "gemm_splitk_reduce")
 res = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for d in sorted(glob.glob(root + "/*_p*")):
     if not os.path.isdir(d):

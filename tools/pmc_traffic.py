@@ -13,7 +13,7 @@ import sys
 
 root, steps = sys.argv[1], int(sys.argv[2])
 cls = [("gemm_bf16_nt_kernel", "gemm_bf16"), ("gemm_bt_kernel", "gemm_bf16"), ("gemm_bt_drain_kernel", "gemm_bf16"),
-       ("gemm_skinny_kernel", "gemm_bf16"), ("gemm_splitk", "gemm_bf16"), ("gemm_pp", "gemm_bf16"), ("gemm_rows16", "gemm_bf16"), ("flash_", "flash_d64"), ("tok_attn", "tok_attention"),
+       ("gemm_skinny", "gemm_bf16"), ("gemm_splitk", "gemm_bf16"), ("gemm_pp", "gemm_bf16"), ("gemm_rows16", "gemm_bf16"), ("flash_", "flash_d64"), ("tok_attn", "tok_attention"),
        ("temporal_attention", "temporal_attention_kernel"), ("layernorm", "layernorm_kernel"),
        ("softmax_rows", "softmax_rows_kernel"), ("transpose", "transpose_kernel"), ("im2col", "im2col_kernel")]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))

@@ -1,7 +1,7 @@
 """Tiny driver for rocprofv3 counter passes:
     python tools/prof_kernels.py flash|flashbwd|kmajor|tokattn|prefillattn|gemm|gemm4k|gemmsvr|gemm256|gemm8k|gemmmlp [iters] [gemm_big: -1 | 0 | 20 .. 26] [flash_mode]
-gemm256 = the M = 256 query-side product of the TTA with 16 COLD weight matrices in rotation and split-K scratch, as the
-pipeline runs it (64 x 64 tiles, 4 K slices + reduce)."""
+gemm256 = the M = 256 query-side product of the TTA with 16 COLD weight matrices in rotation, as the pipeline runs it (round 6: the unsplit
+64 x 64 x 128 kernel; gemm256old: 64 x 64 tiles, 4 K slices + reduce)."""
 import sys
 from pathlib import Path
 
@@ -50,6 +50,9 @@ elif what == "kmajor":
         ops.gemm_kmajor(dy, x, a_kmajor=True)
 elif what.startswith("gemm"):
     ops.set_option("gemm_big", variant)
+    if what == "gemm256old":       # the round-5 path of the M = 256 products: 64 x 64 tiles x 4 K slices + reduce
+        ops.set_option("gemm_skinny", 0)
+        what = "gemm256"
     M, N, K = {"gemm": (16384, 2304, 768), "gemm4k": (2048, 4096, 4096), "gemmsvr": (2048, 12288, 4096), "gemm256": (256, 4096, 4096),
                "gemm8k": (8192, 8192, 8192), "gemmmlp": (16384, 3072, 768)}[what]
     a = torch.randn(M, K, device="cuda").to(bf)

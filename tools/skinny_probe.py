@@ -29,8 +29,9 @@ for (M, N, K) in ((256, 4096, 4096), (256, 12288, 4096)):
     name_once = [0]
     print(f"M={M} N={N} K={K}  (weights {N * K * 2 / 1e6:.0f} MB each, HBM floor at 5 TB/s {N * K * 2 / 5e6:.1f} us)")
     for tile, sk in ((0, 0), (0, -9), (64, -1), (64, 2), (64, 4), (64, 8), (128, -1), (128, 2), (128, 4), (128, 8), (128, 16)):
-        ops.set_option("gemm_skinny", 0 if sk == -9 else 1)       # (0, -9): the heuristic without the round-6 skinny kernel
-        sk = 0 if sk == -9 else sk
+        ops.set_option("gemm_skinny", 0 if sk == -9 else 1)   # (0, 0): the heuristic = the unsplit 64 x 64 x 128 form; (0, -9): the round-5 path
+        label = {-9: "round-5 path (64^2 x 4 slices)", 0: "heuristic (64x64x128 unsplit)"}.get(sk)
+        sk = 0 if sk < -1 else sk
         ops.set_option("gemm_tile", tile)
         ops.set_option("gemm_splitk", sk)
         ops.set_option("gemm_big", 0 if tile == 0 else -1)
@@ -48,10 +49,8 @@ for (M, N, K) in ((256, 4096, 4096), (256, 12288, 4096)):
         if ref is None:
             ref = out.float().clone()
         err = (out.float() - ref).abs().max().item()
-        name = ("heuristic" if ref is not None and err == 0 and tile == 0 and name_once[0] == 0 else "heuristic, gemm_skinny=0") if tile == 0 else f"tile {tile} splitk {sk if sk > 0 else 1}"
-        if tile == 0:
-            name_once[0] += 1
-        print(f"   {name:22s} {us:7.1f} us  {2.0 * M * N * K / us / 1e6:6.0f} TF/s   max|diff vs heuristic| {err:.3e}")
+        name = label if tile == 0 else f"tile {tile} splitk {sk if sk > 0 else 1}"
+        print(f"   {name:28s} {us:7.1f} us  {2.0 * M * N * K / us / 1e6:6.0f} TF/s   max|diff vs heuristic| {err:.3e}")
     o2 = torch.empty((M, N), dtype=bf, device=dev)
     for i in range(16):
         torch.matmul(a, ws[i].t(), out=o2)

@@ -24,7 +24,7 @@ struct Options {
   int gemm_big_drain = 1;   // 1: deep 256 x 192 products with >= 2 tiles per workgroup run the drain form (tile i's epilogue under tile i + 1's K loop; GELU products too); 2: the same without the GELU products (whose drain form rounds the pre-activation first); 0: never (A/B)
   int gemm_big_ring = 1;    // 1: products that make one round of 256 x 128 tiles take the ring form (bt_pick_ring); 0: never (A/B)
   int gemm_big_skinny = 1;  // 1: partial-round products may take the big-tile kernel with K slices (bt_pick_sliced); 0: never
-  int gemm_skinny = 0;      // (default OFF: 28.4 vs 30.7 us standalone, but the pipeline loses 0.5-0.9 %, profiles/r06_ab_skinny.log) 1: 64 < M <= 256 rows against N = 2048 .. 4096 columns take the 256 x 64-tile kernel with the in-launch K-slice reduction (gemm_skinny.hip); 0: 64 x 64 tiles + reduce launch (A/B)
+  int gemm_skinny = 1;      // 1: 64 < M <= 256 rows against N = 2048 .. 4096 columns (the TTA query chain) take the unsplit 64 x 64 x 128 kernel (gemm_skinny.hip); 0: 64 x 64 tiles x 4 K slices + reduce launch (A/B)
   int gemm_tail_fused = 1;  // 1: <= 16 rows behind a multiple of 256 (the ViT's cls rows) are computed inside the big-tile launch; 0: few-rows launch
   int kmajor_b = 1;         // 1: P V / DiffTS aggregation read V / X in place as K-major B operands; 0: transposed copies
   int flash_mode = 0;       // 0 pick, 1 plain 128-row units, 7 double pipeline (generated asm KV loop)
@@ -46,12 +46,9 @@ struct SideStream {  // created lazily, one per caller stream that ever ran a to
 
 struct Scratch {
   hipStream_t st;
-  void* p;        // partial-sum area (behind the ticket counters)
+  void* p;
   size_t bytes;
-  unsigned* cnt = nullptr;  // kScratchCounters zeroed ticket counters (in-launch split-K reductions: gemm_skinny.hip); null without a scratch
 };
-constexpr size_t kScratchHeader = 4096;                       // bytes reserved at the head of a registered scratch buffer
-constexpr int kScratchCounters = (int)(kScratchHeader / 4);
 
 struct ProfRec {
   hipEvent_t a, b;
@@ -69,10 +66,7 @@ struct Context {
   size_t ev_used = 0;
 
   SideStream* side_for(hipStream_t owner);  // null if the stream / events cannot be created
-  // Registers `p` as the split-K scratch of launches on `st` (null: none).  The first kScratchHeader bytes become ticket counters and are
-  // zeroed ON THE STREAM here (kernels that use them leave them at zero); the rest is what scratch_of() hands out as the partial-sum area.
   void set_scratch(hipStream_t st, void* p, size_t bytes);
-  void restore_scratch(const Scratch& s);   // puts back what scratch_of() returned earlier (no zeroing: its counters are still clean)
   Scratch scratch_of(hipStream_t st);
   void release();  // destroys the side streams / events (no work may be in flight on them)
   ~Context() { release(); }

@@ -35,28 +35,17 @@ SideStream* Context::side_for(hipStream_t owner) {
 }
 
 void Context::set_scratch(hipStream_t st, void* p, size_t bytes) {
-  Scratch n{st, nullptr, 0, nullptr};
-  if (p && bytes > 2 * kScratchHeader) {
-    n.cnt = reinterpret_cast<unsigned*>(p);
-    n.p = reinterpret_cast<char*>(p) + kScratchHeader;
-    n.bytes = bytes - kScratchHeader;
-    (void)hipMemsetAsync(p, 0, kScratchHeader, st);   // in stream order ahead of every launch that may draw a ticket
-  }
-  restore_scratch(n);
-}
-
-void Context::restore_scratch(const Scratch& n) {
   std::lock_guard<std::mutex> lk(mu);
   for (auto& s : scratch)
-    if (s.st == n.st) { s = n; return; }
-  scratch.push_back(n);
+    if (s.st == st) { s.p = p; s.bytes = bytes; return; }
+  scratch.push_back({st, p, bytes});
 }
 
 Scratch Context::scratch_of(hipStream_t st) {
   std::lock_guard<std::mutex> lk(mu);
   for (auto& s : scratch)
     if (s.st == st) return s;
-  return {st, nullptr, 0, nullptr};
+  return {st, nullptr, 0};
 }
 
 void Context::release() {

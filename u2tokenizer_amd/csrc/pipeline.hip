@@ -40,7 +40,7 @@ struct ScratchScope {
     prev = cx.scratch_of(st);
     cx.set_scratch(st, p, bytes);
   }
-  ~ScratchScope() { if (on) cx.restore_scratch(prev); }
+  ~ScratchScope() { if (on) cx.set_scratch(st, prev.p, prev.bytes); }
 };
 
 #define U2_RUN(expr)                  \
@@ -388,7 +388,7 @@ int tokenizer_forward(const TokConfig& c, const void* const* W, const bf16_t* v_
   // for this stream only while the launches below are being enqueued
   // (24 MB covers the E x E products; the TTA self-attention's packed q|k|v product takes the big-tile kernel in 4 K slices:
   //  4 x rows x 3E fp32)
-  const size_t kSplitK = kScratchHeader + std::max<size_t>(24u << 20, (size_t)16 * B * c.num_query * 3 * E);
+  const size_t kSplitK = std::max<size_t>(24u << 20, (size_t)16 * B * c.num_query * 3 * E);
   char* skw = ar.get<char>(kSplitK);
   U2_CHECK_WS(ar);
   Context& cx = ctx();
