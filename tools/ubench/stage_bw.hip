@@ -11,7 +11,8 @@
 template <int MODE, int BK, int DEPTH, int NWAVES_ISSUE, int SWZ = 0>
 __global__ __launch_bounds__(512) void stage_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B,
                                                     int K, int lda, int ntile, unsigned* sink) {
-  constexpr int ROWS = 512, CPR = BK / 8, RPP = 64 / CPR, STAGE = ROWS * BK * 2, NP = STAGE / 1024;
+  constexpr int ROWS = BK > 64 ? 512 * 64 / BK : 512, HALF = ROWS / 2;   // (BK 128 / 256: fewer rows, the same 64 KB per stage -- round 6)
+  constexpr int CPR = BK / 8, RPP = 64 / CPR, STAGE = ROWS * BK * 2, NP = STAGE / 1024;
   constexpr int PW = NP / NWAVES_ISSUE;  // pieces per issuing wave
   __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -26,7 +27,7 @@ __global__ __launch_bounds__(512) void stage_kernel(const unsigned short* __rest
 #pragma unroll
       for (int i = 0; i < PW; ++i) {
         const int r = (i * NWAVES_ISSUE + wave) * RPP + lane / CPR;
-        voff[i] = ((r < 256 ? (bm0 + r) : (bn0 + r - 256)) * lda + (lane % CPR) * 8) * 2;
+        voff[i] = ((r < HALF ? (bm0 + r) : (bn0 + r - HALF)) * lda + (lane % CPR) * 8) * 2;
       }
       const unsigned short* src[PW];
 #pragma unroll
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(512) void stage_kernel(const unsigned short* __rest
         if (SWZ == 2) gc ^= ((r >> 1) & 3) << 1;     // 32-B pairs stay together
         if (SWZ == 3) gc ^= ((r >> 1) & 1) << 2;     // swap 64-B halves only
         if (SWZ == 4) gc = (gc + (r & 7)) & 7;       // rotation
-        src[i] = (r < 256 ? A + (size_t)(bm0 + r) * lda : B + (size_t)(bn0 + r - 256) * lda) + gc * 8;
+        src[i] = (r < HALF ? A + (size_t)(bm0 + r) * lda : B + (size_t)(bn0 + r - HALF) * lda) + gc * 8;
       }
       const int nkt = K / BK;
       for (int kt = 0; kt < nkt; ++kt) {
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(512) void stage_kernel(const unsigned short* __rest
 #pragma unroll
           for (int i = 0; i < PW; ++i) {
 #if defined(__HIP_DEVICE_COMPILE__)
-            if ((i * NWAVES_ISSUE + wave) * RPP < 256)
+            if ((i * NWAVES_ISSUE + wave) * RPP < HALF)
               __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(s + i * NWAVES_ISSUE * 1024), 16,
                                                        voff[i], kt * BK * 2, 0, 0);
             else
@@ -92,7 +93,7 @@ static void run(const char* name, const unsigned short* A, const unsigned short*
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0; hipEventElapsedTime(&ms, e0, e1); ms /= it;
-  const double bytes = 256.0 * ntile * (K / BK) * 512 * BK * 2;
+  const double bytes = 256.0 * ntile * (K / BK) * (BK > 64 ? 512 * 64 / BK : 512) * BK * 2;
   printf("%-44s %8.1f us  %6.2f TB/s  %5.1f B/clk/CU@2.1GHz\n", name, ms * 1e3, bytes / ms / 1e9, bytes / 256 / (ms * 1e-3 * 2.1e9));
 }
 
@@ -106,6 +107,11 @@ int main() {
   run<0, 32, 2, 8>("glds  BK32 depth2 8 waves", A, B, sink);
   run<0, 32, 4, 8>("glds  BK32 depth4 8 waves", A, B, sink);
   run<0, 64, 2, 8>("glds  BK64 depth2 8 waves", A, B, sink);
+  run<0, 128, 2, 8>("glds  BK128 (256-B row pieces) 8 waves", A, B, sink);
+  run<0, 128, 2, 4>("glds  BK128 (256-B row pieces) 4 waves", A, B, sink);
+  run<0, 256, 2, 8>("glds  BK256 (512-B row pieces) 8 waves", A, B, sink);
+  run<0, 256, 2, 4>("glds  BK256 (512-B row pieces) 4 waves", A, B, sink);
+  run<0, 512, 2, 4>("glds  BK512 (1-KB row pieces) 4 waves", A, B, sink);
   run<0, 64, 1, 8>("glds  BK64 depth1 8 waves", A, B, sink);
   run<0, 64, 2, 4>("glds  BK64 depth2 4 waves", A, B, sink);
   run<3, 64, 2, 8>("buffer_load..lds BK64 depth2 8 waves", A, B, sink);
