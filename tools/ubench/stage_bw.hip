@@ -8,16 +8,58 @@
 #include <cstdlib>
 #include <vector>
 
-template <int MODE, int BK, int DEPTH, int NWAVES_ISSUE, int SWZ = 0>
+// BG (round 6): what the OTHER four waves do meanwhile -- 0: nothing; 1: ds_read_b128 back to back (the LDS read port saturated);
+//   2: the read : matrix-op mix of one k16 step of the deep 256 x 192 GEMM loop (7 ds_read_b128 : 12 v_mfma_f32_32x32x16_bf16), i.e.
+//   the load the staging pieces of gemm_bt.hip compete with.  The background waves poll an LDS flag the last issuing wave sets.
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16_t;
+template <int MODE, int BK, int DEPTH, int NWAVES_ISSUE, int SWZ = 0, int BG = 0>
 __global__ __launch_bounds__(512) void stage_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B,
-                                                    int K, int lda, int ntile, unsigned* sink) {
+                                                    int K, int lda, int ntile, unsigned* sink, unsigned long long* bgcount) {
   constexpr int ROWS = BK > 64 ? 512 * 64 / BK : 512, HALF = ROWS / 2;   // (BK 128 / 256: fewer rows, the same 64 KB per stage -- round 6)
   constexpr int CPR = BK / 8, RPP = 64 / CPR, STAGE = ROWS * BK * 2, NP = STAGE / 1024;
   constexpr int PW = NP / NWAVES_ISSUE;  // pieces per issuing wave
   __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+  __shared__ volatile int done_flag;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned acc = 0;
-  if (wave < NWAVES_ISSUE) {
+  if (BG != 0) {
+    if (threadIdx.x == 0) done_flag = 0;
+    __syncthreads();
+  }
+  if (BG != 0 && wave >= 4) {
+    // background: fragment-shaped reads (16 bytes per lane, 1 KB per instruction) walking over both stages
+    f32x16_t c[4] = {};
+    unsigned long long n = 0;
+    const unsigned base = (unsigned)(size_t)(lds + lane * 16) + (wave - 4) * 7168;   // (LDS byte address: the low 32 bits of the pointer)
+    bf16x8_t f[2][7];
+#define ISSUE7(F, ADDR)                                                                                                               \
+  asm volatile("ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:1024\n\tds_read_b128 %2, %7 offset:2048\n\tds_read_b128 %3, %7 offset:3072\n\t" \
+               "ds_read_b128 %4, %7 offset:4096\n\tds_read_b128 %5, %7 offset:5120\n\tds_read_b128 %6, %7 offset:6144"                \
+               : "=&v"(F[0]), "=&v"(F[1]), "=&v"(F[2]), "=&v"(F[3]), "=&v"(F[4]), "=&v"(F[5]), "=&v"(F[6]) : "v"(ADDR) : "memory")
+#define LANDED7(F)                                                                                                                    \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]), "+v"(F[4]), "+v"(F[5]), "+v"(F[6])::"memory")
+    ISSUE7(f[0], base);
+    unsigned step = 0;
+    while (done_flag == 0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        step = (step + 28672) % (2 * STAGE - 32768);
+        ISSUE7(f[(u + 1) & 1], base + step);            // the next k16 step's fragments are in flight under this step's matrix ops
+        if constexpr (BG == 2) {
+#pragma unroll
+          for (int i = 0; i < 12; ++i) c[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[u & 1][i % 4], f[u & 1][4 + i % 3], c[i & 3], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 7; ++i) acc += (unsigned)__builtin_bit_cast(unsigned short, f[u & 1][i][0]);
+        }
+        LANDED7(f[(u + 1) & 1]);
+      }
+      n += 28;
+    }
+    if constexpr (BG == 2) acc += (unsigned)c[0][0] + (unsigned)c[1][1] + (unsigned)c[2][2] + (unsigned)c[3][3];
+    if (lane == 0) atomicAdd(bgcount, n);
+  } else if (wave < NWAVES_ISSUE) {
     for (int t = 0; t < ntile; ++t) {
       const int tile = blockIdx.x + t * gridDim.x;
       const int bm0 = (tile % 32) * 256, bn0 = (tile / 32 % 32) * 256;
@@ -78,23 +120,38 @@ __global__ __launch_bounds__(512) void stage_kernel(const unsigned short* __rest
       }
     }
   }
+  if (BG != 0 && wave < NWAVES_ISSUE) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wave == NWAVES_ISSUE - 1 && lane == 0) done_flag = 1;      // (the last issuing wave: the others are a piece ahead at most)
+  }
   if (acc == 0x12345678u) sink[0] = acc;
 }
 
-template <int MODE, int BK, int DEPTH, int NW, int SWZ = 0>
+template <int MODE, int BK, int DEPTH, int NW, int SWZ = 0, int BG = 0>
 static void run(const char* name, const unsigned short* A, const unsigned short* B, unsigned* sink) {
   const int K = 8192, ntile = 4;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((stage_kernel<MODE, BK, DEPTH, NW, SWZ>), dim3(256), dim3(512), 0, 0, A, B, K, 8192, ntile, sink);
+  static unsigned long long* bgc = nullptr;
+  if (!bgc) hipMalloc(&bgc, 8);
+  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((stage_kernel<MODE, BK, DEPTH, NW, SWZ, BG>), dim3(256), dim3(512), 0, 0, A, B, K, 8192, ntile, sink, bgc);
+  hipMemset(bgc, 0, 8);
   hipEventRecord(e0);
   const int it = 5;
-  for (int w = 0; w < it; ++w) hipLaunchKernelGGL((stage_kernel<MODE, BK, DEPTH, NW, SWZ>), dim3(256), dim3(512), 0, 0, A, B, K, 8192, ntile, sink);
+  for (int w = 0; w < it; ++w) hipLaunchKernelGGL((stage_kernel<MODE, BK, DEPTH, NW, SWZ, BG>), dim3(256), dim3(512), 0, 0, A, B, K, 8192, ntile, sink, bgc);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0; hipEventElapsedTime(&ms, e0, e1); ms /= it;
   const double bytes = 256.0 * ntile * (K / BK) * (BK > 64 ? 512 * 64 / BK : 512) * BK * 2;
-  printf("%-44s %8.1f us  %6.2f TB/s  %5.1f B/clk/CU@2.1GHz\n", name, ms * 1e3, bytes / ms / 1e9, bytes / 256 / (ms * 1e-3 * 2.1e9));
+  printf("%-44s %8.1f us  %6.2f TB/s  %5.1f B/clk/CU@2.1GHz", name, ms * 1e3, bytes / ms / 1e9, bytes / 256 / (ms * 1e-3 * 2.1e9));
+  if (BG) {
+    unsigned long long n = 0;
+    hipMemcpy(&n, bgc, 8, hipMemcpyDeviceToHost);
+    const double rd = (double)n / it * 1024.0 / 256 / (ms * 1e-3 * 2.1e9);
+    printf("   | background: %5.1f B/clk/CU of ds_read_b128%s", rd, BG == 2 ? " + 12 MFMA 32x32x16 per 7 reads" : "");
+    if (BG == 2) printf(" = %4.1f %% of the matrix pipe", 100.0 * ((double)n / it / 7 * 12 * 32) / 256 / 4 / (ms * 1e-3 * 2.1e9));
+  }
+  printf("\n");
 }
 
 int main() {
@@ -112,6 +169,9 @@ int main() {
   run<0, 256, 2, 8>("glds  BK256 (512-B row pieces) 8 waves", A, B, sink);
   run<0, 256, 2, 4>("glds  BK256 (512-B row pieces) 4 waves", A, B, sink);
   run<0, 512, 2, 4>("glds  BK512 (1-KB row pieces) 4 waves", A, B, sink);
+  run<0, 64, 2, 4, 1, 1>("glds  BK64 4 waves swz | 4 waves reading LDS", A, B, sink);
+  run<0, 64, 2, 4, 1, 2>("glds  BK64 4 waves swz | 4 waves GEMM mix", A, B, sink);
+  run<3, 64, 2, 4, 0, 2>("buffer_load..lds BK64 4 waves | GEMM mix", A, B, sink);
   run<0, 64, 1, 8>("glds  BK64 depth1 8 waves", A, B, sink);
   run<0, 64, 2, 4>("glds  BK64 depth2 4 waves", A, B, sink);
   run<3, 64, 2, 8>("buffer_load..lds BK64 depth2 8 waves", A, B, sink);
