@@ -430,13 +430,16 @@ def test_tok_attention(ops, nb, Sq, Skv, H, d, bias, splits):
     got = [ops.tok_attention(dq, dk, dv, H, scale, None if tbl is None else tbl.to(D), 512, splits) for _ in range(3)]
     assert torch.equal(got[0], got[1]) and torch.equal(got[0], got[2])
     close_bf16(got[0], _tok_attn_ref(q, k, v, H, scale, tbl))
-    if d >= 256:  # the 4-wave form of the same head dims (option tok_wide = 0) stays a tested path
-        ops.set_option("tok_wide", 0)
+    if d >= 256:  # the 4-wave form of the same head dims (option tok_wide = 0) stays a tested path; and the 8-wave form's FLAT-encoded
+        # DMA (tok_wide = 1; the default 2 issues buffer_load ... lds) moves the same bytes: same bits
         try:
+            ops.set_option("tok_wide", 1)
+            assert torch.equal(ops.tok_attention(dq, dk, dv, H, scale, None if tbl is None else tbl.to(D), 512, splits), got[0])
+            ops.set_option("tok_wide", 0)
             close_bf16(ops.tok_attention(dq, dk, dv, H, scale, None if tbl is None else tbl.to(D), 512, splits),
                        _tok_attn_ref(q, k, v, H, scale, tbl))
         finally:
-            ops.set_option("tok_wide", 1)
+            ops.set_option("tok_wide", 2)
 
 
 def test_tok_attention_forced_rescale_and_split_merge(ops):
@@ -694,7 +697,7 @@ def test_gemm_big_tile_k_slices(ops, variant, slices):
 
 @pytest.mark.parametrize("M,N,K", [(256, 4096, 4096), (200, 2048, 2048), (129, 4096, 1024), (256, 2048, 8192), (65, 3072, 1536)])
 def test_gemm_skinny_unsplit_form(ops, M, N, K):
-    """Round 6, gemm_skinny.hip (option gemm_skinny, default 1): 64 < M <= 256 rows against a 2048 .. 4096-column weight run 64 x 64 tiles
+    """Round 6, gemm_skinny.hip (option gemm_skinny, default 2): 64 < M <= 256 rows against a 2048 .. 4096-column weight run 64 x 64 tiles
     over the WHOLE K in 128-wide K tiles (256-byte LDS rows swizzled by row & 15, three stages, one counted wait per tile) -- no K
     slices, no partial sums, no reduce launch.  Every epilogue; rows past M; bit-repeatable; with the option off the round-5 path (64 x 64
     tiles x K slices + reduce, needs the scratch) gives the same values up to summation order (that the new kernel RUNS is what the bench line's
@@ -706,15 +709,18 @@ def test_gemm_skinny_unsplit_form(ops, M, N, K):
     ops.set_gemm_scratch(scratch)
 
     try:
-        ops.set_option("gemm_skinny", 1)
+        ops.set_option("gemm_skinny", 1)           # the FLAT-encoded pieces (A/B form): the same bits as the default's buffer_load ... lds
+        flat = ops.gemm(ad, bd, bias=biasd).clone()
+        ops.set_option("gemm_skinny", 2)
         outs = [ops.gemm(ad, bd, bias=biasd).clone() for _ in range(4)]
+        assert torch.equal(flat, outs[0])
         ops.set_option("gemm_skinny", 0)
         old = [ops.gemm(ad, bd, bias=biasd).clone()]
         assert all(torch.equal(outs[0], o) for o in outs[1:])
         close_bf16(outs[0], base + bias.float())
         close_bf16(old[0], base + bias.float())
         assert (old[0].float() - outs[0].float()).abs().max() <= 2 * ULP * (base + bias.float()).abs().max()
-        ops.set_option("gemm_skinny", 1)
+        ops.set_option("gemm_skinny", 2)
         close_bf16(ops.gemm(ad, bd), base)
         close_bf16(ops.gemm(ad, bd, bias=biasd, residual=resd), base + bias.float() + res.float())
         close_bf16(ops.gemm(ad, bd, bias=biasd, gelu=True), F.gelu(base + bias.float()), rounds=4)
@@ -722,7 +728,7 @@ def test_gemm_skinny_unsplit_form(ops, M, N, K):
         ops.set_gemm_scratch(None)                 # the unsplit form needs no scratch
         assert torch.equal(ops.gemm(ad, bd, bias=biasd), outs[0])
     finally:
-        ops.set_option("gemm_skinny", 1)
+        ops.set_option("gemm_skinny", 2)
         ops.set_option("profile", 0)
         ops.set_gemm_scratch(None)
         torch.cuda.synchronize()

@@ -28,7 +28,7 @@ elif what == "flashbwd":
     for _ in range(iters):
         ops.flash_attention_d64_bwd(qkv, out, dout, 12, 0.125)
 elif what == "tokattn":
-    ops.set_option("tok_wide", 1 if variant == 0 else 0)   # (third argument 1: the 4-wave form)
+    ops.set_option("tok_wide", 2 if variant == 0 else 0)   # (third argument 1: the 4-wave form)
     # the SVR's spatial attention core at E = 4096: 8 chunks, 8 heads of 512, 256 x 256, relative bias; packed q | k | v
     E, H = 4096, 8
     qkv = (torch.randn(8, 256, 3 * E, device="cuda") * 0.5).to(bf)

@@ -29,7 +29,7 @@ for (M, N, K) in ((256, 4096, 4096), (256, 12288, 4096)):
     name_once = [0]
     print(f"M={M} N={N} K={K}  (weights {N * K * 2 / 1e6:.0f} MB each, HBM floor at 5 TB/s {N * K * 2 / 5e6:.1f} us)")
     for tile, sk in ((0, 0), (0, -9), (64, -1), (64, 2), (64, 4), (64, 8), (128, -1), (128, 2), (128, 4), (128, 8), (128, 16)):
-        ops.set_option("gemm_skinny", 0 if sk == -9 else 1)   # (0, 0): the heuristic = the unsplit 64 x 64 x 128 form; (0, -9): the round-5 path
+        ops.set_option("gemm_skinny", 0 if sk == -9 else 2)   # (0, 0): the heuristic = the unsplit 64 x 64 x 128 form; (0, -9): the round-5 path
         label = {-9: "round-5 path (64^2 x 4 slices)", 0: "heuristic (64x64x128 unsplit)"}.get(sk)
         sk = 0 if sk < -1 else sk
         ops.set_option("gemm_tile", tile)
@@ -63,4 +63,4 @@ for (M, N, K) in ((256, 4096, 4096), (256, 12288, 4096)):
     e1.record()
     torch.cuda.synchronize()
     print(f"   {'torch.matmul (vendor)':22s} {e0.elapsed_time(e1) / 64 * 1e3:7.1f} us   (no bias)")
-ops.set_option("gemm_tile", 0); ops.set_option("gemm_splitk", 0); ops.set_option("gemm_big", 0); ops.set_option("gemm_skinny", 1)
+ops.set_option("gemm_tile", 0); ops.set_option("gemm_splitk", 0); ops.set_option("gemm_big", 0); ops.set_option("gemm_skinny", 2)

@@ -66,6 +66,7 @@ __global__ __launch_bounds__(512) void stage_kernel(const unsigned short* __rest
       const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
       const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7fffffff, 0x00020000);
       int voff[PW];
+      [[maybe_unused]] unsigned long long dummy64[4] = {1, 2, 3, 4};
 #pragma unroll
       for (int i = 0; i < PW; ++i) {
         const int r = (i * NWAVES_ISSUE + wave) * RPP + lane / CPR;
@@ -85,11 +86,12 @@ __global__ __launch_bounds__(512) void stage_kernel(const unsigned short* __rest
       const int nkt = K / BK;
       for (int kt = 0; kt < nkt; ++kt) {
         char* s = lds + (kt & 1) * STAGE + wave * 1024;
-        if constexpr (MODE == 3) {
+        if constexpr (MODE == 3 || MODE == 4) {
           // MUBUF form: one descriptor per matrix, 32-bit per-lane offsets, the K advance in the scalar offset
 #pragma unroll
           for (int i = 0; i < PW; ++i) {
 #if defined(__HIP_DEVICE_COMPILE__)
+            if constexpr (MODE == 4) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(dummy64[i & 3]) : "s"((unsigned long long)kt));
             if ((i * NWAVES_ISSUE + wave) * RPP < HALF)
               __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(s + i * NWAVES_ISSUE * 1024), 16,
                                                        voff[i], kt * BK * 2, 0, 0);
@@ -172,6 +174,9 @@ int main() {
   run<0, 64, 2, 4, 1, 1>("glds  BK64 4 waves swz | 4 waves reading LDS", A, B, sink);
   run<0, 64, 2, 4, 1, 2>("glds  BK64 4 waves swz | 4 waves GEMM mix", A, B, sink);
   run<3, 64, 2, 4, 0, 2>("buffer_load..lds BK64 4 waves | GEMM mix", A, B, sink);
+  run<4, 64, 2, 4, 0, 2>("buffer_load..lds + 1 VALU u64 add per piece | GEMM mix", A, B, sink);
+  run<0, 64, 2, 4, 0, 2>("glds  BK64 4 waves no swizzle | GEMM mix", A, B, sink);
+  run<4, 64, 2, 4, 0, 0>("buffer_load..lds + 1 VALU u64 add per piece", A, B, sink);
   run<0, 64, 1, 8>("glds  BK64 depth1 8 waves", A, B, sink);
   run<0, 64, 2, 4>("glds  BK64 depth2 4 waves", A, B, sink);
   run<3, 64, 2, 8>("buffer_load..lds BK64 depth2 8 waves", A, B, sink);

@@ -56,13 +56,13 @@ int u2tok_set_option(const char* name, int value) {
       {"gemm_big_grid", &Options::gemm_big_grid, 1, 4096}, {"gemm_big_gelu", &Options::gemm_big_gelu, 0, 1},
       {"gemm_big_splitk", &Options::gemm_big_splitk, 0, 16}, {"gemm_big_skinny", &Options::gemm_big_skinny, 0, 1},
       {"gemm_big_ring", &Options::gemm_big_ring, 0, 1},   {"gemm_big_deep", &Options::gemm_big_deep, 0, 1},
-      {"gemm_big_drain", &Options::gemm_big_drain, 0, 2}, {"gemm_skinny", &Options::gemm_skinny, 0, 1},
+      {"gemm_big_drain", &Options::gemm_big_drain, 0, 2}, {"gemm_skinny", &Options::gemm_skinny, 0, 2},
        {"kmajor_b", &Options::kmajor_b, 0, 1},            {"gemm_tail_fused", &Options::gemm_tail_fused, 0, 1},
       {"flash_mode", &Options::flash_mode, 0, 7},        {"flash_q_prescaled", &Options::flash_q_prescaled, 0, 1},
       {"vit_flash", &Options::vit_flash, 0, 1},         {"tta_overlap", &Options::tta_overlap, 0, 1},
       {"vit_vt_epilogue", &Options::vit_vt_epilogue, 0, 1},
       {"tok_flash", &Options::tok_flash, 0, 1},
-      {"tok_wide", &Options::tok_wide, 0, 1},
+      {"tok_wide", &Options::tok_wide, 0, 2},
   };
   if (!strcmp(name, "gemm_tile")) {
     if (value != 0 && value != 64 && value != 128) return U2_ERR_ARG;

@@ -24,7 +24,7 @@ struct Options {
   int gemm_big_drain = 1;   // 1: deep 256 x 192 products with >= 2 tiles per workgroup run the drain form (tile i's epilogue under tile i + 1's K loop; GELU products too); 2: the same without the GELU products (whose drain form rounds the pre-activation first); 0: never (A/B)
   int gemm_big_ring = 1;    // 1: products that make one round of 256 x 128 tiles take the ring form (bt_pick_ring); 0: never (A/B)
   int gemm_big_skinny = 1;  // 1: partial-round products may take the big-tile kernel with K slices (bt_pick_sliced); 0: never
-  int gemm_skinny = 1;      // 1: 64 < M <= 256 rows against N = 2048 .. 4096 columns (the TTA query chain) take the unsplit 64 x 64 x 128 kernel (gemm_skinny.hip); 0: 64 x 64 tiles x 4 K slices + reduce launch (A/B)
+  int gemm_skinny = 2;      // 2 (1: the same kernel with FLAT-encoded global_load_lds pieces instead of buffer_load ... lds -- A/B): 64 < M <= 256 rows against N = 2048 .. 4096 columns (the TTA query chain) take the unsplit 64 x 64 x 128 kernel (gemm_skinny.hip); 0: 64 x 64 tiles x 4 K slices + reduce launch (A/B)
   int gemm_tail_fused = 1;  // 1: <= 16 rows behind a multiple of 256 (the ViT's cls rows) are computed inside the big-tile launch; 0: few-rows launch
   int kmajor_b = 1;         // 1: P V / DiffTS aggregation read V / X in place as K-major B operands; 0: transposed copies
   int flash_mode = 0;       // 0 pick, 1 plain 128-row units, 7 double pipeline (generated asm KV loop)
@@ -32,7 +32,7 @@ struct Options {
   int vit_flash = 1;        // 0: unfused ViT attention (debug)
   int vit_vt_epilogue = 1;  // 1: the ViT's q|k|v product writes V^T from its own V tiles (transposed-tile form of the 256 x 192 kernel); 0: transpose launch
   int tok_flash = 1;        // 1: fused attention kernel for the tokenizer's attention cores (tokattn.hip); 0: GEMM chain
-  int tok_wide = 1;         // 1: head dims 256 / 512 of the fused kernel run the 8-wave form (two waves per SIMD, tok_attn2_kernel); 0: the 4-wave form (A/B)
+  int tok_wide = 2;         // 2 (1: the same kernel with FLAT-encoded global_load_lds pieces instead of buffer_load ... lds -- A/B): head dims 256 / 512 of the fused kernel run the 8-wave form (two waves per SIMD, tok_attn2_kernel); 0: the 4-wave form (A/B)
   int tta_overlap = 1;      // k | v projections of the TTA cross attentions on a side stream
   int profile = 0;          // bracket every launch with hipEvents (u2tok_profile_collect)
 };

@@ -33,6 +33,10 @@ namespace {
 typedef unsigned int sk_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int S64_STAGE = 32768, S64_NS = 3;
 
+// MUBUF: the pieces leave as `buffer_load_dwordx4 ... lds` (descriptor + 32-bit lane offset, the K advance in the scalar offset) instead of
+// `global_load_lds_dwordx4` (64-bit lane addresses, a VALU add per piece) -- tools/ubench/stage_bw.hip, profiles/r06_stage_bw.log: beside
+// waves that issue MFMAs the FLAT-encoded form stages 14 B/clk per CU, the MUBUF form 44.
+template <bool MUBUF>
 __global__ __launch_bounds__(256, 1) void gemm_skinny64_kernel(GemmDesc d, int nstrips, int mtiles) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -54,22 +58,38 @@ __global__ __launch_bounds__(256, 1) void gemm_skinny64_kernel(GemmDesc d, int n
   const int pr = lane >> 4, pc = lane & 15;
   const bf16_t* pa[4];
   const bf16_t* pw[4];
+  int va[4], vw[4];   // (MUBUF: byte offsets from the operand's base; the launcher keeps both operands under 2 GB)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = 4 * (4 * wave + i) + pr;
-    pa[i] = d.A + (int64_t)min(m0 + row, d.M - 1) * d.lda + ((pc ^ (row & 15)) << 3);
-    pw[i] = d.B + (int64_t)min(n0 + row, d.N - 1) * d.ldb + ((pc ^ (row & 15)) << 3);
+    const int64_t oa = (int64_t)min(m0 + row, d.M - 1) * d.lda + ((pc ^ (row & 15)) << 3);
+    const int64_t ow = (int64_t)min(n0 + row, d.N - 1) * d.ldb + ((pc ^ (row & 15)) << 3);
+    pa[i] = d.A + oa;
+    pw[i] = d.B + ow;
+    va[i] = (int)(oa * 2);
+    vw[i] = (int)(ow * 2);
   }
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)d.B, 0, 0x7fffffff, 0x00020000);
   auto issue = [&](int t) {
     char* st = lds + (t % S64_NS) * S64_STAGE + (4 * wave) * 1024;
+    if constexpr (MUBUF) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[i] + t * 128),
-                                       (__attribute__((address_space(3))) void*)(st + i * 1024), 16, 0, 0);
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + i * 1024), 16, va[i], t * 256, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pw[i] + t * 128),
-                                       (__attribute__((address_space(3))) void*)(st + 16384 + i * 1024), 16, 0, 0);
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(st + 16384 + i * 1024), 16, vw[i], t * 256, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[i] + t * 128),
+                                         (__attribute__((address_space(3))) void*)(st + i * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pw[i] + t * 128),
+                                         (__attribute__((address_space(3))) void*)(st + 16384 + i * 1024), 16, 0, 0);
+    }
   };
   // fragments: lane (l31, hi) reads row l31 of its wave's 32-row block, k chunk 2 kk + hi (kk = 0 .. 7), swizzled by the row
   const int fa = (32 * wm + l31) * 256, fw = 16384 + (32 * wn + l31) * 256;
@@ -156,7 +176,9 @@ int gemm_skinny_try(const GemmDesc& d, hipStream_t stream) {
   const int nstrips = d.N >> 6;
   if ((d.K >> 6) < 16 || nstrips < 32 || nstrips > 64) return 0;
   const int mtiles = (d.M + 63) >> 6;
-  hipLaunchKernelGGL(gemm_skinny64_kernel, dim3(nstrips * mtiles), dim3(256), S64_NS * S64_STAGE, stream, d, nstrips, mtiles);
+  const bool mubuf = o.gemm_skinny == 2 && (int64_t)d.M * d.lda < (1ll << 29) && (int64_t)d.N * d.ldb < (1ll << 29);
+  if (mubuf) hipLaunchKernelGGL(gemm_skinny64_kernel<true>, dim3(nstrips * mtiles), dim3(256), S64_NS * S64_STAGE, stream, d, nstrips, mtiles);
+  else hipLaunchKernelGGL(gemm_skinny64_kernel<false>, dim3(nstrips * mtiles), dim3(256), S64_NS * S64_STAGE, stream, d, nstrips, mtiles);
   return launch_status() == U2_OK ? 1 : U2_ERR_LAUNCH;
 }
 

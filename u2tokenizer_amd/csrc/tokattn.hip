@@ -411,7 +411,10 @@ __device__ __forceinline__ float row_sum4(float v) {
 // block the other one can hold the matrix pipe; every wave issues half the fragment reads per MFMA of the old loop.
 // LDS at d = 512: 2 x 32 KB K stages + 2 x 32 KB V stages + 16 KB exchange (2 parities x 8 waves x 1 KB) + bias window
 // = 146.5 KB, one workgroup per CU; key splits / bias / tails exactly as tok_attn_kernel (same TokAttnArgs, same merge).
-template <int DH, bool TIMED = false>
+// MUBUF (option tok_wide = 2, round 6): the tiles' pieces leave as `buffer_load_dwordx4 ... lds` (descriptor over the batch entry's K / V,
+// 32-bit lane offset, tile and piece origin in the scalar offset) instead of the FLAT-encoded global_load_lds: beside waves that issue
+// MFMAs the FLAT form stages a third of what the MUBUF form does (tools/ubench/stage_bw.hip, profiles/r06_stage_bw.log).
+template <int DH, bool TIMED = false, bool MUBUF = false>
 __global__ __launch_bounds__(512) void tok_attn2_kernel(const TokAttnArgs a) {
   unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
 #define U2_STAMP(i_)                                            \
@@ -476,23 +479,38 @@ __global__ __launch_bounds__(512) void tok_attn2_kernel(const TokAttnArgs a) {
     koff[j] = (uint32_t)row0 * (uint32_t)(a.ldk * 2) + ((cp0 ^ (row & (SEG - 1))) << 4);
   }
   vofs = (uint32_t)row0 * (uint32_t)(a.ldv * 2) + (((cp0 & ~(SEG - 1)) | (((cp0 & (SEG - 1)) - tv_rot<SEG>(row0)) & (SEG - 1))) << 4);
+  // (MUBUF: one descriptor per operand over this batch entry's rows; byte offsets of a tile stay far below 2^31 -- the launcher checks)
+  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kb_, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vb_, 0, 0x7fffffff, 0x00020000);
   auto dma_tile = [&](const bf16_t* base, int64_t ld, bool is_k, int kt, char* dst) {
     const char* const tb = reinterpret_cast<const char*>(base) + (int64_t)kt * BK * ld * 2;
+    const int ld2 = (int)(ld * 2), tbo = kt * BK * ld2;   // (MUBUF: scalar byte offset of the tile)
     if (kt * BK + BK <= Skv) {
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
-        const char* const rb = tb + (int64_t)(i * RSTEP) * ld * 2;  // scalar
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rb + (is_k ? koff[i & 1] : vofs)),
-                                         (__attribute__((address_space(3))) void*)(dst + (i * 512 + w * 64) * 16), 16, 0, 0);
+        if constexpr (MUBUF) {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(is_k ? rsK : rsV, (__attribute__((address_space(3))) void*)(dst + (i * 512 + w * 64) * 16), 16,
+                                                   (int)(is_k ? koff[i & 1] : vofs), tbo + i * RSTEP * ld2, 0, 0);
+        } else {
+          const char* const rb = tb + (int64_t)(i * RSTEP) * ld * 2;  // scalar
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rb + (is_k ? koff[i & 1] : vofs)),
+                                           (__attribute__((address_space(3))) void*)(dst + (i * 512 + w * 64) * 16), 16, 0, 0);
+        }
       }
     } else {
       const int last = Skv - 1 - kt * BK;  // rows past the last key read a copy of it (masked in the softmax)
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
         const int row = row0 + i * RSTEP;
-        const char* const rb = tb + (int64_t)(i * RSTEP) * ld * 2 - (int64_t)(row - min(row, last)) * ld * 2;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rb + (is_k ? koff[i & 1] : vofs)),
-                                         (__attribute__((address_space(3))) void*)(dst + (i * 512 + w * 64) * 16), 16, 0, 0);
+        if constexpr (MUBUF) {
+          const int back = (row - min(row, last)) * ld2;   // (<= the row's own offset inside the tile: the sum stays >= 0)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(is_k ? rsK : rsV, (__attribute__((address_space(3))) void*)(dst + (i * 512 + w * 64) * 16), 16,
+                                                   (int)(is_k ? koff[i & 1] : vofs) + i * RSTEP * ld2 - back, tbo, 0, 0);
+        } else {
+          const char* const rb = tb + (int64_t)(i * RSTEP) * ld * 2 - (int64_t)(row - min(row, last)) * ld * 2;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rb + (is_k ? koff[i & 1] : vofs)),
+                                           (__attribute__((address_space(3))) void*)(dst + (i * 512 + w * 64) * 16), 16, 0, 0);
+        }
       }
     }
   };
@@ -849,9 +867,11 @@ int attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out,
   do {                                                                                                                 \
     constexpr size_t smem_ = 4 * 32 * (D_) * 2 + 16384 + TOKATTN_BIAS_SLOTS * 4;                                       \
     if (a.dbg) hipLaunchKernelGGL((tok_attn2_kernel<D_, true>), dim3((unsigned)grid), dim3(512), smem_, stream, a);   \
+    else if (mubuf) hipLaunchKernelGGL((tok_attn2_kernel<D_, false, true>), dim3((unsigned)grid), dim3(512), smem_, stream, a); \
     else hipLaunchKernelGGL((tok_attn2_kernel<D_, false>), dim3((unsigned)grid), dim3(512), smem_, stream, a);        \
   } while (0)
   const bool wide = d >= 256 && !causal && opts().tok_wide;  // two waves per SIMD (tok_attn2_kernel)
+  const bool mubuf = opts().tok_wide == 2 && (int64_t)Skv * ldk < (1ll << 29) && (int64_t)Skv * ldv < (1ll << 29);
   if (d == 512) { if (wide) U2_TA2(512); else U2_TA(512); }
   else if (d == 256) { if (wide) U2_TA2(256); else U2_TA(256); }
   else if (d == 128) U2_TA(128);
