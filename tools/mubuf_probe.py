@@ -71,3 +71,33 @@ for (M, N, K) in ((256, 4096, 4096), (200, 4096, 4096), (256, 2048, 4096)):
         us.setdefault(mode, []).append(timeit(fn, 64))
     print(f"gemm {M} x {N} x {K} (16 cold weights in rotation)   FLAT {min(us[1]):7.1f} us   MUBUF {min(us[2]):7.1f} us   same bits: {torch.equal(outs[1], outs[2])}")
 ops.set_option("gemm_skinny", 2)
+
+# the small-tile kernel (gemm.hip): the training path's products -- dW = dY^T X (both operands K-major), dX = dY W (B K-major) -- and a plain
+# product on forced 128^2 tiles; option gemm_mubuf 0 / 1
+scratch2 = torch.empty(256 << 20, dtype=torch.uint8, device=D)
+ops.set_gemm_scratch(scratch2)
+cases = [("dW fc1  (3072 x 768, K = 16392), both K-major", lambda: ops.gemm_kmajor(dy1, x1, a_kmajor=True)),
+         ("dW qkv  (2304 x 768, K = 16392), both K-major", lambda: ops.gemm_kmajor(dy2, x1, a_kmajor=True)),
+         ("dX fc1  (16392 x 768, K = 3072), B K-major", lambda: ops.gemm_kmajor(dy1, w1, a_kmajor=False)),
+         ("dX SVR  (2048 x 4096, K = 4096), B K-major", lambda: ops.gemm_kmajor(dy3, w3, a_kmajor=False)),
+         ("plain 2048 x 4096 x 4096, forced 128^2 tiles", lambda: ops.gemm(a4, w4))]
+dy1 = torch.randn(16392, 3072, device=D, generator=g).to(bf)
+dy2 = torch.randn(16392, 2304, device=D, generator=g).to(bf)
+x1 = torch.randn(16392, 768, device=D, generator=g).to(bf)
+w1 = torch.randn(3072, 768, device=D, generator=g).to(bf)
+dy3 = torch.randn(2048, 4096, device=D, generator=g).to(bf)
+w3 = torch.randn(4096, 4096, device=D, generator=g).to(bf)
+a4, w4 = dy3, w3
+for name, fn in cases:
+    forced = "forced" in name
+    if forced:
+        ops.set_option("gemm_tile", 128); ops.set_option("gemm_big", -1)
+    outs, us = {}, {}
+    for mode in (0, 1, 0, 1):
+        ops.set_option("gemm_mubuf", mode)
+        outs[mode] = fn().clone()
+        us.setdefault(mode, []).append(timeit(fn, 20))
+    if forced:
+        ops.set_option("gemm_tile", 0); ops.set_option("gemm_big", 0)
+    print(f"{name:50s} FLAT {min(us[0]):8.1f} us   MUBUF {min(us[1]):8.1f} us   same bits: {torch.equal(outs[0], outs[1])}")
+ops.set_option("gemm_mubuf", 1)

@@ -161,4 +161,16 @@ static inline int launch_status() {
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+
+// 16 bytes per lane from a raw buffer (descriptor + 32-bit lane offset + scalar offset) straight into LDS: `buffer_load_dwordx4 ... lds`.
+// Device pass only -- the host pass of hipcc does not know the builtin, and a template kernel that names it unguarded silently loses its
+// host stub (undefined __device_stub__ symbol at load time).
+__device__ __forceinline__ void lds_dma_mubuf16(const void* base_rsrc_ptr, void* lds_dst, int voffset, int soffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base_rsrc_ptr), 0, 0x7fffffff, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
+#else
+  (void)base_rsrc_ptr; (void)lds_dst; (void)voffset; (void)soffset;
+#endif
+}
 }  // namespace u2

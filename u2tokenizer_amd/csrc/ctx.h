@@ -15,6 +15,7 @@ namespace u2 {
 
 struct Options {
   int gemm_tile = 0;        // 0 heuristic, 64 / 128 force the small-tile kernel's tile
+  int gemm_mubuf = 1;       // 1: the small-tile kernel's LDS-DMA pieces leave as buffer_load ... lds where the operands span < 2 GB; 0: FLAT-encoded global_load_lds (A/B)
   int gemm_splitk = 0;      // -1 never, 0 heuristic, 2..16 force that many K slices where scratch allows
   int gemm_big = 0;         // -1 never, 0 heuristic, 20 / 21 / 22 force the 256x256 / 256x192 / 256x128 (ring) big-tile kernel, 24 / 26 the deep forms, 27 the drain form
   int gemm_big_grid = 256;  // persistent workgroups of the big-tile kernel

@@ -102,6 +102,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
   const bf16_t* pb[CB];
   int ka[CA], kb[CB];
   bool oka[CA], okb[CB];
+  // MUBUF form (d.mubuf; round 6): byte offsets from this batch entry's operand base, one raw descriptor per operand, the K advance in the
+  // scalar offset.  (Beside waves that issue MFMAs -- here: the other workgroup of the CU -- the FLAT-encoded global_load_lds stages a
+  // third of what buffer_load ... lds does: tools/ubench/stage_bw.hip, profiles/r06_stage_bw.log.)  A chunk that does not exist (K tail,
+  // columns past M / N of a K-major operand) takes the lane offset 2^31: past num_records whichever way the range check reads it -> zeros.
+  int va[CA], vb[CB];
+  const bool mubuf = d.mubuf != 0;
 #pragma unroll
   for (int i = 0; i < CA; ++i) {
     const int c = i * 256 + tid;
@@ -117,6 +123,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
       oka[i] = true;
       pa[i] = A + (int64_t)grow * d.lda + gc * 8;
     }
+    va[i] = (int)((pa[i] - A) * 2);
   }
 #pragma unroll
   for (int i = 0; i < CB; ++i) {
@@ -133,6 +140,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
       okb[i] = true;
       pb[i] = B + (int64_t)grow * d.ldb + gc * 8;
     }
+    vb[i] = (int)((pb[i] - B) * 2);
   }
 
   f32x4 acc[MI][NI];
@@ -178,6 +186,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmDesc d) {
   auto dma = [&](int kt, int buf) {
     const int k0 = kt * BK;
     char* s = lds + buf * STAGE;
+    if (mubuf) {
+      const int sa = (int)((TA ? (int64_t)kt * kadv_a : (int64_t)k0) * 2), sb = (int)((int64_t)kt * kadv_b * 2);
+#pragma unroll
+      for (int i = 0; i < CA; ++i) {
+        const bool ok = (TA ? oka[i] : true) && k0 + ka[i] < d.K;
+        lds_dma_mubuf16(A, s + (i * 256 + wave * 64) * 16, ok ? va[i] : (int)0x80000000, sa);
+      }
+#pragma unroll
+      for (int i = 0; i < CB; ++i) {
+        const bool ok = (TB ? okb[i] : true) && k0 + kb[i] < d.K;
+        lds_dma_mubuf16(B, s + BM * ROWB + (i * 256 + wave * 64) * 16, ok ? vb[i] : (int)0x80000000, sb);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < CA; ++i) {
       const void* src;
@@ -462,6 +484,12 @@ static int launch_tile(GemmDesc d, hipStream_t stream) {
   dim3 grid(d.tiles_m * d.tiles_n, d.nz, d.ksplit > 1 ? d.ksplit : 1);
   constexpr int smem = 2 * (BM + BN) * 64 * 2;
   const bool ta = d.flags & GEMM_A_KMAJOR, tb = d.flags & GEMM_B_KMAJOR;
+  {  // MUBUF pieces when every byte offset of a batch entry's operands (K tile advance included) stays below 2^31
+    const int64_t ktiles = cdiv(d.K, 64) + 1;
+    const int64_t ea = (ta ? ktiles * 64 * d.lda + d.M : (int64_t)d.M * d.lda + ktiles * 64) * 2;
+    const int64_t eb = (tb ? ktiles * 64 * d.ldb + d.N : d.ldbk ? ktiles * d.ldbk + (int64_t)d.N * d.ldb : (int64_t)d.N * d.ldb + ktiles * 64) * 2;
+    d.mubuf = (opts().gemm_mubuf && ea < (1ll << 31) - 65536 && eb < (1ll << 31) - 65536) ? 1 : 0;
+  }
   if (ta) hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, true, true>), grid, dim3(256), smem, stream, d);
   else if (tb) hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, false, true>), grid, dim3(256), smem, stream, d);
   else hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN>), grid, dim3(256), smem, stream, d);

@@ -69,17 +69,15 @@ __global__ __launch_bounds__(256, 1) void gemm_skinny64_kernel(GemmDesc d, int n
     va[i] = (int)(oa * 2);
     vw[i] = (int)(ow * 2);
   }
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A, 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)d.B, 0, 0x7fffffff, 0x00020000);
   auto issue = [&](int t) {
     char* st = lds + (t % S64_NS) * S64_STAGE + (4 * wave) * 1024;
     if constexpr (MUBUF) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + i * 1024), 16, va[i], t * 256, 0, 0);
+        lds_dma_mubuf16(d.A, st + i * 1024, va[i], t * 256);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(st + 16384 + i * 1024), 16, vw[i], t * 256, 0, 0);
+        lds_dma_mubuf16(d.B, st + 16384 + i * 1024, vw[i], t * 256);
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i)

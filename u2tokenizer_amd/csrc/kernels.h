@@ -68,6 +68,9 @@ struct GemmDesc {
   // in-launch tail (filled by the big-tile launcher): rows [M, M + tail_rows) of A / C / R (<= 16: the ViT's cls rows behind the
   // patch rows) are computed inside the same launch by the few-rows arithmetic (rows16.h) instead of a launch of their own
   int tail_rows = 0;
+  // classic tile kernel (filled by its launcher): 1 = the LDS-DMA pieces leave as buffer_load ... lds (both operands of a batch entry
+  // span < 2 GB), 0 = FLAT-encoded global_load_lds (option gemm_mubuf 0, or larger operands)
+  int mubuf = 0;
 };
 
 // Options (tile, split-K, big-tile selection) and the split-K scratch registration of the launch stream come from the

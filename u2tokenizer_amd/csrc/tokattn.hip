@@ -480,8 +480,6 @@ __global__ __launch_bounds__(512) void tok_attn2_kernel(const TokAttnArgs a) {
   }
   vofs = (uint32_t)row0 * (uint32_t)(a.ldv * 2) + (((cp0 & ~(SEG - 1)) | (((cp0 & (SEG - 1)) - tv_rot<SEG>(row0)) & (SEG - 1))) << 4);
   // (MUBUF: one descriptor per operand over this batch entry's rows; byte offsets of a tile stay far below 2^31 -- the launcher checks)
-  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kb_, 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vb_, 0, 0x7fffffff, 0x00020000);
   auto dma_tile = [&](const bf16_t* base, int64_t ld, bool is_k, int kt, char* dst) {
     const char* const tb = reinterpret_cast<const char*>(base) + (int64_t)kt * BK * ld * 2;
     const int ld2 = (int)(ld * 2), tbo = kt * BK * ld2;   // (MUBUF: scalar byte offset of the tile)
@@ -489,8 +487,7 @@ __global__ __launch_bounds__(512) void tok_attn2_kernel(const TokAttnArgs a) {
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
         if constexpr (MUBUF) {
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(is_k ? rsK : rsV, (__attribute__((address_space(3))) void*)(dst + (i * 512 + w * 64) * 16), 16,
-                                                   (int)(is_k ? koff[i & 1] : vofs), tbo + i * RSTEP * ld2, 0, 0);
+          lds_dma_mubuf16(base, dst + (i * 512 + w * 64) * 16, (int)(is_k ? koff[i & 1] : vofs), tbo + i * RSTEP * ld2);
         } else {
           const char* const rb = tb + (int64_t)(i * RSTEP) * ld * 2;  // scalar
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rb + (is_k ? koff[i & 1] : vofs)),
@@ -504,8 +501,7 @@ __global__ __launch_bounds__(512) void tok_attn2_kernel(const TokAttnArgs a) {
         const int row = row0 + i * RSTEP;
         if constexpr (MUBUF) {
           const int back = (row - min(row, last)) * ld2;   // (<= the row's own offset inside the tile: the sum stays >= 0)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(is_k ? rsK : rsV, (__attribute__((address_space(3))) void*)(dst + (i * 512 + w * 64) * 16), 16,
-                                                   (int)(is_k ? koff[i & 1] : vofs) + i * RSTEP * ld2 - back, tbo, 0, 0);
+          lds_dma_mubuf16(base, dst + (i * 512 + w * 64) * 16, (int)(is_k ? koff[i & 1] : vofs) + i * RSTEP * ld2 - back, tbo);
         } else {
           const char* const rb = tb + (int64_t)(i * RSTEP) * ld * 2 - (int64_t)(row - min(row, last)) * ld * 2;
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rb + (is_k ? koff[i & 1] : vofs)),
