@@ -529,6 +529,45 @@ def test_gemm_kmajor_operands(ops, tile):
         torch.cuda.synchronize()
 
 
+def test_gemm_small_tile_flat_and_mubuf_pieces_agree(ops):
+    """Round 6: the small-tile kernel's LDS-DMA pieces leave as buffer_load ... lds (option gemm_mubuf, default 1; the chunk that does
+    not exist -- K tail, columns past M / N of a K-major operand -- takes an out-of-range lane offset and lands as zeros) or as the
+    FLAT-encoded global_load_lds of rounds 1-5 (0): the same bits on ragged shapes of every operand form, batched and K-tile-major."""
+    scratch = torch.empty(64 << 20, dtype=torch.uint8, device=D)
+    ops.set_gemm_scratch(scratch)
+
+    def both(fn):
+        out = []
+        for mode in (0, 1):
+            ops.set_option("gemm_mubuf", mode)
+            out.append(fn().clone())
+        assert torch.equal(out[0], out[1])
+
+    try:
+        for tile in (64, 128):
+            ops.set_option("gemm_tile", tile)
+            for (M, N, K) in [(300, 200, 136), (77, 520, 72), (2049, 768, 776)]:
+                a, b, bias = rnd(M, K, seed=1).to(D), rnd(N, K, seed=2).to(D), rnd(N, seed=3).to(D)
+                both(lambda: ops.gemm(a, b, bias=bias))
+            a3, b3 = rnd(6, 100, 72, seed=10).to(D), rnd(6, 90, 72, seed=11).to(D)
+            both(lambda: ops.gemm(a3, b3, out_f32=True))
+            for (M, N, K) in [(200, 72, 136), (264, 8, 72), (256, 1000, 2048)]:
+                a, bk = rnd(M, K, seed=4).to(D), rnd(K, N, seed=5).to(D)
+                both(lambda: ops.gemm_kmajor(a, bk, a_kmajor=False))
+            for (M, N, K) in [(72, 200, 131), (520, 8, 1157), (768, 2304, 2049)]:
+                ak, bk = rnd(K, M, seed=6).to(D), rnd(K, N, seed=7).to(D)
+                both(lambda: ops.gemm_kmajor(ak, bk, a_kmajor=True))
+        ops.set_option("gemm_tile", 0)
+        a, w = rnd(77, 128, seed=8).to(D), rnd(200, 128, seed=9).to(D)
+        wt = ops.pack_ktile_major(w)
+        both(lambda: ops.gemm(a, wt, b_ktile=True))
+    finally:
+        ops.set_option("gemm_tile", 0)
+        ops.set_option("gemm_mubuf", 1)
+        ops.set_gemm_scratch(None)
+        torch.cuda.synchronize()
+
+
 def test_gemm_ktile_major_weights(ops):
     """B handed over K-tile-major ([K/64][N][64], ops.pack_ktile_major): same products as the row-major weight, with and
     without split-K, tails in M and N."""

@@ -17,7 +17,7 @@ sys.path.insert(0, str(ROOT))
 import bench  # noqa: E402
 from u2tokenizer_amd import ops  # noqa: E402
 
-DEFAULTS = dict(gemm_big=0, gemm_big_ring=1, gemm_big_deep=1, gemm_big_skinny=1, gemm_big_gelu=1, gemm_splitk=0, flash_mode=0, tta_overlap=1, gemm_tile=0, kmajor_b=1, tok_flash=1, tok_wide=2, vit_vt_epilogue=1, gemm_tail_fused=1, gemm_big_drain=1, gemm_skinny=2, gemm_big_grid=256)
+DEFAULTS = dict(ln_wide=1, gemm_mubuf=1, gemm_big=0, gemm_big_ring=1, gemm_big_deep=1, gemm_big_skinny=1, gemm_big_gelu=1, gemm_splitk=0, flash_mode=0, tta_overlap=1, gemm_tile=0, kmajor_b=1, tok_flash=1, tok_wide=2, vit_vt_epilogue=1, gemm_tail_fused=1, gemm_big_drain=1, gemm_skinny=2, gemm_big_grid=256)
 
 
 def main():

@@ -14,6 +14,7 @@
 namespace u2 {
 
 struct Options {
+  int ln_wide = 1;          // 1: LayerNorm rows of >= 2048 elements take a workgroup per row (layernorm_wide_kernel); 0: a wave per row (A/B)
   int gemm_tile = 0;        // 0 heuristic, 64 / 128 force the small-tile kernel's tile
   int gemm_mubuf = 1;       // 1: the small-tile kernel's LDS-DMA pieces leave as buffer_load ... lds where the operands span < 2 GB; 0: FLAT-encoded global_load_lds (A/B)
   int gemm_splitk = 0;      // -1 never, 0 heuristic, 2..16 force that many K slices where scratch allows

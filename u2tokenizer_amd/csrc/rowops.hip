@@ -74,6 +74,81 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
   }
 }
 
+// Long rows (C >= 2048: the tokenizer's hidden size), few of them (2048 SVR tokens, 256 TTA queries): one WORKGROUP per row -- four waves
+// share the row's loads (2 KB in flight per wave instead of 8, four times the waves), the two reductions cross the waves through LDS.
+// (option ln_wide, default 1; 0: one wave per row like the narrow rows)
+template <int NC>  // chunks (8 elements) per THREAD: C <= NC * 2048
+__global__ __launch_bounds__(256) void layernorm_wide_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res,
+                                                             const bf16_t* __restrict__ w, const bf16_t* __restrict__ bias,
+                                                             bf16_t* __restrict__ y, int nb, int rows, int C,
+                                                             int64_t x_bs, int64_t x_ld, int64_t res_bs, int64_t res_ld,
+                                                             int64_t y_bs, int64_t y_ld, float eps) {
+  __shared__ float red[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t row = blockIdx.x;
+  const int b = (int)(row / rows), r = (int)(row - (int64_t)b * rows);
+  const bf16_t* xp = x + b * x_bs + r * x_ld;
+  const bf16_t* rp = res ? res + b * res_bs + r * res_ld : nullptr;
+  bf16_t* yp = y + b * y_bs + r * y_ld;
+  const int nchunk = C >> 3;
+  float v[NC][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = i * 256 + tid;
+    if (c < nchunk) {
+      const uint4 u = *reinterpret_cast<const uint4*>(xp + c * 8);
+      v[i][0] = bf16lo(u.x); v[i][1] = bf16hi(u.x); v[i][2] = bf16lo(u.y); v[i][3] = bf16hi(u.y);
+      v[i][4] = bf16lo(u.z); v[i][5] = bf16hi(u.z); v[i][6] = bf16lo(u.w); v[i][7] = bf16hi(u.w);
+      if (rp) {
+        const uint4 q = *reinterpret_cast<const uint4*>(rp + c * 8);
+        v[i][0] += bf16lo(q.x); v[i][1] += bf16hi(q.x); v[i][2] += bf16lo(q.y); v[i][3] += bf16hi(q.y);
+        v[i][4] += bf16lo(q.z); v[i][5] += bf16hi(q.z); v[i][6] += bf16lo(q.w); v[i][7] += bf16hi(q.w);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += v[i][j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+    }
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[0][wave] = sum;
+  __syncthreads();
+  const float mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    if (i * 256 + tid < nchunk) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float dlt = v[i][j] - mean; sq += dlt * dlt; }
+    }
+  }
+  sq = wave_sum(sq);
+  if (lane == 0) red[1][wave] = sq;
+  __syncthreads();
+  const float rstd = rsqrtf(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = i * 256 + tid;
+    if (c < nchunk) {
+      const uint4 uw = *reinterpret_cast<const uint4*>(w + c * 8);
+      const uint4 ub = *reinterpret_cast<const uint4*>(bias + c * 8);
+      float o[8];
+      o[0] = (v[i][0] - mean) * rstd * bf16lo(uw.x) + bf16lo(ub.x);
+      o[1] = (v[i][1] - mean) * rstd * bf16hi(uw.x) + bf16hi(ub.x);
+      o[2] = (v[i][2] - mean) * rstd * bf16lo(uw.y) + bf16lo(ub.y);
+      o[3] = (v[i][3] - mean) * rstd * bf16hi(uw.y) + bf16hi(ub.y);
+      o[4] = (v[i][4] - mean) * rstd * bf16lo(uw.z) + bf16lo(ub.z);
+      o[5] = (v[i][5] - mean) * rstd * bf16hi(uw.z) + bf16hi(ub.z);
+      o[6] = (v[i][6] - mean) * rstd * bf16lo(uw.w) + bf16lo(ub.w);
+      o[7] = (v[i][7] - mean) * rstd * bf16hi(uw.w) + bf16hi(ub.w);
+      *reinterpret_cast<uint4*>(yp + c * 8) =
+          uint4{pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]), pack2_bf16(o[4], o[5]), pack2_bf16(o[6], o[7])};
+    }
+  }
+}
+
 int layernorm_bf16(const bf16_t* x, const bf16_t* res, const bf16_t* w, const bf16_t* bias, bf16_t* y,
                    int nb, int rows, int C, int64_t x_bs, int64_t x_ld, int64_t res_bs, int64_t res_ld,
                    int64_t y_bs, int64_t y_ld, float eps, hipStream_t stream) {
@@ -84,6 +159,17 @@ int layernorm_bf16(const bf16_t* x, const bf16_t* res, const bf16_t* w, const bf
   const int64_t total = (int64_t)nb * rows;
   dim3 grid((unsigned)cdiv(total, 4));
   ProfScope ps(PROF_ROWOP, 0, stream, (double)total * C * 2.0 * (res ? 3.0 : 2.0));
+  if (opts().ln_wide && C >= 2048 && total <= 65535 * 4) {   // long rows: a workgroup per row
+    dim3 gw((unsigned)total);
+#define U2_LNW(NC)                                                                                              \
+  hipLaunchKernelGGL((layernorm_wide_kernel<NC>), gw, dim3(256), 0, stream, x, res, w, bias, y, nb, rows, C,    \
+                     x_bs, x_ld, res_bs, res_ld, y_bs, y_ld, eps)
+    if (C <= 2048) U2_LNW(1);
+    else if (C <= 4096) U2_LNW(2);
+    else U2_LNW(4);
+#undef U2_LNW
+    return launch_status();
+  }
 #define U2_LN(NC)                                                                                          \
   hipLaunchKernelGGL((layernorm_kernel<NC>), grid, dim3(256), 0, stream, x, res, w, bias, y, nb, rows, C,  \
                      x_bs, x_ld, res_bs, res_ld, y_bs, y_ld, eps)
