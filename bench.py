@@ -669,7 +669,8 @@ def main():
             line["kernel_table"] = {
                 "source": "rocprofv3 --kernel-trace --stats child of this command: the 6 timed volumes of its trace (the warm-up volume "
                           "dropped), one stream, tokenizer side stream off (tta_overlap=0), no counters",
-                "kernels": table[:24],
+                "kernels": table[:40],
+                "launches_per_volume": round(sum(k["launches_per_volume"] for k in table), 1),
                 "classes": {k: {"ms_per_volume": round(v, 4),
                                 "tflops": (round(flops[cls_key.index(k)] / nprof / v / 1e9, 1)
                                            if k in cls_key and flops[cls_key.index(k)] > 0 and v > 0 else None),
