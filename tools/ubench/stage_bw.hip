@@ -13,7 +13,9 @@
 //   the load the staging pieces of gemm_bt.hip compete with.  The background waves poll an LDS flag the last issuing wave sets.
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16_t;
-template <int MODE, int BK, int DEPTH, int NWAVES_ISSUE, int SWZ = 0, int BG = 0>
+// ROT (round 6): workgroup b walks the K tiles in the rotated order (kt + rot_b) mod nkt -- workgroups that share a panel are then at
+// different K tiles instead of missing the same cache lines together
+template <int MODE, int BK, int DEPTH, int NWAVES_ISSUE, int SWZ = 0, int BG = 0, int ROT = 0>
 __global__ __launch_bounds__(512) void stage_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B,
                                                     int K, int lda, int ntile, unsigned* sink, unsigned long long* bgcount) {
   constexpr int ROWS = BK > 64 ? 512 * 64 / BK : 512, HALF = ROWS / 2;   // (BK 128 / 256: fewer rows, the same 64 KB per stage -- round 6)
@@ -84,8 +86,10 @@ __global__ __launch_bounds__(512) void stage_kernel(const unsigned short* __rest
         src[i] = (r < HALF ? A + (size_t)(bm0 + r) * lda : B + (size_t)(bn0 + r - HALF) * lda) + gc * 8;
       }
       const int nkt = K / BK;
-      for (int kt = 0; kt < nkt; ++kt) {
-        char* s = lds + (kt & 1) * STAGE + wave * 1024;
+      const int rot = ROT == 1 ? (int)((blockIdx.x / 8) * 37u % (unsigned)nkt) : ROT == 2 ? (int)((blockIdx.x / 32) * (nkt / 8)) : 0;
+      for (int kt_ = 0; kt_ < nkt; ++kt_) {
+        const int kt = ROT ? (kt_ + rot) % nkt : kt_;
+        char* s = lds + (kt_ & 1) * STAGE + wave * 1024;
         if constexpr (MODE == 3 || MODE == 4) {
           // MUBUF form: one descriptor per matrix, 32-bit per-lane offsets, the K advance in the scalar offset
 #pragma unroll
@@ -100,13 +104,13 @@ __global__ __launch_bounds__(512) void stage_kernel(const unsigned short* __rest
                                                        voff[i], kt * BK * 2, 0, 0);
 #endif
           }
-          if (kt >= DEPTH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * DEPTH > 63 ? 63 : PW * DEPTH) : "memory");
+          if (kt_ >= DEPTH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * DEPTH > 63 ? 63 : PW * DEPTH) : "memory");
         } else if constexpr (MODE == 0) {
 #pragma unroll
           for (int i = 0; i < PW; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + kt * BK),
                                              (__attribute__((address_space(3))) void*)(s + i * NWAVES_ISSUE * 1024), 16, 0, 0);
-          if (kt >= DEPTH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * DEPTH > 63 ? 63 : PW * DEPTH) : "memory");
+          if (kt_ >= DEPTH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * DEPTH > 63 ? 63 : PW * DEPTH) : "memory");
         } else {
           uint4 r[PW];
 #pragma unroll
@@ -129,18 +133,18 @@ __global__ __launch_bounds__(512) void stage_kernel(const unsigned short* __rest
   if (acc == 0x12345678u) sink[0] = acc;
 }
 
-template <int MODE, int BK, int DEPTH, int NW, int SWZ = 0, int BG = 0>
+template <int MODE, int BK, int DEPTH, int NW, int SWZ = 0, int BG = 0, int ROT = 0>
 static void run(const char* name, const unsigned short* A, const unsigned short* B, unsigned* sink) {
   const int K = 8192, ntile = 4;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   static unsigned long long* bgc = nullptr;
   if (!bgc) hipMalloc(&bgc, 8);
-  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((stage_kernel<MODE, BK, DEPTH, NW, SWZ, BG>), dim3(256), dim3(512), 0, 0, A, B, K, 8192, ntile, sink, bgc);
+  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((stage_kernel<MODE, BK, DEPTH, NW, SWZ, BG, ROT>), dim3(256), dim3(512), 0, 0, A, B, K, 8192, ntile, sink, bgc);
   hipMemset(bgc, 0, 8);
   hipEventRecord(e0);
   const int it = 5;
-  for (int w = 0; w < it; ++w) hipLaunchKernelGGL((stage_kernel<MODE, BK, DEPTH, NW, SWZ, BG>), dim3(256), dim3(512), 0, 0, A, B, K, 8192, ntile, sink, bgc);
+  for (int w = 0; w < it; ++w) hipLaunchKernelGGL((stage_kernel<MODE, BK, DEPTH, NW, SWZ, BG, ROT>), dim3(256), dim3(512), 0, 0, A, B, K, 8192, ntile, sink, bgc);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0; hipEventElapsedTime(&ms, e0, e1); ms /= it;
@@ -177,6 +181,11 @@ int main() {
   run<4, 64, 2, 4, 0, 2>("buffer_load..lds + 1 VALU u64 add per piece | GEMM mix", A, B, sink);
   run<0, 64, 2, 4, 0, 2>("glds  BK64 4 waves no swizzle | GEMM mix", A, B, sink);
   run<4, 64, 2, 4, 0, 0>("buffer_load..lds + 1 VALU u64 add per piece", A, B, sink);
+  run<3, 64, 2, 4, 0, 0, 1>("buffer_load..lds BK64 4 waves, K order rotated per workgroup", A, B, sink);
+  run<3, 64, 2, 4, 0, 0, 2>("buffer_load..lds BK64 4 waves, rotated per A-panel sharer", A, B, sink);
+  run<3, 64, 2, 4, 0, 2, 1>("buffer_load..lds BK64 4 waves, rotated | GEMM mix", A, B, sink);
+  run<3, 64, 1, 4, 0, 0, 0>("buffer_load..lds BK64 4 waves depth 1", A, B, sink);
+  run<3, 64, 1, 4, 0, 0, 1>("buffer_load..lds BK64 4 waves depth 1, rotated", A, B, sink);
   run<0, 64, 1, 8>("glds  BK64 depth1 8 waves", A, B, sink);
   run<0, 64, 2, 4>("glds  BK64 depth2 4 waves", A, B, sink);
   run<3, 64, 2, 8>("buffer_load..lds BK64 depth2 8 waves", A, B, sink);
