@@ -176,7 +176,7 @@ def test_selection_stage_is_bit_exact(ops):
 
 
 def test_multiscale_pool_fixed_and_gated(ops):
-    for k in (64, 30, 3, 1):
+    for k in (64, 30, 31, 3, 1):   # (31, 30, 3: the tokens past the last group of four)
         x = rnd(2, k, 512, seed=16)
         close_bf16(ops.multiscale_pool(x.to(D)), O.multi_scale_pool({}, None, x.float()), rounds=1)
         gw, gb = rnd(1, 512, scale=0.3, seed=17), rnd(1, seed=18)
