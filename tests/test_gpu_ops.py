@@ -409,7 +409,9 @@ def _tok_attn_ref(q, k, v, H, scale, tbl=None, L=512):
     (1, 1, 1, 1, 64, True, 0), (1, 16, 33, 1, 128, False, 0), (1, 512, 512, 2, 64, True, 4),
     # wide heads (8-wave form: a wave pair per 16-query block) with tails everywhere, one-tile and odd tile counts, splits
     (2, 37, 53, 2, 256, True, 0), (2, 37, 53, 2, 256, True, 2), (1, 100, 70, 1, 512, False, 3), (1, 1, 1, 1, 512, True, 0),
-    (1, 130, 97, 2, 512, True, 0), (3, 64, 32, 1, 256, False, 0), (1, 16, 33, 1, 512, False, 2), (1, 300, 480, 2, 512, True, 5)])
+    (1, 130, 97, 2, 512, True, 0), (3, 64, 32, 1, 256, False, 0), (1, 16, 33, 1, 512, False, 2), (1, 300, 480, 2, 512, True, 5),
+    # the merge kernel's compile-time split counts 6, 7 and the run-time form behind 8 (round 6)
+    (1, 128, 384, 2, 128, False, 6), (1, 64, 448, 2, 256, False, 7), (1, 64, 640, 1, 512, False, 10)])
 def test_tok_attention(ops, nb, Sq, Skv, H, d, bias, splits):
     """The fused attention core of the tokenizer (u2tok_tok_attention) against an fp32 softmax(q k^T scale + bias) v of the
     same bf16 inputs; q / k / v are column slices of packed buffers, as the pipeline passes them; three launches must
