@@ -53,7 +53,7 @@ int u2tok_set_option(const char* name, int value) {
   struct Opt { const char* name; int Options::*field; int lo, hi; };
   static const Opt table[] = {
       {"gemm_splitk", &Options::gemm_splitk, -1, 16},   {"gemm_mubuf", &Options::gemm_mubuf, 0, 1}, {"ln_wide", &Options::ln_wide, 0, 1},   {"gemm_big", &Options::gemm_big, -1, 27},
-      {"gemm_big_grid", &Options::gemm_big_grid, 1, 4096}, {"gemm_big_gelu", &Options::gemm_big_gelu, 0, 1},
+      {"gemm_big_grid", &Options::gemm_big_grid, 1, 4096}, {"gemm_big_group_m", &Options::gemm_big_group_m, 0, 64}, {"gemm_big_gelu", &Options::gemm_big_gelu, 0, 1},
       {"gemm_big_splitk", &Options::gemm_big_splitk, 0, 16}, {"gemm_big_skinny", &Options::gemm_big_skinny, 0, 1},
       {"gemm_big_ring", &Options::gemm_big_ring, 0, 1},   {"gemm_big_deep", &Options::gemm_big_deep, 0, 1},
       {"gemm_big_drain", &Options::gemm_big_drain, 0, 2}, {"gemm_skinny", &Options::gemm_skinny, 0, 2},

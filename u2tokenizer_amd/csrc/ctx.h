@@ -20,6 +20,7 @@ struct Options {
   int gemm_splitk = 0;      // -1 never, 0 heuristic, 2..16 force that many K slices where scratch allows
   int gemm_big = 0;         // -1 never, 0 heuristic, 20 / 21 / 22 force the 256x256 / 256x192 / 256x128 (ring) big-tile kernel, 24 / 26 the deep forms, 27 the drain form
   int gemm_big_grid = 256;  // persistent workgroups of the big-tile kernel
+  int gemm_big_group_m = 0; // 0 heuristic; 1 .. 64: row tiles per group of the big-tile kernels' tile walk (A/B)
   int gemm_big_gelu = 1;    // 1: GELU products may take the big-tile kernel too (two-stage form); 0: always the 128^2 kernel
   int gemm_big_splitk = 0;  // K slices of a FORCED big-tile launch (gemm_big = 20 / 21): measurements, tests
   int gemm_big_deep = 1;    // 1: unsliced 256 x 192 / 256 x 256 products take the deep form (three LDS stages for B, two for A); 0: two stages (A/B)

@@ -41,7 +41,7 @@ __device__ __forceinline__ void pp_tile(const GemmDesc& d, int round, int gd, in
   const int pid = base + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   z = pid / tiles_mn;
   const int rem = pid - z * tiles_mn;
-  constexpr int GROUP_M = 8;
+  const int GROUP_M = d.group_m;
   const int per_group = GROUP_M * d.tiles_n;
   const int group = rem / per_group, in_g = rem - group * per_group;
   const int first_m = group * GROUP_M;
@@ -754,9 +754,16 @@ static bool bt_drain_ok(const GemmDesc& d) {
   return tiles >= 2 * (int64_t)opts().gemm_big_grid;   // every workgroup has a tile to hide the previous one under
 }
 
+// Row tiles per group of the tile walk (pp_tile).  An XCD runs 32 consecutive ids = group_m row tiles x 32 / group_m column tiles at a time.
+static int bt_group_m(const GemmDesc& d) {
+  const int o = opts().gemm_big_group_m;
+  return o > 0 ? o : 8;
+}
+
 static int bt_launch_drain(GemmDesc d, hipStream_t stream) {
   d.tiles_m = d.M / 256;
   d.tiles_n = d.N / 192;
+  d.group_m = bt_group_m(d);
   const int64_t total = (int64_t)d.tiles_m * d.tiles_n;
   const int grid = (int)std::min<int64_t>(total, opts().gemm_big_grid);
   const bool tail = d.tail_rows > 0;
@@ -773,6 +780,7 @@ static int bt_launch_deep(GemmDesc d, hipStream_t stream) {
   if (d.ksplit > 1) return U2_ERR_ARG;
   d.tiles_m = (int)cdiv(d.M, 256);
   d.tiles_n = (int)cdiv(d.N, 64 * NJ);
+  d.group_m = bt_group_m(d);
   const int64_t total = (int64_t)d.tiles_m * d.tiles_n * d.nz;
   if (total > 0x3fffffff) return U2_ERR_ARG;
   const int grid = (int)std::min<int64_t>(total, opts().gemm_big_grid);
@@ -797,6 +805,7 @@ static int bt_launch(GemmDesc d, hipStream_t stream) {
   if (d.vt) return U2_ERR_ARG;  // only the deep 256 x 192 form leaves transposed tiles (bt_launch_deep): never drop the request silently
   d.tiles_m = (int)cdiv(d.M, 256);
   d.tiles_n = (int)cdiv(d.N, 64 * NJ);
+  d.group_m = bt_group_m(d);
   if (d.ksplit > 1 && (d.nz != 1 || PAIR || !d.partial)) return U2_ERR_ARG;
   const int64_t total = (int64_t)d.tiles_m * d.tiles_n * (d.ksplit > 1 ? d.ksplit : d.nz);
   if (total > 0x3fffffff) return U2_ERR_ARG;

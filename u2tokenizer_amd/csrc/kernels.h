@@ -71,6 +71,8 @@ struct GemmDesc {
   // classic tile kernel (filled by its launcher): 1 = the LDS-DMA pieces leave as buffer_load ... lds (both operands of a batch entry
   // span < 2 GB), 0 = FLAT-encoded global_load_lds (option gemm_mubuf 0, or larger operands)
   int mubuf = 0;
+  // big-tile kernels (filled by their launchers): row tiles per group of the tile walk (pp_tile: ids walk `group_m` row tiles column by column)
+  int group_m = 8;
 };
 
 // Options (tile, split-K, big-tile selection) and the split-K scratch registration of the launch stream come from the
