@@ -613,6 +613,7 @@ def gen_deep(nj, deep):
             def win(m, half, st, s_k):
                 return {slot: [(m, i, st, s_k) for i in sched[m][w].get(half * nslot + slot, [])] for slot in range(nslot)}
 
+            IN_LOOP[0] = True     # (--ablate-deep: measurement-only builds)
             mfma_block(0, xk(win(smat, 1, shallow_next, K1), 1, sa, sb, 1), xa, xb)
             mfma_block(1, xk(win(dmat, 0, deep_tgt, K2), 0, sa, sb, 2), xa, xb)
             mfma_block(0, xk(win(dmat, 1, deep_tgt, K2), 1, sa, sb, 3), xa, xb)
@@ -620,6 +621,7 @@ def gen_deep(nj, deep):
             e("s_barrier")
             # behind the barrier: the shallow operand's stage of tile t is free -> first half of its tile t+2
             mfma_block(1, xk(win(smat, 0, st_of[smat], K2), 0, na, nb, 0), xa, xb)
+            IN_LOOP[0] = False
             e(f"s_add_u32 {s(S_KT)}, {s(S_KT)}, 1")
             e(f"s_mov_b32 {s(S_K1A)}, {s(S_K2A)}")
             e(f"s_mov_b32 {s(S_K1B)}, {s(S_K2B)}")
@@ -960,6 +962,8 @@ print("// GENERATED by tools/gen_gemm_bt_asm.py -- do not edit")
 print("// clang-format off")
 # --ablate a,b: measurement-only build (WRONG results) of the four-wave two-stage loops, see ABL
 ABLATE = set(sys.argv[sys.argv.index("--ablate") + 1].split(",")) if "--ablate" in sys.argv else set()
+# --ablate-deep a,b: the same for the deep forms (variants 24 / 26 and the transposed twin; the drain forms stay whole)
+ABLATE_DEEP = set(sys.argv[sys.argv.index("--ablate-deep") + 1].split(",")) if "--ablate-deep" in sys.argv else set()
 for nj, abl in ((4, ""), (3, ""), (3, "pair")):
     ABL.clear()
     ABL.update(ABLATE)
@@ -979,6 +983,7 @@ for i, line in enumerate(out):
 deep_hi = {}
 for nj, deep, swap in ((3, "b", False), (4, "b", False), (3, "b", True)):
     ABL.clear()
+    ABL.update(ABLATE_DEEP)
     SWAP[0] = swap
     deep_hi[(nj, deep)] = gen_deep(nj, deep)
     SWAP[0] = False

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(512) void stage_kernel(const unsigned short* __rest
       for (int kt_ = 0; kt_ < nkt; ++kt_) {
         const int kt = ROT ? (kt_ + rot) % nkt : kt_;
         char* s = lds + (kt_ & 1) * STAGE + wave * 1024;
-        if constexpr (MODE == 3 || MODE == 4) {
+        if constexpr (MODE == 3 || MODE == 4 || MODE == 5) {
           // MUBUF form: one descriptor per matrix, 32-bit per-lane offsets, the K advance in the scalar offset
 #pragma unroll
           for (int i = 0; i < PW; ++i) {
@@ -104,7 +104,11 @@ __global__ __launch_bounds__(512) void stage_kernel(const unsigned short* __rest
                                                        voff[i], kt * BK * 2, 0, 0);
 #endif
           }
-          if (kt_ >= DEPTH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * DEPTH > 63 ? 63 : PW * DEPTH) : "memory");
+          if constexpr (MODE == 5) {
+            // the GEMM K loop's shape (round 6): all but the DEPTH youngest pieces of this wave must have landed, then the workgroup's barrier
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH > 63 ? 63 : DEPTH) : "memory");
+            __builtin_amdgcn_s_barrier();
+          } else if (kt_ >= DEPTH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * DEPTH > 63 ? 63 : PW * DEPTH) : "memory");
         } else if constexpr (MODE == 0) {
 #pragma unroll
           for (int i = 0; i < PW; ++i)
@@ -184,6 +188,15 @@ int main() {
   run<3, 64, 2, 4, 0, 0, 1>("buffer_load..lds BK64 4 waves, K order rotated per workgroup", A, B, sink);
   run<3, 64, 2, 4, 0, 0, 2>("buffer_load..lds BK64 4 waves, rotated per A-panel sharer", A, B, sink);
   run<3, 64, 2, 4, 0, 2, 1>("buffer_load..lds BK64 4 waves, rotated | GEMM mix", A, B, sink);
+  run<3, 64, 2, 1>("buffer_load..lds BK64 depth2 ONE issuing wave", A, B, sink);
+  run<3, 64, 2, 2>("buffer_load..lds BK64 depth2 two issuing waves", A, B, sink);
+  run<5, 64, 0, 4>("K-loop shape: 16 pieces / wave, vmcnt(0) + barrier per stage", A, B, sink);
+  run<5, 64, 6, 4>("K-loop shape: 16 pieces / wave, vmcnt(6) + barrier", A, B, sink);
+  run<5, 64, 12, 4>("K-loop shape: 16 pieces / wave, vmcnt(12) + barrier", A, B, sink);
+  run<5, 64, 16, 4>("K-loop shape: 16 pieces / wave, vmcnt(16) + barrier", A, B, sink);
+  run<5, 64, 24, 4>("K-loop shape: 16 pieces / wave, vmcnt(24) + barrier", A, B, sink);
+  run<5, 64, 32, 4>("K-loop shape: 16 pieces / wave, vmcnt(32) + barrier", A, B, sink);
+  run<5, 64, 48, 4>("K-loop shape: 16 pieces / wave, vmcnt(48) + barrier", A, B, sink);
   run<3, 64, 1, 4, 0, 0, 0>("buffer_load..lds BK64 4 waves depth 1", A, B, sink);
   run<3, 64, 1, 4, 0, 0, 1>("buffer_load..lds BK64 4 waves depth 1, rotated", A, B, sink);
   run<0, 64, 1, 8>("glds  BK64 depth1 8 waves", A, B, sink);
