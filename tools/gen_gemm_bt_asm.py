@@ -645,164 +645,6 @@ def gen_deep(nj, deep):
     return vhi
 
 
-# ---- half-tile stages (round 6, end): the deep 256 x 192 loop on FIVE stages of HALF a K tile per operand ------------------------------------
-# The ablation builds of the deep form (profiles/r06_bt_deep_ablations.log: DMA stream alone 124 us, MFMAs alone 108, whole 164 for
-# 2048 x 12288 x 4096) put one exposed memory round trip in every iteration: with two stages the shallow operand's tile t + 1 is issued in
-# the iteration whose closing wait needs it.  Capacity, not order: a stage here holds a 32-wide K HALF (A 256 rows x 64 B = 16 KB, B 192
-# rows x 64 B = 12 KB), five of them per operand (140 KB), and half-step h issues half-tile h + 4 into the stage half-step h - 1 left --
-# every piece a wait needs was issued three half-steps (1.5 K tiles) earlier:
-#     half-step h (stage h mod 5 of both rings):
-#       block s0: 12 MFMAs of k16 step 0 out of buffer 0 | reads of step 1 (this stage) -> buffer 1 | this wave's 4 A pieces of half-tile h + 4
-#       s_waitcnt vmcnt(18); s_barrier       half-tile h + 1 has landed (its pieces: half-step h - 3; younger: 7 + 7 + the 4 just issued)
-#       block s1: 12 MFMAs of step 1 out of buffer 1     | reads of step 0 of half-tile h + 1 -> buffer 0 | the 3 B pieces of half-tile h + 4
-# LDS rows are 64 bytes: position p of row r holds the row's 16-byte chunk p ^ ((r >> 2) & 3) (eight lanes of a fragment read -- rows r .. r + 7,
-# one chunk -- then cover 32 banks once; sixteen lanes all 64).  DMA pieces are 16 rows x 64 B; the wave's lane offsets carry the swizzle,
-# the piece's rows and the K half travel in the scalar offset.  Unrolled over the five stage phases; a tile of nkt K tiles is 2 nkt
-# half-steps, entered at the phase the previous tile left (operand st0 = half-steps so far mod 5).
-def gen_deep_half():
-    global NJ
-    NJ = 3
-    del out[:]
-    NS = 5
-    nread, nslot = 4 + NJ, 4 * NJ
-    ASTG, BSTG, OFFB = 16384, 12288, 5 * 16384
-    VB = 56
-    XAA = [[VB + 2 * st + k for k in range(2)] for st in range(NS)]
-    XAB = [[VB + 2 * NS + 2 * st + k for k in range(2)] for st in range(NS)]
-    XBUF = VB + 4 * NS
-    vhi = XBUF + 2 * nread * 4 - 1
-    S_H, S_IH, S_NH, S_IA, S_IB = S_KT, S_K1A, S_K2A, S_K1B, S_K2B     # half-step, issue index (h + 4), 2 nkt, byte offsets of half-tile h + 4
-
-    def xa(b, i):
-        return vr(XBUF + 4 * nread * b + 4 * i, 4)
-
-    def xb(b, j):
-        return vr(XBUF + 4 * nread * b + 16 + 4 * j, 4)
-
-    def xread(b, st, kk, n):
-        order = [("a", 0)] + [("b", j) for j in range(NJ)] + [("a", 1), ("a", 2), ("a", 3)]
-        m, idx = order[n]
-        if m == "a":
-            e(f"ds_read_b128 {xa(b, idx)}, {v(XAA[st][kk])} offset:{2048 * idx}")
-        else:
-            e(f"ds_read_b128 {xb(b, idx)}, {v(XAB[st][kk])} offset:{2048 * idx}")
-
-    def piece(mat, p, st):
-        if mat == "a":
-            e(f"s_add_u32 m0, {s(S_DA)}, {ASTG * st + 1024 * p}")
-            e(f"s_add_u32 {s(S_TMP)}, {s(S_IA)}, {s(S_ROWA[p])}")
-            e(f"buffer_load_dwordx4 %[va0], %[rsa], {s(S_TMP)} offen lds")
-        else:
-            e(f"s_add_u32 m0, {s(S_DB)}, {BSTG * st + 1024 * p}")
-            e(f"s_add_u32 {s(S_TMP)}, {s(S_IB)}, {s(S_ROWB[p])}")
-            e(f"buffer_load_dwordx4 %[vb0], %[rsb], {s(S_TMP)} offen lds")
-
-    # ---- setup
-    for st in range(NS):
-        for k in range(2):
-            if st == 0:
-                if k:
-                    e(f"v_xor_b32 {v(XAA[0][1])}, 32, %[aa0]")
-                    e(f"v_xor_b32 {v(XAB[0][1])}, 32, %[ab0]")
-                else:
-                    e(f"v_mov_b32 {v(XAA[0][0])}, %[aa0]")
-                    e(f"v_mov_b32 {v(XAB[0][0])}, %[ab0]")
-    for st in range(1, NS):
-        for k in range(2):
-            e(f"v_add_u32 {v(XAA[st][k])}, {ASTG * st}, {v(XAA[0][k])}")
-            e(f"v_add_u32 {v(XAB[st][k])}, {BSTG * st}, {v(XAB[0][k])}")
-    e(f"s_mov_b32 {s(S_ROWA[0])}, 0")
-    for q in (1, 2, 3):
-        e(f"s_add_u32 {s(S_ROWA[q])}, {s(S_ROWA[q - 1])}, %[lda16]")
-    e(f"s_mov_b32 {s(S_ROWB[0])}, 0")
-    for q in (1, 2):
-        e(f"s_add_u32 {s(S_ROWB[q])}, {s(S_ROWB[q - 1])}, %[ldb16]")
-    e(f"s_mov_b32 {s(S_H)}, 0")
-    e(f"s_lshl_b32 {s(S_NH)}, %[nkt], 1")
-    e(f"s_lshl_b32 {s(S_DA)}, %[wave], 12")
-    e(f"s_mul_i32 {s(S_DB)}, %[wave], 3072")
-    e(f"s_add_u32 {s(S_DB)}, {s(S_DB)}, {OFFB}")
-    e("s_cmp_eq_u32 %[first], 0")
-    e("s_cbranch_scc1 .Lhf_cont_%=")
-    # first tile of the workgroup (st0 = 0): half-tiles 0 .. 3 in order, then wait for half-tile 0
-    e(f"s_mov_b32 {s(S_IA)}, %[base_a]")
-    e(f"s_mov_b32 {s(S_IB)}, %[base_b]")
-    for q in range(4):
-        for p in range(4):
-            piece("a", p, q)
-        for p in range(3):
-            piece("b", p, q)
-        e(f"s_add_u32 {s(S_IA)}, {s(S_IA)}, 64")
-        e(f"s_add_u32 {s(S_IB)}, {s(S_IB)}, 64")
-    e("s_waitcnt vmcnt(21)")
-    e("s_barrier")
-    e(".Lhf_cont_%=:")
-    # half-tile h + 4 of this tile sits 256 bytes into the rows (2 nkt >= 6: it belongs to this tile)
-    e(f"s_add_u32 {s(S_IA)}, %[base_a], 256")
-    e(f"s_add_u32 {s(S_IB)}, %[base_b], 256")
-    e(f"s_mov_b32 {s(S_IH)}, 4")
-    for w in (1, 2, 3):
-        e(f"s_cmp_eq_u32 %[wave], {w}")
-        e(f"s_cbranch_scc1 .Lhf_w{w}_%=")
-    for w in range(4):
-        if w:
-            e(f".Lhf_w{w}_%=:")
-        e("s_waitcnt lgkmcnt(0)")
-        for u in range(1, NS):
-            e(f"s_cmp_eq_u32 %[st0], {u}")
-            e(f"s_cbranch_scc1 .Lhf_e{w}_{u}_%=")
-        for u in range(NS):
-            if u:
-                e(f".Lhf_e{w}_{u}_%=:")
-            for n in range(nread):
-                xread(0, u, 0, n)
-            e(f"s_branch .Lhf_b{w}_{u}_%=")
-        # the wave's pieces in its own slots: A pieces in block s0 at slots 3 w' + 3 i (w' = wave), B pieces in block s1
-        a_slots = {(w + 3 * i) % nslot: i for i in range(4)}
-        b_slots = {(w + 4 * i) % nslot: i for i in range(3)}
-        for u in range(NS):
-            e(f".Lhf_b{w}_{u}_%=:")
-            tgt = (u + 4) % NS
-
-            def f0(slot, u=u, tgt=tgt):
-                if slot < nread:
-                    xread(1, u, 1, slot)
-                if slot in a_slots:
-                    piece("a", a_slots[slot], tgt)
-
-            def f1(slot, u=u, tgt=tgt):
-                if slot < nread:
-                    xread(0, (u + 1) % NS, 0, slot)
-                if slot in b_slots:
-                    piece("b", b_slots[slot], tgt)
-
-            IN_LOOP[0] = True
-            mfma_block(0, f0, xa, xb)
-            e("s_waitcnt vmcnt(18)")
-            e("s_barrier")
-            mfma_block(1, f1, xa, xb)
-            IN_LOOP[0] = False
-            e(f"s_add_u32 {s(S_H)}, {s(S_H)}, 1")
-            e(f"s_add_u32 {s(S_IH)}, {s(S_IH)}, 1")
-            e(f"s_add_u32 {s(S_IA)}, {s(S_IA)}, 64")
-            e(f"s_add_u32 {s(S_IB)}, {s(S_IB)}, 64")
-            e(f"s_cmp_eq_u32 {s(S_IH)}, {s(S_NH)}")
-            e(f"s_cselect_b32 {s(S_IA)}, %[nbase_a], {s(S_IA)}")
-            e(f"s_cselect_b32 {s(S_IB)}, %[nbase_b], {s(S_IB)}")
-            e(f"s_cmp_lt_u32 {s(S_H)}, {s(S_NH)}")
-            if u < NS - 1:
-                e("s_cbranch_scc0 .Lhf_done_%=")
-            else:
-                e(f"s_cbranch_scc1 .Lhf_b{w}_0_%=")
-        if w < 3:
-            e("s_branch .Lhf_done_%=")
-    e(".Lhf_done_%=:")
-    e("s_waitcnt lgkmcnt(0)")
-    e("s_nop 15")
-    e("s_nop 7")
-    return vhi
-
-
 # ---- drain forms (round 6): tile i's epilogue under the K loop of tile i + 1 ------------------------------------------------
 # What the K = 768 products of the ViT lose is not their K loop but the seam between two output tiles of a workgroup: the accumulators
 # are the only copy of the tile, so swap -> scale / bias (-> GELU) -> pack -> store (25 MB per round of tiles, all 256 workgroups at
@@ -1148,13 +990,6 @@ for nj, deep, swap in ((3, "b", False), (4, "b", False), (3, "b", True)):
     print(f"#define GEMM_BT_ASM_TEXT_NJ{nj}_D{deep.upper()}{'_T' if swap else ''} \\")
     for i, line in enumerate(out):
         print(f'  "{line}\\n"' + (" \\" if i + 1 < len(out) else ""))
-ABL.clear()
-ABL.update(ABLATE_DEEP)
-half_hi = gen_deep_half()
-ABL.clear()
-print("#define GEMM_BT_ASM_TEXT_NJ3_HALF \\")
-for i, line in enumerate(out):
-    print(f'  "{line}\\n"' + (" \\" if i + 1 < len(out) else ""))
 # round 6: the deep 256 x 192 loops on the PINNED accumulator file (a[0:191] literal) -- the first tile of a workgroup of the drain kernel --
 # and the drain forms (gen_deep_drain): plain, transposed tile, GELU
 for swap in (False, True):

@@ -52,7 +52,7 @@ int u2tok_set_option(const char* name, int value) {
   Options& o = ctx().opt;
   struct Opt { const char* name; int Options::*field; int lo, hi; };
   static const Opt table[] = {
-      {"gemm_splitk", &Options::gemm_splitk, -1, 16},   {"gemm_mubuf", &Options::gemm_mubuf, 0, 1}, {"ln_wide", &Options::ln_wide, 0, 1},   {"gemm_big", &Options::gemm_big, -1, 28},
+      {"gemm_splitk", &Options::gemm_splitk, -1, 16},   {"gemm_mubuf", &Options::gemm_mubuf, 0, 1}, {"ln_wide", &Options::ln_wide, 0, 1},   {"gemm_big", &Options::gemm_big, -1, 27},
       {"gemm_big_grid", &Options::gemm_big_grid, 1, 4096}, {"gemm_big_group_m", &Options::gemm_big_group_m, 0, 64}, {"gemm_big_gelu", &Options::gemm_big_gelu, 0, 1},
       {"gemm_big_splitk", &Options::gemm_big_splitk, 0, 16}, {"gemm_big_skinny", &Options::gemm_big_skinny, 0, 1},
       {"gemm_big_ring", &Options::gemm_big_ring, 0, 1},   {"gemm_big_deep", &Options::gemm_big_deep, 0, 1},
@@ -73,7 +73,7 @@ int u2tok_set_option(const char* name, int value) {
   for (const Opt& t : table)
     if (!strcmp(name, t.name)) {
       if (value < t.lo || value > t.hi) return U2_ERR_ARG;
-      if (t.field == &Options::gemm_big && value > 0 && !(value >= 20 && value <= 28)) return U2_ERR_ARG;
+      if (t.field == &Options::gemm_big && value > 0 && !(value >= 20 && value <= 27)) return U2_ERR_ARG;
       if (t.field == &Options::flash_mode && value != 0 && value != 1 && value != 7) return U2_ERR_ARG;
       o.*(t.field) = value;
       return U2_OK;

@@ -331,8 +331,7 @@ __device__ __forceinline__ void bt_tail_block(const GemmDesc& d, int n0, float (
 template <int NJ, bool PAIR = false, bool SPLIT = false, int DEEP = 0, bool VT = false, bool TAIL = false>  // 32-column blocks per wave: tile = 256 x (64 NJ)
 __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
   static_assert(!TAIL || (!PAIR && !SPLIT), "the in-launch tail exists for the plain forms");
-  static_assert(DEEP == 0 || ((DEEP == 2 || DEEP == 3) && NJ >= 3 && !PAIR && !SPLIT), "the deep forms are plain 256 x 192 / 256 x 256 kernels");
-  static_assert(DEEP != 3 || (NJ == 3 && !VT), "the half-tile-stage form exists for plain 256 x 192 tiles");
+  static_assert(DEEP == 0 || (DEEP == 2 && NJ >= 3 && !PAIR && !SPLIT), "the deep forms are plain 256 x 192 / 256 x 256 kernels");
   static_assert(!VT || (DEEP == 2 && NJ == 3), "the transposed-tile form exists for 256 x 192 deep tiles");
   static_assert(!(PAIR && SPLIT), "the pair form is not sliced");
   static_assert(!PAIR || NJ == 3, "the pair form exists for 256 x 192 tiles");
@@ -343,10 +342,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
   using CFG = BTCfg<BN>;
   // two stages: [stage][A tile 32 KB | B tile <= 32 KB];  ring: three stages of [A tile 32 KB | B tile 16 KB]
   // deep forms: [A stages of 32 KB][B stages of 8 NJ KB], three of the deep operand and two of the other
-  // DEEP = 3 (round 6, variant 28): FIVE stages of HALF a K tile per operand (A 16 KB, B 12 KB each; tools/gen_gemm_bt_asm.py, gen_deep_half)
-  constexpr bool HALF = DEEP == 3;
-  constexpr int OFFB = HALF ? 5 * 16384 : DEEP == 2 ? 2 * 32768 : 32768;
-  constexpr int LDS_BYTES = HALF ? 5 * (16384 + 12288) : DEEP == 2 ? 2 * 32768 + 3 * NJ * 8192 : RING ? 147456 : 131072;
+  constexpr int OFFB = DEEP == 2 ? 2 * 32768 : 32768;
+  constexpr int LDS_BYTES = DEEP == 2 ? 2 * 32768 + 3 * NJ * 8192 : RING ? 147456 : 131072;
   __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -375,18 +372,14 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
   // Lane offsets are relative to the tile origin; the origin (and the K tile) travel in the scalar offset.
   const int pr = lane >> 3, sw0 = (lane >> 4) & 3, pc = lane & 7;
   const int ra = wave * 64 + pr;
-  // (HALF: pieces of 16 rows x 64 B -- lane = (row lane >> 2, position lane & 3), LDS position p of row r holds chunk p ^ ((r >> 2) & 3);
-  //  the piece's 16-row step and the K half travel in the scalar offset, so one lane offset per operand)
-  const int va0 = HALF ? ((wave * 64 + (lane >> 2)) * (int)d.lda + (((lane & 3) ^ ((lane >> 4) & 3)) << 3)) * 2
-                       : (ra * (int)d.lda + ((pc ^ sw0) << 3)) * 2;
+  const int va0 = (ra * (int)d.lda + ((pc ^ sw0) << 3)) * 2;
   const int va1 = ((ra + 8) * (int)d.lda + ((pc ^ sw0 ^ 4) << 3)) * 2;
   // PAIR (GEMM_SWIGLU: B = [gate rows | up rows], N = 2 I, C[m][j] = silu(gate_j) * up_j; NJ = 3): tile row
   // R = 32 b + 16 half + i  <->  weight row half * I + (bn0 / 2) + 16 b + i, so every 32-column MFMA block holds 16 gate columns
   // and THE SAME 16 up columns, which the epilogue finds in one lane (t = 0 / 1).  The lane offsets then address a row inside a
   // 16-row group and the group's offset is a scalar per (wave, group) handed to the K loop.
   const int rb = (PAIR ? 0 : wave * (16 * NJ)) + pr;
-  const int vb0 = HALF ? ((wave * 48 + (lane >> 2)) * (int)d.ldb + (((lane & 3) ^ ((lane >> 4) & 3)) << 3)) * 2
-                       : (rb * (int)d.ldb + ((pc ^ sw0) << 3)) * 2;
+  const int vb0 = (rb * (int)d.ldb + ((pc ^ sw0) << 3)) * 2;
   const int vb1 = ((rb + 8) * (int)d.ldb + ((pc ^ sw0 ^ 4) << 3)) * 2;
   [[maybe_unused]] int rowb[3] = {0, 0, 0};
   if constexpr (PAIR) {
@@ -428,11 +421,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
     rsb[3] = 0x00020000;
     const int first = (r == 0 || !chain) ? 1 : 0;
     if (first) st0 = 0;
-    // (HALF: 64-byte rows, the fragment of k16 step kk is chunk (2 kk + hi) ^ ((row >> 2) & 3) of its row)
-    const uint32_t hk0 = (uint32_t)(l31 * 64 + ((hi ^ ((l31 >> 2) & 3)) << 4));
-    const uint32_t aa0 = HALF ? lds_u32 + wm * 8192 + hk0
-                              : (lds_u32 + wm * 16384 + abk0) ^ ((RING || DEEP) ? 0u : st0);  // (ring / deep: stage 0's addresses, the asm adds the stage)
-    const uint32_t ab0 = HALF ? lds_u32 + OFFB + wn * 6144 + hk0 : (lds_u32 + OFFB + wn * (NJ * 4096) + abk0) ^ ((RING || DEEP) ? 0u : st0);
+    const uint32_t aa0 = (lds_u32 + wm * 16384 + abk0) ^ ((RING || DEEP) ? 0u : st0);  // (ring / deep: stage 0's addresses, the asm adds the stage)
+    const uint32_t ab0 = (lds_u32 + OFFB + wn * (NJ * 4096) + abk0) ^ ((RING || DEEP) ? 0u : st0);
     // (readfirstlane: the values are uniform, but hipcc keeps loop-carried tile coordinates in VGPRs)
     const int base_a = __builtin_amdgcn_readfirstlane((bm0 * (int)d.lda + kt0 * 64) * 2);
     const int base_b = __builtin_amdgcn_readfirstlane(((PAIR ? bn0 >> 1 : bn0) * (int)d.ldb + kt0 * 64) * 2);
@@ -457,12 +447,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
       [rsb] "s"(rsb), [lda16] "s"(lda16), [nkt] "s"(nkt), [wave] "s"(wave), [st0] "s"(st0_s), [first] "s"(first_s),   \
       [base_a] "s"(base_a), [base_b] "s"(base_b), [nbase_a] "s"(nbase_a), [nbase_b] "s"(nbase_b)
     [[maybe_unused]] const bool vt_tile = VT && bn0 >= d.vt_n0;  // (uniform) this tile's accumulators come out transposed
-    if constexpr (HALF) {
-      asm volatile(GEMM_BT_ASM_TEXT_NJ3_HALF
-                   : BT_ACC3(0, 0), BT_ACC3(0, 1), BT_ACC3(1, 0), BT_ACC3(1, 1)
-                   : BT_IN, [ldb16] "s"(ldb16)
-                   : GEMM_BT_ASM_CLOBBERS_NJ3_DEEP);
-    } else if constexpr (DEEP != 0 && NJ == 3) {
+    if constexpr (DEEP != 0 && NJ == 3) {
       if (VT && vt_tile)
         asm volatile(GEMM_BT_ASM_TEXT_NJ3_DB_T
                      : BT_ACC3(0, 0), BT_ACC3(0, 1), BT_ACC3(1, 0), BT_ACC3(1, 1)
@@ -536,8 +521,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_kernel(GemmDesc d) {
       pp_epilogue<CFG, 0, PAIR>(d, acc[0], z, bm0 + wm * 128, bn0, 0, wn, lane, bpre, fast);
       pp_epilogue<CFG, 0, PAIR>(d, acc[1], z, bm0 + wm * 128, bn0, 1, wn, lane, bpre, fast);
     }
-    if constexpr (HALF) st0 = (st0 + 2u * (uint32_t)nkt) % 5u;
-    else if constexpr (DEEP != 0) st0 = (st0 + (uint32_t)nkt) % 6u;
+    if constexpr (DEEP != 0) st0 = (st0 + (uint32_t)nkt) % 6u;
     else if constexpr (RING) st0 = (st0 + (uint32_t)nkt) % 3u;
     else st0 ^= (uint32_t)(nkt & 1) << 16;
     z = zn; bm0 = bm0n; bn0 = bn0n;
@@ -800,12 +784,6 @@ static int bt_launch_deep(GemmDesc d, hipStream_t stream) {
   const int64_t total = (int64_t)d.tiles_m * d.tiles_n * d.nz;
   if (total > 0x3fffffff) return U2_ERR_ARG;
   const int grid = (int)std::min<int64_t>(total, opts().gemm_big_grid);
-  if constexpr (NJ == 3 && DEEP == 3) {
-    if (d.tail_rows && !d.vt) {
-      hipLaunchKernelGGL((gemm_bt_kernel<3, false, false, 3, false, true>), dim3(grid), dim3(256), 0, stream, d);
-      return launch_status();
-    }
-  }
   if constexpr (NJ == 3 && DEEP == 2) {
     if (d.vt) {
       if (d.tail_rows) hipLaunchKernelGGL((gemm_bt_kernel<3, false, false, 2, true, true>), dim3(grid), dim3(256), 0, stream, d);
@@ -880,7 +858,6 @@ static int bt_slices(GemmDesc& d, int64_t tiles, int want, hipStream_t stream) {
 
 // variants: 20 = 256 x 256, 21 = 256 x 192, 22 = 256 x 128 tiles (ring form); 24 = 256 x 192 with B deep, 26 = 256 x 256 with B deep,
 // 27 = 24 as the drain form (tile i's epilogue under tile i + 1's K loop)
-// 28 = 256 x 192 tiles on five stages of HALF a K tile per operand (round 6)
 static int bt_launch_variant(int v, const GemmDesc& d, hipStream_t stream) {
   switch (v) {
     case 20: return bt_launch<4>(d, stream);
@@ -888,7 +865,6 @@ static int bt_launch_variant(int v, const GemmDesc& d, hipStream_t stream) {
     case 23: case 25: return U2_ERR_ARG;  // (the A-deep twins of round 4: removed)
     case 24: return bt_launch_deep<3, 2>(d, stream);
     case 26: return bt_launch_deep<4, 2>(d, stream);
-    case 28: return (d.K >> 6) >= 3 ? bt_launch_deep<3, 3>(d, stream) : U2_ERR_ARG;   // five half-tile stages per operand
     case 27: return bt_drain_ok(d) ? bt_launch_drain(d, stream) : U2_ERR_ARG;
     default: return bt_launch<3>(d, stream);
   }
@@ -1005,7 +981,6 @@ int gemm_big_try(const GemmDesc& d, hipStream_t stream) {
     GemmDesc ds = d;
     if (mode <= 22) bt_slices(ds, 0, opts().gemm_big_splitk, stream);
     if (mode == 27 && !bt_drain_ok(ds)) return 0;
-    if (mode == 28 && (ds.K >> 6) < 3) return 0;   // (the half-tile-stage form looks four half-tiles ahead inside one tile)
     const int e = bt_launch_variant(mode, ds, stream);
     return e == U2_OK ? 1 : e;
   }
@@ -1024,7 +999,7 @@ int gemm_big_try(const GemmDesc& d, hipStream_t stream) {
   }
   auto launch = [&](int v) {
     // <= 16 tail rows ride in the launch of the plain 256 x 256 (20) and deep 256 x 192 (24) forms -- what the ViT's products run
-    const bool in_launch = split_tail && rem <= 16 && !(d.K & 31) && !(d.flags & GEMM_BIAS_M) && (v == 20 || v == 24 || v == 27 || v == 28) &&
+    const bool in_launch = split_tail && rem <= 16 && !(d.K & 31) && !(d.flags & GEMM_BIAS_M) && (v == 20 || v == 24 || v == 27) &&
                            opts().gemm_tail_fused && main.ksplit <= 1;
     if (in_launch) main.tail_rows = rem;
     int e = bt_launch_variant(v, main, stream);
