@@ -519,12 +519,14 @@ def gen_deep(nj, deep):
     dmat, smat = ("a", "b") if deep == "a" else ("b", "a")
     npc = {"a": 8, "b": npb}
     window = 2 * nslot
-    # piece i of wave w of a matrix -> position in its two-step window
+    # piece i of wave w of a matrix -> position in its two-step window.  (--shallow-window N, measurement: the SHALLOW operand's pieces in the
+    # first N slots behind the barrier instead of the whole two-step window -- earlier issue, denser burst)
+    swin = int(sys.argv[sys.argv.index("--shallow-window") + 1]) if "--shallow-window" in sys.argv else window
     sched = {m: {w: {} for w in range(4)} for m in "ab"}
     for m in "ab":
         for i in range(npc[m]):
             for w in range(4):
-                g = (i * 4 + w) * window // (4 * npc[m])
+                g = (i * 4 + w) * (swin if m == smat else window) // (4 * npc[m])
                 sched[m][w].setdefault(g, []).append(i)
     K0, K1, K2 = (S_K0A, S_K0B), (S_K1A, S_K1B), (S_K2A, S_K2B)
     # ---- setup (common)
