@@ -140,8 +140,12 @@ def frag_waits():
         need = max(0 if i == 0 else NJ + i, 1 + j)
         if need > have:
             have = need
-            waits[slot] = (nread - 1 - need) + min(slot, nread)
+            waits[slot] = (nread - 1 - need) + min(slot * RPS, nread)
     return waits
+
+
+# --reads-per-slot N (measurement, deep form only): N fragment reads behind each of the first ceil((4 + NJ) / N) MFMAs of a k16 step instead of one
+RPS = int(sys.argv[sys.argv.index("--reads-per-slot") + 1]) if "--reads-per-slot" in sys.argv else 1
 
 
 SWAP = [False]   # True: MFMA operands exchanged -> the accumulator tile comes out TRANSPOSED (lane = column n, registers = rows m)
@@ -606,8 +610,8 @@ def gen_deep(nj, deep):
             def xk(items, rb, rsa, rsb, rkk):
                 """companions of a k16 step's slots: fragment reads + the DMA pieces in items: slot -> [(matrix, piece, stage, K)]"""
                 def f(slot):
-                    if slot < nread:
-                        xread(rb, rsa, rsb, rkk, slot)
+                    for n in range(slot * RPS, min(nread, slot * RPS + RPS)):
+                        xread(rb, rsa, rsb, rkk, n)
                     for (m, i, st, s_k) in items.get(slot, []):
                         xpiece(m, i, st, s_k)
                 return f
