@@ -87,6 +87,7 @@ def bfrag(b, j):
     return vr(BUF + 32 * b + 16 + 4 * j, 4)
 
 
+FRAG_AGPR = "--frag-agpr" in sys.argv
 FIXED_ACC = [False]   # True: accumulator (i, j) is the literal tuple a[16 (NJ i + j) : +15] (the drain forms pin the accumulator file)
 
 
@@ -498,9 +499,13 @@ def gen_deep(nj, deep):
     vhi = XBUF + 2 * nread * 4 - 1
 
     def xa(b, i):
+        if FRAG_AGPR and FIXED_ACC[0]:   # (--frag-agpr, measurement: the fragment double buffer in a[192:247], the accumulators' spare registers)
+            return f"a[{192 + 4 * nread * b + 4 * i}:{192 + 4 * nread * b + 4 * i + 3}]"
         return vr(XBUF + 4 * nread * b + 4 * i, 4)
 
     def xb(b, j):
+        if FRAG_AGPR and FIXED_ACC[0]:
+            return f"a[{192 + 4 * nread * b + 16 + 4 * j}:{192 + 4 * nread * b + 16 + 4 * j + 3}]"
         return vr(XBUF + 4 * nread * b + 16 + 4 * j, 4)
 
     def xread(b, sa, sb, kk, n):
@@ -779,9 +784,13 @@ def gen_deep_drain(swap, gelu):
     assert XBUF + 2 * nread * 4 == HOLD
 
     def xa(b, i):
+        if FRAG_AGPR and FIXED_ACC[0]:   # (--frag-agpr, measurement: the fragment double buffer in a[192:247], the accumulators' spare registers)
+            return f"a[{192 + 4 * nread * b + 4 * i}:{192 + 4 * nread * b + 4 * i + 3}]"
         return vr(XBUF + 4 * nread * b + 4 * i, 4)
 
     def xb(b, j):
+        if FRAG_AGPR and FIXED_ACC[0]:
+            return f"a[{192 + 4 * nread * b + 16 + 4 * j}:{192 + 4 * nread * b + 16 + 4 * j + 3}]"
         return vr(XBUF + 4 * nread * b + 16 + 4 * j, 4)
 
     def xread(b, sa, sb, kk, n):
@@ -1026,7 +1035,7 @@ for i in range(0, len(clob), 12):
     print("  " + ", ".join(clob[i:i + 12]) + (", \\" if i + 12 < len(clob) else ""))
 # the accumulator file of the drain kernel: named literally by its statements, which list it as clobbered (no operand carries it: the
 # compiler would shuttle 192 loop-carried values through VGPRs and scratch around every statement) -- gemm_bt.hip, gemm_bt_drain_kernel
-clob = [f'"a{i}"' for i in range(192)]
+clob = [f'"a{i}"' for i in range(248 if FRAG_AGPR else 192)]
 print("#define GEMM_BT_ASM_CLOBBERS_ACC192 \\")
 for i in range(0, len(clob), 12):
     print("  " + ", ".join(clob[i:i + 12]) + (", \\" if i + 12 < len(clob) else ""))
